@@ -1,0 +1,158 @@
+/*
+ * mf_oracle.h -- CPU ORACLE for the MicroFlow quantized-operator hot path.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * link or call anything in oracle/.  The product (microflow-rs_amd/) never does.
+ *
+ * It is a plain-C restatement of the reference's algorithm, deliberately
+ * structured like the reference (per-output-pixel view extraction, per-channel
+ * loops, three integer passes, f32 epilogue) so that it doubles as the
+ * "reference-faithful CPU baseline".  Every function cites the reference
+ * file:line (relative to the upstream repo root) it follows.
+ *
+ * Parity status: PINNED.  tests/test_oracle_golden.py checks this oracle
+ * against every known-answer test the reference holds for the path (the unit
+ * KATs of src/ops/{*}.rs, src/tensor.rs, src/quantize.rs, src/activation.rs, the
+ * preprocess KATs of microflow-macros/src/ops/{*}.rs, the three whole-model
+ * vectors of tests/{*}.rs and the 500 recorded outputs of
+ * analysis/accuracy/data/sine-microflow.csv).
+ * Softmax's expf is a restatement of the musl/FreeBSD-derived algorithm the
+ * `libm` 0.2 crate ships (the crate source is NOT under the reference tree;
+ * see DESIGN.md); it is pinned only at the reference's 9 softmax points.
+ *
+ * Build with:  gcc -O2 -ffp-contract=off -fno-fast-math  (see oracle/Makefile)
+ * f32 operations must stay individually rounded (Rust never fuses mul+add).
+ */
+#ifndef MF_ORACLE_H
+#define MF_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* activation codes = TFLite ActivationFunctionType (tflite.fbs:552-559) */
+enum { ORC_ACT_NONE = 0, ORC_ACT_RELU = 1, ORC_ACT_RELU6 = 3 };
+/* padding codes = TFLite Padding (tflite.fbs:548) */
+enum { ORC_PAD_SAME = 0, ORC_PAD_VALID = 1 };
+/* operator kinds = TFLite builtin codes */
+enum {
+    ORC_OP_AVERAGE_POOL_2D = 1,
+    ORC_OP_CONV_2D = 3,
+    ORC_OP_DEPTHWISE_CONV_2D = 4,
+    ORC_OP_FULLY_CONNECTED = 9,
+    ORC_OP_RESHAPE = 22,
+    ORC_OP_SOFTMAX = 25
+};
+
+/* ---- scalar primitives ------------------------------------------------- */
+float orc_roundf(float x);              /* libm::roundf: half away from zero          */
+float orc_expf(float x);                /* libm::expf (musl-derived) restatement      */
+int8_t orc_sat_i8(float x);             /* Rust `x as i8`: trunc, clamp, NaN -> 0     */
+int8_t orc_quantize(float x, float scale, int8_t zp);       /* src/quantize.rs:16-18  */
+float orc_dequantize(int8_t q, float scale, int8_t zp);     /* src/quantize.rs:27-29  */
+int8_t orc_relu(int8_t x, int8_t zp);                       /* src/activation.rs:21-23 */
+int8_t orc_relu6(int8_t x, float scale, int8_t zp);         /* src/activation.rs:32-34 */
+int8_t orc_softmax_scalar(float x, float sum, float scale, int8_t zp); /* activation.rs:44-46 */
+
+/* ---- view extraction: src/tensor.rs:180-228 ----------------------------
+ * in: one image, NHWC [H][W][C].  buf: [KH][KW][C], mask: [KH][KW].
+ * returns len (#in-bounds taps), or -1 if a VALID view leaves the tensor
+ * (the reference would panic on the out-of-range index). */
+int orc_view(const int8_t *in, int H, int W, int C, int fi, int fj, int KH, int KW, int pad,
+             int sh, int sw, int8_t *buf, uint8_t *mask);
+
+/* ---- operators (single image / single tensor, like the reference) ------ */
+/* src/ops/fully_connected.rs:24-82.  in [M][K] row-major; w [N][K] row-major
+ * (= the memory order of the reference's column-major K x N SMatrix). */
+void orc_fully_connected(const int8_t *in, int M, int K, const int8_t *w, int N, int8_t wzp,
+                         float oscale, int8_t ozp, int act, const float *c0, float c1,
+                         const int32_t *c2, int32_t c3, int8_t *out);
+/* src/ops/conv_2d.rs:28-108.  filters [N][KH][KW][C]; fzp has nq entries
+ * (fallback to [0]); c1 has nc1 entries (fallback to [0]). returns 0 / -1. */
+int orc_conv_2d(const int8_t *in, int H, int W, int C, const int8_t *f, int N, int KH, int KW,
+                const int8_t *fzp, int nq, int8_t izp, float oscale, int8_t ozp, int act, int pad,
+                int sh, int sw, int OH, int OW, const float *c0, const float *c1, int nc1,
+                int8_t *out);
+/* src/ops/depthwise_conv_2d.rs:28-105.  weights [1][KH][KW][WC]; input has
+ * Cin channels; output channel c reads input channel c if c < Cin else 0. */
+int orc_depthwise_conv_2d(const int8_t *in, int H, int W, int Cin, const int8_t *w, int KH, int KW,
+                          int WC, const int8_t *wzp, int nq, int8_t izp, float oscale, int8_t ozp,
+                          int act, int pad, int sh, int sw, int OH, int OW, const float *c0,
+                          const float *c1, int nc1, int8_t *out);
+/* src/ops/average_pool_2d.rs:29-66 */
+int orc_average_pool_2d(const int8_t *in, int H, int W, int C, int FH, int FW, float oscale,
+                        int8_t ozp, int act, int pad, int sh, int sw, int OH, int OW, float c0,
+                        float c1, int8_t *out);
+/* src/ops/softmax.rs:15-27.  in [rows][cols] row-major; the sum runs over the
+ * WHOLE tensor in column-major order and ignores the input zero point. */
+void orc_softmax(const int8_t *in, int rows, int cols, float iscale, float oscale, int8_t ozp,
+                 int8_t *out);
+
+/* ---- constant preparation ("preprocess") -------------------------------- */
+/* microflow-macros/src/ops/fully_connected.rs:100-123.
+ * w [N][K]; bias [N]; in_shape1 = input.shape[1] of the (rank-fixed) input
+ * tensor -- the reference uses that, not K, for c3. */
+void orc_preprocess_fully_connected(float iscale, int8_t izp, int in_shape1, const int8_t *w,
+                                    int K, int N, float wscale, int8_t wzp, const int32_t *bias,
+                                    float bscale, int32_t bzp, float oscale, float *c0, float *c1,
+                                    int32_t *c2, int32_t *c3);
+/* microflow-macros/src/ops/conv_2d.rs:94-114 and depthwise_conv_2d.rs:100-120.
+ * n = number of c0 entries (filters.shape[0] / weights.shape[3]); bscale/bzp
+ * have nbq entries (fallback [0]); fscale has nfq entries = len(c1). */
+void orc_preprocess_conv(float iscale, int n, const int32_t *bias, const float *bscale,
+                         const int32_t *bzp, int nbq, const float *fscale, int nfq, float oscale,
+                         float *c0, float *c1);
+/* microflow-macros/src/ops/average_pool_2d.rs:77-83 */
+void orc_preprocess_average_pool_2d(float iscale, int8_t izp, float oscale, int8_t ozp, float *c0,
+                                    float *c1);
+
+/* ---- whole model -------------------------------------------------------- */
+typedef struct orc_model orc_model;
+
+typedef struct {
+    int kind;                 /* ORC_OP_*                                   */
+    int in_shape[4], in_rank; /* as stored in the .tflite tensor            */
+    int out_shape[4], out_rank;
+    int KH, KW, sh, sw, pad, act;
+    int n_c0, n_c1;           /* lengths of the constant arrays             */
+    float in_scale, out_scale;
+    int in_zp, out_zp;
+    size_t out_elems;         /* per image                                  */
+} orc_op_info;
+
+/* microflow-macros/src/lib.rs:46-208 (the part that reads the model). NULL on
+ * failure; *err (if non-NULL) gets a static message. */
+orc_model *orc_model_load(const uint8_t *buf, size_t len, const char **err);
+void orc_model_free(orc_model *m);
+int orc_model_num_ops(const orc_model *m);
+int orc_model_op_info(const orc_model *m, int i, orc_op_info *info);
+/* copies of the constants for op i (any pointer may be NULL) */
+int orc_model_op_constants(const orc_model *m, int i, float *c0, float *c1, int32_t *c2,
+                           int32_t *c3);
+size_t orc_model_input_elems(const orc_model *m);
+size_t orc_model_output_elems(const orc_model *m);
+void orc_model_io_quant(const orc_model *m, float *iscale, int *izp, float *oscale, int *ozp);
+void orc_model_io_shape(const orc_model *m, int *in_shape, int *in_rank, int *out_shape,
+                        int *out_rank);
+/* sum over ops of out_elems (size of the `layers` dump buffer) */
+size_t orc_model_layers_elems(const orc_model *m);
+
+/* predict_inner on ONE quantized input (lib.rs:198-201).  out_q: final int8
+ * tensor; layers (optional): every op's output, concatenated in op order. */
+int orc_model_run_quantized(const orc_model *m, const int8_t *in_q, int8_t *out_q, int8_t *layers);
+/* predict_quantized (lib.rs:193-196): run + dequantize */
+int orc_model_predict_quantized(const orc_model *m, const int8_t *in_q, float *out);
+/* predict (lib.rs:188-191): quantize + run + dequantize */
+int orc_model_predict(const orc_model *m, const float *in, float *out);
+/* n independent predicts over a contiguous batch (the reference has no batch
+ * dimension on the conv path: src/ops/conv_2d.rs:40,49,53) */
+int orc_model_run_quantized_batch(const orc_model *m, const int8_t *in_q, size_t n, int8_t *out_q);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,43 @@
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+MODELS = os.path.join(ROOT, "models")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def kats():
+    with open(os.path.join(GOLDEN, "reference_kats.json")) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="session")
+def samples():
+    return dict(np.load(os.path.join(GOLDEN, "samples.npz")))
+
+
+@pytest.fixture(scope="session")
+def oracle_vectors():
+    return dict(np.load(os.path.join(GOLDEN, "oracle_vectors.npz")))
+
+
+@pytest.fixture(scope="session")
+def O():
+    from oracle import oracle
+    oracle.build()
+    return oracle
+
+
+def model_path(name):
+    return os.path.join(MODELS, name + ".tflite")
