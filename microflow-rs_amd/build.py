@@ -1,0 +1,65 @@
+"""Builds libmicroflow_amd.so in-tree with hipcc for gfx950.
+
+    python microflow-rs_amd/build.py [--force]
+
+-ffp-contract=off is part of the numerical contract: the reference (Rust) never
+fuses a multiply and an add, and hipcc does by default.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libmicroflow_amd.so")
+SOURCES = ["capi.cpp", "hostmath.cpp", "tflite.cpp", "model.cpp", "ops.hip", "kernels.hip"]
+HEADERS = ["mf_internal.hpp", "kernels.hpp", os.path.join("..", "..", "include", "microflow_amd.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
+         "-fno-fast-math", "-Wall", "-Wno-unused-result"]
+
+
+def hipcc():
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found: libmicroflow_amd.so cannot be built")
+    return exe
+
+
+def stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    if not force and not stale():
+        return LIB
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    cc = hipcc()
+    objs = []
+    procs = []
+    for src in SOURCES:
+        obj = os.path.join(objdir, src + ".o")
+        objs.append(obj)
+        cmd = [cc] + FLAGS + ["-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for src, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            sys.stderr.write(out.decode(errors="replace"))
+            raise RuntimeError("hipcc failed on " + src)
+        if verbose and out:
+            sys.stdout.write(out.decode(errors="replace"))
+    cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

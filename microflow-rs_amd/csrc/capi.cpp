@@ -1,0 +1,368 @@
+// capi.cpp -- the extern "C" boundary declared in include/microflow_amd.h.
+// Nothing crosses it but plain pointers, sizes and status codes; C++ exceptions are
+// translated to mf_status + a thread-local message.
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "mf_internal.hpp"
+
+namespace mf {
+static thread_local std::string g_last_error;
+void set_last_error(const std::string &msg) { g_last_error = msg; }
+void fail(int code, const std::string &msg) { throw Error{code, msg}; }
+} // namespace mf
+
+struct mf_op {
+    mf::OpImpl *impl;
+};
+struct mf_model {
+    mf::ModelImpl *impl;
+};
+
+#define MF_TRY(...)                                    \
+    try {                                              \
+        __VA_ARGS__;                                   \
+        return MF_OK;                                  \
+    } catch (const mf::Error &e) {                     \
+        mf::set_last_error(e.msg);                     \
+        return e.code;                                 \
+    } catch (const std::bad_alloc &) {                 \
+        mf::set_last_error("out of host memory");      \
+        return MF_ERR_OOM;                             \
+    } catch (const std::exception &e) {                \
+        mf::set_last_error(e.what());                  \
+        return MF_ERR_INVALID_ARG;                     \
+    }
+
+#define MF_NEED(cond)                                                         \
+    if (!(cond)) mf::fail(MF_ERR_INVALID_ARG, "invalid argument: " #cond)
+
+extern "C" {
+
+const char *mf_last_error(void) { return mf::g_last_error.c_str(); }
+int mf_abi_version(void) { return MF_ABI_VERSION; }
+int mf_device_count(void) { return mf::dev_count(); }
+
+// ---- 1. constant preparation ------------------------------------------------
+int mf_preprocess_fully_connected(float input_scale, int8_t input_zero_point, int in_shape1,
+                                  const int8_t *weights, int K, int N, float weights_scale,
+                                  int8_t weights_zero_point, const int32_t *bias, float bias_scale,
+                                  int32_t bias_zero_point, float output_scale, float *c0,
+                                  float *c1, int32_t *c2, int32_t *c3) {
+    MF_TRY({
+        MF_NEED(weights && bias && c0 && c1 && c2 && c3 && K > 0 && N > 0);
+        mf::h_preprocess_fc(input_scale, input_zero_point, in_shape1, weights, K, N, weights_scale,
+                            weights_zero_point, bias, bias_scale, bias_zero_point, output_scale, c0,
+                            c1, c2, c3);
+    })
+}
+
+int mf_preprocess_conv_2d(float input_scale, int n, const int32_t *bias, const float *bias_scale,
+                          const int32_t *bias_zero_point, int nbq, const float *filter_scale,
+                          int nfq, float output_scale, float *c0, float *c1) {
+    MF_TRY({
+        MF_NEED(bias && bias_scale && bias_zero_point && filter_scale && c0 && c1 && n > 0 &&
+                nbq > 0 && nfq > 0);
+        mf::h_preprocess_conv(input_scale, n, bias, bias_scale, bias_zero_point, nbq, filter_scale,
+                              nfq, output_scale, c0, c1);
+    })
+}
+
+int mf_preprocess_depthwise_conv_2d(float input_scale, int n, const int32_t *bias,
+                                    const float *bias_scale, const int32_t *bias_zero_point,
+                                    int nbq, const float *weights_scale, int nfq,
+                                    float output_scale, float *c0, float *c1) {
+    // identical formulas (depthwise_conv_2d.rs:106-119 vs conv_2d.rs:100-113)
+    return mf_preprocess_conv_2d(input_scale, n, bias, bias_scale, bias_zero_point, nbq,
+                                 weights_scale, nfq, output_scale, c0, c1);
+}
+
+int mf_preprocess_average_pool_2d(float input_scale, int8_t input_zero_point, float output_scale,
+                                  int8_t output_zero_point, float *c0, float *c1) {
+    MF_TRY({
+        MF_NEED(c0 && c1);
+        mf::h_preprocess_pool(input_scale, input_zero_point, output_scale, output_zero_point, c0, c1);
+    })
+}
+
+// ---- 2. prepared operators ----------------------------------------------------
+static int check_act_arg(int a) {
+    if (a != MF_ACT_NONE && a != MF_ACT_RELU && a != MF_ACT_RELU6)
+        mf::fail(MF_ERR_UNSUPPORTED, "unsupported fused activation: " + std::to_string(a) +
+                                         ". Supported activations are NONE, RELU, and RELU6");
+    return a;
+}
+static int check_pad_arg(int p) {
+    if (p != MF_PAD_SAME && p != MF_PAD_VALID) mf::fail(MF_ERR_INVALID_ARG, "bad view_padding");
+    return p;
+}
+static void wrap_op(mf::OpImpl *impl, mf_op **out) {
+    mf_op *h = new (std::nothrow) mf_op{impl};
+    if (!h) {
+        mf::op_destroy(impl);
+        mf::fail(MF_ERR_OOM, "out of host memory");
+    }
+    *out = h;
+}
+
+int mf_fully_connected_create(int device, int M, int K, int N, const int8_t *weights,
+                              int8_t weights_zero_point, float output_scale,
+                              int8_t output_zero_point, int fused_activation, const float *c0,
+                              float c1, const int32_t *c2, int32_t c3, mf_op **op) {
+    MF_TRY({
+        MF_NEED(op && weights && c0 && c2);
+        mf::OpSpec s;
+        s.kind = MF_OP_FULLY_CONNECTED;
+        s.M = M, s.K = K, s.N = N;
+        s.weights = weights, s.wzp = &weights_zero_point, s.nq = 1;
+        s.oscale = output_scale, s.ozp = output_zero_point, s.act = check_act_arg(fused_activation);
+        s.c0 = c0, s.c1 = &c1, s.nc1 = 1, s.c2 = c2, s.c3 = c3;
+        wrap_op(mf::op_create(device, s), op);
+    })
+}
+
+int mf_conv_2d_create(int device, int H, int W, int C, int N, int KH, int KW, const int8_t *filters,
+                      const int8_t *filters_zero_point, int nq, int8_t input_zero_point,
+                      float output_scale, int8_t output_zero_point, int fused_activation,
+                      int view_padding, int stride_h, int stride_w, int OH, int OW,
+                      const float *c0, const float *c1, int nc1, mf_op **op) {
+    MF_TRY({
+        MF_NEED(op && filters && filters_zero_point && c0 && c1);
+        mf::OpSpec s;
+        s.kind = MF_OP_CONV_2D;
+        s.H = H, s.W = W, s.C = C, s.N = N, s.KH = KH, s.KW = KW;
+        s.weights = filters, s.wzp = filters_zero_point, s.nq = nq, s.izp = input_zero_point;
+        s.oscale = output_scale, s.ozp = output_zero_point, s.act = check_act_arg(fused_activation);
+        s.pad = check_pad_arg(view_padding), s.sh = stride_h, s.sw = stride_w, s.OH = OH, s.OW = OW;
+        s.c0 = c0, s.c1 = c1, s.nc1 = nc1;
+        wrap_op(mf::op_create(device, s), op);
+    })
+}
+
+int mf_depthwise_conv_2d_create(int device, int H, int W, int Cin, int KH, int KW, int C,
+                                const int8_t *weights, const int8_t *weights_zero_point, int nq,
+                                int8_t input_zero_point, float output_scale,
+                                int8_t output_zero_point, int fused_activation, int view_padding,
+                                int stride_h, int stride_w, int OH, int OW, const float *c0,
+                                const float *c1, int nc1, mf_op **op) {
+    MF_TRY({
+        MF_NEED(op && weights && weights_zero_point && c0 && c1);
+        mf::OpSpec s;
+        s.kind = MF_OP_DEPTHWISE_CONV_2D;
+        s.H = H, s.W = W, s.C = Cin, s.N = C, s.KH = KH, s.KW = KW;
+        s.weights = weights, s.wzp = weights_zero_point, s.nq = nq, s.izp = input_zero_point;
+        s.oscale = output_scale, s.ozp = output_zero_point, s.act = check_act_arg(fused_activation);
+        s.pad = check_pad_arg(view_padding), s.sh = stride_h, s.sw = stride_w, s.OH = OH, s.OW = OW;
+        s.c0 = c0, s.c1 = c1, s.nc1 = nc1;
+        wrap_op(mf::op_create(device, s), op);
+    })
+}
+
+int mf_average_pool_2d_create(int device, int H, int W, int C, int FH, int FW, float output_scale,
+                              int8_t output_zero_point, int fused_activation, int view_padding,
+                              int stride_h, int stride_w, int OH, int OW, float c0, float c1,
+                              mf_op **op) {
+    MF_TRY({
+        MF_NEED(op);
+        mf::OpSpec s;
+        s.kind = MF_OP_AVERAGE_POOL_2D;
+        s.H = H, s.W = W, s.C = C, s.N = C, s.KH = FH, s.KW = FW;
+        s.oscale = output_scale, s.ozp = output_zero_point, s.act = check_act_arg(fused_activation);
+        s.pad = check_pad_arg(view_padding), s.sh = stride_h, s.sw = stride_w, s.OH = OH, s.OW = OW;
+        s.pool_c0 = c0, s.pool_c1 = c1;
+        wrap_op(mf::op_create(device, s), op);
+    })
+}
+
+int mf_softmax_create(int device, int rows, int cols, float input_scale, float output_scale,
+                      int8_t output_zero_point, mf_op **op) {
+    MF_TRY({
+        MF_NEED(op);
+        mf::OpSpec s;
+        s.kind = MF_OP_SOFTMAX;
+        s.M = rows, s.N = cols, s.in_scale = input_scale;
+        s.oscale = output_scale, s.ozp = output_zero_point;
+        wrap_op(mf::op_create(device, s), op);
+    })
+}
+
+int mf_op_run(mf_op *op, const int8_t *d_input, size_t batch, int8_t *d_output, void *stream) {
+    MF_TRY({
+        MF_NEED(op && op->impl);
+        mf::op_run(op->impl, d_input, batch, d_output, stream);
+    })
+}
+size_t mf_op_input_elems(const mf_op *op) { return op && op->impl ? mf::op_in_elems(op->impl) : 0; }
+size_t mf_op_output_elems(const mf_op *op) { return op && op->impl ? mf::op_out_elems(op->impl) : 0; }
+const char *mf_op_kernel_name(const mf_op *op) { return op && op->impl ? mf::op_kernel_name(op->impl) : ""; }
+int mf_op_set_generic(mf_op *op, int generic) {
+    MF_TRY({
+        MF_NEED(op && op->impl);
+        mf::op_set_generic(op->impl, generic != 0);
+    })
+}
+void mf_op_destroy(mf_op *op) {
+    if (!op) return;
+    mf::op_destroy(op->impl);
+    delete op;
+}
+
+int mf_quantize(int device, const float *d_input, size_t n, float scale, int8_t zero_point,
+                int8_t *d_output, void *stream) {
+    MF_TRY({
+        MF_NEED(n == 0 || (d_input && d_output));
+        mf::dev_quantize(device, d_input, n, scale, zero_point, d_output, stream);
+    })
+}
+int mf_dequantize(int device, const int8_t *d_input, size_t n, float scale, int8_t zero_point,
+                  float *d_output, void *stream) {
+    MF_TRY({
+        MF_NEED(n == 0 || (d_input && d_output));
+        mf::dev_dequantize(device, d_input, n, scale, zero_point, d_output, stream);
+    })
+}
+
+// ---- 3. whole model -------------------------------------------------------------
+int mf_model_create(const uint8_t *tflite, size_t len, mf_model **model) {
+    MF_TRY({
+        MF_NEED(model);
+        if (!tflite) mf::fail(MF_ERR_INVALID_MODEL, "invalid model, please provide a valid TensorFlow Lite model");
+        mf::ModelImpl *impl = mf::model_create(tflite, len);
+        mf_model *h = new (std::nothrow) mf_model{impl};
+        if (!h) {
+            mf::model_destroy(impl);
+            mf::fail(MF_ERR_OOM, "out of host memory");
+        }
+        *model = h;
+    })
+}
+void mf_model_destroy(mf_model *model) {
+    if (!model) return;
+    mf::model_destroy(model->impl);
+    delete model;
+}
+
+int mf_model_get_info(const mf_model *model, mf_model_info *info) {
+    MF_TRY({
+        MF_NEED(model && model->impl && info);
+        const mf::ParsedModel &pm = mf::model_parsed(model->impl);
+        std::memset(info, 0, sizeof(*info));
+        info->input_rank = pm.in_rank, info->output_rank = pm.out_rank;
+        for (int i = 0; i < 4; ++i) info->input_shape[i] = pm.in_shape[i], info->output_shape[i] = pm.out_shape[i];
+        info->input_scale = pm.in_scale, info->output_scale = pm.out_scale;
+        info->input_zero_point = pm.in_zp, info->output_zero_point = pm.out_zp;
+        info->input_elems = pm.in_elems, info->output_elems = pm.out_elems;
+        info->num_ops = (int)pm.ops.size();
+    })
+}
+
+int mf_model_get_op(const mf_model *model, int index, mf_op_desc *d) {
+    MF_TRY({
+        MF_NEED(model && model->impl && d);
+        const mf::ParsedModel &pm = mf::model_parsed(model->impl);
+        MF_NEED(index >= 0 && index < (int)pm.ops.size());
+        const mf::ParsedOp &o = pm.ops[(size_t)index];
+        std::memset(d, 0, sizeof(*d));
+        d->kind = o.kind, d->in_rank = o.in_rank, d->out_rank = o.out_rank;
+        for (int i = 0; i < 4; ++i) d->in_shape[i] = o.in_shape[i], d->out_shape[i] = o.out_shape[i];
+        d->KH = o.KH, d->KW = o.KW, d->stride_h = o.sh, d->stride_w = o.sw;
+        d->padding = o.pad, d->activation = o.act;
+        d->n_c0 = (int)o.c0.size(), d->n_c1 = (int)o.c1.size();
+        d->in_scale = o.in_scale, d->out_scale = o.out_scale;
+        d->in_zero_point = o.in_zp, d->out_zero_point = o.out_zp;
+        d->out_elems = o.out_elems;
+        d->kernel = mf::model_op_kernel(model->impl, index);
+    })
+}
+
+int mf_model_get_op_constants(const mf_model *model, int index, float *c0, float *c1, int32_t *c2,
+                              int32_t *c3) {
+    MF_TRY({
+        MF_NEED(model && model->impl);
+        const mf::ParsedModel &pm = mf::model_parsed(model->impl);
+        MF_NEED(index >= 0 && index < (int)pm.ops.size());
+        const mf::ParsedOp &o = pm.ops[(size_t)index];
+        if (c0 && !o.c0.empty()) std::memcpy(c0, o.c0.data(), o.c0.size() * sizeof(float));
+        if (c1 && !o.c1.empty()) std::memcpy(c1, o.c1.data(), o.c1.size() * sizeof(float));
+        if (c2 && !o.c2.empty()) std::memcpy(c2, o.c2.data(), o.c2.size() * sizeof(int32_t));
+        if (c3) *c3 = o.c3;
+    })
+}
+
+int mf_model_prepare(mf_model *model, int device, size_t max_batch) {
+    MF_TRY({
+        MF_NEED(model && model->impl);
+        mf::model_prepare(model->impl, device, max_batch);
+    })
+}
+int mf_model_set_stream(mf_model *model, void *stream) {
+    MF_TRY({
+        MF_NEED(model && model->impl);
+        mf::model_set_stream(model->impl, stream);
+    })
+}
+int mf_model_sync(mf_model *model) {
+    MF_TRY({
+        MF_NEED(model && model->impl);
+        mf::model_sync(model->impl);
+    })
+}
+int mf_model_set_generic(mf_model *model, int generic) {
+    MF_TRY({
+        MF_NEED(model && model->impl);
+        mf::model_set_generic(model->impl, generic != 0);
+    })
+}
+
+int mf_model_predict(mf_model *model, const float *input, size_t batch, float *output, int mem) {
+    MF_TRY({
+        MF_NEED(model && model->impl && (batch == 0 || (input && output)));
+        mf::model_run(model->impl, input, nullptr, batch, output, nullptr, mem, -1);
+    })
+}
+int mf_model_predict_quantized(mf_model *model, const int8_t *input, size_t batch, float *output,
+                               int mem) {
+    MF_TRY({
+        MF_NEED(model && model->impl && (batch == 0 || (input && output)));
+        mf::model_run(model->impl, nullptr, input, batch, output, nullptr, mem, -1);
+    })
+}
+int mf_model_run_quantized(mf_model *model, const int8_t *input, size_t batch, int8_t *output,
+                           int mem) {
+    MF_TRY({
+        MF_NEED(model && model->impl && (batch == 0 || (input && output)));
+        mf::model_run(model->impl, nullptr, input, batch, nullptr, output, mem, -1);
+    })
+}
+int mf_model_run_until(mf_model *model, const int8_t *input, size_t batch, int last_op,
+                       int8_t *output, int mem) {
+    MF_TRY({
+        MF_NEED(model && model->impl && (batch == 0 || (input && output)) && last_op >= 0);
+        mf::model_run(model->impl, nullptr, input, batch, nullptr, output, mem, last_op);
+    })
+}
+
+// ---- 4. measurement helpers -------------------------------------------------------
+int mf_synth_i8(int device, uint64_t seed, uint64_t first_byte, size_t n, int8_t *d_output,
+                void *stream) {
+    MF_TRY({
+        MF_NEED(n == 0 || d_output);
+        mf::dev_synth_i8(device, seed, first_byte, n, d_output, stream);
+    })
+}
+int mf_checksum_i8(int device, const int8_t *d_input, size_t n, uint64_t *checksum, void *stream) {
+    MF_TRY({
+        MF_NEED(checksum && (n == 0 || d_input));
+        *checksum = mf::dev_checksum_i8(device, d_input, n, stream);
+    })
+}
+int mf_model_time_device(mf_model *model, const int8_t *d_input, size_t batch, int8_t *d_output,
+                         int warmup, int iters, float *avg_ms, float *per_op_ms) {
+    MF_TRY({
+        MF_NEED(model && model->impl && d_input && d_output);
+        mf::model_time_device(model->impl, d_input, batch, d_output, warmup, iters, avg_ms, per_op_ms);
+    })
+}
+
+} // extern "C"

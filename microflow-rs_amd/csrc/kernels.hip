@@ -1,0 +1,810 @@
+// kernels.hip -- hand-written HIP kernels for gfx950 (MI355X / CDNA4).
+//
+// One kernel family per reference function in src/ops/ (upstream file:line in each
+// header comment).  All of them share one arithmetic contract:
+//
+//   acc (i32)  = sum over ALL window taps of (v' - izp) * (w - wzp)
+//                with v' = izp at out-of-range taps          [== x0 - x1 - k2 + k3]
+//   y          = sat_i8(roundf((f32(ozp) + c0[c]) + c1[c] * f32(acc)))   then activation
+//
+// The device never evaluates `izp`-dependent terms per pixel: the host folds
+//   Kc[c] = -izp * sum_all_taps w[c] + T * izp * wzp[c]   (T = taps contributing to c)
+// so that acc = dot(v', w) - wzp[c] * sum(v') + Kc[c]; padding is realised by
+// filling the halo with izp, which makes every pixel -- border or interior -- run
+// the same code.  A[c] = fl32(f32(ozp) + c0[c]) and S[c] = c1[c or 0] are folded on
+// the host too, and the activation is a clamp [lo, hi] (relu: lo = ozp; relu6:
+// hi = quantize(6.0)).
+//
+// f32 rules: no contraction (this file is built with -ffp-contract=off AND uses the
+// explicit __fmul_rn/__fadd_rn/__fdiv_rn forms), int->float is v_cvt_f32_i32 (RNE),
+// roundf is trunc(x + copysign(pred(0.5), x)) which is exact for every finite x.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kernels.hpp"
+
+namespace mf {
+namespace k {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------------
+// shared device helpers
+// ------------------------------------------------------------------------
+__device__ __forceinline__ int requant(int acc, float A, float S, float lo_f, float hi_f) {
+    // (f32(ozp) + c0) + c1 * f32(acc): two roundings, like the reference (conv_2d.rs:93-98)
+    const float x = __fadd_rn(A, __fmul_rn(S, (float)acc));
+    // libm::roundf = half away from zero = trunc(x + copysign(0x1.fffffep-2, x))
+    float r = __fadd_rn(x, __builtin_copysignf(0x1.fffffep-2f, x));
+    // saturating cast + activation clamp, done in f32 so that the int conversion below
+    // is always in range (it truncates toward zero)
+    r = __builtin_amdgcn_fmed3f(r, lo_f, hi_f);
+    return (int)r;
+}
+
+// 4 ints in [-128,127] -> one dword of int8 (byte 0 = a)
+__device__ __forceinline__ uint32_t pack4(int a, int b, int c, int d) {
+    const uint32_t lo = __builtin_amdgcn_perm((uint32_t)b, (uint32_t)a, 0x0c0c0400u);
+    const uint32_t hi = __builtin_amdgcn_perm((uint32_t)d, (uint32_t)c, 0x0c0c0400u);
+    return __builtin_amdgcn_perm(hi, lo, 0x05040100u);
+}
+
+__device__ __forceinline__ int sdot4(uint32_t a, uint32_t b, int c) {
+    return __builtin_amdgcn_sdot4((int)a, (int)b, c, false);
+}
+
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+    uint64_t z = x + 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+// ------------------------------------------------------------------------
+// Generic (any shape) kernels: one thread per output element.  They exist for
+// API completeness (the reference's unit KATs, odd filter shapes, non-zero weight
+// zero points) and as the in-product cross-check of the fast paths.
+// ------------------------------------------------------------------------
+
+// microflow::ops::conv_2d  (src/ops/conv_2d.rs:28-108)
+__global__ __launch_bounds__(256) void conv2d_generic(const int8_t *__restrict__ in,
+                                                      int8_t *__restrict__ out, ConvArgs p,
+                                                      size_t total) {
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * 256) {
+        const int n = (int)(idx % p.N);
+        size_t t = idx / p.N;
+        const int ox = (int)(t % p.OW);
+        t /= p.OW;
+        const int oy = (int)(t % p.OH);
+        const size_t img = t / p.OH;
+        const int8_t *ip = in + img * (size_t)p.H * p.W * p.C;
+        const int8_t *wp = p.w + (size_t)n * p.KH * p.KW * p.C;
+        const int shy = p.pad_same ? (p.KH - 1) / 2 : 0, shx = p.pad_same ? (p.KW - 1) / 2 : 0;
+        int dot = 0, vs = 0;
+        for (int ky = 0; ky < p.KH; ++ky) {
+            const int iy = oy * p.sh + ky - shy;
+            for (int kx = 0; kx < p.KW; ++kx) {
+                const int ix = ox * p.sw + kx - shx;
+                const bool ok = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+                const int8_t *vp = ip + ((size_t)iy * p.W + ix) * p.C;
+                const int8_t *fp = wp + ((size_t)ky * p.KW + kx) * p.C;
+                for (int c = 0; c < p.C; ++c) {
+                    const int v = ok ? (int)vp[c] : p.izp;
+                    dot += v * (int)fp[c];
+                    vs += v;
+                }
+            }
+        }
+        const int acc = dot - p.wzp[n] * vs + p.Kc[n];
+        out[idx] = (int8_t)requant(acc, p.A[n], p.S[n], p.lo_f, p.hi_f);
+    }
+}
+
+// microflow::ops::depthwise_conv_2d  (src/ops/depthwise_conv_2d.rs:28-105)
+__global__ __launch_bounds__(256) void dwconv_generic(const int8_t *__restrict__ in,
+                                                      int8_t *__restrict__ out, ConvArgs p,
+                                                      size_t total) {
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * 256) {
+        const int c = (int)(idx % p.N);
+        size_t t = idx / p.N;
+        const int ox = (int)(t % p.OW);
+        t /= p.OW;
+        const int oy = (int)(t % p.OH);
+        const size_t img = t / p.OH;
+        const int ci = c < p.C ? c : 0; // v.get(c).copied().unwrap_or(v[0])  (depthwise_conv_2d.rs:67)
+        const int8_t *ip = in + img * (size_t)p.H * p.W * p.C;
+        const int shy = p.pad_same ? (p.KH - 1) / 2 : 0, shx = p.pad_same ? (p.KW - 1) / 2 : 0;
+        int dot = 0, vs = 0;
+        for (int ky = 0; ky < p.KH; ++ky) {
+            const int iy = oy * p.sh + ky - shy;
+            for (int kx = 0; kx < p.KW; ++kx) {
+                const int ix = ox * p.sw + kx - shx;
+                const bool ok = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+                const int v = ok ? (int)ip[((size_t)iy * p.W + ix) * p.C + ci] : p.izp;
+                dot += v * (int)p.w[((size_t)ky * p.KW + kx) * p.N + c];
+                vs += v;
+            }
+        }
+        const int acc = dot - p.wzp[c] * vs + p.Kc[c];
+        out[idx] = (int8_t)requant(acc, p.A[c], p.S[c], p.lo_f, p.hi_f);
+    }
+}
+
+// microflow::ops::average_pool_2d  (src/ops/average_pool_2d.rs:29-66)
+//   x = (1 / f32(len)) * f32(sum over the zero-filled window);  y = roundf(c0 * x + c1)
+__global__ __launch_bounds__(256) void avgpool_generic(const int8_t *__restrict__ in,
+                                                       int8_t *__restrict__ out, PoolArgs p,
+                                                       size_t total) {
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * 256) {
+        const int c = (int)(idx % p.C);
+        size_t t = idx / p.C;
+        const int ox = (int)(t % p.OW);
+        t /= p.OW;
+        const int oy = (int)(t % p.OH);
+        const size_t img = t / p.OH;
+        const int8_t *ip = in + img * (size_t)p.H * p.W * p.C;
+        const int shy = p.pad_same ? (p.KH - 1) / 2 : 0, shx = p.pad_same ? (p.KW - 1) / 2 : 0;
+        int sum = 0, len = 0;
+        for (int ky = 0; ky < p.KH; ++ky) {
+            const int iy = oy * p.sh + ky - shy;
+            for (int kx = 0; kx < p.KW; ++kx) {
+                const int ix = ox * p.sw + kx - shx;
+                if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) {
+                    sum += (int)ip[((size_t)iy * p.W + ix) * p.C + c];
+                    ++len;
+                }
+            }
+        }
+        const float inv = __fdiv_rn(1.0f, (float)len);
+        const float x = __fmul_rn(inv, (float)sum);
+        const float y = __fadd_rn(__fmul_rn(p.c0, x), p.c1);
+        float r = __fadd_rn(y, __builtin_copysignf(0x1.fffffep-2f, y));
+        // NaN (len == 0) converts to 0 like Rust's `as`; fmed3 is skipped for it
+        int q = (r != r) ? 0 : (int)__builtin_amdgcn_fmed3f(r, -128.0f, 127.0f);
+        q = max(q, p.lo);
+        q = min(q, p.hi);
+        out[idx] = (int8_t)q;
+    }
+}
+
+// microflow::ops::fully_connected  (src/ops/fully_connected.rs:24-82), any M/K/N.
+// in [batch*M][K], w [N][K], out [batch*M][N].
+__global__ __launch_bounds__(256) void fc_generic(const int8_t *__restrict__ in,
+                                                  int8_t *__restrict__ out, FcArgs p,
+                                                  size_t total) {
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * 256) {
+        const int j = (int)(idx % p.N);
+        const size_t row = idx / p.N;
+        const int8_t *x = in + row * (size_t)p.K;
+        const int8_t *w = p.w + (size_t)j * p.K;
+        int dot = 0, rs = 0;
+        if ((p.K & 3) == 0) {
+            const uint32_t *x4 = (const uint32_t *)x, *w4 = (const uint32_t *)w;
+            for (int k = 0; k < p.K / 4; ++k) {
+                const uint32_t v = x4[k];
+                dot = sdot4(v, w4[k], dot);
+                rs = sdot4(v, 0x01010101u, rs);
+            }
+        } else {
+            for (int k = 0; k < p.K; ++k) {
+                dot += (int)x[k] * (int)w[k];
+                rs += (int)x[k];
+            }
+        }
+        const int acc = dot - p.wzp * rs + p.Kc[j];
+        out[idx] = (int8_t)requant(acc, p.A[j], p.S, p.lo_f, p.hi_f);
+    }
+}
+
+// FullyConnected with few outputs and a long reduction (speech: K=4000, N=4):
+// one wavefront per input row, 16-byte coalesced loads, DPP/shuffle reduction.
+// Memory-bound: every input byte is read exactly once.
+template <int N>
+__global__ __launch_bounds__(256) void fc_rowwave(const int8_t *__restrict__ in,
+                                                  int8_t *__restrict__ out, FcArgs p, size_t rows) {
+    const int lane = threadIdx.x & 63;
+    const size_t wave = ((size_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+    const size_t nwaves = ((size_t)gridDim.x * 256) >> 6;
+    const int K16 = p.K >> 4; // K % 16 == 0 is a routing precondition
+    for (size_t row = wave; row < rows; row += nwaves) {
+        const uint4 *x = (const uint4 *)(in + row * (size_t)p.K);
+        int dot[N], rs = 0;
+#pragma unroll
+        for (int j = 0; j < N; ++j) dot[j] = 0;
+        for (int k = lane; k < K16; k += 64) {
+            const uint4 v = x[k];
+            rs = sdot4(v.x, 0x01010101u, rs);
+            rs = sdot4(v.y, 0x01010101u, rs);
+            rs = sdot4(v.z, 0x01010101u, rs);
+            rs = sdot4(v.w, 0x01010101u, rs);
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                const uint4 w = ((const uint4 *)(p.w + (size_t)j * p.K))[k];
+                dot[j] = sdot4(v.x, w.x, dot[j]);
+                dot[j] = sdot4(v.y, w.y, dot[j]);
+                dot[j] = sdot4(v.z, w.z, dot[j]);
+                dot[j] = sdot4(v.w, w.w, dot[j]);
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            rs += __shfl_xor(rs, off, 64);
+#pragma unroll
+            for (int j = 0; j < N; ++j) dot[j] += __shfl_xor(dot[j], off, 64);
+        }
+        if (lane < N) {
+            int d = 0;
+#pragma unroll
+            for (int j = 0; j < N; ++j) d = (lane == j) ? dot[j] : d;
+            const int acc = d - p.wzp * rs + p.Kc[lane];
+            out[row * N + lane] = (int8_t)requant(acc, p.A[lane], p.S, p.lo_f, p.hi_f);
+        }
+    }
+}
+
+// microflow::ops::softmax  (src/ops/softmax.rs:15-27).  One thread per inference.
+// e_k = f32(q_k) * input_scale has only 256 possible values, so expf comes from a
+// host-built table (libm's algorithm runs on the host, never the device's expf).
+// The sum runs over the whole rows x cols tensor in column-major order.
+__global__ __launch_bounds__(256) void softmax_table(const int8_t *__restrict__ in,
+                                                     int8_t *__restrict__ out, SoftmaxArgs p,
+                                                     size_t batch) {
+    for (size_t b = (size_t)blockIdx.x * 256 + threadIdx.x; b < batch;
+         b += (size_t)gridDim.x * 256) {
+        const int8_t *x = in + b * (size_t)p.rows * p.cols;
+        int8_t *y = out + b * (size_t)p.rows * p.cols;
+        float sum = 0.0f;
+        for (int j = 0; j < p.cols; ++j)
+            for (int i = 0; i < p.rows; ++i) sum = __fadd_rn(sum, p.exp_table[(int)x[i * p.cols + j] + 128]);
+        for (int i = 0; i < p.rows * p.cols; ++i) {
+            const float e = p.exp_table[(int)x[i] + 128];
+            const float prob = __fdiv_rn(e, sum);
+            const float q = __fadd_rn(__fdiv_rn(prob, p.oscale), p.ozp_f); // quantize (quantize.rs:17)
+            const float r = __fadd_rn(q, __builtin_copysignf(0x1.fffffep-2f, q));
+            y[i] = (r != r) ? (int8_t)0 : (int8_t)(int)__builtin_amdgcn_fmed3f(r, -128.0f, 127.0f);
+        }
+    }
+}
+
+// src/quantize.rs:16-18 over a buffer: q = sat(roundf(x / scale + f32(zp)))
+__global__ __launch_bounds__(256) void quantize_f32(const float *__restrict__ in,
+                                                    int8_t *__restrict__ out, size_t n, float scale,
+                                                    float zp_f) {
+    // 4 values per thread: one 16-byte load, one 4-byte store
+    const size_t n4 = n >> 2;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const float4 v = ((const float4 *)in)[i];
+        int q[4];
+        const float xs[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float t = __fadd_rn(__fdiv_rn(xs[k], scale), zp_f);
+            const float r = __fadd_rn(t, __builtin_copysignf(0x1.fffffep-2f, t));
+            q[k] = (r != r) ? 0 : (int)__builtin_amdgcn_fmed3f(r, -128.0f, 127.0f);
+        }
+        ((uint32_t *)out)[i] = pack4(q[0], q[1], q[2], q[3]);
+    }
+    for (size_t i = (n4 << 2) + (size_t)blockIdx.x * 256 + threadIdx.x; i < n;
+         i += (size_t)gridDim.x * 256) {
+        const float t = __fadd_rn(__fdiv_rn(in[i], scale), zp_f);
+        const float r = __fadd_rn(t, __builtin_copysignf(0x1.fffffep-2f, t));
+        out[i] = (r != r) ? (int8_t)0 : (int8_t)(int)__builtin_amdgcn_fmed3f(r, -128.0f, 127.0f);
+    }
+}
+
+// src/quantize.rs:27-29: x = scale * (f32(q) - f32(zp))
+__global__ __launch_bounds__(256) void dequantize_i8(const int8_t *__restrict__ in,
+                                                     float *__restrict__ out, size_t n, float scale,
+                                                     float zp_f) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        out[i] = __fmul_rn(scale, __fsub_rn((float)in[i], zp_f));
+}
+
+// counter-based synthetic input: 8 bytes per thread
+__global__ __launch_bounds__(256) void synth_i8(int8_t *__restrict__ out, size_t n, uint64_t seed,
+                                                uint64_t first) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const uint64_t g = first + i;
+        const uint64_t w = splitmix64(seed + (g >> 3));
+        out[i] = (int8_t)(uint8_t)(w >> ((g & 7) * 8));
+    }
+}
+
+// position-sensitive checksum: sum (u8 + 1) * splitmix64(i); one atomic per block
+__global__ __launch_bounds__(256) void checksum_i8(const int8_t *__restrict__ in, size_t n,
+                                                   unsigned long long *__restrict__ result) {
+    __shared__ unsigned long long part[256];
+    unsigned long long s = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        s += ((unsigned long long)(uint8_t)in[i] + 1ull) * splitmix64(i);
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) part[threadIdx.x] += part[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) atomicAdd(result, part[0]);
+}
+
+// ------------------------------------------------------------------------
+// FAST PATH 1 -- DepthwiseConv2D 3x3, SAME, NHWC, C % 4 == 0, weight zp == 0.
+// (src/ops/depthwise_conv_2d.rs:28-105; person_detect ops 1,3,5,...,25)
+//
+// HBM-bound by construction: every input byte is read from HBM once, every output
+// byte written once.  One workgroup owns G whole images per step:
+//   fill   : 16-byte coalesced global loads of the G contiguous NHWC images into an LDS
+//            tile whose 1-pixel halo ring was pre-filled with izp (padding == izp makes
+//            border pixels identical to interior ones).  The loads of step i+1 are
+//            issued before the compute of step i and land in registers (prefetch).
+//   compute: lane = (pixel, 4-channel group).  The 4-channel group of a lane never
+//            changes, so its 9 tap-weight dwords live in VGPRs as 36 byte-masked
+//            copies: acc[k] += sdot4(v, w & (0xff << 8k)) is one full-rate VALU op per
+//            MAC with no unpacking of either operand.
+//   store  : one dword (4 channels) per lane, consecutive lanes = consecutive addresses.
+// LDS row layout: [LP pad][W*C bytes][LP pad], LP = max(C,16), so every 16-byte fill
+// store is 16-byte aligned (MI355X guide, G17) and tap (ky,kx) of a lane is a constant
+// offset ky*ROW + kx*C from its base address.
+// ------------------------------------------------------------------------
+template <int H, int W, int C, int S, int G>
+__global__ __launch_bounds__(256) void dw3x3_nhwc(const int8_t *__restrict__ in,
+                                                  int8_t *__restrict__ out, DwFastArgs p,
+                                                  int batch) {
+    constexpr int C4 = C / 4;
+    constexpr int OH = (H + S - 1) / S, OW = (W + S - 1) / S;
+    constexpr int LP = C < 16 ? 16 : C;
+    constexpr int ROW = LP + W * C + LP;          // bytes per LDS row
+    constexpr int TILE = (H + 2) * ROW;           // bytes per image tile (1 halo row above/below)
+    constexpr int IMG = H * W * C;                // bytes per input image
+    constexpr int CHUNKS = G * IMG / 16;          // 16-byte chunks per step
+    constexpr int NPRE = (CHUNKS + 255) / 256;    // prefetch registers (uint4) per thread
+    constexpr int ROWCH = W * C / 16;             // chunks per image row
+    constexpr int OUTS = G * OH * OW * C4;        // output dwords per step
+    constexpr int NOUT = (OUTS + 255) / 256;
+    static_assert(256 % C4 == 0, "channel group of a lane must be loop-invariant");
+    static_assert((W * C) % 16 == 0 && IMG % 16 == 0, "rows must be whole 16-byte chunks");
+
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const int tid = threadIdx.x;
+
+    // halo ring (and everything else) := izp, once; the fill only ever rewrites interiors
+    for (int i = tid; i < G * TILE / 16; i += 256)
+        ((uint4 *)lds)[i] = make_uint4(p.izp4, p.izp4, p.izp4, p.izp4);
+
+    // per-lane constants of this lane's channel group
+    const int cg = tid & (C4 - 1);
+    uint32_t wm[9][4];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const uint32_t w = ((const uint32_t *)p.w)[t * C4 + cg];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) wm[t][k] = w & (0xffu << (8 * k));
+    }
+    const float4 A = ((const float4 *)p.A)[cg], Sc = ((const float4 *)p.S)[cg];
+    const int4 Kc = ((const int4 *)p.Kc)[cg];
+
+    const int nsteps = (batch + G - 1) / G;
+    int step = blockIdx.x;
+    uint4 pre[NPRE];
+    auto prefetch = [&](int st) {
+        const uint4 *src = (const uint4 *)(in + (size_t)st * G * IMG);
+        const int valid = min(G, batch - st * G) * (IMG / 16); // chunks that exist
+#pragma unroll
+        for (int j = 0; j < NPRE; ++j) {
+            const int q = tid + 256 * j;
+            if (q < valid) pre[j] = src[q];
+        }
+    };
+    if (step < nsteps) prefetch(step);
+    __syncthreads();
+
+    for (; step < nsteps; step += gridDim.x) {
+        // ---- fill: registers -> LDS interiors ----
+        const int valid = min(G, batch - step * G) * (IMG / 16);
+#pragma unroll
+        for (int j = 0; j < NPRE; ++j) {
+            const int q = tid + 256 * j;
+            if (q < CHUNKS && q < valid) {
+                const int g = q / (IMG / 16), r = q % (IMG / 16);
+                const int y = r / ROWCH, xc = r % ROWCH;
+                *(uint4 *)(lds + g * TILE + (y + 1) * ROW + LP + xc * 16) = pre[j];
+            }
+        }
+        __syncthreads();
+        const int next = step + gridDim.x;
+        if (next < nsteps) prefetch(next); // in flight during the compute below
+
+        // ---- compute + store ----
+        uint32_t *dst = (uint32_t *)out + (size_t)step * G * OH * OW * C4;
+        const int nvalid = min(G, batch - step * G) * OH * OW * C4;
+#pragma unroll 2
+        for (int i = 0; i < NOUT; ++i) {
+            const int o = tid + 256 * i;
+            if (o < OUTS && o < nvalid) {
+                const int pix = o / C4;
+                const int g = pix / (OH * OW), rem = pix % (OH * OW);
+                const int oy = rem / OW, ox = rem % OW;
+                // tap (ky,kx): row oy*S + ky (halo row 0 == input row -1), col ox*S + kx - 1
+                const uint8_t *base = lds + g * TILE + (oy * S) * ROW + LP + (ox * S - 1) * C + cg * 4;
+                int a0 = Kc.x, a1 = Kc.y, a2 = Kc.z, a3 = Kc.w;
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const uint32_t v = *(const uint32_t *)(base + ky * ROW + kx * C);
+                        const int t = ky * 3 + kx;
+                        a0 = sdot4(v, wm[t][0], a0);
+                        a1 = sdot4(v, wm[t][1], a1);
+                        a2 = sdot4(v, wm[t][2], a2);
+                        a3 = sdot4(v, wm[t][3], a3);
+                    }
+                const int q0 = requant(a0, A.x, Sc.x, p.lo_f, p.hi_f);
+                const int q1 = requant(a1, A.y, Sc.y, p.lo_f, p.hi_f);
+                const int q2 = requant(a2, A.z, Sc.z, p.lo_f, p.hi_f);
+                const int q3 = requant(a3, A.w, Sc.w, p.lo_f, p.hi_f);
+                dst[o] = pack4(q0, q1, q2, q3);
+            }
+        }
+        __syncthreads(); // everyone done reading before the next fill overwrites
+    }
+}
+
+// ------------------------------------------------------------------------
+// FAST PATH 2 -- DepthwiseConv2D 3x3 stride 2 SAME with ONE input channel and DM
+// output channels (the network stem: person_detect op 0, 96x96x1 -> 48x48x8).
+// (src/ops/depthwise_conv_2d.rs:67: every output channel reads input channel 0.)
+//
+// A lane produces two horizontally adjacent output pixels x DM=8 channels = one
+// 16-byte store.  Per filter row it reads two LDS dwords, builds the two 3-tap
+// windows with one v_perm and one shift, and issues one sdot4 per (pixel, channel,
+// row) against wave-uniform weight dwords [w(ky,0,c), w(ky,1,c), w(ky,2,c), 0] that
+// live in SGPRs.
+// ------------------------------------------------------------------------
+template <int H, int W, int G>
+__global__ __launch_bounds__(256) void dw3x3_stem8(const int8_t *__restrict__ in,
+                                                   int8_t *__restrict__ out, DwStemArgs p,
+                                                   int batch) {
+    constexpr int DM = 8, S = 2;
+    constexpr int OH = (H + S - 1) / S, OW = (W + S - 1) / S;
+    constexpr int LP = 16;
+    constexpr int ROW = LP + W + LP;
+    constexpr int TILE = (H + 2) * ROW;
+    constexpr int IMG = H * W;
+    constexpr int CHUNKS = G * IMG / 16;
+    constexpr int NPRE = (CHUNKS + 255) / 256;
+    constexpr int ROWCH = W / 16;
+    constexpr int PAIRS = OW / 2;                 // lane tasks per output row
+    constexpr int TASKS = G * OH * PAIRS;
+    constexpr int NTASK = (TASKS + 255) / 256;
+    static_assert(W % 16 == 0 && OW % 2 == 0, "stem geometry");
+
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < G * TILE / 16; i += 256)
+        ((uint4 *)lds)[i] = make_uint4(p.izp4, p.izp4, p.izp4, p.izp4);
+
+    const int nsteps = (batch + G - 1) / G;
+    int step = blockIdx.x;
+    uint4 pre[NPRE];
+    auto prefetch = [&](int st) {
+        const uint4 *src = (const uint4 *)(in + (size_t)st * G * IMG);
+        const int valid = min(G, batch - st * G) * (IMG / 16);
+#pragma unroll
+        for (int j = 0; j < NPRE; ++j) {
+            const int q = tid + 256 * j;
+            if (q < valid) pre[j] = src[q];
+        }
+    };
+    if (step < nsteps) prefetch(step);
+    __syncthreads();
+
+    for (; step < nsteps; step += gridDim.x) {
+        const int valid = min(G, batch - step * G) * (IMG / 16);
+#pragma unroll
+        for (int j = 0; j < NPRE; ++j) {
+            const int q = tid + 256 * j;
+            if (q < CHUNKS && q < valid) {
+                const int g = q / (IMG / 16), r = q % (IMG / 16);
+                const int y = r / ROWCH, xc = r % ROWCH;
+                *(uint4 *)(lds + g * TILE + (y + 1) * ROW + LP + xc * 16) = pre[j];
+            }
+        }
+        __syncthreads();
+        const int next = step + gridDim.x;
+        if (next < nsteps) prefetch(next);
+
+        uint4 *dst = (uint4 *)out + (size_t)step * G * OH * PAIRS;
+        const int nvalid = min(G, batch - step * G) * OH * PAIRS;
+#pragma unroll 1
+        for (int i = 0; i < NTASK; ++i) {
+            const int o = tid + 256 * i;
+            if (o < TASKS && o < nvalid) {
+                const int g = o / (OH * PAIRS), rem = o % (OH * PAIRS);
+                const int oy = rem / PAIRS, j = rem % PAIRS;
+                // pixels ox = 2j, 2j+1 need input cols 4j-1 .. 4j+3 of rows 2oy-1 .. 2oy+1:
+                // LDS dwords (LP + 4j - 4)/4 and (LP + 4j)/4 of tile rows 2oy .. 2oy+2
+                const uint32_t *rowp = (const uint32_t *)(lds + g * TILE + (oy * S) * ROW + LP + 4 * j - 4);
+                uint32_t ta[3], tb[3];
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    const uint32_t d0 = rowp[ky * (ROW / 4)], d1 = rowp[ky * (ROW / 4) + 1];
+                    ta[ky] = __builtin_amdgcn_perm(d0, d1, 0x0c010007u); // [d0.b3, d1.b0, d1.b1, 0]
+                    tb[ky] = d1 >> 8;                                    // [d1.b1, d1.b2, d1.b3, 0]
+                }
+                int qa[DM], qb[DM];
+#pragma unroll
+                for (int c = 0; c < DM; ++c) {
+                    int a = p.Kc[c], b = p.Kc[c];
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky) {
+                        a = sdot4(ta[ky], p.wrow[ky][c], a);
+                        b = sdot4(tb[ky], p.wrow[ky][c], b);
+                    }
+                    qa[c] = requant(a, p.A[c], p.S[c], p.lo_f, p.hi_f);
+                    qb[c] = requant(b, p.A[c], p.S[c], p.lo_f, p.hi_f);
+                }
+                uint4 v;
+                v.x = pack4(qa[0], qa[1], qa[2], qa[3]);
+                v.y = pack4(qa[4], qa[5], qa[6], qa[7]);
+                v.z = pack4(qb[0], qb[1], qb[2], qb[3]);
+                v.w = pack4(qb[4], qb[5], qb[6], qb[7]);
+                dst[o] = v;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------
+// FAST PATH 3 -- Conv2D 1x1 stride 1 (pointwise) as an int8 MFMA GEMM.
+// (src/ops/conv_2d.rs:28-108 with KH = KW = 1; person_detect ops 2,4,...,26)
+//
+//   D[out channel][pixel] = sum_k Wt[out channel][k] * X[pixel][k]
+//   v_mfma_i32_16x16x64_i8:  A = weights (rows = 16 out channels), B = pixels
+//   (cols = 16 pixels), so that a lane ends up holding 4 CONSECUTIVE out channels of
+//   one pixel per 16x16 tile and can store them packed.
+//
+// In NHWC with the batch outermost, the activations of the whole batch ARE the
+// row-major [pixels][K] matrix -- no im2col, no LDS staging of activations: lane
+// (p = lane&15, g = lane>>4) loads its 16 bytes of operand B straight from HBM in
+// MFMA layout, and every wave-level load instruction covers whole contiguous 1 KiB.
+// K < 64 (early layers) would waste the 64-deep MFMA k-span, so 64/K pixel groups
+// share one B register and the host pre-builds Q = 64/K zero-padded copies A_q of the
+// weights, each selecting one group's k-bytes (block-diagonal trick): loads stay
+// 16 B/lane fully coalesced at every K.  The weight rows are permuted on the host so
+// that tile tt row 4g+j is channel base + g*(NB/4) + 4*tt + j: after TB tiles a lane
+// holds NB/4 consecutive output bytes -> one 4/8/16-byte store.
+// N > 64 is split over the waves of the workgroup (NSPLIT = N/64), which all read the
+// same pixels (L1/L2 hits).  HBM-bound: MFMA work is ~1/8 of the memory time.
+// ------------------------------------------------------------------------
+template <int K, int N>
+__global__ __launch_bounds__(256) void pw_mfma(const int8_t *__restrict__ in,
+                                               int8_t *__restrict__ out, PwArgs p,
+                                               long long npix) {
+    constexpr int NB = N < 64 ? N : 64;        // channels per wave block
+    constexpr int TB = NB / 16;                // 16-channel MFMA tiles per block
+    constexpr int NSPLIT = N / NB;             // waves sharing one pixel chunk
+    constexpr int KS = K < 64 ? 1 : K / 64;    // 64-deep k steps
+    constexpr int Q = K < 64 ? 64 / K : 1;     // pixel groups per B register
+    constexpr int CPIX = (K < 64) ? (1024 / K) : 16; // pixels per chunk
+    constexpr int SLOTS = 4 / NSPLIT;          // pixel chunks processed concurrently per WG
+    static_assert(N % 16 == 0 && (K == 8 || K % 16 == 0), "pw_mfma shape");
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pcol = lane & 15, g = lane >> 4;
+    const int blk = wave % NSPLIT;             // which 64-channel block this wave owns
+    const int slot = wave / NSPLIT;
+
+    // operand A (weights), pre-arranged by the host: [blk][q][tt][ks][lane] x 16 bytes
+    v4i Aw[Q][TB][KS];
+#pragma unroll
+    for (int q = 0; q < Q; ++q)
+#pragma unroll
+        for (int tt = 0; tt < TB; ++tt)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+                Aw[q][tt][ks] = ((const v4i *)p.wprep)[((((size_t)blk * Q + q) * TB + tt) * KS + ks) * 64 + lane];
+    // epilogue constants of this lane's channels: block base + g*(NB/4) + 4*tt + j
+    float4 cA[TB], cS[TB];
+    int4 cK[TB];
+#pragma unroll
+    for (int tt = 0; tt < TB; ++tt) {
+        const int ch = blk * NB + g * (NB / 4) + 4 * tt;
+        cA[tt] = *(const float4 *)(p.A + ch);
+        cS[tt] = *(const float4 *)(p.S + ch);
+        cK[tt] = *(const int4 *)(p.Kc + ch);
+    }
+
+    const long long nchunks = (npix + CPIX - 1) / CPIX;
+    const long long stride = (long long)gridDim.x * SLOTS;
+    long long chunk = (long long)blockIdx.x * SLOTS + slot;
+
+    auto loadB = [&](long long ch, v4i (&b)[KS]) {
+        if constexpr (K >= 64) {
+            long long pix = ch * 16 + pcol;
+            pix = pix < npix ? pix : npix - 1;
+            const int8_t *src = in + pix * K + g * 16;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) b[ks] = *(const v4i *)(src + ks * 64);
+        } else if constexpr (K == 32) {
+            long long pix = ch * CPIX + (g >> 1) * 16 + pcol;
+            pix = pix < npix ? pix : npix - 1;
+            b[0] = *(const v4i *)(in + pix * 32 + (g & 1) * 16);
+        } else if constexpr (K == 16) {
+            long long pix = ch * CPIX + g * 16 + pcol;
+            pix = pix < npix ? pix : npix - 1;
+            b[0] = *(const v4i *)(in + pix * 16);
+        } else { // K == 8: 16 bytes = 2 pixels; npix is even whenever H*W is (routing precondition)
+            long long pix = ch * CPIX + 2 * (g * 16 + pcol);
+            pix = pix + 1 < npix ? pix : npix - 2;
+            b[0] = *(const v4i *)(in + pix * 8);
+        }
+    };
+
+    v4i B[KS], Bn[KS];
+    if (chunk < nchunks) loadB(chunk, B);
+    for (; chunk < nchunks; chunk += stride) {
+        const long long nxt = chunk + stride;
+        if (nxt < nchunks) loadB(nxt, Bn);
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            // pixel this lane's column belongs to for sub-group q
+            long long pix;
+            if constexpr (K >= 64) pix = chunk * 16 + pcol;
+            else if constexpr (K == 8) pix = chunk * CPIX + 2 * ((q >> 1) * 16 + pcol) + (q & 1);
+            else pix = chunk * CPIX + q * 16 + pcol;
+            uint32_t packed[TB];
+#pragma unroll
+            for (int tt = 0; tt < TB; ++tt) {
+                v4i acc = {0, 0, 0, 0};
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks)
+                    acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(Aw[q][tt][ks], B[ks], acc, 0, 0, 0);
+                const int q0 = requant(acc[0] + cK[tt].x, cA[tt].x, cS[tt].x, p.lo_f, p.hi_f);
+                const int q1 = requant(acc[1] + cK[tt].y, cA[tt].y, cS[tt].y, p.lo_f, p.hi_f);
+                const int q2 = requant(acc[2] + cK[tt].z, cA[tt].z, cS[tt].z, p.lo_f, p.hi_f);
+                const int q3 = requant(acc[3] + cK[tt].w, cA[tt].w, cS[tt].w, p.lo_f, p.hi_f);
+                packed[tt] = pack4(q0, q1, q2, q3);
+            }
+            if (pix < npix) {
+                int8_t *dstp = out + pix * N + blk * NB + g * (NB / 4);
+                if constexpr (TB == 1) *(uint32_t *)dstp = packed[0];
+                else if constexpr (TB == 2) *(uint2 *)dstp = make_uint2(packed[0], packed[1]);
+                else *(uint4 *)dstp = make_uint4(packed[0], packed[1], packed[2], packed[3]);
+            }
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) B[ks] = Bn[ks];
+    }
+}
+
+// ------------------------------------------------------------------------
+// launchers (host)
+// ------------------------------------------------------------------------
+static inline int grid_for(size_t total, int per_block = 256, int cap = 256 * 8) {
+    size_t g = (total + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    return (int)(g < (size_t)cap ? g : (size_t)cap);
+}
+
+void launch_conv2d_generic(const int8_t *in, int8_t *out, const ConvArgs &a, size_t batch, hipStream_t s) {
+    const size_t total = batch * a.OH * a.OW * a.N;
+    hipLaunchKernelGGL(conv2d_generic, dim3(grid_for(total)), dim3(256), 0, s, in, out, a, total);
+}
+void launch_dwconv_generic(const int8_t *in, int8_t *out, const ConvArgs &a, size_t batch, hipStream_t s) {
+    const size_t total = batch * a.OH * a.OW * a.N;
+    hipLaunchKernelGGL(dwconv_generic, dim3(grid_for(total)), dim3(256), 0, s, in, out, a, total);
+}
+void launch_avgpool_generic(const int8_t *in, int8_t *out, const PoolArgs &a, size_t batch, hipStream_t s) {
+    const size_t total = batch * a.OH * a.OW * a.C;
+    hipLaunchKernelGGL(avgpool_generic, dim3(grid_for(total)), dim3(256), 0, s, in, out, a, total);
+}
+void launch_fc_generic(const int8_t *in, int8_t *out, const FcArgs &a, size_t rows, hipStream_t s) {
+    const size_t total = rows * a.N;
+    hipLaunchKernelGGL(fc_generic, dim3(grid_for(total)), dim3(256), 0, s, in, out, a, total);
+}
+bool launch_fc_rowwave(const int8_t *in, int8_t *out, const FcArgs &a, size_t rows, hipStream_t s) {
+    const int grid = grid_for(rows, 4);
+    switch (a.N) {
+    case 1: hipLaunchKernelGGL(fc_rowwave<1>, dim3(grid), dim3(256), 0, s, in, out, a, rows); return true;
+    case 2: hipLaunchKernelGGL(fc_rowwave<2>, dim3(grid), dim3(256), 0, s, in, out, a, rows); return true;
+    case 4: hipLaunchKernelGGL(fc_rowwave<4>, dim3(grid), dim3(256), 0, s, in, out, a, rows); return true;
+    case 8: hipLaunchKernelGGL(fc_rowwave<8>, dim3(grid), dim3(256), 0, s, in, out, a, rows); return true;
+    default: return false;
+    }
+}
+void launch_softmax(const int8_t *in, int8_t *out, const SoftmaxArgs &a, size_t batch, hipStream_t s) {
+    hipLaunchKernelGGL(softmax_table, dim3(grid_for(batch)), dim3(256), 0, s, in, out, a, batch);
+}
+void launch_quantize(const float *in, int8_t *out, size_t n, float scale, float zp_f, hipStream_t s) {
+    hipLaunchKernelGGL(quantize_f32, dim3(grid_for((n + 3) / 4)), dim3(256), 0, s, in, out, n, scale, zp_f);
+}
+void launch_dequantize(const int8_t *in, float *out, size_t n, float scale, float zp_f, hipStream_t s) {
+    hipLaunchKernelGGL(dequantize_i8, dim3(grid_for(n)), dim3(256), 0, s, in, out, n, scale, zp_f);
+}
+void launch_synth(int8_t *out, size_t n, uint64_t seed, uint64_t first, hipStream_t s) {
+    hipLaunchKernelGGL(synth_i8, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, s, out, n, seed, first);
+}
+void launch_checksum(const int8_t *in, size_t n, unsigned long long *result, hipStream_t s) {
+    hipLaunchKernelGGL(checksum_i8, dim3(grid_for(n, 256 * 16, 1024)), dim3(256), 0, s, in, n, result);
+}
+
+// ---- fast-path dispatch tables ------------------------------------------------
+template <int H, int W, int C, int S, int G>
+static void launch_dw(const int8_t *in, int8_t *out, const DwFastArgs &a, int batch, hipStream_t s) {
+    constexpr int LP = C < 16 ? 16 : C;
+    constexpr int lds = G * (H + 2) * (LP + W * C + LP);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)dw3x3_nhwc<H, W, C, S, G>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set = true;
+    }
+    const int nsteps = (batch + G - 1) / G;
+    const int grid = nsteps < 256 * 4 ? nsteps : 256 * 4;
+    hipLaunchKernelGGL((dw3x3_nhwc<H, W, C, S, G>), dim3(grid), dim3(256), lds, s, in, out, a, batch);
+}
+
+const char *dw_fast_name(int H, int W, int C, int S) {
+#define MF_DW(h, w, c, s, g) \
+    if (H == h && W == w && C == c && S == s) return "dw3x3_nhwc<" #h "," #w "," #c "," #s "," #g ">";
+    MF_DW_SHAPES(MF_DW)
+#undef MF_DW
+    return nullptr;
+}
+bool launch_dw_fast(int H, int W, int C, int S, const int8_t *in, int8_t *out, const DwFastArgs &a,
+                    int batch, hipStream_t s) {
+#define MF_DW(h, w, c, st, g)                          \
+    if (H == h && W == w && C == c && S == st) {       \
+        launch_dw<h, w, c, st, g>(in, out, a, batch, s); \
+        return true;                                   \
+    }
+    MF_DW_SHAPES(MF_DW)
+#undef MF_DW
+    return false;
+}
+
+const char *dw_stem_name(int H, int W, int DM, int S) {
+    if (H == 96 && W == 96 && DM == 8 && S == 2) return "dw3x3_stem8<96,96,2>";
+    return nullptr;
+}
+bool launch_dw_stem(int H, int W, int DM, int S, const int8_t *in, int8_t *out, const DwStemArgs &a,
+                    int batch, hipStream_t s) {
+    if (H == 96 && W == 96 && DM == 8 && S == 2) {
+        constexpr int G = 2, lds = G * (96 + 2) * (16 + 96 + 16);
+        const int nsteps = (batch + G - 1) / G;
+        const int grid = nsteps < 256 * 4 ? nsteps : 256 * 4;
+        hipLaunchKernelGGL((dw3x3_stem8<96, 96, G>), dim3(grid), dim3(256), lds, s, in, out, a, batch);
+        return true;
+    }
+    return false;
+}
+
+const char *pw_name(int K, int N) {
+#define MF_PW(k, n) \
+    if (K == k && N == n) return "pw_mfma<" #k "," #n ">";
+    MF_PW_SHAPES(MF_PW)
+#undef MF_PW
+    return nullptr;
+}
+bool launch_pw(int K, int N, const int8_t *in, int8_t *out, const PwArgs &a, long long npix, hipStream_t s) {
+#define MF_PW(k, n)                                                                             \
+    if (K == k && N == n) {                                                                     \
+        constexpr int NB = n < 64 ? n : 64, SLOTS = 4 / (n / NB), CPIX = k < 64 ? 1024 / k : 16; \
+        const long long nchunks = (npix + CPIX - 1) / CPIX;                                     \
+        long long grid = (nchunks + SLOTS - 1) / SLOTS;                                         \
+        if (grid > 256 * 8) grid = 256 * 8;                                                     \
+        if (grid < 1) grid = 1;                                                                 \
+        hipLaunchKernelGGL((pw_mfma<k, n>), dim3((int)grid), dim3(256), 0, s, in, out, a, npix); \
+        return true;                                                                            \
+    }
+    MF_PW_SHAPES(MF_PW)
+#undef MF_PW
+    return false;
+}
+
+} // namespace k
+} // namespace mf

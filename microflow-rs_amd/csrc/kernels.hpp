@@ -1,0 +1,115 @@
+// kernels.hpp -- argument blocks and launchers of the HIP kernels (kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace mf {
+namespace k {
+
+// Per-channel folded epilogue constants live in HBM (tiny, L2-resident):
+//   A[c]  = fl32(f32(ozp) + c0[c])      S[c] = c1[c or 0]
+//   Kc[c] = -izp * sum_taps w[c] + T * izp * wzp[c]   (FC: c3 - c2[c])
+//   wzp[c] expanded to one int per channel
+// lo_f / hi_f: activation clamp merged with the int8 saturation, as floats.
+struct ConvArgs {
+    int H, W, C;        // input (per inference); for depthwise C = input channels
+    int N;              // output channels
+    int KH, KW, sh, sw, OH, OW;
+    int pad_same;
+    int izp;
+    float lo_f, hi_f;
+    const int8_t *w;    // conv [N][KH][KW][C]; depthwise [KH][KW][N]
+    const int *wzp;     // [N]
+    const float *A;     // [N]
+    const float *S;     // [N]
+    const int *Kc;      // [N]
+};
+struct PoolArgs {
+    int H, W, C, KH, KW, sh, sw, OH, OW, pad_same;
+    float c0, c1;
+    int lo, hi;
+};
+struct FcArgs {
+    int K, N;
+    int wzp;
+    float S;            // c1 (per-tensor weight scale only)
+    float lo_f, hi_f;
+    const int8_t *w;    // [N][K]
+    const float *A;     // [N]
+    const int *Kc;      // [N] = c3 - c2[j]
+};
+struct SoftmaxArgs {
+    int rows, cols;
+    float oscale, ozp_f;
+    const float *exp_table; // [256]: expf(f32(q) * input_scale), q = index - 128
+};
+struct DwFastArgs {
+    const int8_t *w;    // [3][3][C]
+    const float *A;
+    const float *S;
+    const int *Kc;
+    uint32_t izp4;      // izp replicated in 4 bytes
+    float lo_f, hi_f;
+};
+struct DwStemArgs {
+    uint32_t wrow[3][8]; // [ky][c] = bytes (w[ky][0][c], w[ky][1][c], w[ky][2][c], 0)
+    float A[8], S[8];
+    int Kc[8];
+    uint32_t izp4;
+    float lo_f, hi_f;
+};
+struct PwArgs {
+    const void *wprep;  // [blk][q][tile][kstep][lane] x 16 bytes, MFMA operand-A layout
+    const float *A;
+    const float *S;
+    const int *Kc;
+    float lo_f, hi_f;
+};
+
+// shapes with a compiled fast depthwise kernel: H, W, C, stride, images per step
+#define MF_DW_SHAPES(X) \
+    X(48, 48, 8, 1, 1)  \
+    X(48, 48, 16, 2, 1) \
+    X(24, 24, 32, 1, 1) \
+    X(24, 24, 32, 2, 1) \
+    X(12, 12, 64, 1, 2) \
+    X(12, 12, 64, 2, 2) \
+    X(6, 6, 128, 1, 4)  \
+    X(6, 6, 128, 2, 4)  \
+    X(3, 3, 256, 1, 8)
+
+// (K = input channels, N = output channels) with a compiled pointwise MFMA kernel
+#define MF_PW_SHAPES(X) \
+    X(8, 16)            \
+    X(16, 32)           \
+    X(32, 32)           \
+    X(32, 64)           \
+    X(64, 64)           \
+    X(64, 128)          \
+    X(128, 128)         \
+    X(128, 256)         \
+    X(256, 256)
+
+void launch_conv2d_generic(const int8_t *in, int8_t *out, const ConvArgs &a, size_t batch, hipStream_t s);
+void launch_dwconv_generic(const int8_t *in, int8_t *out, const ConvArgs &a, size_t batch, hipStream_t s);
+void launch_avgpool_generic(const int8_t *in, int8_t *out, const PoolArgs &a, size_t batch, hipStream_t s);
+void launch_fc_generic(const int8_t *in, int8_t *out, const FcArgs &a, size_t rows, hipStream_t s);
+bool launch_fc_rowwave(const int8_t *in, int8_t *out, const FcArgs &a, size_t rows, hipStream_t s);
+void launch_softmax(const int8_t *in, int8_t *out, const SoftmaxArgs &a, size_t batch, hipStream_t s);
+void launch_quantize(const float *in, int8_t *out, size_t n, float scale, float zp_f, hipStream_t s);
+void launch_dequantize(const int8_t *in, float *out, size_t n, float scale, float zp_f, hipStream_t s);
+void launch_synth(int8_t *out, size_t n, uint64_t seed, uint64_t first, hipStream_t s);
+void launch_checksum(const int8_t *in, size_t n, unsigned long long *result, hipStream_t s);
+
+const char *dw_fast_name(int H, int W, int C, int S);
+bool launch_dw_fast(int H, int W, int C, int S, const int8_t *in, int8_t *out, const DwFastArgs &a,
+                    int batch, hipStream_t s);
+const char *dw_stem_name(int H, int W, int DM, int S);
+bool launch_dw_stem(int H, int W, int DM, int S, const int8_t *in, int8_t *out, const DwStemArgs &a,
+                    int batch, hipStream_t s);
+const char *pw_name(int K, int N);
+bool launch_pw(int K, int N, const int8_t *in, int8_t *out, const PwArgs &a, long long npix, hipStream_t s);
+
+} // namespace k
+} // namespace mf

@@ -1,0 +1,127 @@
+// mf_internal.hpp -- internal declarations of libmicroflow_amd.so (not part of the ABI).
+//
+// Layering:
+//   capi.cpp      extern "C" boundary (include/microflow_amd.h), error translation
+//   model.cpp     .tflite -> ParsedModel -> prepared device ops -> launch sequence
+//   tflite.cpp    minimal FlatBuffers reader for the ~10 TFLite tables the path needs
+//   hostmath.cpp  f32 constant preparation in the reference's evaluation order
+//   ops.hip       prepared operators: constant folding, kernel routing, launches
+//   kernels.hip   the HIP kernels (gfx950)
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/microflow_amd.h"
+
+namespace mf {
+
+struct Error {
+    int code;
+    std::string msg;
+};
+[[noreturn]] void fail(int code, const std::string &msg);
+void set_last_error(const std::string &msg);
+
+// ---- host numerics (hostmath.cpp) --------------------------------------
+// All individually rounded f32 operations; this translation unit is compiled
+// with -ffp-contract=off.
+float h_roundf(float x);                              // round half away from zero
+float h_expf(float x);                                // libm 0.2 (musl-derived) expf
+int8_t h_sat_i8(float x);                             // Rust `as i8`
+int8_t h_quantize(float x, float scale, int8_t zp);   // src/quantize.rs:16-18
+void h_preprocess_fc(float iscale, int8_t izp, int in_shape1, const int8_t *w, int K, int N,
+                     float wscale, int8_t wzp, const int32_t *bias, float bscale, int32_t bzp,
+                     float oscale, float *c0, float *c1, int32_t *c2, int32_t *c3);
+void h_preprocess_conv(float iscale, int n, const int32_t *bias, const float *bscale,
+                       const int32_t *bzp, int nbq, const float *fscale, int nfq, float oscale,
+                       float *c0, float *c1);
+void h_preprocess_pool(float iscale, int8_t izp, float oscale, int8_t ozp, float *c0, float *c1);
+
+// ---- parsed model (tflite.cpp) -------------------------------------------
+struct ParsedOp {
+    int kind = 0;
+    int in_rank = 0, in_shape[4] = {0, 0, 0, 0};
+    int out_rank = 0, out_shape[4] = {0, 0, 0, 0};
+    int KH = 0, KW = 0, sh = 0, sw = 0, pad = 0, act = 0;
+    float in_scale = 0, out_scale = 0;
+    int in_zp = 0, out_zp = 0;
+    size_t in_elems = 0, out_elems = 0;
+    // geometry
+    int H = 0, W = 0, C = 0; // conv/dw/pool input
+    int N = 0;               // conv filters / dw channels / fc outputs / softmax cols
+    int M = 0, K = 0;        // fc rows / depth; softmax rows = M
+    int OH = 0, OW = 0;
+    std::vector<int8_t> weights; // fc [N][K]; conv [N][KH][KW][C]; dw [KH][KW][N]
+    std::vector<int8_t> wzp;     // weight zero points (1 or per channel)
+    std::vector<float> c0, c1;
+    std::vector<int32_t> c2;
+    int32_t c3 = 0;
+};
+struct ParsedModel {
+    int in_rank = 0, in_shape[4] = {0, 0, 0, 0};
+    int out_rank = 0, out_shape[4] = {0, 0, 0, 0};
+    float in_scale = 0, out_scale = 0;
+    int in_zp = 0, out_zp = 0;
+    size_t in_elems = 0, out_elems = 0, max_elems = 0;
+    std::vector<ParsedOp> ops;
+};
+ParsedModel parse_tflite(const uint8_t *buf, size_t len);
+
+// ---- prepared device operator (ops.hip) ------------------------------------
+struct OpImpl; // device buffers + kernel routing
+struct OpSpec {
+    int kind = 0;
+    int M = 0, K = 0, N = 0;
+    int H = 0, W = 0, C = 0, KH = 0, KW = 0, sh = 1, sw = 1, pad = 0, OH = 0, OW = 0;
+    int act = 0;
+    int izp = 0;             // zero point of the running input tensor
+    float in_scale = 0;      // softmax only
+    float oscale = 0;
+    int ozp = 0;
+    const int8_t *weights = nullptr;
+    const int8_t *wzp = nullptr;
+    int nq = 0;
+    const float *c0 = nullptr;
+    const float *c1 = nullptr;
+    int nc1 = 0;
+    const int32_t *c2 = nullptr;
+    int32_t c3 = 0;
+    float pool_c0 = 0, pool_c1 = 0;
+};
+OpImpl *op_create(int device, const OpSpec &spec);
+void op_destroy(OpImpl *op);
+void op_run(OpImpl *op, const int8_t *d_in, size_t batch, int8_t *d_out, void *stream);
+size_t op_in_elems(const OpImpl *op);
+size_t op_out_elems(const OpImpl *op);
+const char *op_kernel_name(const OpImpl *op);
+void op_set_generic(OpImpl *op, bool generic);
+
+void dev_quantize(int device, const float *d_in, size_t n, float scale, int8_t zp, int8_t *d_out,
+                  void *stream);
+void dev_dequantize(int device, const int8_t *d_in, size_t n, float scale, int8_t zp, float *d_out,
+                    void *stream);
+void dev_synth_i8(int device, uint64_t seed, uint64_t first, size_t n, int8_t *d_out, void *stream);
+uint64_t dev_checksum_i8(int device, const int8_t *d_in, size_t n, void *stream);
+int dev_count();
+void dev_require(int device); // throws MF_ERR_NO_DEVICE
+
+// ---- model runtime (model.cpp) ----------------------------------------------
+struct ModelImpl;
+ModelImpl *model_create(const uint8_t *buf, size_t len);
+void model_destroy(ModelImpl *m);
+const ParsedModel &model_parsed(const ModelImpl *m);
+const char *model_op_kernel(const ModelImpl *m, int i);
+void model_prepare(ModelImpl *m, int device, size_t max_batch);
+void model_set_stream(ModelImpl *m, void *stream);
+void model_sync(ModelImpl *m);
+void model_set_generic(ModelImpl *m, bool generic);
+// in_f32 or in_i8 (exactly one non-null); out_f32 or out_i8 (exactly one non-null)
+void model_run(ModelImpl *m, const float *in_f32, const int8_t *in_i8, size_t batch,
+               float *out_f32, int8_t *out_i8, int mem, int last_op);
+void model_time_device(ModelImpl *m, const int8_t *d_in, size_t batch, int8_t *d_out, int warmup,
+                       int iters, float *avg_ms, float *per_op_ms);
+
+} // namespace mf

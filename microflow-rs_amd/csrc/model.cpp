@@ -1,0 +1,273 @@
+// model.cpp -- the runtime half of what #[model("x.tflite")] generates
+// (microflow-macros/src/lib.rs:185-203): predict / predict_quantized /
+// predict_inner over a BATCH of independent inferences.
+//
+// Device memory plan (sized for 288 GB of HBM, no reuse tricks needed):
+//   weights + folded constants : resident per op (person_detect: ~0.3 MB)
+//   act[0], act[1]             : ping-pong activation buffers, batch x max tensor bytes
+//   in_q / io_f32              : staging for host-fed batches
+// Every op reads one buffer and writes the other; Reshape is an alias (the 2D<->4D
+// maps of src/tensor.rs:103-141 are the identity in NHWC memory).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "mf_internal.hpp"
+
+namespace mf {
+
+#define MF_HIP(call)                                                                          \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            fail(e_ == hipErrorOutOfMemory ? MF_ERR_OOM : MF_ERR_HIP,                         \
+                 std::string(#call) + ": " + hipGetErrorString(e_));                          \
+    } while (0)
+
+struct ModelImpl {
+    ParsedModel pm;
+    int device = -1;
+    bool prepared = false;
+    bool generic = false;
+    hipStream_t stream = nullptr;
+    std::vector<OpImpl *> ops; // nullptr for Reshape
+    size_t cap_batch = 0;
+    int8_t *act[2] = {nullptr, nullptr};
+    int8_t *in_q = nullptr;   // quantized input staging (host-fed or f32 path)
+    float *io_f32 = nullptr;  // f32 input / output staging
+    size_t io_f32_elems = 0;
+
+    ~ModelImpl() {
+        if (device >= 0) (void)hipSetDevice(device);
+        for (OpImpl *o : ops) op_destroy(o);
+        free_buffers();
+    }
+    void free_buffers() {
+        for (auto &p : act) {
+            if (p) (void)hipFree(p);
+            p = nullptr;
+        }
+        if (in_q) (void)hipFree(in_q);
+        if (io_f32) (void)hipFree(io_f32);
+        in_q = nullptr;
+        io_f32 = nullptr;
+        cap_batch = 0;
+    }
+};
+
+ModelImpl *model_create(const uint8_t *buf, size_t len) {
+    std::unique_ptr<ModelImpl> m(new ModelImpl);
+    m->pm = parse_tflite(buf, len);
+    return m.release();
+}
+void model_destroy(ModelImpl *m) { delete m; }
+const ParsedModel &model_parsed(const ModelImpl *m) { return m->pm; }
+const char *model_op_kernel(const ModelImpl *m, int i) {
+    if (!m->prepared || i < 0 || i >= (int)m->ops.size() || !m->ops[i]) return "";
+    return op_kernel_name(m->ops[i]);
+}
+
+static void ensure_capacity(ModelImpl *m, size_t batch) {
+    if (batch <= m->cap_batch) return;
+    MF_HIP(hipSetDevice(m->device));
+    MF_HIP(hipStreamSynchronize(m->stream));
+    m->free_buffers();
+    const ParsedModel &pm = m->pm;
+    const size_t act_bytes = ((batch * pm.max_elems + 255) / 256) * 256 + 256;
+    for (auto &p : m->act) MF_HIP(hipMalloc((void **)&p, act_bytes));
+    MF_HIP(hipMalloc((void **)&m->in_q, ((batch * pm.in_elems + 255) / 256) * 256 + 256));
+    m->io_f32_elems = batch * std::max(pm.in_elems, pm.out_elems);
+    MF_HIP(hipMalloc((void **)&m->io_f32, m->io_f32_elems * sizeof(float) + 256));
+    m->cap_batch = batch;
+}
+
+void model_prepare(ModelImpl *m, int device, size_t max_batch) {
+    dev_require(device);
+    if (m->prepared && m->device != device)
+        fail(MF_ERR_INVALID_ARG, "model already prepared on another device");
+    m->device = device;
+    if (!m->prepared) {
+        // predict_inner's running tensor: every op stamps its output scale / zero point on
+        // it (Tensor::new(output, output_scale, output_zero_point)); Reshape keeps them.
+        float cur_scale = m->pm.in_scale;
+        int cur_zp = m->pm.in_zp;
+        for (const ParsedOp &po : m->pm.ops) {
+            if (po.kind == MF_OP_RESHAPE) {
+                m->ops.push_back(nullptr);
+                continue;
+            }
+            OpSpec s;
+            s.kind = po.kind;
+            s.M = po.M, s.K = po.K, s.N = po.N;
+            s.H = po.H, s.W = po.W, s.C = po.C, s.KH = po.KH, s.KW = po.KW;
+            s.sh = po.sh ? po.sh : 1, s.sw = po.sw ? po.sw : 1, s.pad = po.pad;
+            s.OH = po.OH, s.OW = po.OW, s.act = po.act;
+            s.izp = cur_zp;          // input.zero_point[0] of the running tensor (conv_2d.rs:56)
+            s.in_scale = cur_scale;  // input.scale[0] of the running tensor (softmax.rs:20)
+            s.oscale = po.out_scale, s.ozp = po.out_zp;
+            s.weights = po.weights.empty() ? nullptr : po.weights.data();
+            s.wzp = po.wzp.empty() ? nullptr : po.wzp.data();
+            s.nq = (int)po.wzp.size();
+            s.c0 = po.c0.empty() ? nullptr : po.c0.data();
+            s.c1 = po.c1.empty() ? nullptr : po.c1.data();
+            s.nc1 = (int)po.c1.size();
+            s.c2 = po.c2.empty() ? nullptr : po.c2.data();
+            s.c3 = po.c3;
+            if (po.kind == MF_OP_AVERAGE_POOL_2D) s.pool_c0 = po.c0[0], s.pool_c1 = po.c1[0];
+            m->ops.push_back(op_create(device, s));
+            cur_scale = po.out_scale;
+            cur_zp = po.out_zp;
+        }
+        m->prepared = true;
+        model_set_generic(m, m->generic);
+    }
+    if (max_batch) ensure_capacity(m, max_batch);
+}
+
+void model_set_stream(ModelImpl *m, void *stream) { m->stream = (hipStream_t)stream; }
+
+void model_sync(ModelImpl *m) {
+    if (!m->prepared) return;
+    MF_HIP(hipSetDevice(m->device));
+    MF_HIP(hipStreamSynchronize(m->stream));
+}
+
+void model_set_generic(ModelImpl *m, bool generic) {
+    m->generic = generic;
+    for (OpImpl *o : m->ops)
+        if (o) op_set_generic(o, generic);
+}
+
+// run ops [0..last_op] reading from `src`; returns the buffer holding the result
+static const int8_t *run_ops(ModelImpl *m, const int8_t *src, size_t batch, int last_op) {
+    const int8_t *cur = src;
+    int which = 0;
+    for (int i = 0; i <= last_op; ++i) {
+        OpImpl *o = m->ops[i];
+        if (!o) continue; // Reshape: alias
+        int8_t *dst = m->act[which];
+        if (dst == cur) {
+            which ^= 1;
+            dst = m->act[which];
+        }
+        op_run(o, cur, batch, dst, m->stream);
+        cur = dst;
+        which ^= 1;
+    }
+    return cur;
+}
+
+void model_run(ModelImpl *m, const float *in_f32, const int8_t *in_i8, size_t batch, float *out_f32,
+               int8_t *out_i8, int mem, int last_op) {
+    if (!m->prepared) fail(MF_ERR_INVALID_ARG, "model not prepared: call mf_model_prepare first");
+    if ((in_f32 == nullptr) == (in_i8 == nullptr) || (out_f32 == nullptr) == (out_i8 == nullptr))
+        fail(MF_ERR_INVALID_ARG, "null buffer");
+    if (mem != MF_MEM_HOST && mem != MF_MEM_DEVICE) fail(MF_ERR_INVALID_ARG, "bad mem kind");
+    const ParsedModel &pm = m->pm;
+    const int nops = (int)pm.ops.size();
+    if (last_op < 0) last_op = nops - 1;
+    if (last_op >= nops) fail(MF_ERR_INVALID_ARG, "op index out of range");
+    if (!batch) return;
+    MF_HIP(hipSetDevice(m->device));
+    ensure_capacity(m, batch);
+    const size_t out_elems = last_op == nops - 1 ? pm.out_elems : pm.ops[last_op].out_elems;
+    const bool host = mem == MF_MEM_HOST;
+    hipStream_t s = m->stream;
+
+    // ---- input ----
+    const int8_t *q_in;
+    if (in_f32) { // Tensor::quantize(input, scale, zero_point)  (lib.rs:189)
+        const float *d_f = in_f32;
+        if (host) {
+            MF_HIP(hipMemcpyAsync(m->io_f32, in_f32, batch * pm.in_elems * sizeof(float),
+                                  hipMemcpyHostToDevice, s));
+            d_f = m->io_f32;
+        }
+        dev_quantize(m->device, d_f, batch * pm.in_elems, pm.in_scale, (int8_t)pm.in_zp, m->in_q, s);
+        q_in = m->in_q;
+    } else if (host) {
+        MF_HIP(hipMemcpyAsync(m->in_q, in_i8, batch * pm.in_elems, hipMemcpyHostToDevice, s));
+        q_in = m->in_q;
+    } else {
+        q_in = in_i8; // device-resident batch: consumed in place
+    }
+
+    // ---- predict_inner ----
+    const int8_t *res = run_ops(m, q_in, batch, last_op);
+
+    // ---- output ----
+    if (out_i8) {
+        MF_HIP(hipMemcpyAsync(out_i8, res, batch * out_elems, host ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, s));
+    } else { // .dequantize()  (lib.rs:190) with the parameters the last op stamped on the tensor
+        float oscale = pm.out_scale;
+        int ozp = pm.out_zp;
+        if (last_op != nops - 1) oscale = pm.ops[last_op].out_scale, ozp = pm.ops[last_op].out_zp;
+        float *d_o = host ? m->io_f32 : out_f32;
+        dev_dequantize(m->device, res, batch * out_elems, oscale, (int8_t)ozp, d_o, s);
+        if (host)
+            MF_HIP(hipMemcpyAsync(out_f32, m->io_f32, batch * out_elems * sizeof(float),
+                                  hipMemcpyDeviceToHost, s));
+    }
+    if (host) MF_HIP(hipStreamSynchronize(s));
+}
+
+void model_time_device(ModelImpl *m, const int8_t *d_in, size_t batch, int8_t *d_out, int warmup,
+                       int iters, float *avg_ms, float *per_op_ms) {
+    if (!m->prepared) fail(MF_ERR_INVALID_ARG, "model not prepared");
+    if (iters <= 0 || !batch) fail(MF_ERR_INVALID_ARG, "iters and batch must be positive");
+    MF_HIP(hipSetDevice(m->device));
+    ensure_capacity(m, batch);
+    const int nops = (int)m->pm.ops.size();
+    hipStream_t s = m->stream;
+    hipEvent_t e0, e1;
+    MF_HIP(hipEventCreate(&e0));
+    MF_HIP(hipEventCreate(&e1));
+    for (int i = 0; i < warmup; ++i) model_run(m, nullptr, d_in, batch, nullptr, d_out, MF_MEM_DEVICE, -1);
+    MF_HIP(hipEventRecord(e0, s));
+    for (int i = 0; i < iters; ++i) model_run(m, nullptr, d_in, batch, nullptr, d_out, MF_MEM_DEVICE, -1);
+    MF_HIP(hipEventRecord(e1, s));
+    MF_HIP(hipEventSynchronize(e1));
+    float ms = 0;
+    MF_HIP(hipEventElapsedTime(&ms, e0, e1));
+    if (avg_ms) *avg_ms = ms / (float)iters;
+
+    if (per_op_ms) { // second sweep: one event pair per op, on the same stream
+        std::vector<hipEvent_t> ev((size_t)nops + 1);
+        for (auto &e : ev) MF_HIP(hipEventCreate(&e));
+        std::vector<double> acc((size_t)nops, 0.0);
+        for (int it = 0; it < iters; ++it) {
+            const int8_t *cur = d_in;
+            int which = 0;
+            MF_HIP(hipEventRecord(ev[0], s));
+            for (int i = 0; i < nops; ++i) {
+                OpImpl *o = m->ops[i];
+                if (o) {
+                    int8_t *dst = m->act[which];
+                    if (dst == cur) {
+                        which ^= 1;
+                        dst = m->act[which];
+                    }
+                    op_run(o, cur, batch, dst, s);
+                    cur = dst;
+                    which ^= 1;
+                }
+                MF_HIP(hipEventRecord(ev[(size_t)i + 1], s));
+            }
+            MF_HIP(hipEventSynchronize(ev[(size_t)nops]));
+            for (int i = 0; i < nops; ++i) {
+                float t = 0;
+                MF_HIP(hipEventElapsedTime(&t, ev[(size_t)i], ev[(size_t)i + 1]));
+                acc[(size_t)i] += t;
+            }
+        }
+        for (int i = 0; i < nops; ++i) per_op_ms[i] = (float)(acc[(size_t)i] / iters);
+        for (auto &e : ev) (void)hipEventDestroy(e);
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+}
+
+} // namespace mf

@@ -1,0 +1,389 @@
+// ops.hip -- prepared operators: fold the reference's constants into the
+// per-channel device arrays the kernels consume, pick a kernel for the shape,
+// launch.  Host code only (HIP runtime API); the kernels are in kernels.hip.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "kernels.hpp"
+#include "mf_internal.hpp"
+
+namespace mf {
+
+#define MF_HIP(call)                                                                          \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            fail(e_ == hipErrorOutOfMemory ? MF_ERR_OOM : MF_ERR_HIP,                         \
+                 std::string(#call) + ": " + hipGetErrorString(e_));                          \
+    } while (0)
+
+int dev_count() {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+void dev_require(int device) {
+    const int n = dev_count();
+    if (n <= 0)
+        fail(MF_ERR_NO_DEVICE, "no HIP device available: libmicroflow_amd has no CPU fallback");
+    if (device < 0 || device >= n)
+        fail(MF_ERR_INVALID_ARG, "device index " + std::to_string(device) + " out of range (" +
+                                     std::to_string(n) + " devices)");
+    MF_HIP(hipSetDevice(device));
+}
+
+namespace {
+
+inline int32_t wrap_add(int32_t a, int32_t b) { return (int32_t)((uint32_t)a + (uint32_t)b); }
+inline int32_t wrap_sub(int32_t a, int32_t b) { return (int32_t)((uint32_t)a - (uint32_t)b); }
+inline int32_t wrap_mul(int32_t a, int32_t b) { return (int32_t)((uint32_t)a * (uint32_t)b); }
+
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() {
+        if (p) (void)hipFree(p);
+    }
+    void upload(const void *src, size_t bytes) {
+        if (p) {
+            (void)hipFree(p);
+            p = nullptr;
+        }
+        if (!bytes) return;
+        MF_HIP(hipMalloc(&p, bytes));
+        MF_HIP(hipMemcpy(p, src, bytes, hipMemcpyHostToDevice));
+    }
+    template <typename T> const T *as() const { return (const T *)p; }
+};
+
+// activation + int8 saturation as one clamp [lo, hi]  (src/activation.rs:21-34)
+void act_bounds(int act, float oscale, int ozp, int &lo, int &hi) {
+    lo = -128;
+    hi = 127;
+    if (act == MF_ACT_RELU || act == MF_ACT_RELU6) lo = ozp;        // max(y, zero_point)
+    if (act == MF_ACT_RELU6) hi = h_quantize(6.0f, oscale, (int8_t)ozp); // min(.., quantize(6.0))
+    if (lo > hi) lo = hi; // min(max(y, lo), hi) == hi for every y when lo > hi
+}
+
+} // namespace
+
+struct OpImpl {
+    int device = 0;
+    OpSpec s; // pointers inside are NOT valid after create
+    size_t in_elems = 0, out_elems = 0;
+    bool force_generic = false;
+    std::string generic_name, fast_name;
+    enum Fast { NONE, DW_NHWC, DW_STEM, PW_MFMA, FC_ROWWAVE } fast = NONE;
+
+    DevBuf d_w, d_wzp, d_A, d_S, d_Kc, d_wprep, d_table;
+    k::ConvArgs conv{};
+    k::PoolArgs pool{};
+    k::FcArgs fc{};
+    k::SoftmaxArgs sm{};
+    k::DwFastArgs dwf{};
+    k::DwStemArgs stem{};
+    k::PwArgs pw{};
+};
+
+namespace {
+
+// per-channel A/S/Kc/wzp arrays for the conv-like operators
+void fold_conv_constants(OpImpl &op, const OpSpec &s, bool depthwise, std::vector<float> &A,
+                         std::vector<float> &S, std::vector<int32_t> &Kc,
+                         std::vector<int32_t> &wzp) {
+    const int N = s.N;
+    const int taps = s.KH * s.KW;
+    A.resize(N), S.resize(N), Kc.resize(N), wzp.resize(N);
+    for (int c = 0; c < N; ++c) {
+        volatile float a = (float)s.ozp + s.c0[c]; // f32(ozp) + c0[c], rounded once, as the reference does first
+        A[c] = a;
+        S[c] = s.c1[c < s.nc1 ? c : 0];            // constants.1.get(b).unwrap_or(constants.1[0])
+        wzp[c] = s.wzp[c < s.nq ? c : 0];          // zero_point.get(b).unwrap_or(zero_point[0])
+        int32_t wsum = 0;
+        int32_t T;
+        if (depthwise) { // weights [KH][KW][N]
+            for (int t = 0; t < taps; ++t) wsum = wrap_add(wsum, s.weights[(size_t)t * N + c]);
+            T = taps;
+        } else { // filters [N][KH][KW][C]
+            const int8_t *f = s.weights + (size_t)c * taps * s.C;
+            for (int t = 0; t < taps * s.C; ++t) wsum = wrap_add(wsum, f[t]);
+            T = taps * s.C;
+        }
+        // Kc = -izp * sum(w) + T * izp * wzp   (k2 and k3 of the reference with the halo == izp)
+        Kc[c] = wrap_add(wrap_sub(0, wrap_mul(s.izp, wsum)), wrap_mul(wrap_mul(T, s.izp), wzp[c]));
+    }
+    (void)op;
+}
+
+bool all_zero(const std::vector<int32_t> &v) {
+    return std::all_of(v.begin(), v.end(), [](int32_t x) { return x == 0; });
+}
+
+// operand A of v_mfma_i32_16x16x64_i8 for pw_mfma<K,N>: [blk][q][tt][ks][lane][16 bytes]
+std::vector<int8_t> build_pw_weights(const int8_t *w /*[N][K]*/, int K, int N) {
+    const int NB = N < 64 ? N : 64, TB = NB / 16, NSPLIT = N / NB;
+    const int KS = K < 64 ? 1 : K / 64, Q = K < 64 ? 64 / K : 1;
+    std::vector<int8_t> out((size_t)NSPLIT * Q * TB * KS * 64 * 16, 0);
+    for (int blk = 0; blk < NSPLIT; ++blk)
+        for (int q = 0; q < Q; ++q)
+            for (int tt = 0; tt < TB; ++tt)
+                for (int ks = 0; ks < KS; ++ks)
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int r = lane & 15, g = lane >> 4; // A row, k-block of this lane
+                        // row r = 4*gr + j of tile tt is channel base + gr*(NB/4) + 4*tt + j
+                        const int gr = r >> 2, j = r & 3;
+                        const int ch = blk * NB + gr * (NB / 4) + 4 * tt + j;
+                        int8_t *dst = &out[(((((size_t)blk * Q + q) * TB + tt) * KS + ks) * 64 + lane) * 16];
+                        for (int i = 0; i < 16; ++i) {
+                            int k = -1;
+                            if (K >= 64) k = ks * 64 + g * 16 + i;
+                            else if (K == 32) k = ((g >> 1) == q) ? (g & 1) * 16 + i : -1;
+                            else if (K == 16) k = (g == q) ? i : -1;
+                            else if (K == 8) k = (g == (q >> 1) && (i >> 3) == (q & 1)) ? (i & 7) : -1;
+                            dst[i] = k >= 0 ? w[(size_t)ch * K + k] : (int8_t)0;
+                        }
+                    }
+    return out;
+}
+
+} // namespace
+
+OpImpl *op_create(int device, const OpSpec &s) {
+    dev_require(device);
+    std::unique_ptr<OpImpl> op(new OpImpl);
+    op->device = device;
+    op->s = s;
+    int lo, hi;
+    act_bounds(s.act, s.oscale, s.ozp, lo, hi);
+
+    switch (s.kind) {
+    case MF_OP_CONV_2D:
+    case MF_OP_DEPTHWISE_CONV_2D: {
+        const bool dw = s.kind == MF_OP_DEPTHWISE_CONV_2D;
+        if (s.H <= 0 || s.W <= 0 || s.C <= 0 || s.N <= 0 || s.KH <= 0 || s.KW <= 0 || s.OH <= 0 ||
+            s.OW <= 0 || s.sh <= 0 || s.sw <= 0 || s.nq <= 0 || s.nc1 <= 0 || !s.weights || !s.wzp ||
+            !s.c0 || !s.c1)
+            fail(MF_ERR_INVALID_ARG, "conv: bad arguments");
+        if (s.pad == MF_PAD_VALID &&
+            ((s.OH - 1) * s.sh + s.KH > s.H || (s.OW - 1) * s.sw + s.KW > s.W))
+            fail(MF_ERR_INVALID_ARG, "conv: VALID view leaves the input (the reference would panic, src/tensor.rs:223)");
+        op->in_elems = (size_t)s.H * s.W * s.C;
+        op->out_elems = (size_t)s.OH * s.OW * s.N;
+        std::vector<float> A, S;
+        std::vector<int32_t> Kc, wzp;
+        fold_conv_constants(*op, s, dw, A, S, Kc, wzp);
+        const size_t wbytes = dw ? (size_t)s.KH * s.KW * s.N : (size_t)s.N * s.KH * s.KW * s.C;
+        op->d_w.upload(s.weights, wbytes);
+        op->d_wzp.upload(wzp.data(), wzp.size() * 4);
+        op->d_A.upload(A.data(), A.size() * 4);
+        op->d_S.upload(S.data(), S.size() * 4);
+        op->d_Kc.upload(Kc.data(), Kc.size() * 4);
+        k::ConvArgs &a = op->conv;
+        a.H = s.H, a.W = s.W, a.C = s.C, a.N = s.N, a.KH = s.KH, a.KW = s.KW, a.sh = s.sh, a.sw = s.sw;
+        a.OH = s.OH, a.OW = s.OW, a.pad_same = s.pad == MF_PAD_SAME, a.izp = s.izp;
+        a.lo_f = (float)lo, a.hi_f = (float)hi;
+        a.w = op->d_w.as<int8_t>(), a.wzp = op->d_wzp.as<int>(), a.A = op->d_A.as<float>();
+        a.S = op->d_S.as<float>(), a.Kc = op->d_Kc.as<int>();
+        op->generic_name = dw ? "dwconv_generic" : "conv2d_generic";
+
+        const bool zero_wzp = all_zero(wzp);
+        const bool same3x3 = s.KH == 3 && s.KW == 3 && s.pad == MF_PAD_SAME && s.sh == s.sw &&
+                             s.OH == (s.H + s.sh - 1) / s.sh && s.OW == (s.W + s.sw - 1) / s.sw;
+        if (dw && zero_wzp && same3x3 && s.C == s.N && k::dw_fast_name(s.H, s.W, s.C, s.sh)) {
+            op->fast = OpImpl::DW_NHWC;
+            op->fast_name = k::dw_fast_name(s.H, s.W, s.C, s.sh);
+            k::DwFastArgs &f = op->dwf;
+            f.w = a.w, f.A = a.A, f.S = a.S, f.Kc = a.Kc;
+            f.izp4 = 0x01010101u * (uint32_t)(uint8_t)(int8_t)s.izp;
+            f.lo_f = a.lo_f, f.hi_f = a.hi_f;
+        } else if (dw && zero_wzp && same3x3 && s.C == 1 && k::dw_stem_name(s.H, s.W, s.N, s.sh)) {
+            op->fast = OpImpl::DW_STEM;
+            op->fast_name = k::dw_stem_name(s.H, s.W, s.N, s.sh);
+            k::DwStemArgs &f = op->stem;
+            for (int ky = 0; ky < 3; ++ky)
+                for (int c = 0; c < 8; ++c) {
+                    uint32_t d = 0;
+                    for (int kx = 0; kx < 3; ++kx)
+                        d |= (uint32_t)(uint8_t)s.weights[((size_t)ky * 3 + kx) * s.N + c] << (8 * kx);
+                    f.wrow[ky][c] = d;
+                }
+            for (int c = 0; c < 8; ++c) f.A[c] = A[c], f.S[c] = S[c], f.Kc[c] = Kc[c];
+            f.izp4 = 0x01010101u * (uint32_t)(uint8_t)(int8_t)s.izp;
+            f.lo_f = a.lo_f, f.hi_f = a.hi_f;
+        } else if (!dw && zero_wzp && s.KH == 1 && s.KW == 1 && s.sh == 1 && s.sw == 1 &&
+                   s.OH == s.H && s.OW == s.W && k::pw_name(s.C, s.N) &&
+                   (s.C != 8 || ((s.H * s.W) % 2 == 0))) {
+            op->fast = OpImpl::PW_MFMA;
+            op->fast_name = k::pw_name(s.C, s.N);
+            const std::vector<int8_t> prep = build_pw_weights(s.weights, s.C, s.N);
+            op->d_wprep.upload(prep.data(), prep.size());
+            k::PwArgs &f = op->pw;
+            f.wprep = op->d_wprep.p, f.A = a.A, f.S = a.S, f.Kc = a.Kc;
+            f.lo_f = a.lo_f, f.hi_f = a.hi_f;
+        }
+        break;
+    }
+    case MF_OP_AVERAGE_POOL_2D: {
+        if (s.H <= 0 || s.W <= 0 || s.C <= 0 || s.KH <= 0 || s.KW <= 0 || s.OH <= 0 || s.OW <= 0 ||
+            s.sh <= 0 || s.sw <= 0)
+            fail(MF_ERR_INVALID_ARG, "average_pool_2d: bad arguments");
+        if (s.pad == MF_PAD_VALID &&
+            ((s.OH - 1) * s.sh + s.KH > s.H || (s.OW - 1) * s.sw + s.KW > s.W))
+            fail(MF_ERR_INVALID_ARG, "average_pool_2d: VALID view leaves the input");
+        op->in_elems = (size_t)s.H * s.W * s.C;
+        op->out_elems = (size_t)s.OH * s.OW * s.C;
+        k::PoolArgs &a = op->pool;
+        a.H = s.H, a.W = s.W, a.C = s.C, a.KH = s.KH, a.KW = s.KW, a.sh = s.sh, a.sw = s.sw;
+        a.OH = s.OH, a.OW = s.OW, a.pad_same = s.pad == MF_PAD_SAME;
+        a.c0 = s.pool_c0, a.c1 = s.pool_c1, a.lo = lo, a.hi = hi;
+        op->generic_name = "avgpool_generic";
+        break;
+    }
+    case MF_OP_FULLY_CONNECTED: {
+        if (s.M <= 0 || s.K <= 0 || s.N <= 0 || !s.weights || !s.c0 || !s.c2)
+            fail(MF_ERR_INVALID_ARG, "fully_connected: bad arguments");
+        op->in_elems = (size_t)s.M * s.K;
+        op->out_elems = (size_t)s.M * s.N;
+        std::vector<float> A(s.N);
+        std::vector<int32_t> Kc(s.N);
+        for (int j = 0; j < s.N; ++j) {
+            volatile float a = (float)s.ozp + s.c0[j];
+            A[j] = a;
+            Kc[j] = wrap_sub(s.c3, s.c2[j]); // acc = x0 - x1 - c2[j] + c3
+        }
+        op->d_w.upload(s.weights, (size_t)s.N * s.K);
+        op->d_A.upload(A.data(), A.size() * 4);
+        op->d_Kc.upload(Kc.data(), Kc.size() * 4);
+        k::FcArgs &a = op->fc;
+        a.K = s.K, a.N = s.N, a.wzp = s.wzp ? s.wzp[0] : 0, a.S = s.c1[0];
+        a.lo_f = (float)lo, a.hi_f = (float)hi;
+        a.w = op->d_w.as<int8_t>(), a.A = op->d_A.as<float>(), a.Kc = op->d_Kc.as<int>();
+        op->generic_name = "fc_generic";
+        if (s.K % 16 == 0 && s.K >= 256 && (s.N == 1 || s.N == 2 || s.N == 4 || s.N == 8)) {
+            op->fast = OpImpl::FC_ROWWAVE;
+            op->fast_name = "fc_rowwave<" + std::to_string(s.N) + ">";
+        }
+        break;
+    }
+    case MF_OP_SOFTMAX: {
+        if (s.M <= 0 || s.N <= 0) fail(MF_ERR_INVALID_ARG, "softmax: bad arguments");
+        op->in_elems = op->out_elems = (size_t)s.M * s.N;
+        // exp table over the 256 possible int8 inputs: expf(f32(q) * input.scale[0])
+        // (src/ops/softmax.rs:20-21), libm's algorithm evaluated on the host
+        std::vector<float> table(256);
+        for (int q = -128; q <= 127; ++q) {
+            volatile float e = (float)q * s.in_scale;
+            table[q + 128] = h_expf(e);
+        }
+        op->d_table.upload(table.data(), 256 * 4);
+        k::SoftmaxArgs &a = op->sm;
+        a.rows = s.M, a.cols = s.N, a.oscale = s.oscale, a.ozp_f = (float)s.ozp;
+        a.exp_table = op->d_table.as<float>();
+        op->generic_name = "softmax_table";
+        break;
+    }
+    default:
+        fail(MF_ERR_UNSUPPORTED, "unsupported operator kind " + std::to_string(s.kind));
+    }
+    // the spec's host pointers die with the caller
+    op->s.weights = nullptr, op->s.wzp = nullptr, op->s.c0 = op->s.c1 = nullptr, op->s.c2 = nullptr;
+    return op.release();
+}
+
+void op_destroy(OpImpl *op) {
+    if (!op) return;
+    (void)hipSetDevice(op->device);
+    delete op;
+}
+
+size_t op_in_elems(const OpImpl *op) { return op->in_elems; }
+size_t op_out_elems(const OpImpl *op) { return op->out_elems; }
+const char *op_kernel_name(const OpImpl *op) {
+    return (op->fast != OpImpl::NONE && !op->force_generic) ? op->fast_name.c_str()
+                                                             : op->generic_name.c_str();
+}
+void op_set_generic(OpImpl *op, bool g) { op->force_generic = g; }
+
+void op_run(OpImpl *op, const int8_t *d_in, size_t batch, int8_t *d_out, void *stream) {
+    if (!batch) return;
+    if (!d_in || !d_out) fail(MF_ERR_INVALID_ARG, "op_run: null device pointer");
+    hipStream_t s = (hipStream_t)stream;
+    const OpSpec &sp = op->s;
+    const bool fast = op->fast != OpImpl::NONE && !op->force_generic;
+    bool done = false;
+    if (fast) {
+        if (batch > 0x7fffffffull / 4) fail(MF_ERR_INVALID_ARG, "batch too large for one launch");
+        switch (op->fast) {
+        case OpImpl::DW_NHWC:
+            done = k::launch_dw_fast(sp.H, sp.W, sp.C, sp.sh, d_in, d_out, op->dwf, (int)batch, s);
+            break;
+        case OpImpl::DW_STEM:
+            done = k::launch_dw_stem(sp.H, sp.W, sp.N, sp.sh, d_in, d_out, op->stem, (int)batch, s);
+            break;
+        case OpImpl::PW_MFMA:
+            done = k::launch_pw(sp.C, sp.N, d_in, d_out, op->pw, (long long)batch * sp.H * sp.W, s);
+            break;
+        case OpImpl::FC_ROWWAVE:
+            done = k::launch_fc_rowwave(d_in, d_out, op->fc, batch * sp.M, s);
+            break;
+        default: break;
+        }
+    }
+    if (!done) {
+        switch (sp.kind) {
+        case MF_OP_CONV_2D: k::launch_conv2d_generic(d_in, d_out, op->conv, batch, s); break;
+        case MF_OP_DEPTHWISE_CONV_2D: k::launch_dwconv_generic(d_in, d_out, op->conv, batch, s); break;
+        case MF_OP_AVERAGE_POOL_2D: k::launch_avgpool_generic(d_in, d_out, op->pool, batch, s); break;
+        case MF_OP_FULLY_CONNECTED: k::launch_fc_generic(d_in, d_out, op->fc, batch * sp.M, s); break;
+        case MF_OP_SOFTMAX: k::launch_softmax(d_in, d_out, op->sm, batch, s); break;
+        default: fail(MF_ERR_UNSUPPORTED, "op_run: bad kind");
+        }
+    }
+    MF_HIP(hipGetLastError());
+}
+
+void dev_quantize(int device, const float *d_in, size_t n, float scale, int8_t zp, int8_t *d_out,
+                  void *stream) {
+    dev_require(device);
+    if (!n) return;
+    k::launch_quantize(d_in, d_out, n, scale, (float)zp, (hipStream_t)stream);
+    MF_HIP(hipGetLastError());
+}
+void dev_dequantize(int device, const int8_t *d_in, size_t n, float scale, int8_t zp, float *d_out,
+                    void *stream) {
+    dev_require(device);
+    if (!n) return;
+    k::launch_dequantize(d_in, d_out, n, scale, (float)zp, (hipStream_t)stream);
+    MF_HIP(hipGetLastError());
+}
+void dev_synth_i8(int device, uint64_t seed, uint64_t first, size_t n, int8_t *d_out, void *stream) {
+    dev_require(device);
+    if (!n) return;
+    k::launch_synth(d_out, n, seed, first, (hipStream_t)stream);
+    MF_HIP(hipGetLastError());
+}
+uint64_t dev_checksum_i8(int device, const int8_t *d_in, size_t n, void *stream) {
+    dev_require(device);
+    unsigned long long *d_res = nullptr, h = 0;
+    MF_HIP(hipMalloc((void **)&d_res, 8));
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(d_res, 0, 8, s);
+    if (e == hipSuccess && n) {
+        k::launch_checksum(d_in, n, d_res, s);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(&h, d_res, 8, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(d_res);
+    if (e != hipSuccess) fail(MF_ERR_HIP, std::string("checksum: ") + hipGetErrorString(e));
+    return (uint64_t)h;
+}
+
+} // namespace mf

@@ -1,0 +1,207 @@
+"""The `#[model("x.tflite")]` surface (microflow-macros/src/lib.rs:185-203) on top of
+the C ABI: predict / predict_quantized, plus the batched forms the MI355X build adds.
+
+numpy arrays are treated as HOST buffers (the library stages them through HBM);
+torch CUDA tensors are consumed and produced in place on the device.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _lib
+
+OP_NAMES = {1: "average_pool_2d", 3: "conv_2d", 4: "depthwise_conv_2d", 9: "fully_connected",
+            22: "reshape", 25: "softmax"}
+
+
+class Model:
+    def __init__(self, path_or_bytes, device=None, max_batch=0):
+        if isinstance(path_or_bytes, (bytes, bytearray, memoryview)):
+            data = bytes(path_or_bytes)
+        else:
+            if not os.path.exists(path_or_bytes):  # lib.rs:50-55
+                raise FileNotFoundError("couldn't find '%s', please provide a valid path"
+                                        % path_or_bytes)
+            with open(path_or_bytes, "rb") as f:
+                data = f.read()
+        L = _lib.lib()
+        h = C.c_void_p()
+        _lib.check(L.mf_model_create(data, len(data), C.byref(h)))
+        self._h = h
+        info = _lib.ModelInfo()
+        _lib.check(L.mf_model_get_info(h, C.byref(info)))
+        self.input_shape = tuple(info.input_shape[: info.input_rank])
+        self.output_shape = tuple(info.output_shape[: info.output_rank])
+        self.input_scale, self.input_zero_point = np.float32(info.input_scale), info.input_zero_point
+        self.output_scale, self.output_zero_point = np.float32(info.output_scale), info.output_zero_point
+        self.input_elems, self.output_elems = info.input_elems, info.output_elems
+        self.num_ops = info.num_ops
+        self._device = device
+        self._prepared = False
+        if max_batch:
+            self.prepare(max_batch)
+
+    # ---- introspection (no GPU needed) -------------------------------------
+    def op(self, i):
+        d = _lib.OpDesc()
+        _lib.check(_lib.lib().mf_model_get_op(self._h, i, C.byref(d)))
+        return dict(kind=d.kind, name=OP_NAMES.get(d.kind, "?"),
+                    in_shape=tuple(d.in_shape[: d.in_rank]), out_shape=tuple(d.out_shape[: d.out_rank]),
+                    KH=d.KH, KW=d.KW, sh=d.stride_h, sw=d.stride_w, pad=d.padding, act=d.activation,
+                    n_c0=d.n_c0, n_c1=d.n_c1, in_scale=np.float32(d.in_scale),
+                    out_scale=np.float32(d.out_scale), in_zp=d.in_zero_point, out_zp=d.out_zero_point,
+                    out_elems=d.out_elems, kernel=(d.kernel or b"").decode())
+
+    @property
+    def ops(self):
+        return [self.op(i) for i in range(self.num_ops)]
+
+    def op_constants(self, i):
+        d = self.op(i)
+        c0 = np.zeros(max(d["n_c0"], 1), np.float32)
+        c1 = np.zeros(max(d["n_c1"], 1), np.float32)
+        c2 = np.zeros(max(d["n_c0"], 1), np.int32)
+        c3 = C.c_int32(0)
+        _lib.check(_lib.lib().mf_model_get_op_constants(
+            self._h, i, c0.ctypes.data_as(C.c_void_p), c1.ctypes.data_as(C.c_void_p),
+            c2.ctypes.data_as(C.c_void_p), C.byref(c3)))
+        return c0, c1, c2, c3.value
+
+    # ---- device -------------------------------------------------------------
+    def prepare(self, max_batch=1, device=None):
+        if device is None:
+            device = self._device
+        if device is None:
+            import torch
+            if not torch.cuda.is_available():
+                raise _lib.MicroflowError(_lib.MF_ERR_NO_DEVICE,
+                                          "no GPU visible: microflow has no CPU fallback")
+            device = torch.cuda.current_device()
+        self._device = int(device)
+        _lib.check(_lib.lib().mf_model_prepare(self._h, self._device, int(max_batch)))
+        self._prepared = True
+        return self
+
+    def set_generic(self, generic=True):
+        _lib.check(_lib.lib().mf_model_set_generic(self._h, int(generic)))
+        return self
+
+    def sync(self):
+        _lib.check(_lib.lib().mf_model_sync(self._h))
+
+    def _io(self, x, np_dtype, elems, out_elems, out_torch_dtype, out_np_dtype, trailing):
+        """Normalise an input to (pointer, batch, mem, output buffer, finish())."""
+        import torch
+        if isinstance(x, torch.Tensor):
+            if not x.is_cuda:
+                x = x.numpy()
+        if isinstance(x, np.ndarray) or not isinstance(x, torch.Tensor):
+            a = np.ascontiguousarray(x, dtype=np_dtype)
+            if a.size % elems:
+                raise ValueError("input has %d elements, expected a multiple of %d" % (a.size, elems))
+            batch = a.size // elems
+            single = a.size == elems and a.ndim <= len(self.input_shape)
+            out = np.empty((batch, out_elems), out_np_dtype)
+            fin = (lambda: out.reshape(trailing) if single else out.reshape((batch,) + trailing))
+            return a.ctypes.data_as(C.c_void_p), batch, _lib.MF_MEM_HOST, out.ctypes.data_as(C.c_void_p), fin, a
+        xt = x.contiguous()
+        if xt.numel() % elems:
+            raise ValueError("input has %d elements, expected a multiple of %d" % (xt.numel(), elems))
+        batch = xt.numel() // elems
+        single = xt.numel() == elems and xt.dim() <= len(self.input_shape)
+        out = torch.empty((batch, out_elems), dtype=out_torch_dtype, device=xt.device)
+        _lib.check(_lib.lib().mf_model_set_stream(self._h, torch.cuda.current_stream(xt.device).cuda_stream))
+        fin = (lambda: out.reshape(trailing) if single else out.reshape((batch,) + trailing))
+        return xt.data_ptr(), batch, _lib.MF_MEM_DEVICE, out.data_ptr(), fin, xt
+
+    def _ensure(self, batch):
+        if not self._prepared:
+            self.prepare(batch)
+
+    # ---- the #[model] methods -------------------------------------------------
+    def predict(self, x):
+        """M::predict (lib.rs:188-191).  x: f32 [input_shape] or [B, *input_shape]."""
+        import torch
+        p, batch, mem, o, fin, keep = self._io(x, np.float32, self.input_elems, self.output_elems,
+                                               torch.float32, np.float32, self.output_shape)
+        self._ensure(batch)
+        _lib.check(_lib.lib().mf_model_predict(self._h, p, batch, o, mem))
+        return fin()
+
+    def predict_quantized(self, xq):
+        """M::predict_quantized (lib.rs:193-196).  xq: int8."""
+        import torch
+        p, batch, mem, o, fin, keep = self._io(xq, np.int8, self.input_elems, self.output_elems,
+                                               torch.float32, np.float32, self.output_shape)
+        self._ensure(batch)
+        _lib.check(_lib.lib().mf_model_predict_quantized(self._h, p, batch, o, mem))
+        return fin()
+
+    predict_batch = predict                      # new surface: B independent inferences
+    predict_quantized_batch = predict_quantized
+
+    def run_quantized(self, xq):
+        """predict_inner (lib.rs:198-201): int8 in, int8 out (before dequantize)."""
+        import torch
+        p, batch, mem, o, fin, keep = self._io(xq, np.int8, self.input_elems, self.output_elems,
+                                               torch.int8, np.int8, self.output_shape)
+        self._ensure(batch)
+        _lib.check(_lib.lib().mf_model_run_quantized(self._h, p, batch, o, mem))
+        return fin()
+
+    def run_until(self, xq, last_op):
+        """int8 output of op `last_op` for the whole batch (per-layer parity localisation)."""
+        import torch
+        d = self.op(last_op)
+        p, batch, mem, o, fin, keep = self._io(xq, np.int8, self.input_elems, d["out_elems"],
+                                               torch.int8, np.int8, d["out_shape"])
+        self._ensure(batch)
+        _lib.check(_lib.lib().mf_model_run_until(self._h, p, batch, int(last_op), o, mem))
+        return fin()
+
+    def time_device(self, d_in, d_out, batch, warmup=3, iters=20, per_op=True):
+        """HIP-event timing of `iters` passes over a device-resident batch (torch tensors)."""
+        import torch
+        self._ensure(batch)
+        _lib.check(_lib.lib().mf_model_set_stream(self._h, torch.cuda.current_stream().cuda_stream))
+        avg = C.c_float(0)
+        per = (C.c_float * self.num_ops)() if per_op else None
+        _lib.check(_lib.lib().mf_model_time_device(self._h, d_in.data_ptr(), int(batch),
+                                                   d_out.data_ptr(), int(warmup), int(iters),
+                                                   C.byref(avg), per))
+        return avg.value, (list(per) if per_op else None)
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                _lib.lib().mf_model_destroy(h)
+            except Exception:  # noqa: BLE001
+                pass
+
+
+def model(path, device=None):
+    """`#[model("path.tflite")] struct M;` -> `M = model("path.tflite")`; then
+    `M.predict(x)` / `M.predict_quantized(xq)` like the generated associated functions."""
+    return Model(path, device=device)
+
+
+def synth_i8(seed, first_byte, n, device=None):
+    """Counter-based synthetic int8 stream generated directly in HBM (mf_synth_i8)."""
+    import torch
+    dev = torch.cuda.current_device() if device is None else device
+    out = torch.empty(int(n), dtype=torch.int8, device="cuda:%d" % dev)
+    _lib.check(_lib.lib().mf_synth_i8(dev, int(seed), int(first_byte), int(n), out.data_ptr(),
+                                      torch.cuda.current_stream(dev).cuda_stream))
+    return out
+
+
+def checksum_i8(t):
+    """Position-sensitive 64-bit checksum of an int8 CUDA tensor (mf_checksum_i8)."""
+    import torch
+    t = t.contiguous()
+    res = C.c_uint64(0)
+    _lib.check(_lib.lib().mf_checksum_i8(t.device.index or 0, t.data_ptr(), t.numel(), C.byref(res),
+                                         torch.cuda.current_stream(t.device).cuda_stream))
+    return res.value

@@ -1,0 +1,144 @@
+"""Host side of the product (no GPU): .tflite reader, constant preparation, error
+behaviour -- compared with the reference's preprocess KATs and with the oracle."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import microflow_rs_amd as mf
+from microflow_rs_amd import _lib
+from tests.conftest import model_path
+
+f32 = np.float32
+
+
+def _vp(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def pre_fc(iscale, izp, shape1, w_nk, wscale, wzp, bias, bscale, bzp, oscale):
+    w = np.ascontiguousarray(w_nk, np.int8)
+    N, K = w.shape
+    b = np.ascontiguousarray(bias, np.int32)
+    c0, c1, c2, c3 = np.zeros(N, f32), np.zeros(1, f32), np.zeros(N, np.int32), np.zeros(1, np.int32)
+    _lib.check(_lib.lib().mf_preprocess_fully_connected(iscale, izp, shape1, _vp(w), K, N, wscale, wzp,
+                                                        _vp(b), bscale, bzp, oscale, _vp(c0), _vp(c1),
+                                                        _vp(c2), _vp(c3)))
+    return c0, c1[0], c2, int(c3[0])
+
+
+def pre_conv(fn, iscale, bias, bscale, bzp, fscale, oscale):
+    b = np.ascontiguousarray(bias, np.int32)
+    bs, bz = np.ascontiguousarray(bscale, f32), np.ascontiguousarray(bzp, np.int32)
+    fs = np.ascontiguousarray(fscale, f32)
+    c0, c1 = np.zeros(b.size, f32), np.zeros(fs.size, f32)
+    _lib.check(getattr(_lib.lib(), fn)(iscale, b.size, _vp(b), _vp(bs), _vp(bz), min(bs.size, bz.size),
+                                       _vp(fs), fs.size, oscale, _vp(c0), _vp(c1)))
+    return c0, c1
+
+
+def test_preprocess_kats(kats):
+    k = kats["fully_connected_preprocess"]
+    c0, c1, c2, c3 = pre_fc(k["input_scale"], k["input_zero_point"], k["input_shape"][1],
+                            np.array(k["weights_kxn"], np.int8).T, k["weights_scale"],
+                            k["weights_zero_point"], k["biases"], k["biases_scale"],
+                            k["biases_zero_point"], k["output_scale"])
+    assert np.array_equal(c0, np.array(k["c0"], f32)) and c1 == f32(k["c1"])
+    assert c2.tolist() == k["c2"] and c3 == k["c3"]
+    for name, fn, key in (("conv_2d_preprocess", "mf_preprocess_conv_2d", "filters_scale"),
+                          ("depthwise_conv_2d_preprocess", "mf_preprocess_depthwise_conv_2d",
+                           "weights_scale")):
+        k = kats[name]
+        c0, c1 = pre_conv(fn, k["input_scale"], k["biases"], k["biases_scale"],
+                          k["biases_zero_point"], k[key], k["output_scale"])
+        assert np.array_equal(c0, np.array(k["c0"], f32)), name
+        assert np.array_equal(c1, np.array(k["c1"], f32)), name
+    k = kats["average_pool_2d_preprocess"]
+    c0, c1 = np.zeros(1, f32), np.zeros(1, f32)
+    _lib.check(_lib.lib().mf_preprocess_average_pool_2d(k["input_scale"], k["input_zero_point"],
+                                                        k["output_scale"], k["output_zero_point"],
+                                                        _vp(c0), _vp(c1)))
+    assert c0[0] == f32(k["c0"]) and c1[0] == f32(k["c1"])
+
+
+@pytest.mark.parametrize("name", ["sine", "speech", "person_detect"])
+def test_model_parse_matches_oracle(O, name):
+    """Two independently written readers + constant preparations must agree bit for bit."""
+    m = mf.model(model_path(name))
+    o = O.Model(model_path(name))
+    assert m.input_shape == o.in_shape and m.output_shape == o.out_shape
+    assert m.input_scale == o.in_scale and m.input_zero_point == o.in_zp
+    assert m.output_scale == o.out_scale and m.output_zero_point == o.out_zp
+    assert m.num_ops == o.num_ops
+    for i in range(m.num_ops):
+        a, b = m.op(i), o.ops[i]
+        for key in ("kind", "in_shape", "out_shape", "KH", "KW", "sh", "sw", "pad", "act", "n_c0",
+                    "n_c1", "out_elems", "in_zp", "out_zp"):
+            if a["kind"] in (22, 25) and key in ("n_c0", "n_c1"):
+                continue
+            assert a[key] == b[key], (i, key, a[key], b[key])
+        assert a["in_scale"] == b["in_scale"] and a["out_scale"] == b["out_scale"]
+        if a["kind"] in (1, 3, 4, 9):
+            ca, cb = m.op_constants(i), o.op_constants(i)
+            assert np.array_equal(ca[0].view(np.uint32), cb[0].view(np.uint32)), (i, "c0")
+            assert np.array_equal(ca[1].view(np.uint32), cb[1].view(np.uint32)), (i, "c1")
+            if a["kind"] == 9:
+                assert np.array_equal(ca[2], cb[2]) and ca[3] == cb[3]
+
+
+def _create(data):
+    h = C.c_void_p()
+    st = _lib.lib().mf_model_create(bytes(data), len(data), C.byref(h))
+    if st == 0:
+        _lib.lib().mf_model_destroy(h)
+    return st, (_lib.lib().mf_last_error() or b"").decode()
+
+
+def test_invalid_models_are_rejected():
+    good = open(model_path("sine"), "rb").read()
+    assert _create(good)[0] == 0
+    st, msg = _create(b"")
+    assert st == _lib.MF_ERR_INVALID_MODEL and "invalid model" in msg
+    st, msg = _create(b"\x00" * 64)
+    assert st == _lib.MF_ERR_INVALID_MODEL
+    st, msg = _create(good[:200])
+    assert st == _lib.MF_ERR_INVALID_MODEL
+    # random corruption must never crash: every outcome is a status code
+    rng = np.random.default_rng(0)
+    for _ in range(200):
+        bad = bytearray(good)
+        for p in rng.integers(0, len(bad), 8):
+            bad[p] = rng.integers(0, 256)
+        assert _create(bad)[0] in (0, 1, 2, 3)
+
+
+def test_unsupported_operator_and_missing_file():
+    # flip every FULLY_CONNECTED opcode (9) of sine.tflite to ADD (0): "unsupported operator"
+    o = None
+    data = bytearray(open(model_path("sine"), "rb").read())
+    # OperatorCode tables are tiny; locate via the reader of the oracle-independent product:
+    # brute force -- change one byte at a time until the status flips to UNSUPPORTED
+    hits = 0
+    for p in range(len(data)):
+        if data[p] == 9:
+            bad = bytearray(data)
+            bad[p] = 0
+            st, msg = _create(bad)
+            if st == _lib.MF_ERR_UNSUPPORTED and "unsupported operator" in msg:
+                hits += 1
+    assert hits >= 1
+    with pytest.raises(FileNotFoundError) as ei:
+        mf.model("/nonexistent/model.tflite")
+    assert "couldn't find" in str(ei.value)
+
+
+def test_bad_arguments_return_status_codes():
+    L = _lib.lib()
+    h = C.c_void_p()
+    assert L.mf_model_create(None, 0, C.byref(h)) == _lib.MF_ERR_INVALID_MODEL
+    assert L.mf_model_get_info(None, None) == _lib.MF_ERR_INVALID_ARG
+    assert L.mf_op_run(None, None, 1, None, None) == _lib.MF_ERR_INVALID_ARG
+    assert L.mf_op_input_elems(None) == 0
+    L.mf_op_destroy(None)
+    L.mf_model_destroy(None)
