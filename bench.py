@@ -1,0 +1,213 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the quantized-operator hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload person_detect|speech]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json): person_detect.tflite, int8, 65536 independent inferences per
+GPU (configs[2]; configs[3] = the same shard on each of 8 GPUs, i.e. weak scaling).
+One "step" = one pass of predict_inner (all 29 kernels: 14 DepthwiseConv2D, 14 Conv2D,
+AveragePool2D, Softmax) over the GPU's batch, int8 in -> int8 out, with the synthetic
+input batch already resident in HBM when the timed region starts.
+
+The JSON line carries, beside the driver's contract fields:
+  roofline     : the dominant kernel (largest share of the step) -- achieved algorithmic
+                 GB/s from HIP-event timing on the launch stream vs the 8 TB/s HBM peak
+  kernels      : the same figure for every operator of the step
+  depthwise    : the 14 DepthwiseConv2D kernels aggregated (the north-star target)
+  cpu_baseline : the reference-faithful C restatement (oracle/, "port") timed on this
+                 box's host cores over a bounded sample of the same input stream
+  parity       : sampled bit-exact comparison of the GPU outputs with that oracle
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 achievable)
+WORKLOADS = {
+    # name: (model file, BASELINE config index used as stream id, per-GPU batch)
+    "person_detect": ("person_detect.tflite", 3, 65536),
+    "speech": ("speech.tflite", 2, 4096),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="person_detect", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the BASELINE size)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+
+    import microflow_rs_amd as mf
+    from microflow_rs_amd import _lib
+    from microflow_rs_amd.model import checksum_i8, synth_i8
+    from microflow_rs_amd.shard import gather_checksums, max_over_ranks, shard_range
+    from tests.synth import SEED
+
+    fname, cfg, base_batch = WORKLOADS[args.workload]
+    B = args.batch or base_batch
+    m = mf.model(os.path.join(ROOT, "models", fname))
+    m.prepare(B, device=local_rank)
+    L = _lib.lib()
+    stream = torch.cuda.current_stream()
+    _lib.check(L.mf_model_set_stream(m._h, stream.cuda_stream))
+
+    # this rank's shard of the global synthetic stream, generated directly in HBM
+    first, count = shard_range(B * world, rank, world)
+    x = synth_i8(SEED + cfg, first * m.input_elems, count * m.input_elems)
+    y = torch.empty(count * m.output_elems, dtype=torch.int8, device="cuda")
+
+    def step():
+        _lib.check(L.mf_model_run_quantized(m._h, x.data_ptr(), count, y.data_ptr(), _lib.MF_MEM_DEVICE))
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        elapsed = max_over_ranks(dist, elapsed, device="cuda")
+    ms_per_step = elapsed / args.steps * 1e3
+    value = B * world / (elapsed / args.steps)
+
+    # output checksums of every shard (outside the timed region; RCCL all_gather of 8 bytes)
+    ck = checksum_i8(y)
+    cks = [ck]
+    if world > 1:
+        cks = gather_checksums(dist, ck, device="cuda")
+
+    result = None
+    if rank == 0:
+        # ---- per-kernel HIP-event timing on the launch stream ----
+        avg_ms, per_op = m.time_device(x, y, count, warmup=1, iters=max(5, min(args.steps, 20)))
+        kernels = []
+        for i in range(m.num_ops):
+            d = m.op(i)
+            if not d["kernel"]:
+                continue
+            in_elems = int(np.prod(d["in_shape"]))
+            nbytes = (in_elems + d["out_elems"]) * count  # algorithmic: unique in + out bytes
+            gbs = nbytes / (per_op[i] * 1e-3) / 1e9 if per_op[i] > 0 else 0.0
+            kernels.append({"op": i, "kind": d["name"], "kernel": d["kernel"], "ms": round(per_op[i], 4),
+                            "bytes": nbytes, "GBps": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4)})
+        dom = max(kernels, key=lambda k: k["ms"])
+        roofline = {"bound": "hbm", "kernel": dom["kernel"], "op": dom["op"], "achieved": dom["GBps"],
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["frac"], "traffic": None,
+                    "ms": dom["ms"], "algorithmic_bytes": dom["bytes"],
+                    "method": "HIP events on the launch stream, avg of %d launches" % max(5, min(args.steps, 20))}
+
+        def agg(kind):
+            ks = [k for k in kernels if k["kind"] == kind]
+            ms = sum(k["ms"] for k in ks)
+            by = sum(k["bytes"] for k in ks)
+            gbs = by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+            return {"kernels": len(ks), "ms": round(ms, 4), "bytes": by, "GBps": round(gbs, 1),
+                    "frac": round(gbs / HBM_PEAK_GBS, 4)}
+
+        # ---- parity: sampled bit-exact comparison with the CPU oracle ----
+        from oracle import oracle as O
+        om = O.Model(os.path.join(ROOT, "models", fname))
+        idx = sorted(set([0, 1, count // 3, count // 2, count - 2, count - 1]))
+        xs = x.reshape(count, -1)[idx].cpu().numpy()
+        ys = y.reshape(count, -1)[idx].cpu().numpy()
+        parity_ok = bool(np.array_equal(ys, om.run_quantized_batch(xs)))
+
+        cpu = None
+        if not args.no_cpu_baseline and world == 1:
+            cpu = cpu_baseline(om, x.reshape(count, -1), args.cpu_seconds)
+
+        result = {
+            "metric": "inferences/sec (int8) for %s" % fname, "value": round(value, 1),
+            "unit": "inferences/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "i8", "data": "synthetic",
+            "config": {"workload": "%s batch=%d per GPU, predict_inner int8->int8, inputs resident in HBM"
+                                   % (fname, B), "per_gpu_batch": B, "global_batch": B * world,
+                       "parallelism": "batch shard x%d, no data-path collective" % world},
+            "roofline": roofline,
+            "depthwise": agg("depthwise_conv_2d"), "conv_2d": agg("conv_2d"),
+            "event_ms_per_step": round(avg_ms, 4),
+            "kernels": kernels,
+            "cpu_baseline": cpu,
+            "parity": {"bit_exact_vs_oracle": parity_ok, "sampled_images": len(idx),
+                       "output_checksums": ["%016x" % c for c in cks]},
+        }
+        if not parity_ok:
+            result["value"] = 0.0
+            result["error"] = "GPU outputs differ from the CPU oracle: number withheld"
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result))
+        if not result["parity"]["bit_exact_vs_oracle"]:
+            sys.exit(1)
+
+
+def cpu_baseline(om, x_dev_rows, seconds):
+    """Time the oracle (oracle/mf_oracle.c: scalar restatement of the reference algorithm,
+    gcc -O2, one thread) on this box's host over a bounded sample of the same stream."""
+    probe = x_dev_rows[:8].cpu().numpy()
+    t0 = time.perf_counter()
+    om.run_quantized_batch(probe)
+    per_img = (time.perf_counter() - t0) / 8
+    n = int(max(16, min(x_dev_rows.shape[0], seconds / max(per_img, 1e-6))))
+    xs = x_dev_rows[:n].cpu().numpy()
+    t0 = time.perf_counter()
+    om.run_quantized_batch(xs)
+    dt = time.perf_counter() - t0
+    cpu_model = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                cpu_model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"value": round(n / dt, 2), "unit": "inferences/s", "cores": 1, "kind": "port",
+            "sample": "%d images of the same synthetic stream, 1 thread, %.1f s" % (n, dt),
+            "host": {"cpu": cpu_model, "logical_cores": os.cpu_count()},
+            "note": "C restatement of the reference algorithm (oracle/), not the Rust binary"}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,48 @@
+#!/bin/bash
+# Runs on the GPU box (via gpurun): GPU tests, smoke, bench, rocprofv3 kernel stats.
+# Everything is written under gpurun_out/ (merged back by gpurun).
+set +e
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+OUT=gpurun_out
+mkdir -p $OUT
+export TMPDIR=/tmp
+rocm-smi --showproductname 2>/dev/null | head -8 > $OUT/gpu.txt
+lscpu | egrep "Model name|^CPU\(s\)" >> $OUT/gpu.txt
+STEPS=${STEPS:-all}
+
+if [[ $STEPS == all || $STEPS == *test* ]]; then
+  timeout 1500 python -m pytest tests -m gpu -x -q ${PYTEST_ARGS} > $OUT/pytest_gpu.log 2>&1
+  echo "pytest exit $?" >> $OUT/pytest_gpu.log
+  tail -25 $OUT/pytest_gpu.log
+fi
+if [[ $STEPS == all || $STEPS == *smoke* ]]; then
+  timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1
+  echo "smoke exit $?" >> $OUT/smoke.log
+  tail -3 $OUT/smoke.log
+fi
+if [[ $STEPS == all || $STEPS == *bench* ]]; then
+  timeout 600 python bench.py ${BENCH_ARGS} > $OUT/bench.json 2> $OUT/bench.err
+  echo "bench exit $?"
+  tail -5 $OUT/bench.err
+  python - <<'PY'
+import json
+try:
+    r = json.loads(open("gpurun_out/bench.json").read().strip().splitlines()[-1])
+    print("value", r["value"], r["unit"], "ms/step", r["ms_per_step"], "roofline", r["roofline"])
+    print("depthwise", r["depthwise"], "conv", r["conv_2d"])
+    for k in r["kernels"]:
+        print("%2d %-18s %-28s %8.4f ms %8.1f GB/s %.3f" % (k["op"], k["kind"], k["kernel"], k["ms"], k["GBps"], k["frac"]))
+    print("cpu", r["cpu_baseline"]); print("parity", r["parity"])
+except Exception as e:
+    print("bench parse failed", e)
+PY
+fi
+if [[ $STEPS == all || $STEPS == *prof* ]]; then
+  rm -rf $OUT/prof
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/$OUT/prof" -- \
+      python "$OLDPWD/bench.py" --steps 5 --warmup 2 --no-cpu-baseline > "$OLDPWD/$OUT/prof_bench.json" 2> "$OLDPWD/$OUT/prof.err")
+  echo "rocprof exit $?"
+  find $OUT/prof -name "*kernel_stats*" | head
+  f=$(find $OUT/prof -name "*kernel_stats.csv" | head -1)
+  [ -n "$f" ] && head -40 "$f"
+fi

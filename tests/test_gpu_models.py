@@ -1,0 +1,171 @@
+"""Whole-model parity on the GPU through the C ABI: the reference's golden vectors,
+the recorded sine outputs, the sample tensors, seeded batches against the CPU oracle
+(with per-layer localisation), ragged batch sizes, and full-size properties."""
+import csv
+import os
+
+import numpy as np
+import pytest
+
+from tests.conftest import GOLDEN, model_path
+from tests.synth import SEED, layer_checksum, synth_i8
+
+pytestmark = pytest.mark.gpu
+f32 = np.float32
+
+
+@pytest.fixture(scope="module")
+def mf():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    import microflow_rs_amd as m
+    return m
+
+
+@pytest.fixture(scope="module")
+def models(mf):
+    return {n: mf.model(model_path(n)) for n in ("sine", "speech", "person_detect")}
+
+
+@pytest.mark.parametrize("name", ["sine", "speech", "person_detect"])
+def test_reference_golden_vectors(models, kats, name):
+    """tests/{sine,speech,person_detect}.rs: exact f32 outputs for a constant 0.5 input."""
+    k = kats[name + "_model"]
+    m = models[name]
+    out = m.predict(np.full(m.input_shape, k["input_fill"], f32))
+    assert out.shape == m.output_shape
+    assert np.array_equal(out.reshape(-1), np.array(k["output"], f32)), out
+    # and with the shape-generic kernels only
+    m.set_generic(True)
+    out = m.predict(np.full(m.input_shape, k["input_fill"], f32))
+    m.set_generic(False)
+    assert np.array_equal(out.reshape(-1), np.array(k["output"], f32)), out
+
+
+def test_sine_500_recorded_outputs(models):
+    rows = list(csv.reader(open(os.path.join(GOLDEN, "sine_microflow.csv"))))[1:]
+    x = np.array([f32(r[0]) for r in rows], f32).reshape(-1, 1, 1)
+    y = np.array([f32(r[1]) for r in rows], f32)
+    out = models["sine"].predict(x)          # one batch of 500 independent predicts
+    assert out.shape == (500, 1, 1)
+    assert np.array_equal(out.reshape(-1), y)
+
+
+def test_sample_tensors(models, samples, oracle_vectors):
+    pm, sm = models["person_detect"], models["speech"]
+    for name, m in (("PERSON", pm), ("NO_PERSON", pm), ("YES", sm), ("NO", sm)):
+        q = m.run_quantized(samples[name])
+        assert np.array_equal(q.reshape(-1), oracle_vectors["sample_" + name].reshape(-1)), name
+        f = m.predict_quantized(samples[name])
+        assert np.array_equal(f.reshape(-1), oracle_vectors["sample_" + name + "_f32"].reshape(-1)), name
+
+
+@pytest.mark.parametrize("name,cfg", [("sine", 1), ("speech", 2), ("person_detect", 3)])
+def test_committed_oracle_vectors(models, oracle_vectors, name, cfg):
+    m = models[name]
+    n = int(oracle_vectors[name + "_n"][0])
+    x = synth_i8(cfg, 0, n, m.input_elems)
+    out = m.run_quantized(x.reshape((n,) + m.input_shape))
+    assert np.array_equal(out.reshape(n, -1), oracle_vectors[name + "_final"])
+    # per-layer checksums localise a mismatch to the first wrong operator
+    sums = oracle_vectors[name + "_layer_checksums"]
+    for i in range(m.num_ops):
+        lay = m.run_until(x.reshape((n,) + m.input_shape), i)
+        got = [layer_checksum(lay[j]) for j in range(n)]
+        assert got == sums[:, i].tolist(), (name, "first mismatching op", i, m.op(i)["name"], m.op(i)["kernel"])
+
+
+@pytest.mark.parametrize("name,cfg,n", [("speech", 2, 96), ("person_detect", 3, 48)])
+def test_seeded_batch_vs_oracle_live(models, O, name, cfg, n):
+    """Fresh comparison against the oracle (not the committed fixtures), different images."""
+    m = models[name]
+    o = O.Model(model_path(name))
+    x = synth_i8(cfg, 1000, n, m.input_elems)
+    want = o.run_quantized_batch(x)
+    got = m.run_quantized(x.reshape((n,) + m.input_shape)).reshape(n, -1)
+    assert np.array_equal(got, want)
+    # f32 entry point: identical quantized data -> identical outputs
+    xf = (x.astype(f32) - f32(m.input_zero_point)) * m.input_scale
+    gf = m.predict(xf.reshape((n,) + m.input_shape)).reshape(n, -1)
+    wf = np.stack([o.predict(xf[i]) for i in range(8)]).reshape(8, -1)
+    assert np.array_equal(gf[:8], wf)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 7, 17, 129])
+def test_ragged_batches(models, O, n):
+    """Batch sizes that are not multiples of any tile (images per workgroup, MFMA chunks)."""
+    m = models["person_detect"]
+    o = O.Model(model_path("person_detect"))
+    x = synth_i8(3, 5000, n, m.input_elems)
+    got = m.run_quantized(x.reshape((n,) + m.input_shape)).reshape(n, -1)
+    k = min(n, 4)
+    want = o.run_quantized_batch(x[:k])
+    assert np.array_equal(got[:k], want)
+    # batch invariance: every image's result is independent of its position / batch size
+    single = np.stack([m.run_quantized(x[i].reshape(m.input_shape)).reshape(-1) for i in (0, n - 1)])
+    assert np.array_equal(single, got[[0, n - 1]])
+
+
+def test_device_synth_matches_host(mf):
+    from microflow_rs_amd.model import checksum_i8, synth_i8 as dsynth
+    d = dsynth(SEED + 3, 9216 * 5, 9216 * 3 + 5)
+    h = synth_i8(3, 0, 9, 9216).reshape(-1)[9216 * 5: 9216 * 8 + 5]
+    assert np.array_equal(d.cpu().numpy(), h)
+    assert checksum_i8(d) == int(layer_checksum(h))
+
+
+def test_full_size_properties(mf, models, O):
+    """BASELINE config 3 size (65536 images): size-independent properties.
+    - fast kernels == shape-generic kernels over the whole batch (checksum of checksums),
+    - a sampled subset equals the oracle,
+    - shards recombine: running [0,B) equals running [0,B/2) and [B/2,B) separately."""
+    import torch
+    from microflow_rs_amd.model import checksum_i8, synth_i8 as dsynth
+    m = models["person_detect"]
+    B = 65536
+    x = dsynth(SEED + 3, 0, B * m.input_elems).reshape((B,) + m.input_shape)
+    y = m.run_quantized(x)
+    m.sync()
+    full = checksum_i8(y)
+    # sampled oracle check
+    idx = [0, 1, 777, 32767, 32768, 65535]
+    o = O.Model(model_path("person_detect"))
+    xs = x[idx].cpu().numpy().reshape(len(idx), -1)
+    assert np.array_equal(y[idx].cpu().numpy().reshape(len(idx), -1), o.run_quantized_batch(xs))
+    # shard recombination (the multi-GPU decomposition on one device)
+    y0 = m.run_quantized(x[: B // 2])
+    y1 = m.run_quantized(x[B // 2:])
+    m.sync()
+    assert checksum_i8(torch.cat([y0, y1])) == full
+    # generic kernels on a slice large enough to cross every tile boundary many times
+    S = 4096
+    m.set_generic(True)
+    yg = m.run_quantized(x[:S])
+    m.sync()
+    m.set_generic(False)
+    assert torch.equal(yg, y[:S])
+
+
+def test_speech_batch_4096(mf, models, O):
+    """BASELINE config 2: speech, batch 4096, bit-exact sample check + batch invariance."""
+    from microflow_rs_amd.model import synth_i8 as dsynth
+    m = models["speech"]
+    B = 4096
+    x = dsynth(SEED + 2, 0, B * m.input_elems).reshape((B,) + m.input_shape)
+    y = m.run_quantized(x)
+    o = O.Model(model_path("speech"))
+    idx = list(range(0, B, 257))
+    want = o.run_quantized_batch(x[idx].cpu().numpy().reshape(len(idx), -1))
+    assert np.array_equal(y[idx].cpu().numpy().reshape(len(idx), -1), want)
+
+
+def test_kernel_routing(models):
+    """The fast HIP kernels are the ones that run for person_detect."""
+    m = models["person_detect"]
+    m.prepare(1)
+    names = [m.op(i)["kernel"] for i in range(m.num_ops)]
+    assert names[0].startswith("dw3x3_stem8")
+    assert sum(n.startswith("dw3x3_nhwc") for n in names) == 13
+    assert sum(n.startswith("pw_mfma") for n in names) == 13
+    assert names[28] == "conv2d_generic" and names[27] == "avgpool_generic"
+    assert names[29] == "" and names[30] == "softmax_table"

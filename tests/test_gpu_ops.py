@@ -1,0 +1,294 @@
+"""Parity of every operator kernel against the reference's unit KATs and the CPU
+oracle, called through the C ABI (via the Python mirror of microflow::ops).
+Bit-exact: all comparisons are array_equal on int8."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+f32 = np.float32
+
+
+@pytest.fixture(scope="module")
+def mf():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    import microflow_rs_amd as m
+    assert m.lib().mf_device_count() > 0
+    return m
+
+
+ACT = {"none": 0, "relu": 1, "relu6": 3}
+PAD = {"same": 0, "valid": 1}
+
+
+def _acts(mf, name):
+    return mf.FusedActivation(ACT[name])
+
+
+# ---- the reference's own unit tests, through the reference-shaped API -------------
+def test_fully_connected_layer(mf, kats):
+    k = kats["fully_connected_layer"]
+    c = k["constants"]
+    out = mf.ops.fully_connected(
+        mf.Tensor2D(np.array(k["input"], np.int8), [k["input_scale"]], [k["input_zero_point"]]),
+        mf.Tensor2D(np.array(k["weights_kxn"], np.int8), [k["weights_scale"]], [k["weights_zero_point"]]),
+        [k["output_scale"]], [k["output_zero_point"]],
+        mf.ops.FullyConnectedOptions(_acts(mf, k["activation"])),
+        (c["c0"], c["c1"], c["c2"], c["c3"]))
+    assert out.buffer.tolist() == k["output"]
+    assert out.scale == [k["output_scale"]] and out.zero_point == [k["output_zero_point"]]
+
+
+def test_conv_2d_layer(mf, kats):
+    k = kats["conv_2d_layer"]
+    c = k["constants"]
+    out = mf.ops.conv_2d(
+        mf.Tensor4D(np.array(k["input"], np.int8)[None], [k["input_scale"]], [k["input_zero_point"]]),
+        mf.Tensor4D(np.array(k["filters"], np.int8), k["filters_scale"], k["filters_zero_point"]),
+        [k["output_scale"]], [k["output_zero_point"]],
+        mf.ops.Conv2DOptions(_acts(mf, k["activation"]), mf.TensorViewPadding(PAD[k["padding"]]),
+                             tuple(k["strides"])),
+        (c["c0"], c["c1"]), (2, 3))
+    assert out.buffer[0].tolist() == k["output"]   # includes saturation to 127
+
+
+def test_depthwise_conv_2d_layer(mf, kats):
+    k = kats["depthwise_conv_2d_layer"]
+    c = k["constants"]
+    out = mf.ops.depthwise_conv_2d(
+        mf.Tensor4D(np.array(k["input"], np.int8)[None], [k["input_scale"]], [k["input_zero_point"]]),
+        mf.Tensor4D(np.array(k["weights"], np.int8)[None], k["weights_scale"], k["weights_zero_point"]),
+        [k["output_scale"]], [k["output_zero_point"]],
+        mf.ops.DepthwiseConv2DOptions(_acts(mf, k["activation"]),
+                                      mf.TensorViewPadding(PAD[k["padding"]]), tuple(k["strides"])),
+        (c["c0"], c["c1"]), (2, 3))
+    assert out.buffer[0].tolist() == k["output"]
+
+
+def test_average_pool_2d_layer(mf, kats):
+    k = kats["average_pool_2d_layer"]
+    c = k["constants"]
+    out = mf.ops.average_pool_2d(
+        mf.Tensor4D(np.array(k["input"], np.int8)[None], [k["input_scale"]], [k["input_zero_point"]]),
+        tuple(k["filter_shape"]), [k["output_scale"]], [k["output_zero_point"]],
+        mf.ops.AveragePool2DOptions(_acts(mf, k["activation"]),
+                                    mf.TensorViewPadding(PAD[k["padding"]]), tuple(k["strides"])),
+        (c["c0"], c["c1"]), (2, 3))
+    assert out.buffer[0].tolist() == k["output"]   # divides by the in-bounds count
+
+
+def test_softmax_layer(mf, kats):
+    k = kats["softmax_layer"]
+    out = mf.ops.softmax(mf.Tensor2D(np.array(k["input"], np.int8), [k["input_scale"]],
+                                     [k["input_zero_point"]]),
+                         [k["output_scale"]], [k["output_zero_point"]])
+    assert out.buffer.tolist() == k["output"]      # sum over the WHOLE 2x3 tensor
+
+
+def test_reshape_layer(mf, kats):
+    k = kats["reshape_layer"]
+    out = mf.ops.reshape(mf.Tensor2D(np.array(k["input"], np.int8), [0.7], [8]), k["output_shape"])
+    assert out.buffer.tolist() == k["output"] and isinstance(out, mf.Tensor4D)
+
+
+def test_quantize_dequantize(mf, kats, O):
+    k = kats["tensor_2d"]
+    q = mf.ops.quantize(np.array(k["buffer"], f32), k["scale"], k["zero_point"])
+    assert q.tolist() == k["quantized"]
+    d = mf.ops.dequantize(np.array(k["quantized"], np.int8), k["scale"], k["zero_point"])
+    assert np.array_equal(d, np.array(k["dequantized"], f32))
+    k4 = kats["tensor_4d"]
+    q = mf.ops.quantize(np.array(k4["buffer"], f32), k4["scale"], k4["zero_point"])
+    assert q.tolist() == k4["quantized"]
+    k = kats["quantize_value"]
+    assert mf.ops.quantize(np.array([k["value"]], f32), k["scale"], k["zero_point"]).tolist() == [k["quantized"]]
+    # random + adversarial values (ties, saturation, the pred(0.5) case, odd lengths)
+    rng = np.random.default_rng(1)
+    x = np.concatenate([rng.normal(0, 3, 4099).astype(f32),
+                        np.array([0.5, -0.5, 1.5, 2.5, -2.5, 0.49999997, -0.49999997, 1e9, -1e9, 0.0], f32)])
+    for scale, zp in ((0.0078431377, -1), (0.1, 3), (1.0, 0), (0.0235294122, -128)):
+        got = mf.ops.quantize(x, scale, zp)
+        want = O.quantize_array(x, scale, zp)
+        assert np.array_equal(got, want), (scale, zp)
+        qq = rng.integers(-128, 128, 1001).astype(np.int8)
+        dg = mf.ops.dequantize(qq, scale, zp)
+        dw = np.array([O.dequantize(v, scale, zp) for v in qq], f32)
+        assert np.array_equal(dg.view(np.uint32), dw.view(np.uint32))
+
+
+# ---- randomized parity vs the oracle ------------------------------------------------
+def _rand_consts(rng, n, taps, per_channel=True):
+    c0 = rng.uniform(-30, 30, n).astype(f32)
+    s = 40.0 / (5476.0 * np.sqrt(taps))
+    c1 = (rng.uniform(0.5, 1.5, n if per_channel else 1) * s).astype(f32)
+    return c0, c1
+
+
+DW_CASES = [
+    # H, W, Cin, C, KH, KW, sh, sw, pad, OH, OW, wzp_nonzero, act
+    (48, 48, 8, 8, 3, 3, 1, 1, 0, 48, 48, False, 3),
+    (48, 48, 16, 16, 3, 3, 2, 2, 0, 24, 24, False, 3),
+    (24, 24, 32, 32, 3, 3, 1, 1, 0, 24, 24, False, 3),
+    (24, 24, 32, 32, 3, 3, 2, 2, 0, 12, 12, False, 1),
+    (12, 12, 64, 64, 3, 3, 1, 1, 0, 12, 12, False, 3),
+    (12, 12, 64, 64, 3, 3, 2, 2, 0, 6, 6, False, 0),
+    (6, 6, 128, 128, 3, 3, 1, 1, 0, 6, 6, False, 3),
+    (6, 6, 128, 128, 3, 3, 2, 2, 0, 3, 3, False, 3),
+    (3, 3, 256, 256, 3, 3, 1, 1, 0, 3, 3, False, 3),
+    (96, 96, 1, 8, 3, 3, 2, 2, 0, 48, 48, False, 3),     # stem
+    (49, 40, 1, 8, 10, 8, 2, 2, 0, 25, 20, False, 1),    # speech op 1
+    (7, 9, 3, 3, 3, 3, 1, 1, 0, 7, 9, True, 0),          # generic, non-zero weight zp
+    (8, 8, 4, 4, 2, 3, 1, 2, 1, 7, 3, True, 3),          # VALID, rectangular
+    (5, 6, 2, 6, 3, 3, 1, 1, 0, 5, 6, True, 0),          # channels beyond Cin read channel 0
+]
+
+
+@pytest.mark.parametrize("case", DW_CASES, ids=lambda c: "x".join(map(str, c[:8])))
+def test_depthwise_vs_oracle(mf, O, case):
+    H, W, Cin, C, KH, KW, sh, sw, pad, OH, OW, wzp_nz, act = case
+    rng = np.random.default_rng(hash(case) % (2 ** 32))
+    batch = 5
+    x = rng.integers(-128, 128, (batch, H, W, Cin)).astype(np.int8)
+    w = rng.integers(-128, 128, (KH, KW, C)).astype(np.int8)
+    wzp = rng.integers(-20, 20, C).astype(np.int8) if wzp_nz else np.zeros(C, np.int8)
+    izp = int(rng.integers(-128, 128))
+    oscale, ozp = 0.0235294122, int(rng.integers(-128, 0))
+    c0, c1 = _rand_consts(rng, C, KH * KW)
+    opts = mf.ops.DepthwiseConv2DOptions(mf.FusedActivation(act), mf.TensorViewPadding(pad), (sh, sw))
+    op = mf.ops.prepare_depthwise_conv_2d((H, W, Cin), w, wzp, izp, oscale, ozp, opts, (c0, c1), (OH, OW))
+    want = np.stack([O.depthwise_conv_2d(x[i], w, wzp, izp, oscale, ozp, act, pad, (sh, sw), (OH, OW),
+                                         c0, c1) for i in range(batch)])
+    got = op(x)
+    assert np.array_equal(got, want), (op.kernel, np.argwhere(got != want)[:5])
+    if op.kernel != "dwconv_generic":  # the shape-generic kernel must agree as well
+        fast_kernel = op.kernel
+        op.set_generic(True)
+        assert op.kernel == "dwconv_generic"
+        assert np.array_equal(op(x), want), fast_kernel
+
+
+PW_CASES = [(48, 48, 8, 16), (24, 24, 16, 32), (24, 24, 32, 32), (12, 12, 32, 64), (12, 12, 64, 64),
+            (6, 6, 64, 128), (6, 6, 128, 128), (3, 3, 128, 256), (3, 3, 256, 256), (1, 1, 256, 2)]
+
+
+@pytest.mark.parametrize("case", PW_CASES, ids=lambda c: "x".join(map(str, c)))
+@pytest.mark.parametrize("batch", [1, 3, 37])
+def test_pointwise_conv_vs_oracle(mf, O, case, batch):
+    H, W, C, N = case
+    rng = np.random.default_rng(hash(case) % (2 ** 32) + batch)
+    x = rng.integers(-128, 128, (batch, H, W, C)).astype(np.int8)
+    f = rng.integers(-128, 128, (N, 1, 1, C)).astype(np.int8)
+    fzp = np.zeros(N, np.int8)
+    izp, oscale, ozp, act = -128, 0.0235294122, -128, 3
+    c0, c1 = _rand_consts(rng, N, C)
+    opts = mf.ops.Conv2DOptions(mf.FusedActivation(act), mf.TensorViewPadding.SAME, (1, 1))
+    op = mf.ops.prepare_conv_2d((H, W, C), f, fzp, izp, oscale, ozp, opts, (c0, c1), (H, W))
+    if N % 16 == 0:
+        assert op.kernel.startswith("pw_mfma"), op.kernel
+    want = np.stack([O.conv_2d(x[i], f, fzp, izp, oscale, ozp, act, 0, (1, 1), (H, W), c0, c1)
+                     for i in range(batch)])
+    got = op(x)
+    assert np.array_equal(got, want), (op.kernel, np.argwhere(got != want)[:5])
+    op.set_generic(True)
+    assert np.array_equal(op(x), want)
+
+
+CONV_CASES = [
+    # H, W, C, N, KH, KW, sh, sw, pad, OH, OW, per_channel_zp
+    (6, 7, 3, 5, 3, 3, 1, 1, 0, 6, 7, True),
+    (9, 9, 4, 8, 3, 3, 2, 2, 0, 5, 5, True),
+    (8, 8, 2, 3, 2, 3, 1, 1, 1, 7, 6, False),
+    (5, 5, 16, 16, 1, 1, 1, 1, 0, 5, 5, True),    # 1x1 but non-zero filter zp -> generic
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "x".join(map(str, c[:8])))
+def test_conv_generic_vs_oracle(mf, O, case):
+    H, W, C, N, KH, KW, sh, sw, pad, OH, OW, pc = case
+    rng = np.random.default_rng(hash(case) % (2 ** 32))
+    batch = 4
+    x = rng.integers(-128, 128, (batch, H, W, C)).astype(np.int8)
+    f = rng.integers(-128, 128, (N, KH, KW, C)).astype(np.int8)
+    fzp = rng.integers(-30, 30, N if pc else 1).astype(np.int8)
+    izp, oscale, ozp, act = int(rng.integers(-128, 128)), 0.05, int(rng.integers(-100, 100)), 1
+    c0, c1 = _rand_consts(rng, N, KH * KW * C, per_channel=pc)
+    opts = mf.ops.Conv2DOptions(mf.FusedActivation(act), mf.TensorViewPadding(pad), (sh, sw))
+    op = mf.ops.prepare_conv_2d((H, W, C), f, fzp, izp, oscale, ozp, opts, (c0, c1), (OH, OW))
+    assert op.kernel == "conv2d_generic"
+    want = np.stack([O.conv_2d(x[i], f, fzp, izp, oscale, ozp, act, pad, (sh, sw), (OH, OW), c0, c1)
+                     for i in range(batch)])
+    assert np.array_equal(op(x), want)
+
+
+@pytest.mark.parametrize("case", [(3, 3, 256, 3, 3, 2, 2, 1, 1, 1), (6, 8, 5, 2, 3, 1, 1, 0, 6, 8),
+                                  (7, 7, 4, 3, 3, 2, 2, 0, 4, 4)],
+                         ids=lambda c: "x".join(map(str, c)))
+def test_average_pool_vs_oracle(mf, O, case):
+    H, W, C, FH, FW, sh, sw, pad, OH, OW = case
+    rng = np.random.default_rng(7)
+    batch = 6
+    x = rng.integers(-128, 128, (batch, H, W, C)).astype(np.int8)
+    iscale, izp, oscale, ozp = 0.0235294122, -128, 0.0186093301, -128
+    c0, c1 = O.preprocess_average_pool_2d(iscale, izp, oscale, ozp)
+    for act in (0, 1, 3):
+        opts = mf.ops.AveragePool2DOptions(mf.FusedActivation(act), mf.TensorViewPadding(pad), (sh, sw))
+        op = mf.ops.prepare_average_pool_2d((H, W, C), (FH, FW), oscale, ozp, opts, (c0, c1), (OH, OW))
+        want = np.stack([O.average_pool_2d(x[i], (FH, FW), oscale, ozp, act, pad, (sh, sw), (OH, OW), c0, c1)
+                         for i in range(batch)])
+        assert np.array_equal(op(x), want), act
+
+
+@pytest.mark.parametrize("case", [(1, 1, 16, 0), (1, 16, 16, 0), (1, 16, 1, 5), (1, 4000, 4, 0),
+                                  (3, 37, 11, -7), (2, 512, 8, 3), (1, 4096, 2, 0)],
+                         ids=lambda c: "x".join(map(str, c)))
+def test_fully_connected_vs_oracle(mf, O, case):
+    M, K, N, wzp = case
+    rng = np.random.default_rng(K * 131 + N)
+    batch = 9
+    x = rng.integers(-128, 128, (batch, M, K)).astype(np.int8)
+    w = rng.integers(-128, 128, (N, K)).astype(np.int8)
+    bias = rng.integers(-2000, 2000, N).astype(np.int32)
+    iscale, izp, wscale, oscale, ozp = 0.05, int(rng.integers(-128, 128)), 0.01, 0.05 * np.sqrt(K), 14
+    c0, c1, c2, c3 = O.preprocess_fully_connected(iscale, izp, K, w, wscale, wzp, bias, iscale * wscale, 0, oscale)
+    for act in (0, 1):
+        op = mf.ops.prepare_fully_connected(M, w, wzp, oscale, ozp, mf.ops.FullyConnectedOptions(mf.FusedActivation(act)),
+                                            (c0, c1, c2, c3))
+        want = np.stack([O.fully_connected(x[i], w, wzp, oscale, ozp, act, c0, c1, c2, c3) for i in range(batch)])
+        got = op(x)
+        assert np.array_equal(got, want), (op.kernel, act)
+        if op.kernel != "fc_generic":
+            op.set_generic(True)
+            assert np.array_equal(op(x), want)
+
+
+def test_softmax_vs_oracle(mf, O):
+    rng = np.random.default_rng(3)
+    for rows, cols, iscale, oscale, ozp in ((1, 4, 0.0917319208, 1 / 256, -128), (1, 2, 0.0125187514, 1 / 256, -128),
+                                            (2, 3, 0.7, 0.9, 10), (1, 10, 0.3, 1 / 256, -128)):
+        x = rng.integers(-128, 128, (300, rows, cols)).astype(np.int8)
+        op = mf.ops.prepare_softmax(rows, cols, iscale, oscale, ozp)
+        want = np.stack([O.softmax(x[i], iscale, oscale, ozp) for i in range(x.shape[0])])
+        assert np.array_equal(op(x), want), (rows, cols)
+
+
+def test_softmax_every_int8_pair(mf, O):
+    """All 65536 (a, b) int8 pairs for person_detect's 2-class softmax: exhaustive parity."""
+    a, b = np.meshgrid(np.arange(-128, 128), np.arange(-128, 128), indexing="ij")
+    x = np.stack([a.reshape(-1), b.reshape(-1)], -1).astype(np.int8).reshape(-1, 1, 2)
+    op = mf.ops.prepare_softmax(1, 2, 0.0125187514, 1 / 256, -128)
+    got = op(x)
+    idx = np.random.default_rng(0).choice(x.shape[0], 4096, replace=False)
+    want = np.stack([O.softmax(x[i], 0.0125187514, 1 / 256, -128) for i in idx])
+    assert np.array_equal(got[idx], want)
+
+
+def test_device_tensors_stay_on_device(mf):
+    import torch
+    x = torch.randint(-128, 128, (4, 6, 6, 128), dtype=torch.int8, device="cuda")
+    w = np.ones((3, 3, 128), np.int8)
+    opts = mf.ops.DepthwiseConv2DOptions(mf.FusedActivation.RELU6, mf.TensorViewPadding.SAME, (1, 1))
+    op = mf.ops.prepare_depthwise_conv_2d((6, 6, 128), w, np.zeros(1, np.int8), -128, 0.02, -128, opts,
+                                          (np.zeros(128, f32), np.full(1, 0.01, f32)), (6, 6))
+    y = op(x)
+    assert isinstance(y, torch.Tensor) and y.is_cuda and y.shape == (4, 6, 6, 128)
