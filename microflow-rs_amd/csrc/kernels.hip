@@ -27,6 +27,10 @@ namespace mf {
 namespace k {
 
 typedef int v4i __attribute__((ext_vector_type(4)));
+// native vector type for register-resident staging arrays: arrays of HIP's struct-based
+// uint4 that are conditionally re-assigned are NOT promoted to registers by hipcc (they
+// end up in scratch memory); ext_vector_type arrays are.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------------
 // shared device helpers
@@ -331,23 +335,44 @@ __global__ __launch_bounds__(256) void checksum_i8(const int8_t *__restrict__ in
 }
 
 // ------------------------------------------------------------------------
+// HBM -> LDS staging for the depthwise kernels: LDS-DMA (`global_load_lds_dwordx4`,
+// gfx950), 16 bytes per lane straight into LDS with no VGPR round trip.
+//
+// Why not registers: (1) a predicated register prefetch makes hipcc branch around every
+// element and wait vmcnt(0) after each one; (2) an array of HIP's struct-based uint4 that
+// is conditionally re-assigned is not promoted to registers (it went to scratch); (3) even
+// with both fixed, hipcc flushed vmcnt(0) in the pre-header of the compute loop, i.e. the
+// prefetch never overlapped the compute.  A DMA has no destination register, so nothing
+// waits on it except the one explicit `s_waitcnt vmcnt(0)` + barrier per step below.
+// The LDS destination of a DMA instruction is wave-uniform base + lane * 16.
+// ------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void gbl_void_t;
+
+__device__ __forceinline__ void dma16(const int8_t *src_lane, uint8_t *lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((gbl_void_t *)src_lane, (lds_void_t *)lds_wave_base, 16, 0, 0);
+}
+
+// ------------------------------------------------------------------------
 // FAST PATH 1 -- DepthwiseConv2D 3x3, SAME, NHWC, C % 4 == 0, weight zp == 0.
 // (src/ops/depthwise_conv_2d.rs:28-105; person_detect ops 1,3,5,...,25)
 //
 // HBM-bound by construction: every input byte is read from HBM once, every output
-// byte written once.  One workgroup owns G whole images per step:
-//   fill   : 16-byte coalesced global loads of the G contiguous NHWC images into an LDS
-//            tile whose 1-pixel halo ring was pre-filled with izp (padding == izp makes
-//            border pixels identical to interior ones).  The loads of step i+1 are
-//            issued before the compute of step i and land in registers (prefetch).
+// byte written once.  One workgroup owns G whole images per step and double-buffers
+// them in LDS:
+//   stage  : one DMA instruction per image row (W*C <= 1 KiB) into an LDS tile whose
+//            1-pixel halo ring was pre-filled with izp once (padding == izp makes border
+//            pixels identical to interior ones).  The DMAs of step i+1 are issued right
+//            after the barrier of step i and fly during its compute.
 //   compute: lane = (pixel, 4-channel group).  The 4-channel group of a lane never
 //            changes, so its 9 tap-weight dwords live in VGPRs as 36 byte-masked
-//            copies: acc[k] += sdot4(v, w & (0xff << 8k)) is one full-rate VALU op per
-//            MAC with no unpacking of either operand.
+//            copies: acc[k] += sdot4(v, w & (0xff << 8k)) is one VALU op per MAC with
+//            no unpacking of either operand.
 //   store  : one dword (4 channels) per lane, consecutive lanes = consecutive addresses.
-// LDS row layout: [LP pad][W*C bytes][LP pad], LP = max(C,16), so every 16-byte fill
-// store is 16-byte aligned (MI355X guide, G17) and tap (ky,kx) of a lane is a constant
-// offset ky*ROW + kx*C from its base address.
+// LDS row layout: [LP pad][W*C bytes][LP pad], LP = max(C,16): rows start 16-byte
+// aligned and tap (ky,kx) of a lane is the constant offset ky*ROW + kx*C from its base.
+// One barrier per step: after it, every wave has finished reading the other buffer
+// (safe to overwrite) and every wave's DMAs into this buffer have landed.
 // ------------------------------------------------------------------------
 template <int H, int W, int C, int S, int G>
 __global__ __launch_bounds__(256) void dw3x3_nhwc(const int8_t *__restrict__ in,
@@ -356,22 +381,25 @@ __global__ __launch_bounds__(256) void dw3x3_nhwc(const int8_t *__restrict__ in,
     constexpr int C4 = C / 4;
     constexpr int OH = (H + S - 1) / S, OW = (W + S - 1) / S;
     constexpr int LP = C < 16 ? 16 : C;
-    constexpr int ROW = LP + W * C + LP;          // bytes per LDS row
+    constexpr int ROWB = W * C;                   // payload bytes per image row
+    constexpr int ROW = LP + ROWB + LP;           // bytes per LDS row
     constexpr int TILE = (H + 2) * ROW;           // bytes per image tile (1 halo row above/below)
-    constexpr int IMG = H * W * C;                // bytes per input image
-    constexpr int CHUNKS = G * IMG / 16;          // 16-byte chunks per step
-    constexpr int NPRE = (CHUNKS + 255) / 256;    // prefetch registers (uint4) per thread
-    constexpr int ROWCH = W * C / 16;             // chunks per image row
+    constexpr int BUF = G * TILE;                 // one staging buffer (two are allocated)
+    constexpr int IMG = H * ROWB;                 // bytes per input image
+    constexpr int ROWCH = ROWB / 16;              // 16-byte chunks (= DMA lanes) per row
+    constexpr int NROWS = G * H;                  // DMA instructions per step
     constexpr int OUTS = G * OH * OW * C4;        // output dwords per step
     constexpr int NOUT = (OUTS + 255) / 256;
     static_assert(256 % C4 == 0, "channel group of a lane must be loop-invariant");
-    static_assert((W * C) % 16 == 0 && IMG % 16 == 0, "rows must be whole 16-byte chunks");
+    static_assert(ROWB % 16 == 0 && ROWCH <= 64, "one DMA instruction per row");
 
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-    // halo ring (and everything else) := izp, once; the fill only ever rewrites interiors
-    for (int i = tid; i < G * TILE / 16; i += 256)
+    // both buffers := izp, once; the DMAs only ever rewrite the interiors
+    for (int i = tid; i < 2 * BUF / 16; i += 256)
         ((uint4 *)lds)[i] = make_uint4(p.izp4, p.izp4, p.izp4, p.izp4);
 
     // per-lane constants of this lane's channel group
@@ -385,39 +413,30 @@ __global__ __launch_bounds__(256) void dw3x3_nhwc(const int8_t *__restrict__ in,
     }
     const float4 A = ((const float4 *)p.A)[cg], Sc = ((const float4 *)p.S)[cg];
     const int4 Kc = ((const int4 *)p.Kc)[cg];
+    __syncthreads(); // halo fill complete before any DMA lands
 
-    const int nsteps = (batch + G - 1) / G;
-    int step = blockIdx.x;
-    uint4 pre[NPRE];
-    auto prefetch = [&](int st) {
-        const uint4 *src = (const uint4 *)(in + (size_t)st * G * IMG);
-        const int valid = min(G, batch - st * G) * (IMG / 16); // chunks that exist
+    auto stage = [&](int st, int buf) {
 #pragma unroll
-        for (int j = 0; j < NPRE; ++j) {
-            const int q = tid + 256 * j;
-            if (q < valid) pre[j] = src[q];
+        for (int k = 0; k < (NROWS + 3) / 4; ++k) {
+            const int r = k * 4 + wave;           // wave-uniform row of the step
+            const int g = r / H, y = r % H;
+            if (r < NROWS && st * G + g < batch && lane < ROWCH)
+                dma16(in + ((size_t)(st * G + g) * IMG + y * ROWB + lane * 16),
+                      lds + buf * BUF + g * TILE + (y + 1) * ROW + LP);
         }
     };
-    if (step < nsteps) prefetch(step);
-    __syncthreads();
 
-    for (; step < nsteps; step += gridDim.x) {
-        // ---- fill: registers -> LDS interiors ----
-        const int valid = min(G, batch - step * G) * (IMG / 16);
-#pragma unroll
-        for (int j = 0; j < NPRE; ++j) {
-            const int q = tid + 256 * j;
-            if (q < CHUNKS && q < valid) {
-                const int g = q / (IMG / 16), r = q % (IMG / 16);
-                const int y = r / ROWCH, xc = r % ROWCH;
-                *(uint4 *)(lds + g * TILE + (y + 1) * ROW + LP + xc * 16) = pre[j];
-            }
-        }
-        __syncthreads();
+    const int nsteps = (batch + G - 1) / G;
+    int step = blockIdx.x, cur = 0;
+    if (step < nsteps) stage(step, 0);
+
+    for (; step < nsteps; step += gridDim.x, cur ^= 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's DMAs (and old stores) done
+        __syncthreads();                                  // ... and everyone else's
         const int next = step + gridDim.x;
-        if (next < nsteps) prefetch(next); // in flight during the compute below
+        if (next < nsteps) stage(next, cur ^ 1);          // flies during the compute below
 
-        // ---- compute + store ----
+        const uint8_t *tile = lds + cur * BUF;
         uint32_t *dst = (uint32_t *)out + (size_t)step * G * OH * OW * C4;
         const int nvalid = min(G, batch - step * G) * OH * OW * C4;
 #pragma unroll 2
@@ -428,7 +447,7 @@ __global__ __launch_bounds__(256) void dw3x3_nhwc(const int8_t *__restrict__ in,
                 const int g = pix / (OH * OW), rem = pix % (OH * OW);
                 const int oy = rem / OW, ox = rem % OW;
                 // tap (ky,kx): row oy*S + ky (halo row 0 == input row -1), col ox*S + kx - 1
-                const uint8_t *base = lds + g * TILE + (oy * S) * ROW + LP + (ox * S - 1) * C + cg * 4;
+                const uint8_t *base = tile + g * TILE + (oy * S) * ROW + LP + (ox * S - 1) * C + cg * 4;
                 int a0 = Kc.x, a1 = Kc.y, a2 = Kc.z, a3 = Kc.w;
 #pragma unroll
                 for (int ky = 0; ky < 3; ++ky)
@@ -448,7 +467,6 @@ __global__ __launch_bounds__(256) void dw3x3_nhwc(const int8_t *__restrict__ in,
                 dst[o] = pack4(q0, q1, q2, q3);
             }
         }
-        __syncthreads(); // everyone done reading before the next fill overwrites
     }
 }
 
@@ -461,7 +479,9 @@ __global__ __launch_bounds__(256) void dw3x3_nhwc(const int8_t *__restrict__ in,
 // 16-byte store.  Per filter row it reads two LDS dwords, builds the two 3-tap
 // windows with one v_perm and one shift, and issues one sdot4 per (pixel, channel,
 // row) against wave-uniform weight dwords [w(ky,0,c), w(ky,1,c), w(ky,2,c), 0] that
-// live in SGPRs.
+// live in SGPRs.  Staging: the image is copied verbatim (contiguous 1 KiB DMAs) between
+// two izp rows; the only tap that is not covered by those rows, column -1 of the first
+// pixel pair, is patched with a select.
 // ------------------------------------------------------------------------
 template <int H, int W, int G>
 __global__ __launch_bounds__(256) void dw3x3_stem8(const int8_t *__restrict__ in,
@@ -469,53 +489,46 @@ __global__ __launch_bounds__(256) void dw3x3_stem8(const int8_t *__restrict__ in
                                                    int batch) {
     constexpr int DM = 8, S = 2;
     constexpr int OH = (H + S - 1) / S, OW = (W + S - 1) / S;
-    constexpr int LP = 16;
-    constexpr int ROW = LP + W + LP;
-    constexpr int TILE = (H + 2) * ROW;
+    constexpr int GUARD = 16;                     // the j == 0 lanes read 4 bytes before a row
+    constexpr int TILE = GUARD + (H + 2) * W;     // [guard][izp row][H rows][izp row]
+    constexpr int BUF = G * TILE;
     constexpr int IMG = H * W;
-    constexpr int CHUNKS = G * IMG / 16;
-    constexpr int NPRE = (CHUNKS + 255) / 256;
-    constexpr int ROWCH = W / 16;
+    constexpr int NI = IMG / 1024;                // 1 KiB DMA instructions per image
     constexpr int PAIRS = OW / 2;                 // lane tasks per output row
     constexpr int TASKS = G * OH * PAIRS;
     constexpr int NTASK = (TASKS + 255) / 256;
-    static_assert(W % 16 == 0 && OW % 2 == 0, "stem geometry");
+    static_assert(IMG % 1024 == 0 && W % 16 == 0 && OW % 2 == 0 && TILE % 16 == 0, "stem geometry");
 
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int tid = threadIdx.x;
-    for (int i = tid; i < G * TILE / 16; i += 256)
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int i = tid; i < 2 * BUF / 16; i += 256)
         ((uint4 *)lds)[i] = make_uint4(p.izp4, p.izp4, p.izp4, p.izp4);
-
-    const int nsteps = (batch + G - 1) / G;
-    int step = blockIdx.x;
-    uint4 pre[NPRE];
-    auto prefetch = [&](int st) {
-        const uint4 *src = (const uint4 *)(in + (size_t)st * G * IMG);
-        const int valid = min(G, batch - st * G) * (IMG / 16);
-#pragma unroll
-        for (int j = 0; j < NPRE; ++j) {
-            const int q = tid + 256 * j;
-            if (q < valid) pre[j] = src[q];
-        }
-    };
-    if (step < nsteps) prefetch(step);
     __syncthreads();
 
-    for (; step < nsteps; step += gridDim.x) {
-        const int valid = min(G, batch - step * G) * (IMG / 16);
+    auto stage = [&](int st, int buf) {
 #pragma unroll
-        for (int j = 0; j < NPRE; ++j) {
-            const int q = tid + 256 * j;
-            if (q < CHUNKS && q < valid) {
-                const int g = q / (IMG / 16), r = q % (IMG / 16);
-                const int y = r / ROWCH, xc = r % ROWCH;
-                *(uint4 *)(lds + g * TILE + (y + 1) * ROW + LP + xc * 16) = pre[j];
-            }
+        for (int k = 0; k < (G * NI + 3) / 4; ++k) {
+            const int r = k * 4 + wave;           // wave-uniform 1 KiB piece of the step
+            const int g = r / NI, c = r % NI;
+            if (r < G * NI && st * G + g < batch)
+                dma16(in + ((size_t)(st * G + g) * IMG + c * 1024 + lane * 16),
+                      lds + buf * BUF + g * TILE + GUARD + W + c * 1024);
         }
+    };
+
+    const int nsteps = (batch + G - 1) / G;
+    int step = blockIdx.x, cur = 0;
+    if (step < nsteps) stage(step, 0);
+
+    for (; step < nsteps; step += gridDim.x, cur ^= 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         const int next = step + gridDim.x;
-        if (next < nsteps) prefetch(next);
+        if (next < nsteps) stage(next, cur ^ 1);
 
+        const uint8_t *tile = lds + cur * BUF;
         uint4 *dst = (uint4 *)out + (size_t)step * G * OH * PAIRS;
         const int nvalid = min(G, batch - step * G) * OH * PAIRS;
 #pragma unroll 1
@@ -524,13 +537,15 @@ __global__ __launch_bounds__(256) void dw3x3_stem8(const int8_t *__restrict__ in
             if (o < TASKS && o < nvalid) {
                 const int g = o / (OH * PAIRS), rem = o % (OH * PAIRS);
                 const int oy = rem / PAIRS, j = rem % PAIRS;
-                // pixels ox = 2j, 2j+1 need input cols 4j-1 .. 4j+3 of rows 2oy-1 .. 2oy+1:
-                // LDS dwords (LP + 4j - 4)/4 and (LP + 4j)/4 of tile rows 2oy .. 2oy+2
-                const uint32_t *rowp = (const uint32_t *)(lds + g * TILE + (oy * S) * ROW + LP + 4 * j - 4);
+                // pixels ox = 2j, 2j+1 need input cols 4j-1 .. 4j+3 of rows 2oy-1 .. 2oy+1 =
+                // tile rows 2oy .. 2oy+2 (tile row 0 is the izp row): dwords at cols 4j-4 and 4j
+                const uint32_t *rowp = (const uint32_t *)(tile + g * TILE + GUARD + (oy * S) * W + 4 * j - 4);
                 uint32_t ta[3], tb[3];
 #pragma unroll
                 for (int ky = 0; ky < 3; ++ky) {
-                    const uint32_t d0 = rowp[ky * (ROW / 4)], d1 = rowp[ky * (ROW / 4) + 1];
+                    uint32_t d0 = rowp[ky * (W / 4)];
+                    const uint32_t d1 = rowp[ky * (W / 4) + 1];
+                    d0 = j == 0 ? p.izp4 : d0;                          // column -1 is padding
                     ta[ky] = __builtin_amdgcn_perm(d0, d1, 0x0c010007u); // [d0.b3, d1.b0, d1.b1, 0]
                     tb[ky] = d1 >> 8;                                    // [d1.b1, d1.b2, d1.b3, 0]
                 }
@@ -554,7 +569,6 @@ __global__ __launch_bounds__(256) void dw3x3_stem8(const int8_t *__restrict__ in
                 dst[o] = v;
             }
         }
-        __syncthreads();
     }
 }
 
@@ -736,15 +750,18 @@ void launch_checksum(const int8_t *in, size_t n, unsigned long long *result, hip
 template <int H, int W, int C, int S, int G>
 static void launch_dw(const int8_t *in, int8_t *out, const DwFastArgs &a, int batch, hipStream_t s) {
     constexpr int LP = C < 16 ? 16 : C;
-    constexpr int lds = G * (H + 2) * (LP + W * C + LP);
+    constexpr int lds = 2 * G * (H + 2) * (LP + W * C + LP); // two staging buffers
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void *)dw3x3_nhwc<H, W, C, S, G>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
+    // persistent workgroups: exactly as many as are resident (LDS- or VGPR-limited), so
+    // that every workgroup walks the same number of steps
+    constexpr int by_lds = 163840 / lds, per_cu = by_lds < 1 ? 1 : (by_lds > 5 ? 5 : by_lds);
     const int nsteps = (batch + G - 1) / G;
-    const int grid = nsteps < 256 * 4 ? nsteps : 256 * 4;
+    const int grid = nsteps < 256 * per_cu ? nsteps : 256 * per_cu;
     hipLaunchKernelGGL((dw3x3_nhwc<H, W, C, S, G>), dim3(grid), dim3(256), lds, s, in, out, a, batch);
 }
 
@@ -774,9 +791,9 @@ const char *dw_stem_name(int H, int W, int DM, int S) {
 bool launch_dw_stem(int H, int W, int DM, int S, const int8_t *in, int8_t *out, const DwStemArgs &a,
                     int batch, hipStream_t s) {
     if (H == 96 && W == 96 && DM == 8 && S == 2) {
-        constexpr int G = 2, lds = G * (96 + 2) * (16 + 96 + 16);
+        constexpr int G = 2, lds = 2 * G * (16 + (96 + 2) * 96);
         const int nsteps = (batch + G - 1) / G;
-        const int grid = nsteps < 256 * 4 ? nsteps : 256 * 4;
+        const int grid = nsteps < 256 * 4 ? nsteps : 256 * 4; // 37.7 KB LDS -> 4 resident per CU
         hipLaunchKernelGGL((dw3x3_stem8<96, 96, G>), dim3(grid), dim3(256), lds, s, in, out, a, batch);
         return true;
     }

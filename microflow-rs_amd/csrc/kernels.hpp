@@ -73,11 +73,11 @@ struct PwArgs {
     X(48, 48, 16, 2, 1) \
     X(24, 24, 32, 1, 1) \
     X(24, 24, 32, 2, 1) \
-    X(12, 12, 64, 1, 2) \
+    X(12, 12, 64, 1, 1) \
     X(12, 12, 64, 2, 2) \
-    X(6, 6, 128, 1, 4)  \
+    X(6, 6, 128, 1, 2)  \
     X(6, 6, 128, 2, 4)  \
-    X(3, 3, 256, 1, 8)
+    X(3, 3, 256, 1, 4)
 
 // (K = input channels, N = output channels) with a compiled pointwise MFMA kernel
 #define MF_PW_SHAPES(X) \

@@ -1,0 +1,81 @@
+// Microbenchmark: sustained wave-instruction rates on gfx950 for the ops the epilogue
+// and the depthwise inner loop are made of.  Prints lane-ops/s and the rate relative to
+// v_fma_f32.  Build: hipcc --offload-arch=gfx950 -O3 valu_rates.hip -o valu_rates
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+#include <vector>
+
+#define ITERS 2048
+#define NACC 8
+
+template <int OP>
+__global__ __launch_bounds__(256) void bench(uint32_t *out, uint32_t seed) {
+    uint32_t a[NACC];
+    float f[NACC];
+    const uint32_t t = threadIdx.x + seed;
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) { a[i] = t * (i + 3) + 1; f[i] = (float)(t + i) * 0.001f; }
+    uint32_t w = t * 2654435761u | 1u;
+    float g = 1.0001f, h = 0.49999997f;
+    __shared__ uint32_t lds[4096];
+    if (OP == 10 || OP == 11) { for (int i = threadIdx.x; i < 4096; i += 256) lds[i] = i * seed; __syncthreads(); }
+    for (int it = 0; it < ITERS; ++it) {
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) {
+            if (OP == 0) f[i] = __builtin_fmaf(f[i], g, h);
+            if (OP == 1) a[i] = (uint32_t)__builtin_amdgcn_sdot4((int)a[i], (int)w, (int)a[i], false);
+            if (OP == 2) a[i] = __builtin_amdgcn_perm(a[i], w, 0x05040100u + i);
+            if (OP == 3) f[i] = __fmul_rn(f[i], g);
+            if (OP == 4) f[i] = __fadd_rn(f[i], h);
+            if (OP == 5) { f[i] = (float)(int)a[i]; a[i] += (uint32_t)f[i]; }            // cvt_f32_i32 + cvt back + add (3 ops)
+            if (OP == 6) f[i] = __builtin_amdgcn_fmed3f(f[i], g, h);
+            if (OP == 7) f[i] = __builtin_copysignf(h, f[i]) ;
+            if (OP == 8) a[i] = a[i] * w + 7u;                                            // v_mad_u32_u24? (mul_lo + add)
+            if (OP == 9) a[i] = (uint32_t)(((int)(a[i] << 8)) >> 24) + w;  // bfe
+            if (OP == 10) a[i] += lds[(a[i] + threadIdx.x) & 4095];                       // ds_read_b32 dependent
+            if (OP == 11) a[i] += lds[(threadIdx.x + i * 256 + it) & 4095];               // ds_read_b32 streaming
+            if (OP == 12) a[i] = (uint32_t)(((int)(a[i] << 8) >> 8) * ((int)(w << 8) >> 8)) + a[i]; // mad_i24
+            if (OP == 13) { int v = (int)f[i]; a[i] ^= (uint32_t)v; }                       // cvt_i32_f32 + xor
+        }
+        if (OP == 7) { h = -h; }
+    }
+    uint32_t r = 0;
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) r ^= a[i] ^ __float_as_uint(f[i]);
+    if (r == 0x12345678u) out[0] = r;
+}
+
+template <int OP> double run(const char *name, double ops_per_iter, double base) {
+    uint32_t *d; hipMalloc(&d, 4);
+    const int grid = 256 * 8;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(bench<OP>, dim3(grid), dim3(256), 0, 0, d, 1u);
+    hipEventRecord(e0);
+    for (int r = 0; r < 5; ++r) hipLaunchKernelGGL(bench<OP>, dim3(grid), dim3(256), 0, 0, d, 2u + r);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    const double laneops = 5.0 * grid * 256.0 * ITERS * NACC * ops_per_iter;
+    const double rate = laneops / (ms * 1e-3);
+    printf("%-28s %8.2f T lane-ops/s  (%.2fx fma)  %.3f ms\n", name, rate / 1e12, base > 0 ? rate / base : 1.0, ms / 5);
+    hipFree(d);
+    return rate;
+}
+
+int main() {
+    double b = run<0>("v_fma_f32", 1, 0);
+    run<1>("v_dot4_i32_i8", 1, b);
+    run<2>("v_perm_b32", 1, b);
+    run<3>("v_mul_f32", 1, b);
+    run<4>("v_add_f32", 1, b);
+    run<5>("cvt_f32_i32+cvt_u32+add", 3, b);
+    run<6>("v_med3_f32", 1, b);
+    run<7>("v_bfi copysign", 1, b);
+    run<8>("mul_lo_u32 + add", 2, b);
+    run<9>("shl+ashr+add (bfe)", 3, b);
+    run<10>("ds_read_b32 dependent", 1, b);
+    run<11>("ds_read_b32 streaming", 1, b);
+    run<12>("v_mul_i24 + add (mad_i24)", 1, b);
+    run<13>("cvt_i32_f32 + xor", 2, b);
+    return 0;
+}
