@@ -605,7 +605,17 @@ __global__ __launch_bounds__(256) void pw_mfma(const int8_t *__restrict__ in,
     constexpr int Q = K < 64 ? 64 / K : 1;     // pixel groups per B register
     constexpr int CPIX = (K < 64) ? (1024 / K) : 16; // pixels per chunk
     constexpr int SLOTS = 4 / NSPLIT;          // pixel chunks processed concurrently per WG
+    // chunks per loop iteration: their loads are all issued before the first use, so a wave
+    // keeps U*KS KiB in flight (one 16-pixel chunk per iteration left HBM latency exposed)
+    constexpr int U = K >= 256 ? 2 : (K >= 64 ? 4 : 2);
+    // narrow outputs (N < 64) go through a per-wave LDS patch so that every global store is
+    // 16 bytes per lane and a wave writes whole contiguous KiB
+    constexpr bool XPOSE = TB < 4;
+    constexpr int CBYTES = CPIX * N;           // output bytes per chunk (XPOSE: 1 or 2 KiB)
     static_assert(N % 16 == 0 && (K == 8 || K % 16 == 0), "pw_mfma shape");
+    static_assert(!XPOSE || (NSPLIT == 1 && CBYTES % 1024 == 0), "transposed store geometry");
+
+    __shared__ __attribute__((aligned(16))) uint8_t patch[XPOSE ? 4 * CBYTES : 16];
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int pcol = lane & 15, g = lane >> 4;
@@ -633,9 +643,10 @@ __global__ __launch_bounds__(256) void pw_mfma(const int8_t *__restrict__ in,
     }
 
     const long long nchunks = (npix + CPIX - 1) / CPIX;
-    const long long stride = (long long)gridDim.x * SLOTS;
-    long long chunk = (long long)blockIdx.x * SLOTS + slot;
+    const long long stride = (long long)gridDim.x * SLOTS * U;
+    long long chunk0 = ((long long)blockIdx.x * SLOTS + slot) * U;
 
+    // loads are never predicated (clamped instead): see the depthwise staging notes
     auto loadB = [&](long long ch, v4i (&b)[KS]) {
         if constexpr (K >= 64) {
             long long pix = ch * 16 + pcol;
@@ -651,47 +662,75 @@ __global__ __launch_bounds__(256) void pw_mfma(const int8_t *__restrict__ in,
             long long pix = ch * CPIX + g * 16 + pcol;
             pix = pix < npix ? pix : npix - 1;
             b[0] = *(const v4i *)(in + pix * 16);
-        } else { // K == 8: 16 bytes = 2 pixels; npix is even whenever H*W is (routing precondition)
+        } else { // K == 8: 16 bytes = 2 pixels; npix is even (routing precondition)
             long long pix = ch * CPIX + 2 * (g * 16 + pcol);
             pix = pix + 1 < npix ? pix : npix - 2;
             b[0] = *(const v4i *)(in + pix * 8);
         }
     };
 
-    v4i B[KS], Bn[KS];
-    if (chunk < nchunks) loadB(chunk, B);
-    for (; chunk < nchunks; chunk += stride) {
-        const long long nxt = chunk + stride;
-        if (nxt < nchunks) loadB(nxt, Bn);
+    v4i B[U][KS], Bn[U][KS];
 #pragma unroll
-        for (int q = 0; q < Q; ++q) {
-            // pixel this lane's column belongs to for sub-group q
-            long long pix;
-            if constexpr (K >= 64) pix = chunk * 16 + pcol;
-            else if constexpr (K == 8) pix = chunk * CPIX + 2 * ((q >> 1) * 16 + pcol) + (q & 1);
-            else pix = chunk * CPIX + q * 16 + pcol;
-            uint32_t packed[TB];
+    for (int u = 0; u < U; ++u) loadB(min(chunk0 + u, nchunks - 1), B[u]);
+
+    for (; chunk0 < nchunks; chunk0 += stride) {
+        const long long nxt = chunk0 + stride;
 #pragma unroll
-            for (int tt = 0; tt < TB; ++tt) {
-                v4i acc = {0, 0, 0, 0};
+        for (int u = 0; u < U; ++u) loadB(min(nxt + u, nchunks - 1), Bn[u]); // harmless re-read at the tail
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks)
-                    acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(Aw[q][tt][ks], B[ks], acc, 0, 0, 0);
-                const int q0 = requant(acc[0] + cK[tt].x, cA[tt].x, cS[tt].x, p.lo_f, p.hi_f);
-                const int q1 = requant(acc[1] + cK[tt].y, cA[tt].y, cS[tt].y, p.lo_f, p.hi_f);
-                const int q2 = requant(acc[2] + cK[tt].z, cA[tt].z, cS[tt].z, p.lo_f, p.hi_f);
-                const int q3 = requant(acc[3] + cK[tt].w, cA[tt].w, cS[tt].w, p.lo_f, p.hi_f);
-                packed[tt] = pack4(q0, q1, q2, q3);
-            }
-            if (pix < npix) {
-                int8_t *dstp = out + pix * N + blk * NB + g * (NB / 4);
-                if constexpr (TB == 1) *(uint32_t *)dstp = packed[0];
-                else if constexpr (TB == 2) *(uint2 *)dstp = make_uint2(packed[0], packed[1]);
-                else *(uint4 *)dstp = make_uint4(packed[0], packed[1], packed[2], packed[3]);
+        for (int u = 0; u < U; ++u) {
+            const long long chunk = chunk0 + u;
+            if (chunk < nchunks) { // wave-uniform
+#pragma unroll
+                for (int q = 0; q < Q; ++q) {
+                    // pixel (within the chunk) this lane's MFMA column belongs to for sub-group q
+                    int lpix;
+                    if constexpr (K >= 64) lpix = pcol;
+                    else if constexpr (K == 8) lpix = 2 * ((q >> 1) * 16 + pcol) + (q & 1);
+                    else lpix = q * 16 + pcol;
+                    uint32_t packed[TB];
+#pragma unroll
+                    for (int tt = 0; tt < TB; ++tt) {
+                        v4i acc = {0, 0, 0, 0};
+#pragma unroll
+                        for (int ks = 0; ks < KS; ++ks)
+                            acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(Aw[q][tt][ks], B[u][ks], acc, 0, 0, 0);
+                        const int q0 = requant(acc[0] + cK[tt].x, cA[tt].x, cS[tt].x, p.lo_f, p.hi_f);
+                        const int q1 = requant(acc[1] + cK[tt].y, cA[tt].y, cS[tt].y, p.lo_f, p.hi_f);
+                        const int q2 = requant(acc[2] + cK[tt].z, cA[tt].z, cS[tt].z, p.lo_f, p.hi_f);
+                        const int q3 = requant(acc[3] + cK[tt].w, cA[tt].w, cS[tt].w, p.lo_f, p.hi_f);
+                        packed[tt] = pack4(q0, q1, q2, q3);
+                    }
+                    if constexpr (XPOSE) {
+                        uint8_t *dstp = patch + wave * CBYTES + lpix * N + g * (NB / 4);
+                        if constexpr (TB == 1) *(uint32_t *)dstp = packed[0];
+                        else *(uint2 *)dstp = make_uint2(packed[0], packed[1]);
+                    } else {
+                        const long long pix = chunk * CPIX + lpix;
+                        if (pix < npix)
+                            *(uint4 *)(out + pix * N + blk * NB + g * 16) =
+                                make_uint4(packed[0], packed[1], packed[2], packed[3]);
+                    }
+                }
+                if constexpr (XPOSE) {
+                    // same wave wrote the patch; LDS ops of a wave complete in order
+                    __builtin_amdgcn_wave_barrier();
+                    const long long obase = chunk * (long long)CBYTES;
+                    const long long obytes = npix * N;
+#pragma unroll
+                    for (int j = 0; j < CBYTES / 1024; ++j) {
+                        const int off = (j * 64 + lane) * 16;
+                        const uint4 v = *(const uint4 *)(patch + wave * CBYTES + off);
+                        if (obase + off < obytes) *(uint4 *)(out + obase + off) = v;
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
             }
         }
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) B[ks] = Bn[ks];
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) B[u][ks] = Bn[u][ks];
     }
 }
 
@@ -811,8 +850,9 @@ bool launch_pw(int K, int N, const int8_t *in, int8_t *out, const PwArgs &a, lon
 #define MF_PW(k, n)                                                                             \
     if (K == k && N == n) {                                                                     \
         constexpr int NB = n < 64 ? n : 64, SLOTS = 4 / (n / NB), CPIX = k < 64 ? 1024 / k : 16; \
+        constexpr int U = k >= 256 ? 2 : (k >= 64 ? 4 : 2);                                     \
         const long long nchunks = (npix + CPIX - 1) / CPIX;                                     \
-        long long grid = (nchunks + SLOTS - 1) / SLOTS;                                         \
+        long long grid = (nchunks + SLOTS * U - 1) / (SLOTS * U);                               \
         if (grid > 256 * 8) grid = 256 * 8;                                                     \
         if (grid < 1) grid = 1;                                                                 \
         hipLaunchKernelGGL((pw_mfma<k, n>), dim3((int)grid), dim3(256), 0, s, in, out, a, npix); \
