@@ -404,12 +404,32 @@ __global__ __launch_bounds__(256) void dw3x3_nhwc(const int8_t *__restrict__ in,
 
     // per-lane constants of this lane's channel group
     const int cg = tid & (C4 - 1);
-    uint32_t wm[9][4];
+    // S == 2: 9 tap dwords as 36 byte-masked copies (one sdot4 per MAC, no unpacking).
+    // S == 1: per filter row and channel the 3 taps as ONE dword (w0,w1,w2,0) and its
+    //         shifted twin (0,w0,w1,w2): a 4-pixel window transposed to per-channel dwords
+    //         then yields TWO adjacent outputs with two real 3-MAC sdot4s.
+    uint32_t wm[S == 2 ? 9 : 1][4];
+    uint32_t wA[S == 1 ? 3 : 1][4], wB[S == 1 ? 3 : 1][4];
+    if constexpr (S == 2) {
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-        const uint32_t w = ((const uint32_t *)p.w)[t * C4 + cg];
+        for (int t = 0; t < 9; ++t) {
+            const uint32_t w = ((const uint32_t *)p.w)[t * C4 + cg];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) wm[t][k] = w & (0xffu << (8 * k));
+            for (int k = 0; k < 4; ++k) wm[t][k] = w & (0xffu << (8 * k));
+        }
+    } else {
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const uint32_t w0 = ((const uint32_t *)p.w)[(ky * 3 + 0) * C4 + cg];
+            const uint32_t w1 = ((const uint32_t *)p.w)[(ky * 3 + 1) * C4 + cg];
+            const uint32_t w2 = ((const uint32_t *)p.w)[(ky * 3 + 2) * C4 + cg];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                wA[ky][k] = ((w0 >> (8 * k)) & 0xffu) | (((w1 >> (8 * k)) & 0xffu) << 8) |
+                            (((w2 >> (8 * k)) & 0xffu) << 16);
+                wB[ky][k] = wA[ky][k] << 8;
+            }
+        }
     }
     const float4 A = ((const float4 *)p.A)[cg], Sc = ((const float4 *)p.S)[cg];
     const int4 Kc = ((const int4 *)p.Kc)[cg];
@@ -438,33 +458,84 @@ __global__ __launch_bounds__(256) void dw3x3_nhwc(const int8_t *__restrict__ in,
 
         const uint8_t *tile = lds + cur * BUF;
         uint32_t *dst = (uint32_t *)out + (size_t)step * G * OH * OW * C4;
-        const int nvalid = min(G, batch - step * G) * OH * OW * C4;
+        if constexpr (S == 2) {
+            const int nvalid = min(G, batch - step * G) * OH * OW * C4;
 #pragma unroll 2
-        for (int i = 0; i < NOUT; ++i) {
-            const int o = tid + 256 * i;
-            if (o < OUTS && o < nvalid) {
-                const int pix = o / C4;
-                const int g = pix / (OH * OW), rem = pix % (OH * OW);
-                const int oy = rem / OW, ox = rem % OW;
-                // tap (ky,kx): row oy*S + ky (halo row 0 == input row -1), col ox*S + kx - 1
-                const uint8_t *base = tile + g * TILE + (oy * S) * ROW + LP + (ox * S - 1) * C + cg * 4;
-                int a0 = Kc.x, a1 = Kc.y, a2 = Kc.z, a3 = Kc.w;
+            for (int i = 0; i < NOUT; ++i) {
+                const int o = tid + 256 * i;
+                if (o < OUTS && o < nvalid) {
+                    const int pix = o / C4;
+                    const int g = pix / (OH * OW), rem = pix % (OH * OW);
+                    const int oy = rem / OW, ox = rem % OW;
+                    // tap (ky,kx): row oy*S + ky (halo row 0 == input row -1), col ox*S + kx - 1
+                    const uint8_t *base = tile + g * TILE + (oy * S) * ROW + LP + (ox * S - 1) * C + cg * 4;
+                    int a0 = Kc.x, a1 = Kc.y, a2 = Kc.z, a3 = Kc.w;
 #pragma unroll
-                for (int ky = 0; ky < 3; ++ky)
+                    for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-                    for (int kx = 0; kx < 3; ++kx) {
-                        const uint32_t v = *(const uint32_t *)(base + ky * ROW + kx * C);
-                        const int t = ky * 3 + kx;
-                        a0 = sdot4(v, wm[t][0], a0);
-                        a1 = sdot4(v, wm[t][1], a1);
-                        a2 = sdot4(v, wm[t][2], a2);
-                        a3 = sdot4(v, wm[t][3], a3);
+                        for (int kx = 0; kx < 3; ++kx) {
+                            const uint32_t v = *(const uint32_t *)(base + ky * ROW + kx * C);
+                            const int t = ky * 3 + kx;
+                            a0 = sdot4(v, wm[t][0], a0);
+                            a1 = sdot4(v, wm[t][1], a1);
+                            a2 = sdot4(v, wm[t][2], a2);
+                            a3 = sdot4(v, wm[t][3], a3);
+                        }
+                    const int q0 = requant(a0, A.x, Sc.x, p.lo_f, p.hi_f);
+                    const int q1 = requant(a1, A.y, Sc.y, p.lo_f, p.hi_f);
+                    const int q2 = requant(a2, A.z, Sc.z, p.lo_f, p.hi_f);
+                    const int q3 = requant(a3, A.w, Sc.w, p.lo_f, p.hi_f);
+                    dst[o] = pack4(q0, q1, q2, q3);
+                }
+            }
+        } else {
+            // task = 2 adjacent output pixels x 4 channels.  Per filter row: the 4 input pixels
+            // ox0-1 .. ox0+2 (4 channel dwords) are byte-transposed (8 v_perm) into 4 per-channel
+            // window dwords [v(-1),v(0),v(+1),v(+2)]; pixel ox0 = window . (w0,w1,w2,0), pixel
+            // ox0+1 = window . (0,w0,w1,w2): 6 VALU ops per output byte instead of 9.
+            constexpr int OWP = (OW + 1) / 2;
+            constexpr int TASKS = G * OH * OWP * C4;
+            constexpr int NTASK = (TASKS + 255) / 256;
+            const int gvalid = min(G, batch - step * G);
+#pragma unroll 1
+            for (int i = 0; i < NTASK; ++i) {
+                const int t = tid + 256 * i;
+                const int pp = t / C4;
+                const int g = pp / (OH * OWP), rem = pp % (OH * OWP);
+                const int oy = rem / OWP, ox0 = 2 * (rem % OWP);
+                if (t < TASKS && g < gvalid) {
+                    const uint8_t *base = tile + g * TILE + oy * ROW + LP + (ox0 - 1) * C + cg * 4;
+                    int o0[4] = {Kc.x, Kc.y, Kc.z, Kc.w}, o1[4] = {Kc.x, Kc.y, Kc.z, Kc.w};
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky) {
+                        const uint32_t s0 = *(const uint32_t *)(base + ky * ROW);
+                        const uint32_t s1 = *(const uint32_t *)(base + ky * ROW + C);
+                        const uint32_t s2 = *(const uint32_t *)(base + ky * ROW + 2 * C);
+                        const uint32_t s3 = *(const uint32_t *)(base + ky * ROW + 3 * C);
+                        // 4x4 byte transpose: win[k] = (s0.k, s1.k, s2.k, s3.k)
+                        const uint32_t ab_lo = __builtin_amdgcn_perm(s1, s0, 0x05010400u);
+                        const uint32_t ab_hi = __builtin_amdgcn_perm(s1, s0, 0x07030602u);
+                        const uint32_t cd_lo = __builtin_amdgcn_perm(s3, s2, 0x05010400u);
+                        const uint32_t cd_hi = __builtin_amdgcn_perm(s3, s2, 0x07030602u);
+                        uint32_t win[4];
+                        win[0] = __builtin_amdgcn_perm(cd_lo, ab_lo, 0x05040100u);
+                        win[1] = __builtin_amdgcn_perm(cd_lo, ab_lo, 0x07060302u);
+                        win[2] = __builtin_amdgcn_perm(cd_hi, ab_hi, 0x05040100u);
+                        win[3] = __builtin_amdgcn_perm(cd_hi, ab_hi, 0x07060302u);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            o0[k] = sdot4(win[k], wA[ky][k], o0[k]);
+                            o1[k] = sdot4(win[k], wB[ky][k], o1[k]);
+                        }
                     }
-                const int q0 = requant(a0, A.x, Sc.x, p.lo_f, p.hi_f);
-                const int q1 = requant(a1, A.y, Sc.y, p.lo_f, p.hi_f);
-                const int q2 = requant(a2, A.z, Sc.z, p.lo_f, p.hi_f);
-                const int q3 = requant(a3, A.w, Sc.w, p.lo_f, p.hi_f);
-                dst[o] = pack4(q0, q1, q2, q3);
+                    uint32_t d0 = pack4(requant(o0[0], A.x, Sc.x, p.lo_f, p.hi_f), requant(o0[1], A.y, Sc.y, p.lo_f, p.hi_f),
+                                        requant(o0[2], A.z, Sc.z, p.lo_f, p.hi_f), requant(o0[3], A.w, Sc.w, p.lo_f, p.hi_f));
+                    uint32_t d1 = pack4(requant(o1[0], A.x, Sc.x, p.lo_f, p.hi_f), requant(o1[1], A.y, Sc.y, p.lo_f, p.hi_f),
+                                        requant(o1[2], A.z, Sc.z, p.lo_f, p.hi_f), requant(o1[3], A.w, Sc.w, p.lo_f, p.hi_f));
+                    uint32_t *dp = dst + ((size_t)(g * OH + oy) * OW + ox0) * C4 + cg;
+                    dp[0] = d0;
+                    if (ox0 + 1 < OW) dp[C4] = d1;
+                }
             }
         }
     }
@@ -789,7 +860,7 @@ void launch_checksum(const int8_t *in, size_t n, unsigned long long *result, hip
 template <int H, int W, int C, int S, int G>
 static void launch_dw(const int8_t *in, int8_t *out, const DwFastArgs &a, int batch, hipStream_t s) {
     constexpr int LP = C < 16 ? 16 : C;
-    constexpr int lds = 2 * G * (H + 2) * (LP + W * C + LP); // two staging buffers
+    constexpr int lds = 2 * G * (H + 2) * (LP + W * C + LP) + 256; // two staging buffers + read slack
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void *)dw3x3_nhwc<H, W, C, S, G>,
