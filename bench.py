@@ -37,7 +37,10 @@ WORKLOADS = {
     # name: (model file, BASELINE config index used as stream id, per-GPU batch)
     "person_detect": ("person_detect.tflite", 3, 65536),
     "speech": ("speech.tflite", 2, 4096),
+    # BASELINE config 5: generated single-op FullyConnected model, one [4096,4096] input per step
+    "fc4096": (None, 5, 1),
 }
+INT8_MFMA_PEAK_TOPS = 5033.0  # dense int8 = 2x the ~2.5 PF dense bf16 MFMA peak (MI355X_MICROARCH.md)
 
 
 def main():
@@ -77,6 +80,8 @@ def main():
 
     fname, cfg, base_batch = WORKLOADS[args.workload]
     B = args.batch or base_batch
+    if args.workload == "fc4096":
+        return bench_fc4096(args, mf, _lib, torch, world, rank, local_rank)
     m = mf.model(os.path.join(ROOT, "models", fname))
     m.prepare(B, device=local_rank)
     L = _lib.lib()
@@ -181,6 +186,52 @@ def main():
         print(json.dumps(result))
         if not result["parity"]["bit_exact_vs_oracle"]:
             sys.exit(1)
+
+
+def bench_fc4096(args, mf, _lib, torch, world, rank, local_rank):
+    """FullyConnected 4096x4096x4096 through the model API: one step = one predict_inner over a
+    [4096, 4096] int8 input (one dense int8 GEMM + fused requantize epilogue)."""
+    from tools.make_fc_model import synthetic_fc
+    from oracle import oracle as O
+    M = K = N = 4096
+    blob = synthetic_fc(M, K, N, wzp=0, seed=5)
+    m = mf.model(blob)
+    m.prepare(1, device=local_rank)
+    L = _lib.lib()
+    _lib.check(L.mf_model_set_stream(m._h, torch.cuda.current_stream().cuda_stream))
+    g = torch.Generator(device="cuda").manual_seed(1234 + rank)
+    x = torch.randint(-128, 128, (M, K), dtype=torch.int8, device="cuda", generator=g)  # random operands
+    y = torch.empty(M * N, dtype=torch.int8, device="cuda")
+    for _ in range(args.warmup):
+        _lib.check(L.mf_model_run_quantized(m._h, x.data_ptr(), 1, y.data_ptr(), _lib.MF_MEM_DEVICE))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        _lib.check(L.mf_model_run_quantized(m._h, x.data_ptr(), 1, y.data_ptr(), _lib.MF_MEM_DEVICE))
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    avg_ms, per_op = m.time_device(x, y, 1, warmup=1, iters=max(5, min(args.steps, 20)))
+    ops = 2.0 * M * K * N
+    tops = ops / (per_op[0] * 1e-3) / 1e12
+    rows = [0, 777, 4095]
+    om = O.Model(synthetic_fc(len(rows), K, N, wzp=0, seed=5))
+    want = om.run_quantized(x[rows].cpu().numpy()).reshape(len(rows), N)
+    ok = bool(np.array_equal(y.reshape(M, N)[rows].cpu().numpy(), want))
+    result = {
+        "metric": "int8 GEMM TOP/s, FullyConnected 4096x4096x4096 via predict_inner",
+        "value": round(ops / (elapsed / args.steps) / 1e12, 1), "unit": "TOP/s", "n_gpus": 1,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "i8",
+        "data": "synthetic", "config": {"workload": "FullyConnected int8 M=K=N=4096 (generated single-op .tflite)"},
+        "roofline": {"bound": "mfma", "kernel": m.op(0)["kernel"], "achieved": round(tops, 1),
+                     "peak": INT8_MFMA_PEAK_TOPS, "unit": "TOP/s", "frac": round(tops / INT8_MFMA_PEAK_TOPS, 4),
+                     "traffic": None, "ms": round(per_op[0], 4), "algorithmic_ops": ops,
+                     "method": "HIP events on the launch stream"},
+        "parity": {"bit_exact_vs_oracle": ok, "sampled_rows": len(rows)},
+    }
+    print(json.dumps(result))
+    if not ok:
+        sys.exit(1)
 
 
 def cpu_baseline(om, x_dev_rows, seconds):

@@ -20,6 +20,7 @@
 // roundf is trunc(x + copysign(pred(0.5), x)) which is exact for every finite x.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "kernels.hpp"
 
@@ -806,6 +807,188 @@ __global__ __launch_bounds__(256) void pw_mfma(const int8_t *__restrict__ in,
 }
 
 // ------------------------------------------------------------------------
+// FAST PATH 4 -- FullyConnected as a dense int8 MFMA GEMM (BASELINE config 5).
+// (src/ops/fully_connected.rs:24-82; rows of all inferences form one [M][K] matrix)
+//
+//   Y[m][n] = requant( sum_k X[m][k] * W[n][k]  - wzp * rowsum(X[m])  + (c3 - c2[n]) )
+//
+// Both operands are K-contiguous ("NT" GEMM), the natural layout for
+// v_mfma_i32_32x32x32_i8 whose lanes each hold 16 consecutive k-bytes of one row.
+//   tile     : 128 (m) x 128 (n) per workgroup, 4 waves as 2 x 2, each wave 64 x 64 =
+//              2 x 2 MFMA tiles, accumulators in registers (64 VGPRs).
+//   staging  : BK = 128 bytes per step; X and W tiles go HBM/L2 -> LDS by LDS-DMA
+//              (global_load_lds_dwordx4), double buffered: the DMAs of step t+1 fly during
+//              the MFMAs of step t; one `vmcnt(0)` + barrier per step.
+//   LDS image: [row][128 B], 16-byte slot index XOR ((row >> 1) & 7) -- with that key the 16
+//              lanes of every ds_read_b128 service group ({0-3,12-15,20-27}, ...) hit 16
+//              distinct 16-byte bank slots (row & 7 would be 2-way).  A DMA writes LDS linearly
+//              (base + lane*16), so the swizzle is applied to the GLOBAL source chunk each
+//              lane fetches and again on the fragment reads (guide rule 21: both sides).
+//   operands : MFMA "A" = W rows (n), MFMA "B" = X rows (m), so that D[n][m] leaves every
+//              lane with 16 results of ONE output row m.  The lane -> W-row map is permuted
+//              (rho -> 16*((rho>>2)&1) + 4*(rho>>3) + (rho&3)) so those 16 results are 16
+//              CONSECUTIVE n: one packed 16-byte store per lane per tile, no transposition.
+//   grid     : XCD-aware remap so the 8 tiles that share panels sit behind the same L2.
+// The f32 epilogue is the reference's, fused; |acc| can exceed 2^24 at K = 4096, where
+// f32(acc) rounds to nearest even exactly like Rust's `as f32`.
+// ------------------------------------------------------------------------
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN) void fc_mfma(const int8_t *__restrict__ X,
+                                                        int8_t *__restrict__ Y, FcGemmArgs p) {
+    constexpr int BK = 128;
+    constexpr int NW = WM * WN;                              // waves per workgroup
+    constexpr int MT = BM / WM / 32, NT = BN / WN / 32;      // 32x32 MFMA tiles per wave
+    constexpr int XT = BM * BK, WT = BN * BK, BUF = XT + WT; // one staging buffer (two allocated)
+    constexpr int XP = XT / 1024 / NW, WP = WT / 1024 / NW;  // 1 KiB DMA pieces per wave
+    static_assert(XT % (1024 * NW) == 0 && WT % (1024 * NW) == 0, "DMA pieces must divide over the waves");
+    // swizzle key: with (row >> 1) & 7 the 16 lanes of every ds_read_b128 service group
+    // ({0-3,12-15,20-27}, ...) hit 16 distinct 16-byte bank slots (row & 7 would be 2-way)
+    auto key = [](int row) { return (row >> 1) & 7; };
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+
+    // XCD-aware 2-D tile order.  Dispatch puts block b on XCD b % 8 and each XCD runs its
+    // blocks in order, one residency-full at a time.  Those PM*PN co-resident tiles are
+    // mapped to a PM x PN patch, which needs only PM X-panels + PN W-panels per k-step
+    // through that XCD's L2 instead of ~1 + PM*PN for a row-major order.
+    constexpr int PM = (BM == 128) ? 8 : 4, PN = 8;           // 64 resident 128^2 tiles, 32 256^2 tiles
+    const int tiles_m = p.M / BM, tiles_n = p.N / BN;
+    int tm, tn;
+    {
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;   // j-th block of this XCD
+        const int patches_n = tiles_n / PN, npatch = (tiles_m / PM) * patches_n;
+        if (tiles_m % PM == 0 && tiles_n % PN == 0 && (npatch & 7) == 0) {
+            const int patch = xcd * (npatch >> 3) + j / (PM * PN), t = j % (PM * PN);
+            tm = (patch / patches_n) * PM + t / PN;
+            tn = (patch % patches_n) * PN + t % PN;
+        } else {
+            tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
+        }
+    }
+    const int K = p.K;
+    const int8_t *Xt = X + (size_t)tm * BM * K;
+    const int8_t *Wt = p.w + (size_t)tn * BN * K;
+
+    // DMA piece i (1 KiB) of a tile = rows 8i .. 8i+7; lane -> (row, swizzled 16-byte slot)
+    auto stage = [&](int kt, int buf) {
+        const int r8 = lane >> 3, s8 = lane & 7;
+#pragma unroll
+        for (int j = 0; j < XP; ++j) {
+            const int i = wave * XP + j, row = 8 * i + r8;
+            dma16(Xt + (size_t)row * K + (size_t)kt * BK + ((s8 ^ key(row)) << 4), lds + buf * BUF + i * 1024);
+        }
+#pragma unroll
+        for (int j = 0; j < WP; ++j) {
+            const int i = wave * WP + j, row = 8 * i + r8;
+            dma16(Wt + (size_t)row * K + (size_t)kt * BK + ((s8 ^ key(row)) << 4), lds + buf * BUF + XT + i * 1024);
+        }
+    };
+
+    v16i acc[NT][MT];
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int b = 0; b < MT; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0;
+
+    // fragment rows of this lane
+    const int rho = lane & 31, half = lane >> 5;
+    const int nloc = 16 * ((rho >> 2) & 1) + 4 * (rho >> 3) + (rho & 3);
+    int xoff[MT], woff[NT], xkey[MT], wkey[NT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+        const int row = wm * (BM / WM) + t * 32 + rho;
+        xoff[t] = row * BK, xkey[t] = key(row);
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int row = wn * (BN / WN) + t * 32 + nloc;
+        woff[t] = XT + row * BK, wkey[t] = key(row);
+    }
+
+    const int nk = K / BK;
+    int cur = 0;
+    stage(0, 0);
+    for (int kt = 0; kt < nk; ++kt, cur ^= 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (kt + 1 < nk) stage(kt + 1, cur ^ 1);
+        const uint8_t *lb = lds + cur * BUF;
+#pragma unroll
+        for (int ks = 0; ks < BK / 32; ++ks) {
+            v4i a[NT], b[MT];
+#pragma unroll
+            for (int t = 0; t < MT; ++t) b[t] = *(const v4i *)(lb + xoff[t] + (((ks * 2 + half) ^ xkey[t]) << 4));
+#pragma unroll
+            for (int t = 0; t < NT; ++t) a[t] = *(const v4i *)(lb + woff[t] + (((ks * 2 + half) ^ wkey[t]) << 4));
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    acc[nt][mt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[nt], b[mt], acc[nt][mt], 0, 0, 0);
+        }
+    }
+
+    // epilogue: lane (m column = lane & 31, half) holds n = tile + 16*half + r, r = 0..15
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int n0 = tn * BN + wn * (BN / WN) + nt * 32 + 16 * half;
+        float cA[16];
+        int cK[16];
+#pragma unroll
+        for (int r = 0; r < 16; r += 4) {
+            const float4 fa = *(const float4 *)(p.A + n0 + r);
+            const int4 ik = *(const int4 *)(p.Kc + n0 + r);
+            cA[r] = fa.x, cA[r + 1] = fa.y, cA[r + 2] = fa.z, cA[r + 3] = fa.w;
+            cK[r] = ik.x, cK[r + 1] = ik.y, cK[r + 2] = ik.z, cK[r + 3] = ik.w;
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int m = tm * BM + wm * (BM / WM) + mt * 32 + rho;
+            const int corr = p.rowsum ? p.wzp * p.rowsum[m] : 0; // x1 = wzp * row-sum of the input
+            uint32_t d[4];
+#pragma unroll
+            for (int r = 0; r < 16; r += 4) {
+                const int q0 = requant(acc[nt][mt][r] + cK[r] - corr, cA[r], p.S, p.lo_f, p.hi_f);
+                const int q1 = requant(acc[nt][mt][r + 1] + cK[r + 1] - corr, cA[r + 1], p.S, p.lo_f, p.hi_f);
+                const int q2 = requant(acc[nt][mt][r + 2] + cK[r + 2] - corr, cA[r + 2], p.S, p.lo_f, p.hi_f);
+                const int q3 = requant(acc[nt][mt][r + 3] + cK[r + 3] - corr, cA[r + 3], p.S, p.lo_f, p.hi_f);
+                d[r >> 2] = pack4(q0, q1, q2, q3);
+            }
+            *(uint4 *)(Y + (size_t)m * p.N + n0) = make_uint4(d[0], d[1], d[2], d[3]);
+        }
+    }
+}
+
+// sum_k x[row][k] for the weight-zero-point term of FullyConnected (fully_connected.rs:60-64);
+// one wave per row, 16-byte loads.  Only launched when wzp != 0.
+__global__ __launch_bounds__(256) void fc_rowsum(const int8_t *__restrict__ in, int *__restrict__ rowsum,
+                                                 size_t rows, int K) {
+    const int lane = threadIdx.x & 63;
+    const size_t wave = ((size_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+    const size_t nwaves = ((size_t)gridDim.x * 256) >> 6;
+    for (size_t row = wave; row < rows; row += nwaves) {
+        const uint4 *x = (const uint4 *)(in + row * (size_t)K);
+        int rs = 0;
+        for (int k = lane; k < (K >> 4); k += 64) {
+            const uint4 v = x[k];
+            rs = sdot4(v.x, 0x01010101u, rs);
+            rs = sdot4(v.y, 0x01010101u, rs);
+            rs = sdot4(v.z, 0x01010101u, rs);
+            rs = sdot4(v.w, 0x01010101u, rs);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) rs += __shfl_xor(rs, off, 64);
+        if (lane == 0) rowsum[row] = rs;
+    }
+}
+
+// ------------------------------------------------------------------------
 // launchers (host)
 // ------------------------------------------------------------------------
 static inline int grid_for(size_t total, int per_block = 256, int cap = 256 * 8) {
@@ -839,6 +1022,33 @@ bool launch_fc_rowwave(const int8_t *in, int8_t *out, const FcArgs &a, size_t ro
     case 8: hipLaunchKernelGGL(fc_rowwave<8>, dim3(grid), dim3(256), 0, s, in, out, a, rows); return true;
     default: return false;
     }
+}
+bool fc_mfma_supported(size_t rows, int N, int K) {
+    return rows > 0 && rows % 128 == 0 && N % 128 == 0 && K % 128 == 0 && rows / 128 * (size_t)(N / 128) < (1u << 30);
+}
+void launch_fc_rowsum(const int8_t *in, int *rowsum, size_t rows, int K, hipStream_t s) {
+    hipLaunchKernelGGL(fc_rowsum, dim3(grid_for(rows, 4)), dim3(256), 0, s, in, rowsum, rows, K);
+}
+template <int BM, int BN, int WM, int WN>
+static void launch_fc_mfma_t(const int8_t *in, int8_t *out, const FcGemmArgs &a, hipStream_t s) {
+    constexpr int lds = 2 * (BM + BN) * 128;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)fc_mfma<BM, BN, WM, WN>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set = true;
+    }
+    const int grid = (a.M / BM) * (a.N / BN);
+    hipLaunchKernelGGL((fc_mfma<BM, BN, WM, WN>), dim3(grid), dim3(64 * WM * WN), lds, s, in, out, a);
+}
+void launch_fc_mfma(const int8_t *in, int8_t *out, const FcGemmArgs &a, hipStream_t s) {
+    static const int force = [] { const char *e = getenv("MF_FC_TILE"); return e ? atoi(e) : 0; }();
+    // 256 x 256 tiles halve the L2 -> LDS traffic per MAC; they need >= 256 tiles to fill the chip
+    const bool big = a.M % 256 == 0 && a.N % 256 == 0 && (size_t)(a.M / 256) * (a.N / 256) >= 192;
+    if ((big && force != 128) || (force == 256 && a.M % 256 == 0 && a.N % 256 == 0))
+        launch_fc_mfma_t<256, 256, 2, 4>(in, out, a, s);
+    else
+        launch_fc_mfma_t<128, 128, 2, 2>(in, out, a, s);
 }
 void launch_softmax(const int8_t *in, int8_t *out, const SoftmaxArgs &a, size_t batch, hipStream_t s) {
     hipLaunchKernelGGL(softmax_table, dim3(grid_for(batch)), dim3(256), 0, s, in, out, a, batch);

@@ -39,6 +39,16 @@ struct FcArgs {
     const float *A;     // [N]
     const int *Kc;      // [N] = c3 - c2[j]
 };
+struct FcGemmArgs {
+    const int8_t *w;    // [N][K]
+    const float *A;     // [N]
+    const int *Kc;      // [N]
+    const int *rowsum;  // [rows] sum_k x[row][k], or nullptr when wzp == 0
+    int wzp;
+    float S;
+    float lo_f, hi_f;
+    int M, N, K;        // M = total rows (batch * rows per inference)
+};
 struct SoftmaxArgs {
     int rows, cols;
     float oscale, ozp_f;
@@ -96,6 +106,10 @@ void launch_dwconv_generic(const int8_t *in, int8_t *out, const ConvArgs &a, siz
 void launch_avgpool_generic(const int8_t *in, int8_t *out, const PoolArgs &a, size_t batch, hipStream_t s);
 void launch_fc_generic(const int8_t *in, int8_t *out, const FcArgs &a, size_t rows, hipStream_t s);
 bool launch_fc_rowwave(const int8_t *in, int8_t *out, const FcArgs &a, size_t rows, hipStream_t s);
+// int8 MFMA GEMM (M % 128 == 0, N % 128 == 0, K % 128 == 0)
+bool fc_mfma_supported(size_t rows, int N, int K);
+void launch_fc_rowsum(const int8_t *in, int *rowsum, size_t rows, int K, hipStream_t s);
+void launch_fc_mfma(const int8_t *in, int8_t *out, const FcGemmArgs &a, hipStream_t s);
 void launch_softmax(const int8_t *in, int8_t *out, const SoftmaxArgs &a, size_t batch, hipStream_t s);
 void launch_quantize(const float *in, int8_t *out, size_t n, float scale, float zp_f, hipStream_t s);
 void launch_dequantize(const int8_t *in, float *out, size_t n, float scale, float zp_f, hipStream_t s);

@@ -80,7 +80,9 @@ struct OpImpl {
     size_t in_elems = 0, out_elems = 0;
     bool force_generic = false;
     std::string generic_name, fast_name;
-    enum Fast { NONE, DW_NHWC, DW_STEM, PW_MFMA, FC_ROWWAVE } fast = NONE;
+    enum Fast { NONE, DW_NHWC, DW_STEM, PW_MFMA, FC_ROWWAVE, FC_MFMA } fast = NONE;
+    int *d_rowsum = nullptr; // FC_MFMA with wzp != 0: per-row input sums
+    size_t rowsum_cap = 0;
 
     DevBuf d_w, d_wzp, d_A, d_S, d_Kc, d_wprep, d_table;
     k::ConvArgs conv{};
@@ -269,6 +271,10 @@ OpImpl *op_create(int device, const OpSpec &s) {
         if (s.K % 16 == 0 && s.K >= 256 && (s.N == 1 || s.N == 2 || s.N == 4 || s.N == 8)) {
             op->fast = OpImpl::FC_ROWWAVE;
             op->fast_name = "fc_rowwave<" + std::to_string(s.N) + ">";
+        } else if (s.N % 128 == 0 && s.K % 128 == 0) {
+            // dense contraction: int8 MFMA GEMM whenever the batch supplies whole 128-row tiles
+            op->fast = OpImpl::FC_MFMA;
+            op->fast_name = "fc_mfma";
         }
         break;
     }
@@ -300,6 +306,7 @@ OpImpl *op_create(int device, const OpSpec &s) {
 void op_destroy(OpImpl *op) {
     if (!op) return;
     (void)hipSetDevice(op->device);
+    if (op->d_rowsum) (void)hipFree(op->d_rowsum);
     delete op;
 }
 
@@ -333,6 +340,28 @@ void op_run(OpImpl *op, const int8_t *d_in, size_t batch, int8_t *d_out, void *s
         case OpImpl::FC_ROWWAVE:
             done = k::launch_fc_rowwave(d_in, d_out, op->fc, batch * sp.M, s);
             break;
+        case OpImpl::FC_MFMA: {
+            const size_t rows = batch * sp.M;
+            if (!k::fc_mfma_supported(rows, sp.N, sp.K)) break; // ragged row count: generic kernel
+            k::FcGemmArgs g{};
+            g.w = op->fc.w, g.A = op->fc.A, g.Kc = op->fc.Kc, g.wzp = op->fc.wzp, g.S = op->fc.S;
+            g.lo_f = op->fc.lo_f, g.hi_f = op->fc.hi_f, g.M = (int)rows, g.N = sp.N, g.K = sp.K;
+            g.rowsum = nullptr;
+            if (op->fc.wzp != 0) {
+                if (op->rowsum_cap < rows) {
+                    MF_HIP(hipStreamSynchronize(s));
+                    if (op->d_rowsum) (void)hipFree(op->d_rowsum);
+                    op->d_rowsum = nullptr;
+                    MF_HIP(hipMalloc((void **)&op->d_rowsum, rows * sizeof(int)));
+                    op->rowsum_cap = rows;
+                }
+                k::launch_fc_rowsum(d_in, op->d_rowsum, rows, sp.K, s);
+                g.rowsum = op->d_rowsum;
+            }
+            k::launch_fc_mfma(d_in, d_out, g, s);
+            done = true;
+            break;
+        }
         default: break;
         }
     }

@@ -169,3 +169,39 @@ def test_kernel_routing(models):
     assert sum(n.startswith("pw_mfma") for n in names) == 13
     assert names[28] == "conv2d_generic" and names[27] == "avgpool_generic"
     assert names[29] == "" and names[30] == "softmax_table"
+
+
+@pytest.mark.parametrize("wzp", [0, 11])
+def test_fc_4096_cubed_through_predict(mf, O, wzp):
+    """BASELINE config 5: FullyConnected 4096x4096x4096 as a generated single-op model run
+    through predict(); MFMA GEMM vs the oracle on sampled rows (rows are independent) and vs
+    the shape-generic kernel on the full output."""
+    import torch
+    from tools.make_fc_model import synthetic_fc
+    M = K = N = 4096
+    blob = synthetic_fc(M, K, N, wzp=wzp, seed=5 + wzp)
+    m = mf.model(blob)
+    m.prepare(1)
+    assert m.op(0)["kernel"] == "fc_mfma" and m.input_shape == (M, K) and m.output_shape == (M, N)
+    rng = np.random.default_rng(1)
+    xq = rng.integers(-128, 128, (M, K), dtype=np.int8)
+    xd = torch.from_numpy(xq).cuda()
+    y = m.run_quantized(xd)
+    m.sync()
+    # oracle on 6 sampled rows: a [6, K] model sharing the same weights
+    rows = [0, 1, 127, 128, 2049, 4095]
+    om = O.Model(synthetic_fc(len(rows), K, N, wzp=wzp, seed=5 + wzp))
+    want = om.run_quantized(xq[rows]).reshape(len(rows), N)
+    assert np.array_equal(y[rows].cpu().numpy(), want)
+    assert len(np.unique(want)) > 100
+    # f32 entry point (quantize -> GEMM -> dequantize) on the same data
+    xf = (xq[rows].astype(f32) - f32(m.input_zero_point)) * m.input_scale
+    wantf = om.predict(xf).reshape(len(rows), N)
+    full_f = m.predict(((xd.float() - float(m.input_zero_point)) * float(m.input_scale)))
+    assert np.array_equal(full_f[rows].cpu().numpy(), wantf)
+    # whole output vs the shape-generic kernel
+    m.set_generic(True)
+    yg = m.run_quantized(xd)
+    m.sync()
+    m.set_generic(False)
+    assert torch.equal(y, yg)

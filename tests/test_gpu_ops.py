@@ -292,3 +292,33 @@ def test_device_tensors_stay_on_device(mf):
                                           (np.zeros(128, f32), np.full(1, 0.01, f32)), (6, 6))
     y = op(x)
     assert isinstance(y, torch.Tensor) and y.is_cuda and y.shape == (4, 6, 6, 128)
+
+
+@pytest.mark.parametrize("case", [(128, 128, 128, 0), (256, 512, 384, 0), (128, 256, 128, 9), (384, 128, 256, -5)],
+                         ids=lambda c: "x".join(map(str, c)))
+def test_fully_connected_mfma_gemm_vs_oracle(mf, O, case):
+    """The int8 MFMA GEMM path (rows = whole 128-row tiles), incl. non-zero weight zero point."""
+    M, K, N, wzp = case
+    rng = np.random.default_rng(M + K + N)
+    x = rng.integers(-128, 128, (M, K)).astype(np.int8)
+    w = rng.integers(-128, 128, (N, K)).astype(np.int8)     # asymmetric operands: a transposed
+    bias = rng.integers(-5000, 5000, N).astype(np.int32)    # write-back cannot pass
+    iscale, izp, wscale = 1 / 128, -128, 1 / 128
+    oscale, ozp = float(iscale * wscale * np.sqrt(K) * 74 * 74 * 3 / 127), 3
+    c0, c1, c2, c3 = O.preprocess_fully_connected(iscale, izp, K, w, wscale, wzp, bias, iscale * wscale, 0, oscale)
+    for act in (0, 1):
+        op = mf.ops.prepare_fully_connected(M, w, wzp, oscale, ozp, mf.ops.FullyConnectedOptions(mf.FusedActivation(act)),
+                                            (c0, c1, c2, c3))
+        assert op.kernel == "fc_mfma"
+        want = O.fully_connected(x, w, wzp, oscale, ozp, act, c0, c1, c2, c3)
+        got = op(x)
+        assert np.array_equal(got, want), np.argwhere(got != want)[:5]
+        assert len(np.unique(got)) > 50          # the outputs really spread over the int8 range
+        # M rows per inference x batch of 2 -> the same tiles, twice
+        got2 = op(np.stack([x, x[::-1]]))
+        assert np.array_equal(got2[0], want) and np.array_equal(got2[1], want[::-1])
+        op.set_generic(True)
+        assert np.array_equal(op(x), want)
+    # a row count that is not a multiple of 128 falls back to the generic kernel, same results
+    op = mf.ops.prepare_fully_connected(100, w, wzp, oscale, ozp, mf.ops.FullyConnectedOptions(), (c0, c1, c2, c3))
+    assert np.array_equal(op(x[:100]), O.fully_connected(x[:100], w, wzp, oscale, ozp, 0, c0, c1, c2, c3))
