@@ -135,8 +135,20 @@ def main():
             kernels.append({"op": i, "kind": d["name"], "kernel": d["kernel"], "ms": round(per_op[i], 4),
                             "bytes": nbytes, "GBps": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4)})
         dom = max(kernels, key=lambda k: k["ms"])
+        # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
+        # (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; scripts/pmc_summary.py), if the batch matches
+        traffic, traffic_src = None, None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")))
+            if pmc.get("per_gpu_batch") == count:
+                for k in pmc["kernels"]:
+                    if k["kernel"] == dom["kernel"]:
+                        traffic, traffic_src = k["traffic_bytes"], "profiles/pmc_traffic_latest.json"
+        except (OSError, ValueError, KeyError):
+            pass
         roofline = {"bound": "hbm", "kernel": dom["kernel"], "op": dom["op"], "achieved": dom["GBps"],
-                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["frac"], "traffic": None,
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["frac"], "traffic": traffic,
+                    "traffic_source": traffic_src,
                     "ms": dom["ms"], "algorithmic_bytes": dom["bytes"],
                     "method": "HIP events on the launch stream, avg of %d launches" % max(5, min(args.steps, 20))}
 

@@ -46,3 +46,16 @@ if [[ $STEPS == all || $STEPS == *prof* ]]; then
   f=$(find $OUT/prof -name "*kernel_stats.csv" | head -1)
   [ -n "$f" ] && head -40 "$f"
 fi
+if [[ $STEPS == *pmc* ]]; then
+  # HBM traffic counters, one --pmc pass per counter (FETCH_SIZE needs 3 of the 4 TCC slots,
+  # WRITE_SIZE 2), with --kernel-trace only (MI355X_MICROARCH.md, HBM section)
+  for c in FETCH_SIZE WRITE_SIZE; do
+    rm -rf $OUT/pmc_$c
+    (cd /tmp && timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OLDPWD/$OUT/pmc_$c" -- \
+        python "$OLDPWD/bench.py" --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> "$OLDPWD/$OUT/pmc_$c.err")
+    echo "pmc $c exit $?"
+    find $OUT/pmc_$c -name "*.csv" | head -5
+  done
+  f=$(find $OUT/pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1)
+  [ -n "$f" ] && head -3 "$f"
+fi

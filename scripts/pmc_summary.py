@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Aggregate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes into per-kernel HBM traffic.
+
+    python scripts/pmc_summary.py gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE [bench.json] > profiles/rNN/pmc_traffic.json
+
+Units and corrections (MI355X_MICROARCH.md, HBM section): FETCH_SIZE / WRITE_SIZE are in KiB
+as derived from the L2's memory-side request counters; on gfx950 FETCH_SIZE reports exactly
+half of the bytes of a wide (16 B/lane) coalesced streaming read, so it is doubled here.
+WRITE_SIZE is reported as is (uncalibrated).  Values are per launch (mean over launches).
+"""
+import csv
+import glob
+import json
+import os
+import re
+import sys
+from collections import defaultdict
+
+
+def load(d, counter):
+    f = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)[0]
+    acc = defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] == counter:
+            acc[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    return acc
+
+
+def short(name):
+    m = re.search(r"mf::k::([A-Za-z0-9_]+)(<[^>]*>)?", name)
+    return (m.group(1) + (m.group(2) or "").replace(" ", "")) if m else name[:40]
+
+
+def main():
+    fetch = load(sys.argv[1], "FETCH_SIZE")
+    write = load(sys.argv[2], "WRITE_SIZE")
+    bench = None
+    if len(sys.argv) > 3:
+        bench = json.loads(open(sys.argv[3]).read().strip().splitlines()[-1])
+    alg = {}
+    if bench:
+        for k in bench["kernels"]:
+            alg.setdefault(k["kernel"], k["bytes"])
+    out = {"per_gpu_batch": bench["config"]["per_gpu_batch"] if bench else None,
+           "unit": "bytes per launch", "fetch_correction": "FETCH_SIZE x 2 (gfx950 wide-read calibration)",
+           "kernels": []}
+    for name in sorted(set(fetch) | set(write)):
+        if "mf::k::" not in name:
+            continue
+        f = sum(fetch.get(name, [0])) / max(len(fetch.get(name, [])), 1) * 1024 * 2
+        w = sum(write.get(name, [0])) / max(len(write.get(name, [])), 1) * 1024
+        s = short(name)
+        e = {"kernel": s, "launches": len(fetch.get(name, [])), "fetch_bytes": int(f), "write_bytes": int(w),
+             "traffic_bytes": int(f + w)}
+        if s in alg:
+            e["algorithmic_bytes"] = alg[s]
+            e["traffic_over_algorithmic"] = round((f + w) / alg[s], 3)
+        out["kernels"].append(e)
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
