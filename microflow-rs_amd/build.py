@@ -15,8 +15,10 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmicroflow_amd.so")
 SOURCES = ["capi.cpp", "hostmath.cpp", "tflite.cpp", "model.cpp", "ops.hip", "kernels.hip"]
 HEADERS = ["mf_internal.hpp", "kernels.hpp", os.path.join("..", "..", "include", "microflow_amd.h")]
+# -amdgpu-mfma-vgpr-form: MFMA results land in VGPRs (gfx950's register file is unified), which
+# removes one v_accvgpr_read per accumulator element from every fused epilogue.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
-         "-fno-fast-math", "-Wall", "-Wno-unused-result"]
+         "-fno-fast-math", "-Wall", "-Wno-unused-result", "-mllvm", "-amdgpu-mfma-vgpr-form=1"]
 
 
 def hipcc():

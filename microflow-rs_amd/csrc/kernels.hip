@@ -375,8 +375,8 @@ __device__ __forceinline__ void dma16(const int8_t *src_lane, uint8_t *lds_wave_
 // One barrier per step: after it, every wave has finished reading the other buffer
 // (safe to overwrite) and every wave's DMAs into this buffer have landed.
 // ------------------------------------------------------------------------
-template <int H, int W, int C, int S, int G>
-__global__ __launch_bounds__(256) void dw3x3_nhwc(const int8_t *__restrict__ in,
+template <int H, int W, int C, int S, int G, int NTHR>
+__global__ __launch_bounds__(NTHR) void dw3x3_nhwc(const int8_t *__restrict__ in,
                                                   int8_t *__restrict__ out, DwFastArgs p,
                                                   int batch) {
     constexpr int C4 = C / 4;
@@ -390,8 +390,9 @@ __global__ __launch_bounds__(256) void dw3x3_nhwc(const int8_t *__restrict__ in,
     constexpr int ROWCH = ROWB / 16;              // 16-byte chunks (= DMA lanes) per row
     constexpr int NROWS = G * H;                  // DMA instructions per step
     constexpr int OUTS = G * OH * OW * C4;        // output dwords per step
-    constexpr int NOUT = (OUTS + 255) / 256;
-    static_assert(256 % C4 == 0, "channel group of a lane must be loop-invariant");
+    constexpr int NOUT = (OUTS + NTHR - 1) / NTHR;
+    constexpr int NWAVE = NTHR / 64;
+    static_assert(NTHR % C4 == 0, "channel group of a lane must be loop-invariant");
     static_assert(ROWB % 16 == 0 && ROWCH <= 64, "one DMA instruction per row");
 
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -400,7 +401,7 @@ __global__ __launch_bounds__(256) void dw3x3_nhwc(const int8_t *__restrict__ in,
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
     // both buffers := izp, once; the DMAs only ever rewrite the interiors
-    for (int i = tid; i < 2 * BUF / 16; i += 256)
+    for (int i = tid; i < 2 * BUF / 16; i += NTHR)
         ((uint4 *)lds)[i] = make_uint4(p.izp4, p.izp4, p.izp4, p.izp4);
 
     // per-lane constants of this lane's channel group
@@ -438,8 +439,8 @@ __global__ __launch_bounds__(256) void dw3x3_nhwc(const int8_t *__restrict__ in,
 
     auto stage = [&](int st, int buf) {
 #pragma unroll
-        for (int k = 0; k < (NROWS + 3) / 4; ++k) {
-            const int r = k * 4 + wave;           // wave-uniform row of the step
+        for (int k = 0; k < (NROWS + NWAVE - 1) / NWAVE; ++k) {
+            const int r = k * NWAVE + wave;           // wave-uniform row of the step
             const int g = r / H, y = r % H;
             if (r < NROWS && st * G + g < batch && lane < ROWCH)
                 dma16(in + ((size_t)(st * G + g) * IMG + y * ROWB + lane * 16),
@@ -463,7 +464,7 @@ __global__ __launch_bounds__(256) void dw3x3_nhwc(const int8_t *__restrict__ in,
             const int nvalid = min(G, batch - step * G) * OH * OW * C4;
 #pragma unroll 2
             for (int i = 0; i < NOUT; ++i) {
-                const int o = tid + 256 * i;
+                const int o = tid + NTHR * i;
                 if (o < OUTS && o < nvalid) {
                     const int pix = o / C4;
                     const int g = pix / (OH * OW), rem = pix % (OH * OW);
@@ -496,11 +497,11 @@ __global__ __launch_bounds__(256) void dw3x3_nhwc(const int8_t *__restrict__ in,
             // ox0+1 = window . (0,w0,w1,w2): 6 VALU ops per output byte instead of 9.
             constexpr int OWP = (OW + 1) / 2;
             constexpr int TASKS = G * OH * OWP * C4;
-            constexpr int NTASK = (TASKS + 255) / 256;
+            constexpr int NTASK = (TASKS + NTHR - 1) / NTHR;
             const int gvalid = min(G, batch - step * G);
 #pragma unroll 1
             for (int i = 0; i < NTASK; ++i) {
-                const int t = tid + 256 * i;
+                const int t = tid + NTHR * i;
                 const int pp = t / C4;
                 const int g = pp / (OH * OWP), rem = pp % (OH * OWP);
                 const int oy = rem / OWP, ox0 = 2 * (rem % OWP);
@@ -763,14 +764,16 @@ __global__ __launch_bounds__(256) void pw_mfma(const int8_t *__restrict__ in,
                     uint32_t packed[TB];
 #pragma unroll
                     for (int tt = 0; tt < TB; ++tt) {
-                        v4i acc = {0, 0, 0, 0};
+                        // the accumulator starts at Kc (the folded zero-point terms): the MFMA's C
+                        // operand does the addition for free
+                        v4i acc = {cK[tt].x, cK[tt].y, cK[tt].z, cK[tt].w};
 #pragma unroll
                         for (int ks = 0; ks < KS; ++ks)
                             acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(Aw[q][tt][ks], B[u][ks], acc, 0, 0, 0);
-                        const int q0 = requant(acc[0] + cK[tt].x, cA[tt].x, cS[tt].x, p.lo_f, p.hi_f);
-                        const int q1 = requant(acc[1] + cK[tt].y, cA[tt].y, cS[tt].y, p.lo_f, p.hi_f);
-                        const int q2 = requant(acc[2] + cK[tt].z, cA[tt].z, cS[tt].z, p.lo_f, p.hi_f);
-                        const int q3 = requant(acc[3] + cK[tt].w, cA[tt].w, cS[tt].w, p.lo_f, p.hi_f);
+                        const int q0 = requant(acc[0], cA[tt].x, cS[tt].x, p.lo_f, p.hi_f);
+                        const int q1 = requant(acc[1], cA[tt].y, cS[tt].y, p.lo_f, p.hi_f);
+                        const int q2 = requant(acc[2], cA[tt].z, cS[tt].z, p.lo_f, p.hi_f);
+                        const int q3 = requant(acc[3], cA[tt].w, cS[tt].w, p.lo_f, p.hi_f);
                         packed[tt] = pack4(q0, q1, q2, q3);
                     }
                     if constexpr (XPOSE) {
@@ -1067,37 +1070,38 @@ void launch_checksum(const int8_t *in, size_t n, unsigned long long *result, hip
 }
 
 // ---- fast-path dispatch tables ------------------------------------------------
-template <int H, int W, int C, int S, int G>
+template <int H, int W, int C, int S, int G, int NTHR>
 static void launch_dw(const int8_t *in, int8_t *out, const DwFastArgs &a, int batch, hipStream_t s) {
     constexpr int LP = C < 16 ? 16 : C;
     constexpr int lds = 2 * G * (H + 2) * (LP + W * C + LP) + 256; // two staging buffers + read slack
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)dw3x3_nhwc<H, W, C, S, G>,
+        (void)hipFuncSetAttribute((const void *)dw3x3_nhwc<H, W, C, S, G, NTHR>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
-    // persistent workgroups: exactly as many as are resident (LDS- or VGPR-limited), so
+    // persistent workgroups: exactly as many as are resident (LDS- or wave-limited), so
     // that every workgroup walks the same number of steps
-    constexpr int by_lds = 163840 / lds, per_cu = by_lds < 1 ? 1 : (by_lds > 5 ? 5 : by_lds);
+    constexpr int by_lds = 163840 / lds, by_waves = 24 / (NTHR / 64);
+    constexpr int per_cu = by_lds < 1 ? 1 : (by_lds > by_waves ? by_waves : by_lds);
     const int nsteps = (batch + G - 1) / G;
     const int grid = nsteps < 256 * per_cu ? nsteps : 256 * per_cu;
-    hipLaunchKernelGGL((dw3x3_nhwc<H, W, C, S, G>), dim3(grid), dim3(256), lds, s, in, out, a, batch);
+    hipLaunchKernelGGL((dw3x3_nhwc<H, W, C, S, G, NTHR>), dim3(grid), dim3(NTHR), lds, s, in, out, a, batch);
 }
 
 const char *dw_fast_name(int H, int W, int C, int S) {
-#define MF_DW(h, w, c, s, g) \
-    if (H == h && W == w && C == c && S == s) return "dw3x3_nhwc<" #h "," #w "," #c "," #s "," #g ">";
+#define MF_DW(h, w, c, s, g, t) \
+    if (H == h && W == w && C == c && S == s) return "dw3x3_nhwc<" #h "," #w "," #c "," #s "," #g "," #t ">";
     MF_DW_SHAPES(MF_DW)
 #undef MF_DW
     return nullptr;
 }
 bool launch_dw_fast(int H, int W, int C, int S, const int8_t *in, int8_t *out, const DwFastArgs &a,
                     int batch, hipStream_t s) {
-#define MF_DW(h, w, c, st, g)                          \
-    if (H == h && W == w && C == c && S == st) {       \
-        launch_dw<h, w, c, st, g>(in, out, a, batch, s); \
-        return true;                                   \
+#define MF_DW(h, w, c, st, g, t)                          \
+    if (H == h && W == w && C == c && S == st) {          \
+        launch_dw<h, w, c, st, g, t>(in, out, a, batch, s); \
+        return true;                                      \
     }
     MF_DW_SHAPES(MF_DW)
 #undef MF_DW

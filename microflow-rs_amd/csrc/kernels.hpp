@@ -77,17 +77,19 @@ struct PwArgs {
     float lo_f, hi_f;
 };
 
-// shapes with a compiled fast depthwise kernel: H, W, C, stride, images per step
-#define MF_DW_SHAPES(X) \
-    X(48, 48, 8, 1, 1)  \
-    X(48, 48, 16, 2, 1) \
-    X(24, 24, 32, 1, 1) \
-    X(24, 24, 32, 2, 1) \
-    X(12, 12, 64, 1, 1) \
-    X(12, 12, 64, 2, 2) \
-    X(6, 6, 128, 1, 2)  \
-    X(6, 6, 128, 2, 4)  \
-    X(3, 3, 256, 1, 4)
+// shapes with a compiled fast depthwise kernel: H, W, C, stride, images per step, threads per
+// workgroup.  LDS (two staging buffers) decides how many workgroups fit a CU; the thread count
+// is chosen so that 4-6 waves per SIMD are resident (the kernels are VALU-bound).
+#define MF_DW_SHAPES(X)      \
+    X(48, 48, 8, 1, 1, 512)  \
+    X(48, 48, 16, 2, 1, 512) \
+    X(24, 24, 32, 1, 1, 512) \
+    X(24, 24, 32, 2, 1, 256) \
+    X(12, 12, 64, 1, 1, 256) \
+    X(12, 12, 64, 2, 2, 256) \
+    X(6, 6, 128, 1, 2, 256)  \
+    X(6, 6, 128, 2, 4, 256)  \
+    X(3, 3, 256, 1, 4, 256)
 
 // (K = input channels, N = output channels) with a compiled pointwise MFMA kernel
 #define MF_PW_SHAPES(X) \

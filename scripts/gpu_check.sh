@@ -59,3 +59,31 @@ if [[ $STEPS == *pmc* ]]; then
   f=$(find $OUT/pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1)
   [ -n "$f" ] && head -3 "$f"
 fi
+if [[ $STEPS == *sqpmc* ]]; then
+  # SQ counters (8 slots per pass) for the issue/stall breakdown of every kernel
+  rm -rf $OUT/pmc_sq
+  (cd /tmp && timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS --kernel-trace --output-format csv -d "$OLDPWD/$OUT/pmc_sq" -- \
+      python "$OLDPWD/bench.py" --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> "$OLDPWD/$OUT/pmc_sq.err")
+  echo "sq pmc exit $?"
+  rm -rf $OUT/pmc_sq2
+  (cd /tmp && timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU_CVT GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$OLDPWD/$OUT/pmc_sq2" -- \
+      python "$OLDPWD/bench.py" --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> "$OLDPWD/$OUT/pmc_sq2.err")
+  echo "sq2 pmc exit $?"
+  python - <<'PY'
+import csv, glob, re
+from collections import defaultdict
+acc = defaultdict(lambda: defaultdict(list))
+for d in ("gpurun_out/pmc_sq", "gpurun_out/pmc_sq2"):
+    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if "mf::k::" in r["Kernel_Name"]:
+                m = re.search(r"mf::k::([A-Za-z0-9_]+)(<[^>]*>)?", r["Kernel_Name"])
+                acc[m.group(1) + (m.group(2) or "").replace(" ", "")][r["Counter_Name"]].append(float(r["Counter_Value"]))
+names = ["SQ_WAVE_CYCLES","SQ_BUSY_CYCLES","SQ_WAIT_ANY","SQ_WAIT_INST_ANY","SQ_ACTIVE_INST_ANY","SQ_ACTIVE_INST_VALU","SQ_ACTIVE_INST_LDS","SQ_WAIT_INST_LDS","SQ_INSTS_VALU","SQ_INSTS_LDS","SQ_INSTS_SALU","SQ_INSTS_VMEM","SQ_LDS_BANK_CONFLICT","SQ_LDS_IDX_ACTIVE","SQ_INSTS_VALU_CVT","GRBM_GUI_ACTIVE"]
+with open("gpurun_out/sq_summary.csv", "w") as o:
+    o.write("kernel," + ",".join(names) + "\n")
+    for k in sorted(acc):
+        o.write(k + "," + ",".join("%.0f" % (sum(acc[k][n]) / max(len(acc[k][n]), 1)) for n in names) + "\n")
+print(open("gpurun_out/sq_summary.csv").read())
+PY
+fi
