@@ -123,17 +123,34 @@ def main():
     result = None
     if rank == 0:
         # ---- per-kernel HIP-event timing on the launch stream ----
-        avg_ms, per_op = m.time_device(x, y, count, warmup=1, iters=max(5, min(args.steps, 20)))
-        kernels = []
-        for i in range(m.num_ops):
-            d = m.op(i)
-            if not d["kernel"]:
-                continue
-            in_elems = int(np.prod(d["in_shape"]))
-            nbytes = (in_elems + d["out_elems"]) * count  # algorithmic: unique in + out bytes
-            gbs = nbytes / (per_op[i] * 1e-3) / 1e9 if per_op[i] > 0 else 0.0
-            kernels.append({"op": i, "kind": d["name"], "kernel": d["kernel"], "ms": round(per_op[i], 4),
-                            "bytes": nbytes, "GBps": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4)})
+        iters = max(5, min(args.steps, 20))
+
+        def kernel_table():
+            avg_ms, per_op = m.time_device(x, y, count, warmup=1, iters=iters)
+            descs = [m.op(i) for i in range(m.num_ops)]
+            rows = []
+            for i, d in enumerate(descs):
+                if not d["kernel"] or d["kernel"].startswith("(fused"):
+                    continue
+                in_elems = int(np.prod(d["in_shape"]))
+                out_elems, kind = d["out_elems"], d["name"]
+                if d["kernel"].startswith("dwpw3x3"):  # fused pair: depthwise input + pointwise output
+                    out_elems, kind = descs[i + 1]["out_elems"], "depthwise_conv_2d+conv_2d"
+                nbytes = (in_elems + out_elems) * count  # algorithmic: unique in + out bytes
+                gbs = nbytes / (per_op[i] * 1e-3) / 1e9 if per_op[i] > 0 else 0.0
+                rows.append({"op": i, "kind": kind, "kernel": d["kernel"], "ms": round(per_op[i], 4),
+                             "bytes": nbytes, "GBps": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4)})
+            return avg_ms, rows
+
+        def agg(rows, kind):
+            ks = [k for k in rows if k["kind"] == kind]
+            ms = sum(k["ms"] for k in ks)
+            by = sum(k["bytes"] for k in ks)
+            gbs = by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+            return {"kernels": len(ks), "ms": round(ms, 4), "bytes": by, "GBps": round(gbs, 1),
+                    "frac": round(gbs / HBM_PEAK_GBS, 4)}
+
+        avg_ms, kernels = kernel_table()
         dom = max(kernels, key=lambda k: k["ms"])
         # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
         # (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; scripts/pmc_summary.py), if the batch matches
@@ -150,15 +167,15 @@ def main():
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["frac"], "traffic": traffic,
                     "traffic_source": traffic_src,
                     "ms": dom["ms"], "algorithmic_bytes": dom["bytes"],
-                    "method": "HIP events on the launch stream, avg of %d launches" % max(5, min(args.steps, 20))}
+                    "method": "HIP events on the launch stream, avg of %d launches" % iters}
 
-        def agg(kind):
-            ks = [k for k in kernels if k["kind"] == kind]
-            ms = sum(k["ms"] for k in ks)
-            by = sum(k["bytes"] for k in ks)
-            gbs = by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-            return {"kernels": len(ks), "ms": round(ms, 4), "bytes": by, "GBps": round(gbs, 1),
-                    "frac": round(gbs / HBM_PEAK_GBS, 4)}
+        # the same step with the DW+PW fusion switched off: one kernel per reference operator
+        # (the layer-wise DepthwiseConv2D / Conv2D roofline figures of BASELINE.json's targets)
+        m.set_fusion(False)
+        lw_ms, lw_kernels = kernel_table()
+        m.set_fusion(True)
+        layerwise = {"ms_per_step": round(lw_ms, 4), "depthwise": agg(lw_kernels, "depthwise_conv_2d"),
+                     "conv_2d": agg(lw_kernels, "conv_2d"), "kernels": lw_kernels}
 
         # ---- parity: sampled bit-exact comparison with the CPU oracle ----
         from oracle import oracle as O
@@ -181,9 +198,11 @@ def main():
                                    % (fname, B), "per_gpu_batch": B, "global_batch": B * world,
                        "parallelism": "batch shard x%d, no data-path collective" % world},
             "roofline": roofline,
-            "depthwise": agg("depthwise_conv_2d"), "conv_2d": agg("conv_2d"),
+            "fused_dwpw": agg(kernels, "depthwise_conv_2d+conv_2d"),
+            "depthwise": layerwise["depthwise"], "conv_2d": layerwise["conv_2d"],
             "event_ms_per_step": round(avg_ms, 4),
             "kernels": kernels,
+            "layerwise": layerwise,
             "cpu_baseline": cpu,
             "parity": {"bit_exact_vs_oracle": parity_ok, "sampled_images": len(idx),
                        "output_checksums": ["%016x" % c for c in cks]},

@@ -315,6 +315,13 @@ int mf_model_set_generic(mf_model *model, int generic) {
     })
 }
 
+int mf_model_set_fusion(mf_model *model, int enabled) {
+    MF_TRY({
+        MF_NEED(model && model->impl);
+        mf::model_set_fusion(model->impl, enabled != 0);
+    })
+}
+
 int mf_model_predict(mf_model *model, const float *input, size_t batch, float *output, int mem) {
     MF_TRY({
         MF_NEED(model && model->impl && (batch == 0 || (input && output)));

@@ -810,6 +810,282 @@ __global__ __launch_bounds__(256) void pw_mfma(const int8_t *__restrict__ in,
 }
 
 // ------------------------------------------------------------------------
+// FAST PATH 3b -- fused DepthwiseConv2D 3x3 -> Conv2D 1x1.
+//
+// The depthwise kernels are VALU-bound and the large pointwise kernels HBM-bound; running
+// them as one kernel removes the depthwise output / pointwise input round trip through HBM
+// (38 % of the layer-wise traffic) and lets the depthwise VALU work hide under the
+// pointwise output stream.  Per step a workgroup
+//   1. has G images staged in LDS by LDS-DMA (double or single buffered, as in FAST PATH 1),
+//   2. runs the depthwise conv exactly as dw3x3_nhwc does, but writes its packed int8
+//      results to an LDS tile MID laid out [pixel][C] -- which IS the row-major operand
+//      matrix the pointwise MFMA kernel reads,
+//   3. barrier, then each wave runs pw_mfma's chunk loop with its B operand fetched from MID
+//      by ds_read_b128 (same lane -> (pixel, k-block) map) and stores the pointwise outputs
+//      to HBM (16 B per lane; narrow N through the per-wave LDS patch).
+// Both requantisations stay exactly the reference's (the intermediate tensor is a real int8
+// tensor, it just never leaves the CU).  Single-buffered variants issue the next step's DMA
+// right after the second barrier, so it still overlaps the pointwise phase.
+// ------------------------------------------------------------------------
+template <int H, int W, int C, int S, int N, int G, int NTHR, bool DBUF>
+__global__ __launch_bounds__(NTHR) void dwpw3x3(const int8_t *__restrict__ in,
+                                                int8_t *__restrict__ out, DwPwArgs p, int batch) {
+    // ---- depthwise geometry (as dw3x3_nhwc) ----
+    constexpr int C4 = C / 4;
+    constexpr int OH = (H + S - 1) / S, OW = (W + S - 1) / S;
+    constexpr int LP = C < 16 ? 16 : C;
+    constexpr int ROWB = W * C, ROW = LP + ROWB + LP, TILE = (H + 2) * ROW, BUF = G * TILE;
+    constexpr int IMG = H * ROWB, ROWCH = ROWB / 16, NROWS = G * H;
+    constexpr int NWAVE = NTHR / 64;
+    constexpr int NBUF = DBUF ? 2 : 1;
+    constexpr int OPIX = OH * OW;                 // pixels per image after the depthwise
+    constexpr int MIDB = G * OPIX * C;            // bytes of the intermediate tensor per step
+    static_assert(NTHR % C4 == 0 && ROWB % 16 == 0 && ROWCH <= 64, "depthwise geometry");
+    // ---- pointwise geometry (as pw_mfma<K = C, N>) ----
+    constexpr int K = C;
+    constexpr int NB = N < 64 ? N : 64, TB = NB / 16, NSPLIT = N / NB;
+    constexpr int KS = K < 64 ? 1 : K / 64, Q = K < 64 ? 64 / K : 1;
+    constexpr int CPIX = (K < 64) ? (1024 / K) : 16;
+    constexpr int SLOTS = NWAVE / NSPLIT;
+    constexpr bool XPOSE = TB < 4;
+    constexpr int CBYTES = CPIX * N;
+    static_assert(NWAVE % NSPLIT == 0 && N % 16 == 0 && (K == 8 || K % 16 == 0), "pointwise geometry");
+    static_assert(!XPOSE || (NSPLIT == 1 && CBYTES % 1024 == 0), "transposed store geometry");
+    static_assert(K != 8 || (OPIX % 2 == 0), "K = 8 loads two pixels per lane");
+    // LDS: [staging x NBUF][slack 256][MID (+64 slack)][patch]
+    constexpr int MID_OFF = NBUF * BUF + 256;
+    constexpr int PATCH_OFF = MID_OFF + MIDB + 64;
+
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    for (int i = tid; i < (NBUF * BUF + 256) / 16; i += NTHR)
+        ((uint4 *)lds)[i] = make_uint4(p.dw.izp4, p.dw.izp4, p.dw.izp4, p.dw.izp4);
+
+    // ---- depthwise per-lane constants ----
+    const int cg = tid & (C4 - 1);
+    uint32_t wm[S == 2 ? 9 : 1][4];
+    uint32_t wA[S == 1 ? 3 : 1][4], wB[S == 1 ? 3 : 1][4];
+    if constexpr (S == 2) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const uint32_t w = ((const uint32_t *)p.dw.w)[t * C4 + cg];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) wm[t][k] = w & (0xffu << (8 * k));
+        }
+    } else {
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const uint32_t w0 = ((const uint32_t *)p.dw.w)[(ky * 3 + 0) * C4 + cg];
+            const uint32_t w1 = ((const uint32_t *)p.dw.w)[(ky * 3 + 1) * C4 + cg];
+            const uint32_t w2 = ((const uint32_t *)p.dw.w)[(ky * 3 + 2) * C4 + cg];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                wA[ky][k] = ((w0 >> (8 * k)) & 0xffu) | (((w1 >> (8 * k)) & 0xffu) << 8) |
+                            (((w2 >> (8 * k)) & 0xffu) << 16);
+                wB[ky][k] = wA[ky][k] << 8;
+            }
+        }
+    }
+    const float4 dA = ((const float4 *)p.dw.A)[cg], dS = ((const float4 *)p.dw.S)[cg];
+    const int4 dK = ((const int4 *)p.dw.Kc)[cg];
+
+    // ---- pointwise per-lane constants ----
+    const int pcol = lane & 15, pg = lane >> 4;
+    const int blk = wave % NSPLIT, slot = wave / NSPLIT;
+    v4i Aw[Q][TB][KS];
+#pragma unroll
+    for (int q = 0; q < Q; ++q)
+#pragma unroll
+        for (int tt = 0; tt < TB; ++tt)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+                Aw[q][tt][ks] = ((const v4i *)p.pw.wprep)[((((size_t)blk * Q + q) * TB + tt) * KS + ks) * 64 + lane];
+    float4 cA[TB], cS[TB];
+    int4 cK[TB];
+#pragma unroll
+    for (int tt = 0; tt < TB; ++tt) {
+        const int ch = blk * NB + pg * (NB / 4) + 4 * tt;
+        cA[tt] = *(const float4 *)(p.pw.A + ch);
+        cS[tt] = *(const float4 *)(p.pw.S + ch);
+        cK[tt] = *(const int4 *)(p.pw.Kc + ch);
+    }
+    __syncthreads(); // halo fill complete before any DMA lands
+
+    auto stage = [&](int st, int buf) {
+#pragma unroll
+        for (int k = 0; k < (NROWS + NWAVE - 1) / NWAVE; ++k) {
+            const int r = k * NWAVE + wave;
+            const int g = r / H, y = r % H;
+            if (r < NROWS && st * G + g < batch && lane < ROWCH)
+                dma16(in + ((size_t)(st * G + g) * IMG + y * ROWB + lane * 16),
+                      lds + buf * BUF + g * TILE + (y + 1) * ROW + LP);
+        }
+    };
+
+    uint8_t *mid = lds + MID_OFF;
+    const int nsteps = (batch + G - 1) / G;
+    int step = blockIdx.x, cur = 0;
+    if (step < nsteps) stage(step, 0);
+
+    for (; step < nsteps; step += gridDim.x) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads(); // B1: staged tile complete; previous pointwise phase done with MID
+        const int next = step + gridDim.x;
+        if constexpr (DBUF) {
+            if (next < nsteps) stage(next, cur ^ 1);
+        }
+        const uint8_t *tile = lds + cur * BUF;
+        const int gvalid = min(G, batch - step * G);
+
+        // ---------------- depthwise phase: staged tile -> MID ----------------
+        if constexpr (S == 2) {
+            constexpr int OUTS = G * OPIX * C4, NOUT = (OUTS + NTHR - 1) / NTHR;
+            const int nvalid = gvalid * OPIX * C4;
+#pragma unroll 2
+            for (int i = 0; i < NOUT; ++i) {
+                const int o = tid + NTHR * i;
+                if (o < OUTS && o < nvalid) {
+                    const int pix = o / C4;
+                    const int g = pix / OPIX, rem = pix % OPIX;
+                    const int oy = rem / OW, ox = rem % OW;
+                    const uint8_t *base = tile + g * TILE + (oy * S) * ROW + LP + (ox * S - 1) * C + cg * 4;
+                    int a0 = dK.x, a1 = dK.y, a2 = dK.z, a3 = dK.w;
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                        for (int kx = 0; kx < 3; ++kx) {
+                            const uint32_t v = *(const uint32_t *)(base + ky * ROW + kx * C);
+                            const int t = ky * 3 + kx;
+                            a0 = sdot4(v, wm[t][0], a0);
+                            a1 = sdot4(v, wm[t][1], a1);
+                            a2 = sdot4(v, wm[t][2], a2);
+                            a3 = sdot4(v, wm[t][3], a3);
+                        }
+                    ((uint32_t *)mid)[o] = pack4(requant(a0, dA.x, dS.x, p.dw.lo_f, p.dw.hi_f),
+                                                 requant(a1, dA.y, dS.y, p.dw.lo_f, p.dw.hi_f),
+                                                 requant(a2, dA.z, dS.z, p.dw.lo_f, p.dw.hi_f),
+                                                 requant(a3, dA.w, dS.w, p.dw.lo_f, p.dw.hi_f));
+                }
+            }
+        } else {
+            constexpr int OWP = (OW + 1) / 2;
+            constexpr int TASKS = G * OH * OWP * C4, NTASK = (TASKS + NTHR - 1) / NTHR;
+#pragma unroll 1
+            for (int i = 0; i < NTASK; ++i) {
+                const int t = tid + NTHR * i;
+                const int pp = t / C4;
+                const int g = pp / (OH * OWP), rem = pp % (OH * OWP);
+                const int oy = rem / OWP, ox0 = 2 * (rem % OWP);
+                if (t < TASKS && g < gvalid) {
+                    const uint8_t *base = tile + g * TILE + oy * ROW + LP + (ox0 - 1) * C + cg * 4;
+                    int o0[4] = {dK.x, dK.y, dK.z, dK.w}, o1[4] = {dK.x, dK.y, dK.z, dK.w};
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky) {
+                        const uint32_t s0 = *(const uint32_t *)(base + ky * ROW);
+                        const uint32_t s1 = *(const uint32_t *)(base + ky * ROW + C);
+                        const uint32_t s2 = *(const uint32_t *)(base + ky * ROW + 2 * C);
+                        const uint32_t s3 = *(const uint32_t *)(base + ky * ROW + 3 * C);
+                        const uint32_t ab_lo = __builtin_amdgcn_perm(s1, s0, 0x05010400u);
+                        const uint32_t ab_hi = __builtin_amdgcn_perm(s1, s0, 0x07030602u);
+                        const uint32_t cd_lo = __builtin_amdgcn_perm(s3, s2, 0x05010400u);
+                        const uint32_t cd_hi = __builtin_amdgcn_perm(s3, s2, 0x07030602u);
+                        uint32_t win[4];
+                        win[0] = __builtin_amdgcn_perm(cd_lo, ab_lo, 0x05040100u);
+                        win[1] = __builtin_amdgcn_perm(cd_lo, ab_lo, 0x07060302u);
+                        win[2] = __builtin_amdgcn_perm(cd_hi, ab_hi, 0x05040100u);
+                        win[3] = __builtin_amdgcn_perm(cd_hi, ab_hi, 0x07060302u);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            o0[k] = sdot4(win[k], wA[ky][k], o0[k]);
+                            o1[k] = sdot4(win[k], wB[ky][k], o1[k]);
+                        }
+                    }
+                    uint32_t *dp = (uint32_t *)mid + ((size_t)(g * OH + oy) * OW + ox0) * C4 + cg;
+                    dp[0] = pack4(requant(o0[0], dA.x, dS.x, p.dw.lo_f, p.dw.hi_f), requant(o0[1], dA.y, dS.y, p.dw.lo_f, p.dw.hi_f),
+                                  requant(o0[2], dA.z, dS.z, p.dw.lo_f, p.dw.hi_f), requant(o0[3], dA.w, dS.w, p.dw.lo_f, p.dw.hi_f));
+                    if (ox0 + 1 < OW)
+                        dp[C4] = pack4(requant(o1[0], dA.x, dS.x, p.dw.lo_f, p.dw.hi_f), requant(o1[1], dA.y, dS.y, p.dw.lo_f, p.dw.hi_f),
+                                       requant(o1[2], dA.z, dS.z, p.dw.lo_f, p.dw.hi_f), requant(o1[3], dA.w, dS.w, p.dw.lo_f, p.dw.hi_f));
+                }
+            }
+        }
+        __syncthreads(); // B2: MID complete; everyone is done reading the staged tile
+        if constexpr (!DBUF) {
+            if (next < nsteps) stage(next, 0); // flies during the pointwise phase
+        }
+
+        // ---------------- pointwise phase: MID -> HBM ----------------
+        const int npix = gvalid * OPIX;                       // valid pixels of this step
+        const int nchunks = (npix + CPIX - 1) / CPIX;
+        int8_t *obase = out + (size_t)step * G * OPIX * N;
+        for (int chunk = slot; chunk < nchunks; chunk += SLOTS) {
+            v4i B[KS];
+            if constexpr (K >= 64) {
+                int pix = chunk * 16 + pcol;
+                pix = pix < npix ? pix : npix - 1;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) B[ks] = *(const v4i *)(mid + pix * K + pg * 16 + ks * 64);
+            } else if constexpr (K == 32) {
+                int pix = chunk * CPIX + (pg >> 1) * 16 + pcol;
+                pix = pix < npix ? pix : npix - 1;
+                B[0] = *(const v4i *)(mid + pix * 32 + (pg & 1) * 16);
+            } else if constexpr (K == 16) {
+                int pix = chunk * CPIX + pg * 16 + pcol;
+                pix = pix < npix ? pix : npix - 1;
+                B[0] = *(const v4i *)(mid + pix * 16);
+            } else {
+                int pix = chunk * CPIX + 2 * (pg * 16 + pcol);
+                pix = pix + 1 < npix ? pix : npix - 2;
+                B[0] = *(const v4i *)(mid + pix * 8);
+            }
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                int lpix;
+                if constexpr (K >= 64) lpix = pcol;
+                else if constexpr (K == 8) lpix = 2 * ((q >> 1) * 16 + pcol) + (q & 1);
+                else lpix = q * 16 + pcol;
+                uint32_t packed[TB];
+#pragma unroll
+                for (int tt = 0; tt < TB; ++tt) {
+                    v4i acc = {cK[tt].x, cK[tt].y, cK[tt].z, cK[tt].w};
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks)
+                        acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(Aw[q][tt][ks], B[ks], acc, 0, 0, 0);
+                    packed[tt] = pack4(requant(acc[0], cA[tt].x, cS[tt].x, p.pw.lo_f, p.pw.hi_f),
+                                       requant(acc[1], cA[tt].y, cS[tt].y, p.pw.lo_f, p.pw.hi_f),
+                                       requant(acc[2], cA[tt].z, cS[tt].z, p.pw.lo_f, p.pw.hi_f),
+                                       requant(acc[3], cA[tt].w, cS[tt].w, p.pw.lo_f, p.pw.hi_f));
+                }
+                if constexpr (XPOSE) {
+                    uint8_t *dstp = lds + PATCH_OFF + wave * CBYTES + lpix * N + pg * (NB / 4);
+                    if constexpr (TB == 1) *(uint32_t *)dstp = packed[0];
+                    else *(uint2 *)dstp = make_uint2(packed[0], packed[1]);
+                } else {
+                    const int pix = chunk * CPIX + lpix;
+                    if (pix < npix)
+                        *(uint4 *)(obase + (size_t)pix * N + blk * NB + pg * 16) =
+                            make_uint4(packed[0], packed[1], packed[2], packed[3]);
+                }
+            }
+            if constexpr (XPOSE) {
+                __builtin_amdgcn_wave_barrier();
+                const int cb = chunk * CBYTES, obytes = npix * N;
+#pragma unroll
+                for (int j = 0; j < CBYTES / 1024; ++j) {
+                    const int off = (j * 64 + lane) * 16;
+                    const uint4 v = *(const uint4 *)(lds + PATCH_OFF + wave * CBYTES + off);
+                    if (cb + off < obytes) *(uint4 *)(obase + cb + off) = v;
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        if constexpr (DBUF) cur ^= 1;
+    }
+}
+
+// ------------------------------------------------------------------------
 // FAST PATH 4 -- FullyConnected as a dense int8 MFMA GEMM (BASELINE config 5).
 // (src/ops/fully_connected.rs:24-82; rows of all inferences form one [M][K] matrix)
 //
@@ -1121,6 +1397,46 @@ bool launch_dw_stem(int H, int W, int DM, int S, const int8_t *in, int8_t *out, 
         hipLaunchKernelGGL((dw3x3_stem8<96, 96, G>), dim3(grid), dim3(256), lds, s, in, out, a, batch);
         return true;
     }
+    return false;
+}
+
+template <int H, int W, int C, int S, int N, int G, int NTHR, int DB>
+static void launch_dwpw_t(const int8_t *in, int8_t *out, const DwPwArgs &a, int batch, hipStream_t s) {
+    constexpr int LP = C < 16 ? 16 : C;
+    constexpr int OH = (H + S - 1) / S, OW = (W + S - 1) / S;
+    constexpr int BUF = G * (H + 2) * (LP + W * C + LP);
+    constexpr int NB = N < 64 ? N : 64, CPIX = C < 64 ? 1024 / C : 16;
+    constexpr int patch = (NB / 16 < 4) ? (NTHR / 64) * CPIX * N : 0;
+    constexpr int lds = (DB ? 2 : 1) * BUF + 256 + G * OH * OW * C + 64 + patch;
+    static_assert(lds <= 163840, "fused tile does not fit the LDS");
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)dwpw3x3<H, W, C, S, N, G, NTHR, (DB != 0)>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set = true;
+    }
+    constexpr int by_lds = 163840 / lds, by_waves = 24 / (NTHR / 64);
+    constexpr int per_cu = by_lds < 1 ? 1 : (by_lds > by_waves ? by_waves : by_lds);
+    const int nsteps = (batch + G - 1) / G;
+    const int grid = nsteps < 256 * per_cu ? nsteps : 256 * per_cu;
+    hipLaunchKernelGGL((dwpw3x3<H, W, C, S, N, G, NTHR, (DB != 0)>), dim3(grid), dim3(NTHR), lds, s, in, out, a, batch);
+}
+const char *dwpw_name(int H, int W, int C, int S, int N) {
+#define MF_DWPW(h, w, c, s, n, g, t, d) \
+    if (H == h && W == w && C == c && S == s && N == n) return "dwpw3x3<" #h "," #w "," #c "," #s "," #n "," #g "," #t "," #d ">";
+    MF_DWPW_SHAPES(MF_DWPW)
+#undef MF_DWPW
+    return nullptr;
+}
+bool launch_dwpw(int H, int W, int C, int S, int N, const int8_t *in, int8_t *out, const DwPwArgs &a,
+                 int batch, hipStream_t s) {
+#define MF_DWPW(h, w, c, st, n, g, t, d)                         \
+    if (H == h && W == w && C == c && S == st && N == n) {       \
+        launch_dwpw_t<h, w, c, st, n, g, t, d>(in, out, a, batch, s); \
+        return true;                                             \
+    }
+    MF_DWPW_SHAPES(MF_DWPW)
+#undef MF_DWPW
     return false;
 }
 

@@ -69,12 +69,19 @@ struct DwStemArgs {
     uint32_t izp4;
     float lo_f, hi_f;
 };
+struct DwPwArgs;
 struct PwArgs {
     const void *wprep;  // [blk][q][tile][kstep][lane] x 16 bytes, MFMA operand-A layout
     const float *A;
     const float *S;
     const int *Kc;
     float lo_f, hi_f;
+};
+
+// fused DepthwiseConv2D 3x3 -> Conv2D 1x1: both argument blocks
+struct DwPwArgs {
+    DwFastArgs dw;
+    PwArgs pw;
 };
 
 // shapes with a compiled fast depthwise kernel: H, W, C, stride, images per step, threads per
@@ -90,6 +97,19 @@ struct PwArgs {
     X(6, 6, 128, 1, 2, 256)  \
     X(6, 6, 128, 2, 4, 256)  \
     X(3, 3, 256, 1, 4, 256)
+
+// fused depthwise 3x3 + pointwise pairs: H, W, C, stride, N (pointwise outputs), images per
+// step, threads per workgroup, double-buffered staging (1) or single (0)
+#define MF_DWPW_SHAPES(X)           \
+    X(48, 48, 8, 1, 16, 1, 512, 1)  \
+    X(48, 48, 16, 2, 32, 1, 512, 0) \
+    X(24, 24, 32, 1, 32, 1, 512, 1) \
+    X(24, 24, 32, 2, 64, 2, 256, 0) \
+    X(12, 12, 64, 1, 64, 2, 512, 1) \
+    X(12, 12, 64, 2, 128, 4, 512, 0) \
+    X(6, 6, 128, 1, 128, 4, 512, 0) \
+    X(6, 6, 128, 2, 256, 4, 256, 0) \
+    X(3, 3, 256, 1, 256, 4, 256, 0)
 
 // (K = input channels, N = output channels) with a compiled pointwise MFMA kernel
 #define MF_PW_SHAPES(X) \
@@ -124,6 +144,9 @@ bool launch_dw_fast(int H, int W, int C, int S, const int8_t *in, int8_t *out, c
 const char *dw_stem_name(int H, int W, int DM, int S);
 bool launch_dw_stem(int H, int W, int DM, int S, const int8_t *in, int8_t *out, const DwStemArgs &a,
                     int batch, hipStream_t s);
+const char *dwpw_name(int H, int W, int C, int S, int N);
+bool launch_dwpw(int H, int W, int C, int S, int N, const int8_t *in, int8_t *out, const DwPwArgs &a,
+                 int batch, hipStream_t s);
 const char *pw_name(int K, int N);
 bool launch_pw(int K, int N, const int8_t *in, int8_t *out, const PwArgs &a, long long npix, hipStream_t s);
 

@@ -98,6 +98,13 @@ size_t op_in_elems(const OpImpl *op);
 size_t op_out_elems(const OpImpl *op);
 const char *op_kernel_name(const OpImpl *op);
 void op_set_generic(OpImpl *op, bool generic);
+// fused DepthwiseConv2D 3x3 -> Conv2D 1x1 (borrows both operators' device buffers; nullptr when
+// the pair has no fused kernel)
+struct FusedImpl;
+FusedImpl *fused_create(OpImpl *dw, OpImpl *pw);
+void fused_destroy(FusedImpl *f);
+void fused_run(FusedImpl *f, const int8_t *d_in, size_t batch, int8_t *d_out, void *stream);
+const char *fused_kernel_name(const FusedImpl *f);
 
 void dev_quantize(int device, const float *d_in, size_t n, float scale, int8_t zp, int8_t *d_out,
                   void *stream);
@@ -118,6 +125,7 @@ void model_prepare(ModelImpl *m, int device, size_t max_batch);
 void model_set_stream(ModelImpl *m, void *stream);
 void model_sync(ModelImpl *m);
 void model_set_generic(ModelImpl *m, bool generic);
+void model_set_fusion(ModelImpl *m, bool enabled);
 // in_f32 or in_i8 (exactly one non-null); out_f32 or out_i8 (exactly one non-null)
 void model_run(ModelImpl *m, const float *in_f32, const int8_t *in_i8, size_t batch,
                float *out_f32, int8_t *out_i8, int mem, int last_op);

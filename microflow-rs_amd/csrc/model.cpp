@@ -34,6 +34,8 @@ struct ModelImpl {
     bool generic = false;
     hipStream_t stream = nullptr;
     std::vector<OpImpl *> ops; // nullptr for Reshape
+    std::vector<FusedImpl *> fused; // fused[i] != nullptr: ops i (depthwise) and i+1 (1x1 conv) as one kernel
+    bool fusion = true;
     size_t cap_batch = 0;
     int8_t *act[2] = {nullptr, nullptr};
     int8_t *in_q = nullptr;   // quantized input staging (host-fed or f32 path)
@@ -42,6 +44,7 @@ struct ModelImpl {
 
     ~ModelImpl() {
         if (device >= 0) (void)hipSetDevice(device);
+        for (FusedImpl *f : fused) fused_destroy(f);
         for (OpImpl *o : ops) op_destroy(o);
         free_buffers();
     }
@@ -65,8 +68,13 @@ ModelImpl *model_create(const uint8_t *buf, size_t len) {
 }
 void model_destroy(ModelImpl *m) { delete m; }
 const ParsedModel &model_parsed(const ModelImpl *m) { return m->pm; }
+static bool fused_at(const ModelImpl *m, int i) {
+    return m->fusion && !m->generic && i >= 0 && i < (int)m->fused.size() && m->fused[(size_t)i];
+}
 const char *model_op_kernel(const ModelImpl *m, int i) {
     if (!m->prepared || i < 0 || i >= (int)m->ops.size() || !m->ops[i]) return "";
+    if (fused_at(m, i)) return fused_kernel_name(m->fused[(size_t)i]);
+    if (fused_at(m, i - 1)) return "(fused into the previous operator)";
     return op_kernel_name(m->ops[i]);
 }
 
@@ -121,6 +129,12 @@ void model_prepare(ModelImpl *m, int device, size_t max_batch) {
             cur_scale = po.out_scale;
             cur_zp = po.out_zp;
         }
+        // peephole: DepthwiseConv2D 3x3 directly followed by a 1x1 Conv2D -> one fused kernel
+        m->fused.assign(m->ops.size(), nullptr);
+        for (size_t i = 0; i + 1 < m->ops.size(); ++i)
+            if (m->pm.ops[i].kind == MF_OP_DEPTHWISE_CONV_2D && m->pm.ops[i + 1].kind == MF_OP_CONV_2D &&
+                !(i > 0 && m->fused[i - 1]))
+                m->fused[i] = fused_create(m->ops[i], m->ops[i + 1]);
         m->prepared = true;
         model_set_generic(m, m->generic);
     }
@@ -134,6 +148,8 @@ void model_sync(ModelImpl *m) {
     MF_HIP(hipSetDevice(m->device));
     MF_HIP(hipStreamSynchronize(m->stream));
 }
+
+void model_set_fusion(ModelImpl *m, bool enabled) { m->fusion = enabled; }
 
 void model_set_generic(ModelImpl *m, bool generic) {
     m->generic = generic;
@@ -153,7 +169,12 @@ static const int8_t *run_ops(ModelImpl *m, const int8_t *src, size_t batch, int 
             which ^= 1;
             dst = m->act[which];
         }
-        op_run(o, cur, batch, dst, m->stream);
+        if (fused_at(m, i) && i + 1 <= last_op) { // depthwise + pointwise in one launch
+            fused_run(m->fused[(size_t)i], cur, batch, dst, m->stream);
+            ++i;
+        } else {
+            op_run(o, cur, batch, dst, m->stream);
+        }
         cur = dst;
         which ^= 1;
     }
@@ -250,7 +271,13 @@ void model_time_device(ModelImpl *m, const int8_t *d_in, size_t batch, int8_t *d
                         which ^= 1;
                         dst = m->act[which];
                     }
-                    op_run(o, cur, batch, dst, s);
+                    if (fused_at(m, i) && i + 1 < nops) { // the pair is timed as one unit (index i)
+                        fused_run(m->fused[(size_t)i], cur, batch, dst, s);
+                        MF_HIP(hipEventRecord(ev[(size_t)i + 1], s));
+                        ++i;
+                    } else {
+                        op_run(o, cur, batch, dst, s);
+                    }
                     cur = dst;
                     which ^= 1;
                 }

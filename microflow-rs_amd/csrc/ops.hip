@@ -378,6 +378,35 @@ void op_run(OpImpl *op, const int8_t *d_in, size_t batch, int8_t *d_out, void *s
     MF_HIP(hipGetLastError());
 }
 
+struct FusedImpl {
+    OpImpl *dw, *pw;
+    k::DwPwArgs args;
+    std::string name;
+};
+
+FusedImpl *fused_create(OpImpl *dw, OpImpl *pw) {
+    if (!dw || !pw || dw->fast != OpImpl::DW_NHWC || pw->fast != OpImpl::PW_MFMA) return nullptr;
+    const OpSpec &d = dw->s, &q = pw->s;
+    // the pointwise conv must consume exactly the depthwise output tensor
+    if (q.H != d.OH || q.W != d.OW || q.C != d.N || dw->device != pw->device) return nullptr;
+    const char *nm = k::dwpw_name(d.H, d.W, d.C, d.sh, q.N);
+    if (!nm) return nullptr;
+    FusedImpl *f = new FusedImpl{dw, pw, {}, nm};
+    f->args.dw = dw->dwf;
+    f->args.pw = pw->pw;
+    return f;
+}
+void fused_destroy(FusedImpl *f) { delete f; }
+const char *fused_kernel_name(const FusedImpl *f) { return f->name.c_str(); }
+void fused_run(FusedImpl *f, const int8_t *d_in, size_t batch, int8_t *d_out, void *stream) {
+    if (!batch) return;
+    if (batch > 0x7fffffffull / 4) fail(MF_ERR_INVALID_ARG, "batch too large for one launch");
+    const OpSpec &d = f->dw->s;
+    if (!k::launch_dwpw(d.H, d.W, d.C, d.sh, f->pw->s.N, d_in, d_out, f->args, (int)batch, (hipStream_t)stream))
+        fail(MF_ERR_UNSUPPORTED, "fused kernel missing");
+    MF_HIP(hipGetLastError());
+}
+
 void dev_quantize(int device, const float *d_in, size_t n, float scale, int8_t zp, int8_t *d_out,
                   void *stream) {
     dev_require(device);

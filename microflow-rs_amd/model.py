@@ -87,6 +87,10 @@ class Model:
         _lib.check(_lib.lib().mf_model_set_generic(self._h, int(generic)))
         return self
 
+    def set_fusion(self, enabled=True):
+        _lib.check(_lib.lib().mf_model_set_fusion(self._h, int(enabled)))
+        return self
+
     def sync(self):
         _lib.check(_lib.lib().mf_model_sync(self._h))
 

@@ -29,7 +29,8 @@ import json
 try:
     r = json.loads(open("gpurun_out/bench.json").read().strip().splitlines()[-1])
     print("value", r["value"], r["unit"], "ms/step", r["ms_per_step"], "roofline", r["roofline"])
-    print("depthwise", r["depthwise"], "conv", r["conv_2d"])
+    print("fused", r.get("fused_dwpw"))
+    print("layerwise ms", r["layerwise"]["ms_per_step"], "depthwise", r["depthwise"], "conv", r["conv_2d"])
     for k in r["kernels"]:
         print("%2d %-18s %-28s %8.4f ms %8.1f GB/s %.3f" % (k["op"], k["kind"], k["kernel"], k["ms"], k["GBps"], k["frac"]))
     print("cpu", r["cpu_baseline"]); print("parity", r["parity"])

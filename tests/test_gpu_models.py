@@ -165,43 +165,31 @@ def test_kernel_routing(models):
     m.prepare(1)
     names = [m.op(i)["kernel"] for i in range(m.num_ops)]
     assert names[0].startswith("dw3x3_stem8")
-    assert sum(n.startswith("dw3x3_nhwc") for n in names) == 13
-    assert sum(n.startswith("pw_mfma") for n in names) == 13
+    assert sum(n.startswith("dwpw3x3") for n in names) == 13          # fused depthwise + 1x1 conv pairs
+    assert sum(n.startswith("(fused") for n in names) == 13
     assert names[28] == "conv2d_generic" and names[27] == "avgpool_generic"
     assert names[29] == "" and names[30] == "softmax_table"
+    m.set_fusion(False)
+    names = [m.op(i)["kernel"] for i in range(m.num_ops)]
+    m.set_fusion(True)
+    assert sum(n.startswith("dw3x3_nhwc") for n in names) == 13
+    assert sum(n.startswith("pw_mfma") for n in names) == 13
 
 
-@pytest.mark.parametrize("wzp", [0, 11])
-def test_fc_4096_cubed_through_predict(mf, O, wzp):
-    """BASELINE config 5: FullyConnected 4096x4096x4096 as a generated single-op model run
-    through predict(); MFMA GEMM vs the oracle on sampled rows (rows are independent) and vs
-    the shape-generic kernel on the full output."""
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 8, 13, 64, 257])
+def test_fused_equals_layerwise(models, n):
+    """DW+PW fusion on/off must give identical int8 tensors at every operator boundary that
+    still exists (i.e. after each pair), for batch sizes around every images-per-step value."""
     import torch
-    from tools.make_fc_model import synthetic_fc
-    M = K = N = 4096
-    blob = synthetic_fc(M, K, N, wzp=wzp, seed=5 + wzp)
-    m = mf.model(blob)
-    m.prepare(1)
-    assert m.op(0)["kernel"] == "fc_mfma" and m.input_shape == (M, K) and m.output_shape == (M, N)
-    rng = np.random.default_rng(1)
-    xq = rng.integers(-128, 128, (M, K), dtype=np.int8)
-    xd = torch.from_numpy(xq).cuda()
-    y = m.run_quantized(xd)
-    m.sync()
-    # oracle on 6 sampled rows: a [6, K] model sharing the same weights
-    rows = [0, 1, 127, 128, 2049, 4095]
-    om = O.Model(synthetic_fc(len(rows), K, N, wzp=wzp, seed=5 + wzp))
-    want = om.run_quantized(xq[rows]).reshape(len(rows), N)
-    assert np.array_equal(y[rows].cpu().numpy(), want)
-    assert len(np.unique(want)) > 100
-    # f32 entry point (quantize -> GEMM -> dequantize) on the same data
-    xf = (xq[rows].astype(f32) - f32(m.input_zero_point)) * m.input_scale
-    wantf = om.predict(xf).reshape(len(rows), N)
-    full_f = m.predict(((xd.float() - float(m.input_zero_point)) * float(m.input_scale)))
-    assert np.array_equal(full_f[rows].cpu().numpy(), wantf)
-    # whole output vs the shape-generic kernel
-    m.set_generic(True)
-    yg = m.run_quantized(xd)
-    m.sync()
-    m.set_generic(False)
-    assert torch.equal(y, yg)
+    m = models["person_detect"]
+    x = synth_i8(3, 9000, n, m.input_elems).reshape((n,) + m.input_shape)
+    for last in (2, 4, 6, 8, 10, 12, 14, 22, 24, 26, 30):
+        m.set_fusion(True)
+        a = m.run_until(x, last)
+        m.set_fusion(False)
+        b = m.run_until(x, last)
+        m.set_fusion(True)
+        assert np.array_equal(a, b), ("first mismatch after op", last, m.op(last - 1)["kernel"])
+    # a depthwise op as the last op always runs unfused
+    assert np.array_equal(m.run_until(x, 1), m.set_fusion(False).run_until(x, 1))
+    m.set_fusion(True)
