@@ -943,7 +943,7 @@ __global__ __launch_bounds__(NTHR) void dwpw3x3(const int8_t *__restrict__ in,
         if constexpr (S == 2) {
             constexpr int OUTS = G * OPIX * C4, NOUT = (OUTS + NTHR - 1) / NTHR;
             const int nvalid = gvalid * OPIX * C4;
-#pragma unroll 2
+#pragma unroll 1
             for (int i = 0; i < NOUT; ++i) {
                 const int o = tid + NTHR * i;
                 if (o < OUTS && o < nvalid) {
@@ -1270,6 +1270,18 @@ __global__ __launch_bounds__(256) void fc_rowsum(const int8_t *__restrict__ in, 
 // ------------------------------------------------------------------------
 // launchers (host)
 // ------------------------------------------------------------------------
+// Persistent-workgroup kernels launch exactly as many workgroups as are resident (LDS-,
+// VGPR- or wave-limited, asked of the runtime once per kernel), so every workgroup walks the
+// same number of steps and none queues behind a finished one.
+template <typename Kern> static int resident_per_cu(Kern kern, int threads, int lds_bytes) {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, threads, (size_t)lds_bytes) != hipSuccess || n < 1) {
+        (void)hipGetLastError();
+        n = 1;
+    }
+    return n;
+}
+
 static inline int grid_for(size_t total, int per_block = 256, int cap = 256 * 8) {
     size_t g = (total + per_block - 1) / per_block;
     if (g < 1) g = 1;
@@ -1356,10 +1368,7 @@ static void launch_dw(const int8_t *in, int8_t *out, const DwFastArgs &a, int ba
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
-    // persistent workgroups: exactly as many as are resident (LDS- or wave-limited), so
-    // that every workgroup walks the same number of steps
-    constexpr int by_lds = 163840 / lds, by_waves = 24 / (NTHR / 64);
-    constexpr int per_cu = by_lds < 1 ? 1 : (by_lds > by_waves ? by_waves : by_lds);
+    static const int per_cu = resident_per_cu(dw3x3_nhwc<H, W, C, S, G, NTHR>, NTHR, lds);
     const int nsteps = (batch + G - 1) / G;
     const int grid = nsteps < 256 * per_cu ? nsteps : 256 * per_cu;
     hipLaunchKernelGGL((dw3x3_nhwc<H, W, C, S, G, NTHR>), dim3(grid), dim3(NTHR), lds, s, in, out, a, batch);
@@ -1392,8 +1401,9 @@ bool launch_dw_stem(int H, int W, int DM, int S, const int8_t *in, int8_t *out, 
                     int batch, hipStream_t s) {
     if (H == 96 && W == 96 && DM == 8 && S == 2) {
         constexpr int G = 2, lds = 2 * G * (16 + (96 + 2) * 96);
+        static const int per_cu = resident_per_cu(dw3x3_stem8<96, 96, G>, 256, lds);
         const int nsteps = (batch + G - 1) / G;
-        const int grid = nsteps < 256 * 4 ? nsteps : 256 * 4; // 37.7 KB LDS -> 4 resident per CU
+        const int grid = nsteps < 256 * per_cu ? nsteps : 256 * per_cu;
         hipLaunchKernelGGL((dw3x3_stem8<96, 96, G>), dim3(grid), dim3(256), lds, s, in, out, a, batch);
         return true;
     }
@@ -1415,8 +1425,7 @@ static void launch_dwpw_t(const int8_t *in, int8_t *out, const DwPwArgs &a, int 
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
-    constexpr int by_lds = 163840 / lds, by_waves = 24 / (NTHR / 64);
-    constexpr int per_cu = by_lds < 1 ? 1 : (by_lds > by_waves ? by_waves : by_lds);
+    static const int per_cu = resident_per_cu(dwpw3x3<H, W, C, S, N, G, NTHR, (DB != 0)>, NTHR, lds);
     const int nsteps = (batch + G - 1) / G;
     const int grid = nsteps < 256 * per_cu ? nsteps : 256 * per_cu;
     hipLaunchKernelGGL((dwpw3x3<H, W, C, S, N, G, NTHR, (DB != 0)>), dim3(grid), dim3(NTHR), lds, s, in, out, a, batch);

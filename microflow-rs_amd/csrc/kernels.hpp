@@ -102,7 +102,7 @@ struct DwPwArgs {
 // step, threads per workgroup, double-buffered staging (1) or single (0)
 #define MF_DWPW_SHAPES(X)           \
     X(48, 48, 8, 1, 16, 1, 512, 1)  \
-    X(48, 48, 16, 2, 32, 1, 512, 0) \
+    X(48, 48, 16, 2, 32, 1, 512, 1) \
     X(24, 24, 32, 1, 32, 1, 512, 1) \
     X(24, 24, 32, 2, 64, 2, 256, 0) \
     X(12, 12, 64, 1, 64, 2, 512, 1) \
