@@ -28,7 +28,10 @@ def load(d, counter):
 
 def short(name):
     m = re.search(r"mf::k::([A-Za-z0-9_]+)(<[^>]*>)?", name)
-    return (m.group(1) + (m.group(2) or "").replace(" ", "")) if m else name[:40]
+    if not m:
+        return name[:40]
+    # rocprofv3 prints bool template arguments as true/false, the library's names use 1/0
+    return m.group(1) + (m.group(2) or "").replace(" ", "").replace(",true>", ",1>").replace(",false>", ",0>")
 
 
 def main():
@@ -39,7 +42,7 @@ def main():
         bench = json.loads(open(sys.argv[3]).read().strip().splitlines()[-1])
     alg = {}
     if bench:
-        for k in bench["kernels"]:
+        for k in bench["kernels"] + bench.get("layerwise", {}).get("kernels", []):
             alg.setdefault(k["kernel"], k["bytes"])
     out = {"per_gpu_batch": bench["config"]["per_gpu_batch"] if bench else None,
            "unit": "bytes per launch", "fetch_correction": "FETCH_SIZE x 2 (gfx950 wide-read calibration)",
