@@ -355,6 +355,53 @@ __device__ __forceinline__ void dma16(const int8_t *src_lane, uint8_t *lds_wave_
 }
 
 // ------------------------------------------------------------------------
+// Stride-1 depthwise 3x3 task: R output rows x 2 adjacent pixels x 4 channels.
+// Per INPUT row the 4 pixels ox0-1 .. ox0+2 (4 channel dwords) are byte-transposed (8 v_perm)
+// into 4 per-channel windows [v(-1), v(0), v(+1), v(+2)]; each window feeds up to three
+// output rows (as filter row ky = input row - output row): pixel ox0 = window . (w0,w1,w2,0),
+// pixel ox0+1 = window . (0,w0,w1,w2).  R = 2 shares the transposes of the two middle
+// input rows: 5 VALU ops per output byte instead of 6 (and 9 for byte-masked taps).
+// `base` = LDS address of (input row oy0-1, pixel ox0-1, this lane's channel group).
+// ------------------------------------------------------------------------
+template <int R, int ROW, int C>
+__device__ __forceinline__ void dw_s1_task(const uint8_t *base, const uint32_t (&wA)[3][4],
+                                           const uint32_t (&wB)[3][4], const int4 Kc,
+                                           int (&o0)[R][4], int (&o1)[R][4]) {
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        o0[j][0] = o1[j][0] = Kc.x, o0[j][1] = o1[j][1] = Kc.y;
+        o0[j][2] = o1[j][2] = Kc.z, o0[j][3] = o1[j][3] = Kc.w;
+    }
+#pragma unroll
+    for (int r = 0; r < R + 2; ++r) {
+        const uint32_t s0 = *(const uint32_t *)(base + r * ROW);
+        const uint32_t s1 = *(const uint32_t *)(base + r * ROW + C);
+        const uint32_t s2 = *(const uint32_t *)(base + r * ROW + 2 * C);
+        const uint32_t s3 = *(const uint32_t *)(base + r * ROW + 3 * C);
+        const uint32_t ab_lo = __builtin_amdgcn_perm(s1, s0, 0x05010400u);
+        const uint32_t ab_hi = __builtin_amdgcn_perm(s1, s0, 0x07030602u);
+        const uint32_t cd_lo = __builtin_amdgcn_perm(s3, s2, 0x05010400u);
+        const uint32_t cd_hi = __builtin_amdgcn_perm(s3, s2, 0x07030602u);
+        uint32_t win[4];
+        win[0] = __builtin_amdgcn_perm(cd_lo, ab_lo, 0x05040100u);
+        win[1] = __builtin_amdgcn_perm(cd_lo, ab_lo, 0x07060302u);
+        win[2] = __builtin_amdgcn_perm(cd_hi, ab_hi, 0x05040100u);
+        win[3] = __builtin_amdgcn_perm(cd_hi, ab_hi, 0x07060302u);
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            const int ky = r - j; // filter row this input row plays for output row j
+            if (ky >= 0 && ky <= 2) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    o0[j][k] = sdot4(win[k], wA[ky][k], o0[j][k]);
+                    o1[j][k] = sdot4(win[k], wB[ky][k], o1[j][k]);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------
 // FAST PATH 1 -- DepthwiseConv2D 3x3, SAME, NHWC, C % 4 == 0, weight zp == 0.
 // (src/ops/depthwise_conv_2d.rs:28-105; person_detect ops 1,3,5,...,25)
 //
@@ -491,52 +538,30 @@ __global__ __launch_bounds__(NTHR) void dw3x3_nhwc(const int8_t *__restrict__ in
                 }
             }
         } else {
-            // task = 2 adjacent output pixels x 4 channels.  Per filter row: the 4 input pixels
-            // ox0-1 .. ox0+2 (4 channel dwords) are byte-transposed (8 v_perm) into 4 per-channel
-            // window dwords [v(-1),v(0),v(+1),v(+2)]; pixel ox0 = window . (w0,w1,w2,0), pixel
-            // ox0+1 = window . (0,w0,w1,w2): 6 VALU ops per output byte instead of 9.
-            constexpr int OWP = (OW + 1) / 2;
-            constexpr int TASKS = G * OH * OWP * C4;
+            // task = R output rows x 2 adjacent pixels x 4 channels (see dw_s1_task)
+            constexpr int R = (OH % 2 == 0) ? 2 : 1;
+            constexpr int OWP = (OW + 1) / 2, OHR = OH / R;
+            constexpr int TASKS = G * OHR * OWP * C4;
             constexpr int NTASK = (TASKS + NTHR - 1) / NTHR;
             const int gvalid = min(G, batch - step * G);
 #pragma unroll 1
             for (int i = 0; i < NTASK; ++i) {
                 const int t = tid + NTHR * i;
                 const int pp = t / C4;
-                const int g = pp / (OH * OWP), rem = pp % (OH * OWP);
-                const int oy = rem / OWP, ox0 = 2 * (rem % OWP);
+                const int g = pp / (OHR * OWP), rem = pp % (OHR * OWP);
+                const int oy0 = R * (rem / OWP), ox0 = 2 * (rem % OWP);
                 if (t < TASKS && g < gvalid) {
-                    const uint8_t *base = tile + g * TILE + oy * ROW + LP + (ox0 - 1) * C + cg * 4;
-                    int o0[4] = {Kc.x, Kc.y, Kc.z, Kc.w}, o1[4] = {Kc.x, Kc.y, Kc.z, Kc.w};
+                    int o0[R][4], o1[R][4];
+                    dw_s1_task<R, ROW, C>(tile + g * TILE + oy0 * ROW + LP + (ox0 - 1) * C + cg * 4, wA, wB, Kc, o0, o1);
 #pragma unroll
-                    for (int ky = 0; ky < 3; ++ky) {
-                        const uint32_t s0 = *(const uint32_t *)(base + ky * ROW);
-                        const uint32_t s1 = *(const uint32_t *)(base + ky * ROW + C);
-                        const uint32_t s2 = *(const uint32_t *)(base + ky * ROW + 2 * C);
-                        const uint32_t s3 = *(const uint32_t *)(base + ky * ROW + 3 * C);
-                        // 4x4 byte transpose: win[k] = (s0.k, s1.k, s2.k, s3.k)
-                        const uint32_t ab_lo = __builtin_amdgcn_perm(s1, s0, 0x05010400u);
-                        const uint32_t ab_hi = __builtin_amdgcn_perm(s1, s0, 0x07030602u);
-                        const uint32_t cd_lo = __builtin_amdgcn_perm(s3, s2, 0x05010400u);
-                        const uint32_t cd_hi = __builtin_amdgcn_perm(s3, s2, 0x07030602u);
-                        uint32_t win[4];
-                        win[0] = __builtin_amdgcn_perm(cd_lo, ab_lo, 0x05040100u);
-                        win[1] = __builtin_amdgcn_perm(cd_lo, ab_lo, 0x07060302u);
-                        win[2] = __builtin_amdgcn_perm(cd_hi, ab_hi, 0x05040100u);
-                        win[3] = __builtin_amdgcn_perm(cd_hi, ab_hi, 0x07060302u);
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            o0[k] = sdot4(win[k], wA[ky][k], o0[k]);
-                            o1[k] = sdot4(win[k], wB[ky][k], o1[k]);
-                        }
+                    for (int j = 0; j < R; ++j) {
+                        uint32_t *dp = dst + ((size_t)(g * OH + oy0 + j) * OW + ox0) * C4 + cg;
+                        dp[0] = pack4(requant(o0[j][0], A.x, Sc.x, p.lo_f, p.hi_f), requant(o0[j][1], A.y, Sc.y, p.lo_f, p.hi_f),
+                                      requant(o0[j][2], A.z, Sc.z, p.lo_f, p.hi_f), requant(o0[j][3], A.w, Sc.w, p.lo_f, p.hi_f));
+                        if (ox0 + 1 < OW)
+                            dp[C4] = pack4(requant(o1[j][0], A.x, Sc.x, p.lo_f, p.hi_f), requant(o1[j][1], A.y, Sc.y, p.lo_f, p.hi_f),
+                                           requant(o1[j][2], A.z, Sc.z, p.lo_f, p.hi_f), requant(o1[j][3], A.w, Sc.w, p.lo_f, p.hi_f));
                     }
-                    uint32_t d0 = pack4(requant(o0[0], A.x, Sc.x, p.lo_f, p.hi_f), requant(o0[1], A.y, Sc.y, p.lo_f, p.hi_f),
-                                        requant(o0[2], A.z, Sc.z, p.lo_f, p.hi_f), requant(o0[3], A.w, Sc.w, p.lo_f, p.hi_f));
-                    uint32_t d1 = pack4(requant(o1[0], A.x, Sc.x, p.lo_f, p.hi_f), requant(o1[1], A.y, Sc.y, p.lo_f, p.hi_f),
-                                        requant(o1[2], A.z, Sc.z, p.lo_f, p.hi_f), requant(o1[3], A.w, Sc.w, p.lo_f, p.hi_f));
-                    uint32_t *dp = dst + ((size_t)(g * OH + oy) * OW + ox0) * C4 + cg;
-                    dp[0] = d0;
-                    if (ox0 + 1 < OW) dp[C4] = d1;
                 }
             }
         }
@@ -970,44 +995,27 @@ __global__ __launch_bounds__(NTHR) void dwpw3x3(const int8_t *__restrict__ in,
                 }
             }
         } else {
-            constexpr int OWP = (OW + 1) / 2;
-            constexpr int TASKS = G * OH * OWP * C4, NTASK = (TASKS + NTHR - 1) / NTHR;
+            constexpr int R = (OH % 2 == 0) ? 2 : 1;
+            constexpr int OWP = (OW + 1) / 2, OHR = OH / R;
+            constexpr int TASKS = G * OHR * OWP * C4, NTASK = (TASKS + NTHR - 1) / NTHR;
 #pragma unroll 1
             for (int i = 0; i < NTASK; ++i) {
                 const int t = tid + NTHR * i;
                 const int pp = t / C4;
-                const int g = pp / (OH * OWP), rem = pp % (OH * OWP);
-                const int oy = rem / OWP, ox0 = 2 * (rem % OWP);
+                const int g = pp / (OHR * OWP), rem = pp % (OHR * OWP);
+                const int oy0 = R * (rem / OWP), ox0 = 2 * (rem % OWP);
                 if (t < TASKS && g < gvalid) {
-                    const uint8_t *base = tile + g * TILE + oy * ROW + LP + (ox0 - 1) * C + cg * 4;
-                    int o0[4] = {dK.x, dK.y, dK.z, dK.w}, o1[4] = {dK.x, dK.y, dK.z, dK.w};
+                    int o0[R][4], o1[R][4];
+                    dw_s1_task<R, ROW, C>(tile + g * TILE + oy0 * ROW + LP + (ox0 - 1) * C + cg * 4, wA, wB, dK, o0, o1);
 #pragma unroll
-                    for (int ky = 0; ky < 3; ++ky) {
-                        const uint32_t s0 = *(const uint32_t *)(base + ky * ROW);
-                        const uint32_t s1 = *(const uint32_t *)(base + ky * ROW + C);
-                        const uint32_t s2 = *(const uint32_t *)(base + ky * ROW + 2 * C);
-                        const uint32_t s3 = *(const uint32_t *)(base + ky * ROW + 3 * C);
-                        const uint32_t ab_lo = __builtin_amdgcn_perm(s1, s0, 0x05010400u);
-                        const uint32_t ab_hi = __builtin_amdgcn_perm(s1, s0, 0x07030602u);
-                        const uint32_t cd_lo = __builtin_amdgcn_perm(s3, s2, 0x05010400u);
-                        const uint32_t cd_hi = __builtin_amdgcn_perm(s3, s2, 0x07030602u);
-                        uint32_t win[4];
-                        win[0] = __builtin_amdgcn_perm(cd_lo, ab_lo, 0x05040100u);
-                        win[1] = __builtin_amdgcn_perm(cd_lo, ab_lo, 0x07060302u);
-                        win[2] = __builtin_amdgcn_perm(cd_hi, ab_hi, 0x05040100u);
-                        win[3] = __builtin_amdgcn_perm(cd_hi, ab_hi, 0x07060302u);
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            o0[k] = sdot4(win[k], wA[ky][k], o0[k]);
-                            o1[k] = sdot4(win[k], wB[ky][k], o1[k]);
-                        }
+                    for (int j = 0; j < R; ++j) {
+                        uint32_t *dp = (uint32_t *)mid + ((size_t)(g * OH + oy0 + j) * OW + ox0) * C4 + cg;
+                        dp[0] = pack4(requant(o0[j][0], dA.x, dS.x, p.dw.lo_f, p.dw.hi_f), requant(o0[j][1], dA.y, dS.y, p.dw.lo_f, p.dw.hi_f),
+                                      requant(o0[j][2], dA.z, dS.z, p.dw.lo_f, p.dw.hi_f), requant(o0[j][3], dA.w, dS.w, p.dw.lo_f, p.dw.hi_f));
+                        if (ox0 + 1 < OW)
+                            dp[C4] = pack4(requant(o1[j][0], dA.x, dS.x, p.dw.lo_f, p.dw.hi_f), requant(o1[j][1], dA.y, dS.y, p.dw.lo_f, p.dw.hi_f),
+                                           requant(o1[j][2], dA.z, dS.z, p.dw.lo_f, p.dw.hi_f), requant(o1[j][3], dA.w, dS.w, p.dw.lo_f, p.dw.hi_f));
                     }
-                    uint32_t *dp = (uint32_t *)mid + ((size_t)(g * OH + oy) * OW + ox0) * C4 + cg;
-                    dp[0] = pack4(requant(o0[0], dA.x, dS.x, p.dw.lo_f, p.dw.hi_f), requant(o0[1], dA.y, dS.y, p.dw.lo_f, p.dw.hi_f),
-                                  requant(o0[2], dA.z, dS.z, p.dw.lo_f, p.dw.hi_f), requant(o0[3], dA.w, dS.w, p.dw.lo_f, p.dw.hi_f));
-                    if (ox0 + 1 < OW)
-                        dp[C4] = pack4(requant(o1[0], dA.x, dS.x, p.dw.lo_f, p.dw.hi_f), requant(o1[1], dA.y, dS.y, p.dw.lo_f, p.dw.hi_f),
-                                       requant(o1[2], dA.z, dS.z, p.dw.lo_f, p.dw.hi_f), requant(o1[3], dA.w, dS.w, p.dw.lo_f, p.dw.hi_f));
                 }
             }
         }

@@ -107,9 +107,9 @@ struct DwPwArgs {
     X(24, 24, 32, 2, 64, 2, 256, 0) \
     X(12, 12, 64, 1, 64, 2, 512, 1) \
     X(12, 12, 64, 2, 128, 4, 512, 0) \
-    X(6, 6, 128, 1, 128, 4, 512, 0) \
+    X(6, 6, 128, 1, 128, 8, 512, 0) \
     X(6, 6, 128, 2, 256, 4, 256, 0) \
-    X(3, 3, 256, 1, 256, 4, 256, 0)
+    X(3, 3, 256, 1, 256, 8, 256, 0)
 
 // (K = input channels, N = output channels) with a compiled pointwise MFMA kernel
 #define MF_PW_SHAPES(X) \
