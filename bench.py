@@ -134,8 +134,16 @@ def main():
                     continue
                 in_elems = int(np.prod(d["in_shape"]))
                 out_elems, kind = d["out_elems"], d["name"]
-                if d["kernel"].startswith("dwpw3x3"):  # fused pair: depthwise input + pointwise output
-                    out_elems, kind = descs[i + 1]["out_elems"], "depthwise_conv_2d+conv_2d"
+                # a fused group reads its first operator's input and writes its last operator's output
+                last = i
+                for j in range(i + 1, len(descs)):
+                    if descs[j]["kernel"].startswith("(fused"):
+                        last = j
+                    elif descs[j]["kernel"]:
+                        break
+                if last != i:
+                    out_elems = descs[last]["out_elems"]
+                    kind = "+".join(descs[j]["name"] for j in range(i, last + 1) if descs[j]["name"] != "reshape")
                 nbytes = (in_elems + out_elems) * count  # algorithmic: unique in + out bytes
                 gbs = nbytes / (per_op[i] * 1e-3) / 1e9 if per_op[i] > 0 else 0.0
                 rows.append({"op": i, "kind": kind, "kernel": d["kernel"], "ms": round(per_op[i], 4),

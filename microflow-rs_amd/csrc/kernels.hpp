@@ -84,6 +84,24 @@ struct DwPwArgs {
     PwArgs pw;
 };
 
+// fused network tail: AveragePool2D (to 1x1) -> Conv2D 1x1 (N <= 8) -> [Reshape] -> Softmax
+struct TailArgs {
+    int H, W, C, N;          // pool input; head outputs
+    int ntaps;               // in-range taps of the single pooling window
+    int tap_off[64];         // their element offsets (iy * W + ix) * C
+    float inv_len;           // 1.0f / f32(ntaps), correctly rounded on the host
+    float pool_c0, pool_c1;
+    int pool_lo, pool_hi;
+    const int8_t *w;         // head filters [N][C]
+    const int *wzp;          // [N]
+    const float *A;          // [N]
+    const float *S;          // [N]
+    const int *Kc;           // [N]
+    float lo_f, hi_f;        // head activation clamp
+    const float *exp_table;  // softmax table [256]
+    float sm_oscale, sm_ozp_f;
+};
+
 // shapes with a compiled fast depthwise kernel: H, W, C, stride, images per step, threads per
 // workgroup.  LDS (two staging buffers) decides how many workgroups fit a CU; the thread count
 // is chosen so that 4-6 waves per SIMD are resident (the kernels are VALU-bound).
@@ -147,6 +165,8 @@ bool launch_dw_stem(int H, int W, int DM, int S, const int8_t *in, int8_t *out, 
 const char *dwpw_name(int H, int W, int C, int S, int N);
 bool launch_dwpw(int H, int W, int C, int S, int N, const int8_t *in, int8_t *out, const DwPwArgs &a,
                  int batch, hipStream_t s);
+bool tail_supported(int C, int N, int ntaps);
+void launch_tail(const int8_t *in, int8_t *out, const TailArgs &a, size_t batch, hipStream_t s);
 const char *pw_name(int K, int N);
 bool launch_pw(int K, int N, const int8_t *in, int8_t *out, const PwArgs &a, long long npix, hipStream_t s);
 

@@ -34,7 +34,10 @@ struct ModelImpl {
     bool generic = false;
     hipStream_t stream = nullptr;
     std::vector<OpImpl *> ops; // nullptr for Reshape
-    std::vector<FusedImpl *> fused; // fused[i] != nullptr: ops i (depthwise) and i+1 (1x1 conv) as one kernel
+    // fused[i] != nullptr: ops i .. fused_last[i] run as ONE kernel (depthwise + 1x1 conv pairs;
+    // the pool -> head conv -> [reshape] -> softmax tail)
+    std::vector<FusedImpl *> fused;
+    std::vector<int> fused_last;
     bool fusion = true;
     size_t cap_batch = 0;
     int8_t *act[2] = {nullptr, nullptr};
@@ -71,10 +74,16 @@ const ParsedModel &model_parsed(const ModelImpl *m) { return m->pm; }
 static bool fused_at(const ModelImpl *m, int i) {
     return m->fusion && !m->generic && i >= 0 && i < (int)m->fused.size() && m->fused[(size_t)i];
 }
+// index of the fused group that swallows op i (without being its first op), or -1
+static int fused_owner(const ModelImpl *m, int i) {
+    for (int j = i - 1; j >= 0 && j >= i - 4; --j)
+        if (fused_at(m, j) && m->fused_last[(size_t)j] >= i) return j;
+    return -1;
+}
 const char *model_op_kernel(const ModelImpl *m, int i) {
     if (!m->prepared || i < 0 || i >= (int)m->ops.size() || !m->ops[i]) return "";
     if (fused_at(m, i)) return fused_kernel_name(m->fused[(size_t)i]);
-    if (fused_at(m, i - 1)) return "(fused into the previous operator)";
+    if (fused_owner(m, i) >= 0) return "(fused into the previous operator)";
     return op_kernel_name(m->ops[i]);
 }
 
@@ -129,12 +138,23 @@ void model_prepare(ModelImpl *m, int device, size_t max_batch) {
             cur_scale = po.out_scale;
             cur_zp = po.out_zp;
         }
-        // peephole: DepthwiseConv2D 3x3 directly followed by a 1x1 Conv2D -> one fused kernel
-        m->fused.assign(m->ops.size(), nullptr);
-        for (size_t i = 0; i + 1 < m->ops.size(); ++i)
-            if (m->pm.ops[i].kind == MF_OP_DEPTHWISE_CONV_2D && m->pm.ops[i + 1].kind == MF_OP_CONV_2D &&
-                !(i > 0 && m->fused[i - 1]))
-                m->fused[i] = fused_create(m->ops[i], m->ops[i + 1]);
+        // peepholes.  (1) DepthwiseConv2D 3x3 directly followed by a 1x1 Conv2D -> one fused kernel.
+        // (2) AveragePool2D (1x1 output) -> Conv2D 1x1 -> [Reshape] -> Softmax -> one tail kernel.
+        const size_t n = m->ops.size();
+        m->fused.assign(n, nullptr);
+        m->fused_last.assign(n, -1);
+        for (size_t i = 0; i + 1 < n; ++i) {
+            if (m->pm.ops[i].kind == MF_OP_DEPTHWISE_CONV_2D && m->pm.ops[i + 1].kind == MF_OP_CONV_2D) {
+                if ((m->fused[i] = fused_create(m->ops[i], m->ops[i + 1]))) m->fused_last[i] = (int)i + 1;
+            } else if (m->pm.ops[i].kind == MF_OP_AVERAGE_POOL_2D && m->pm.ops[i + 1].kind == MF_OP_CONV_2D) {
+                size_t j = i + 2;
+                while (j < n && m->pm.ops[j].kind == MF_OP_RESHAPE) ++j;
+                if (j < n && m->pm.ops[j].kind == MF_OP_SOFTMAX &&
+                    (m->fused[i] = fused_tail_create(m->ops[i], m->ops[i + 1], m->ops[j])))
+                    m->fused_last[i] = (int)j;
+            }
+            if (m->fused[i]) i = (size_t)m->fused_last[i]; // groups do not overlap
+        }
         m->prepared = true;
         model_set_generic(m, m->generic);
     }
@@ -169,9 +189,9 @@ static const int8_t *run_ops(ModelImpl *m, const int8_t *src, size_t batch, int 
             which ^= 1;
             dst = m->act[which];
         }
-        if (fused_at(m, i) && i + 1 <= last_op) { // depthwise + pointwise in one launch
+        if (fused_at(m, i) && m->fused_last[(size_t)i] <= last_op) { // the whole group in one launch
             fused_run(m->fused[(size_t)i], cur, batch, dst, m->stream);
-            ++i;
+            i = m->fused_last[(size_t)i];
         } else {
             op_run(o, cur, batch, dst, m->stream);
         }
@@ -271,10 +291,10 @@ void model_time_device(ModelImpl *m, const int8_t *d_in, size_t batch, int8_t *d
                         which ^= 1;
                         dst = m->act[which];
                     }
-                    if (fused_at(m, i) && i + 1 < nops) { // the pair is timed as one unit (index i)
+                    if (fused_at(m, i)) { // the group is timed as one unit (index i), its other ops 0
                         fused_run(m->fused[(size_t)i], cur, batch, dst, s);
-                        MF_HIP(hipEventRecord(ev[(size_t)i + 1], s));
-                        ++i;
+                        for (int j = i; j < m->fused_last[(size_t)i]; ++j) MF_HIP(hipEventRecord(ev[(size_t)j + 1], s));
+                        i = m->fused_last[(size_t)i];
                     } else {
                         op_run(o, cur, batch, dst, s);
                     }

@@ -379,8 +379,10 @@ void op_run(OpImpl *op, const int8_t *d_in, size_t batch, int8_t *d_out, void *s
 }
 
 struct FusedImpl {
-    OpImpl *dw, *pw;
-    k::DwPwArgs args;
+    enum Kind { DWPW, TAIL } kind;
+    OpImpl *a, *b, *c;
+    k::DwPwArgs dwpw;
+    k::TailArgs tail;
     std::string name;
 };
 
@@ -391,18 +393,54 @@ FusedImpl *fused_create(OpImpl *dw, OpImpl *pw) {
     if (q.H != d.OH || q.W != d.OW || q.C != d.N || dw->device != pw->device) return nullptr;
     const char *nm = k::dwpw_name(d.H, d.W, d.C, d.sh, q.N);
     if (!nm) return nullptr;
-    FusedImpl *f = new FusedImpl{dw, pw, {}, nm};
-    f->args.dw = dw->dwf;
-    f->args.pw = pw->pw;
+    FusedImpl *f = new FusedImpl{FusedImpl::DWPW, dw, pw, nullptr, {}, {}, nm};
+    f->dwpw.dw = dw->dwf;
+    f->dwpw.pw = pw->pw;
     return f;
 }
+
+FusedImpl *fused_tail_create(OpImpl *pool, OpImpl *conv, OpImpl *sm) {
+    if (!pool || !conv || !sm) return nullptr;
+    const OpSpec &p = pool->s, &c = conv->s, &m = sm->s;
+    if (p.kind != MF_OP_AVERAGE_POOL_2D || c.kind != MF_OP_CONV_2D || m.kind != MF_OP_SOFTMAX) return nullptr;
+    if (p.OH != 1 || p.OW != 1) return nullptr;                       // one pooling window
+    if (c.KH != 1 || c.KW != 1 || c.H != 1 || c.W != 1 || c.OH != 1 || c.OW != 1 || c.C != p.C) return nullptr;
+    if (m.M != 1 || m.N != c.N) return nullptr;                       // softmax over the head's N values
+    // the in-range taps of the single window (focus (0,0); src/tensor.rs:180-228)
+    const int shy = p.pad == MF_PAD_SAME ? (p.KH - 1) / 2 : 0, shx = p.pad == MF_PAD_SAME ? (p.KW - 1) / 2 : 0;
+    std::vector<int> taps;
+    for (int ky = 0; ky < p.KH; ++ky)
+        for (int kx = 0; kx < p.KW; ++kx) {
+            const int iy = ky - shy, ix = kx - shx;
+            if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) taps.push_back((iy * p.W + ix) * p.C);
+        }
+    if (!k::tail_supported(p.C, c.N, (int)taps.size())) return nullptr;
+    FusedImpl *f = new FusedImpl{FusedImpl::TAIL, pool, conv, sm, {}, {}, "tail_pool_head_softmax<" + std::to_string(c.N) + ">"};
+    k::TailArgs &t = f->tail;
+    t.H = p.H, t.W = p.W, t.C = p.C, t.N = c.N;
+    t.ntaps = (int)taps.size();
+    for (int i = 0; i < t.ntaps; ++i) t.tap_off[i] = taps[(size_t)i];
+    volatile float inv = 1.0f / (float)t.ntaps; // 1. / view.len as f32 (average_pool_2d.rs:52)
+    t.inv_len = inv;
+    t.pool_c0 = pool->pool.c0, t.pool_c1 = pool->pool.c1, t.pool_lo = pool->pool.lo, t.pool_hi = pool->pool.hi;
+    t.w = conv->conv.w, t.wzp = conv->conv.wzp, t.A = conv->conv.A, t.S = conv->conv.S, t.Kc = conv->conv.Kc;
+    t.lo_f = conv->conv.lo_f, t.hi_f = conv->conv.hi_f;
+    t.exp_table = sm->sm.exp_table, t.sm_oscale = sm->sm.oscale, t.sm_ozp_f = sm->sm.ozp_f;
+    return f;
+}
+
 void fused_destroy(FusedImpl *f) { delete f; }
 const char *fused_kernel_name(const FusedImpl *f) { return f->name.c_str(); }
 void fused_run(FusedImpl *f, const int8_t *d_in, size_t batch, int8_t *d_out, void *stream) {
     if (!batch) return;
+    if (f->kind == FusedImpl::TAIL) {
+        k::launch_tail(d_in, d_out, f->tail, batch, (hipStream_t)stream);
+        MF_HIP(hipGetLastError());
+        return;
+    }
     if (batch > 0x7fffffffull / 4) fail(MF_ERR_INVALID_ARG, "batch too large for one launch");
-    const OpSpec &d = f->dw->s;
-    if (!k::launch_dwpw(d.H, d.W, d.C, d.sh, f->pw->s.N, d_in, d_out, f->args, (int)batch, (hipStream_t)stream))
+    const OpSpec &d = f->a->s;
+    if (!k::launch_dwpw(d.H, d.W, d.C, d.sh, f->b->s.N, d_in, d_out, f->dwpw, (int)batch, (hipStream_t)stream))
         fail(MF_ERR_UNSUPPORTED, "fused kernel missing");
     MF_HIP(hipGetLastError());
 }

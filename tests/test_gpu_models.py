@@ -166,14 +166,16 @@ def test_kernel_routing(models):
     names = [m.op(i)["kernel"] for i in range(m.num_ops)]
     assert names[0].startswith("dw3x3_stem8")
     assert sum(n.startswith("dwpw3x3") for n in names) == 13          # fused depthwise + 1x1 conv pairs
-    assert sum(n.startswith("(fused") for n in names) == 13
-    assert names[28] == "conv2d_generic" and names[27] == "avgpool_generic"
-    assert names[29] == "" and names[30] == "softmax_table"
+    assert sum(n.startswith("(fused") for n in names) == 13 + 2
+    assert names[27] == "tail_pool_head_softmax<2>"                   # pool + head conv + softmax
+    assert names[28].startswith("(fused") and names[29] == "" and names[30].startswith("(fused")
     m.set_fusion(False)
     names = [m.op(i)["kernel"] for i in range(m.num_ops)]
     m.set_fusion(True)
     assert sum(n.startswith("dw3x3_nhwc") for n in names) == 13
     assert sum(n.startswith("pw_mfma") for n in names) == 13
+    assert names[28] == "conv2d_generic" and names[27] == "avgpool_generic"
+    assert names[29] == "" and names[30] == "softmax_table"
 
 
 @pytest.mark.parametrize("n", [1, 2, 3, 5, 8, 13, 64, 257])
@@ -183,7 +185,7 @@ def test_fused_equals_layerwise(models, n):
     import torch
     m = models["person_detect"]
     x = synth_i8(3, 9000, n, m.input_elems).reshape((n,) + m.input_shape)
-    for last in (2, 4, 6, 8, 10, 12, 14, 22, 24, 26, 30):
+    for last in (2, 4, 6, 8, 10, 12, 14, 22, 24, 26, 27, 28, 30):
         m.set_fusion(True)
         a = m.run_until(x, last)
         m.set_fusion(False)
