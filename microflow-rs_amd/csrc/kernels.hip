@@ -671,6 +671,69 @@ __global__ __launch_bounds__(256) void dw3x3_stem8(const int8_t *__restrict__ in
 }
 
 // ------------------------------------------------------------------------
+// FAST PATH 2b -- DepthwiseConv2D with ONE input channel, up to 8 output channels, any filter
+// size / stride / padding (speech.tflite op 1: 49x40x1 -> 25x20x8, 10x8 filter, stride 2).
+// (src/ops/depthwise_conv_2d.rs:67: every output channel reads input channel 0.)
+// One workgroup stages one image in LDS inside an izp halo (so SAME padding needs no
+// per-tap test), the filter as int32 [tap][8] in LDS (a broadcast read per tap), and each
+// thread produces whole output pixels: one LDS byte + 8 multiply-adds per tap, 8 bytes per
+// store.  Every input byte is read from HBM once.
+// ------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dw_c1_lds(const int8_t *__restrict__ in, int8_t *__restrict__ out,
+                                                 DwC1Args p, size_t batch) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const int shy = p.pad_same ? (p.KH - 1) / 2 : 0, shx = p.pad_same ? (p.KW - 1) / 2 : 0;
+    // halo'd tile covering every tap of every output pixel
+    const int TH = (p.OH - 1) * p.sh + p.KH, TW = (p.OW - 1) * p.sw + p.KW;
+    const int tile_bytes = (TH * TW + 15) & ~15;
+    int *wl = (int *)(lds + tile_bytes);
+    const int taps = p.KH * p.KW, tid = threadIdx.x;
+    for (int i = tid; i < taps * 8; i += 256) wl[i] = p.w32[i];
+    int Kc[8];
+    float A[8], S[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        Kc[c] = c < p.N ? p.Kc[c] : 0;
+        A[c] = c < p.N ? p.A[c] : 0.0f;
+        S[c] = c < p.N ? p.S[c] : 0.0f;
+    }
+    for (size_t img = blockIdx.x; img < batch; img += gridDim.x) {
+        __syncthreads(); // previous image fully consumed
+        const int8_t *x = in + img * (size_t)p.H * p.W;
+        for (int i = tid; i < TH * TW; i += 256) {
+            const int ty = i / TW, tx = i % TW;
+            const int iy = ty - shy, ix = tx - shx;
+            ((int8_t *)lds)[i] = (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) ? x[iy * p.W + ix] : (int8_t)p.izp;
+        }
+        __syncthreads();
+        for (int o = tid; o < p.OH * p.OW; o += 256) {
+            const int oy = o / p.OW, ox = o % p.OW;
+            int acc[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) acc[c] = Kc[c];
+            const int8_t *t0 = (const int8_t *)lds + (oy * p.sh) * TW + ox * p.sw;
+            for (int ky = 0; ky < p.KH; ++ky)
+                for (int kx = 0; kx < p.KW; ++kx) {
+                    const int v = t0[ky * TW + kx];
+                    const int4 w0 = *(const int4 *)(wl + (ky * p.KW + kx) * 8);
+                    const int4 w1 = *(const int4 *)(wl + (ky * p.KW + kx) * 8 + 4);
+                    acc[0] += v * w0.x, acc[1] += v * w0.y, acc[2] += v * w0.z, acc[3] += v * w0.w;
+                    acc[4] += v * w1.x, acc[5] += v * w1.y, acc[6] += v * w1.z, acc[7] += v * w1.w;
+                }
+            int q[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) q[c] = requant(acc[c], A[c], S[c], p.lo_f, p.hi_f);
+            int8_t *dst = out + (img * (size_t)p.OH * p.OW + o) * p.N;
+            if (p.N == 8) {
+                *(uint2 *)dst = make_uint2(pack4(q[0], q[1], q[2], q[3]), pack4(q[4], q[5], q[6], q[7]));
+            } else {
+                for (int c = 0; c < p.N; ++c) dst[c] = (int8_t)q[c];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------
 // FAST PATH 3 -- Conv2D 1x1 stride 1 (pointwise) as an int8 MFMA GEMM.
 // (src/ops/conv_2d.rs:28-108 with KH = KW = 1; person_detect ops 2,4,...,26)
 //
@@ -1479,6 +1542,18 @@ bool launch_dw_fast(int H, int W, int C, int S, const int8_t *in, int8_t *out, c
     MF_DW_SHAPES(MF_DW)
 #undef MF_DW
     return false;
+}
+
+static int dw_c1_lds_bytes(const DwC1Args &a) {
+    const int TH = (a.OH - 1) * a.sh + a.KH, TW = (a.OW - 1) * a.sw + a.KW;
+    return ((TH * TW + 15) & ~15) + a.KH * a.KW * 8 * 4;
+}
+bool dw_c1_supported(const DwC1Args &a) {
+    return a.N >= 1 && a.N <= 8 && dw_c1_lds_bytes(a) <= 64 * 1024;
+}
+void launch_dw_c1(const int8_t *in, int8_t *out, const DwC1Args &a, size_t batch, hipStream_t s) {
+    const int grid = (int)(batch < 256 * 8 ? batch : 256 * 8);
+    hipLaunchKernelGGL(dw_c1_lds, dim3(grid), dim3(256), dw_c1_lds_bytes(a), s, in, out, a, batch);
 }
 
 const char *dw_stem_name(int H, int W, int DM, int S) {

@@ -62,6 +62,16 @@ struct DwFastArgs {
     uint32_t izp4;      // izp replicated in 4 bytes
     float lo_f, hi_f;
 };
+// depthwise with ONE input channel and up to 8 output channels, any filter / stride (speech op 1)
+struct DwC1Args {
+    int H, W, N, KH, KW, sh, sw, OH, OW, pad_same;
+    int izp;
+    float lo_f, hi_f;
+    const int *w32;     // [KH*KW][8] weights widened to int (zero padded to 8 channels)
+    const float *A;
+    const float *S;
+    const int *Kc;
+};
 struct DwStemArgs {
     uint32_t wrow[3][8]; // [ky][c] = bytes (w[ky][0][c], w[ky][1][c], w[ky][2][c], 0)
     float A[8], S[8];
@@ -159,6 +169,8 @@ void launch_checksum(const int8_t *in, size_t n, unsigned long long *result, hip
 const char *dw_fast_name(int H, int W, int C, int S);
 bool launch_dw_fast(int H, int W, int C, int S, const int8_t *in, int8_t *out, const DwFastArgs &a,
                     int batch, hipStream_t s);
+bool dw_c1_supported(const DwC1Args &a);
+void launch_dw_c1(const int8_t *in, int8_t *out, const DwC1Args &a, size_t batch, hipStream_t s);
 const char *dw_stem_name(int H, int W, int DM, int S);
 bool launch_dw_stem(int H, int W, int DM, int S, const int8_t *in, int8_t *out, const DwStemArgs &a,
                     int batch, hipStream_t s);

@@ -80,11 +80,12 @@ struct OpImpl {
     size_t in_elems = 0, out_elems = 0;
     bool force_generic = false;
     std::string generic_name, fast_name;
-    enum Fast { NONE, DW_NHWC, DW_STEM, PW_MFMA, FC_ROWWAVE, FC_MFMA } fast = NONE;
+    enum Fast { NONE, DW_NHWC, DW_STEM, DW_C1, PW_MFMA, FC_ROWWAVE, FC_MFMA } fast = NONE;
     int *d_rowsum = nullptr; // FC_MFMA with wzp != 0: per-row input sums
     size_t rowsum_cap = 0;
 
     DevBuf d_w, d_wzp, d_A, d_S, d_Kc, d_wprep, d_table;
+    k::DwC1Args dwc1{};
     k::ConvArgs conv{};
     k::PoolArgs pool{};
     k::FcArgs fc{};
@@ -219,6 +220,21 @@ OpImpl *op_create(int device, const OpSpec &s) {
             for (int c = 0; c < 8; ++c) f.A[c] = A[c], f.S[c] = S[c], f.Kc[c] = Kc[c];
             f.izp4 = 0x01010101u * (uint32_t)(uint8_t)(int8_t)s.izp;
             f.lo_f = a.lo_f, f.hi_f = a.hi_f;
+        } else if (dw && zero_wzp && s.C == 1 && s.N <= 8) {
+            // one input channel, few output channels, any filter: LDS-staged direct kernel
+            k::DwC1Args &f = op->dwc1;
+            f.H = s.H, f.W = s.W, f.N = s.N, f.KH = s.KH, f.KW = s.KW, f.sh = s.sh, f.sw = s.sw;
+            f.OH = s.OH, f.OW = s.OW, f.pad_same = s.pad == MF_PAD_SAME, f.izp = s.izp;
+            f.lo_f = a.lo_f, f.hi_f = a.hi_f, f.A = a.A, f.S = a.S, f.Kc = a.Kc;
+            if (k::dw_c1_supported(f)) {
+                std::vector<int32_t> w32((size_t)s.KH * s.KW * 8, 0);
+                for (int t = 0; t < s.KH * s.KW; ++t)
+                    for (int c = 0; c < s.N; ++c) w32[(size_t)t * 8 + c] = s.weights[(size_t)t * s.N + c];
+                op->d_wprep.upload(w32.data(), w32.size() * 4);
+                f.w32 = op->d_wprep.as<int>();
+                op->fast = OpImpl::DW_C1;
+                op->fast_name = "dw_c1_lds";
+            }
         } else if (!dw && zero_wzp && s.KH == 1 && s.KW == 1 && s.sh == 1 && s.sw == 1 &&
                    s.OH == s.H && s.OW == s.W && k::pw_name(s.C, s.N) &&
                    (s.C != 8 || ((s.H * s.W) % 2 == 0))) {
@@ -333,6 +349,10 @@ void op_run(OpImpl *op, const int8_t *d_in, size_t batch, int8_t *d_out, void *s
             break;
         case OpImpl::DW_STEM:
             done = k::launch_dw_stem(sp.H, sp.W, sp.N, sp.sh, d_in, d_out, op->stem, (int)batch, s);
+            break;
+        case OpImpl::DW_C1:
+            k::launch_dw_c1(d_in, d_out, op->dwc1, batch, s);
+            done = true;
             break;
         case OpImpl::PW_MFMA:
             done = k::launch_pw(sp.C, sp.N, d_in, d_out, op->pw, (long long)batch * sp.H * sp.W, s);
