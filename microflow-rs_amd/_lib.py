@@ -121,6 +121,13 @@ def lib():
             raise ImportError(
                 "libmicroflow_amd.so is missing and could not be built (%s). Run "
                 "`python microflow-rs_amd/build.py`; this package has no CPU fallback." % e)
+    # PyTorch-ROCm bundles its own libamdhip64; if it is going to be used in this process (device
+    # memory, streams) it must be loaded FIRST so that the library binds to the same HIP runtime
+    # -- two runtimes in one process see no devices.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(_LIB)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(L, name)  # AttributeError here = ABI / header drift: fail loudly
