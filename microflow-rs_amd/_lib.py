@@ -12,6 +12,7 @@ _LIB = os.path.join(_HERE, "libmicroflow_amd.so")
 MF_OK, MF_ERR_INVALID_MODEL, MF_ERR_UNSUPPORTED, MF_ERR_INVALID_ARG = 0, 1, 2, 3
 MF_ERR_NO_DEVICE, MF_ERR_HIP, MF_ERR_OOM = 4, 5, 6
 MF_MEM_HOST, MF_MEM_DEVICE = 0, 1
+MF_ELEM_I8, MF_ELEM_U8 = 0, 1
 STATUS_NAMES = {0: "MF_OK", 1: "MF_ERR_INVALID_MODEL", 2: "MF_ERR_UNSUPPORTED",
                 3: "MF_ERR_INVALID_ARG", 4: "MF_ERR_NO_DEVICE", 5: "MF_ERR_HIP", 6: "MF_ERR_OOM"}
 
@@ -28,7 +29,8 @@ class ModelInfo(C.Structure):
                 ("output_rank", C.c_int), ("output_shape", C.c_int * 4),
                 ("input_scale", C.c_float), ("output_scale", C.c_float),
                 ("input_zero_point", C.c_int), ("output_zero_point", C.c_int),
-                ("input_elems", C.c_size_t), ("output_elems", C.c_size_t), ("num_ops", C.c_int)]
+                ("input_elems", C.c_size_t), ("output_elems", C.c_size_t), ("num_ops", C.c_int),
+                ("element_type", C.c_int)]
 
 
 class OpDesc(C.Structure):
@@ -100,6 +102,13 @@ SIGNATURES = {
     "mf_model_time_device": (C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_int, C.c_int,
                                        C.POINTER(C.c_float), _vp]),
 }
+
+# T = u8 instantiations: the i8 signature with every int8_t value parameter as uint8_t
+for _n in ("mf_preprocess_fully_connected", "mf_preprocess_average_pool_2d",
+           "mf_fully_connected_create", "mf_conv_2d_create", "mf_depthwise_conv_2d_create",
+           "mf_average_pool_2d_create", "mf_softmax_create", "mf_quantize", "mf_dequantize"):
+    _r, _a = SIGNATURES[_n]
+    SIGNATURES[_n + "_u8"] = (_r, [C.c_uint8 if t is C.c_int8 else t for t in _a])
 
 _lib = None
 

@@ -4,6 +4,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <vector>
 
 #include "mf_internal.hpp"
 
@@ -52,9 +53,21 @@ int mf_preprocess_fully_connected(float input_scale, int8_t input_zero_point, in
                                   float *c1, int32_t *c2, int32_t *c3) {
     MF_TRY({
         MF_NEED(weights && bias && c0 && c1 && c2 && c3 && K > 0 && N > 0);
-        mf::h_preprocess_fc(input_scale, input_zero_point, in_shape1, weights, K, N, weights_scale,
+        mf::h_preprocess_fc(input_scale, input_zero_point, in_shape1, weights, false, K, N, weights_scale,
                             weights_zero_point, bias, bias_scale, bias_zero_point, output_scale, c0,
                             c1, c2, c3);
+    })
+}
+int mf_preprocess_fully_connected_u8(float input_scale, uint8_t input_zero_point, int in_shape1,
+                                     const uint8_t *weights, int K, int N, float weights_scale,
+                                     uint8_t weights_zero_point, const int32_t *bias, float bias_scale,
+                                     int32_t bias_zero_point, float output_scale, float *c0,
+                                     float *c1, int32_t *c2, int32_t *c3) {
+    MF_TRY({
+        MF_NEED(weights && bias && c0 && c1 && c2 && c3 && K > 0 && N > 0);
+        mf::h_preprocess_fc(input_scale, input_zero_point, in_shape1, (const int8_t *)weights, true, K, N,
+                            weights_scale, weights_zero_point, bias, bias_scale, bias_zero_point,
+                            output_scale, c0, c1, c2, c3);
     })
 }
 
@@ -86,6 +99,14 @@ int mf_preprocess_average_pool_2d(float input_scale, int8_t input_zero_point, fl
     })
 }
 
+int mf_preprocess_average_pool_2d_u8(float input_scale, uint8_t input_zero_point, float output_scale,
+                                     uint8_t output_zero_point, float *c0, float *c1) {
+    MF_TRY({
+        MF_NEED(c0 && c1);
+        mf::h_preprocess_pool(input_scale, input_zero_point, output_scale, output_zero_point, c0, c1);
+    })
+}
+
 // ---- 2. prepared operators ----------------------------------------------------
 static int check_act_arg(int a) {
     if (a != MF_ACT_NONE && a != MF_ACT_RELU && a != MF_ACT_RELU6)
@@ -106,19 +127,79 @@ static void wrap_op(mf::OpImpl *impl, mf_op **out) {
     *out = h;
 }
 
+// One implementation per operator for both element types: zero points arrive widened to int,
+// weights as raw bytes of T.
+static void create_fc(int device, bool u8, int M, int K, int N, const void *weights, int wzp,
+                      float output_scale, int ozp, int act, const float *c0, float c1,
+                      const int32_t *c2, int32_t c3, mf_op **op) {
+    MF_NEED(op && weights && c0 && c2);
+    mf::OpSpec s;
+    s.kind = MF_OP_FULLY_CONNECTED, s.u8 = u8;
+    s.M = M, s.K = K, s.N = N;
+    s.weights = (const int8_t *)weights, s.wzp = &wzp, s.nq = 1;
+    s.oscale = output_scale, s.ozp = ozp, s.act = check_act_arg(act);
+    s.c0 = c0, s.c1 = &c1, s.nc1 = 1, s.c2 = c2, s.c3 = c3;
+    wrap_op(mf::op_create(device, s), op);
+}
+extern "C++" {
+template <typename T>
+static std::vector<int> widen(const T *zp, int nq) {
+    MF_NEED(zp && nq > 0);
+    return std::vector<int>(zp, zp + nq);
+}
+}
+static void create_conv(int device, bool u8, bool dw, int H, int W, int Cin, int N, int KH, int KW,
+                        const void *weights, const std::vector<int> &wzp, int izp, float output_scale,
+                        int ozp, int act, int pad, int sh, int sw, int OH, int OW, const float *c0,
+                        const float *c1, int nc1, mf_op **op) {
+    MF_NEED(op && weights && c0 && c1);
+    mf::OpSpec s;
+    s.kind = dw ? MF_OP_DEPTHWISE_CONV_2D : MF_OP_CONV_2D, s.u8 = u8;
+    s.H = H, s.W = W, s.C = Cin, s.N = N, s.KH = KH, s.KW = KW;
+    s.weights = (const int8_t *)weights, s.wzp = wzp.data(), s.nq = (int)wzp.size(), s.izp = izp;
+    s.oscale = output_scale, s.ozp = ozp, s.act = check_act_arg(act);
+    s.pad = check_pad_arg(pad), s.sh = sh, s.sw = sw, s.OH = OH, s.OW = OW;
+    s.c0 = c0, s.c1 = c1, s.nc1 = nc1;
+    wrap_op(mf::op_create(device, s), op);
+}
+static void create_pool(int device, bool u8, int H, int W, int C, int FH, int FW, float output_scale,
+                        int ozp, int act, int pad, int sh, int sw, int OH, int OW, float c0, float c1,
+                        mf_op **op) {
+    MF_NEED(op);
+    mf::OpSpec s;
+    s.kind = MF_OP_AVERAGE_POOL_2D, s.u8 = u8;
+    s.H = H, s.W = W, s.C = C, s.N = C, s.KH = FH, s.KW = FW;
+    s.oscale = output_scale, s.ozp = ozp, s.act = check_act_arg(act);
+    s.pad = check_pad_arg(pad), s.sh = sh, s.sw = sw, s.OH = OH, s.OW = OW;
+    s.pool_c0 = c0, s.pool_c1 = c1;
+    wrap_op(mf::op_create(device, s), op);
+}
+static void create_softmax(int device, bool u8, int rows, int cols, float input_scale,
+                           float output_scale, int ozp, mf_op **op) {
+    MF_NEED(op);
+    mf::OpSpec s;
+    s.kind = MF_OP_SOFTMAX, s.u8 = u8;
+    s.M = rows, s.N = cols, s.in_scale = input_scale;
+    s.oscale = output_scale, s.ozp = ozp;
+    wrap_op(mf::op_create(device, s), op);
+}
+
 int mf_fully_connected_create(int device, int M, int K, int N, const int8_t *weights,
                               int8_t weights_zero_point, float output_scale,
                               int8_t output_zero_point, int fused_activation, const float *c0,
                               float c1, const int32_t *c2, int32_t c3, mf_op **op) {
     MF_TRY({
-        MF_NEED(op && weights && c0 && c2);
-        mf::OpSpec s;
-        s.kind = MF_OP_FULLY_CONNECTED;
-        s.M = M, s.K = K, s.N = N;
-        s.weights = weights, s.wzp = &weights_zero_point, s.nq = 1;
-        s.oscale = output_scale, s.ozp = output_zero_point, s.act = check_act_arg(fused_activation);
-        s.c0 = c0, s.c1 = &c1, s.nc1 = 1, s.c2 = c2, s.c3 = c3;
-        wrap_op(mf::op_create(device, s), op);
+        create_fc(device, false, M, K, N, weights, weights_zero_point, output_scale, output_zero_point,
+                  fused_activation, c0, c1, c2, c3, op);
+    })
+}
+int mf_fully_connected_create_u8(int device, int M, int K, int N, const uint8_t *weights,
+                                 uint8_t weights_zero_point, float output_scale,
+                                 uint8_t output_zero_point, int fused_activation, const float *c0,
+                                 float c1, const int32_t *c2, int32_t c3, mf_op **op) {
+    MF_TRY({
+        create_fc(device, true, M, K, N, weights, weights_zero_point, output_scale, output_zero_point,
+                  fused_activation, c0, c1, c2, c3, op);
     })
 }
 
@@ -128,15 +209,20 @@ int mf_conv_2d_create(int device, int H, int W, int C, int N, int KH, int KW, co
                       int view_padding, int stride_h, int stride_w, int OH, int OW,
                       const float *c0, const float *c1, int nc1, mf_op **op) {
     MF_TRY({
-        MF_NEED(op && filters && filters_zero_point && c0 && c1);
-        mf::OpSpec s;
-        s.kind = MF_OP_CONV_2D;
-        s.H = H, s.W = W, s.C = C, s.N = N, s.KH = KH, s.KW = KW;
-        s.weights = filters, s.wzp = filters_zero_point, s.nq = nq, s.izp = input_zero_point;
-        s.oscale = output_scale, s.ozp = output_zero_point, s.act = check_act_arg(fused_activation);
-        s.pad = check_pad_arg(view_padding), s.sh = stride_h, s.sw = stride_w, s.OH = OH, s.OW = OW;
-        s.c0 = c0, s.c1 = c1, s.nc1 = nc1;
-        wrap_op(mf::op_create(device, s), op);
+        create_conv(device, false, false, H, W, C, N, KH, KW, filters, widen(filters_zero_point, nq),
+                    input_zero_point, output_scale, output_zero_point, fused_activation, view_padding,
+                    stride_h, stride_w, OH, OW, c0, c1, nc1, op);
+    })
+}
+int mf_conv_2d_create_u8(int device, int H, int W, int C, int N, int KH, int KW, const uint8_t *filters,
+                         const uint8_t *filters_zero_point, int nq, uint8_t input_zero_point,
+                         float output_scale, uint8_t output_zero_point, int fused_activation,
+                         int view_padding, int stride_h, int stride_w, int OH, int OW,
+                         const float *c0, const float *c1, int nc1, mf_op **op) {
+    MF_TRY({
+        create_conv(device, true, false, H, W, C, N, KH, KW, filters, widen(filters_zero_point, nq),
+                    input_zero_point, output_scale, output_zero_point, fused_activation, view_padding,
+                    stride_h, stride_w, OH, OW, c0, c1, nc1, op);
     })
 }
 
@@ -147,15 +233,21 @@ int mf_depthwise_conv_2d_create(int device, int H, int W, int Cin, int KH, int K
                                 int stride_h, int stride_w, int OH, int OW, const float *c0,
                                 const float *c1, int nc1, mf_op **op) {
     MF_TRY({
-        MF_NEED(op && weights && weights_zero_point && c0 && c1);
-        mf::OpSpec s;
-        s.kind = MF_OP_DEPTHWISE_CONV_2D;
-        s.H = H, s.W = W, s.C = Cin, s.N = C, s.KH = KH, s.KW = KW;
-        s.weights = weights, s.wzp = weights_zero_point, s.nq = nq, s.izp = input_zero_point;
-        s.oscale = output_scale, s.ozp = output_zero_point, s.act = check_act_arg(fused_activation);
-        s.pad = check_pad_arg(view_padding), s.sh = stride_h, s.sw = stride_w, s.OH = OH, s.OW = OW;
-        s.c0 = c0, s.c1 = c1, s.nc1 = nc1;
-        wrap_op(mf::op_create(device, s), op);
+        create_conv(device, false, true, H, W, Cin, C, KH, KW, weights, widen(weights_zero_point, nq),
+                    input_zero_point, output_scale, output_zero_point, fused_activation, view_padding,
+                    stride_h, stride_w, OH, OW, c0, c1, nc1, op);
+    })
+}
+int mf_depthwise_conv_2d_create_u8(int device, int H, int W, int Cin, int KH, int KW, int C,
+                                   const uint8_t *weights, const uint8_t *weights_zero_point, int nq,
+                                   uint8_t input_zero_point, float output_scale,
+                                   uint8_t output_zero_point, int fused_activation, int view_padding,
+                                   int stride_h, int stride_w, int OH, int OW, const float *c0,
+                                   const float *c1, int nc1, mf_op **op) {
+    MF_TRY({
+        create_conv(device, true, true, H, W, Cin, C, KH, KW, weights, widen(weights_zero_point, nq),
+                    input_zero_point, output_scale, output_zero_point, fused_activation, view_padding,
+                    stride_h, stride_w, OH, OW, c0, c1, nc1, op);
     })
 }
 
@@ -164,33 +256,33 @@ int mf_average_pool_2d_create(int device, int H, int W, int C, int FH, int FW, f
                               int stride_h, int stride_w, int OH, int OW, float c0, float c1,
                               mf_op **op) {
     MF_TRY({
-        MF_NEED(op);
-        mf::OpSpec s;
-        s.kind = MF_OP_AVERAGE_POOL_2D;
-        s.H = H, s.W = W, s.C = C, s.N = C, s.KH = FH, s.KW = FW;
-        s.oscale = output_scale, s.ozp = output_zero_point, s.act = check_act_arg(fused_activation);
-        s.pad = check_pad_arg(view_padding), s.sh = stride_h, s.sw = stride_w, s.OH = OH, s.OW = OW;
-        s.pool_c0 = c0, s.pool_c1 = c1;
-        wrap_op(mf::op_create(device, s), op);
+        create_pool(device, false, H, W, C, FH, FW, output_scale, output_zero_point, fused_activation,
+                    view_padding, stride_h, stride_w, OH, OW, c0, c1, op);
+    })
+}
+int mf_average_pool_2d_create_u8(int device, int H, int W, int C, int FH, int FW, float output_scale,
+                                 uint8_t output_zero_point, int fused_activation, int view_padding,
+                                 int stride_h, int stride_w, int OH, int OW, float c0, float c1,
+                                 mf_op **op) {
+    MF_TRY({
+        create_pool(device, true, H, W, C, FH, FW, output_scale, output_zero_point, fused_activation,
+                    view_padding, stride_h, stride_w, OH, OW, c0, c1, op);
     })
 }
 
 int mf_softmax_create(int device, int rows, int cols, float input_scale, float output_scale,
                       int8_t output_zero_point, mf_op **op) {
-    MF_TRY({
-        MF_NEED(op);
-        mf::OpSpec s;
-        s.kind = MF_OP_SOFTMAX;
-        s.M = rows, s.N = cols, s.in_scale = input_scale;
-        s.oscale = output_scale, s.ozp = output_zero_point;
-        wrap_op(mf::op_create(device, s), op);
-    })
+    MF_TRY({ create_softmax(device, false, rows, cols, input_scale, output_scale, output_zero_point, op); })
+}
+int mf_softmax_create_u8(int device, int rows, int cols, float input_scale, float output_scale,
+                         uint8_t output_zero_point, mf_op **op) {
+    MF_TRY({ create_softmax(device, true, rows, cols, input_scale, output_scale, output_zero_point, op); })
 }
 
 int mf_op_run(mf_op *op, const int8_t *d_input, size_t batch, int8_t *d_output, void *stream) {
     MF_TRY({
         MF_NEED(op && op->impl);
-        mf::op_run(op->impl, d_input, batch, d_output, stream);
+        mf::op_run_external(op->impl, d_input, batch, d_output, stream);
     })
 }
 size_t mf_op_input_elems(const mf_op *op) { return op && op->impl ? mf::op_in_elems(op->impl) : 0; }
@@ -212,14 +304,30 @@ int mf_quantize(int device, const float *d_input, size_t n, float scale, int8_t 
                 int8_t *d_output, void *stream) {
     MF_TRY({
         MF_NEED(n == 0 || (d_input && d_output));
-        mf::dev_quantize(device, d_input, n, scale, zero_point, d_output, stream);
+        mf::dev_quantize(device, d_input, n, scale, zero_point, false, d_output, stream);
+    })
+}
+int mf_quantize_u8(int device, const float *d_input, size_t n, float scale, uint8_t zero_point,
+                   uint8_t *d_output, void *stream) {
+    MF_TRY({
+        MF_NEED(n == 0 || (d_input && d_output));
+        // quantize into the internal domain, then back to real u8 bytes in place
+        mf::dev_quantize(device, d_input, n, scale, zero_point, true, (int8_t *)d_output, stream);
+        mf::dev_xor80(device, (const int8_t *)d_output, n, (int8_t *)d_output, stream);
     })
 }
 int mf_dequantize(int device, const int8_t *d_input, size_t n, float scale, int8_t zero_point,
                   float *d_output, void *stream) {
     MF_TRY({
         MF_NEED(n == 0 || (d_input && d_output));
-        mf::dev_dequantize(device, d_input, n, scale, zero_point, d_output, stream);
+        mf::dev_dequantize(device, d_input, n, scale, zero_point, false, d_output, stream);
+    })
+}
+int mf_dequantize_u8(int device, const uint8_t *d_input, size_t n, float scale, uint8_t zero_point,
+                     float *d_output, void *stream) {
+    MF_TRY({
+        MF_NEED(n == 0 || (d_input && d_output));
+        mf::dev_dequantize_u8_raw(device, d_input, n, scale, zero_point, d_output, stream);
     })
 }
 
@@ -254,6 +362,7 @@ int mf_model_get_info(const mf_model *model, mf_model_info *info) {
         info->input_zero_point = pm.in_zp, info->output_zero_point = pm.out_zp;
         info->input_elems = pm.in_elems, info->output_elems = pm.out_elems;
         info->num_ops = (int)pm.ops.size();
+        info->element_type = pm.u8 ? MF_ELEM_U8 : MF_ELEM_I8;
     })
 }
 

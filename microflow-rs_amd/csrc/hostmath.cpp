@@ -46,11 +46,25 @@ int8_t h_sat_i8(float x) {
     return (int8_t)(int32_t)x;
 }
 
+// Rust `as u8` on f32
+static int h_sat_u8(float x) {
+    if (std::isnan(x)) return 0;
+    if (x >= 255.0f) return 255;
+    if (x <= 0.0f) return 0;
+    return (int)(int32_t)x;
+}
+
 // src/quantize.rs:16-18
 int8_t h_quantize(float x, float scale, int8_t zp) {
     volatile float q = x / scale;
     volatile float s = q + (float)zp;
     return h_sat_i8(h_roundf(s));
+}
+// the same for either element type; zp and the result are plain ints in T's range
+int h_quantize_t(float x, float scale, int zp, bool u8) {
+    volatile float q = x / scale;
+    volatile float s = q + (float)zp;
+    return u8 ? h_sat_u8(h_roundf(s)) : (int)h_sat_i8(h_roundf(s));
 }
 
 // expf of the `libm` 0.2 crate (musl expf.c lineage): used on the HOST to build the
@@ -100,8 +114,9 @@ float h_expf(float x) {
 }
 
 // microflow-macros/src/ops/fully_connected.rs:100-123
-void h_preprocess_fc(float iscale, int8_t izp, int in_shape1, const int8_t *w, int K, int N,
-                     float wscale, int8_t wzp, const int32_t *bias, float bscale, int32_t bzp,
+// izp / wzp are values of T; `u8` says how the weight bytes read
+void h_preprocess_fc(float iscale, int izp, int in_shape1, const int8_t *w, bool u8, int K, int N,
+                     float wscale, int wzp, const int32_t *bias, float bscale, int32_t bzp,
                      float oscale, float *c0, float *c1, int32_t *c2, int32_t *c3) {
     volatile float ratio = bscale / oscale; // (bias_scale / output_scale) * f32(bias - zp)
     for (int j = 0; j < N; ++j) {
@@ -113,7 +128,7 @@ void h_preprocess_fc(float iscale, int8_t izp, int in_shape1, const int8_t *w, i
     for (int j = 0; j < N; ++j) { // column sums of the K x N matrix, times the input zero point
         int32_t s = 0;
         const int8_t *col = w + (size_t)j * K;
-        for (int k = 0; k < K; ++k) s = wrap_add(s, col[k]);
+        for (int k = 0; k < K; ++k) s = wrap_add(s, u8 ? (int32_t)(uint8_t)col[k] : (int32_t)col[k]);
         c2[j] = wrap_mul(s, izp);
     }
     *c3 = wrap_mul(wrap_mul(in_shape1, izp), wzp);
@@ -136,7 +151,7 @@ void h_preprocess_conv(float iscale, int n, const int32_t *bias, const float *bs
 }
 
 // microflow-macros/src/ops/average_pool_2d.rs:77-83
-void h_preprocess_pool(float iscale, int8_t izp, float oscale, int8_t ozp, float *c0, float *c1) {
+void h_preprocess_pool(float iscale, int izp, float oscale, int ozp, float *c0, float *c1) {
     *c0 = iscale / oscale;
     volatile float prod = iscale * (float)izp;
     volatile float q = prod / oscale;

@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void conv2d_generic(const int8_t *__restrict__
             }
         }
         const int acc = dot - p.wzp[n] * vs + p.Kc[n];
-        out[idx] = (int8_t)requant(acc, p.A[n], p.S[n], p.lo_f, p.hi_f);
+        out[idx] = (int8_t)(requant(acc, p.A[n], p.S[n], p.lo_f, p.hi_f) ^ p.xr);
     }
 }
 
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256) void dwconv_generic(const int8_t *__restrict__
             }
         }
         const int acc = dot - p.wzp[c] * vs + p.Kc[c];
-        out[idx] = (int8_t)requant(acc, p.A[c], p.S[c], p.lo_f, p.hi_f);
+        out[idx] = (int8_t)(requant(acc, p.A[c], p.S[c], p.lo_f, p.hi_f) ^ p.xr);
     }
 }
 
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256) void avgpool_generic(const int8_t *__restrict_
             for (int kx = 0; kx < p.KW; ++kx) {
                 const int ix = ox * p.sw + kx - shx;
                 if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) {
-                    sum += (int)ip[((size_t)iy * p.W + ix) * p.C + c];
+                    sum += (int)ip[((size_t)iy * p.W + ix) * p.C + c] + p.bias;
                     ++len;
                 }
             }
@@ -168,10 +168,10 @@ __global__ __launch_bounds__(256) void avgpool_generic(const int8_t *__restrict_
         const float y = __fadd_rn(__fmul_rn(p.c0, x), p.c1);
         float r = __fadd_rn(y, __builtin_copysignf(0x1.fffffep-2f, y));
         // NaN (len == 0) converts to 0 like Rust's `as`; fmed3 is skipped for it
-        int q = (r != r) ? 0 : (int)__builtin_amdgcn_fmed3f(r, -128.0f, 127.0f);
+        int q = (r != r) ? 0 : (int)__builtin_amdgcn_fmed3f(r, p.sat_lo, p.sat_hi);
         q = max(q, p.lo);
         q = min(q, p.hi);
-        out[idx] = (int8_t)q;
+        out[idx] = (int8_t)(q ^ p.xr);
     }
 }
 
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256) void fc_generic(const int8_t *__restrict__ in,
             }
         }
         const int acc = dot - p.wzp * rs + p.Kc[j];
-        out[idx] = (int8_t)requant(acc, p.A[j], p.S, p.lo_f, p.hi_f);
+        out[idx] = (int8_t)(requant(acc, p.A[j], p.S, p.lo_f, p.hi_f) ^ p.xr);
     }
 }
 
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(256) void fc_rowwave(const int8_t *__restrict__ in,
 #pragma unroll
             for (int j = 0; j < N; ++j) d = (lane == j) ? dot[j] : d;
             const int acc = d - p.wzp * rs + p.Kc[lane];
-            out[row * N + lane] = (int8_t)requant(acc, p.A[lane], p.S, p.lo_f, p.hi_f);
+            out[row * N + lane] = (int8_t)(requant(acc, p.A[lane], p.S, p.lo_f, p.hi_f) ^ p.xr);
         }
     }
 }
@@ -270,7 +270,8 @@ __global__ __launch_bounds__(256) void softmax_table(const int8_t *__restrict__ 
             const float prob = __fdiv_rn(e, sum);
             const float q = __fadd_rn(__fdiv_rn(prob, p.oscale), p.ozp_f); // quantize (quantize.rs:17)
             const float r = __fadd_rn(q, __builtin_copysignf(0x1.fffffep-2f, q));
-            y[i] = (r != r) ? (int8_t)0 : (int8_t)(int)__builtin_amdgcn_fmed3f(r, -128.0f, 127.0f);
+            const int qi = (r != r) ? 0 : (int)__builtin_amdgcn_fmed3f(r, p.sat_lo, p.sat_hi);
+            y[i] = (int8_t)(qi ^ p.xr);
         }
     }
 }
@@ -278,7 +279,7 @@ __global__ __launch_bounds__(256) void softmax_table(const int8_t *__restrict__ 
 // src/quantize.rs:16-18 over a buffer: q = sat(roundf(x / scale + f32(zp)))
 __global__ __launch_bounds__(256) void quantize_f32(const float *__restrict__ in,
                                                     int8_t *__restrict__ out, size_t n, float scale,
-                                                    float zp_f) {
+                                                    float zp_f, float sat_lo, float sat_hi, int xr) {
     // 4 values per thread: one 16-byte load, one 4-byte store
     const size_t n4 = n >> 2;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
@@ -289,24 +290,41 @@ __global__ __launch_bounds__(256) void quantize_f32(const float *__restrict__ in
         for (int k = 0; k < 4; ++k) {
             const float t = __fadd_rn(__fdiv_rn(xs[k], scale), zp_f);
             const float r = __fadd_rn(t, __builtin_copysignf(0x1.fffffep-2f, t));
-            q[k] = (r != r) ? 0 : (int)__builtin_amdgcn_fmed3f(r, -128.0f, 127.0f);
+            q[k] = (r != r) ? 0 : (int)__builtin_amdgcn_fmed3f(r, sat_lo, sat_hi);
         }
-        ((uint32_t *)out)[i] = pack4(q[0], q[1], q[2], q[3]);
+        ((uint32_t *)out)[i] = pack4(q[0], q[1], q[2], q[3]) ^ (0x01010101u * (uint32_t)xr);
     }
     for (size_t i = (n4 << 2) + (size_t)blockIdx.x * 256 + threadIdx.x; i < n;
          i += (size_t)gridDim.x * 256) {
         const float t = __fadd_rn(__fdiv_rn(in[i], scale), zp_f);
         const float r = __fadd_rn(t, __builtin_copysignf(0x1.fffffep-2f, t));
-        out[i] = (r != r) ? (int8_t)0 : (int8_t)(int)__builtin_amdgcn_fmed3f(r, -128.0f, 127.0f);
+        const int qi = (r != r) ? 0 : (int)__builtin_amdgcn_fmed3f(r, sat_lo, sat_hi);
+        out[i] = (int8_t)(qi ^ xr);
     }
+}
+
+// u8 <-> internal i8 domain at the quantized boundary of a u8 model: byte ^ 0x80
+__global__ __launch_bounds__(256) void xor80_bytes(const int8_t *in, int8_t *out,  // may alias (in place)
+                                                   size_t n) {
+    const size_t n16 = n >> 4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) {
+        u32x4 v = ((const u32x4 *)in)[i];
+        v ^= 0x80808080u;
+        ((u32x4 *)out)[i] = v;
+    }
+    for (size_t i = (n16 << 4) + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        out[i] = (int8_t)(in[i] ^ 0x80);
 }
 
 // src/quantize.rs:27-29: x = scale * (f32(q) - f32(zp))
 __global__ __launch_bounds__(256) void dequantize_i8(const int8_t *__restrict__ in,
                                                      float *__restrict__ out, size_t n, float scale,
-                                                     float zp_f) {
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
-        out[i] = __fmul_rn(scale, __fsub_rn((float)in[i], zp_f));
+                                                     float zp_f, int raw_u8) {
+    // raw_u8: the bytes are real u8 values (ABI-level mf_dequantize_u8), not the internal domain
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const int q = raw_u8 ? (int)(uint8_t)in[i] : (int)in[i];
+        out[i] = __fmul_rn(scale, __fsub_rn((float)q, zp_f));
+    }
 }
 
 // counter-based synthetic input: 8 bytes per thread
@@ -1388,7 +1406,7 @@ __global__ __launch_bounds__(64 * WM * WN) void fc_mfma(const int8_t *__restrict
                 const int q1 = requant(acc[nt][mt][r + 1] + cK[r + 1] - corr, cA[r + 1], p.S, p.lo_f, p.hi_f);
                 const int q2 = requant(acc[nt][mt][r + 2] + cK[r + 2] - corr, cA[r + 2], p.S, p.lo_f, p.hi_f);
                 const int q3 = requant(acc[nt][mt][r + 3] + cK[r + 3] - corr, cA[r + 3], p.S, p.lo_f, p.hi_f);
-                d[r >> 2] = pack4(q0, q1, q2, q3);
+                d[r >> 2] = pack4(q0, q1, q2, q3) ^ p.xr4;
             }
             *(uint4 *)(Y + (size_t)m * p.N + n0) = make_uint4(d[0], d[1], d[2], d[3]);
         }
@@ -1495,11 +1513,15 @@ void launch_fc_mfma(const int8_t *in, int8_t *out, const FcGemmArgs &a, hipStrea
 void launch_softmax(const int8_t *in, int8_t *out, const SoftmaxArgs &a, size_t batch, hipStream_t s) {
     hipLaunchKernelGGL(softmax_table, dim3(grid_for(batch)), dim3(256), 0, s, in, out, a, batch);
 }
-void launch_quantize(const float *in, int8_t *out, size_t n, float scale, float zp_f, hipStream_t s) {
-    hipLaunchKernelGGL(quantize_f32, dim3(grid_for((n + 3) / 4)), dim3(256), 0, s, in, out, n, scale, zp_f);
+void launch_quantize(const float *in, int8_t *out, size_t n, float scale, float zp_f, bool u8, hipStream_t s) {
+    hipLaunchKernelGGL(quantize_f32, dim3(grid_for((n + 3) / 4)), dim3(256), 0, s, in, out, n, scale, zp_f,
+                       u8 ? 0.0f : -128.0f, u8 ? 255.0f : 127.0f, u8 ? 0x80 : 0);
 }
-void launch_dequantize(const int8_t *in, float *out, size_t n, float scale, float zp_f, hipStream_t s) {
-    hipLaunchKernelGGL(dequantize_i8, dim3(grid_for(n)), dim3(256), 0, s, in, out, n, scale, zp_f);
+void launch_xor80(const int8_t *in, int8_t *out, size_t n, hipStream_t s) {
+    hipLaunchKernelGGL(xor80_bytes, dim3(grid_for((n + 15) / 16)), dim3(256), 0, s, in, out, n);
+}
+void launch_dequantize(const int8_t *in, float *out, size_t n, float scale, float zp_f, bool raw_u8, hipStream_t s) {
+    hipLaunchKernelGGL(dequantize_i8, dim3(grid_for(n)), dim3(256), 0, s, in, out, n, scale, zp_f, raw_u8 ? 1 : 0);
 }
 void launch_synth(int8_t *out, size_t n, uint64_t seed, uint64_t first, hipStream_t s) {
     hipLaunchKernelGGL(synth_i8, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, s, out, n, seed, first);

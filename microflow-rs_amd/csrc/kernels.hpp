@@ -12,6 +12,12 @@ namespace k {
 //   Kc[c] = -izp * sum_taps w[c] + T * izp * wzp[c]   (FC: c3 - c2[c])
 //   wzp[c] expanded to one int per channel
 // lo_f / hi_f: activation clamp merged with the int8 saturation, as floats.
+//
+// Element type u8 (the reference's `T = u8`): activations and weights live in HBM in the i8
+// domain (byte ^ 0x80, i.e. value - 128) and every zero point is shifted by -128, which leaves
+// each (v - zp) factor -- hence the i32 accumulator -- unchanged.  The f32 epilogue runs in the
+// u8 domain exactly as the reference's (A = f32(ozp_u8) + c0, clamp inside [0, 255]); `xr` =
+// 0x80 then moves the stored byte back to the i8 domain.  xr = 0 for i8.
 struct ConvArgs {
     int H, W, C;        // input (per inference); for depthwise C = input channels
     int N;              // output channels
@@ -24,11 +30,15 @@ struct ConvArgs {
     const float *A;     // [N]
     const float *S;     // [N]
     const int *Kc;      // [N]
+    int xr;             // 0 (i8) or 0x80 (u8)
 };
 struct PoolArgs {
     int H, W, C, KH, KW, sh, sw, OH, OW, pad_same;
     float c0, c1;
     int lo, hi;
+    int bias;           // added per in-bounds tap: 0 (i8) or 128 (u8: stored byte + 128 = value)
+    float sat_lo, sat_hi; // `as T` saturation: [-128,127] or [0,255]
+    int xr;
 };
 struct FcArgs {
     int K, N;
@@ -38,6 +48,7 @@ struct FcArgs {
     const int8_t *w;    // [N][K]
     const float *A;     // [N]
     const int *Kc;      // [N] = c3 - c2[j]
+    int xr;
 };
 struct FcGemmArgs {
     const int8_t *w;    // [N][K]
@@ -48,11 +59,14 @@ struct FcGemmArgs {
     float S;
     float lo_f, hi_f;
     int M, N, K;        // M = total rows (batch * rows per inference)
+    uint32_t xr4;       // 0 or 0x80808080
 };
 struct SoftmaxArgs {
     int rows, cols;
     float oscale, ozp_f;
-    const float *exp_table; // [256]: expf(f32(q) * input_scale), q = index - 128
+    const float *exp_table; // [256]: expf(f32(q) * input_scale), index = stored byte + 128
+    float sat_lo, sat_hi;
+    int xr;
 };
 struct DwFastArgs {
     const int8_t *w;    // [3][3][C]
@@ -161,8 +175,9 @@ bool fc_mfma_supported(size_t rows, int N, int K);
 void launch_fc_rowsum(const int8_t *in, int *rowsum, size_t rows, int K, hipStream_t s);
 void launch_fc_mfma(const int8_t *in, int8_t *out, const FcGemmArgs &a, hipStream_t s);
 void launch_softmax(const int8_t *in, int8_t *out, const SoftmaxArgs &a, size_t batch, hipStream_t s);
-void launch_quantize(const float *in, int8_t *out, size_t n, float scale, float zp_f, hipStream_t s);
-void launch_dequantize(const int8_t *in, float *out, size_t n, float scale, float zp_f, hipStream_t s);
+void launch_quantize(const float *in, int8_t *out, size_t n, float scale, float zp_f, bool u8, hipStream_t s);
+void launch_xor80(const int8_t *in, int8_t *out, size_t n, hipStream_t s);
+void launch_dequantize(const int8_t *in, float *out, size_t n, float scale, float zp_f, bool raw_u8, hipStream_t s);
 void launch_synth(int8_t *out, size_t n, uint64_t seed, uint64_t first, hipStream_t s);
 void launch_checksum(const int8_t *in, size_t n, unsigned long long *result, hipStream_t s);
 

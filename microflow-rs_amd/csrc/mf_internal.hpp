@@ -32,13 +32,14 @@ float h_roundf(float x);                              // round half away from ze
 float h_expf(float x);                                // libm 0.2 (musl-derived) expf
 int8_t h_sat_i8(float x);                             // Rust `as i8`
 int8_t h_quantize(float x, float scale, int8_t zp);   // src/quantize.rs:16-18
-void h_preprocess_fc(float iscale, int8_t izp, int in_shape1, const int8_t *w, int K, int N,
-                     float wscale, int8_t wzp, const int32_t *bias, float bscale, int32_t bzp,
+int h_quantize_t(float x, float scale, int zp, bool u8); // either element type
+void h_preprocess_fc(float iscale, int izp, int in_shape1, const int8_t *w, bool u8, int K, int N,
+                     float wscale, int wzp, const int32_t *bias, float bscale, int32_t bzp,
                      float oscale, float *c0, float *c1, int32_t *c2, int32_t *c3);
 void h_preprocess_conv(float iscale, int n, const int32_t *bias, const float *bscale,
                        const int32_t *bzp, int nbq, const float *fscale, int nfq, float oscale,
                        float *c0, float *c1);
-void h_preprocess_pool(float iscale, int8_t izp, float oscale, int8_t ozp, float *c0, float *c1);
+void h_preprocess_pool(float iscale, int izp, float oscale, int ozp, float *c0, float *c1);
 
 // ---- parsed model (tflite.cpp) -------------------------------------------
 struct ParsedOp {
@@ -54,13 +55,14 @@ struct ParsedOp {
     int N = 0;               // conv filters / dw channels / fc outputs / softmax cols
     int M = 0, K = 0;        // fc rows / depth; softmax rows = M
     int OH = 0, OW = 0;
-    std::vector<int8_t> weights; // fc [N][K]; conv [N][KH][KW][C]; dw [KH][KW][N]
-    std::vector<int8_t> wzp;     // weight zero points (1 or per channel)
+    std::vector<int8_t> weights; // fc [N][K]; conv [N][KH][KW][C]; dw [KH][KW][N] (raw bytes of T)
+    std::vector<int> wzp;        // weight zero points (1 or per channel), values of T
     std::vector<float> c0, c1;
     std::vector<int32_t> c2;
     int32_t c3 = 0;
 };
 struct ParsedModel {
+    bool u8 = false; // element type T of every quantized tensor: INT8 (false) or UINT8 (true)
     int in_rank = 0, in_shape[4] = {0, 0, 0, 0};
     int out_rank = 0, out_shape[4] = {0, 0, 0, 0};
     float in_scale = 0, out_scale = 0;
@@ -74,6 +76,10 @@ ParsedModel parse_tflite(const uint8_t *buf, size_t len);
 struct OpImpl; // device buffers + kernel routing
 struct OpSpec {
     int kind = 0;
+    // Element type T.  With u8 = true the zero points (izp, ozp, wzp) are u8 values, `weights`
+    // are raw u8 bytes, c2/c3 come from the u8 preprocess; activations are exchanged with the
+    // operator in the INTERNAL i8 domain (byte ^ 0x80) -- see kernels.hpp.
+    bool u8 = false;
     int M = 0, K = 0, N = 0;
     int H = 0, W = 0, C = 0, KH = 0, KW = 0, sh = 1, sw = 1, pad = 0, OH = 0, OW = 0;
     int act = 0;
@@ -82,7 +88,7 @@ struct OpSpec {
     float oscale = 0;
     int ozp = 0;
     const int8_t *weights = nullptr;
-    const int8_t *wzp = nullptr;
+    const int *wzp = nullptr;
     int nq = 0;
     const float *c0 = nullptr;
     const float *c1 = nullptr;
@@ -94,6 +100,8 @@ struct OpSpec {
 OpImpl *op_create(int device, const OpSpec &spec);
 void op_destroy(OpImpl *op);
 void op_run(OpImpl *op, const int8_t *d_in, size_t batch, int8_t *d_out, void *stream);
+// the ABI's view: a u8 operator exchanges real u8 bytes (two extra byte passes)
+void op_run_external(OpImpl *op, const int8_t *d_in, size_t batch, int8_t *d_out, void *stream);
 size_t op_in_elems(const OpImpl *op);
 size_t op_out_elems(const OpImpl *op);
 const char *op_kernel_name(const OpImpl *op);
@@ -108,10 +116,14 @@ void fused_destroy(FusedImpl *f);
 void fused_run(FusedImpl *f, const int8_t *d_in, size_t batch, int8_t *d_out, void *stream);
 const char *fused_kernel_name(const FusedImpl *f);
 
-void dev_quantize(int device, const float *d_in, size_t n, float scale, int8_t zp, int8_t *d_out,
+// zp is a value of T; with u8 the int8 buffer is in the internal domain (byte ^ 0x80)
+void dev_quantize(int device, const float *d_in, size_t n, float scale, int zp, bool u8, int8_t *d_out,
                   void *stream);
-void dev_dequantize(int device, const int8_t *d_in, size_t n, float scale, int8_t zp, float *d_out,
+void dev_dequantize(int device, const int8_t *d_in, size_t n, float scale, int zp, bool u8, float *d_out,
                     void *stream);
+void dev_dequantize_u8_raw(int device, const uint8_t *d_in, size_t n, float scale, int zp, float *d_out,
+                           void *stream); // real u8 bytes in
+void dev_xor80(int device, const int8_t *d_in, size_t n, int8_t *d_out, void *stream);
 void dev_synth_i8(int device, uint64_t seed, uint64_t first, size_t n, int8_t *d_out, void *stream);
 uint64_t dev_checksum_i8(int device, const int8_t *d_in, size_t n, void *stream);
 int dev_count();

@@ -118,6 +118,7 @@ void model_prepare(ModelImpl *m, int device, size_t max_batch) {
             }
             OpSpec s;
             s.kind = po.kind;
+            s.u8 = m->pm.u8;
             s.M = po.M, s.K = po.K, s.N = po.N;
             s.H = po.H, s.W = po.W, s.C = po.C, s.KH = po.KH, s.KW = po.KW;
             s.sh = po.sh ? po.sh : 1, s.sw = po.sw ? po.sw : 1, s.pad = po.pad;
@@ -227,10 +228,14 @@ void model_run(ModelImpl *m, const float *in_f32, const int8_t *in_i8, size_t ba
                                   hipMemcpyHostToDevice, s));
             d_f = m->io_f32;
         }
-        dev_quantize(m->device, d_f, batch * pm.in_elems, pm.in_scale, (int8_t)pm.in_zp, m->in_q, s);
+        dev_quantize(m->device, d_f, batch * pm.in_elems, pm.in_scale, pm.in_zp, pm.u8, m->in_q, s);
         q_in = m->in_q;
     } else if (host) {
         MF_HIP(hipMemcpyAsync(m->in_q, in_i8, batch * pm.in_elems, hipMemcpyHostToDevice, s));
+        if (pm.u8) dev_xor80(m->device, m->in_q, batch * pm.in_elems, m->in_q, s); // u8 -> internal i8 domain
+        q_in = m->in_q;
+    } else if (pm.u8) {
+        dev_xor80(m->device, in_i8, batch * pm.in_elems, m->in_q, s);
         q_in = m->in_q;
     } else {
         q_in = in_i8; // device-resident batch: consumed in place
@@ -241,13 +246,19 @@ void model_run(ModelImpl *m, const float *in_f32, const int8_t *in_i8, size_t ba
 
     // ---- output ----
     if (out_i8) {
-        MF_HIP(hipMemcpyAsync(out_i8, res, batch * out_elems, host ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, s));
+        if (pm.u8) { // internal i8 domain -> u8 (the op buffers are scratch: in place, unless no op ran)
+            int8_t *tmp = res == q_in ? m->act[0] : const_cast<int8_t *>(res);
+            dev_xor80(m->device, res, batch * out_elems, host ? tmp : out_i8, s);
+            if (host) MF_HIP(hipMemcpyAsync(out_i8, tmp, batch * out_elems, hipMemcpyDeviceToHost, s));
+        } else {
+            MF_HIP(hipMemcpyAsync(out_i8, res, batch * out_elems, host ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, s));
+        }
     } else { // .dequantize()  (lib.rs:190) with the parameters the last op stamped on the tensor
         float oscale = pm.out_scale;
         int ozp = pm.out_zp;
         if (last_op != nops - 1) oscale = pm.ops[last_op].out_scale, ozp = pm.ops[last_op].out_zp;
         float *d_o = host ? m->io_f32 : out_f32;
-        dev_dequantize(m->device, res, batch * out_elems, oscale, (int8_t)ozp, d_o, s);
+        dev_dequantize(m->device, res, batch * out_elems, oscale, ozp, pm.u8, d_o, s);
         if (host)
             MF_HIP(hipMemcpyAsync(out_f32, m->io_f32, batch * out_elems * sizeof(float),
                                   hipMemcpyDeviceToHost, s));

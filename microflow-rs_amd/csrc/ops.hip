@@ -63,12 +63,12 @@ struct DevBuf {
     template <typename T> const T *as() const { return (const T *)p; }
 };
 
-// activation + int8 saturation as one clamp [lo, hi]  (src/activation.rs:21-34)
-void act_bounds(int act, float oscale, int ozp, int &lo, int &hi) {
-    lo = -128;
-    hi = 127;
+// activation + `as T` saturation as one clamp [lo, hi] in T's domain  (src/activation.rs:21-34)
+void act_bounds(int act, float oscale, int ozp, bool u8, int &lo, int &hi) {
+    lo = u8 ? 0 : -128;
+    hi = u8 ? 255 : 127;
     if (act == MF_ACT_RELU || act == MF_ACT_RELU6) lo = ozp;        // max(y, zero_point)
-    if (act == MF_ACT_RELU6) hi = h_quantize(6.0f, oscale, (int8_t)ozp); // min(.., quantize(6.0))
+    if (act == MF_ACT_RELU6) hi = h_quantize_t(6.0f, oscale, ozp, u8); // min(.., quantize(6.0))
     if (lo > hi) lo = hi; // min(max(y, lo), hi) == hi for every y when lo > hi
 }
 
@@ -83,6 +83,8 @@ struct OpImpl {
     enum Fast { NONE, DW_NHWC, DW_STEM, DW_C1, PW_MFMA, FC_ROWWAVE, FC_MFMA } fast = NONE;
     int *d_rowsum = nullptr; // FC_MFMA with wzp != 0: per-row input sums
     size_t rowsum_cap = 0;
+    int8_t *d_ext = nullptr; // op_run_external on a u8 operator: input moved to the i8 domain
+    size_t ext_cap = 0;
 
     DevBuf d_w, d_wzp, d_A, d_S, d_Kc, d_wprep, d_table;
     k::DwC1Args dwc1{};
@@ -158,13 +160,28 @@ std::vector<int8_t> build_pw_weights(const int8_t *w /*[N][K]*/, int K, int N) {
 
 } // namespace
 
-OpImpl *op_create(int device, const OpSpec &s) {
+OpImpl *op_create(int device, const OpSpec &spec) {
     dev_require(device);
     std::unique_ptr<OpImpl> op(new OpImpl);
     op->device = device;
-    op->s = s;
+    OpSpec s = spec;
+    // T = u8: move the integer side to the i8 domain (every value and zero point minus 128);
+    // ozp, A, the clamp and the saturation stay in the u8 domain (kernels.hpp)
+    const int beta = s.u8 ? 128 : 0;
+    const int xr = s.u8 ? 0x80 : 0;
+    std::vector<int8_t> w_i8;
+    std::vector<int> wzp_i8;
+    auto to_i8_domain = [&](size_t wbytes) {
+        if (!s.u8) return;
+        w_i8.resize(wbytes);
+        for (size_t i = 0; i < wbytes; ++i) w_i8[i] = (int8_t)(s.weights[i] ^ (int8_t)0x80);
+        wzp_i8.resize((size_t)s.nq);
+        for (int i = 0; i < s.nq; ++i) wzp_i8[(size_t)i] = s.wzp[i] - beta;
+        s.weights = w_i8.data(), s.wzp = wzp_i8.data();
+        s.izp -= beta;
+    };
     int lo, hi;
-    act_bounds(s.act, s.oscale, s.ozp, lo, hi);
+    act_bounds(s.act, s.oscale, s.ozp, s.u8, lo, hi);
 
     switch (s.kind) {
     case MF_OP_CONV_2D:
@@ -179,6 +196,7 @@ OpImpl *op_create(int device, const OpSpec &s) {
             fail(MF_ERR_INVALID_ARG, "conv: VALID view leaves the input (the reference would panic, src/tensor.rs:223)");
         op->in_elems = (size_t)s.H * s.W * s.C;
         op->out_elems = (size_t)s.OH * s.OW * s.N;
+        to_i8_domain(dw ? (size_t)s.KH * s.KW * s.N : (size_t)s.N * s.KH * s.KW * s.C);
         std::vector<float> A, S;
         std::vector<int32_t> Kc, wzp;
         fold_conv_constants(*op, s, dw, A, S, Kc, wzp);
@@ -194,9 +212,11 @@ OpImpl *op_create(int device, const OpSpec &s) {
         a.lo_f = (float)lo, a.hi_f = (float)hi;
         a.w = op->d_w.as<int8_t>(), a.wzp = op->d_wzp.as<int>(), a.A = op->d_A.as<float>();
         a.S = op->d_S.as<float>(), a.Kc = op->d_Kc.as<int>();
+        a.xr = xr;
         op->generic_name = dw ? "dwconv_generic" : "conv2d_generic";
 
-        const bool zero_wzp = all_zero(wzp);
+        // the shape-specialised kernels below store i8-domain epilogue results only
+        const bool zero_wzp = all_zero(wzp) && !s.u8;
         const bool same3x3 = s.KH == 3 && s.KW == 3 && s.pad == MF_PAD_SAME && s.sh == s.sw &&
                              s.OH == (s.H + s.sh - 1) / s.sh && s.OW == (s.W + s.sw - 1) / s.sw;
         if (dw && zero_wzp && same3x3 && s.C == s.N && k::dw_fast_name(s.H, s.W, s.C, s.sh)) {
@@ -261,6 +281,8 @@ OpImpl *op_create(int device, const OpSpec &s) {
         a.H = s.H, a.W = s.W, a.C = s.C, a.KH = s.KH, a.KW = s.KW, a.sh = s.sh, a.sw = s.sw;
         a.OH = s.OH, a.OW = s.OW, a.pad_same = s.pad == MF_PAD_SAME;
         a.c0 = s.pool_c0, a.c1 = s.pool_c1, a.lo = lo, a.hi = hi;
+        a.bias = beta, a.xr = xr;
+        a.sat_lo = s.u8 ? 0.0f : -128.0f, a.sat_hi = s.u8 ? 255.0f : 127.0f;
         op->generic_name = "avgpool_generic";
         break;
     }
@@ -269,19 +291,30 @@ OpImpl *op_create(int device, const OpSpec &s) {
             fail(MF_ERR_INVALID_ARG, "fully_connected: bad arguments");
         op->in_elems = (size_t)s.M * s.K;
         op->out_elems = (size_t)s.M * s.N;
+        const int wzp_t = s.wzp ? s.wzp[0] : 0; // in T's domain
+        if (!s.wzp) s.nq = 0;
+        to_i8_domain((size_t)s.N * s.K);
         std::vector<float> A(s.N);
         std::vector<int32_t> Kc(s.N);
         for (int j = 0; j < s.N; ++j) {
             volatile float a = (float)s.ozp + s.c0[j];
             A[j] = a;
             Kc[j] = wrap_sub(s.c3, s.c2[j]); // acc = x0 - x1 - c2[j] + c3
+            if (s.u8) {
+                // with x = x' + 128, w = w' + 128:  x0 - x1 = sum x'w' - (wzp - 128) sum x'
+                //                                   + 128 sum_k w'[j][k] + K 128 (128 - wzp)
+                int32_t ws = 0;
+                for (int k = 0; k < s.K; ++k) ws = wrap_add(ws, s.weights[(size_t)j * s.K + k]);
+                Kc[j] = wrap_add(Kc[j], wrap_add(wrap_mul(beta, ws),
+                                                 wrap_mul(wrap_mul(s.K, beta), beta - wzp_t)));
+            }
         }
         op->d_w.upload(s.weights, (size_t)s.N * s.K);
         op->d_A.upload(A.data(), A.size() * 4);
         op->d_Kc.upload(Kc.data(), Kc.size() * 4);
         k::FcArgs &a = op->fc;
-        a.K = s.K, a.N = s.N, a.wzp = s.wzp ? s.wzp[0] : 0, a.S = s.c1[0];
-        a.lo_f = (float)lo, a.hi_f = (float)hi;
+        a.K = s.K, a.N = s.N, a.wzp = wzp_t - beta, a.S = s.c1[0];
+        a.lo_f = (float)lo, a.hi_f = (float)hi, a.xr = xr;
         a.w = op->d_w.as<int8_t>(), a.A = op->d_A.as<float>(), a.Kc = op->d_Kc.as<int>();
         op->generic_name = "fc_generic";
         if (s.K % 16 == 0 && s.K >= 256 && (s.N == 1 || s.N == 2 || s.N == 4 || s.N == 8)) {
@@ -299,21 +332,24 @@ OpImpl *op_create(int device, const OpSpec &s) {
         op->in_elems = op->out_elems = (size_t)s.M * s.N;
         // exp table over the 256 possible int8 inputs: expf(f32(q) * input.scale[0])
         // (src/ops/softmax.rs:20-21), libm's algorithm evaluated on the host
+        // (entry = stored byte + 128, which is q + 128 for i8 and q itself for u8)
         std::vector<float> table(256);
-        for (int q = -128; q <= 127; ++q) {
-            volatile float e = (float)q * s.in_scale;
-            table[q + 128] = h_expf(e);
+        for (int i = 0; i < 256; ++i) {
+            volatile float e = (float)(s.u8 ? i : i - 128) * s.in_scale;
+            table[(size_t)i] = h_expf(e);
         }
         op->d_table.upload(table.data(), 256 * 4);
         k::SoftmaxArgs &a = op->sm;
         a.rows = s.M, a.cols = s.N, a.oscale = s.oscale, a.ozp_f = (float)s.ozp;
         a.exp_table = op->d_table.as<float>();
+        a.sat_lo = s.u8 ? 0.0f : -128.0f, a.sat_hi = s.u8 ? 255.0f : 127.0f, a.xr = xr;
         op->generic_name = "softmax_table";
         break;
     }
     default:
         fail(MF_ERR_UNSUPPORTED, "unsupported operator kind " + std::to_string(s.kind));
     }
+    op->s = s;
     // the spec's host pointers die with the caller
     op->s.weights = nullptr, op->s.wzp = nullptr, op->s.c0 = op->s.c1 = nullptr, op->s.c2 = nullptr;
     return op.release();
@@ -323,6 +359,7 @@ void op_destroy(OpImpl *op) {
     if (!op) return;
     (void)hipSetDevice(op->device);
     if (op->d_rowsum) (void)hipFree(op->d_rowsum);
+    if (op->d_ext) (void)hipFree(op->d_ext);
     delete op;
 }
 
@@ -366,6 +403,7 @@ void op_run(OpImpl *op, const int8_t *d_in, size_t batch, int8_t *d_out, void *s
             k::FcGemmArgs g{};
             g.w = op->fc.w, g.A = op->fc.A, g.Kc = op->fc.Kc, g.wzp = op->fc.wzp, g.S = op->fc.S;
             g.lo_f = op->fc.lo_f, g.hi_f = op->fc.hi_f, g.M = (int)rows, g.N = sp.N, g.K = sp.K;
+            g.xr4 = 0x01010101u * (uint32_t)op->fc.xr;
             g.rowsum = nullptr;
             if (op->fc.wzp != 0) {
                 if (op->rowsum_cap < rows) {
@@ -398,6 +436,26 @@ void op_run(OpImpl *op, const int8_t *d_in, size_t batch, int8_t *d_out, void *s
     MF_HIP(hipGetLastError());
 }
 
+// The C ABI's mf_op_run: a u8 operator takes and returns real u8 bytes.
+void op_run_external(OpImpl *op, const int8_t *d_in, size_t batch, int8_t *d_out, void *stream) {
+    if (!op->s.u8) return op_run(op, d_in, batch, d_out, stream);
+    if (!batch) return;
+    if (!d_in || !d_out) fail(MF_ERR_INVALID_ARG, "op_run: null device pointer");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t n_in = batch * op->in_elems;
+    if (op->ext_cap < n_in) {
+        MF_HIP(hipStreamSynchronize(s));
+        if (op->d_ext) (void)hipFree(op->d_ext);
+        op->d_ext = nullptr;
+        MF_HIP(hipMalloc((void **)&op->d_ext, n_in + 256));
+        op->ext_cap = n_in;
+    }
+    k::launch_xor80(d_in, op->d_ext, n_in, s);
+    op_run(op, op->d_ext, batch, d_out, stream);
+    k::launch_xor80(d_out, d_out, batch * op->out_elems, s);
+    MF_HIP(hipGetLastError());
+}
+
 struct FusedImpl {
     enum Kind { DWPW, TAIL } kind;
     OpImpl *a, *b, *c;
@@ -422,6 +480,7 @@ FusedImpl *fused_create(OpImpl *dw, OpImpl *pw) {
 FusedImpl *fused_tail_create(OpImpl *pool, OpImpl *conv, OpImpl *sm) {
     if (!pool || !conv || !sm) return nullptr;
     const OpSpec &p = pool->s, &c = conv->s, &m = sm->s;
+    if (p.u8 || c.u8 || m.u8) return nullptr; // i8 epilogues only
     if (p.kind != MF_OP_AVERAGE_POOL_2D || c.kind != MF_OP_CONV_2D || m.kind != MF_OP_SOFTMAX) return nullptr;
     if (p.OH != 1 || p.OW != 1) return nullptr;                       // one pooling window
     if (c.KH != 1 || c.KW != 1 || c.H != 1 || c.W != 1 || c.OH != 1 || c.OW != 1 || c.C != p.C) return nullptr;
@@ -465,18 +524,32 @@ void fused_run(FusedImpl *f, const int8_t *d_in, size_t batch, int8_t *d_out, vo
     MF_HIP(hipGetLastError());
 }
 
-void dev_quantize(int device, const float *d_in, size_t n, float scale, int8_t zp, int8_t *d_out,
+void dev_quantize(int device, const float *d_in, size_t n, float scale, int zp, bool u8, int8_t *d_out,
                   void *stream) {
     dev_require(device);
     if (!n) return;
-    k::launch_quantize(d_in, d_out, n, scale, (float)zp, (hipStream_t)stream);
+    k::launch_quantize(d_in, d_out, n, scale, (float)zp, u8, (hipStream_t)stream);
     MF_HIP(hipGetLastError());
 }
-void dev_dequantize(int device, const int8_t *d_in, size_t n, float scale, int8_t zp, float *d_out,
+void dev_dequantize(int device, const int8_t *d_in, size_t n, float scale, int zp, bool u8, float *d_out,
                     void *stream) {
     dev_require(device);
     if (!n) return;
-    k::launch_dequantize(d_in, d_out, n, scale, (float)zp, (hipStream_t)stream);
+    // f32(q) - f32(zp) with q = stored + 128: both small integers, so the shift moves to zp exactly
+    k::launch_dequantize(d_in, d_out, n, scale, (float)(zp - (u8 ? 128 : 0)), false, (hipStream_t)stream);
+    MF_HIP(hipGetLastError());
+}
+void dev_dequantize_u8_raw(int device, const uint8_t *d_in, size_t n, float scale, int zp, float *d_out,
+                           void *stream) {
+    dev_require(device);
+    if (!n) return;
+    k::launch_dequantize((const int8_t *)d_in, d_out, n, scale, (float)zp, true, (hipStream_t)stream);
+    MF_HIP(hipGetLastError());
+}
+void dev_xor80(int device, const int8_t *d_in, size_t n, int8_t *d_out, void *stream) {
+    dev_require(device);
+    if (!n) return;
+    k::launch_xor80(d_in, d_out, n, (hipStream_t)stream);
     MF_HIP(hipGetLastError());
 }
 void dev_synth_i8(int device, uint64_t seed, uint64_t first, size_t n, int8_t *d_out, void *stream) {

@@ -133,13 +133,18 @@ void need_quant(const TensorInfo &t, const char *what) {
         fail(MF_ERR_INVALID_MODEL, std::string("invalid model: ") + what + " has no quantization");
 }
 
-void require_i8(const TensorInfo &t, const char *op) {
-    if (t.type == TT_UINT8)
-        fail(MF_ERR_UNSUPPORTED, std::string(op) + ": UINT8 tensors are not supported by this build (INT8 only)");
-    if (t.type != TT_INT8)
+// The reference monomorphises every operator on its input tensor's type (i8 or u8, e.g.
+// microflow-macros/src/ops/conv_2d.rs:58-83); a model whose tensors mix the two does not
+// type-check there.  Here: every quantized tensor must have the model input's type.
+void require_elem(const TensorInfo &t, const char *op, bool u8) {
+    if (t.type != TT_INT8 && t.type != TT_UINT8)
         fail(MF_ERR_UNSUPPORTED, std::string(op) + " supports only INT8/UINT8 input tensors, got type " +
                                      std::to_string(t.type));
+    if ((t.type == TT_UINT8) != u8)
+        fail(MF_ERR_UNSUPPORTED, std::string(op) + ": tensor element type differs from the model input's (mixed INT8/UINT8)");
 }
+// zero points are i64 in the file and cast to T (microflow-macros/src/tensor.rs:81-88)
+int zp_of(int64_t z, bool u8) { return u8 ? (int)(uint8_t)z : (int)(int8_t)z; }
 
 int check_act(int a) { // microflow-macros/src/activation.rs:26-38
     if (a != MF_ACT_NONE && a != MF_ACT_RELU && a != MF_ACT_RELU6)
@@ -152,7 +157,7 @@ int check_pad(int p) {
     return p;
 }
 
-void set_shapes(ParsedOp &op, const TensorInfo &in, const TensorInfo &out) {
+void set_shapes(ParsedOp &op, const TensorInfo &in, const TensorInfo &out, bool u8) {
     op.in_rank = (int)in.shape.size();
     op.out_rank = (int)out.shape.size();
     for (int i = 0; i < op.in_rank; ++i) op.in_shape[i] = in.shape[i];
@@ -160,9 +165,9 @@ void set_shapes(ParsedOp &op, const TensorInfo &in, const TensorInfo &out) {
     op.in_elems = in.elems();
     op.out_elems = out.elems();
     if (!in.scale.empty()) op.in_scale = in.scale[0];
-    if (!in.zp.empty()) op.in_zp = (int8_t)in.zp[0];
+    if (!in.zp.empty()) op.in_zp = zp_of(in.zp[0], u8);
     if (!out.scale.empty()) op.out_scale = out.scale[0];
-    if (!out.zp.empty()) op.out_zp = (int8_t)out.zp[0];
+    if (!out.zp.empty()) op.out_zp = zp_of(out.zp[0], u8);
 }
 
 } // namespace
@@ -185,27 +190,28 @@ ParsedModel parse_tflite(const uint8_t *data, size_t len) {
     { // model input (lib.rs:66-126)
         TensorInfo t = read_tensor(tensors, buffers, g_in.get<int32_t>(0));
         fix_rank1(t);
-        if (t.type == TT_UINT8)
-            fail(MF_ERR_UNSUPPORTED, "unsupported input tensor type: UINT8 (this build implements the INT8 path)");
-        if (t.type != TT_INT8)
+        if (t.type != TT_INT8 && t.type != TT_UINT8)
             fail(MF_ERR_UNSUPPORTED, "unsupported input tensor type: " + std::to_string(t.type) +
                                          ". Supported input types are INT8 and UINT8");
         if (t.shape.size() != 2 && t.shape.size() != 4)
             fail(MF_ERR_UNSUPPORTED, "unsupported input tensor rank: " + std::to_string(t.shape.size()) +
                                          ". Supported ranks are 2 and 4");
         need_quant(t, "model input");
+        pm.u8 = t.type == TT_UINT8;
         pm.in_rank = (int)t.shape.size();
         for (int i = 0; i < pm.in_rank; ++i) pm.in_shape[i] = t.shape[i];
         pm.in_scale = t.scale[0];
-        pm.in_zp = (int8_t)t.zp[0];
+        pm.in_zp = zp_of(t.zp[0], pm.u8);
         pm.in_elems = t.elems();
     }
     { // model output (lib.rs:153-183)
         TensorInfo t = read_tensor(tensors, buffers, g_out.get<int32_t>(0));
         fix_rank1(t);
-        if (t.type != TT_INT8)
+        if (t.type != TT_INT8 && t.type != TT_UINT8)
             fail(MF_ERR_UNSUPPORTED, "unsupported output tensor type: " + std::to_string(t.type) +
                                          ". Supported output types are INT8 and UINT8");
+        if ((t.type == TT_UINT8) != pm.u8)
+            fail(MF_ERR_UNSUPPORTED, "model input and output element types differ (mixed INT8/UINT8)");
         if (t.shape.size() != 2 && t.shape.size() != 4)
             fail(MF_ERR_UNSUPPORTED, "unsupported output tensor rank: " + std::to_string(t.shape.size()) +
                                          ". Supported ranks are 2 and 4");
@@ -213,7 +219,7 @@ ParsedModel parse_tflite(const uint8_t *data, size_t len) {
         pm.out_rank = (int)t.shape.size();
         for (int i = 0; i < pm.out_rank; ++i) pm.out_shape[i] = t.shape[i];
         pm.out_scale = t.scale[0];
-        pm.out_zp = (int8_t)t.zp[0];
+        pm.out_zp = zp_of(t.zp[0], pm.u8);
         pm.out_elems = t.elems();
     }
     pm.max_elems = pm.in_elems;
@@ -235,14 +241,14 @@ ParsedModel parse_tflite(const uint8_t *data, size_t len) {
 
         switch (code) {
         case MF_OP_FULLY_CONNECTED: { // microflow-macros/src/ops/fully_connected.rs:66-98
-            require_i8(in, "FullyConnected");
+            require_elem(in, "FullyConnected", pm.u8), require_elem(out, "FullyConnected", pm.u8);
             if (ins.size() < 3) fail(MF_ERR_INVALID_MODEL, "invalid model: FullyConnected needs 3 inputs");
             TensorInfo w = read_tensor(tensors, buffers, ins.get<int32_t>(1));
             TensorInfo b = read_tensor(tensors, buffers, ins.get<int32_t>(2));
             fix_rank1(in), fix_rank1(out), fix_rank1(w), fix_rank1(b);
             need_quant(in, "FullyConnected input"), need_quant(out, "FullyConnected output");
             need_quant(w, "FullyConnected weights"), need_quant(b, "FullyConnected bias");
-            if (w.shape.size() != 2 || w.type != TT_INT8 || b.type != TT_INT32)
+            if (w.shape.size() != 2 || w.type != (pm.u8 ? TT_UINT8 : TT_INT8) || b.type != TT_INT32)
                 fail(MF_ERR_UNSUPPORTED, "FullyConnected: unsupported weights/bias tensors");
             po.N = w.shape[0];
             po.K = w.shape[1];
@@ -250,16 +256,16 @@ ParsedModel parse_tflite(const uint8_t *data, size_t len) {
             if (in.elems() != (size_t)po.M * po.K || w.data_len < (size_t)po.N * po.K ||
                 b.data_len < (size_t)po.N * 4)
                 fail(MF_ERR_INVALID_MODEL, "invalid model: FullyConnected shapes do not agree");
-            set_shapes(po, in, out);
+            set_shapes(po, in, out, pm.u8);
             po.out_elems = (size_t)po.M * po.N;
             po.act = check_act(opt.scalar<int8_t>(0, 0)); // FullyConnectedOptions { act:0 }
             po.weights.assign((const int8_t *)w.data, (const int8_t *)w.data + (size_t)po.N * po.K);
-            po.wzp.assign(1, (int8_t)w.zp[0]);
+            po.wzp.assign(1, zp_of(w.zp[0], pm.u8));
             std::vector<int32_t> bias(po.N);
             std::memcpy(bias.data(), b.data, (size_t)po.N * 4);
             po.c0.resize(po.N), po.c1.resize(1), po.c2.resize(po.N);
-            h_preprocess_fc(in.scale[0], (int8_t)in.zp[0], in.shape[1], po.weights.data(), po.K, po.N,
-                            w.scale[0], (int8_t)w.zp[0], bias.data(), b.scale[0], (int32_t)b.zp[0],
+            h_preprocess_fc(in.scale[0], zp_of(in.zp[0], pm.u8), in.shape[1], po.weights.data(), pm.u8, po.K, po.N,
+                            w.scale[0], zp_of(w.zp[0], pm.u8), bias.data(), b.scale[0], (int32_t)b.zp[0],
                             out.scale[0], po.c0.data(), po.c1.data(), po.c2.data(), &po.c3);
             break;
         }
@@ -267,18 +273,18 @@ ParsedModel parse_tflite(const uint8_t *data, size_t len) {
         case MF_OP_DEPTHWISE_CONV_2D: { // microflow-macros/src/ops/depthwise_conv_2d.rs:62-89
             const bool dw = code == MF_OP_DEPTHWISE_CONV_2D;
             const char *nm = dw ? "DepthwiseConv2D" : "Conv2D";
-            require_i8(in, nm);
+            require_elem(in, nm, pm.u8), require_elem(out, nm, pm.u8);
             if (ins.size() < 3) fail(MF_ERR_INVALID_MODEL, std::string("invalid model: ") + nm + " needs 3 inputs");
             TensorInfo w = read_tensor(tensors, buffers, ins.get<int32_t>(1));
             TensorInfo b = read_tensor(tensors, buffers, ins.get<int32_t>(2));
             fix_rank1(b);
             need_quant(in, nm), need_quant(out, nm), need_quant(w, nm), need_quant(b, nm);
-            if (in.shape.size() != 4 || out.shape.size() != 4 || w.shape.size() != 4 || w.type != TT_INT8 ||
+            if (in.shape.size() != 4 || out.shape.size() != 4 || w.shape.size() != 4 || w.type != (pm.u8 ? TT_UINT8 : TT_INT8) ||
                 b.type != TT_INT32)
                 fail(MF_ERR_UNSUPPORTED, std::string(nm) + ": unsupported tensors");
             if (in.shape[0] != 1 || out.shape[0] != 1) // src/ops/conv_2d.rs:40,49 hard-code batch 1
                 fail(MF_ERR_UNSUPPORTED, std::string(nm) + ": tensor batch must be 1 (independent inferences are batched by the caller)");
-            set_shapes(po, in, out);
+            set_shapes(po, in, out, pm.u8);
             po.H = in.shape[1], po.W = in.shape[2], po.C = in.shape[3];
             po.KH = w.shape[1], po.KW = w.shape[2];
             po.OH = out.shape[1], po.OW = out.shape[2];
@@ -300,7 +306,7 @@ ParsedModel parse_tflite(const uint8_t *data, size_t len) {
             if (w.data_len < w.elems() || b.data_len < (size_t)po.N * 4)
                 fail(MF_ERR_INVALID_MODEL, "invalid model: short weight buffer");
             po.weights.assign((const int8_t *)w.data, (const int8_t *)w.data + w.elems());
-            for (int64_t z : w.zp) po.wzp.push_back((int8_t)z);
+            for (int64_t z : w.zp) po.wzp.push_back(zp_of(z, pm.u8));
             std::vector<int32_t> bias(po.N);
             std::memcpy(bias.data(), b.data, (size_t)po.N * 4);
             std::vector<int32_t> bzp;
@@ -312,13 +318,13 @@ ParsedModel parse_tflite(const uint8_t *data, size_t len) {
             break;
         }
         case MF_OP_AVERAGE_POOL_2D: { // microflow-macros/src/ops/average_pool_2d.rs:47-66
-            require_i8(in, "AveragePool2D");
+            require_elem(in, "AveragePool2D", pm.u8), require_elem(out, "AveragePool2D", pm.u8);
             need_quant(in, "AveragePool2D"), need_quant(out, "AveragePool2D");
             if (in.shape.size() != 4 || out.shape.size() != 4)
                 fail(MF_ERR_UNSUPPORTED, "AveragePool2D: unsupported tensors");
             if (in.shape[0] != 1 || out.shape[0] != 1)
                 fail(MF_ERR_UNSUPPORTED, "AveragePool2D: tensor batch must be 1");
-            set_shapes(po, in, out);
+            set_shapes(po, in, out, pm.u8);
             po.H = in.shape[1], po.W = in.shape[2], po.C = in.shape[3], po.N = po.C;
             po.OH = out.shape[1], po.OW = out.shape[2];
             // Pool2DOptions { padding:0 stride_w:1 stride_h:2 filter_width:3 filter_height:4 act:5 }
@@ -332,16 +338,16 @@ ParsedModel parse_tflite(const uint8_t *data, size_t len) {
                 fail(MF_ERR_INVALID_MODEL, "invalid model: bad pool geometry");
             if (out.shape[3] != po.C) fail(MF_ERR_INVALID_MODEL, "invalid model: pool channels");
             po.c0.resize(1), po.c1.resize(1);
-            h_preprocess_pool(in.scale[0], (int8_t)in.zp[0], out.scale[0], (int8_t)out.zp[0], po.c0.data(),
+            h_preprocess_pool(in.scale[0], zp_of(in.zp[0], pm.u8), out.scale[0], zp_of(out.zp[0], pm.u8), po.c0.data(),
                               po.c1.data());
             break;
         }
         case MF_OP_SOFTMAX: { // microflow-macros/src/ops/softmax.rs:20-49
-            require_i8(in, "Softmax");
+            require_elem(in, "Softmax", pm.u8), require_elem(out, "Softmax", pm.u8);
             fix_rank1(in), fix_rank1(out);
             need_quant(in, "Softmax"), need_quant(out, "Softmax");
             if (out.shape.size() != 2) fail(MF_ERR_UNSUPPORTED, "Softmax: output tensor must have rank 2");
-            set_shapes(po, in, out);
+            set_shapes(po, in, out, pm.u8);
             po.M = out.shape[0], po.N = out.shape[1];
             if (in.elems() != out.elems()) fail(MF_ERR_INVALID_MODEL, "invalid model: softmax shapes");
             break;
@@ -350,7 +356,7 @@ ParsedModel parse_tflite(const uint8_t *data, size_t len) {
             if (out.shape.size() != 2 && out.shape.size() != 4)
                 fail(MF_ERR_UNSUPPORTED, "Reshape supports only output tensor ranks 2 and 4, got rank " +
                                              std::to_string(out.shape.size()));
-            set_shapes(po, in, out);
+            set_shapes(po, in, out, pm.u8);
             if (in.elems() != out.elems()) fail(MF_ERR_INVALID_MODEL, "invalid model: reshape changes size");
             break;
         }

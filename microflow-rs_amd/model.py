@@ -37,6 +37,8 @@ class Model:
         self.output_scale, self.output_zero_point = np.float32(info.output_scale), info.output_zero_point
         self.input_elems, self.output_elems = info.input_elems, info.output_elems
         self.num_ops = info.num_ops
+        # element type T of the model's quantized tensors (i8 or u8, microflow src/quantize.rs:32-53)
+        self.dtype = np.uint8 if info.element_type == _lib.MF_ELEM_U8 else np.int8
         self._device = device
         self._prepared = False
         if max_batch:
@@ -100,6 +102,12 @@ class Model:
         if isinstance(x, torch.Tensor):
             if not x.is_cuda:
                 x = x.numpy()
+        if np_dtype != np.float32:  # quantized input: the other 1-byte integer type is a caller bug
+            got = x.dtype if isinstance(x, np.ndarray) else getattr(x, "dtype", None)
+            other = {np.int8: (np.dtype(np.uint8), torch.uint8),
+                     np.uint8: (np.dtype(np.int8), torch.int8)}[np_dtype]
+            if got is not None and got in other:
+                raise TypeError("model element type is %s, got %s" % (np.dtype(np_dtype).name, got))
         if isinstance(x, np.ndarray) or not isinstance(x, torch.Tensor):
             a = np.ascontiguousarray(x, dtype=np_dtype)
             if a.size % elems:
@@ -119,6 +127,10 @@ class Model:
         fin = (lambda: out.reshape(trailing) if single else out.reshape((batch,) + trailing))
         return xt.data_ptr(), batch, _lib.MF_MEM_DEVICE, out.data_ptr(), fin, xt
 
+    def _tdtype(self):
+        import torch
+        return torch.uint8 if self.dtype == np.uint8 else torch.int8
+
     def _ensure(self, batch):
         if not self._prepared:
             self.prepare(batch)
@@ -134,9 +146,9 @@ class Model:
         return fin()
 
     def predict_quantized(self, xq):
-        """M::predict_quantized (lib.rs:193-196).  xq: int8."""
+        """M::predict_quantized (lib.rs:193-196).  xq: the model's element type (int8 / uint8)."""
         import torch
-        p, batch, mem, o, fin, keep = self._io(xq, np.int8, self.input_elems, self.output_elems,
+        p, batch, mem, o, fin, keep = self._io(xq, self.dtype, self.input_elems, self.output_elems,
                                                torch.float32, np.float32, self.output_shape)
         self._ensure(batch)
         _lib.check(_lib.lib().mf_model_predict_quantized(self._h, p, batch, o, mem))
@@ -148,8 +160,8 @@ class Model:
     def run_quantized(self, xq):
         """predict_inner (lib.rs:198-201): int8 in, int8 out (before dequantize)."""
         import torch
-        p, batch, mem, o, fin, keep = self._io(xq, np.int8, self.input_elems, self.output_elems,
-                                               torch.int8, np.int8, self.output_shape)
+        p, batch, mem, o, fin, keep = self._io(xq, self.dtype, self.input_elems, self.output_elems,
+                                               self._tdtype(), self.dtype, self.output_shape)
         self._ensure(batch)
         _lib.check(_lib.lib().mf_model_run_quantized(self._h, p, batch, o, mem))
         return fin()
@@ -158,8 +170,8 @@ class Model:
         """int8 output of op `last_op` for the whole batch (per-layer parity localisation)."""
         import torch
         d = self.op(last_op)
-        p, batch, mem, o, fin, keep = self._io(xq, np.int8, self.input_elems, d["out_elems"],
-                                               torch.int8, np.int8, d["out_shape"])
+        p, batch, mem, o, fin, keep = self._io(xq, self.dtype, self.input_elems, d["out_elems"],
+                                               self._tdtype(), self.dtype, d["out_shape"])
         self._ensure(batch)
         _lib.check(_lib.lib().mf_model_run_until(self._h, p, batch, int(last_op), o, mem))
         return fin()

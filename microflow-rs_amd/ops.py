@@ -65,12 +65,31 @@ def _ptr(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
+def _elem(a):
+    """Element type T (src/quantize.rs:32-53) of a buffer: np.uint8 -> u8, everything else i8."""
+    dt = getattr(a, "dtype", None)
+    if dt is None:
+        return np.int8
+    try:
+        import torch
+        if dt == torch.uint8:
+            return np.uint8
+    except ImportError:
+        pass
+    return np.uint8 if dt == np.uint8 else np.int8
+
+
+def _fn(name, dtype):
+    return getattr(_lib.lib(), name + ("_u8" if dtype == np.uint8 else ""))
+
+
 class PreparedOp:
     """A prepared operator (mf_op): weights + folded constants resident in HBM."""
 
-    def __init__(self, handle, in_tail, out_tail):
+    def __init__(self, handle, in_tail, out_tail, dtype=np.int8):
         self._h = handle
         self.in_tail, self.out_tail = tuple(in_tail), tuple(out_tail)
+        self.dtype = dtype
 
     @property
     def kernel(self):
@@ -81,12 +100,17 @@ class PreparedOp:
         return self
 
     def __call__(self, x):
-        """x: numpy int8 (host) or torch int8 cuda tensor, shape [..batch] + in_tail."""
+        """x: numpy (host) or torch cuda tensor of the operator's element type (int8 / uint8),
+        shape [..batch] + in_tail."""
         torch = _torch()
         is_np = not isinstance(x, torch.Tensor)
-        xt = torch.as_tensor(np.ascontiguousarray(x, dtype=np.int8)).cuda() if is_np else x.contiguous()
-        if xt.dtype != torch.int8:
-            raise TypeError("int8 tensor expected")
+        tdt = torch.uint8 if self.dtype == np.uint8 else torch.int8
+        if is_np and isinstance(x, np.ndarray) and x.dtype.kind in "iu" and x.dtype.itemsize == 1 \
+                and x.dtype != self.dtype:
+            raise TypeError("%s tensor expected" % np.dtype(self.dtype).name)
+        xt = torch.as_tensor(np.ascontiguousarray(x, dtype=self.dtype)).cuda() if is_np else x.contiguous()
+        if xt.dtype != tdt:
+            raise TypeError("%s tensor expected" % np.dtype(self.dtype).name)
         in_elems = int(np.prod(self.in_tail))
         if xt.numel() % in_elems:
             raise ValueError("input size %d is not a multiple of %d" % (xt.numel(), in_elems))
@@ -96,7 +120,7 @@ class PreparedOp:
             lead = tuple(xt.shape[:-nt])   # [..batch dims] + operator shape
         else:
             lead = (batch,)
-        out = torch.empty(lead + self.out_tail, dtype=torch.int8, device=xt.device)
+        out = torch.empty(lead + self.out_tail, dtype=tdt, device=xt.device)
         stream = torch.cuda.current_stream(xt.device).cuda_stream
         _lib.check(_lib.lib().mf_op_run(self._h, xt.data_ptr(), batch, out.data_ptr(), stream))
         if is_np:
@@ -119,23 +143,24 @@ def _device():
 
 def prepare_fully_connected(M, weights_nk, weights_zero_point, output_scale, output_zero_point,
                             options, constants):
-    w = _host(weights_nk, np.int8)
+    dt = _elem(weights_nk)
+    w = _host(weights_nk, dt)
     N, K = w.shape
     c0, c1, c2, c3 = constants
     c0, c2 = _host(np.reshape(c0, -1), np.float32), _host(np.reshape(c2, -1), np.int32)
     h = C.c_void_p()
-    _lib.check(_lib.lib().mf_fully_connected_create(
+    _lib.check(_fn("mf_fully_connected_create", dt)(
         _device(), M, K, N, _ptr(w), int(weights_zero_point), float(output_scale),
         int(output_zero_point), int(options.fused_activation), _ptr(c0), float(c1), _ptr(c2),
         int(c3), C.byref(h)))
-    return PreparedOp(h, (M, K), (M, N))
+    return PreparedOp(h, (M, K), (M, N), dt)
 
 
 def fully_connected(input: Tensor2D, weights: Tensor2D, output_scale, output_zero_point,
                     options: FullyConnectedOptions, constants) -> Tensor2D:
     """microflow::ops::fully_connected (src/ops/fully_connected.rs:24-41).
     `weights.buffer` is K x N like the reference's Tensor2D<T, INPUT_COLS, WEIGHTS_COLS>."""
-    w_kn = np.asarray(weights.buffer, dtype=np.int8)
+    w_kn = np.asarray(weights.buffer, dtype=_elem(weights.buffer))
     M = int(input.buffer.shape[-2])
     op = prepare_fully_connected(M, w_kn.T, weights.zero_point[0], output_scale[0],
                                  output_zero_point[0], options, constants)
@@ -144,20 +169,21 @@ def fully_connected(input: Tensor2D, weights: Tensor2D, output_scale, output_zer
 
 def prepare_conv_2d(in_hwc, filters, filters_zero_point, input_zero_point, output_scale,
                     output_zero_point, options, constants, out_hw):
-    f = _host(filters, np.int8)
+    dt = _elem(filters)
+    f = _host(filters, dt)
     N, KH, KW, Cc = f.shape
     H, W, C_in = in_hwc
     if C_in != Cc:
         raise ValueError("filter channels != input channels")
-    fzp = _host(np.reshape(filters_zero_point, -1), np.int8)
+    fzp = _host(np.reshape(filters_zero_point, -1), dt)
     c0, c1 = (_host(np.reshape(c, -1), np.float32) for c in constants)
     h = C.c_void_p()
-    _lib.check(_lib.lib().mf_conv_2d_create(
+    _lib.check(_fn("mf_conv_2d_create", dt)(
         _device(), H, W, Cc, N, KH, KW, _ptr(f), _ptr(fzp), fzp.size, int(input_zero_point),
         float(output_scale), int(output_zero_point), int(options.fused_activation),
         int(options.view_padding), options.strides[0], options.strides[1], out_hw[0], out_hw[1],
         _ptr(c0), _ptr(c1), c1.size, C.byref(h)))
-    return PreparedOp(h, (H, W, Cc), (out_hw[0], out_hw[1], N))
+    return PreparedOp(h, (H, W, Cc), (out_hw[0], out_hw[1], N), dt)
 
 
 def conv_2d(input: Tensor4D, filters: Tensor4D, output_scale, output_zero_point,
@@ -171,20 +197,21 @@ def conv_2d(input: Tensor4D, filters: Tensor4D, output_scale, output_zero_point,
 
 def prepare_depthwise_conv_2d(in_hwc, weights, weights_zero_point, input_zero_point, output_scale,
                               output_zero_point, options, constants, out_hw):
-    w = _host(weights, np.int8)
+    dt = _elem(weights)
+    w = _host(weights, dt)
     if w.ndim == 4:
         w = w[0]
     KH, KW, WC = w.shape
     H, W, Cin = in_hwc
-    wzp = _host(np.reshape(weights_zero_point, -1), np.int8)
+    wzp = _host(np.reshape(weights_zero_point, -1), dt)
     c0, c1 = (_host(np.reshape(c, -1), np.float32) for c in constants)
     h = C.c_void_p()
-    _lib.check(_lib.lib().mf_depthwise_conv_2d_create(
+    _lib.check(_fn("mf_depthwise_conv_2d_create", dt)(
         _device(), H, W, Cin, KH, KW, WC, _ptr(w), _ptr(wzp), wzp.size, int(input_zero_point),
         float(output_scale), int(output_zero_point), int(options.fused_activation),
         int(options.view_padding), options.strides[0], options.strides[1], out_hw[0], out_hw[1],
         _ptr(c0), _ptr(c1), c1.size, C.byref(h)))
-    return PreparedOp(h, (H, W, Cin), (out_hw[0], out_hw[1], WC))
+    return PreparedOp(h, (H, W, Cin), (out_hw[0], out_hw[1], WC), dt)
 
 
 def depthwise_conv_2d(input: Tensor4D, weights: Tensor4D, output_scale, output_zero_point,
@@ -198,15 +225,15 @@ def depthwise_conv_2d(input: Tensor4D, weights: Tensor4D, output_scale, output_z
 
 
 def prepare_average_pool_2d(in_hwc, filter_shape, output_scale, output_zero_point, options,
-                            constants, out_hw):
+                            constants, out_hw, dtype=np.int8):
     H, W, Cc = in_hwc
     h = C.c_void_p()
-    _lib.check(_lib.lib().mf_average_pool_2d_create(
+    _lib.check(_fn("mf_average_pool_2d_create", dtype)(
         _device(), H, W, Cc, filter_shape[0], filter_shape[1], float(output_scale),
         int(output_zero_point), int(options.fused_activation), int(options.view_padding),
         options.strides[0], options.strides[1], out_hw[0], out_hw[1], float(constants[0]),
         float(constants[1]), C.byref(h)))
-    return PreparedOp(h, (H, W, Cc), (out_hw[0], out_hw[1], Cc))
+    return PreparedOp(h, (H, W, Cc), (out_hw[0], out_hw[1], Cc), dtype)
 
 
 def average_pool_2d(input: Tensor4D, filter_shape, output_scale, output_zero_point,
@@ -214,22 +241,23 @@ def average_pool_2d(input: Tensor4D, filter_shape, output_scale, output_zero_poi
     """microflow::ops::average_pool_2d (src/ops/average_pool_2d.rs:29-45)."""
     shp = tuple(input.buffer.shape)
     op = prepare_average_pool_2d(shp[-3:], filter_shape, output_scale[0], output_zero_point[0],
-                                 options, constants, output_shape)
+                                 options, constants, output_shape, dtype=_elem(input.buffer))
     return Tensor4D(op(input.buffer), list(output_scale), list(output_zero_point))
 
 
-def prepare_softmax(rows, cols, input_scale, output_scale, output_zero_point):
+def prepare_softmax(rows, cols, input_scale, output_scale, output_zero_point, dtype=np.int8):
     h = C.c_void_p()
-    _lib.check(_lib.lib().mf_softmax_create(_device(), rows, cols, float(input_scale),
-                                            float(output_scale), int(output_zero_point),
-                                            C.byref(h)))
-    return PreparedOp(h, (rows, cols), (rows, cols))
+    _lib.check(_fn("mf_softmax_create", dtype)(_device(), rows, cols, float(input_scale),
+                                               float(output_scale), int(output_zero_point),
+                                               C.byref(h)))
+    return PreparedOp(h, (rows, cols), (rows, cols), dtype)
 
 
 def softmax(input: Tensor2D, output_scale, output_zero_point) -> Tensor2D:
     """microflow::ops::softmax (src/ops/softmax.rs:15-19)."""
     rows, cols = input.buffer.shape[-2:]
-    op = prepare_softmax(int(rows), int(cols), input.scale[0], output_scale[0], output_zero_point[0])
+    op = prepare_softmax(int(rows), int(cols), input.scale[0], output_scale[0], output_zero_point[0],
+                         dtype=_elem(input.buffer))
     return Tensor2D(op(input.buffer), list(output_scale), list(output_zero_point))
 
 
@@ -241,13 +269,13 @@ def reshape(input, output_shape):
     return cls(buf, list(input.scale), list(input.zero_point))
 
 
-def quantize(x, scale, zero_point):
-    """Tensor{2D,4D}::quantize (src/tensor.rs:80-86,246-256) on the device."""
+def quantize(x, scale, zero_point, dtype=np.int8):
+    """Tensor{2D,4D}::quantize (src/tensor.rs:80-86,246-256) on the device; dtype = T."""
     torch = _torch()
     is_np = not isinstance(x, torch.Tensor)
     xt = torch.as_tensor(np.ascontiguousarray(x, dtype=np.float32)).cuda() if is_np else x.contiguous()
-    out = torch.empty(xt.shape, dtype=torch.int8, device=xt.device)
-    _lib.check(_lib.lib().mf_quantize(xt.device.index or 0, xt.data_ptr(), xt.numel(), float(scale),
+    out = torch.empty(xt.shape, dtype=torch.uint8 if dtype == np.uint8 else torch.int8, device=xt.device)
+    _lib.check(_fn("mf_quantize", dtype)(xt.device.index or 0, xt.data_ptr(), xt.numel(), float(scale),
                                       int(zero_point), out.data_ptr(),
                                       torch.cuda.current_stream(xt.device).cuda_stream))
     return out.cpu().numpy() if is_np else out
@@ -257,9 +285,10 @@ def dequantize(q, scale, zero_point):
     """Tensor{2D,4D}::dequantize (src/tensor.rs:89-92,259-262) on the device."""
     torch = _torch()
     is_np = not isinstance(q, torch.Tensor)
-    qt = torch.as_tensor(np.ascontiguousarray(q, dtype=np.int8)).cuda() if is_np else q.contiguous()
+    dt = _elem(q)
+    qt = torch.as_tensor(np.ascontiguousarray(q, dtype=dt)).cuda() if is_np else q.contiguous()
     out = torch.empty(qt.shape, dtype=torch.float32, device=qt.device)
-    _lib.check(_lib.lib().mf_dequantize(qt.device.index or 0, qt.data_ptr(), qt.numel(),
+    _lib.check(_fn("mf_dequantize", dt)(qt.device.index or 0, qt.data_ptr(), qt.numel(),
                                         float(scale), int(zero_point), out.data_ptr(),
                                         torch.cuda.current_stream(qt.device).cuda_stream))
     return out.cpu().numpy() if is_np else out

@@ -93,296 +93,36 @@ float orc_expf(float x) {
     return scalbnf(y, k);
 }
 
-/* simba `to_subset_unchecked` / `from_superset_unchecked` for f32 -> i8 are
- * Rust `as` casts: truncate toward zero, saturate, NaN -> 0.
- * Call sites: src/quantize.rs:17, src/ops/fully_connected.rs:68, conv_2d.rs:93,
- * depthwise_conv_2d.rs:90, average_pool_2d.rs:56. */
-int8_t orc_sat_i8(float x) {
-    if (x != x) return 0;
-    if (x <= -128.0f) return -128;
-    if (x >= 127.0f) return 127;
-    return (int8_t)(int)x;
-}
-
-/* src/quantize.rs:16-18 : roundf(input / scale + f32(zero_point)) as T */
-int8_t orc_quantize(float x, float scale, int8_t zp) {
-    float q = x / scale;
-    q = q + (float)zp;
-    return orc_sat_i8(orc_roundf(q));
-}
-
-/* src/quantize.rs:27-29 : scale * (f32(input) - f32(zero_point)) */
-float orc_dequantize(int8_t q, float scale, int8_t zp) {
-    float d = (float)q - (float)zp;
-    return scale * d;
-}
-
-/* src/activation.rs:21-23 */
-int8_t orc_relu(int8_t x, int8_t zp) { return x > zp ? x : zp; }
-
-/* src/activation.rs:32-34 : min(relu(x), quantize(6.0, scale, zp)) */
-int8_t orc_relu6(int8_t x, float scale, int8_t zp) {
-    int8_t r = orc_relu(x, zp);
-    int8_t six = orc_quantize(6.0f, scale, zp);
-    return r < six ? r : six;
-}
-
-/* src/activation.rs:44-46 : quantize(expf(input) / sum, scale, zp) */
-int8_t orc_softmax_scalar(float x, float sum, float scale, int8_t zp) {
-    float e = orc_expf(x);
-    float p = e / sum;
-    return orc_quantize(p, scale, zp);
-}
-
-static inline int8_t apply_act(int8_t y, int act, float oscale, int8_t ozp) {
-    /* match in every op epilogue, e.g. src/ops/conv_2d.rs:100-104 */
-    switch (act) {
-        case ORC_ACT_RELU: return orc_relu(y, ozp);
-        case ORC_ACT_RELU6: return orc_relu6(y, oscale, ozp);
-        default: return y;
-    }
-}
-
 /* wrapping i32 arithmetic (Rust release semantics) */
 static inline int32_t wadd(int32_t a, int32_t b) { return (int32_t)((uint32_t)a + (uint32_t)b); }
 static inline int32_t wsub(int32_t a, int32_t b) { return (int32_t)((uint32_t)a - (uint32_t)b); }
 static inline int32_t wmul(int32_t a, int32_t b) { return (int32_t)((uint32_t)a * (uint32_t)b); }
 
-/* ======================================================================= */
-/* view extraction: src/tensor.rs:180-228                                   */
-/* ======================================================================= */
-int orc_view(const int8_t *in, int H, int W, int C, int fi, int fj, int KH, int KW, int pad,
-             int sh, int sw, int8_t *buf, uint8_t *mask) {
-    int len = KH * KW; /* tensor.rs:187 */
-    for (int m = 0; m < KH; ++m) {
-        for (int n = 0; n < KW; ++n) {
-            int8_t *dst = buf + ((size_t)m * KW + n) * C;
-            mask[m * KW + n] = 1;
-            if (pad == ORC_PAD_SAME) {
-                /* tensor.rs:193 : shift = ((ROWS-1)/2, (COLS-1)/2), independent of stride */
-                int shift_r = (KH - 1) / 2, shift_c = (KW - 1) / 2;
-                int r = sh * fi + m - shift_r; /* checked_sub -> negative means out */
-                int c = sw * fj + n - shift_c;
-                if (r < 0 || c < 0 || r >= H || c >= W) { /* tensor.rs:196-219 */
-                    len -= 1;
-                    mask[m * KW + n] = 0;
-                    memset(dst, 0, (size_t)C);
-                } else {
-                    memcpy(dst, in + ((size_t)r * W + c) * C, (size_t)C);
-                }
-            } else { /* tensor.rs:221-224 : direct index, must be in range */
-                int r = sh * fi + m, c = sw * fj + n;
-                if (r >= H || c >= W) return -1;
-                memcpy(dst, in + ((size_t)r * W + c) * C, (size_t)C);
-            }
-        }
-    }
-    return len;
-}
 
-/* ======================================================================= */
-/* operators                                                                */
-/* ======================================================================= */
-
-/* src/ops/fully_connected.rs:42-81 */
-void orc_fully_connected(const int8_t *in, int M, int K, const int8_t *w, int N, int8_t wzp,
-                         float oscale, int8_t ozp, int act, const float *c0, float c1,
-                         const int32_t *c2, int32_t c3, int8_t *out) {
-    for (int i = 0; i < M; ++i) {
-        /* :60-64 row-sum of the input times the weights zero point */
-        int32_t rs = 0;
-        for (int k = 0; k < K; ++k) rs = wadd(rs, (int32_t)in[(size_t)i * K + k]);
-        int32_t x1 = wmul(rs, (int32_t)wzp);
-        for (int j = 0; j < N; ++j) {
-            /* :47-57 dot product of input row i and weights column j */
-            int32_t x0 = 0;
-            for (int k = 0; k < K; ++k)
-                x0 = wadd(x0, wmul((int32_t)in[(size_t)i * K + k], (int32_t)w[(size_t)j * K + k]));
-            /* :67-72 */
-            int32_t acc = wadd(wsub(wsub(x0, x1), c2[j]), c3);
-            float a = (float)ozp + c0[j];
-            float b = c1 * (float)acc;
-            int8_t y = orc_sat_i8(orc_roundf(a + b));
-            out[(size_t)i * N + j] = apply_act(y, act, oscale, ozp);
-        }
-    }
-}
-
-/* src/ops/conv_2d.rs:50-107 */
-int orc_conv_2d(const int8_t *in, int H, int W, int C, const int8_t *f, int N, int KH, int KW,
-                const int8_t *fzp, int nq, int8_t izp8, float oscale, int8_t ozp, int act, int pad,
-                int sh, int sw, int OH, int OW, const float *c0, const float *c1, int nc1,
-                int8_t *out) {
-    size_t taps = (size_t)KH * KW;
-    int8_t *vbuf = (int8_t *)malloc(taps * C);
-    uint8_t *mask = (uint8_t *)malloc(taps);
-    if (!vbuf || !mask) {
-        free(vbuf);
-        free(mask);
-        return -1;
-    }
-    int rc = 0;
-    for (int i = 0; i < OH && rc == 0; ++i) {
-        for (int j = 0; j < OW; ++j) {
-            int len = orc_view(in, H, W, C, i, j, KH, KW, pad, sh, sw, vbuf, mask); /* :52-53 */
-            if (len < 0) {
-                rc = -1;
-                break;
-            }
-            for (int b = 0; b < N; ++b) { /* :55 */
-                int32_t izp = (int32_t)izp8;
-                int32_t fz = (int32_t)(b < nq ? fzp[b] : fzp[0]); /* :57-63 */
-                const int8_t *fb = f + (size_t)b * taps * C;
-                int32_t x0 = 0, vs = 0, ms = 0;
-                for (size_t t = 0; t < taps; ++t) /* :66-72 */
-                    for (int c = 0; c < C; ++c)
-                        x0 = wadd(x0, wmul((int32_t)vbuf[t * C + c], (int32_t)fb[t * C + c]));
-                for (size_t t = 0; t < taps; ++t) /* :74-76 */
-                    for (int c = 0; c < C; ++c) vs = wadd(vs, (int32_t)vbuf[t * C + c]);
-                int32_t x1 = wmul(vs, fz);
-                for (size_t t = 0; t < taps; ++t) /* :82-89 */
-                    if (mask[t])
-                        for (int c = 0; c < C; ++c) ms = wadd(ms, (int32_t)fb[t * C + c]);
-                int32_t k2 = wmul(izp, ms);
-                int32_t k3 = wmul(wmul(wmul((int32_t)len, (int32_t)C), izp), fz); /* :90 */
-                int32_t acc = wadd(wsub(wsub(x0, x1), k2), k3);
-                float c1b = b < nc1 ? c1[b] : c1[0]; /* :96 */
-                float a = (float)ozp + c0[b];
-                float bb = c1b * (float)acc;
-                int8_t y = orc_sat_i8(orc_roundf(a + bb)); /* :93-98 */
-                out[((size_t)i * OW + j) * N + b] = apply_act(y, act, oscale, ozp);
-            }
-        }
-    }
-    free(vbuf);
-    free(mask);
-    return rc;
-}
-
-/* src/ops/depthwise_conv_2d.rs:50-104 */
-int orc_depthwise_conv_2d(const int8_t *in, int H, int W, int Cin, const int8_t *w, int KH, int KW,
-                          int WC, const int8_t *wzp, int nq, int8_t izp8, float oscale, int8_t ozp,
-                          int act, int pad, int sh, int sw, int OH, int OW, const float *c0,
-                          const float *c1, int nc1, int8_t *out) {
-    size_t taps = (size_t)KH * KW;
-    int8_t *vbuf = (int8_t *)malloc(taps * Cin);
-    uint8_t *mask = (uint8_t *)malloc(taps);
-    if (!vbuf || !mask) {
-        free(vbuf);
-        free(mask);
-        return -1;
-    }
-    int rc = 0;
-    for (int i = 0; i < OH && rc == 0; ++i) {
-        for (int j = 0; j < OW; ++j) {
-            int len = orc_view(in, H, W, Cin, i, j, KH, KW, pad, sh, sw, vbuf, mask); /* :52-53 */
-            if (len < 0) {
-                rc = -1;
-                break;
-            }
-            for (int c = 0; c < WC; ++c) { /* :55 */
-                int32_t izp = (int32_t)izp8;
-                int32_t wz = (int32_t)(c < nq ? wzp[c] : wzp[0]); /* :57-63 */
-                int ci = c < Cin ? c : 0; /* v.get(c).copied().unwrap_or(v[0])  :67,72 */
-                int32_t x0 = 0, vs = 0, ms = 0;
-                for (size_t t = 0; t < taps; ++t) /* :66-69 */
-                    x0 = wadd(x0, wmul((int32_t)vbuf[t * Cin + ci], (int32_t)w[t * WC + c]));
-                for (size_t t = 0; t < taps; ++t) /* :71-73 */
-                    vs = wadd(vs, (int32_t)vbuf[t * Cin + ci]);
-                int32_t x1 = wmul(vs, wz);
-                for (size_t t = 0; t < taps; ++t) /* :79-86 */
-                    if (mask[t]) ms = wadd(ms, (int32_t)w[t * WC + c]);
-                int32_t k2 = wmul(izp, ms);
-                int32_t k3 = wmul(wmul((int32_t)len, izp), wz); /* :87 */
-                int32_t acc = wadd(wsub(wsub(x0, x1), k2), k3);
-                float c1c = c < nc1 ? c1[c] : c1[0]; /* :93 */
-                float a = (float)ozp + c0[c];
-                float bb = c1c * (float)acc;
-                int8_t y = orc_sat_i8(orc_roundf(a + bb)); /* :90-95 */
-                out[((size_t)i * OW + j) * WC + c] = apply_act(y, act, oscale, ozp);
-            }
-        }
-    }
-    free(vbuf);
-    free(mask);
-    return rc;
-}
-
-/* src/ops/average_pool_2d.rs:46-65 */
-int orc_average_pool_2d(const int8_t *in, int H, int W, int C, int FH, int FW, float oscale,
-                        int8_t ozp, int act, int pad, int sh, int sw, int OH, int OW, float c0,
-                        float c1, int8_t *out) {
-    size_t taps = (size_t)FH * FW;
-    int8_t *vbuf = (int8_t *)malloc(taps * C);
-    uint8_t *mask = (uint8_t *)malloc(taps);
-    if (!vbuf || !mask) {
-        free(vbuf);
-        free(mask);
-        return -1;
-    }
-    int rc = 0;
-    for (int i = 0; i < OH && rc == 0; ++i) {
-        for (int j = 0; j < OW; ++j) {
-            int len = orc_view(in, H, W, C, i, j, FH, FW, pad, sh, sw, vbuf, mask); /* :48-49 */
-            if (len < 0) {
-                rc = -1;
-                break;
-            }
-            for (int c = 0; c < C; ++c) { /* :51 */
-                int32_t s = 0;
-                for (size_t t = 0; t < taps; ++t) s = wadd(s, (int32_t)vbuf[t * C + c]);
-                float inv = 1.0f / (float)len; /* :52 : 1. / len as f32 * (sum as f32) */
-                float x = inv * (float)s;
-                float y = c0 * x;
-                y = y + c1; /* :56 */
-                int8_t q = orc_sat_i8(orc_roundf(y));
-                out[((size_t)i * OW + j) * C + c] = apply_act(q, act, oscale, ozp);
-            }
-        }
-    }
-    free(vbuf);
-    free(mask);
-    return rc;
-}
-
-/* src/ops/softmax.rs:20-27 */
-void orc_softmax(const int8_t *in, int rows, int cols, float iscale, float oscale, int8_t ozp,
-                 int8_t *out) {
-    /* :20  exp = f32(q) * input.scale[0]  (no zero-point subtraction)
-     * :21  sum = exp.map(expf).sum()  -- nalgebra iterates column-major */
-    float sum = 0.0f;
-    for (int j = 0; j < cols; ++j)
-        for (int i = 0; i < rows; ++i) {
-            float e = (float)in[(size_t)i * cols + j] * iscale;
-            sum = sum + orc_expf(e);
-        }
-    for (int i = 0; i < rows; ++i)
-        for (int j = 0; j < cols; ++j) {
-            float e = (float)in[(size_t)i * cols + j] * iscale;
-            out[(size_t)i * cols + j] = orc_softmax_scalar(e, sum, oscale, ozp);
-        }
-}
+/* element-type generic scalar primitives, view extraction and operators */
+#define ELEM int8_t
+#define ELEM_MIN (-128)
+#define ELEM_MAX 127
+#define FN(n) n
+#include "mf_oracle_ops.inc"
+#undef ELEM
+#undef ELEM_MIN
+#undef ELEM_MAX
+#undef FN
+int8_t orc_sat_i8(float x) { return orc_sat(x); }
+#define ELEM uint8_t
+#define ELEM_MIN 0
+#define ELEM_MAX 255
+#define FN(n) n##_u8
+#include "mf_oracle_ops.inc"
+#undef ELEM
+#undef ELEM_MIN
+#undef ELEM_MAX
+#undef FN
 
 /* ======================================================================= */
 /* constant preparation                                                     */
 /* ======================================================================= */
-
-/* microflow-macros/src/ops/fully_connected.rs:100-123 */
-void orc_preprocess_fully_connected(float iscale, int8_t izp, int in_shape1, const int8_t *w,
-                                    int K, int N, float wscale, int8_t wzp, const int32_t *bias,
-                                    float bscale, int32_t bzp, float oscale, float *c0, float *c1,
-                                    int32_t *c2, int32_t *c3) {
-    float r = bscale / oscale; /* :108 biases.scale[0] / output.scale[0] * (...) */
-    for (int j = 0; j < N; ++j) c0[j] = r * (float)wsub(bias[j], bzp);
-    float p = iscale * wscale; /* :114 */
-    *c1 = p / oscale;
-    for (int j = 0; j < N; ++j) { /* :115-118 row_sum of the K x N matrix times izp */
-        int32_t s = 0;
-        for (int k = 0; k < K; ++k) s = wadd(s, (int32_t)w[(size_t)j * K + k]);
-        c2[j] = wmul(s, (int32_t)izp);
-    }
-    *c3 = wmul(wmul((int32_t)in_shape1, (int32_t)izp), (int32_t)wzp); /* :119-121 */
-}
 
 /* microflow-macros/src/ops/conv_2d.rs:100-113 and depthwise_conv_2d.rs:106-119 */
 void orc_preprocess_conv(float iscale, int n, const int32_t *bias, const float *bscale,
@@ -401,12 +141,15 @@ void orc_preprocess_conv(float iscale, int n, const int32_t *bias, const float *
 }
 
 /* microflow-macros/src/ops/average_pool_2d.rs:77-83 */
-void orc_preprocess_average_pool_2d(float iscale, int8_t izp, float oscale, int8_t ozp, float *c0,
-                                    float *c1) {
+static void preprocess_pool_int(float iscale, int izp, float oscale, int ozp, float *c0, float *c1) {
     *c0 = iscale / oscale;
     float p = iscale * (float)izp;
     float q = p / oscale;
     *c1 = (float)ozp - q;
+}
+void orc_preprocess_average_pool_2d(float iscale, int8_t izp, float oscale, int8_t ozp, float *c0,
+                                    float *c1) {
+    preprocess_pool_int(iscale, izp, oscale, ozp, c0, c1);
 }
 
 /* ======================================================================= */
@@ -493,6 +236,7 @@ typedef struct {
 } op_t;
 
 struct orc_model {
+    int is_u8; /* element type of every activation/weight tensor: 0 = INT8, 1 = UINT8 */
     int nops;
     op_t *ops;
     int in_shape[4], in_rank, out_shape[4], out_rank;
@@ -500,6 +244,9 @@ struct orc_model {
     int in_zp, out_zp;
     size_t in_elems, out_elems, max_elems, layers_elems;
 };
+
+/* zero points are i64 in the file, cast to T (microflow-macros/src/tensor.rs:81-88) */
+static int zp_of(int64_t z, int is_u8) { return is_u8 ? (int)(uint8_t)z : (int)(int8_t)z; }
 
 static size_t prod(const int *s, int r) {
     size_t p = 1;
@@ -580,7 +327,7 @@ void orc_model_free(orc_model *m) {
         goto fail;           \
     } while (0)
 
-static void fill_info_shapes(op_t *o, const tens_t *in, const tens_t *out) {
+static void fill_info_shapes(op_t *o, const tens_t *in, const tens_t *out, int is_u8) {
     o->info.in_rank = in->rank;
     o->info.out_rank = out->rank;
     for (int i = 0; i < 4; ++i) {
@@ -588,9 +335,9 @@ static void fill_info_shapes(op_t *o, const tens_t *in, const tens_t *out) {
         o->info.out_shape[i] = i < out->rank ? out->shape[i] : 0;
     }
     o->info.in_scale = in->nscale ? in->scale[0] : 0.0f;
-    o->info.in_zp = in->nzp ? (int)(int8_t)in->zp[0] : 0;
+    o->info.in_zp = in->nzp ? zp_of(in->zp[0], is_u8) : 0;
     o->info.out_scale = out->nscale ? out->scale[0] : 0.0f;
-    o->info.out_zp = out->nzp ? (int)(int8_t)out->zp[0] : 0;
+    o->info.out_zp = out->nzp ? zp_of(out->zp[0], is_u8) : 0;
     o->info.out_elems = prod(out->shape, out->rank);
 }
 
@@ -616,14 +363,15 @@ orc_model *orc_model_load(const uint8_t *buf, size_t len, const char **err) {
     /* model input: lib.rs:66-126 */
     if (read_tensor(b, tensors, buffers, (int32_t)rd32(b, sin + 4), &tin)) FAIL("invalid model");
     rank1_fix(&tin);
-    if (tin.type == 3) FAIL("unsupported input tensor type UINT8 (oracle restates the i8 path)");
-    if (tin.type != 9) FAIL("unsupported input tensor type");
+    if (tin.type != 9 && tin.type != 3) FAIL("unsupported input tensor type");
+    m->is_u8 = tin.type == 3;
+    const int ET = tin.type; /* every quantized tensor of the model must have this type */
     if (tin.rank != 2 && tin.rank != 4) FAIL("unsupported input tensor rank");
     if (!tin.nscale || !tin.nzp) FAIL("invalid model");
     m->in_rank = tin.rank;
     memcpy(m->in_shape, tin.shape, sizeof(m->in_shape));
     m->in_scale = tin.scale[0];
-    m->in_zp = (int8_t)tin.zp[0];
+    m->in_zp = zp_of(tin.zp[0], m->is_u8);
     m->in_elems = prod(tin.shape, tin.rank);
     tens_free(&tin);
     memset(&tin, 0, sizeof(tin));
@@ -631,13 +379,13 @@ orc_model *orc_model_load(const uint8_t *buf, size_t len, const char **err) {
     /* model output: lib.rs:153-183 */
     if (read_tensor(b, tensors, buffers, (int32_t)rd32(b, sout + 4), &tout)) FAIL("invalid model");
     rank1_fix(&tout);
-    if (tout.type != 9) FAIL("unsupported output tensor type");
+    if (tout.type != ET) FAIL("unsupported output tensor type");
     if (tout.rank != 2 && tout.rank != 4) FAIL("unsupported output tensor rank");
     if (!tout.nscale || !tout.nzp) FAIL("invalid model");
     m->out_rank = tout.rank;
     memcpy(m->out_shape, tout.shape, sizeof(m->out_shape));
     m->out_scale = tout.scale[0];
-    m->out_zp = (int8_t)tout.zp[0];
+    m->out_zp = zp_of(tout.zp[0], m->is_u8);
     m->out_elems = prod(tout.shape, tout.rank);
     tens_free(&tout);
     memset(&tout, 0, sizeof(tout));
@@ -663,9 +411,9 @@ orc_model *orc_model_load(const uint8_t *buf, size_t len, const char **err) {
         o->info.kind = code;
         if (read_tensor(b, tensors, buffers, i0, &tin) || read_tensor(b, tensors, buffers, o0, &tout))
             FAIL("invalid model");
-        if (code != ORC_OP_RESHAPE && (tin.type != 9 || !tin.nscale || !tin.nzp || !tout.nscale ||
-                                       !tout.nzp))
-            FAIL("operator supports only INT8 tensors in the oracle");
+        if (code != ORC_OP_RESHAPE && (tin.type != ET || tout.type != ET || !tin.nscale || !tin.nzp ||
+                                       !tout.nscale || !tout.nzp))
+            FAIL("operator tensors must all have the model's element type (INT8 or UINT8)");
 
         if (code == ORC_OP_FULLY_CONNECTED) {
             /* microflow-macros/src/ops/fully_connected.rs:66-98 */
@@ -677,12 +425,12 @@ orc_model *orc_model_load(const uint8_t *buf, size_t len, const char **err) {
             rank1_fix(&tout);
             rank1_fix(&tw);
             rank1_fix(&tb);
-            if (tw.rank != 2 || tw.type != 9 || tb.type != 2 || !tw.nscale || !tw.nzp ||
+            if (tw.rank != 2 || tw.type != ET || tb.type != 2 || !tw.nscale || !tw.nzp ||
                 !tb.nscale || !tb.nzp)
                 FAIL("invalid fully_connected tensors");
             int N = tw.shape[0], K = tw.shape[1];
             if (tw.data_len < (size_t)N * K || tb.data_len < (size_t)N * 4) FAIL("invalid model");
-            fill_info_shapes(o, &tin, &tout);
+            fill_info_shapes(o, &tin, &tout, m->is_u8);
             o->M = tin.shape[0];
             o->K = K;
             o->N = N;
@@ -701,10 +449,16 @@ orc_model *orc_model_load(const uint8_t *buf, size_t len, const char **err) {
             o->c2 = (int32_t *)malloc(sizeof(int32_t) * (size_t)N);
             o->info.n_c0 = N;
             o->info.n_c1 = 1;
-            orc_preprocess_fully_connected(tin.scale[0], (int8_t)tin.zp[0], tin.shape[1], o->weights,
-                                           K, N, tw.scale[0], (int8_t)tw.zp[0], bias, tb.scale[0],
-                                           (int32_t)tb.zp[0], tout.scale[0], o->c0, o->c1, o->c2,
-                                           &o->c3);
+            if (m->is_u8)
+                orc_preprocess_fully_connected_u8(tin.scale[0], (uint8_t)tin.zp[0], tin.shape[1],
+                                                  (const uint8_t *)o->weights, K, N, tw.scale[0],
+                                                  (uint8_t)tw.zp[0], bias, tb.scale[0], (int32_t)tb.zp[0],
+                                                  tout.scale[0], o->c0, o->c1, o->c2, &o->c3);
+            else
+                orc_preprocess_fully_connected(tin.scale[0], (int8_t)tin.zp[0], tin.shape[1], o->weights,
+                                               K, N, tw.scale[0], (int8_t)tw.zp[0], bias, tb.scale[0],
+                                               (int32_t)tb.zp[0], tout.scale[0], o->c0, o->c1, o->c2,
+                                               &o->c3);
             free(bias);
         } else if (code == ORC_OP_CONV_2D || code == ORC_OP_DEPTHWISE_CONV_2D) {
             /* microflow-macros/src/ops/conv_2d.rs:58-83, depthwise_conv_2d.rs:62-89 */
@@ -713,11 +467,11 @@ orc_model *orc_model_load(const uint8_t *buf, size_t len, const char **err) {
                 read_tensor(b, tensors, buffers, (int32_t)rd32(b, oin + 12), &tb))
                 FAIL("invalid model");
             rank1_fix(&tb);
-            if (tin.rank != 4 || tout.rank != 4 || tw.rank != 4 || tw.type != 9 || tb.type != 2 ||
+            if (tin.rank != 4 || tout.rank != 4 || tw.rank != 4 || tw.type != ET || tb.type != 2 ||
                 !tw.nscale || !tw.nzp || !tb.nscale || !tb.nzp)
                 FAIL("invalid conv tensors");
             if (tin.shape[0] != 1) FAIL("conv path has batch 1 only (src/ops/conv_2d.rs:40)");
-            fill_info_shapes(o, &tin, &tout);
+            fill_info_shapes(o, &tin, &tout, m->is_u8);
             o->H = tin.shape[1];
             o->W = tin.shape[2];
             o->C = tin.shape[3];
@@ -766,7 +520,7 @@ orc_model *orc_model_load(const uint8_t *buf, size_t len, const char **err) {
             /* microflow-macros/src/ops/average_pool_2d.rs:47-66 */
             if (tin.rank != 4 || tout.rank != 4) FAIL("invalid pool tensors");
             if (tin.shape[0] != 1) FAIL("pool path has batch 1 only");
-            fill_info_shapes(o, &tin, &tout);
+            fill_info_shapes(o, &tin, &tout, m->is_u8);
             o->H = tin.shape[1];
             o->W = tin.shape[2];
             o->C = tin.shape[3];
@@ -779,8 +533,8 @@ orc_model *orc_model_load(const uint8_t *buf, size_t len, const char **err) {
             o->info.KW = fld_i32(b, opt, 3, 0);
             o->info.KH = fld_i32(b, opt, 4, 0);
             o->info.act = fld_i8(b, opt, 5, 0);
-            orc_preprocess_average_pool_2d(tin.scale[0], (int8_t)tin.zp[0], tout.scale[0],
-                                           (int8_t)tout.zp[0], &o->pool_c0, &o->pool_c1);
+            preprocess_pool_int(tin.scale[0], zp_of(tin.zp[0], m->is_u8), tout.scale[0],
+                                zp_of(tout.zp[0], m->is_u8), &o->pool_c0, &o->pool_c1);
             o->info.n_c0 = 1;
             o->info.n_c1 = 1;
         } else if (code == ORC_OP_SOFTMAX) {
@@ -788,13 +542,13 @@ orc_model *orc_model_load(const uint8_t *buf, size_t len, const char **err) {
             rank1_fix(&tin);
             rank1_fix(&tout);
             if (tout.rank != 2) FAIL("softmax output must be rank 2");
-            fill_info_shapes(o, &tin, &tout);
+            fill_info_shapes(o, &tin, &tout, m->is_u8);
             o->M = tout.shape[0];
             o->N = tout.shape[1];
         } else if (code == ORC_OP_RESHAPE) {
             /* microflow-macros/src/ops/reshape.rs:33-42 */
             if (tout.rank != 2 && tout.rank != 4) FAIL("Reshape supports only output ranks 2 and 4");
-            fill_info_shapes(o, &tin, &tout);
+            fill_info_shapes(o, &tin, &tout, m->is_u8);
         } else {
             FAIL("unsupported operator"); /* lib.rs:148 */
         }
@@ -841,6 +595,7 @@ int orc_model_op_constants(const orc_model *m, int i, float *c0, float *c1, int3
     if (c3) *c3 = o->c3;
     return 0;
 }
+int orc_model_is_u8(const orc_model *m) { return m->is_u8; }
 size_t orc_model_input_elems(const orc_model *m) { return m->in_elems; }
 size_t orc_model_output_elems(const orc_model *m) { return m->out_elems; }
 size_t orc_model_layers_elems(const orc_model *m) { return m->layers_elems; }
@@ -871,35 +626,65 @@ int orc_model_run_quantized(const orc_model *m, const int8_t *in_q, int8_t *out_
     memcpy(a, in_q, m->in_elems);
     size_t cur_elems = m->in_elems;
     float cur_scale = m->in_scale; /* running tensor's scale[0] */
-    int8_t cur_zp = (int8_t)m->in_zp;
+    int cur_zp = m->in_zp;
     int rc = 0;
     size_t loff = 0;
+    const int U = m->is_u8;
+    const uint8_t *ua;
+    uint8_t *ub;
     for (int i = 0; i < m->nops && rc == 0; ++i) {
         const op_t *o = &m->ops[i];
         const orc_op_info *f = &o->info;
+        ua = (const uint8_t *)a;
+        ub = (uint8_t *)bb;
+        const uint8_t *uw = (const uint8_t *)o->weights, *uz = (const uint8_t *)o->wzp;
         switch (f->kind) {
             case ORC_OP_FULLY_CONNECTED:
-                orc_fully_connected(a, o->M, o->K, o->weights, o->N, o->wzp[0], f->out_scale,
-                                    (int8_t)f->out_zp, f->act, o->c0, o->c1[0], o->c2, o->c3, bb);
+                if (U)
+                    orc_fully_connected_u8(ua, o->M, o->K, uw, o->N, uz[0], f->out_scale,
+                                           (uint8_t)f->out_zp, f->act, o->c0, o->c1[0], o->c2, o->c3,
+                                           ub);
+                else
+                    orc_fully_connected(a, o->M, o->K, o->weights, o->N, o->wzp[0], f->out_scale,
+                                        (int8_t)f->out_zp, f->act, o->c0, o->c1[0], o->c2, o->c3, bb);
                 break;
             case ORC_OP_CONV_2D:
-                rc = orc_conv_2d(a, o->H, o->W, o->C, o->weights, o->N, f->KH, f->KW, o->wzp, o->nq,
-                                 cur_zp, f->out_scale, (int8_t)f->out_zp, f->act, f->pad, f->sh,
-                                 f->sw, o->OH, o->OW, o->c0, o->c1, f->n_c1, bb);
+                if (U)
+                    rc = orc_conv_2d_u8(ua, o->H, o->W, o->C, uw, o->N, f->KH, f->KW, uz, o->nq,
+                                        (uint8_t)cur_zp, f->out_scale, (uint8_t)f->out_zp, f->act,
+                                        f->pad, f->sh, f->sw, o->OH, o->OW, o->c0, o->c1, f->n_c1, ub);
+                else
+                    rc = orc_conv_2d(a, o->H, o->W, o->C, o->weights, o->N, f->KH, f->KW, o->wzp,
+                                     o->nq, (int8_t)cur_zp, f->out_scale, (int8_t)f->out_zp, f->act,
+                                     f->pad, f->sh, f->sw, o->OH, o->OW, o->c0, o->c1, f->n_c1, bb);
                 break;
             case ORC_OP_DEPTHWISE_CONV_2D:
-                rc = orc_depthwise_conv_2d(a, o->H, o->W, o->C, o->weights, f->KH, f->KW, o->WC,
-                                           o->wzp, o->nq, cur_zp, f->out_scale, (int8_t)f->out_zp,
-                                           f->act, f->pad, f->sh, f->sw, o->OH, o->OW, o->c0, o->c1,
-                                           f->n_c1, bb);
+                if (U)
+                    rc = orc_depthwise_conv_2d_u8(ua, o->H, o->W, o->C, uw, f->KH, f->KW, o->WC, uz,
+                                                  o->nq, (uint8_t)cur_zp, f->out_scale,
+                                                  (uint8_t)f->out_zp, f->act, f->pad, f->sh, f->sw,
+                                                  o->OH, o->OW, o->c0, o->c1, f->n_c1, ub);
+                else
+                    rc = orc_depthwise_conv_2d(a, o->H, o->W, o->C, o->weights, f->KH, f->KW, o->WC,
+                                               o->wzp, o->nq, (int8_t)cur_zp, f->out_scale,
+                                               (int8_t)f->out_zp, f->act, f->pad, f->sh, f->sw, o->OH,
+                                               o->OW, o->c0, o->c1, f->n_c1, bb);
                 break;
             case ORC_OP_AVERAGE_POOL_2D:
-                rc = orc_average_pool_2d(a, o->H, o->W, o->C, f->KH, f->KW, f->out_scale,
-                                         (int8_t)f->out_zp, f->act, f->pad, f->sh, f->sw, o->OH,
-                                         o->OW, o->pool_c0, o->pool_c1, bb);
+                if (U)
+                    rc = orc_average_pool_2d_u8(ua, o->H, o->W, o->C, f->KH, f->KW, f->out_scale,
+                                                (uint8_t)f->out_zp, f->act, f->pad, f->sh, f->sw,
+                                                o->OH, o->OW, o->pool_c0, o->pool_c1, ub);
+                else
+                    rc = orc_average_pool_2d(a, o->H, o->W, o->C, f->KH, f->KW, f->out_scale,
+                                             (int8_t)f->out_zp, f->act, f->pad, f->sh, f->sw, o->OH,
+                                             o->OW, o->pool_c0, o->pool_c1, bb);
                 break;
             case ORC_OP_SOFTMAX:
-                orc_softmax(a, o->M, o->N, cur_scale, f->out_scale, (int8_t)f->out_zp, bb);
+                if (U)
+                    orc_softmax_u8(ua, o->M, o->N, cur_scale, f->out_scale, (uint8_t)f->out_zp, ub);
+                else
+                    orc_softmax(a, o->M, o->N, cur_scale, f->out_scale, (int8_t)f->out_zp, bb);
                 break;
             case ORC_OP_RESHAPE: /* src/ops/reshape.rs:3-8 + src/tensor.rs:103-141: logical
                                     NHWC order is preserved, so in row-major memory it is a copy */
@@ -910,7 +695,7 @@ int orc_model_run_quantized(const orc_model *m, const int8_t *in_q, int8_t *out_
         if (rc) break;
         if (f->kind != ORC_OP_RESHAPE) { /* Tensor::new(output, output_scale, output_zero_point) */
             cur_scale = f->out_scale;
-            cur_zp = (int8_t)f->out_zp;
+            cur_zp = f->out_zp;
         }
         cur_elems = f->out_elems;
         if (layers) {
@@ -935,7 +720,8 @@ int orc_model_predict_quantized(const orc_model *m, const int8_t *in_q, float *o
     int rc = orc_model_run_quantized(m, in_q, q, NULL);
     if (rc == 0)
         for (size_t i = 0; i < m->out_elems; ++i)
-            out[i] = orc_dequantize(q[i], m->out_scale, (int8_t)m->out_zp);
+            out[i] = m->is_u8 ? orc_dequantize_u8((uint8_t)q[i], m->out_scale, (uint8_t)m->out_zp)
+                              : orc_dequantize(q[i], m->out_scale, (int8_t)m->out_zp);
     free(q);
     return rc;
 }
@@ -945,7 +731,8 @@ int orc_model_predict(const orc_model *m, const float *in, float *out) {
     int8_t *q = (int8_t *)malloc(m->in_elems ? m->in_elems : 1);
     if (!q) return -1;
     for (size_t i = 0; i < m->in_elems; ++i)
-        q[i] = orc_quantize(in[i], m->in_scale, (int8_t)m->in_zp);
+        q[i] = m->is_u8 ? (int8_t)orc_quantize_u8(in[i], m->in_scale, (uint8_t)m->in_zp)
+                        : orc_quantize(in[i], m->in_scale, (int8_t)m->in_zp);
     int rc = orc_model_predict_quantized(m, q, out);
     free(q);
     return rc;

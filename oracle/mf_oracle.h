@@ -110,6 +110,40 @@ void orc_preprocess_conv(float iscale, int n, const int32_t *bias, const float *
 void orc_preprocess_average_pool_2d(float iscale, int8_t izp, float oscale, int8_t ozp, float *c0,
                                     float *c1);
 
+/* ---- the same operators for T = u8 ---------------------------------------
+ * The reference is generic over the element type (`T: Quantized`, src/quantize.rs:6-13, with
+ * impls for i8 and u8 only -- src/quantize.rs:32-53); the macro picks u8 for TensorType::UINT8
+ * (microflow-macros/src/lib.rs:118-128 and ops/{*}.rs parse functions).  mf_oracle_ops.inc is
+ * the single restatement, instantiated for both element types. */
+uint8_t orc_sat_u8(float x); /* Rust `x as u8` */
+uint8_t orc_quantize_u8(float x, float scale, uint8_t zp);
+float orc_dequantize_u8(uint8_t q, float scale, uint8_t zp);
+uint8_t orc_relu_u8(uint8_t x, uint8_t zp);
+uint8_t orc_relu6_u8(uint8_t x, float scale, uint8_t zp);
+uint8_t orc_softmax_scalar_u8(float x, float sum, float scale, uint8_t zp);
+int orc_view_u8(const uint8_t *in, int H, int W, int C, int fi, int fj, int KH, int KW, int pad,
+                int sh, int sw, uint8_t *buf, uint8_t *mask);
+void orc_fully_connected_u8(const uint8_t *in, int M, int K, const uint8_t *w, int N, uint8_t wzp,
+                            float oscale, uint8_t ozp, int act, const float *c0, float c1,
+                            const int32_t *c2, int32_t c3, uint8_t *out);
+int orc_conv_2d_u8(const uint8_t *in, int H, int W, int C, const uint8_t *f, int N, int KH, int KW,
+                   const uint8_t *fzp, int nq, uint8_t izp, float oscale, uint8_t ozp, int act,
+                   int pad, int sh, int sw, int OH, int OW, const float *c0, const float *c1, int nc1,
+                   uint8_t *out);
+int orc_depthwise_conv_2d_u8(const uint8_t *in, int H, int W, int Cin, const uint8_t *w, int KH,
+                             int KW, int WC, const uint8_t *wzp, int nq, uint8_t izp, float oscale,
+                             uint8_t ozp, int act, int pad, int sh, int sw, int OH, int OW,
+                             const float *c0, const float *c1, int nc1, uint8_t *out);
+int orc_average_pool_2d_u8(const uint8_t *in, int H, int W, int C, int FH, int FW, float oscale,
+                           uint8_t ozp, int act, int pad, int sh, int sw, int OH, int OW, float c0,
+                           float c1, uint8_t *out);
+void orc_softmax_u8(const uint8_t *in, int rows, int cols, float iscale, float oscale, uint8_t ozp,
+                    uint8_t *out);
+void orc_preprocess_fully_connected_u8(float iscale, uint8_t izp, int in_shape1, const uint8_t *w,
+                                       int K, int N, float wscale, uint8_t wzp, const int32_t *bias,
+                                       float bscale, int32_t bzp, float oscale, float *c0, float *c1,
+                                       int32_t *c2, int32_t *c3);
+
 /* ---- whole model -------------------------------------------------------- */
 typedef struct orc_model orc_model;
 
@@ -133,6 +167,9 @@ int orc_model_op_info(const orc_model *m, int i, orc_op_info *info);
 /* copies of the constants for op i (any pointer may be NULL) */
 int orc_model_op_constants(const orc_model *m, int i, float *c0, float *c1, int32_t *c2,
                            int32_t *c3);
+/* 0 = INT8 model, 1 = UINT8 model.  For a UINT8 model the int8_t* buffers of the calls below
+ * carry the raw u8 bytes. */
+int orc_model_is_u8(const orc_model *m);
 size_t orc_model_input_elems(const orc_model *m);
 size_t orc_model_output_elems(const orc_model *m);
 void orc_model_io_quant(const orc_model *m, float *iscale, int *izp, float *oscale, int *ozp);

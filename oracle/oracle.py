@@ -25,9 +25,9 @@ OP_NAMES = {1: "average_pool_2d", 3: "conv_2d", 4: "depthwise_conv_2d", 9: "full
 def build(force=False):
     """Compile oracle/libmf_oracle.so with gcc (seconds)."""
     src = os.path.join(_HERE, "mf_oracle.c")
-    hdr = os.path.join(_HERE, "mf_oracle.h")
+    deps = [src, os.path.join(_HERE, "mf_oracle.h"), os.path.join(_HERE, "mf_oracle_ops.inc")]
     if (not force and os.path.exists(_SO)
-            and os.path.getmtime(_SO) >= max(os.path.getmtime(src), os.path.getmtime(hdr))):
+            and os.path.getmtime(_SO) >= max(os.path.getmtime(d) for d in deps)):
         return _SO
     subprocess.check_call(
         ["gcc", "-O2", "-std=c11", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-shared",
@@ -98,6 +98,18 @@ def lib():
     L.orc_preprocess_average_pool_2d.restype = None
     L.orc_preprocess_average_pool_2d.argtypes = [C.c_float, C.c_int8, C.c_float, C.c_int8, f32p,
                                                  f32p]
+    # T = u8 instantiations: same signatures with every i8 replaced by u8
+    for n in ("orc_quantize", "orc_dequantize", "orc_relu", "orc_relu6", "orc_softmax_scalar",
+              "orc_view", "orc_fully_connected", "orc_conv_2d", "orc_depthwise_conv_2d",
+              "orc_average_pool_2d", "orc_softmax", "orc_preprocess_fully_connected"):
+        f, g = getattr(L, n), getattr(L, n + "_u8")
+        sw = {C.c_int8: C.c_uint8, i8p: u8p}
+        g.restype = sw.get(f.restype, f.restype)
+        g.argtypes = [sw.get(t, t) for t in f.argtypes]
+    L.orc_sat_u8.restype = C.c_uint8
+    L.orc_sat_u8.argtypes = [C.c_float]
+    L.orc_model_is_u8.restype = C.c_int
+    L.orc_model_is_u8.argtypes = [C.c_void_p]
     L.orc_model_load.restype = C.c_void_p
     L.orc_model_load.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_char_p)]
     L.orc_model_free.restype = None
@@ -137,6 +149,24 @@ def _i8(a):
     return np.ascontiguousarray(a, dtype=np.int8)
 
 
+# Element type (the reference's `T: Quantized`): decided by the dtype of the input array --
+# np.uint8 selects the u8 instantiation, anything else i8.
+def _dt(a):
+    return np.uint8 if getattr(a, "dtype", None) == np.uint8 else np.int8
+
+
+def _ct(dt):
+    return C.c_uint8 if dt == np.uint8 else C.c_int8
+
+
+def _fn(name, dt):
+    return getattr(lib(), name + ("_u8" if dt == np.uint8 else ""))
+
+
+def _q(a, dt):
+    return np.ascontiguousarray(a, dtype=dt)
+
+
 def _f32(a):
     return np.ascontiguousarray(np.atleast_1d(a), dtype=np.float32)
 
@@ -154,30 +184,31 @@ def expf(x):
     return lib().orc_expf(np.float32(x))
 
 
-def quantize(x, scale, zp):
-    return int(lib().orc_quantize(np.float32(x), np.float32(scale), int(zp)))
+def quantize(x, scale, zp, dt=np.int8):
+    return int(_fn("orc_quantize", dt)(np.float32(x), np.float32(scale), int(zp)))
 
 
-def dequantize(q, scale, zp):
-    return np.float32(lib().orc_dequantize(int(q), np.float32(scale), int(zp)))
+def dequantize(q, scale, zp, dt=np.int8):
+    return np.float32(_fn("orc_dequantize", dt)(int(q), np.float32(scale), int(zp)))
 
 
-def relu(x, zp):
-    return int(lib().orc_relu(int(x), int(zp)))
+def relu(x, zp, dt=np.int8):
+    return int(_fn("orc_relu", dt)(int(x), int(zp)))
 
 
-def relu6(x, scale, zp):
-    return int(lib().orc_relu6(int(x), np.float32(scale), int(zp)))
+def relu6(x, scale, zp, dt=np.int8):
+    return int(_fn("orc_relu6", dt)(int(x), np.float32(scale), int(zp)))
 
 
-def softmax_scalar(x, s, scale, zp):
-    return int(lib().orc_softmax_scalar(np.float32(x), np.float32(s), np.float32(scale), int(zp)))
+def softmax_scalar(x, s, scale, zp, dt=np.int8):
+    return int(_fn("orc_softmax_scalar", dt)(np.float32(x), np.float32(s), np.float32(scale),
+                                             int(zp)))
 
 
-def quantize_array(x, scale, zp):
+def quantize_array(x, scale, zp, dt=np.int8):
     x = np.asarray(x, dtype=np.float32)
-    out = np.empty(x.shape, np.int8)
-    f = lib().orc_quantize
+    out = np.empty(x.shape, dt)
+    f = _fn("orc_quantize", dt)
     xf, of = x.reshape(-1), out.reshape(-1)
     for i in range(xf.size):
         of[i] = f(xf[i], np.float32(scale), int(zp))
@@ -187,44 +218,50 @@ def quantize_array(x, scale, zp):
 # ---- view ------------------------------------------------------------------
 def view(inp, focus, kshape, pad, strides):
     """inp [H][W][C] int8 -> (buffer [KH][KW][C], mask [KH][KW] bool, len)."""
-    inp = _i8(inp)
+    dt = _dt(inp)
+    ct = _ct(dt)
+    inp = _q(inp, dt)
     H, W, Cc = inp.shape
     KH, KW = kshape
-    buf = np.zeros((KH, KW, Cc), np.int8)
+    buf = np.zeros((KH, KW, Cc), dt)
     mask = np.zeros((KH, KW), np.uint8)
-    n = lib().orc_view(_p(inp, C.c_int8), H, W, Cc, focus[0], focus[1], KH, KW, pad, strides[0],
-                       strides[1], _p(buf, C.c_int8), _p(mask, C.c_uint8))
+    n = _fn("orc_view", dt)(_p(inp, ct), H, W, Cc, focus[0], focus[1], KH, KW, pad, strides[0],
+                       strides[1], _p(buf, ct), _p(mask, C.c_uint8))
     return buf, mask.astype(bool), n
 
 
 # ---- operators -------------------------------------------------------------
 def fully_connected(inp, w_nk, wzp, oscale, ozp, act, c0, c1, c2, c3):
     """inp [M][K]; w_nk [N][K] (TFLite order)."""
-    inp, w_nk = _i8(inp), _i8(w_nk)
+    dt = _dt(inp)
+    ct = _ct(dt)
+    inp, w_nk = _q(inp, dt), _q(w_nk, dt)
     M, K = inp.shape
     N = w_nk.shape[0]
     assert w_nk.shape[1] == K
     c0, c2 = _f32(c0), _i32(c2)
-    out = np.empty((M, N), np.int8)
-    lib().orc_fully_connected(_p(inp, C.c_int8), M, K, _p(w_nk, C.c_int8), N, int(wzp),
+    out = np.empty((M, N), dt)
+    _fn("orc_fully_connected", dt)(_p(inp, ct), M, K, _p(w_nk, ct), N, int(wzp),
                               np.float32(oscale), int(ozp), act, _p(c0, C.c_float), np.float32(c1),
-                              _p(c2, C.c_int32), int(c3), _p(out, C.c_int8))
+                              _p(c2, C.c_int32), int(c3), _p(out, ct))
     return out
 
 
 def conv_2d(inp, filters, fzp, izp, oscale, ozp, act, pad, strides, out_hw, c0, c1):
     """inp [H][W][C]; filters [N][KH][KW][C] -> [OH][OW][N]."""
-    inp, filters, fzp = _i8(inp), _i8(filters), _i8(np.atleast_1d(fzp))
+    dt = _dt(inp)
+    ct = _ct(dt)
+    inp, filters, fzp = _q(inp, dt), _q(filters, dt), _q(np.atleast_1d(fzp), dt)
     H, W, Cc = inp.shape
     N, KH, KW, C2 = filters.shape
     assert C2 == Cc
     c0, c1 = _f32(c0), _f32(c1)
     OH, OW = out_hw
-    out = np.empty((OH, OW, N), np.int8)
-    rc = lib().orc_conv_2d(_p(inp, C.c_int8), H, W, Cc, _p(filters, C.c_int8), N, KH, KW,
-                           _p(fzp, C.c_int8), fzp.size, int(izp), np.float32(oscale), int(ozp), act,
+    out = np.empty((OH, OW, N), dt)
+    rc = _fn("orc_conv_2d", dt)(_p(inp, ct), H, W, Cc, _p(filters, ct), N, KH, KW,
+                           _p(fzp, ct), fzp.size, int(izp), np.float32(oscale), int(ozp), act,
                            pad, strides[0], strides[1], OH, OW, _p(c0, C.c_float),
-                           _p(c1, C.c_float), c1.size, _p(out, C.c_int8))
+                           _p(c1, C.c_float), c1.size, _p(out, ct))
     if rc:
         raise ValueError("orc_conv_2d: view out of range")
     return out
@@ -232,57 +269,65 @@ def conv_2d(inp, filters, fzp, izp, oscale, ozp, act, pad, strides, out_hw, c0, 
 
 def depthwise_conv_2d(inp, weights, wzp, izp, oscale, ozp, act, pad, strides, out_hw, c0, c1):
     """inp [H][W][Cin]; weights [KH][KW][WC] (leading 1 optional) -> [OH][OW][WC]."""
-    inp, weights, wzp = _i8(inp), _i8(weights), _i8(np.atleast_1d(wzp))
+    dt = _dt(inp)
+    ct = _ct(dt)
+    inp, weights, wzp = _q(inp, dt), _q(weights, dt), _q(np.atleast_1d(wzp), dt)
     if weights.ndim == 4:
         weights = weights[0]
     H, W, Cin = inp.shape
     KH, KW, WC = weights.shape
     c0, c1 = _f32(c0), _f32(c1)
     OH, OW = out_hw
-    out = np.empty((OH, OW, WC), np.int8)
-    rc = lib().orc_depthwise_conv_2d(_p(inp, C.c_int8), H, W, Cin, _p(weights, C.c_int8), KH, KW,
-                                     WC, _p(wzp, C.c_int8), wzp.size, int(izp), np.float32(oscale),
+    out = np.empty((OH, OW, WC), dt)
+    rc = _fn("orc_depthwise_conv_2d", dt)(_p(inp, ct), H, W, Cin, _p(weights, ct), KH, KW,
+                                     WC, _p(wzp, ct), wzp.size, int(izp), np.float32(oscale),
                                      int(ozp), act, pad, strides[0], strides[1], OH, OW,
                                      _p(c0, C.c_float), _p(c1, C.c_float), c1.size,
-                                     _p(out, C.c_int8))
+                                     _p(out, ct))
     if rc:
         raise ValueError("orc_depthwise_conv_2d: view out of range")
     return out
 
 
 def average_pool_2d(inp, fshape, oscale, ozp, act, pad, strides, out_hw, c0, c1):
-    inp = _i8(inp)
+    dt = _dt(inp)
+    ct = _ct(dt)
+    inp = _q(inp, dt)
     H, W, Cc = inp.shape
     OH, OW = out_hw
-    out = np.empty((OH, OW, Cc), np.int8)
-    rc = lib().orc_average_pool_2d(_p(inp, C.c_int8), H, W, Cc, fshape[0], fshape[1],
+    out = np.empty((OH, OW, Cc), dt)
+    rc = _fn("orc_average_pool_2d", dt)(_p(inp, ct), H, W, Cc, fshape[0], fshape[1],
                                    np.float32(oscale), int(ozp), act, pad, strides[0], strides[1],
-                                   OH, OW, np.float32(c0), np.float32(c1), _p(out, C.c_int8))
+                                   OH, OW, np.float32(c0), np.float32(c1), _p(out, ct))
     if rc:
         raise ValueError("orc_average_pool_2d: view out of range")
     return out
 
 
 def softmax(inp, iscale, oscale, ozp):
-    inp = _i8(inp)
+    dt = _dt(inp)
+    ct = _ct(dt)
+    inp = _q(inp, dt)
     rows, cols = inp.shape
-    out = np.empty((rows, cols), np.int8)
-    lib().orc_softmax(_p(inp, C.c_int8), rows, cols, np.float32(iscale), np.float32(oscale),
-                      int(ozp), _p(out, C.c_int8))
+    out = np.empty((rows, cols), dt)
+    _fn("orc_softmax", dt)(_p(inp, ct), rows, cols, np.float32(iscale), np.float32(oscale),
+                      int(ozp), _p(out, ct))
     return out
 
 
 # ---- preprocess ------------------------------------------------------------
 def preprocess_fully_connected(iscale, izp, in_shape1, w_nk, wscale, wzp, bias, bscale, bzp,
                                oscale):
-    w_nk, bias = _i8(w_nk), _i32(bias)
+    dt = _dt(w_nk)
+    ct = _ct(dt)
+    w_nk, bias = _q(w_nk, dt), _i32(bias)
     N, K = w_nk.shape
     c0 = np.empty(N, np.float32)
     c1 = np.empty(1, np.float32)
     c2 = np.empty(N, np.int32)
     c3 = np.empty(1, np.int32)
-    lib().orc_preprocess_fully_connected(np.float32(iscale), int(izp), int(in_shape1),
-                                         _p(w_nk, C.c_int8), K, N, np.float32(wscale), int(wzp),
+    _fn("orc_preprocess_fully_connected", dt)(np.float32(iscale), int(izp), int(in_shape1),
+                                         _p(w_nk, ct), K, N, np.float32(wscale), int(wzp),
                                          _p(bias, C.c_int32), np.float32(bscale), int(bzp),
                                          np.float32(oscale), _p(c0, C.c_float), _p(c1, C.c_float),
                                          _p(c2, C.c_int32), _p(c3, C.c_int32))
@@ -325,6 +370,7 @@ class Model:
             raise ValueError("oracle: " + (err.value.decode() if err.value else "load failed"))
         L = lib()
         self.num_ops = L.orc_model_num_ops(self._h)
+        self.dtype = np.uint8 if L.orc_model_is_u8(self._h) else np.int8  # element type T
         self.in_elems = L.orc_model_input_elems(self._h)
         self.out_elems = L.orc_model_output_elems(self._h)
         self.layers_elems = L.orc_model_layers_elems(self._h)
@@ -357,6 +403,15 @@ class Model:
             _lib.orc_model_free(h)
             self._h = None
 
+    def _bytes(self, q):
+        """Quantized input as the raw bytes the C side takes (int8_t* carries u8 for a u8 model)."""
+        q = np.asarray(q)
+        if q.dtype != self.dtype:
+            if q.dtype.kind in "iu" and q.dtype.itemsize == 1:
+                raise TypeError(f"model element type is {np.dtype(self.dtype).name}, got {q.dtype}")
+            q = q.astype(self.dtype)
+        return np.ascontiguousarray(q).view(np.int8)
+
     def op_constants(self, i):
         op = self.ops[i]
         c0 = np.zeros(max(op["n_c0"], 1), np.float32)
@@ -369,7 +424,7 @@ class Model:
 
     def run_quantized(self, in_q, layers=False):
         """predict_inner on one input; returns int8 output (and per-op outputs)."""
-        in_q = _i8(in_q).reshape(-1)
+        in_q = self._bytes(in_q).reshape(-1)
         assert in_q.size == self.in_elems
         out = np.empty(self.out_elems, np.int8)
         lay = np.empty(self.layers_elems, np.int8) if layers else None
@@ -377,8 +432,10 @@ class Model:
                                            _p(lay, C.c_int8) if layers else None)
         if rc:
             raise RuntimeError("oracle run failed")
+        out = out.view(self.dtype)
         if not layers:
             return out
+        lay = lay.view(self.dtype)
         outs, off = [], 0
         for op in self.ops:
             outs.append(lay[off: off + op["out_elems"]].reshape(op["out_shape"]))
@@ -386,17 +443,17 @@ class Model:
         return out, outs
 
     def run_quantized_batch(self, in_q):
-        in_q = _i8(in_q).reshape(-1, self.in_elems)
+        in_q = self._bytes(in_q).reshape(-1, self.in_elems)
         n = in_q.shape[0]
         out = np.empty((n, self.out_elems), np.int8)
         rc = lib().orc_model_run_quantized_batch(self._h, _p(in_q, C.c_int8), n,
                                                  _p(out, C.c_int8))
         if rc:
             raise RuntimeError("oracle run failed")
-        return out
+        return out.view(self.dtype)
 
     def predict_quantized(self, in_q):
-        in_q = _i8(in_q).reshape(-1)
+        in_q = self._bytes(in_q).reshape(-1)
         assert in_q.size == self.in_elems
         out = np.empty(self.out_elems, np.float32)
         rc = lib().orc_model_predict_quantized(self._h, _p(in_q, C.c_int8), _p(out, C.c_float))

@@ -155,9 +155,13 @@ def fc_model(M, K, N, weights, bias, in_q, w_q, b_q, out_q, activation=0):
     return bytes(fb.buf)
 
 
-def synthetic_fc(M, K, N, wzp=0, seed=5, activation=0):
+def synthetic_fc(M, K, N, wzp=0, seed=5, activation=0, u8=False):
     """BASELINE config 5: uniform int8 weights, input zp -128, scales chosen so that the
-    outputs spread over the int8 range instead of saturating."""
+    outputs spread over the int8 range instead of saturating.
+    u8=True: the same model with UINT8 tensors (`wzp` then is a u8 value)."""
+    if u8:
+        from make_u8_model import to_u8
+        return to_u8(synthetic_fc(M, K, N, wzp - 128, seed, activation))
     rng = np.random.default_rng(seed)
     w = rng.integers(-128, 128, (N, K), dtype=np.int8)
     bias = rng.integers(-4096, 4096, N).astype(np.int64)
@@ -180,7 +184,8 @@ if __name__ == "__main__":
     ap.add_argument("--n", type=int, default=4096)
     ap.add_argument("--wzp", type=int, default=0)
     ap.add_argument("--seed", type=int, default=5)
+    ap.add_argument("--u8", action="store_true", help="UINT8 tensors (wzp is then a u8 value)")
     a = ap.parse_args()
-    blob = synthetic_fc(a.m, a.k, a.n, a.wzp, a.seed)
+    blob = synthetic_fc(a.m, a.k, a.n, a.wzp, a.seed, u8=a.u8)
     open(a.out, "wb").write(blob)
     print(a.out, len(blob), "bytes")
