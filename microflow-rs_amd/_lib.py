@@ -97,6 +97,8 @@ SIGNATURES = {
     "mf_model_run_until": (C.c_int, [_vp, _vp, C.c_size_t, C.c_int, _vp, C.c_int]),
     "mf_model_set_generic": (C.c_int, [_vp, C.c_int]),
     "mf_model_set_fusion": (C.c_int, [_vp, C.c_int]),
+    "mf_model_set_graph": (C.c_int, [_vp, C.c_int]),
+    "mf_model_graph_launches": (C.c_ulonglong, [_vp]),
     "mf_synth_i8": (C.c_int, [C.c_int, C.c_uint64, C.c_uint64, C.c_size_t, _vp, _vp]),
     "mf_checksum_i8": (C.c_int, [C.c_int, _vp, C.c_size_t, C.POINTER(C.c_uint64), _vp]),
     "mf_model_time_device": (C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_int, C.c_int,

@@ -431,6 +431,16 @@ int mf_model_set_fusion(mf_model *model, int enabled) {
     })
 }
 
+int mf_model_set_graph(mf_model *model, int enabled) {
+    MF_TRY({
+        MF_NEED(model && model->impl);
+        mf::model_set_graph(model->impl, enabled != 0);
+    })
+}
+unsigned long long mf_model_graph_launches(const mf_model *model) {
+    return model && model->impl ? mf::model_graph_launches(model->impl) : 0;
+}
+
 int mf_model_predict(mf_model *model, const float *input, size_t batch, float *output, int mem) {
     MF_TRY({
         MF_NEED(model && model->impl && (batch == 0 || (input && output)));

@@ -140,6 +140,9 @@ void model_set_stream(ModelImpl *m, void *stream);
 void model_sync(ModelImpl *m);
 void model_set_generic(ModelImpl *m, bool generic);
 void model_set_fusion(ModelImpl *m, bool enabled);
+// replay the device-resident launch sequence as a hipGraph (captured on the 2nd identical call)
+void model_set_graph(ModelImpl *m, bool enabled);
+uint64_t model_graph_launches(const ModelImpl *m);
 // in_f32 or in_i8 (exactly one non-null); out_f32 or out_i8 (exactly one non-null)
 void model_run(ModelImpl *m, const float *in_f32, const int8_t *in_i8, size_t batch,
                float *out_f32, int8_t *out_i8, int mem, int last_op);

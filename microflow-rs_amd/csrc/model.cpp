@@ -45,11 +45,41 @@ struct ModelImpl {
     float *io_f32 = nullptr;  // f32 input / output staging
     size_t io_f32_elems = 0;
 
+    // hipGraph replay of the device-resident path (mf_model_set_graph): the launch sequence of one
+    // (input, output, batch) triple is captured the second time it is seen and replayed afterwards,
+    // so a small-batch predict costs one graph launch instead of one launch per operator.
+    struct GraphKey {
+        const void *in = nullptr, *out = nullptr;
+        size_t batch = 0;
+        int last_op = 0;
+        bool in_f32 = false, out_f32 = false;
+        uint64_t epoch = 0;
+        bool operator==(const GraphKey &o) const {
+            return in == o.in && out == o.out && batch == o.batch && last_op == o.last_op &&
+                   in_f32 == o.in_f32 && out_f32 == o.out_f32 && epoch == o.epoch;
+        }
+    };
+    bool use_graph = false;
+    uint64_t epoch = 0; // bumped whenever buffers or kernel routing change
+    hipStream_t cap_stream = nullptr;
+    hipGraphExec_t gexec = nullptr;
+    GraphKey gkey, gcand;
+    bool gvalid = false, gcand_valid = false;
+    uint64_t graph_launches = 0;
+
     ~ModelImpl() {
         if (device >= 0) (void)hipSetDevice(device);
+        drop_graph();
+        if (cap_stream) (void)hipStreamDestroy(cap_stream);
         for (FusedImpl *f : fused) fused_destroy(f);
         for (OpImpl *o : ops) op_destroy(o);
         free_buffers();
+    }
+    void drop_graph() {
+        if (gexec) (void)hipGraphExecDestroy(gexec);
+        gexec = nullptr;
+        gvalid = gcand_valid = false;
+        ++epoch;
     }
     void free_buffers() {
         for (auto &p : act) {
@@ -91,6 +121,7 @@ static void ensure_capacity(ModelImpl *m, size_t batch) {
     if (batch <= m->cap_batch) return;
     MF_HIP(hipSetDevice(m->device));
     MF_HIP(hipStreamSynchronize(m->stream));
+    m->drop_graph();
     m->free_buffers();
     const ParsedModel &pm = m->pm;
     const size_t act_bytes = ((batch * pm.max_elems + 255) / 256) * 256 + 256;
@@ -170,16 +201,25 @@ void model_sync(ModelImpl *m) {
     MF_HIP(hipStreamSynchronize(m->stream));
 }
 
-void model_set_fusion(ModelImpl *m, bool enabled) { m->fusion = enabled; }
+void model_set_fusion(ModelImpl *m, bool enabled) {
+    m->fusion = enabled;
+    m->drop_graph();
+}
+void model_set_graph(ModelImpl *m, bool enabled) {
+    m->use_graph = enabled;
+    if (!enabled) m->drop_graph();
+}
+uint64_t model_graph_launches(const ModelImpl *m) { return m->graph_launches; }
 
 void model_set_generic(ModelImpl *m, bool generic) {
     m->generic = generic;
+    m->drop_graph();
     for (OpImpl *o : m->ops)
         if (o) op_set_generic(o, generic);
 }
 
 // run ops [0..last_op] reading from `src`; returns the buffer holding the result
-static const int8_t *run_ops(ModelImpl *m, const int8_t *src, size_t batch, int last_op) {
+static const int8_t *run_ops(ModelImpl *m, const int8_t *src, size_t batch, int last_op, hipStream_t stream) {
     const int8_t *cur = src;
     int which = 0;
     for (int i = 0; i <= last_op; ++i) {
@@ -191,15 +231,84 @@ static const int8_t *run_ops(ModelImpl *m, const int8_t *src, size_t batch, int 
             dst = m->act[which];
         }
         if (fused_at(m, i) && m->fused_last[(size_t)i] <= last_op) { // the whole group in one launch
-            fused_run(m->fused[(size_t)i], cur, batch, dst, m->stream);
+            fused_run(m->fused[(size_t)i], cur, batch, dst, stream);
             i = m->fused_last[(size_t)i];
         } else {
-            op_run(o, cur, batch, dst, m->stream);
+            op_run(o, cur, batch, dst, stream);
         }
         cur = dst;
         which ^= 1;
     }
     return cur;
+}
+
+// The whole device-resident sequence (boundary conversion -> ops -> boundary conversion) on
+// `s`: every pointer is a device pointer, nothing synchronizes -- so it can be stream-captured.
+static void enqueue_device(ModelImpl *m, const float *in_f32, const int8_t *in_i8, size_t batch,
+                           float *out_f32, int8_t *out_i8, int last_op, hipStream_t s) {
+    const ParsedModel &pm = m->pm;
+    const int nops = (int)pm.ops.size();
+    const size_t out_elems = last_op == nops - 1 ? pm.out_elems : pm.ops[last_op].out_elems;
+    const int8_t *q_in;
+    if (in_f32) { // Tensor::quantize(input, scale, zero_point)  (lib.rs:189)
+        dev_quantize(m->device, in_f32, batch * pm.in_elems, pm.in_scale, pm.in_zp, pm.u8, m->in_q, s);
+        q_in = m->in_q;
+    } else if (pm.u8) { // u8 -> internal i8 domain
+        dev_xor80(m->device, in_i8, batch * pm.in_elems, m->in_q, s);
+        q_in = m->in_q;
+    } else {
+        q_in = in_i8; // consumed in place
+    }
+    const int8_t *res = run_ops(m, q_in, batch, last_op, s);
+    if (out_i8) {
+        if (pm.u8) dev_xor80(m->device, res, batch * out_elems, out_i8, s);
+        else MF_HIP(hipMemcpyAsync(out_i8, res, batch * out_elems, hipMemcpyDeviceToDevice, s));
+    } else { // .dequantize()  (lib.rs:190) with the parameters the last op stamped on the tensor
+        float oscale = pm.out_scale;
+        int ozp = pm.out_zp;
+        if (last_op != nops - 1) oscale = pm.ops[last_op].out_scale, ozp = pm.ops[last_op].out_zp;
+        dev_dequantize(m->device, res, batch * out_elems, oscale, ozp, pm.u8, out_f32, s);
+    }
+}
+
+// device path with graph replay: eager the first time a key is seen, captured the second time
+static void run_device(ModelImpl *m, const float *in_f32, const int8_t *in_i8, size_t batch,
+                       float *out_f32, int8_t *out_i8, int last_op) {
+    hipStream_t s = m->stream;
+    if (!m->use_graph) return enqueue_device(m, in_f32, in_i8, batch, out_f32, out_i8, last_op, s);
+    ModelImpl::GraphKey k;
+    k.in = in_f32 ? (const void *)in_f32 : (const void *)in_i8;
+    k.out = out_f32 ? (const void *)out_f32 : (const void *)out_i8;
+    k.batch = batch, k.last_op = last_op, k.in_f32 = in_f32 != nullptr, k.out_f32 = out_f32 != nullptr;
+    k.epoch = m->epoch;
+    if (m->gvalid && m->gkey == k) {
+        MF_HIP(hipGraphLaunch(m->gexec, s));
+        ++m->graph_launches;
+        return;
+    }
+    if (!(m->gcand_valid && m->gcand == k)) { // first sighting: run eagerly (lets operators size their scratch)
+        m->gcand = k, m->gcand_valid = true;
+        return enqueue_device(m, in_f32, in_i8, batch, out_f32, out_i8, last_op, s);
+    }
+    if (!m->cap_stream) MF_HIP(hipStreamCreateWithFlags(&m->cap_stream, hipStreamNonBlocking));
+    MF_HIP(hipStreamBeginCapture(m->cap_stream, hipStreamCaptureModeRelaxed));
+    hipGraph_t g = nullptr;
+    try {
+        enqueue_device(m, in_f32, in_i8, batch, out_f32, out_i8, last_op, m->cap_stream);
+    } catch (...) {
+        (void)hipStreamEndCapture(m->cap_stream, &g);
+        if (g) (void)hipGraphDestroy(g);
+        throw;
+    }
+    MF_HIP(hipStreamEndCapture(m->cap_stream, &g));
+    hipGraphExec_t e = nullptr;
+    hipError_t err = hipGraphInstantiate(&e, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    if (err != hipSuccess) fail(MF_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(err));
+    if (m->gexec) (void)hipGraphExecDestroy(m->gexec);
+    m->gexec = e, m->gkey = k, m->gvalid = true, m->gcand_valid = false;
+    MF_HIP(hipGraphLaunch(m->gexec, s));
+    ++m->graph_launches;
 }
 
 void model_run(ModelImpl *m, const float *in_f32, const int8_t *in_i8, size_t batch, float *out_f32,
@@ -218,52 +327,34 @@ void model_run(ModelImpl *m, const float *in_f32, const int8_t *in_i8, size_t ba
     const size_t out_elems = last_op == nops - 1 ? pm.out_elems : pm.ops[last_op].out_elems;
     const bool host = mem == MF_MEM_HOST;
     hipStream_t s = m->stream;
+    if (!host) return run_device(m, in_f32, in_i8, batch, out_f32, out_i8, last_op);
 
-    // ---- input ----
+    // ---- host buffers staged through HBM: H2D, the device sequence, D2H, then wait ----
     const int8_t *q_in;
     if (in_f32) { // Tensor::quantize(input, scale, zero_point)  (lib.rs:189)
-        const float *d_f = in_f32;
-        if (host) {
-            MF_HIP(hipMemcpyAsync(m->io_f32, in_f32, batch * pm.in_elems * sizeof(float),
-                                  hipMemcpyHostToDevice, s));
-            d_f = m->io_f32;
-        }
-        dev_quantize(m->device, d_f, batch * pm.in_elems, pm.in_scale, pm.in_zp, pm.u8, m->in_q, s);
-        q_in = m->in_q;
-    } else if (host) {
+        MF_HIP(hipMemcpyAsync(m->io_f32, in_f32, batch * pm.in_elems * sizeof(float), hipMemcpyHostToDevice, s));
+        dev_quantize(m->device, m->io_f32, batch * pm.in_elems, pm.in_scale, pm.in_zp, pm.u8, m->in_q, s);
+    } else {
         MF_HIP(hipMemcpyAsync(m->in_q, in_i8, batch * pm.in_elems, hipMemcpyHostToDevice, s));
         if (pm.u8) dev_xor80(m->device, m->in_q, batch * pm.in_elems, m->in_q, s); // u8 -> internal i8 domain
-        q_in = m->in_q;
-    } else if (pm.u8) {
-        dev_xor80(m->device, in_i8, batch * pm.in_elems, m->in_q, s);
-        q_in = m->in_q;
-    } else {
-        q_in = in_i8; // device-resident batch: consumed in place
     }
-
-    // ---- predict_inner ----
-    const int8_t *res = run_ops(m, q_in, batch, last_op);
-
-    // ---- output ----
+    q_in = m->in_q;
+    const int8_t *res = run_ops(m, q_in, batch, last_op, s); // predict_inner
     if (out_i8) {
-        if (pm.u8) { // internal i8 domain -> u8 (the op buffers are scratch: in place, unless no op ran)
+        if (pm.u8) { // internal i8 domain -> u8, in place in the scratch buffer holding the result
             int8_t *tmp = res == q_in ? m->act[0] : const_cast<int8_t *>(res);
-            dev_xor80(m->device, res, batch * out_elems, host ? tmp : out_i8, s);
-            if (host) MF_HIP(hipMemcpyAsync(out_i8, tmp, batch * out_elems, hipMemcpyDeviceToHost, s));
-        } else {
-            MF_HIP(hipMemcpyAsync(out_i8, res, batch * out_elems, host ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, s));
+            dev_xor80(m->device, res, batch * out_elems, tmp, s);
+            res = tmp;
         }
+        MF_HIP(hipMemcpyAsync(out_i8, res, batch * out_elems, hipMemcpyDeviceToHost, s));
     } else { // .dequantize()  (lib.rs:190) with the parameters the last op stamped on the tensor
         float oscale = pm.out_scale;
         int ozp = pm.out_zp;
         if (last_op != nops - 1) oscale = pm.ops[last_op].out_scale, ozp = pm.ops[last_op].out_zp;
-        float *d_o = host ? m->io_f32 : out_f32;
-        dev_dequantize(m->device, res, batch * out_elems, oscale, ozp, pm.u8, d_o, s);
-        if (host)
-            MF_HIP(hipMemcpyAsync(out_f32, m->io_f32, batch * out_elems * sizeof(float),
-                                  hipMemcpyDeviceToHost, s));
+        dev_dequantize(m->device, res, batch * out_elems, oscale, ozp, pm.u8, m->io_f32, s);
+        MF_HIP(hipMemcpyAsync(out_f32, m->io_f32, batch * out_elems * sizeof(float), hipMemcpyDeviceToHost, s));
     }
-    if (host) MF_HIP(hipStreamSynchronize(s));
+    MF_HIP(hipStreamSynchronize(s));
 }
 
 void model_time_device(ModelImpl *m, const int8_t *d_in, size_t batch, int8_t *d_out, int warmup,

@@ -93,10 +93,19 @@ class Model:
         _lib.check(_lib.lib().mf_model_set_fusion(self._h, int(enabled)))
         return self
 
+    def set_graph(self, enabled=True):
+        """hipGraph replay of device-resident calls that repeat the same buffers (small batches)."""
+        _lib.check(_lib.lib().mf_model_set_graph(self._h, int(enabled)))
+        return self
+
+    @property
+    def graph_launches(self):
+        return int(_lib.lib().mf_model_graph_launches(self._h))
+
     def sync(self):
         _lib.check(_lib.lib().mf_model_sync(self._h))
 
-    def _io(self, x, np_dtype, elems, out_elems, out_torch_dtype, out_np_dtype, trailing):
+    def _io(self, x, np_dtype, elems, out_elems, out_torch_dtype, out_np_dtype, trailing, out=None):
         """Normalise an input to (pointer, batch, mem, output buffer, finish())."""
         import torch
         if isinstance(x, torch.Tensor):
@@ -122,7 +131,12 @@ class Model:
             raise ValueError("input has %d elements, expected a multiple of %d" % (xt.numel(), elems))
         batch = xt.numel() // elems
         single = xt.numel() == elems and xt.dim() <= len(self.input_shape)
-        out = torch.empty((batch, out_elems), dtype=out_torch_dtype, device=xt.device)
+        if out is None:
+            out = torch.empty((batch, out_elems), dtype=out_torch_dtype, device=xt.device)
+        elif (not out.is_cuda or out.dtype != out_torch_dtype or out.numel() != batch * out_elems
+              or not out.is_contiguous()):
+            raise ValueError("out= must be a contiguous cuda tensor of %d %s values"
+                             % (batch * out_elems, out_torch_dtype))
         _lib.check(_lib.lib().mf_model_set_stream(self._h, torch.cuda.current_stream(xt.device).cuda_stream))
         fin = (lambda: out.reshape(trailing) if single else out.reshape((batch,) + trailing))
         return xt.data_ptr(), batch, _lib.MF_MEM_DEVICE, out.data_ptr(), fin, xt
@@ -136,20 +150,22 @@ class Model:
             self.prepare(batch)
 
     # ---- the #[model] methods -------------------------------------------------
-    def predict(self, x):
-        """M::predict (lib.rs:188-191).  x: f32 [input_shape] or [B, *input_shape]."""
+    def predict(self, x, out=None):
+        """M::predict (lib.rs:188-191).  x: f32 [input_shape] or [B, *input_shape].
+        out= (cuda inputs only): preallocated result tensor; feeding the same x / out buffers
+        again is what lets set_graph() replay the launch sequence."""
         import torch
         p, batch, mem, o, fin, keep = self._io(x, np.float32, self.input_elems, self.output_elems,
-                                               torch.float32, np.float32, self.output_shape)
+                                               torch.float32, np.float32, self.output_shape, out)
         self._ensure(batch)
         _lib.check(_lib.lib().mf_model_predict(self._h, p, batch, o, mem))
         return fin()
 
-    def predict_quantized(self, xq):
+    def predict_quantized(self, xq, out=None):
         """M::predict_quantized (lib.rs:193-196).  xq: the model's element type (int8 / uint8)."""
         import torch
         p, batch, mem, o, fin, keep = self._io(xq, self.dtype, self.input_elems, self.output_elems,
-                                               torch.float32, np.float32, self.output_shape)
+                                               torch.float32, np.float32, self.output_shape, out)
         self._ensure(batch)
         _lib.check(_lib.lib().mf_model_predict_quantized(self._h, p, batch, o, mem))
         return fin()
@@ -157,11 +173,11 @@ class Model:
     predict_batch = predict                      # new surface: B independent inferences
     predict_quantized_batch = predict_quantized
 
-    def run_quantized(self, xq):
+    def run_quantized(self, xq, out=None):
         """predict_inner (lib.rs:198-201): int8 in, int8 out (before dequantize)."""
         import torch
         p, batch, mem, o, fin, keep = self._io(xq, self.dtype, self.input_elems, self.output_elems,
-                                               self._tdtype(), self.dtype, self.output_shape)
+                                               self._tdtype(), self.dtype, self.output_shape, out)
         self._ensure(batch)
         _lib.check(_lib.lib().mf_model_run_quantized(self._h, p, batch, o, mem))
         return fin()

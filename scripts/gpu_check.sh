@@ -41,7 +41,7 @@ fi
 if [[ $STEPS == all || $STEPS == *prof* ]]; then
   rm -rf $OUT/prof
   (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/$OUT/prof" -- \
-      python "$OLDPWD/bench.py" --steps 5 --warmup 2 --no-cpu-baseline > "$OLDPWD/$OUT/prof_bench.json" 2> "$OLDPWD/$OUT/prof.err")
+      python "$OLDPWD/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-host-fed > "$OLDPWD/$OUT/prof_bench.json" 2> "$OLDPWD/$OUT/prof.err")
   echo "rocprof exit $?"
   find $OUT/prof -name "*kernel_stats*" | head
   f=$(find $OUT/prof -name "*kernel_stats.csv" | head -1)
@@ -53,7 +53,7 @@ if [[ $STEPS == *pmc* ]]; then
   for c in FETCH_SIZE WRITE_SIZE; do
     rm -rf $OUT/pmc_$c
     (cd /tmp && timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OLDPWD/$OUT/pmc_$c" -- \
-        python "$OLDPWD/bench.py" --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> "$OLDPWD/$OUT/pmc_$c.err")
+        python "$OLDPWD/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-host-fed > /dev/null 2> "$OLDPWD/$OUT/pmc_$c.err")
     echo "pmc $c exit $?"
     find $OUT/pmc_$c -name "*.csv" | head -5
   done
@@ -64,11 +64,11 @@ if [[ $STEPS == *sqpmc* ]]; then
   # SQ counters (8 slots per pass) for the issue/stall breakdown of every kernel
   rm -rf $OUT/pmc_sq
   (cd /tmp && timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS --kernel-trace --output-format csv -d "$OLDPWD/$OUT/pmc_sq" -- \
-      python "$OLDPWD/bench.py" --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> "$OLDPWD/$OUT/pmc_sq.err")
+      python "$OLDPWD/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-host-fed > /dev/null 2> "$OLDPWD/$OUT/pmc_sq.err")
   echo "sq pmc exit $?"
   rm -rf $OUT/pmc_sq2
   (cd /tmp && timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU_CVT GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$OLDPWD/$OUT/pmc_sq2" -- \
-      python "$OLDPWD/bench.py" --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> "$OLDPWD/$OUT/pmc_sq2.err")
+      python "$OLDPWD/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-host-fed > /dev/null 2> "$OLDPWD/$OUT/pmc_sq2.err")
   echo "sq2 pmc exit $?"
   python - <<'PY'
 import csv, glob, re

@@ -2,6 +2,7 @@
 the recorded sine outputs, the sample tensors, seeded batches against the CPU oracle
 (with per-layer localisation), ragged batch sizes, and full-size properties."""
 import csv
+import importlib
 import os
 
 import numpy as np
@@ -195,3 +196,45 @@ def test_fused_equals_layerwise(models, n):
     # a depthwise op as the last op always runs unfused
     assert np.array_equal(m.run_until(x, 1), m.set_fusion(False).run_until(x, 1))
     m.set_fusion(True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,batch", [("sine", 1), ("speech", 5), ("person_detect", 3)])
+def test_graph_replay_equals_eager(name, batch):
+    """mf_model_set_graph: the captured launch sequence gives the eager path's results, is only
+    used for repeated (input, output, batch) triples, and is dropped when routing changes."""
+    import torch
+    mf = importlib.import_module("microflow_rs_amd")
+    m = mf.model(model_path(name))
+    rng = np.random.default_rng(5)
+    x = torch.as_tensor(rng.integers(-128, 128, (batch, m.input_elems)).astype(np.int8)).cuda()
+    want = m.run_quantized(x).clone()
+    m.set_graph(True)
+    out = torch.empty_like(want)
+    for it in range(4):  # 1st call eager, 2nd captures + replays, then replays
+        out.zero_()
+        m.run_quantized(x, out=out)
+        assert torch.equal(out, want), it
+    assert m.graph_launches == 3
+    # new input values in the SAME buffer: the replay reads the buffer, not a snapshot
+    x2 = torch.as_tensor(rng.integers(-128, 128, (batch, m.input_elems)).astype(np.int8)).cuda()
+    want2 = m.set_graph(False).run_quantized(x2).clone()
+    m.set_graph(True)
+    x.copy_(x2)
+    for it in range(3):
+        m.run_quantized(x, out=out)
+        assert torch.equal(out, want2), it
+    n = m.graph_launches
+    # the f32 entry point is a different sequence (quantize + dequantize): its own capture
+    xf = (x.float() - float(m.input_zero_point)) * float(m.input_scale)
+    of = torch.empty((batch, m.output_elems), dtype=torch.float32, device="cuda")
+    ref = m.set_graph(False).predict(xf).clone()
+    m.set_graph(True)
+    for it in range(3):
+        m.predict(xf, out=of)
+        assert torch.equal(of.reshape(ref.shape), ref), it
+    assert m.graph_launches == n + 2
+    # routing change invalidates the graph
+    m.set_fusion(False)
+    m.run_quantized(x, out=out)
+    assert torch.equal(out, want2)
