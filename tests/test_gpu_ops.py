@@ -1,6 +1,8 @@
 """Parity of every operator kernel against the reference's unit KATs and the CPU
 oracle, called through the C ABI (via the Python mirror of microflow::ops).
 Bit-exact: all comparisons are array_equal on int8."""
+import os
+
 import numpy as np
 import pytest
 
@@ -322,3 +324,38 @@ def test_fully_connected_mfma_gemm_vs_oracle(mf, O, case):
     # a row count that is not a multiple of 128 falls back to the generic kernel, same results
     op = mf.ops.prepare_fully_connected(100, w, wzp, oscale, ozp, mf.ops.FullyConnectedOptions(), (c0, c1, c2, c3))
     assert np.array_equal(op(x[:100]), O.fully_connected(x[:100], w, wzp, oscale, ozp, 0, c0, c1, c2, c3))
+
+
+_TILE256_SCRIPT = r"""
+import sys, numpy as np
+sys.path.insert(0, {root!r})
+import microflow_rs_amd as mf
+from oracle import oracle as O
+for (M, K, N, wzp) in [(256, 128, 256, 0), (256, 256, 256, 0), (512, 384, 256, 7), (256, 640, 512, 0), (768, 1024, 256, -3)]:
+    rng = np.random.default_rng(M + K + N)
+    x = rng.integers(-128, 128, (M, K)).astype(np.int8)
+    w = rng.integers(-128, 128, (N, K)).astype(np.int8)
+    bias = rng.integers(-5000, 5000, N).astype(np.int32)
+    oscale = float(np.sqrt(K) * 74 * 74 * 3 / 127 / 16384)
+    c = O.preprocess_fully_connected(1 / 128, -128, K, w, 1 / 128, wzp, bias, 1 / 16384, 0, oscale)
+    op = mf.ops.prepare_fully_connected(M, w, wzp, oscale, 3, mf.ops.FullyConnectedOptions(), c)
+    assert op.kernel == "fc_mfma", op.kernel
+    want = O.fully_connected(x, w, wzp, oscale, 3, 0, *c)
+    for rep in range(5):                       # repeated launches: a staging race would not be stable
+        got = op(x)
+        assert np.array_equal(got, want), (M, K, N, rep, np.argwhere(got != want)[:4])
+print("tile256 ok")
+"""
+
+
+def test_fully_connected_mfma_256_tile_schedule():
+    """The 256x256-tile kernel (staggered wave rows) is normally chosen only for >= 192 tiles;
+    MF_FC_TILE=256 forces it so that K = 1, 2, 3, 5, 8 staging steps are all checked against
+    the oracle (first/last-tile paths of the software pipeline)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MF_FC_TILE="256")
+    r = subprocess.run([sys.executable, "-c", _TILE256_SCRIPT.format(root=root)], env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0 and "tile256 ok" in r.stdout, r.stdout + r.stderr
