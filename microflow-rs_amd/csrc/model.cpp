@@ -62,6 +62,7 @@ struct ModelImpl {
     bool use_graph = false;
     uint64_t epoch = 0; // bumped whenever buffers or kernel routing change
     hipStream_t cap_stream = nullptr;
+    hipStream_t copy_stream = nullptr; // H2D of host-fed batches, overlapped with compute
     hipGraphExec_t gexec = nullptr;
     GraphKey gkey, gcand;
     bool gvalid = false, gcand_valid = false;
@@ -71,6 +72,7 @@ struct ModelImpl {
         if (device >= 0) (void)hipSetDevice(device);
         drop_graph();
         if (cap_stream) (void)hipStreamDestroy(cap_stream);
+        if (copy_stream) (void)hipStreamDestroy(copy_stream);
         for (FusedImpl *f : fused) fused_destroy(f);
         for (OpImpl *o : ops) op_destroy(o);
         free_buffers();
@@ -329,32 +331,71 @@ void model_run(ModelImpl *m, const float *in_f32, const int8_t *in_i8, size_t ba
     hipStream_t s = m->stream;
     if (!host) return run_device(m, in_f32, in_i8, batch, out_f32, out_i8, last_op);
 
-    // ---- host buffers staged through HBM: H2D, the device sequence, D2H, then wait ----
-    const int8_t *q_in;
-    if (in_f32) { // Tensor::quantize(input, scale, zero_point)  (lib.rs:189)
-        MF_HIP(hipMemcpyAsync(m->io_f32, in_f32, batch * pm.in_elems * sizeof(float), hipMemcpyHostToDevice, s));
-        dev_quantize(m->device, m->io_f32, batch * pm.in_elems, pm.in_scale, pm.in_zp, pm.u8, m->in_q, s);
-    } else {
-        MF_HIP(hipMemcpyAsync(m->in_q, in_i8, batch * pm.in_elems, hipMemcpyHostToDevice, s));
-        if (pm.u8) dev_xor80(m->device, m->in_q, batch * pm.in_elems, m->in_q, s); // u8 -> internal i8 domain
+    // ---- host buffers staged through HBM ----
+    // The batch is cut into chunks of ~64 MB of input: chunk c+1 crosses PCIe on the copy stream
+    // while chunk c computes (pinned host memory makes the copies truly asynchronous; pageable
+    // memory still works, serialized by the runtime).  Each chunk has its own slice of the
+    // staging buffers; the activation ping-pong buffers are reused chunk after chunk, in order.
+    const size_t in_bytes = pm.in_elems * (in_f32 ? sizeof(float) : 1);
+    const size_t out_bytes = out_elems * (out_f32 ? sizeof(float) : 1);
+    size_t chunk = batch;
+    if (in_bytes && out_bytes <= in_bytes) { // (a chunk's f32 output slice must not reach later chunks' input slices)
+        const size_t per = std::max<size_t>(256, ((64u << 20) / in_bytes) & ~(size_t)255);
+        if (batch > per + per / 2) chunk = per;
     }
-    q_in = m->in_q;
-    const int8_t *res = run_ops(m, q_in, batch, last_op, s); // predict_inner
-    if (out_i8) {
-        if (pm.u8) { // internal i8 domain -> u8, in place in the scratch buffer holding the result
-            int8_t *tmp = res == q_in ? m->act[0] : const_cast<int8_t *>(res);
-            dev_xor80(m->device, res, batch * out_elems, tmp, s);
-            res = tmp;
+    if (chunk < batch && !m->copy_stream) MF_HIP(hipStreamCreateWithFlags(&m->copy_stream, hipStreamNonBlocking));
+    std::vector<hipEvent_t> evs;
+    float oscale = pm.out_scale;
+    int ozp = pm.out_zp;
+    if (last_op != nops - 1) oscale = pm.ops[last_op].out_scale, ozp = pm.ops[last_op].out_zp;
+    try {
+        if (chunk < batch) { // the copy stream starts after whatever the caller queued on the compute stream
+            hipEvent_t e;
+            MF_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            evs.push_back(e);
+            MF_HIP(hipEventRecord(e, s));
+            MF_HIP(hipStreamWaitEvent(m->copy_stream, e, 0));
         }
-        MF_HIP(hipMemcpyAsync(out_i8, res, batch * out_elems, hipMemcpyDeviceToHost, s));
-    } else { // .dequantize()  (lib.rs:190) with the parameters the last op stamped on the tensor
-        float oscale = pm.out_scale;
-        int ozp = pm.out_zp;
-        if (last_op != nops - 1) oscale = pm.ops[last_op].out_scale, ozp = pm.ops[last_op].out_zp;
-        dev_dequantize(m->device, res, batch * out_elems, oscale, ozp, pm.u8, m->io_f32, s);
-        MF_HIP(hipMemcpyAsync(out_f32, m->io_f32, batch * out_elems * sizeof(float), hipMemcpyDeviceToHost, s));
+        for (size_t first = 0; first < batch; first += chunk) {
+            const size_t n = std::min(chunk, batch - first);
+            hipStream_t cs = chunk < batch ? m->copy_stream : s;
+            int8_t *q = m->in_q + first * pm.in_elems;
+            float *f = m->io_f32 + first * pm.in_elems;
+            if (in_f32) MF_HIP(hipMemcpyAsync(f, in_f32 + first * pm.in_elems, n * in_bytes, hipMemcpyHostToDevice, cs));
+            else MF_HIP(hipMemcpyAsync(q, in_i8 + first * pm.in_elems, n * in_bytes, hipMemcpyHostToDevice, cs));
+            if (cs != s) {
+                hipEvent_t e;
+                MF_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                evs.push_back(e);
+                MF_HIP(hipEventRecord(e, cs));
+                MF_HIP(hipStreamWaitEvent(s, e, 0));
+            }
+            if (in_f32) // Tensor::quantize(input, scale, zero_point)  (lib.rs:189)
+                dev_quantize(m->device, f, n * pm.in_elems, pm.in_scale, pm.in_zp, pm.u8, q, s);
+            else if (pm.u8)
+                dev_xor80(m->device, q, n * pm.in_elems, q, s); // u8 -> internal i8 domain
+            const int8_t *res = run_ops(m, q, n, last_op, s); // predict_inner
+            if (out_i8) {
+                if (pm.u8) { // internal i8 domain -> u8, in place in the scratch buffer holding the result
+                    int8_t *tmp = res == q ? m->act[0] : const_cast<int8_t *>(res);
+                    dev_xor80(m->device, res, n * out_elems, tmp, s);
+                    res = tmp;
+                }
+                MF_HIP(hipMemcpyAsync(out_i8 + first * out_elems, res, n * out_elems, hipMemcpyDeviceToHost, s));
+            } else { // .dequantize()  (lib.rs:190) with the parameters the last op stamped on the tensor
+                float *fo = m->io_f32 + first * out_elems;
+                dev_dequantize(m->device, res, n * out_elems, oscale, ozp, pm.u8, fo, s);
+                MF_HIP(hipMemcpyAsync(out_f32 + first * out_elems, fo, n * out_bytes, hipMemcpyDeviceToHost, s));
+            }
+        }
+        MF_HIP(hipStreamSynchronize(s));
+    } catch (...) {
+        if (m->copy_stream) (void)hipStreamSynchronize(m->copy_stream);
+        (void)hipStreamSynchronize(s);
+        for (hipEvent_t e : evs) (void)hipEventDestroy(e);
+        throw;
     }
-    MF_HIP(hipStreamSynchronize(s));
+    for (hipEvent_t e : evs) (void)hipEventDestroy(e);
 }
 
 void model_time_device(ModelImpl *m, const int8_t *d_in, size_t batch, int8_t *d_out, int warmup,

@@ -238,3 +238,26 @@ def test_graph_replay_equals_eager(name, batch):
     m.set_fusion(False)
     m.run_quantized(x, out=out)
     assert torch.equal(out, want2)
+
+
+@pytest.mark.gpu
+def test_host_fed_chunked_equals_device():
+    """Host (numpy) batches above ~96 MB are cut into chunks whose H2D copies overlap compute;
+    the results must equal the device-resident path's, for the int8 and the f32 entry points,
+    including a ragged last chunk."""
+    import torch
+    mf = importlib.import_module("microflow_rs_amd")
+    m = mf.model(model_path("person_detect"))
+    n = 12000                                   # 110 MB of int8 input -> chunks of 7168 + 4832
+    x = synth_i8(3, 0, n, m.input_elems)
+    xd = torch.as_tensor(x).cuda()
+    want = m.run_quantized(xd).cpu().numpy()
+    got = m.run_quantized(x)
+    assert isinstance(got, np.ndarray) and np.array_equal(got, want)
+    nf = 3000                                   # 110 MB of f32 input -> chunks of 1792 + 1208
+    xf = ((x[:nf].astype(np.float32) - np.float32(m.input_zero_point)) * m.input_scale).astype(np.float32)
+    wantf = m.predict(torch.as_tensor(xf).cuda()).cpu().numpy()
+    gotf = m.predict(xf)
+    assert np.array_equal(gotf.view(np.uint32), wantf.view(np.uint32))
+    assert np.array_equal(m.predict_quantized(x[:9000]).view(np.uint32),
+                          m.predict_quantized(xd[:9000]).cpu().numpy().view(np.uint32))
