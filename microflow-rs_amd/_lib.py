@@ -144,7 +144,7 @@ def lib():
         fn = getattr(L, name)  # AttributeError here = ABI / header drift: fail loudly
         fn.restype = res
         fn.argtypes = args
-    if L.mf_abi_version() != 1:
+    if L.mf_abi_version() != 2:
         raise ImportError("libmicroflow_amd.so ABI version mismatch")
     _lib = L
     return L

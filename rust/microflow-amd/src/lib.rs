@@ -39,6 +39,9 @@ pub struct mf_model_info {
     pub input_elems: usize,
     pub output_elems: usize,
     pub num_ops: c_int,
+    /// 0 = i8 model, 1 = u8 model (`mf_elem_type`); the macro picks `Buffer<i8>` or `Buffer<u8>`
+    /// for `predict_quantized` from it, like microflow-macros/src/lib.rs:118-128 does.
+    pub element_type: c_int,
 }
 
 pub const MF_OK: c_int = 0;
