@@ -316,6 +316,7 @@ static void run_device(ModelImpl *m, const float *in_f32, const int8_t *in_i8, s
 void model_run(ModelImpl *m, const float *in_f32, const int8_t *in_i8, size_t batch, float *out_f32,
                int8_t *out_i8, int mem, int last_op) {
     if (!m->prepared) fail(MF_ERR_INVALID_ARG, "model not prepared: call mf_model_prepare first");
+    if (!batch) return; // zero inferences: nothing to read or write (empty buffers may be null)
     if ((in_f32 == nullptr) == (in_i8 == nullptr) || (out_f32 == nullptr) == (out_i8 == nullptr))
         fail(MF_ERR_INVALID_ARG, "null buffer");
     if (mem != MF_MEM_HOST && mem != MF_MEM_DEVICE) fail(MF_ERR_INVALID_ARG, "bad mem kind");

@@ -261,3 +261,18 @@ def test_host_fed_chunked_equals_device():
     assert np.array_equal(gotf.view(np.uint32), wantf.view(np.uint32))
     assert np.array_equal(m.predict_quantized(x[:9000]).view(np.uint32),
                           m.predict_quantized(xd[:9000]).cpu().numpy().view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_empty_batch_is_a_no_op(models):
+    """Zero inferences: every entry point returns an empty result and launches nothing."""
+    import torch
+    m = models["speech"]
+    e = m.input_elems
+    assert m.run_quantized(np.zeros((0, e), np.int8)).shape == (0,) + tuple(m.output_shape)
+    assert m.predict(np.zeros((0, e), np.float32)).shape == (0,) + tuple(m.output_shape)
+    got = m.run_quantized(torch.zeros((0, e), dtype=torch.int8, device="cuda"))
+    assert got.is_cuda and got.numel() == 0
+    mf = importlib.import_module("microflow_rs_amd")
+    op = mf.ops.prepare_softmax(1, 4, 0.1, 1 / 256, -128)
+    assert op(np.zeros((0, 1, 4), np.int8)).shape == (0, 1, 4)
