@@ -1719,6 +1719,18 @@ const char *dwpw_name(int H, int W, int C, int S, int N) {
 }
 bool launch_dwpw(int H, int W, int C, int S, int N, const int8_t *in, int8_t *out, const DwPwArgs &a,
                  int batch, hipStream_t s) {
+    static const int alt = [] { const char *e = getenv("MF_DWPW_ALT"); return e ? atoi(e) : -1; }();
+    if (alt >= 0) {
+        int idx = 0;
+        (void)idx;
+#define MF_DWPW(h, w, c, st, n, g, t, d)                                        \
+    if (idx++ == alt && H == h && W == w && C == c && S == st && N == n) {      \
+        launch_dwpw_t<h, w, c, st, n, g, t, d>(in, out, a, batch, s);           \
+        return true;                                                            \
+    }
+        MF_DWPW_ALT_SHAPES(MF_DWPW)
+#undef MF_DWPW
+    }
 #define MF_DWPW(h, w, c, st, n, g, t, d)                         \
     if (H == h && W == w && C == c && S == st && N == n) {       \
         launch_dwpw_t<h, w, c, st, n, g, t, d>(in, out, a, batch, s); \
