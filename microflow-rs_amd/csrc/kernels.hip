@@ -47,6 +47,29 @@ __device__ __forceinline__ int requant(int acc, float A, float S, float lo_f, fl
     return (int)r;
 }
 
+// "Magic" accumulators (MG = true): the accumulator is started at Kc + 0x4B400000, so that its
+// bit pattern read as f32 is 12582912 + acc, exactly, whenever |acc| < 2^22; f32(acc) is then
+// one v_add_f32 (full rate) instead of v_cvt_f32_i32 (half rate).  Both are exact, so the
+// epilogue's value is unchanged.  The host enables it per operator only when the worst-case
+// |acc| over ALL inputs -- max|v - izp| * sum|w - wzp| per channel -- is below 2^22 (ops.hip).
+constexpr int MF_MAGIC_I = 0x4B400000;
+template <bool MG>
+__device__ __forceinline__ int requant_t(int acc, float A, float S, float lo_f, float hi_f) {
+    if constexpr (!MG) {
+        return requant(acc, A, S, lo_f, hi_f);
+    } else {
+        const float f = __fsub_rn(__int_as_float(acc), 12582912.0f);
+        const float x = __fadd_rn(A, __fmul_rn(S, f));
+        float r = __fadd_rn(x, __builtin_copysignf(0x1.fffffep-2f, x));
+        r = __builtin_amdgcn_fmed3f(r, lo_f, hi_f);
+        return (int)r;
+    }
+}
+template <bool MG> __device__ __forceinline__ int4 magic4(int4 k) {
+    if constexpr (MG) k.x += MF_MAGIC_I, k.y += MF_MAGIC_I, k.z += MF_MAGIC_I, k.w += MF_MAGIC_I;
+    return k;
+}
+
 // 4 ints in [-128,127] -> one dword of int8 (byte 0 = a)
 __device__ __forceinline__ uint32_t pack4(int a, int b, int c, int d) {
     const uint32_t lo = __builtin_amdgcn_perm((uint32_t)b, (uint32_t)a, 0x0c0c0400u);
@@ -440,7 +463,7 @@ __device__ __forceinline__ void dw_s1_task(const uint8_t *base, const uint32_t (
 // One barrier per step: after it, every wave has finished reading the other buffer
 // (safe to overwrite) and every wave's DMAs into this buffer have landed.
 // ------------------------------------------------------------------------
-template <int H, int W, int C, int S, int G, int NTHR>
+template <int H, int W, int C, int S, int G, int NTHR, bool MG>
 __global__ __launch_bounds__(NTHR) void dw3x3_nhwc(const int8_t *__restrict__ in,
                                                   int8_t *__restrict__ out, DwFastArgs p,
                                                   int batch) {
@@ -499,7 +522,7 @@ __global__ __launch_bounds__(NTHR) void dw3x3_nhwc(const int8_t *__restrict__ in
         }
     }
     const float4 A = ((const float4 *)p.A)[cg], Sc = ((const float4 *)p.S)[cg];
-    const int4 Kc = ((const int4 *)p.Kc)[cg];
+    const int4 Kc = magic4<MG>(((const int4 *)p.Kc)[cg]);
     __syncthreads(); // halo fill complete before any DMA lands
 
     auto stage = [&](int st, int buf) {
@@ -548,10 +571,10 @@ __global__ __launch_bounds__(NTHR) void dw3x3_nhwc(const int8_t *__restrict__ in
                             a2 = sdot4(v, wm[t][2], a2);
                             a3 = sdot4(v, wm[t][3], a3);
                         }
-                    const int q0 = requant(a0, A.x, Sc.x, p.lo_f, p.hi_f);
-                    const int q1 = requant(a1, A.y, Sc.y, p.lo_f, p.hi_f);
-                    const int q2 = requant(a2, A.z, Sc.z, p.lo_f, p.hi_f);
-                    const int q3 = requant(a3, A.w, Sc.w, p.lo_f, p.hi_f);
+                    const int q0 = requant_t<MG>(a0, A.x, Sc.x, p.lo_f, p.hi_f);
+                    const int q1 = requant_t<MG>(a1, A.y, Sc.y, p.lo_f, p.hi_f);
+                    const int q2 = requant_t<MG>(a2, A.z, Sc.z, p.lo_f, p.hi_f);
+                    const int q3 = requant_t<MG>(a3, A.w, Sc.w, p.lo_f, p.hi_f);
                     dst[o] = pack4(q0, q1, q2, q3);
                 }
             }
@@ -574,11 +597,11 @@ __global__ __launch_bounds__(NTHR) void dw3x3_nhwc(const int8_t *__restrict__ in
 #pragma unroll
                     for (int j = 0; j < R; ++j) {
                         uint32_t *dp = dst + ((size_t)(g * OH + oy0 + j) * OW + ox0) * C4 + cg;
-                        dp[0] = pack4(requant(o0[j][0], A.x, Sc.x, p.lo_f, p.hi_f), requant(o0[j][1], A.y, Sc.y, p.lo_f, p.hi_f),
-                                      requant(o0[j][2], A.z, Sc.z, p.lo_f, p.hi_f), requant(o0[j][3], A.w, Sc.w, p.lo_f, p.hi_f));
+                        dp[0] = pack4(requant_t<MG>(o0[j][0], A.x, Sc.x, p.lo_f, p.hi_f), requant_t<MG>(o0[j][1], A.y, Sc.y, p.lo_f, p.hi_f),
+                                      requant_t<MG>(o0[j][2], A.z, Sc.z, p.lo_f, p.hi_f), requant_t<MG>(o0[j][3], A.w, Sc.w, p.lo_f, p.hi_f));
                         if (ox0 + 1 < OW)
-                            dp[C4] = pack4(requant(o1[j][0], A.x, Sc.x, p.lo_f, p.hi_f), requant(o1[j][1], A.y, Sc.y, p.lo_f, p.hi_f),
-                                           requant(o1[j][2], A.z, Sc.z, p.lo_f, p.hi_f), requant(o1[j][3], A.w, Sc.w, p.lo_f, p.hi_f));
+                            dp[C4] = pack4(requant_t<MG>(o1[j][0], A.x, Sc.x, p.lo_f, p.hi_f), requant_t<MG>(o1[j][1], A.y, Sc.y, p.lo_f, p.hi_f),
+                                           requant_t<MG>(o1[j][2], A.z, Sc.z, p.lo_f, p.hi_f), requant_t<MG>(o1[j][3], A.w, Sc.w, p.lo_f, p.hi_f));
                     }
                 }
             }
@@ -599,7 +622,7 @@ __global__ __launch_bounds__(NTHR) void dw3x3_nhwc(const int8_t *__restrict__ in
 // two izp rows; the only tap that is not covered by those rows, column -1 of the first
 // pixel pair, is patched with a select.
 // ------------------------------------------------------------------------
-template <int H, int W, int G>
+template <int H, int W, int G, bool MG>
 __global__ __launch_bounds__(256) void dw3x3_stem8(const int8_t *__restrict__ in,
                                                    int8_t *__restrict__ out, DwStemArgs p,
                                                    int batch) {
@@ -668,14 +691,14 @@ __global__ __launch_bounds__(256) void dw3x3_stem8(const int8_t *__restrict__ in
                 int qa[DM], qb[DM];
 #pragma unroll
                 for (int c = 0; c < DM; ++c) {
-                    int a = p.Kc[c], b = p.Kc[c];
+                    int a = p.Kc[c] + (MG ? MF_MAGIC_I : 0), b = a;
 #pragma unroll
                     for (int ky = 0; ky < 3; ++ky) {
                         a = sdot4(ta[ky], p.wrow[ky][c], a);
                         b = sdot4(tb[ky], p.wrow[ky][c], b);
                     }
-                    qa[c] = requant(a, p.A[c], p.S[c], p.lo_f, p.hi_f);
-                    qb[c] = requant(b, p.A[c], p.S[c], p.lo_f, p.hi_f);
+                    qa[c] = requant_t<MG>(a, p.A[c], p.S[c], p.lo_f, p.hi_f);
+                    qb[c] = requant_t<MG>(b, p.A[c], p.S[c], p.lo_f, p.hi_f);
                 }
                 uint4 v;
                 v.x = pack4(qa[0], qa[1], qa[2], qa[3]);
@@ -697,6 +720,7 @@ __global__ __launch_bounds__(256) void dw3x3_stem8(const int8_t *__restrict__ in
 // thread produces whole output pixels: one LDS byte + 8 multiply-adds per tap, 8 bytes per
 // store.  Every input byte is read from HBM once.
 // ------------------------------------------------------------------------
+template <bool MG>
 __global__ __launch_bounds__(256) void dw_c1_lds(const int8_t *__restrict__ in, int8_t *__restrict__ out,
                                                  DwC1Args p, size_t batch) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -711,7 +735,7 @@ __global__ __launch_bounds__(256) void dw_c1_lds(const int8_t *__restrict__ in, 
     float A[8], S[8];
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
-        Kc[c] = c < p.N ? p.Kc[c] : 0;
+        Kc[c] = (c < p.N ? p.Kc[c] : 0) + (MG ? MF_MAGIC_I : 0);
         A[c] = c < p.N ? p.A[c] : 0.0f;
         S[c] = c < p.N ? p.S[c] : 0.0f;
     }
@@ -740,7 +764,7 @@ __global__ __launch_bounds__(256) void dw_c1_lds(const int8_t *__restrict__ in, 
                 }
             int q[8];
 #pragma unroll
-            for (int c = 0; c < 8; ++c) q[c] = requant(acc[c], A[c], S[c], p.lo_f, p.hi_f);
+            for (int c = 0; c < 8; ++c) q[c] = requant_t<MG>(acc[c], A[c], S[c], p.lo_f, p.hi_f);
             int8_t *dst = out + (img * (size_t)p.OH * p.OW + o) * p.N;
             if (p.N == 8) {
                 *(uint2 *)dst = make_uint2(pack4(q[0], q[1], q[2], q[3]), pack4(q[4], q[5], q[6], q[7]));
@@ -773,7 +797,7 @@ __global__ __launch_bounds__(256) void dw_c1_lds(const int8_t *__restrict__ in, 
 // N > 64 is split over the waves of the workgroup (NSPLIT = N/64), which all read the
 // same pixels (L1/L2 hits).  HBM-bound: MFMA work is ~1/8 of the memory time.
 // ------------------------------------------------------------------------
-template <int K, int N>
+template <int K, int N, bool MG>
 __global__ __launch_bounds__(256) void pw_mfma(const int8_t *__restrict__ in,
                                                int8_t *__restrict__ out, PwArgs p,
                                                long long npix) {
@@ -818,7 +842,7 @@ __global__ __launch_bounds__(256) void pw_mfma(const int8_t *__restrict__ in,
         const int ch = blk * NB + g * (NB / 4) + 4 * tt;
         cA[tt] = *(const float4 *)(p.A + ch);
         cS[tt] = *(const float4 *)(p.S + ch);
-        cK[tt] = *(const int4 *)(p.Kc + ch);
+        cK[tt] = magic4<MG>(*(const int4 *)(p.Kc + ch));
     }
 
     const long long nchunks = (npix + CPIX - 1) / CPIX;
@@ -876,10 +900,10 @@ __global__ __launch_bounds__(256) void pw_mfma(const int8_t *__restrict__ in,
 #pragma unroll
                         for (int ks = 0; ks < KS; ++ks)
                             acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(Aw[q][tt][ks], B[u][ks], acc, 0, 0, 0);
-                        const int q0 = requant(acc[0], cA[tt].x, cS[tt].x, p.lo_f, p.hi_f);
-                        const int q1 = requant(acc[1], cA[tt].y, cS[tt].y, p.lo_f, p.hi_f);
-                        const int q2 = requant(acc[2], cA[tt].z, cS[tt].z, p.lo_f, p.hi_f);
-                        const int q3 = requant(acc[3], cA[tt].w, cS[tt].w, p.lo_f, p.hi_f);
+                        const int q0 = requant_t<MG>(acc[0], cA[tt].x, cS[tt].x, p.lo_f, p.hi_f);
+                        const int q1 = requant_t<MG>(acc[1], cA[tt].y, cS[tt].y, p.lo_f, p.hi_f);
+                        const int q2 = requant_t<MG>(acc[2], cA[tt].z, cS[tt].z, p.lo_f, p.hi_f);
+                        const int q3 = requant_t<MG>(acc[3], cA[tt].w, cS[tt].w, p.lo_f, p.hi_f);
                         packed[tt] = pack4(q0, q1, q2, q3);
                     }
                     if constexpr (XPOSE) {
@@ -933,7 +957,7 @@ __global__ __launch_bounds__(256) void pw_mfma(const int8_t *__restrict__ in,
 // tensor, it just never leaves the CU).  Single-buffered variants issue the next step's DMA
 // right after the second barrier, so it still overlaps the pointwise phase.
 // ------------------------------------------------------------------------
-template <int H, int W, int C, int S, int N, int G, int NTHR, bool DBUF>
+template <int H, int W, int C, int S, int N, int G, int NTHR, bool DBUF, bool MG>
 __global__ __launch_bounds__(NTHR) void dwpw3x3(const int8_t *__restrict__ in,
                                                 int8_t *__restrict__ out, DwPwArgs p, int batch) {
     // ---- depthwise geometry (as dw3x3_nhwc) ----
@@ -995,7 +1019,7 @@ __global__ __launch_bounds__(NTHR) void dwpw3x3(const int8_t *__restrict__ in,
         }
     }
     const float4 dA = ((const float4 *)p.dw.A)[cg], dS = ((const float4 *)p.dw.S)[cg];
-    const int4 dK = ((const int4 *)p.dw.Kc)[cg];
+    const int4 dK = magic4<MG>(((const int4 *)p.dw.Kc)[cg]);
 
     // ---- pointwise per-lane constants ----
     const int pcol = lane & 15, pg = lane >> 4;
@@ -1015,7 +1039,7 @@ __global__ __launch_bounds__(NTHR) void dwpw3x3(const int8_t *__restrict__ in,
         const int ch = blk * NB + pg * (NB / 4) + 4 * tt;
         cA[tt] = *(const float4 *)(p.pw.A + ch);
         cS[tt] = *(const float4 *)(p.pw.S + ch);
-        cK[tt] = *(const int4 *)(p.pw.Kc + ch);
+        cK[tt] = magic4<MG>(*(const int4 *)(p.pw.Kc + ch));
     }
     __syncthreads(); // halo fill complete before any DMA lands
 
@@ -1069,10 +1093,10 @@ __global__ __launch_bounds__(NTHR) void dwpw3x3(const int8_t *__restrict__ in,
                             a2 = sdot4(v, wm[t][2], a2);
                             a3 = sdot4(v, wm[t][3], a3);
                         }
-                    ((uint32_t *)mid)[o] = pack4(requant(a0, dA.x, dS.x, p.dw.lo_f, p.dw.hi_f),
-                                                 requant(a1, dA.y, dS.y, p.dw.lo_f, p.dw.hi_f),
-                                                 requant(a2, dA.z, dS.z, p.dw.lo_f, p.dw.hi_f),
-                                                 requant(a3, dA.w, dS.w, p.dw.lo_f, p.dw.hi_f));
+                    ((uint32_t *)mid)[o] = pack4(requant_t<MG>(a0, dA.x, dS.x, p.dw.lo_f, p.dw.hi_f),
+                                                 requant_t<MG>(a1, dA.y, dS.y, p.dw.lo_f, p.dw.hi_f),
+                                                 requant_t<MG>(a2, dA.z, dS.z, p.dw.lo_f, p.dw.hi_f),
+                                                 requant_t<MG>(a3, dA.w, dS.w, p.dw.lo_f, p.dw.hi_f));
                 }
             }
         } else {
@@ -1091,11 +1115,11 @@ __global__ __launch_bounds__(NTHR) void dwpw3x3(const int8_t *__restrict__ in,
 #pragma unroll
                     for (int j = 0; j < R; ++j) {
                         uint32_t *dp = (uint32_t *)mid + ((size_t)(g * OH + oy0 + j) * OW + ox0) * C4 + cg;
-                        dp[0] = pack4(requant(o0[j][0], dA.x, dS.x, p.dw.lo_f, p.dw.hi_f), requant(o0[j][1], dA.y, dS.y, p.dw.lo_f, p.dw.hi_f),
-                                      requant(o0[j][2], dA.z, dS.z, p.dw.lo_f, p.dw.hi_f), requant(o0[j][3], dA.w, dS.w, p.dw.lo_f, p.dw.hi_f));
+                        dp[0] = pack4(requant_t<MG>(o0[j][0], dA.x, dS.x, p.dw.lo_f, p.dw.hi_f), requant_t<MG>(o0[j][1], dA.y, dS.y, p.dw.lo_f, p.dw.hi_f),
+                                      requant_t<MG>(o0[j][2], dA.z, dS.z, p.dw.lo_f, p.dw.hi_f), requant_t<MG>(o0[j][3], dA.w, dS.w, p.dw.lo_f, p.dw.hi_f));
                         if (ox0 + 1 < OW)
-                            dp[C4] = pack4(requant(o1[j][0], dA.x, dS.x, p.dw.lo_f, p.dw.hi_f), requant(o1[j][1], dA.y, dS.y, p.dw.lo_f, p.dw.hi_f),
-                                           requant(o1[j][2], dA.z, dS.z, p.dw.lo_f, p.dw.hi_f), requant(o1[j][3], dA.w, dS.w, p.dw.lo_f, p.dw.hi_f));
+                            dp[C4] = pack4(requant_t<MG>(o1[j][0], dA.x, dS.x, p.dw.lo_f, p.dw.hi_f), requant_t<MG>(o1[j][1], dA.y, dS.y, p.dw.lo_f, p.dw.hi_f),
+                                           requant_t<MG>(o1[j][2], dA.z, dS.z, p.dw.lo_f, p.dw.hi_f), requant_t<MG>(o1[j][3], dA.w, dS.w, p.dw.lo_f, p.dw.hi_f));
                     }
                 }
             }
@@ -1142,10 +1166,10 @@ __global__ __launch_bounds__(NTHR) void dwpw3x3(const int8_t *__restrict__ in,
 #pragma unroll
                     for (int ks = 0; ks < KS; ++ks)
                         acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(Aw[q][tt][ks], B[ks], acc, 0, 0, 0);
-                    packed[tt] = pack4(requant(acc[0], cA[tt].x, cS[tt].x, p.pw.lo_f, p.pw.hi_f),
-                                       requant(acc[1], cA[tt].y, cS[tt].y, p.pw.lo_f, p.pw.hi_f),
-                                       requant(acc[2], cA[tt].z, cS[tt].z, p.pw.lo_f, p.pw.hi_f),
-                                       requant(acc[3], cA[tt].w, cS[tt].w, p.pw.lo_f, p.pw.hi_f));
+                    packed[tt] = pack4(requant_t<MG>(acc[0], cA[tt].x, cS[tt].x, p.pw.lo_f, p.pw.hi_f),
+                                       requant_t<MG>(acc[1], cA[tt].y, cS[tt].y, p.pw.lo_f, p.pw.hi_f),
+                                       requant_t<MG>(acc[2], cA[tt].z, cS[tt].z, p.pw.lo_f, p.pw.hi_f),
+                                       requant_t<MG>(acc[3], cA[tt].w, cS[tt].w, p.pw.lo_f, p.pw.hi_f));
                 }
                 if constexpr (XPOSE) {
                     uint8_t *dstp = lds + PATCH_OFF + wave * CBYTES + lpix * N + pg * (NB / 4);
@@ -1626,20 +1650,20 @@ void launch_checksum(const int8_t *in, size_t n, unsigned long long *result, hip
 }
 
 // ---- fast-path dispatch tables ------------------------------------------------
-template <int H, int W, int C, int S, int G, int NTHR>
+template <int H, int W, int C, int S, int G, int NTHR, bool MG>
 static void launch_dw(const int8_t *in, int8_t *out, const DwFastArgs &a, int batch, hipStream_t s) {
     constexpr int LP = C < 16 ? 16 : C;
     constexpr int lds = 2 * G * (H + 2) * (LP + W * C + LP) + 256; // two staging buffers + read slack
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)dw3x3_nhwc<H, W, C, S, G, NTHR>,
+        (void)hipFuncSetAttribute((const void *)dw3x3_nhwc<H, W, C, S, G, NTHR, MG>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
-    static const int per_cu = resident_per_cu(dw3x3_nhwc<H, W, C, S, G, NTHR>, NTHR, lds);
+    static const int per_cu = resident_per_cu(dw3x3_nhwc<H, W, C, S, G, NTHR, MG>, NTHR, lds);
     const int nsteps = (batch + G - 1) / G;
     const int grid = nsteps < 256 * per_cu ? nsteps : 256 * per_cu;
-    hipLaunchKernelGGL((dw3x3_nhwc<H, W, C, S, G, NTHR>), dim3(grid), dim3(NTHR), lds, s, in, out, a, batch);
+    hipLaunchKernelGGL((dw3x3_nhwc<H, W, C, S, G, NTHR, MG>), dim3(grid), dim3(NTHR), lds, s, in, out, a, batch);
 }
 
 const char *dw_fast_name(int H, int W, int C, int S) {
@@ -1653,7 +1677,8 @@ bool launch_dw_fast(int H, int W, int C, int S, const int8_t *in, int8_t *out, c
                     int batch, hipStream_t s) {
 #define MF_DW(h, w, c, st, g, t)                          \
     if (H == h && W == w && C == c && S == st) {          \
-        launch_dw<h, w, c, st, g, t>(in, out, a, batch, s); \
+        if (a.magic) launch_dw<h, w, c, st, g, t, true>(in, out, a, batch, s); \
+        else launch_dw<h, w, c, st, g, t, false>(in, out, a, batch, s);       \
         return true;                                      \
     }
     MF_DW_SHAPES(MF_DW)
@@ -1670,7 +1695,8 @@ bool dw_c1_supported(const DwC1Args &a) {
 }
 void launch_dw_c1(const int8_t *in, int8_t *out, const DwC1Args &a, size_t batch, hipStream_t s) {
     const int grid = (int)(batch < 256 * 8 ? batch : 256 * 8);
-    hipLaunchKernelGGL(dw_c1_lds, dim3(grid), dim3(256), dw_c1_lds_bytes(a), s, in, out, a, batch);
+    if (a.magic) hipLaunchKernelGGL(dw_c1_lds<true>, dim3(grid), dim3(256), dw_c1_lds_bytes(a), s, in, out, a, batch);
+    else hipLaunchKernelGGL(dw_c1_lds<false>, dim3(grid), dim3(256), dw_c1_lds_bytes(a), s, in, out, a, batch);
 }
 
 const char *dw_stem_name(int H, int W, int DM, int S) {
@@ -1681,16 +1707,17 @@ bool launch_dw_stem(int H, int W, int DM, int S, const int8_t *in, int8_t *out, 
                     int batch, hipStream_t s) {
     if (H == 96 && W == 96 && DM == 8 && S == 2) {
         constexpr int G = 2, lds = 2 * G * (16 + (96 + 2) * 96);
-        static const int per_cu = resident_per_cu(dw3x3_stem8<96, 96, G>, 256, lds);
+        static const int per_cu = resident_per_cu(dw3x3_stem8<96, 96, G, false>, 256, lds);
         const int nsteps = (batch + G - 1) / G;
         const int grid = nsteps < 256 * per_cu ? nsteps : 256 * per_cu;
-        hipLaunchKernelGGL((dw3x3_stem8<96, 96, G>), dim3(grid), dim3(256), lds, s, in, out, a, batch);
+        if (a.magic) hipLaunchKernelGGL((dw3x3_stem8<96, 96, G, true>), dim3(grid), dim3(256), lds, s, in, out, a, batch);
+        else hipLaunchKernelGGL((dw3x3_stem8<96, 96, G, false>), dim3(grid), dim3(256), lds, s, in, out, a, batch);
         return true;
     }
     return false;
 }
 
-template <int H, int W, int C, int S, int N, int G, int NTHR, int DB>
+template <int H, int W, int C, int S, int N, int G, int NTHR, int DB, bool MG>
 static void launch_dwpw_t(const int8_t *in, int8_t *out, const DwPwArgs &a, int batch, hipStream_t s) {
     constexpr int LP = C < 16 ? 16 : C;
     constexpr int OH = (H + S - 1) / S, OW = (W + S - 1) / S;
@@ -1701,14 +1728,14 @@ static void launch_dwpw_t(const int8_t *in, int8_t *out, const DwPwArgs &a, int 
     static_assert(lds <= 163840, "fused tile does not fit the LDS");
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)dwpw3x3<H, W, C, S, N, G, NTHR, (DB != 0)>,
+        (void)hipFuncSetAttribute((const void *)dwpw3x3<H, W, C, S, N, G, NTHR, (DB != 0), MG>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
-    static const int per_cu = resident_per_cu(dwpw3x3<H, W, C, S, N, G, NTHR, (DB != 0)>, NTHR, lds);
+    static const int per_cu = resident_per_cu(dwpw3x3<H, W, C, S, N, G, NTHR, (DB != 0), MG>, NTHR, lds);
     const int nsteps = (batch + G - 1) / G;
     const int grid = nsteps < 256 * per_cu ? nsteps : 256 * per_cu;
-    hipLaunchKernelGGL((dwpw3x3<H, W, C, S, N, G, NTHR, (DB != 0)>), dim3(grid), dim3(NTHR), lds, s, in, out, a, batch);
+    hipLaunchKernelGGL((dwpw3x3<H, W, C, S, N, G, NTHR, (DB != 0), MG>), dim3(grid), dim3(NTHR), lds, s, in, out, a, batch);
 }
 const char *dwpw_name(int H, int W, int C, int S, int N) {
 #define MF_DWPW(h, w, c, s, n, g, t, d) \
@@ -1725,7 +1752,8 @@ bool launch_dwpw(int H, int W, int C, int S, int N, const int8_t *in, int8_t *ou
         (void)idx;
 #define MF_DWPW(h, w, c, st, n, g, t, d)                                        \
     if (idx++ == alt && H == h && W == w && C == c && S == st && N == n) {      \
-        launch_dwpw_t<h, w, c, st, n, g, t, d>(in, out, a, batch, s);           \
+        if (a.dw.magic && a.pw.magic) launch_dwpw_t<h, w, c, st, n, g, t, d, true>(in, out, a, batch, s); \
+        else launch_dwpw_t<h, w, c, st, n, g, t, d, false>(in, out, a, batch, s); \
         return true;                                                            \
     }
         MF_DWPW_ALT_SHAPES(MF_DWPW)
@@ -1733,7 +1761,8 @@ bool launch_dwpw(int H, int W, int C, int S, int N, const int8_t *in, int8_t *ou
     }
 #define MF_DWPW(h, w, c, st, n, g, t, d)                         \
     if (H == h && W == w && C == c && S == st && N == n) {       \
-        launch_dwpw_t<h, w, c, st, n, g, t, d>(in, out, a, batch, s); \
+        if (a.dw.magic && a.pw.magic) launch_dwpw_t<h, w, c, st, n, g, t, d, true>(in, out, a, batch, s); \
+        else launch_dwpw_t<h, w, c, st, n, g, t, d, false>(in, out, a, batch, s); \
         return true;                                             \
     }
     MF_DWPW_SHAPES(MF_DWPW)
@@ -1770,7 +1799,8 @@ bool launch_pw(int K, int N, const int8_t *in, int8_t *out, const PwArgs &a, lon
         long long grid = (nchunks + SLOTS * U - 1) / (SLOTS * U);                               \
         if (grid > 256 * 8) grid = 256 * 8;                                                     \
         if (grid < 1) grid = 1;                                                                 \
-        hipLaunchKernelGGL((pw_mfma<k, n>), dim3((int)grid), dim3(256), 0, s, in, out, a, npix); \
+        if (a.magic) hipLaunchKernelGGL((pw_mfma<k, n, true>), dim3((int)grid), dim3(256), 0, s, in, out, a, npix); \
+        else hipLaunchKernelGGL((pw_mfma<k, n, false>), dim3((int)grid), dim3(256), 0, s, in, out, a, npix); \
         return true;                                                                            \
     }
     MF_PW_SHAPES(MF_PW)

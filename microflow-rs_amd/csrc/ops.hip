@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -100,11 +102,14 @@ struct OpImpl {
 namespace {
 
 // per-channel A/S/Kc/wzp arrays for the conv-like operators
-void fold_conv_constants(OpImpl &op, const OpSpec &s, bool depthwise, std::vector<float> &A,
-                         std::vector<float> &S, std::vector<int32_t> &Kc,
-                         std::vector<int32_t> &wzp) {
+// Returns the worst-case |acc| over all inputs: max|v - izp| * max_c sum_taps |w[c] - wzp[c]|
+// (acc = sum over ALL taps of (v' - izp)(w - wzp), the halo contributing 0).
+int64_t fold_conv_constants(OpImpl &op, const OpSpec &s, bool depthwise, std::vector<float> &A,
+                            std::vector<float> &S, std::vector<int32_t> &Kc,
+                            std::vector<int32_t> &wzp) {
     const int N = s.N;
     const int taps = s.KH * s.KW;
+    int64_t max_wabs = 0;
     A.resize(N), S.resize(N), Kc.resize(N), wzp.resize(N);
     for (int c = 0; c < N; ++c) {
         volatile float a = (float)s.ozp + s.c0[c]; // f32(ozp) + c0[c], rounded once, as the reference does first
@@ -113,18 +118,28 @@ void fold_conv_constants(OpImpl &op, const OpSpec &s, bool depthwise, std::vecto
         wzp[c] = s.wzp[c < s.nq ? c : 0];          // zero_point.get(b).unwrap_or(zero_point[0])
         int32_t wsum = 0;
         int32_t T;
+        int64_t wabs = 0;
         if (depthwise) { // weights [KH][KW][N]
-            for (int t = 0; t < taps; ++t) wsum = wrap_add(wsum, s.weights[(size_t)t * N + c]);
+            for (int t = 0; t < taps; ++t) {
+                wsum = wrap_add(wsum, s.weights[(size_t)t * N + c]);
+                wabs += std::abs((int)s.weights[(size_t)t * N + c] - wzp[c]);
+            }
             T = taps;
         } else { // filters [N][KH][KW][C]
             const int8_t *f = s.weights + (size_t)c * taps * s.C;
-            for (int t = 0; t < taps * s.C; ++t) wsum = wrap_add(wsum, f[t]);
+            for (int t = 0; t < taps * s.C; ++t) {
+                wsum = wrap_add(wsum, f[t]);
+                wabs += std::abs((int)f[t] - wzp[c]);
+            }
             T = taps * s.C;
         }
+        max_wabs = std::max(max_wabs, wabs);
         // Kc = -izp * sum(w) + T * izp * wzp   (k2 and k3 of the reference with the halo == izp)
         Kc[c] = wrap_add(wrap_sub(0, wrap_mul(s.izp, wsum)), wrap_mul(wrap_mul(T, s.izp), wzp[c]));
     }
     (void)op;
+    const int64_t vdev = std::max(127 - s.izp, s.izp + 128); // max |v - izp| over int8 v
+    return vdev * max_wabs;
 }
 
 bool all_zero(const std::vector<int32_t> &v) {
@@ -199,7 +214,11 @@ OpImpl *op_create(int device, const OpSpec &spec) {
         to_i8_domain(dw ? (size_t)s.KH * s.KW * s.N : (size_t)s.N * s.KH * s.KW * s.C);
         std::vector<float> A, S;
         std::vector<int32_t> Kc, wzp;
-        fold_conv_constants(*op, s, dw, A, S, Kc, wzp);
+        // the fast kernels may convert the accumulator to f32 by bit pattern when it provably
+        // stays below 2^22 in magnitude (requant_t<true> in kernels.hip)
+        static const bool no_magic = getenv("MF_NO_MAGIC") != nullptr; // tests: force the convert form
+        const int64_t acc_bound = fold_conv_constants(*op, s, dw, A, S, Kc, wzp);
+        const int magic = !no_magic && acc_bound < (1 << 22) ? 1 : 0;
         const size_t wbytes = dw ? (size_t)s.KH * s.KW * s.N : (size_t)s.N * s.KH * s.KW * s.C;
         op->d_w.upload(s.weights, wbytes);
         op->d_wzp.upload(wzp.data(), wzp.size() * 4);
@@ -225,7 +244,7 @@ OpImpl *op_create(int device, const OpSpec &spec) {
             k::DwFastArgs &f = op->dwf;
             f.w = a.w, f.A = a.A, f.S = a.S, f.Kc = a.Kc;
             f.izp4 = 0x01010101u * (uint32_t)(uint8_t)(int8_t)s.izp;
-            f.lo_f = a.lo_f, f.hi_f = a.hi_f;
+            f.lo_f = a.lo_f, f.hi_f = a.hi_f, f.magic = magic;
         } else if (dw && zero_wzp && same3x3 && s.C == 1 && k::dw_stem_name(s.H, s.W, s.N, s.sh)) {
             op->fast = OpImpl::DW_STEM;
             op->fast_name = k::dw_stem_name(s.H, s.W, s.N, s.sh);
@@ -239,13 +258,13 @@ OpImpl *op_create(int device, const OpSpec &spec) {
                 }
             for (int c = 0; c < 8; ++c) f.A[c] = A[c], f.S[c] = S[c], f.Kc[c] = Kc[c];
             f.izp4 = 0x01010101u * (uint32_t)(uint8_t)(int8_t)s.izp;
-            f.lo_f = a.lo_f, f.hi_f = a.hi_f;
+            f.lo_f = a.lo_f, f.hi_f = a.hi_f, f.magic = magic;
         } else if (dw && zero_wzp && s.C == 1 && s.N <= 8) {
             // one input channel, few output channels, any filter: LDS-staged direct kernel
             k::DwC1Args &f = op->dwc1;
             f.H = s.H, f.W = s.W, f.N = s.N, f.KH = s.KH, f.KW = s.KW, f.sh = s.sh, f.sw = s.sw;
             f.OH = s.OH, f.OW = s.OW, f.pad_same = s.pad == MF_PAD_SAME, f.izp = s.izp;
-            f.lo_f = a.lo_f, f.hi_f = a.hi_f, f.A = a.A, f.S = a.S, f.Kc = a.Kc;
+            f.lo_f = a.lo_f, f.hi_f = a.hi_f, f.A = a.A, f.S = a.S, f.Kc = a.Kc, f.magic = magic;
             if (k::dw_c1_supported(f)) {
                 std::vector<int32_t> w32((size_t)s.KH * s.KW * 8, 0);
                 for (int t = 0; t < s.KH * s.KW; ++t)
@@ -264,8 +283,13 @@ OpImpl *op_create(int device, const OpSpec &spec) {
             op->d_wprep.upload(prep.data(), prep.size());
             k::PwArgs &f = op->pw;
             f.wprep = op->d_wprep.p, f.A = a.A, f.S = a.S, f.Kc = a.Kc;
-            f.lo_f = a.lo_f, f.hi_f = a.hi_f;
+            f.lo_f = a.lo_f, f.hi_f = a.hi_f, f.magic = magic;
         }
+        if (getenv("MF_VERBOSE"))
+            fprintf(stderr, "[microflow_amd] %s %dx%dx%d -> %d: kernel %s, worst-case |acc| %lld%s\n",
+                    dw ? "depthwise_conv_2d" : "conv_2d", s.H, s.W, s.C, s.N,
+                    op->fast != OpImpl::NONE ? op->fast_name.c_str() : op->generic_name.c_str(),
+                    (long long)acc_bound, op->fast != OpImpl::NONE && magic ? " (bit-pattern int->f32)" : "");
         break;
     }
     case MF_OP_AVERAGE_POOL_2D: {

@@ -37,6 +37,21 @@ __global__ __launch_bounds__(256) void bench(uint32_t *out, uint32_t seed) {
             if (OP == 11) a[i] += lds[(threadIdx.x + i * 256 + it) & 4095];               // ds_read_b32 streaming
             if (OP == 12) a[i] = (uint32_t)(((int)(a[i] << 8) >> 8) * ((int)(w << 8) >> 8)) + a[i]; // mad_i24
             if (OP == 13) { int v = (int)f[i]; a[i] ^= (uint32_t)v; }                       // cvt_i32_f32 + xor
+            if (OP == 14) asm volatile("v_and_or_b32 %0, %1, %2, %3" : "=v"(a[i]) : "v"(a[i]), "s"(0x80000000u), "v"(w));
+            if (OP == 15) asm volatile("v_lshl_or_b32 %0, %1, 8, %2" : "=v"(a[i]) : "v"(a[i]), "v"(w));
+            if (OP == 16) asm volatile("v_xad_u32 %0, %1, %2, %3" : "=v"(a[i]) : "v"(a[i]), "s"(0x80u), "v"(w));
+            if (OP == 17) asm volatile("v_cvt_pk_u8_f32 %0, %1, 1, %2" : "=v"(a[i]) : "v"(f[i]), "v"(a[i]));
+            if (OP == 18) asm volatile("v_cvt_rpi_i32_f32 %0, %1" : "=v"(a[i]) : "v"(a[i]));
+            if (OP == 19) asm volatile("v_add3_u32 %0, %1, %2, %3" : "=v"(a[i]) : "v"(a[i]), "s"(0x80u), "v"(w));
+            if (OP == 20) asm volatile("v_or3_b32 %0, %1, %2, %3" : "=v"(a[i]) : "v"(a[i]), "s"(0x80u), "v"(w));
+            if (OP == 21) asm volatile("v_cvt_pk_i16_i32 %0, %1, %2" : "=v"(a[i]) : "v"(a[i]), "v"(w));
+            if (OP == 22) asm volatile("v_pk_max_i16 %0, %1, %2" : "=v"(a[i]) : "v"(a[i]), "v"(w));
+            if (OP == 23) asm volatile("v_sat_pk_u8_i16 %0, %1" : "=v"(a[i]) : "v"(a[i]));
+            if (OP == 24) asm volatile("v_trunc_f32 %0, %1" : "=v"(f[i]) : "v"(f[i]));
+            if (OP == 25) asm volatile("v_xor_b32 %0, %1, %2" : "=v"(a[i]) : "v"(a[i]), "v"(w));
+            if (OP == 26) asm volatile("v_max_f32 %0, %1, %2" : "=v"(f[i]) : "v"(f[i]), "v"(g));
+            if (OP == 27) asm volatile("v_max_i32 %0, %1, %2" : "=v"(a[i]) : "v"(a[i]), "v"(w));
+            if (OP == 28) asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(*(double *)&f[i & ~1]) : "v"(*(double *)&f[i & ~1]), "v"(*(double *)&f[i & ~1]));
         }
         if (OP == 7) { h = -h; }
     }
@@ -77,5 +92,19 @@ int main() {
     run<11>("ds_read_b32 streaming", 1, b);
     run<12>("v_mul_i24 + add (mad_i24)", 1, b);
     run<13>("cvt_i32_f32 + xor", 2, b);
+    run<14>("v_and_or_b32", 1, b);
+    run<15>("v_lshl_or_b32", 1, b);
+    run<16>("v_xad_u32", 1, b);
+    run<17>("v_cvt_pk_u8_f32", 1, b);
+    run<18>("v_cvt_rpi_i32_f32", 1, b);
+    run<19>("v_add3_u32", 1, b);
+    run<20>("v_or3_b32", 1, b);
+    run<21>("v_cvt_pk_i16_i32", 1, b);
+    run<22>("v_pk_max_i16", 1, b);
+    run<23>("v_sat_pk_u8_i16", 1, b);
+    run<24>("v_trunc_f32", 1, b);
+    run<25>("v_xor_b32", 1, b);
+    run<26>("v_max_f32", 1, b);
+    run<27>("v_max_i32", 1, b);
     return 0;
 }

@@ -359,3 +359,59 @@ def test_fully_connected_mfma_256_tile_schedule():
     r = subprocess.run([sys.executable, "-c", _TILE256_SCRIPT.format(root=root)], env=env, capture_output=True,
                        text=True, timeout=600)
     assert r.returncode == 0 and "tile256 ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_pointwise_accumulator_extremes(mf, O):
+    """Worst-case accumulators for the bit-pattern int->float conversion of the fast kernels
+    (|acc| < 2^22 is what the host checks): K = 128, |w| = 128, v - izp = 255 gives
+    |acc| = 4 177 920, just inside; the outputs must still equal the oracle's."""
+    H, W, C, N = 6, 6, 128, 128
+    rng = np.random.default_rng(77)
+    f = np.where(rng.integers(0, 2, (N, 1, 1, C)) > 0, 127, -128).astype(np.int8)
+    f[0] = -128                                   # channel 0: every weight -128
+    f[1] = 127                                    # channel 1: every weight +127
+    x = rng.integers(-128, 128, (4, H, W, C)).astype(np.int8)
+    x[0] = 127                                    # v - izp = 255 everywhere -> extreme sums
+    x[1, :, :, :] = np.where(f[2, 0, 0] > 0, 127, -128)   # aligned with channel 2's signs
+    fzp = np.zeros(N, np.int8)
+    izp, oscale, ozp, act = -128, 0.05, 0, 0
+    c0 = rng.uniform(-3, 3, N).astype(f32)
+    c1 = np.full(N, 100.0 / 4177920.0, f32) * rng.uniform(0.9, 1.1, N).astype(f32)
+    opts = mf.ops.Conv2DOptions(mf.FusedActivation(act), mf.TensorViewPadding.SAME, (1, 1))
+    op = mf.ops.prepare_conv_2d((H, W, C), f, fzp, izp, oscale, ozp, opts, (c0, c1), (H, W))
+    assert op.kernel.startswith("pw_mfma"), op.kernel
+    want = np.stack([O.conv_2d(v, f, fzp, izp, oscale, ozp, act, 0, (1, 1), (H, W), c0, c1) for v in x])
+    got = op(x)
+    assert np.array_equal(got, want), np.argwhere(got != want)[:5]
+    assert want[0, 0, 0, 0] < -90 and want[0, 0, 0, 1] > 90   # the extremes are not clamped away
+    op.set_generic(True)
+    assert np.array_equal(op(x), want)
+
+
+_NO_MAGIC_SCRIPT = r"""
+import sys, numpy as np
+sys.path.insert(0, {root!r})
+import microflow_rs_amd as mf
+from oracle import oracle as O
+from tests.synth import synth_i8
+for name, cfg, n in (("person_detect", 3, 5), ("speech", 2, 9)):
+    path = {root!r} + "/models/" + name + ".tflite"
+    m, om = mf.model(path), O.Model(path)
+    x = synth_i8(cfg, 0, n, m.input_elems)
+    assert np.array_equal(m.run_quantized(x).reshape(n, -1), om.run_quantized_batch(x)), name
+    m.set_fusion(False)
+    assert np.array_equal(m.run_quantized(x).reshape(n, -1), om.run_quantized_batch(x)), name
+print("no-magic ok")
+"""
+
+
+def test_models_without_magic_accumulators():
+    """MF_NO_MAGIC=1 forces the v_cvt_f32_i32 form of every fast kernel (the variant used when
+    an operator's worst-case accumulator could reach 2^22): same results."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MF_NO_MAGIC="1")
+    r = subprocess.run([sys.executable, "-c", _NO_MAGIC_SCRIPT.format(root=root)], env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0 and "no-magic ok" in r.stdout, r.stdout + r.stderr
