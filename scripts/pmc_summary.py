@@ -30,8 +30,16 @@ def short(name):
     m = re.search(r"mf::k::([A-Za-z0-9_]+)(<[^>]*>)?", name)
     if not m:
         return name[:40]
-    # rocprofv3 prints bool template arguments as true/false, the library's names use 1/0
-    return m.group(1) + (m.group(2) or "").replace(" ", "").replace(",true>", ",1>").replace(",false>", ",0>")
+    # rocprofv3 prints bool template arguments as true/false, the library's names use 1/0; the
+    # trailing MG argument (bit-pattern int->f32 variant) is not part of the library's names
+    base, args = m.group(1), (m.group(2) or "").replace(" ", "").replace("true", "1").replace("false", "0")
+    if base in ("dw3x3_nhwc", "dw3x3_stem8", "pw_mfma", "dwpw3x3") and args.count(","):
+        args = args[: args.rindex(",")] + ">"
+    if base == "dw_c1_lds":
+        args = ""
+    if base == "dw3x3_stem8":
+        args = "<96,96,2>"
+    return base + args
 
 
 def main():
