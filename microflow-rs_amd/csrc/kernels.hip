@@ -22,6 +22,8 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <atomic>
+
 #include "kernels.hpp"
 
 namespace mf {
@@ -1561,12 +1563,25 @@ __global__ __launch_bounds__(256) void fc_rowsum(const int8_t *__restrict__ in, 
 // Persistent-workgroup kernels launch exactly as many workgroups as are resident (LDS-,
 // VGPR- or wave-limited, asked of the runtime once per kernel), so every workgroup walks the
 // same number of steps and none queues behind a finished one.
-template <typename Kern> static int resident_per_cu(Kern kern, int threads, int lds_bytes) {
-    int n = 0;
+// Function attributes and occupancy are per DEVICE, and one process may drive several GPUs, so
+// each launcher keeps one slot per device (benign race: two threads may both prepare a slot).
+struct LaunchState {
+    static constexpr int MAX_DEV = 64;
+    std::atomic<int> per_cu[MAX_DEV];
+};
+template <typename Kern> static int prepared(LaunchState &st, Kern kern, int threads, int lds_bytes) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= LaunchState::MAX_DEV) dev = LaunchState::MAX_DEV - 1;
+    int n = st.per_cu[dev].load(std::memory_order_relaxed);
+    if (n > 0 && dev != LaunchState::MAX_DEV - 1) return n;
+    if (lds_bytes > 64 * 1024)
+        (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    n = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, threads, (size_t)lds_bytes) != hipSuccess || n < 1) {
         (void)hipGetLastError();
         n = 1;
     }
+    st.per_cu[dev].store(n, std::memory_order_relaxed);
     return n;
 }
 
@@ -1611,12 +1626,8 @@ void launch_fc_rowsum(const int8_t *in, int *rowsum, size_t rows, int K, hipStre
 template <int BM, int BN, int WM, int WN, bool STAGGER>
 static void launch_fc_mfma_t(const int8_t *in, int8_t *out, const FcGemmArgs &a, hipStream_t s) {
     constexpr int lds = 2 * (BM + BN) * 128;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)fc_mfma<BM, BN, WM, WN, STAGGER>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_set = true;
-    }
+    static LaunchState st;
+    (void)prepared(st, fc_mfma<BM, BN, WM, WN, STAGGER>, 64 * WM * WN, lds);
     const int grid = (a.M / BM) * (a.N / BN);
     hipLaunchKernelGGL((fc_mfma<BM, BN, WM, WN, STAGGER>), dim3(grid), dim3(64 * WM * WN), lds, s, in, out, a);
 }
@@ -1654,13 +1665,8 @@ template <int H, int W, int C, int S, int G, int NTHR, bool MG>
 static void launch_dw(const int8_t *in, int8_t *out, const DwFastArgs &a, int batch, hipStream_t s) {
     constexpr int LP = C < 16 ? 16 : C;
     constexpr int lds = 2 * G * (H + 2) * (LP + W * C + LP) + 256; // two staging buffers + read slack
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)dw3x3_nhwc<H, W, C, S, G, NTHR, MG>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_set = true;
-    }
-    static const int per_cu = resident_per_cu(dw3x3_nhwc<H, W, C, S, G, NTHR, MG>, NTHR, lds);
+    static LaunchState st;
+    const int per_cu = prepared(st, dw3x3_nhwc<H, W, C, S, G, NTHR, MG>, NTHR, lds);
     const int nsteps = (batch + G - 1) / G;
     const int grid = nsteps < 256 * per_cu ? nsteps : 256 * per_cu;
     hipLaunchKernelGGL((dw3x3_nhwc<H, W, C, S, G, NTHR, MG>), dim3(grid), dim3(NTHR), lds, s, in, out, a, batch);
@@ -1707,7 +1713,9 @@ bool launch_dw_stem(int H, int W, int DM, int S, const int8_t *in, int8_t *out, 
                     int batch, hipStream_t s) {
     if (H == 96 && W == 96 && DM == 8 && S == 2) {
         constexpr int G = 2, lds = 2 * G * (16 + (96 + 2) * 96);
-        static const int per_cu = resident_per_cu(dw3x3_stem8<96, 96, G, false>, 256, lds);
+        static LaunchState st0, st1;
+        const int per_cu = a.magic ? prepared(st1, dw3x3_stem8<96, 96, G, true>, 256, lds)
+                                   : prepared(st0, dw3x3_stem8<96, 96, G, false>, 256, lds);
         const int nsteps = (batch + G - 1) / G;
         const int grid = nsteps < 256 * per_cu ? nsteps : 256 * per_cu;
         if (a.magic) hipLaunchKernelGGL((dw3x3_stem8<96, 96, G, true>), dim3(grid), dim3(256), lds, s, in, out, a, batch);
@@ -1726,13 +1734,8 @@ static void launch_dwpw_t(const int8_t *in, int8_t *out, const DwPwArgs &a, int 
     constexpr int patch = (NB / 16 < 4) ? (NTHR / 64) * CPIX * N : 0;
     constexpr int lds = (DB ? 2 : 1) * BUF + 256 + G * OH * OW * C + 64 + patch;
     static_assert(lds <= 163840, "fused tile does not fit the LDS");
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)dwpw3x3<H, W, C, S, N, G, NTHR, (DB != 0), MG>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_set = true;
-    }
-    static const int per_cu = resident_per_cu(dwpw3x3<H, W, C, S, N, G, NTHR, (DB != 0), MG>, NTHR, lds);
+    static LaunchState st;
+    const int per_cu = prepared(st, dwpw3x3<H, W, C, S, N, G, NTHR, (DB != 0), MG>, NTHR, lds);
     const int nsteps = (batch + G - 1) / G;
     const int grid = nsteps < 256 * per_cu ? nsteps : 256 * per_cu;
     hipLaunchKernelGGL((dwpw3x3<H, W, C, S, N, G, NTHR, (DB != 0), MG>), dim3(grid), dim3(NTHR), lds, s, in, out, a, batch);

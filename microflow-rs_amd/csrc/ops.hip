@@ -462,6 +462,7 @@ void op_run(OpImpl *op, const int8_t *d_in, size_t batch, int8_t *d_out, void *s
 
 // The C ABI's mf_op_run: a u8 operator takes and returns real u8 bytes.
 void op_run_external(OpImpl *op, const int8_t *d_in, size_t batch, int8_t *d_out, void *stream) {
+    MF_HIP(hipSetDevice(op->device)); // the operator's buffers and kernels live on its device
     if (!op->s.u8) return op_run(op, d_in, batch, d_out, stream);
     if (!batch) return;
     if (!d_in || !d_out) fail(MF_ERR_INVALID_ARG, "op_run: null device pointer");
