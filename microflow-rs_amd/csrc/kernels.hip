@@ -717,22 +717,30 @@ __global__ __launch_bounds__(256) void dw3x3_stem8(const int8_t *__restrict__ in
 // FAST PATH 2b -- DepthwiseConv2D with ONE input channel, up to 8 output channels, any filter
 // size / stride / padding (speech.tflite op 1: 49x40x1 -> 25x20x8, 10x8 filter, stride 2).
 // (src/ops/depthwise_conv_2d.rs:67: every output channel reads input channel 0.)
-// One workgroup stages one image in LDS inside an izp halo (so SAME padding needs no
-// per-tap test), the filter as int32 [tap][8] in LDS (a broadcast read per tap), and each
-// thread produces whole output pixels: one LDS byte + 8 multiply-adds per tap, 8 bytes per
-// store.  Every input byte is read from HBM once.
+// With one input channel the taps of a filter row are CONSECUTIVE input bytes, so a row of the
+// window is KG = ceil(KW/4) dwords and every (filter row, 4-tap group, output channel) is one
+// real 4-MAC v_dot4: 160 dot4 per output pixel for the 10x8 filter instead of 640 multiply-adds.
+//   tile   : one workgroup stages one image in LDS inside an izp halo (SAME padding needs no
+//            per-tap test); rows are padded to a multiple of 4 bytes (+4 of over-read room).
+//   window : a thread owns one output pixel; its row start (ox*sw) is not dword aligned in
+//            general, so it reads KG+1 aligned dwords and shifts with v_alignbyte.
+//   weights: packed on the host as [ky][group][8 channels] dwords (zero beyond KW / N), read
+//            from LDS as broadcast b128s.
+// Every input byte is read from HBM once; the kernel is VALU-bound (54 MAC per byte).
 // ------------------------------------------------------------------------
 template <bool MG>
-__global__ __launch_bounds__(256) void dw_c1_lds(const int8_t *__restrict__ in, int8_t *__restrict__ out,
+__global__ __launch_bounds__(512) void dw_c1_lds(const int8_t *__restrict__ in, int8_t *__restrict__ out,
                                                  DwC1Args p, size_t batch) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int shy = p.pad_same ? (p.KH - 1) / 2 : 0, shx = p.pad_same ? (p.KW - 1) / 2 : 0;
     // halo'd tile covering every tap of every output pixel
-    const int TH = (p.OH - 1) * p.sh + p.KH, TW = (p.OW - 1) * p.sw + p.KW;
-    const int tile_bytes = (TH * TW + 15) & ~15;
-    int *wl = (int *)(lds + tile_bytes);
-    const int taps = p.KH * p.KW, tid = threadIdx.x;
-    for (int i = tid; i < taps * 8; i += 256) wl[i] = p.w32[i];
+    const int TH = (p.OH - 1) * p.sh + p.KH;
+    const int TWP = p.TWP, KG = p.KG;
+    const int tile_bytes = (TH * TWP + 4 + 15) & ~15;
+    uint32_t *wl = (uint32_t *)(lds + tile_bytes);
+    const int tid = threadIdx.x;
+    for (int i = tid; i < p.KH * KG * 8; i += 512) wl[i] = p.wpack[i];
+    for (int i = TH * TWP + tid; i < tile_bytes; i += 512) lds[i] = 0; // over-read room past the last row
     int Kc[8];
     float A[8], S[8];
 #pragma unroll
@@ -741,29 +749,56 @@ __global__ __launch_bounds__(256) void dw_c1_lds(const int8_t *__restrict__ in, 
         A[c] = c < p.N ? p.A[c] : 0.0f;
         S[c] = c < p.N ? p.S[c] : 0.0f;
     }
+    // tile element i = tid + 512 e comes from image byte gofs[e] (or is halo: -1); the same for
+    // every image, so the divisions happen once and an image's loads are issued back to back
+    constexpr int MAXE = 8;
+    int gofs[MAXE];
+#pragma unroll
+    for (int e = 0; e < MAXE; ++e) {
+        const int i = tid + 512 * e;
+        const int ty = i / TWP, tx = i - ty * TWP;
+        const int iy = ty - shy, ix = tx - shx;
+        gofs[e] = (i < TH * TWP && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) ? iy * p.W + ix : -1;
+    }
     for (size_t img = blockIdx.x; img < batch; img += gridDim.x) {
-        __syncthreads(); // previous image fully consumed
         const int8_t *x = in + img * (size_t)p.H * p.W;
-        for (int i = tid; i < TH * TW; i += 256) {
-            const int ty = i / TW, tx = i % TW;
+        int8_t v[MAXE];
+#pragma unroll
+        for (int e = 0; e < MAXE; ++e) v[e] = x[gofs[e] < 0 ? 0 : gofs[e]]; // clamped, unconditional
+        __syncthreads(); // previous image fully consumed
+#pragma unroll
+        for (int e = 0; e < MAXE; ++e)
+            if (tid + 512 * e < TH * TWP) ((int8_t *)lds)[tid + 512 * e] = gofs[e] < 0 ? (int8_t)p.izp : v[e];
+        for (int i = tid + 512 * MAXE; i < TH * TWP; i += 512) { // tiles above 4 KiB: the plain way
+            const int ty = i / TWP, tx = i - ty * TWP;
             const int iy = ty - shy, ix = tx - shx;
+            // columns TW .. TWP-1 only ever meet zero weights; any finite value will do
             ((int8_t *)lds)[i] = (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) ? x[iy * p.W + ix] : (int8_t)p.izp;
         }
         __syncthreads();
-        for (int o = tid; o < p.OH * p.OW; o += 256) {
-            const int oy = o / p.OW, ox = o % p.OW;
+        for (int o = tid; o < p.OH * p.OW; o += 512) {
+            const int oy = o / p.OW, ox = o - oy * p.OW;
             int acc[8];
 #pragma unroll
             for (int c = 0; c < 8; ++c) acc[c] = Kc[c];
-            const int8_t *t0 = (const int8_t *)lds + (oy * p.sh) * TW + ox * p.sw;
-            for (int ky = 0; ky < p.KH; ++ky)
-                for (int kx = 0; kx < p.KW; ++kx) {
-                    const int v = t0[ky * TW + kx];
-                    const int4 w0 = *(const int4 *)(wl + (ky * p.KW + kx) * 8);
-                    const int4 w1 = *(const int4 *)(wl + (ky * p.KW + kx) * 8 + 4);
-                    acc[0] += v * w0.x, acc[1] += v * w0.y, acc[2] += v * w0.z, acc[3] += v * w0.w;
-                    acc[4] += v * w1.x, acc[5] += v * w1.y, acc[6] += v * w1.z, acc[7] += v * w1.w;
+            const int base0 = (oy * p.sh) * TWP + ox * p.sw;
+            for (int ky = 0; ky < p.KH; ++ky) {
+                const int base = base0 + ky * TWP;
+                const uint32_t *row = (const uint32_t *)(lds + (base & ~3));
+                const uint32_t sh = (uint32_t)(base & 3);
+                uint32_t lo = row[0];
+                for (int g = 0; g < KG; ++g) {
+                    const uint32_t hi = row[g + 1];
+                    const uint32_t v = __builtin_amdgcn_alignbyte(hi, lo, sh); // bytes base+4g .. base+4g+3
+                    lo = hi;
+                    const uint4 w0 = *(const uint4 *)(wl + (ky * KG + g) * 8);
+                    const uint4 w1 = *(const uint4 *)(wl + (ky * KG + g) * 8 + 4);
+                    acc[0] = sdot4(v, w0.x, acc[0]), acc[1] = sdot4(v, w0.y, acc[1]);
+                    acc[2] = sdot4(v, w0.z, acc[2]), acc[3] = sdot4(v, w0.w, acc[3]);
+                    acc[4] = sdot4(v, w1.x, acc[4]), acc[5] = sdot4(v, w1.y, acc[5]);
+                    acc[6] = sdot4(v, w1.z, acc[6]), acc[7] = sdot4(v, w1.w, acc[7]);
                 }
+            }
             int q[8];
 #pragma unroll
             for (int c = 0; c < 8; ++c) q[c] = requant_t<MG>(acc[c], A[c], S[c], p.lo_f, p.hi_f);
@@ -1693,16 +1728,16 @@ bool launch_dw_fast(int H, int W, int C, int S, const int8_t *in, int8_t *out, c
 }
 
 static int dw_c1_lds_bytes(const DwC1Args &a) {
-    const int TH = (a.OH - 1) * a.sh + a.KH, TW = (a.OW - 1) * a.sw + a.KW;
-    return ((TH * TW + 15) & ~15) + a.KH * a.KW * 8 * 4;
+    const int TH = (a.OH - 1) * a.sh + a.KH;
+    return ((TH * a.TWP + 4 + 15) & ~15) + a.KH * a.KG * 8 * 4;
 }
 bool dw_c1_supported(const DwC1Args &a) {
     return a.N >= 1 && a.N <= 8 && dw_c1_lds_bytes(a) <= 64 * 1024;
 }
 void launch_dw_c1(const int8_t *in, int8_t *out, const DwC1Args &a, size_t batch, hipStream_t s) {
     const int grid = (int)(batch < 256 * 8 ? batch : 256 * 8);
-    if (a.magic) hipLaunchKernelGGL(dw_c1_lds<true>, dim3(grid), dim3(256), dw_c1_lds_bytes(a), s, in, out, a, batch);
-    else hipLaunchKernelGGL(dw_c1_lds<false>, dim3(grid), dim3(256), dw_c1_lds_bytes(a), s, in, out, a, batch);
+    if (a.magic) hipLaunchKernelGGL(dw_c1_lds<true>, dim3(grid), dim3(512), dw_c1_lds_bytes(a), s, in, out, a, batch);
+    else hipLaunchKernelGGL(dw_c1_lds<false>, dim3(grid), dim3(512), dw_c1_lds_bytes(a), s, in, out, a, batch);
 }
 
 const char *dw_stem_name(int H, int W, int DM, int S) {

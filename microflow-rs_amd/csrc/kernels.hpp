@@ -82,7 +82,8 @@ struct DwC1Args {
     int H, W, N, KH, KW, sh, sw, OH, OW, pad_same;
     int izp;
     float lo_f, hi_f;
-    const int *w32;     // [KH*KW][8] weights widened to int (zero padded to 8 channels)
+    int KG, TWP;        // 4-tap groups per filter row = ceil(KW/4); LDS tile row pitch (bytes, multiple of 4)
+    const uint32_t *wpack; // [KH][KG][8]: bytes (w[ky][4g..4g+3][c]), zero beyond KW and beyond N
     const float *A;
     const float *S;
     const int *Kc;

@@ -265,12 +265,18 @@ OpImpl *op_create(int device, const OpSpec &spec) {
             f.H = s.H, f.W = s.W, f.N = s.N, f.KH = s.KH, f.KW = s.KW, f.sh = s.sh, f.sw = s.sw;
             f.OH = s.OH, f.OW = s.OW, f.pad_same = s.pad == MF_PAD_SAME, f.izp = s.izp;
             f.lo_f = a.lo_f, f.hi_f = a.hi_f, f.A = a.A, f.S = a.S, f.Kc = a.Kc, f.magic = magic;
+            f.KG = (s.KW + 3) / 4;
+            // a window row is read as KG + 1 aligned dwords starting at (row start & ~3)
+            f.TWP = ((((s.OW - 1) * s.sw + 3) & ~3) + 4 * (f.KG + 1) + 3) & ~3;
             if (k::dw_c1_supported(f)) {
-                std::vector<int32_t> w32((size_t)s.KH * s.KW * 8, 0);
-                for (int t = 0; t < s.KH * s.KW; ++t)
-                    for (int c = 0; c < s.N; ++c) w32[(size_t)t * 8 + c] = s.weights[(size_t)t * s.N + c];
-                op->d_wprep.upload(w32.data(), w32.size() * 4);
-                f.w32 = op->d_wprep.as<int>();
+                std::vector<uint32_t> wp((size_t)s.KH * f.KG * 8, 0);
+                for (int ky = 0; ky < s.KH; ++ky)
+                    for (int kx = 0; kx < s.KW; ++kx)
+                        for (int c = 0; c < s.N; ++c)
+                            wp[((size_t)ky * f.KG + kx / 4) * 8 + c] |=
+                                (uint32_t)(uint8_t)s.weights[((size_t)ky * s.KW + kx) * s.N + c] << (8 * (kx & 3));
+                op->d_wprep.upload(wp.data(), wp.size() * 4);
+                f.wpack = op->d_wprep.as<uint32_t>();
                 op->fast = OpImpl::DW_C1;
                 op->fast_name = "dw_c1_lds";
             }

@@ -140,6 +140,10 @@ DW_CASES = [
     (3, 3, 256, 256, 3, 3, 1, 1, 0, 3, 3, False, 3),
     (96, 96, 1, 8, 3, 3, 2, 2, 0, 48, 48, False, 3),     # stem
     (49, 40, 1, 8, 10, 8, 2, 2, 0, 25, 20, False, 1),    # speech op 1
+    (13, 11, 1, 5, 5, 7, 1, 3, 0, 13, 4, False, 0),      # one input channel: odd filter, stride 3, N < 8
+    (9, 9, 1, 8, 2, 2, 1, 1, 1, 8, 8, False, 3),         # one input channel, VALID, 2x2
+    (10, 12, 1, 3, 3, 9, 2, 1, 0, 5, 12, False, 0),      # one input channel, 9-wide rows (3 dword groups)
+    (30, 30, 1, 8, 1, 1, 1, 1, 0, 30, 30, False, 1),     # one input channel, 1x1 filter, > 512 pixels
     (7, 9, 3, 3, 3, 3, 1, 1, 0, 7, 9, True, 0),          # generic, non-zero weight zp
     (8, 8, 4, 4, 2, 3, 1, 2, 1, 7, 3, True, 3),          # VALID, rectangular
     (5, 6, 2, 6, 3, 3, 1, 1, 0, 5, 6, True, 0),          # channels beyond Cin read channel 0
