@@ -11,7 +11,7 @@ use proc_macro::TokenStream;
 use quote::quote;
 use syn::{parse_macro_input, ItemStruct, LitStr};
 
-mod shapes; // fn model_io_shapes(bytes: &[u8]) -> Result<(Vec<usize>, Vec<usize>), String>
+mod shapes; // fn model_io_shapes(bytes: &[u8]) -> Result<(Vec<usize>, Vec<usize>, bool), String>
 
 #[proc_macro_attribute]
 pub fn model(args: TokenStream, item: TokenStream) -> TokenStream {
@@ -21,8 +21,10 @@ pub fn model(args: TokenStream, item: TokenStream) -> TokenStream {
     let bytes = std::fs::read(path.value()).unwrap_or_else(|_| {
         panic!("couldn't find '{}', please provide a valid path", path.value()) // lib.rs:50-55
     });
-    let (ishape, oshape) = shapes::model_io_shapes(&bytes)
+    let (ishape, oshape, is_u8) = shapes::model_io_shapes(&bytes)
         .unwrap_or_else(|e| panic!("{e}")); // "invalid model, ..." / "unsupported ..." (lib.rs:56-96,148)
+    // element type of predict_quantized's input, like microflow-macros/src/lib.rs:71-78
+    let (qty, qcall) = if is_u8 { (quote!(u8), quote!(predict_quantized_u8)) } else { (quote!(i8), quote!(predict_quantized)) };
     let (ibuf, flatten) = match ishape.len() {
         2 => (quote!(Buffer2D), quote!(flatten_2d)),
         _ => (quote!(Buffer4D), quote!(flatten_4d)),
@@ -46,10 +48,10 @@ pub fn model(args: TokenStream, item: TokenStream) -> TokenStream {
                 let v = microflow_amd::layout::#flatten(&input);
                 microflow_amd::layout::#unflatten(&Self::handle().predict(&v, 1))
             }
-            pub fn predict_quantized(input: microflow_amd::buffer::#ibuf<i8, #(#ishape),*>)
+            pub fn predict_quantized(input: microflow_amd::buffer::#ibuf<#qty, #(#ishape),*>)
                 -> microflow_amd::buffer::#obuf<f32, #(#oshape),*> {
                 let v = microflow_amd::layout::#flatten(&input);
-                microflow_amd::layout::#unflatten(&Self::handle().predict_quantized(&v, 1))
+                microflow_amd::layout::#unflatten(&Self::handle().#qcall(&v, 1))
             }
             /// New surface: B independent inferences in one launch sequence.
             pub fn predict_batch(inputs: &[microflow_amd::buffer::#ibuf<f32, #(#ishape),*>])

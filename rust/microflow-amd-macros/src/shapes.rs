@@ -14,11 +14,12 @@ fn field(b: &[u8], table: usize, id: usize) -> Option<usize> {
 fn indirect(b: &[u8], o: usize) -> Option<usize> { Some(o + u32_at(b, o)?) }
 fn vec_elem_table(b: &[u8], v: usize, i: usize) -> Option<usize> { indirect(b, v + 4 + 4 * i) }
 
-fn tensor_shape(b: &[u8], tensors: usize, idx: usize) -> Result<Vec<usize>, String> {
+/// (shape, is_u8) of tensor `idx`: TensorType INT8 = 9 or UINT8 = 3 (microflow-macros/src/lib.rs:71-78)
+fn tensor_shape(b: &[u8], tensors: usize, idx: usize) -> Result<(Vec<usize>, bool), String> {
     let bad = || "invalid model, please provide a valid TensorFlow Lite model".to_string();
     let t = vec_elem_table(b, tensors, idx).ok_or_else(bad)?;
     let ty = field(b, t, 1).and_then(|o| b.get(o).copied()).unwrap_or(0);
-    if ty != 9 { // INT8 only in this build (UINT8 = 3 is SURVEY 8f #4)
+    if ty != 9 && ty != 3 {
         return Err(format!("unsupported tensor type: {ty}. Supported types are INT8 and UINT8"));
     }
     let sh = field(b, t, 0).and_then(|o| indirect(b, o)).ok_or_else(bad)?;
@@ -28,10 +29,11 @@ fn tensor_shape(b: &[u8], tensors: usize, idx: usize) -> Result<Vec<usize>, Stri
     if shape.len() != 2 && shape.len() != 4 {
         return Err(format!("unsupported tensor rank: {}. Supported ranks are 2 and 4", shape.len()));
     }
-    Ok(shape)
+    Ok((shape, ty == 3))
 }
 
-pub fn model_io_shapes(b: &[u8]) -> Result<(Vec<usize>, Vec<usize>), String> {
+/// (input shape, output shape, element type is u8)
+pub fn model_io_shapes(b: &[u8]) -> Result<(Vec<usize>, Vec<usize>, bool), String> {
     let bad = || "invalid model, please provide a valid TensorFlow Lite model".to_string();
     let model = u32_at(b, 0).ok_or_else(bad)?;
     let sgs = field(b, model, 2).and_then(|o| indirect(b, o)).ok_or_else(bad)?;
@@ -41,5 +43,10 @@ pub fn model_io_shapes(b: &[u8]) -> Result<(Vec<usize>, Vec<usize>), String> {
     let outs = field(b, sg, 2).and_then(|o| indirect(b, o)).ok_or_else(bad)?;
     let i0 = i32_at(b, ins + 4).ok_or_else(bad)? as usize;
     let o0 = i32_at(b, outs + 4).ok_or_else(bad)? as usize;
-    Ok((tensor_shape(b, tensors, i0)?, tensor_shape(b, tensors, o0)?))
+    let (ishape, iu8) = tensor_shape(b, tensors, i0)?;
+    let (oshape, ou8) = tensor_shape(b, tensors, o0)?;
+    if iu8 != ou8 {
+        return Err("model input and output element types differ (mixed INT8/UINT8)".to_string());
+    }
+    Ok((ishape, oshape, iu8))
 }

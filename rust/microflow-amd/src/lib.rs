@@ -99,6 +99,17 @@ impl Model {
         check(unsafe { mf_model_predict_quantized(self.raw, input.as_ptr(), batch, out.as_mut_ptr(), MF_MEM_HOST) });
         out
     }
+    /// The same entry point for a UINT8 model (`info.element_type == 1`): the ABI's `int8_t*`
+    /// parameter carries the raw u8 bytes.
+    pub fn predict_quantized_u8(&mut self, input: &[u8], batch: usize) -> Vec<f32> {
+        assert_eq!(self.info.element_type, 1);
+        assert_eq!(input.len(), batch * self.info.input_elems);
+        let mut out = vec![0f32; batch * self.info.output_elems];
+        check(unsafe {
+            mf_model_predict_quantized(self.raw, input.as_ptr() as *const i8, batch, out.as_mut_ptr(), MF_MEM_HOST)
+        });
+        out
+    }
 }
 impl Drop for Model {
     fn drop(&mut self) {
