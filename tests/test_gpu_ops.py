@@ -419,3 +419,44 @@ def test_models_without_magic_accumulators():
     r = subprocess.run([sys.executable, "-c", _NO_MAGIC_SCRIPT.format(root=root)], env=env, capture_output=True,
                        text=True, timeout=600)
     assert r.returncode == 0 and "no-magic ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_quantize_every_float_near_the_int8_range(mf):
+    """Device roundf + saturating cast, exhaustively: EVERY f32 with 2^-3 <= |x| < 2^9 (11 binades
+    x 2^23 mantissas x 2 signs = 185 M values, plus the denormal-to-0.125 range sampled) through
+    mf_quantize(scale 1, zp 0) against round-half-away-from-zero + saturation evaluated in f64."""
+    import torch
+    for e in range(124, 136):                      # biased exponents: 2^-3 .. 2^8
+        bits = (np.arange(1 << 23, dtype=np.uint32) | np.uint32(e << 23))
+        for sign in (0, 0x80000000):
+            x = (bits | np.uint32(sign)).view(f32)
+            got = mf.ops.quantize(torch.as_tensor(x).cuda(), 1.0, 0).cpu().numpy()
+            x64 = x.astype(np.float64)
+            want = np.clip(np.trunc(x64 + np.copysign(0.5, x64)), -128, 127).astype(np.int8)
+            bad = np.nonzero(got != want)[0]
+            assert bad.size == 0, (e, sign, x[bad[:4]], got[bad[:4]], want[bad[:4]])
+    small = np.arange(0, 124 << 23, 4099, dtype=np.uint32).view(f32)   # [0, 0.125): all round to 0
+    assert not mf.ops.quantize(torch.as_tensor(small).cuda(), 1.0, 0).cpu().numpy().any()
+    special = np.array([np.nan, np.inf, -np.inf, 3.4e38, -3.4e38, -0.0], f32)
+    assert mf.ops.quantize(special, 1.0, 0).tolist() == [0, 127, -128, 127, -128, 0]
+
+
+@pytest.mark.parametrize("c1,c0s", [(2.0 ** -6, [0.5, -0.5, 3.25, -7.5, 0.0, 100.5, -100.5, 0.49999997]),
+                                    (0.0123456, [0.1, -0.9, 17.3, -40.2, 0.5, 126.9, -127.4, 1e-3])],
+                         ids=["exact-ties", "generic"])
+def test_requantize_dense_accumulator_sweep(mf, O, c1, c0s):
+    """The f32 epilogue over a DENSE accumulator range: FullyConnected with K = 2, weights
+    (1, 127) and every (x0, x1) pair gives every integer acc in [-16384, 16256]; with c1 = 2^-6
+    and half-integer c0 the sum lands on exact .5 ties for both signs (round half away from
+    zero), and the clamp saturates at both ends."""
+    x = np.stack(np.meshgrid(np.arange(-128, 128), np.arange(-128, 128), indexing="ij"), -1).reshape(-1, 2).astype(np.int8)
+    w = np.tile(np.array([[1, 127]], np.int8), (8, 1))
+    c0 = np.array(c0s, f32)
+    c2, c3 = np.zeros(8, np.int32), 0
+    for act, ozp in ((0, 0), (1, -3), (3, -128)):
+        op = mf.ops.prepare_fully_connected(x.shape[0], w, 0, 0.05, ozp, mf.ops.FullyConnectedOptions(mf.FusedActivation(act)),
+                                            (c0, c1, c2, c3))
+        want = O.fully_connected(x, w, 0, 0.05, ozp, act, c0, c1, c2, c3)
+        got = op(x)
+        assert np.array_equal(got, want), (act, np.argwhere(got != want)[:5])
+    assert len(np.unique(want)) > 100
