@@ -460,3 +460,25 @@ def test_requantize_dense_accumulator_sweep(mf, O, c1, c0s):
         got = op(x)
         assert np.array_equal(got, want), (act, np.argwhere(got != want)[:5])
     assert len(np.unique(want)) > 100
+
+
+def test_requantize_dense_sweep_fast_pointwise(mf, O):
+    """The same dense accumulator sweep through the MFMA pointwise kernel, whose epilogue uses
+    the bit-pattern int->f32 conversion (requant_t<true>): a 256x256x8 'image' whose pixels hold
+    every (x0, x1) pair, filters (1, 127, 0...) -> acc = x0 + 127 x1, exact-tie constants."""
+    H = W = 256
+    px = np.stack(np.meshgrid(np.arange(-128, 128), np.arange(-128, 128), indexing="ij"), -1).reshape(H, W, 2)
+    x = np.zeros((1, H, W, 8), np.int8)
+    x[0, :, :, :2] = px
+    f = np.zeros((16, 1, 1, 8), np.int8)
+    f[:, 0, 0, 0], f[:, 0, 0, 1] = 1, 127
+    f[8:, 0, 0, 1] = -127                                        # second half: acc = x0 - 127 x1
+    c0 = np.array([0.5, -0.5, 3.25, -7.5, 0.0, 100.5, -100.5, 0.49999997] * 2, f32)
+    c1 = np.array([2.0 ** -6] * 4 + [0.0123456] * 4 + [2.0 ** -7] * 4 + [0.05] * 4, f32)
+    for act, ozp in ((0, 0), (3, -128)):
+        opts = mf.ops.Conv2DOptions(mf.FusedActivation(act), mf.TensorViewPadding.SAME, (1, 1))
+        op = mf.ops.prepare_conv_2d((H, W, 8), f, np.zeros(16, np.int8), 0, 0.05, ozp, opts, (c0, c1), (H, W))
+        assert op.kernel == "pw_mfma<8,16>", op.kernel
+        want = O.conv_2d(x[0], f, np.zeros(16, np.int8), 0, 0.05, ozp, act, 0, (1, 1), (H, W), c0, c1)
+        got = op(x)[0]
+        assert np.array_equal(got, want), (act, np.argwhere(got != want)[:5])
