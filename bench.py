@@ -323,11 +323,21 @@ def cpu_baseline(om, x_dev_rows, seconds):
             "note": "C restatement of the reference algorithm (oracle/), not the Rust binary"}
 
 
-def cpu_baseline_all_cores(om, x_dev_rows, per_thread=16):
+def cpu_baseline_all_cores(om, x_dev_rows, per_thread=48):
     """the same oracle with the batch split across every host thread (the C
     call releases the GIL; each thread runs whole inferences, like the reference would per core)."""
     from concurrent.futures import ThreadPoolExecutor
     nthr = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota_note = ""
+    try:  # a container's CPU quota (cgroup v2 cpu.max = "<quota> <period>") caps the usable cores
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            cap = max(1, -(-int(q) // int(per)))
+            if cap < nthr:
+                quota_note = " (cgroup cpu.max allows %d of the host's %d logical cores)" % (cap, nthr)
+                nthr = cap
+    except (OSError, ValueError):
+        pass
     n = min(x_dev_rows.shape[0], nthr * per_thread)
     xs = x_dev_rows[:n].cpu().numpy()
     chunks = [c for c in np.array_split(xs, nthr) if len(c)]
@@ -337,7 +347,7 @@ def cpu_baseline_all_cores(om, x_dev_rows, per_thread=16):
         list(ex.map(om.run_quantized_batch, chunks))
         dt = time.perf_counter() - t0
     return {"value": round(n / dt, 1), "unit": "inferences/s", "cores": len(chunks), "kind": "port",
-            "sample": "%d images split over %d threads, %.1f s" % (n, len(chunks), dt)}
+            "sample": "%d images split over %d threads, %.1f s%s" % (n, len(chunks), dt, quota_note)}
 
 
 if __name__ == "__main__":
