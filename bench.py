@@ -219,6 +219,26 @@ def main():
                         "note": "pinned host buffers through mf_model_run_quantized(MF_MEM_HOST): the batch "
                                 "is cut into ~64 MB chunks whose H2D copies overlap the previous chunk's compute"}
 
+        # ---- the f32 entry point (M::predict): quantize -> ops -> dequantize, device-resident ----
+        predict_f32 = None
+        if world == 1 and not args.no_host_fed:
+            xf = (x.reshape(count, -1).float() - float(m.input_zero_point)) * float(m.input_scale)
+            yf = torch.empty((count, m.output_elems), dtype=torch.float32, device="cuda")
+            run_f = lambda: _lib.check(L.mf_model_predict(  # noqa: E731
+                m._h, xf.data_ptr(), count, yf.data_ptr(), _lib.MF_MEM_DEVICE))
+            run_f()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                run_f()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / 5
+            yq = (yf / float(m.output_scale) + float(m.output_zero_point)).round().to(torch.int8).reshape(-1)
+            predict_f32 = {"value": round(count / dt, 1), "unit": "inferences/s", "ms_per_step": round(dt * 1e3, 3),
+                           "input_bytes": int(xf.numel() * 4), "same_outputs_as_int8_path": bool(torch.equal(yq, y)),
+                           "note": "f32 in HBM -> quantize_f32 kernel -> predict_inner -> dequantize kernel"}
+            del xf, yf
+
         result = {
             "metric": "inferences/sec (int8) for %s" % fname, "value": round(value, 1),
             "unit": "inferences/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -236,6 +256,7 @@ def main():
             "cpu_baseline": cpu,
             "cpu_baseline_all_cores": cpu_mt,
             "host_fed": host_fed,
+            "predict_f32": predict_f32,
             "parity": {"bit_exact_vs_oracle": parity_ok, "sampled_images": len(idx),
                        "output_checksums": ["%016x" % c for c in cks]},
         }
