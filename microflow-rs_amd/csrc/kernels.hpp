@@ -153,15 +153,17 @@ struct TailArgs {
     X(24, 24, 32, 1, 32, 1, 512, 1) \
     X(24, 24, 32, 2, 64, 2, 256, 0) \
     X(12, 12, 64, 1, 64, 4, 512, 0) \
-    X(12, 12, 64, 2, 128, 4, 512, 0) \
+    X(12, 12, 64, 2, 128, 2, 256, 0) \
     X(6, 6, 128, 1, 128, 8, 512, 0) \
-    X(6, 6, 128, 2, 256, 4, 256, 0) \
+    X(6, 6, 128, 2, 256, 8, 512, 0) \
     X(3, 3, 256, 1, 256, 8, 256, 0)
 
 // Tuning candidates: MF_DWPW_ALT=<i> makes the i-th entry (0-based) override the table above for
 // its shape; `scripts/tune_dwpw.sh` runs bench.py once per entry.  Empty in the product build --
 // add (H, W, C, S, N, G, NTHR, DB) rows here to A/B them.  Last sweep (r01, 15 candidates over
-// the four stride-1 pairs): only 12x12x64 moved, (G=2, 512 thr, DB) -> (G=4, 512 thr, SB) -11 %.
+// the four stride-1 pairs): only 12x12x64 moved, (G=2, 512 thr, DB) -> (G=4, 512 thr, SB) -11 %;
+// a second sweep over the stride-2 pairs and the two largest: 12x12x64 s2 -> (G=2, 256 thr) -8 %,
+// 6x6x128 s2 -> (G=8, 512 thr) -9 %, everything else already at its best.
 #define MF_DWPW_ALT_SHAPES(X)
 
 // (K = input channels, N = output channels) with a compiled pointwise MFMA kernel

@@ -10,6 +10,6 @@ import sys, json
 r = json.loads(sys.stdin.read().strip().splitlines()[-1])
 ks = {k['kernel']: k['ms'] for k in r['kernels']}
 print('alt', '$i', 'ms/step', r['ms_per_step'], 'ok' if r['parity']['bit_exact_vs_oracle'] else 'MISMATCH',
-      ' '.join('%s=%.4f' % (k.replace('dwpw3x3', ''), v) for k, v in ks.items() if 'dwpw' in k and any(t in k for t in ('<6,6,128,1', '<12,12,64,1', '<24,24,32,1', '<3,3,256'))))
+      ' '.join('%s=%.4f' % (k.replace('dwpw3x3', ''), v) for k, v in ks.items() if 'dwpw' in k and True))
 "
 done
