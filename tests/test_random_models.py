@@ -1,0 +1,74 @@
+"""Randomized model-level parity: small generated .tflite networks that touch every operator
+the reference supports (microflow-macros/src/lib.rs:138-148) with shapes and options the three
+reference models never use -- K x K Conv2D with strides and VALID padding, rectangular
+depthwise filters, per-channel / per-tensor / non-zero weight zero points, both tails
+(Reshape + FullyConnected + Softmax and Conv2D head + Reshape + Softmax), both element types.
+CPU: the library's parser + constant preparation against the oracle's (two independent
+FlatBuffers readers, C++ vs C).  GPU: every layer of every model, bit for bit."""
+import importlib
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import tflite_writer as tw  # noqa: E402
+
+CASES = [(seed, elem, pc, wz, tail)
+         for seed, (elem, pc, wz, tail) in enumerate([
+             (tw.INT8, True, False, "fc"), (tw.INT8, True, True, "conv"), (tw.INT8, False, True, "fc"),
+             (tw.INT8, False, False, "conv"), (tw.UINT8, True, True, "fc"), (tw.UINT8, False, False, "conv"),
+             (tw.INT8, True, True, "fc"), (tw.UINT8, True, False, "conv"), (tw.INT8, True, False, "conv"),
+             (tw.UINT8, False, True, "fc")])]
+
+
+def _ids(c):
+    return "s%d-%s-%s-%s-%s" % (c[0], "u8" if c[1] == tw.UINT8 else "i8", "perch" if c[2] else "pert",
+                                 "wzp" if c[3] else "wz0", c[4])
+
+
+def _blob(case):
+    seed, elem, pc, wz, tail = case
+    return tw.random_cnn(np.random.default_rng(1000 + seed), elem, pc, wz, tail)
+
+
+@pytest.mark.parametrize("case", CASES, ids=_ids)
+def test_random_model_parse_matches_oracle(O, case):
+    mf = importlib.import_module("microflow_rs_amd")
+    blob = _blob(case)
+    pm, om = mf.Model(blob), O.Model(blob)
+    assert pm.dtype == om.dtype and pm.num_ops == om.num_ops >= 6
+    assert (pm.input_shape, pm.output_shape) == (om.in_shape, om.out_shape)
+    for i in range(pm.num_ops):
+        d, o = pm.op(i), om.ops[i]
+        for k in ("kind", "in_shape", "out_shape", "KH", "KW", "sh", "sw", "pad", "act", "n_c0", "n_c1", "in_zp", "out_zp"):
+            assert d[k] == o[k], (i, k, d[k], o[k])
+        a, b = pm.op_constants(i), om.op_constants(i)
+        for x, y in zip(a[:3], b[:3]):
+            assert np.array_equal(np.asarray(x).view(np.int32), np.asarray(y).view(np.int32)), (i, d["name"])
+        assert a[3] == b[3]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", CASES, ids=_ids)
+def test_random_model_runs_bit_exact(O, case):
+    mf = importlib.import_module("microflow_rs_amd")
+    blob = _blob(case)
+    m, om = mf.Model(blob), O.Model(blob)
+    rng = np.random.default_rng(case[0])
+    lo, hi = (0, 256) if m.dtype == np.uint8 else (-128, 128)
+    n = 7
+    xq = rng.integers(lo, hi, (n, m.input_elems)).astype(m.dtype)
+    want = om.run_quantized_batch(xq)
+    got = m.run_quantized(xq).reshape(n, -1)
+    if not np.array_equal(got, want):                      # localise the first differing layer
+        _, layers = om.run_quantized(xq[0], layers=True)
+        for i, lay in enumerate(layers):
+            g = np.asarray(m.run_until(xq[:1], i)).reshape(-1)
+            assert np.array_equal(g, lay.reshape(-1)), (i, m.op(i)["name"], m.op(i)["kernel"])
+    assert np.array_equal(got, want)
+    pf = m.predict_quantized(xq).reshape(n, -1)
+    wf = np.stack([om.predict_quantized(x).reshape(-1) for x in xq])
+    assert np.array_equal(pf.view(np.uint32), wf.view(np.uint32))
