@@ -445,6 +445,59 @@ __device__ __forceinline__ void dw_s1_task(const uint8_t *base, const uint32_t (
 }
 
 // ------------------------------------------------------------------------
+// Stride-2 depthwise 3x3 task: R output rows x 2 adjacent output pixels x 4 channels.
+// Output pixel ox0 reads input pixels 2ox0-1 .. 2ox0+1, pixel ox0+1 reads 2ox0+1 .. 2ox0+3: per
+// INPUT row five channel dwords s0..s4.  s0..s3 are byte-transposed into per-channel windows
+// [v0,v1,v2,v3] as in the stride-1 task (8 v_perm); one more v_perm per channel builds
+// [v2,v3,v4,0] from the window and s4, so both pixels use the same weight dword (w0,w1,w2,0)
+// in one real 3-MAC dot4 each.  With R = 2 the middle input row (2oy0+1) serves both output
+// rows: 6.75 VALU ops per output byte instead of 9 for byte-masked taps.
+// `base` = LDS address of (input row 2oy0-1, pixel 2ox0-1, this lane's channel group).
+// ------------------------------------------------------------------------
+template <int R, int ROW, int C>
+__device__ __forceinline__ void dw_s2_task(const uint8_t *base, const uint32_t (&wA)[3][4], const int4 Kc,
+                                           int (&o0)[R][4], int (&o1)[R][4]) {
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        o0[j][0] = o1[j][0] = Kc.x, o0[j][1] = o1[j][1] = Kc.y;
+        o0[j][2] = o1[j][2] = Kc.z, o0[j][3] = o1[j][3] = Kc.w;
+    }
+#pragma unroll
+    for (int r = 0; r < 2 * R + 1; ++r) {
+        const uint32_t s0 = *(const uint32_t *)(base + r * ROW);
+        const uint32_t s1 = *(const uint32_t *)(base + r * ROW + C);
+        const uint32_t s2 = *(const uint32_t *)(base + r * ROW + 2 * C);
+        const uint32_t s3 = *(const uint32_t *)(base + r * ROW + 3 * C);
+        const uint32_t s4 = *(const uint32_t *)(base + r * ROW + 4 * C);
+        const uint32_t ab_lo = __builtin_amdgcn_perm(s1, s0, 0x05010400u);
+        const uint32_t ab_hi = __builtin_amdgcn_perm(s1, s0, 0x07030602u);
+        const uint32_t cd_lo = __builtin_amdgcn_perm(s3, s2, 0x05010400u);
+        const uint32_t cd_hi = __builtin_amdgcn_perm(s3, s2, 0x07030602u);
+        uint32_t win[4], winb[4];
+        win[0] = __builtin_amdgcn_perm(cd_lo, ab_lo, 0x05040100u);
+        win[1] = __builtin_amdgcn_perm(cd_lo, ab_lo, 0x07060302u);
+        win[2] = __builtin_amdgcn_perm(cd_hi, ab_hi, 0x05040100u);
+        win[3] = __builtin_amdgcn_perm(cd_hi, ab_hi, 0x07060302u);
+        // [v2, v3, v4 (= byte k of s4), 0]
+        winb[0] = __builtin_amdgcn_perm(s4, win[0], 0x0c040302u);
+        winb[1] = __builtin_amdgcn_perm(s4, win[1], 0x0c050302u);
+        winb[2] = __builtin_amdgcn_perm(s4, win[2], 0x0c060302u);
+        winb[3] = __builtin_amdgcn_perm(s4, win[3], 0x0c070302u);
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            const int ky = r - 2 * j; // filter row this input row plays for output row j
+            if (ky >= 0 && ky <= 2) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    o0[j][k] = sdot4(win[k], wA[ky][k], o0[j][k]);
+                    o1[j][k] = sdot4(winb[k], wA[ky][k], o1[j][k]);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------
 // FAST PATH 1 -- DepthwiseConv2D 3x3, SAME, NHWC, C % 4 == 0, weight zp == 0.
 // (src/ops/depthwise_conv_2d.rs:28-105; person_detect ops 1,3,5,...,25)
 //
@@ -479,8 +532,6 @@ __global__ __launch_bounds__(NTHR) void dw3x3_nhwc(const int8_t *__restrict__ in
     constexpr int IMG = H * ROWB;                 // bytes per input image
     constexpr int ROWCH = ROWB / 16;              // 16-byte chunks (= DMA lanes) per row
     constexpr int NROWS = G * H;                  // DMA instructions per step
-    constexpr int OUTS = G * OH * OW * C4;        // output dwords per step
-    constexpr int NOUT = (OUTS + NTHR - 1) / NTHR;
     constexpr int NWAVE = NTHR / 64;
     static_assert(NTHR % C4 == 0, "channel group of a lane must be loop-invariant");
     static_assert(ROWB % 16 == 0 && ROWCH <= 64, "one DMA instruction per row");
@@ -500,28 +551,20 @@ __global__ __launch_bounds__(NTHR) void dw3x3_nhwc(const int8_t *__restrict__ in
     // S == 1: per filter row and channel the 3 taps as ONE dword (w0,w1,w2,0) and its
     //         shifted twin (0,w0,w1,w2): a 4-pixel window transposed to per-channel dwords
     //         then yields TWO adjacent outputs with two real 3-MAC sdot4s.
-    uint32_t wm[S == 2 ? 9 : 1][4];
-    uint32_t wA[S == 1 ? 3 : 1][4], wB[S == 1 ? 3 : 1][4];
-    if constexpr (S == 2) {
+    uint32_t wA[3][4], wB[3][4]; // (w0,w1,w2,0) and (0,w0,w1,w2) per filter row and channel; wB: stride 1 only
+    {
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const uint32_t w = ((const uint32_t *)p.w)[t * C4 + cg];
+    for (int ky = 0; ky < 3; ++ky) {
+        const uint32_t w0 = ((const uint32_t *)p.w)[(ky * 3 + 0) * C4 + cg];
+        const uint32_t w1 = ((const uint32_t *)p.w)[(ky * 3 + 1) * C4 + cg];
+        const uint32_t w2 = ((const uint32_t *)p.w)[(ky * 3 + 2) * C4 + cg];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) wm[t][k] = w & (0xffu << (8 * k));
+        for (int k = 0; k < 4; ++k) {
+            wA[ky][k] = ((w0 >> (8 * k)) & 0xffu) | (((w1 >> (8 * k)) & 0xffu) << 8) |
+                        (((w2 >> (8 * k)) & 0xffu) << 16);
+            wB[ky][k] = wA[ky][k] << 8;
         }
-    } else {
-#pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-            const uint32_t w0 = ((const uint32_t *)p.w)[(ky * 3 + 0) * C4 + cg];
-            const uint32_t w1 = ((const uint32_t *)p.w)[(ky * 3 + 1) * C4 + cg];
-            const uint32_t w2 = ((const uint32_t *)p.w)[(ky * 3 + 2) * C4 + cg];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                wA[ky][k] = ((w0 >> (8 * k)) & 0xffu) | (((w1 >> (8 * k)) & 0xffu) << 8) |
-                            (((w2 >> (8 * k)) & 0xffu) << 16);
-                wB[ky][k] = wA[ky][k] << 8;
-            }
-        }
+    }
     }
     const float4 A = ((const float4 *)p.A)[cg], Sc = ((const float4 *)p.S)[cg];
     const int4 Kc = magic4<MG>(((const int4 *)p.Kc)[cg]);
@@ -550,37 +593,7 @@ __global__ __launch_bounds__(NTHR) void dw3x3_nhwc(const int8_t *__restrict__ in
 
         const uint8_t *tile = lds + cur * BUF;
         uint32_t *dst = (uint32_t *)out + (size_t)step * G * OH * OW * C4;
-        if constexpr (S == 2) {
-            const int nvalid = min(G, batch - step * G) * OH * OW * C4;
-#pragma unroll 2
-            for (int i = 0; i < NOUT; ++i) {
-                const int o = tid + NTHR * i;
-                if (o < OUTS && o < nvalid) {
-                    const int pix = o / C4;
-                    const int g = pix / (OH * OW), rem = pix % (OH * OW);
-                    const int oy = rem / OW, ox = rem % OW;
-                    // tap (ky,kx): row oy*S + ky (halo row 0 == input row -1), col ox*S + kx - 1
-                    const uint8_t *base = tile + g * TILE + (oy * S) * ROW + LP + (ox * S - 1) * C + cg * 4;
-                    int a0 = Kc.x, a1 = Kc.y, a2 = Kc.z, a3 = Kc.w;
-#pragma unroll
-                    for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                        for (int kx = 0; kx < 3; ++kx) {
-                            const uint32_t v = *(const uint32_t *)(base + ky * ROW + kx * C);
-                            const int t = ky * 3 + kx;
-                            a0 = sdot4(v, wm[t][0], a0);
-                            a1 = sdot4(v, wm[t][1], a1);
-                            a2 = sdot4(v, wm[t][2], a2);
-                            a3 = sdot4(v, wm[t][3], a3);
-                        }
-                    const int q0 = requant_t<MG>(a0, A.x, Sc.x, p.lo_f, p.hi_f);
-                    const int q1 = requant_t<MG>(a1, A.y, Sc.y, p.lo_f, p.hi_f);
-                    const int q2 = requant_t<MG>(a2, A.z, Sc.z, p.lo_f, p.hi_f);
-                    const int q3 = requant_t<MG>(a3, A.w, Sc.w, p.lo_f, p.hi_f);
-                    dst[o] = pack4(q0, q1, q2, q3);
-                }
-            }
-        } else {
+        {
             // task = R output rows x 2 adjacent pixels x 4 channels (see dw_s1_task)
             constexpr int R = (OH % 2 == 0) ? 2 : 1;
             constexpr int OWP = (OW + 1) / 2, OHR = OH / R;
@@ -595,7 +608,9 @@ __global__ __launch_bounds__(NTHR) void dw3x3_nhwc(const int8_t *__restrict__ in
                 const int oy0 = R * (rem / OWP), ox0 = 2 * (rem % OWP);
                 if (t < TASKS && g < gvalid) {
                     int o0[R][4], o1[R][4];
-                    dw_s1_task<R, ROW, C>(tile + g * TILE + oy0 * ROW + LP + (ox0 - 1) * C + cg * 4, wA, wB, Kc, o0, o1);
+                    const uint8_t *base = tile + g * TILE + (oy0 * S) * ROW + LP + (ox0 * S - 1) * C + cg * 4;
+                    if constexpr (S == 2) dw_s2_task<R, ROW, C>(base, wA, Kc, o0, o1);
+                    else dw_s1_task<R, ROW, C>(base, wA, wB, Kc, o0, o1);
 #pragma unroll
                     for (int j = 0; j < R; ++j) {
                         uint32_t *dp = dst + ((size_t)(g * OH + oy0 + j) * OW + ox0) * C4 + cg;
@@ -1032,28 +1047,20 @@ __global__ __launch_bounds__(NTHR) void dwpw3x3(const int8_t *__restrict__ in,
 
     // ---- depthwise per-lane constants ----
     const int cg = tid & (C4 - 1);
-    uint32_t wm[S == 2 ? 9 : 1][4];
-    uint32_t wA[S == 1 ? 3 : 1][4], wB[S == 1 ? 3 : 1][4];
-    if constexpr (S == 2) {
+    uint32_t wA[3][4], wB[3][4]; // (w0,w1,w2,0) and (0,w0,w1,w2) per filter row and channel; wB: stride 1 only
+    {
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const uint32_t w = ((const uint32_t *)p.dw.w)[t * C4 + cg];
+    for (int ky = 0; ky < 3; ++ky) {
+        const uint32_t w0 = ((const uint32_t *)p.dw.w)[(ky * 3 + 0) * C4 + cg];
+        const uint32_t w1 = ((const uint32_t *)p.dw.w)[(ky * 3 + 1) * C4 + cg];
+        const uint32_t w2 = ((const uint32_t *)p.dw.w)[(ky * 3 + 2) * C4 + cg];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) wm[t][k] = w & (0xffu << (8 * k));
+        for (int k = 0; k < 4; ++k) {
+            wA[ky][k] = ((w0 >> (8 * k)) & 0xffu) | (((w1 >> (8 * k)) & 0xffu) << 8) |
+                        (((w2 >> (8 * k)) & 0xffu) << 16);
+            wB[ky][k] = wA[ky][k] << 8;
         }
-    } else {
-#pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-            const uint32_t w0 = ((const uint32_t *)p.dw.w)[(ky * 3 + 0) * C4 + cg];
-            const uint32_t w1 = ((const uint32_t *)p.dw.w)[(ky * 3 + 1) * C4 + cg];
-            const uint32_t w2 = ((const uint32_t *)p.dw.w)[(ky * 3 + 2) * C4 + cg];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                wA[ky][k] = ((w0 >> (8 * k)) & 0xffu) | (((w1 >> (8 * k)) & 0xffu) << 8) |
-                            (((w2 >> (8 * k)) & 0xffu) << 16);
-                wB[ky][k] = wA[ky][k] << 8;
-            }
-        }
+    }
     }
     const float4 dA = ((const float4 *)p.dw.A)[cg], dS = ((const float4 *)p.dw.S)[cg];
     const int4 dK = magic4<MG>(((const int4 *)p.dw.Kc)[cg]);
@@ -1107,36 +1114,7 @@ __global__ __launch_bounds__(NTHR) void dwpw3x3(const int8_t *__restrict__ in,
         const int gvalid = min(G, batch - step * G);
 
         // ---------------- depthwise phase: staged tile -> MID ----------------
-        if constexpr (S == 2) {
-            constexpr int OUTS = G * OPIX * C4, NOUT = (OUTS + NTHR - 1) / NTHR;
-            const int nvalid = gvalid * OPIX * C4;
-#pragma unroll 1
-            for (int i = 0; i < NOUT; ++i) {
-                const int o = tid + NTHR * i;
-                if (o < OUTS && o < nvalid) {
-                    const int pix = o / C4;
-                    const int g = pix / OPIX, rem = pix % OPIX;
-                    const int oy = rem / OW, ox = rem % OW;
-                    const uint8_t *base = tile + g * TILE + (oy * S) * ROW + LP + (ox * S - 1) * C + cg * 4;
-                    int a0 = dK.x, a1 = dK.y, a2 = dK.z, a3 = dK.w;
-#pragma unroll
-                    for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                        for (int kx = 0; kx < 3; ++kx) {
-                            const uint32_t v = *(const uint32_t *)(base + ky * ROW + kx * C);
-                            const int t = ky * 3 + kx;
-                            a0 = sdot4(v, wm[t][0], a0);
-                            a1 = sdot4(v, wm[t][1], a1);
-                            a2 = sdot4(v, wm[t][2], a2);
-                            a3 = sdot4(v, wm[t][3], a3);
-                        }
-                    ((uint32_t *)mid)[o] = pack4(requant_t<MG>(a0, dA.x, dS.x, p.dw.lo_f, p.dw.hi_f),
-                                                 requant_t<MG>(a1, dA.y, dS.y, p.dw.lo_f, p.dw.hi_f),
-                                                 requant_t<MG>(a2, dA.z, dS.z, p.dw.lo_f, p.dw.hi_f),
-                                                 requant_t<MG>(a3, dA.w, dS.w, p.dw.lo_f, p.dw.hi_f));
-                }
-            }
-        } else {
+        {
             constexpr int R = (OH % 2 == 0) ? 2 : 1;
             constexpr int OWP = (OW + 1) / 2, OHR = OH / R;
             constexpr int TASKS = G * OHR * OWP * C4, NTASK = (TASKS + NTHR - 1) / NTHR;
@@ -1148,7 +1126,9 @@ __global__ __launch_bounds__(NTHR) void dwpw3x3(const int8_t *__restrict__ in,
                 const int oy0 = R * (rem / OWP), ox0 = 2 * (rem % OWP);
                 if (t < TASKS && g < gvalid) {
                     int o0[R][4], o1[R][4];
-                    dw_s1_task<R, ROW, C>(tile + g * TILE + oy0 * ROW + LP + (ox0 - 1) * C + cg * 4, wA, wB, dK, o0, o1);
+                    const uint8_t *base = tile + g * TILE + (oy0 * S) * ROW + LP + (ox0 * S - 1) * C + cg * 4;
+                    if constexpr (S == 2) dw_s2_task<R, ROW, C>(base, wA, dK, o0, o1);
+                    else dw_s1_task<R, ROW, C>(base, wA, wB, dK, o0, o1);
 #pragma unroll
                     for (int j = 0; j < R; ++j) {
                         uint32_t *dp = (uint32_t *)mid + ((size_t)(g * OH + oy0 + j) * OW + ox0) * C4 + cg;
