@@ -19,6 +19,7 @@ HEADERS = ["mf_internal.hpp", "kernels.hpp", os.path.join("..", "..", "include",
 # removes one v_accvgpr_read per accumulator element from every fused epilogue.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-fno-fast-math", "-Wall", "-Wno-unused-result", "-mllvm", "-amdgpu-mfma-vgpr-form=1"]
+FLAGS += os.environ.get("MF_EXTRA_HIPCC_FLAGS", "").split()  # kernel-tuning experiments (-DMF_...=n)
 
 
 def hipcc():

@@ -406,6 +406,15 @@ __device__ __forceinline__ void dma16(const int8_t *src_lane, uint8_t *lds_wave_
 // input rows: 5 VALU ops per output byte instead of 6 (and 9 for byte-masked taps).
 // `base` = LDS address of (input row oy0-1, pixel ox0-1, this lane's channel group).
 // ------------------------------------------------------------------------
+// Output rows per depthwise task.  More rows share more input-row transposes (stride 1: 6, 5,
+// 4.67, 4.5 VALU ops per output byte for R = 1..4; stride 2: 7.5, 6.75, 6.5) but give fewer,
+// bigger tasks, which the fixed workgroup sizes then fill less evenly.  Measured per compiled
+// shape (r01, fused and layer-wise kernels alike): R = 3 wins wherever OH % 3 == 0 except on
+// the 48-row stride-1 layer and the 12-row stride-2 one; R = 4 never wins.
+constexpr int dw_rows_per_task(int OH, int S) {
+    if (OH % 3 == 0 && !(S == 1 && OH == 48) && !(S == 2 && OH == 12)) return 3;
+    return (OH % 2 == 0) ? 2 : 1;
+}
 template <int R, int ROW, int C>
 __device__ __forceinline__ void dw_s1_task(const uint8_t *base, const uint32_t (&wA)[3][4],
                                            const uint32_t (&wB)[3][4], const int4 Kc,
@@ -595,7 +604,7 @@ __global__ __launch_bounds__(NTHR) void dw3x3_nhwc(const int8_t *__restrict__ in
         uint32_t *dst = (uint32_t *)out + (size_t)step * G * OH * OW * C4;
         {
             // task = R output rows x 2 adjacent pixels x 4 channels (see dw_s1_task)
-            constexpr int R = (OH % 2 == 0) ? 2 : 1;
+            constexpr int R = dw_rows_per_task(OH, S);
             constexpr int OWP = (OW + 1) / 2, OHR = OH / R;
             constexpr int TASKS = G * OHR * OWP * C4;
             constexpr int NTASK = (TASKS + NTHR - 1) / NTHR;
@@ -1115,7 +1124,7 @@ __global__ __launch_bounds__(NTHR) void dwpw3x3(const int8_t *__restrict__ in,
 
         // ---------------- depthwise phase: staged tile -> MID ----------------
         {
-            constexpr int R = (OH % 2 == 0) ? 2 : 1;
+            constexpr int R = dw_rows_per_task(OH, S);
             constexpr int OWP = (OW + 1) / 2, OHR = OH / R;
             constexpr int TASKS = G * OHR * OWP * C4, NTASK = (TASKS + NTHR - 1) / NTHR;
 #pragma unroll 1
