@@ -149,7 +149,7 @@ struct TailArgs {
 // step, threads per workgroup, double-buffered staging (1) or single (0)
 #define MF_DWPW_SHAPES(X)           \
     X(48, 48, 8, 1, 16, 1, 512, 1)  \
-    X(48, 48, 16, 2, 32, 1, 512, 1) \
+    X(48, 48, 16, 2, 32, 1, 768, 1) \
     X(24, 24, 32, 1, 32, 1, 512, 1) \
     X(24, 24, 32, 2, 64, 2, 256, 0) \
     X(12, 12, 64, 1, 64, 4, 512, 0) \
@@ -163,7 +163,8 @@ struct TailArgs {
 // add (H, W, C, S, N, G, NTHR, DB) rows here to A/B them.  Last sweep (r01, 15 candidates over
 // the four stride-1 pairs): only 12x12x64 moved, (G=2, 512 thr, DB) -> (G=4, 512 thr, SB) -11 %;
 // a second sweep over the stride-2 pairs and the two largest: 12x12x64 s2 -> (G=2, 256 thr) -8 %,
-// 6x6x128 s2 -> (G=8, 512 thr) -9 %, everything else already at its best.
+// 6x6x128 s2 -> (G=8, 512 thr) -9 %, everything else already at its best.  After the rows-per-task
+// change a third sweep (thread counts matched to the new task counts): 48x48x16 s2 -> 768 thr -6 %.
 #define MF_DWPW_ALT_SHAPES(X)
 
 // (K = input channels, N = output channels) with a compiled pointwise MFMA kernel
