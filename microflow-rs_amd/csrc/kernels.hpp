@@ -165,6 +165,8 @@ struct TailArgs {
 // a second sweep over the stride-2 pairs and the two largest: 12x12x64 s2 -> (G=2, 256 thr) -8 %,
 // 6x6x128 s2 -> (G=8, 512 thr) -9 %, everything else already at its best.  After the rows-per-task
 // change a third sweep (thread counts matched to the new task counts): 48x48x16 s2 -> 768 thr -6 %.
+// Thread counts that are not multiples of 256 (384, 576) always lose 20-35 %: a workgroup's waves
+// are dealt round-robin to the 4 SIMDs, so 6 or 9 waves leave one SIMD with 50 % more work.
 #define MF_DWPW_ALT_SHAPES(X)
 
 // (K = input channels, N = output channels) with a compiled pointwise MFMA kernel
