@@ -344,7 +344,7 @@ def cpu_baseline(om, x_dev_rows, seconds):
             "note": "C restatement of the reference algorithm (oracle/), not the Rust binary"}
 
 
-def cpu_baseline_all_cores(om, x_dev_rows, per_thread=48):
+def cpu_baseline_all_cores(om, x_dev_rows, per_thread=448):
     """the same oracle with the batch split across every host thread (the C
     call releases the GIL; each thread runs whole inferences, like the reference would per core)."""
     from concurrent.futures import ThreadPoolExecutor
