@@ -12,9 +12,9 @@ every compute entry point raises if the library or a GPU is missing.
     y = PersonDetect.predict(x)                              # ~ PersonDetect::predict(x)
 """
 from ._lib import MicroflowError, lib, lib_path  # noqa: F401
-from .model import Model, model  # noqa: F401
+from .model import Model, model, run_sharded  # noqa: F401
 from . import ops  # noqa: F401
 from .tensor import (FusedActivation, Tensor2D, Tensor4D, TensorViewPadding)  # noqa: F401
 
-__all__ = ["model", "Model", "ops", "Tensor2D", "Tensor4D", "FusedActivation",
+__all__ = ["model", "Model", "run_sharded", "ops", "Tensor2D", "Tensor4D", "FusedActivation",
            "TensorViewPadding", "MicroflowError", "lib", "lib_path"]

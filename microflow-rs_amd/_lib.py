@@ -95,6 +95,9 @@ SIGNATURES = {
     "mf_model_predict_quantized": (C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_int]),
     "mf_model_run_quantized": (C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_int]),
     "mf_model_run_until": (C.c_int, [_vp, _vp, C.c_size_t, C.c_int, _vp, C.c_int]),
+    "mf_models_run_quantized": (C.c_int, [C.POINTER(_vp), C.c_int, _vp, C.c_size_t, _vp]),
+    "mf_models_predict": (C.c_int, [C.POINTER(_vp), C.c_int, _vp, C.c_size_t, _vp]),
+    "mf_models_predict_quantized": (C.c_int, [C.POINTER(_vp), C.c_int, _vp, C.c_size_t, _vp]),
     "mf_model_set_generic": (C.c_int, [_vp, C.c_int]),
     "mf_model_set_fusion": (C.c_int, [_vp, C.c_int]),
     "mf_model_set_graph": (C.c_int, [_vp, C.c_int]),

@@ -4,6 +4,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "mf_internal.hpp"
@@ -461,6 +462,59 @@ int mf_model_run_quantized(mf_model *model, const int8_t *input, size_t batch, i
         mf::model_run(model->impl, nullptr, input, batch, nullptr, output, mem, -1);
     })
 }
+// One call over several prepared handles (normally one per GPU of the node).  The batch is cut
+// into contiguous shards -- handle i gets images [first_i, first_i + count_i), sizes differing by
+// at most one -- and every shard runs on its own host thread through that handle's device and
+// stream: no collective, no peer access, the model is replicated.  Host buffers only.
+static void run_sharded(mf_model *const *models, int n, const float *in_f32, const int8_t *in_i8, size_t batch,
+                        float *out_f32, int8_t *out_i8) {
+    MF_NEED(models && n >= 1 && (batch == 0 || ((in_f32 || in_i8) && (out_f32 || out_i8))));
+    for (int i = 0; i < n; ++i) MF_NEED(models[i] && models[i]->impl);
+    const mf::ParsedModel &pm = mf::model_parsed(models[0]->impl);
+    for (int i = 1; i < n; ++i) {
+        const mf::ParsedModel &q = mf::model_parsed(models[i]->impl);
+        if (q.in_elems != pm.in_elems || q.out_elems != pm.out_elems || q.u8 != pm.u8 || q.ops.size() != pm.ops.size())
+            mf::fail(MF_ERR_INVALID_ARG, "the handles are not replicas of one model");
+    }
+    std::vector<mf::Error> errs((size_t)n, mf::Error{MF_OK, ""});
+    std::vector<std::thread> th;
+    const size_t base = batch / (size_t)n, rem = batch % (size_t)n;
+    size_t first = 0;
+    for (int i = 0; i < n; ++i) {
+        const size_t count = base + ((size_t)i < rem ? 1 : 0);
+        if (count) {
+            th.emplace_back([=, &errs] {
+                try {
+                    mf::model_run(models[i]->impl, in_f32 ? in_f32 + first * pm.in_elems : nullptr,
+                                  in_i8 ? in_i8 + first * pm.in_elems : nullptr, count,
+                                  out_f32 ? out_f32 + first * pm.out_elems : nullptr,
+                                  out_i8 ? out_i8 + first * pm.out_elems : nullptr, MF_MEM_HOST, -1);
+                } catch (const mf::Error &e) {
+                    errs[(size_t)i] = e;
+                } catch (const std::exception &e) {
+                    errs[(size_t)i] = mf::Error{MF_ERR_HIP, e.what()};
+                }
+            });
+        }
+        first += count;
+    }
+    for (std::thread &t : th) t.join();
+    for (int i = 0; i < n; ++i)
+        if (errs[(size_t)i].code != MF_OK)
+            mf::fail(errs[(size_t)i].code, "shard " + std::to_string(i) + ": " + errs[(size_t)i].msg);
+}
+int mf_models_run_quantized(mf_model *const *models, int n_models, const int8_t *input, size_t batch,
+                            int8_t *output) {
+    MF_TRY({ run_sharded(models, n_models, nullptr, input, batch, nullptr, output); })
+}
+int mf_models_predict(mf_model *const *models, int n_models, const float *input, size_t batch, float *output) {
+    MF_TRY({ run_sharded(models, n_models, input, nullptr, batch, output, nullptr); })
+}
+int mf_models_predict_quantized(mf_model *const *models, int n_models, const int8_t *input, size_t batch,
+                                float *output) {
+    MF_TRY({ run_sharded(models, n_models, nullptr, input, batch, output, nullptr); })
+}
+
 int mf_model_run_until(mf_model *model, const int8_t *input, size_t batch, int last_op,
                        int8_t *output, int mem) {
     MF_TRY({

@@ -219,6 +219,28 @@ def model(path, device=None):
     return Model(path, device=device)
 
 
+def run_sharded(models, x, entry="run_quantized"):
+    """One host batch over several prepared replicas of a model -- normally one per GPU of the node
+    (`[Model(path, device=d, max_batch=B) for d in range(n_gpus)]`) -- from a single process:
+    mf_models_{run_quantized,predict,predict_quantized}.  x: numpy, [B, *input_shape]."""
+    m0 = models[0]
+    kinds = {"run_quantized": (m0.dtype, m0.dtype, "mf_models_run_quantized"),
+             "predict": (np.float32, np.float32, "mf_models_predict"),
+             "predict_quantized": (m0.dtype, np.float32, "mf_models_predict_quantized")}
+    in_dt, out_dt, fn = kinds[entry]
+    a = np.ascontiguousarray(x, dtype=in_dt)
+    if a.size % m0.input_elems:
+        raise ValueError("input has %d elements, expected a multiple of %d" % (a.size, m0.input_elems))
+    batch = a.size // m0.input_elems
+    for m in models:
+        m._ensure(max(1, -(-batch // len(models))))
+    out = np.empty((batch, m0.output_elems), out_dt)
+    handles = (C.c_void_p * len(models))(*[m._h for m in models])
+    _lib.check(getattr(_lib.lib(), fn)(handles, len(models), a.ctypes.data_as(C.c_void_p), batch,
+                                       out.ctypes.data_as(C.c_void_p)))
+    return out.reshape((batch,) + tuple(m0.output_shape))
+
+
 def synth_i8(seed, first_byte, n, device=None):
     """Counter-based synthetic int8 stream generated directly in HBM (mf_synth_i8)."""
     import torch

@@ -276,3 +276,31 @@ def test_empty_batch_is_a_no_op(models):
     mf = importlib.import_module("microflow_rs_amd")
     op = mf.ops.prepare_softmax(1, 4, 0.1, 1 / 256, -128)
     assert op(np.zeros((0, 1, 4), np.int8)).shape == (0, 1, 4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,n,replicas", [("speech", 7, 3), ("person_detect", 5, 2), ("sine", 2, 4)])
+def test_sharded_replicas_in_one_process(O, name, n, replicas):
+    """mf_models_*: one host batch cut into contiguous shards over several prepared replicas, one
+    host thread each (on an 8-GPU node: one replica per GPU; here all replicas share the one GPU,
+    which exercises the same sharding, threading and error paths).  Ragged shards and more
+    replicas than images included."""
+    mf = importlib.import_module("microflow_rs_amd")
+    reps = [mf.Model(model_path(name), device=0) for _ in range(replicas)]
+    om = O.Model(model_path(name))
+    rng = np.random.default_rng(n * replicas)
+    xq = rng.integers(-128, 128, (n, reps[0].input_elems)).astype(np.int8)
+    want = om.run_quantized_batch(xq)
+    got = mf.run_sharded(reps, xq)
+    assert np.array_equal(got.reshape(n, -1), want)
+    pq = mf.run_sharded(reps, xq, "predict_quantized").reshape(n, -1)
+    assert np.array_equal(pq.view(np.uint32), np.stack([om.predict_quantized(x).reshape(-1) for x in xq]).view(np.uint32))
+    xf = ((xq.astype(np.float32) - np.float32(om.in_zp)) * om.in_scale).astype(np.float32)
+    pf = mf.run_sharded(reps, xf, "predict").reshape(n, -1)
+    assert np.array_equal(pf.view(np.uint32), np.stack([om.predict(x).reshape(-1) for x in xf]).view(np.uint32))
+    # handles of different models are rejected
+    other = mf.Model(model_path("sine" if name != "sine" else "speech"), device=0)
+    other.prepare(1)
+    with pytest.raises(mf.MicroflowError):
+        mf._lib.check(mf.lib().mf_models_run_quantized(
+            (__import__("ctypes").c_void_p * 2)(reps[0]._h, other._h), 2, xq.ctypes.data, n, got.ctypes.data))
