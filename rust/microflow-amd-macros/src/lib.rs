@@ -53,12 +53,19 @@ pub fn model(args: TokenStream, item: TokenStream) -> TokenStream {
                 let v = microflow_amd::layout::#flatten(&input);
                 microflow_amd::layout::#unflatten(&Self::handle().#qcall(&v, 1))
             }
-            /// New surface: B independent inferences in one launch sequence.
+            fn all_devices() -> std::sync::MutexGuard<'static, microflow_amd::ModelSet> {
+                static S: once_cell::sync::Lazy<std::sync::Mutex<microflow_amd::ModelSet>> =
+                    once_cell::sync::Lazy::new(|| std::sync::Mutex::new(
+                        microflow_amd::ModelSet::new(include_bytes!(#p))));
+                S.lock().unwrap()
+            }
+            /// New surface: B independent inferences, sharded over every visible GPU
+            /// (one launch sequence per device; no collective).
             pub fn predict_batch(inputs: &[microflow_amd::buffer::#ibuf<f32, #(#ishape),*>])
                 -> Vec<microflow_amd::buffer::#obuf<f32, #(#oshape),*>> {
                 let mut v = Vec::new();
                 for i in inputs { v.extend(microflow_amd::layout::#flatten(i)); }
-                let out = Self::handle().predict(&v, inputs.len());
+                let out = Self::all_devices().predict(&v, inputs.len());
                 let n = out.len() / inputs.len().max(1);
                 out.chunks(n).map(|c| microflow_amd::layout::#unflatten(c)).collect()
             }

@@ -57,6 +57,9 @@ extern "C" {
     pub fn mf_model_predict_quantized(model: *mut mf_model, input: *const i8, batch: usize, output: *mut f32, mem: c_int) -> c_int;
     pub fn mf_model_run_quantized(model: *mut mf_model, input: *const i8, batch: usize, output: *mut i8, mem: c_int) -> c_int;
     pub fn mf_model_set_stream(model: *mut mf_model, stream: *mut c_void) -> c_int;
+    pub fn mf_device_count() -> c_int;
+    pub fn mf_models_predict(models: *const *mut mf_model, n_models: c_int, input: *const f32, batch: usize,
+                             output: *mut f32) -> c_int;
 }
 
 /// One prepared model on one GPU.  Not `Sync`: the C handle is single-threaded; the macro
@@ -111,6 +114,26 @@ impl Model {
         out
     }
 }
+/// One replica of the model per visible GPU, driven from this one process: `predict` cuts the
+/// batch into contiguous shards, one per device (mf_models_predict; no collective).
+pub struct ModelSet {
+    replicas: Vec<Model>,
+}
+impl ModelSet {
+    pub fn new(bytes: &'static [u8]) -> Self {
+        let n = unsafe { mf_device_count() }.max(1);
+        ModelSet { replicas: (0..n).map(|d| Model::new(bytes, d)).collect() }
+    }
+    pub fn predict(&mut self, input: &[f32], batch: usize) -> Vec<f32> {
+        let info = self.replicas[0].info;
+        assert_eq!(input.len(), batch * info.input_elems);
+        let mut out = vec![0f32; batch * info.output_elems];
+        let raws: Vec<*mut mf_model> = self.replicas.iter().map(|m| m.raw).collect();
+        check(unsafe { mf_models_predict(raws.as_ptr(), raws.len() as c_int, input.as_ptr(), batch, out.as_mut_ptr()) });
+        out
+    }
+}
+
 impl Drop for Model {
     fn drop(&mut self) {
         unsafe { mf_model_destroy(self.raw) }
