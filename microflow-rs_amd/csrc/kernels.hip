@@ -1705,6 +1705,19 @@ const char *dw_fast_name(int H, int W, int C, int S) {
 }
 bool launch_dw_fast(int H, int W, int C, int S, const int8_t *in, int8_t *out, const DwFastArgs &a,
                     int batch, hipStream_t s) {
+    static const int alt = [] { const char *e = getenv("MF_DW_ALT"); return e ? atoi(e) : -1; }();
+    if (alt >= 0) { // tuning candidates, see MF_DW_ALT_SHAPES
+        int idx = 0;
+        (void)idx;
+#define MF_DW(h, w, c, st, g, t)                                                \
+    if (idx++ == alt && H == h && W == w && C == c && S == st) {                \
+        if (a.magic) launch_dw<h, w, c, st, g, t, true>(in, out, a, batch, s);  \
+        else launch_dw<h, w, c, st, g, t, false>(in, out, a, batch, s);         \
+        return true;                                                            \
+    }
+        MF_DW_ALT_SHAPES(MF_DW)
+#undef MF_DW
+    }
 #define MF_DW(h, w, c, st, g, t)                          \
     if (H == h && W == w && C == c && S == st) {          \
         if (a.magic) launch_dw<h, w, c, st, g, t, true>(in, out, a, batch, s); \

@@ -138,12 +138,17 @@ struct TailArgs {
     X(48, 48, 8, 1, 1, 512)  \
     X(48, 48, 16, 2, 1, 512) \
     X(24, 24, 32, 1, 1, 512) \
-    X(24, 24, 32, 2, 1, 256) \
-    X(12, 12, 64, 1, 1, 256) \
+    X(24, 24, 32, 2, 1, 512) \
+    X(12, 12, 64, 1, 2, 512) \
     X(12, 12, 64, 2, 2, 256) \
-    X(6, 6, 128, 1, 2, 256)  \
+    X(6, 6, 128, 1, 4, 512)  \
     X(6, 6, 128, 2, 4, 256)  \
     X(3, 3, 256, 1, 4, 256)
+
+// tuning candidates for the table above (MF_DW_ALT=<i>, scripts/tune_dw.sh); empty in the product
+// build.  Last sweep (r01, 25 candidates): 12x12x64 s1 -> (G=2, 512 thr) -11 %, 6x6x128 s1 ->
+// (G=4, 512 thr) -16 %, 24x24x32 s2 -> 512 thr -4 %; the rest already at their best.
+#define MF_DW_ALT_SHAPES(X)
 
 // fused depthwise 3x3 + pointwise pairs: H, W, C, stride, N (pointwise outputs), images per
 // step, threads per workgroup, double-buffered staging (1) or single (0)
