@@ -222,7 +222,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm(const int8_t *__restrict__ 
         stage(0, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (wm == 1) __builtin_amdgcn_s_barrier(); // stagger
+        if ((wave >> 2) == 1) __builtin_amdgcn_s_barrier(); // stagger
         int cur = 0;
         for (int kt = 0; kt < nk; ++kt, cur ^= 1) {
             const uint8_t *lb = lds + cur * BUF;
@@ -265,7 +265,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm(const int8_t *__restrict__ 
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        if (wm == 0) __builtin_amdgcn_s_barrier(); // balance the stagger
+        if ((wave >> 2) == 0) __builtin_amdgcn_s_barrier(); // balance the stagger
     } else if constexpr (MODE == 4) {
         // Two wave groups (wm = 0 / 1: one wave of each per SIMD) run ONE BARRIER apart, so that
         // one group's MFMA section coincides with the other group's LDS-read / DMA-issue section.
@@ -528,6 +528,8 @@ int main(int argc, char **argv) {
     run<256, 256, 2, 4, 128, 2, 4>("256x256 BK128 2buf staggered wave groups", dX, dY, a, ref.data(), r0, nrows, iters);
     run<256, 256, 2, 4, 128, 2, 5>("256x256 staggered, DMA inside MFMA sections", dX, dY, a, ref.data(), r0, nrows, iters);
     run<256, 256, 2, 4, 128, 2, 6>("256x256 staggered, 2 phases x 16 MFMA", dX, dY, a, ref.data(), r0, nrows, iters);
+    run<256, 256, 4, 2, 128, 2, 6>("256x256 staggered 2x16, waves 4x2", dX, dY, a, ref.data(), r0, nrows, iters);
+    run<256, 256, 2, 4, 128, 2, 6>("256x256 staggered, 2 phases x 16 MFMA (again)", dX, dY, a, ref.data(), r0, nrows, iters);
     run<256, 256, 2, 4, 128, 2, 3>("256x256 BK128 2buf frag double-buffer", dX, dY, a, ref.data(), r0, nrows, iters);
     run<256, 256, 4, 2, 128, 2, 3>("256x256 BK128 2buf frag db, waves 4x2", dX, dY, a, ref.data(), r0, nrows, iters);
     run<256, 256, 2, 4, 128, 2, 2>("256x256 BK128 2buf DMA interleaved w/ MFMA", dX, dY, a, ref.data(), r0, nrows, iters);
