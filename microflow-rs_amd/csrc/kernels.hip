@@ -79,6 +79,13 @@ __device__ __forceinline__ uint32_t pack4(int a, int b, int c, int d) {
     return __builtin_amdgcn_perm(hi, lo, 0x05040100u);
 }
 
+// pack4 for either element type: XR4 = 0x80808080 moves u8-domain epilogue results (0..255) back
+// to the stored i8 domain (kernels.hpp), XR4 = 0 is plain i8 (the XOR disappears at compile time)
+template <uint32_t XR4>
+__device__ __forceinline__ uint32_t pack4x(int a, int b, int c, int d) {
+    return pack4(a, b, c, d) ^ XR4;
+}
+
 __device__ __forceinline__ int sdot4(uint32_t a, uint32_t b, int c) {
     return __builtin_amdgcn_sdot4((int)a, (int)b, c, false);
 }
@@ -527,7 +534,7 @@ __device__ __forceinline__ void dw_s2_task(const uint8_t *base, const uint32_t (
 // One barrier per step: after it, every wave has finished reading the other buffer
 // (safe to overwrite) and every wave's DMAs into this buffer have landed.
 // ------------------------------------------------------------------------
-template <int H, int W, int C, int S, int G, int NTHR, bool MG>
+template <int H, int W, int C, int S, int G, int NTHR, bool MG, uint32_t XR4>
 __global__ __launch_bounds__(NTHR) void dw3x3_nhwc(const int8_t *__restrict__ in,
                                                   int8_t *__restrict__ out, DwFastArgs p,
                                                   int batch) {
@@ -623,10 +630,10 @@ __global__ __launch_bounds__(NTHR) void dw3x3_nhwc(const int8_t *__restrict__ in
 #pragma unroll
                     for (int j = 0; j < R; ++j) {
                         uint32_t *dp = dst + ((size_t)(g * OH + oy0 + j) * OW + ox0) * C4 + cg;
-                        dp[0] = pack4(requant_t<MG>(o0[j][0], A.x, Sc.x, p.lo_f, p.hi_f), requant_t<MG>(o0[j][1], A.y, Sc.y, p.lo_f, p.hi_f),
+                        dp[0] = pack4x<XR4>(requant_t<MG>(o0[j][0], A.x, Sc.x, p.lo_f, p.hi_f), requant_t<MG>(o0[j][1], A.y, Sc.y, p.lo_f, p.hi_f),
                                       requant_t<MG>(o0[j][2], A.z, Sc.z, p.lo_f, p.hi_f), requant_t<MG>(o0[j][3], A.w, Sc.w, p.lo_f, p.hi_f));
                         if (ox0 + 1 < OW)
-                            dp[C4] = pack4(requant_t<MG>(o1[j][0], A.x, Sc.x, p.lo_f, p.hi_f), requant_t<MG>(o1[j][1], A.y, Sc.y, p.lo_f, p.hi_f),
+                            dp[C4] = pack4x<XR4>(requant_t<MG>(o1[j][0], A.x, Sc.x, p.lo_f, p.hi_f), requant_t<MG>(o1[j][1], A.y, Sc.y, p.lo_f, p.hi_f),
                                            requant_t<MG>(o1[j][2], A.z, Sc.z, p.lo_f, p.hi_f), requant_t<MG>(o1[j][3], A.w, Sc.w, p.lo_f, p.hi_f));
                     }
                 }
@@ -648,7 +655,7 @@ __global__ __launch_bounds__(NTHR) void dw3x3_nhwc(const int8_t *__restrict__ in
 // two izp rows; the only tap that is not covered by those rows, column -1 of the first
 // pixel pair, is patched with a select.
 // ------------------------------------------------------------------------
-template <int H, int W, int G, bool MG>
+template <int H, int W, int G, bool MG, uint32_t XR4>
 __global__ __launch_bounds__(256) void dw3x3_stem8(const int8_t *__restrict__ in,
                                                    int8_t *__restrict__ out, DwStemArgs p,
                                                    int batch) {
@@ -727,10 +734,10 @@ __global__ __launch_bounds__(256) void dw3x3_stem8(const int8_t *__restrict__ in
                     qb[c] = requant_t<MG>(b, p.A[c], p.S[c], p.lo_f, p.hi_f);
                 }
                 uint4 v;
-                v.x = pack4(qa[0], qa[1], qa[2], qa[3]);
-                v.y = pack4(qa[4], qa[5], qa[6], qa[7]);
-                v.z = pack4(qb[0], qb[1], qb[2], qb[3]);
-                v.w = pack4(qb[4], qb[5], qb[6], qb[7]);
+                v.x = pack4x<XR4>(qa[0], qa[1], qa[2], qa[3]);
+                v.y = pack4x<XR4>(qa[4], qa[5], qa[6], qa[7]);
+                v.z = pack4x<XR4>(qb[0], qb[1], qb[2], qb[3]);
+                v.w = pack4x<XR4>(qb[4], qb[5], qb[6], qb[7]);
                 dst[o] = v;
             }
         }
@@ -752,7 +759,7 @@ __global__ __launch_bounds__(256) void dw3x3_stem8(const int8_t *__restrict__ in
 //            from LDS as broadcast b128s.
 // Every input byte is read from HBM once; the kernel is VALU-bound (54 MAC per byte).
 // ------------------------------------------------------------------------
-template <bool MG>
+template <bool MG, uint32_t XR4>
 __global__ __launch_bounds__(512) void dw_c1_lds(const int8_t *__restrict__ in, int8_t *__restrict__ out,
                                                  DwC1Args p, size_t batch) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -828,9 +835,9 @@ __global__ __launch_bounds__(512) void dw_c1_lds(const int8_t *__restrict__ in, 
             for (int c = 0; c < 8; ++c) q[c] = requant_t<MG>(acc[c], A[c], S[c], p.lo_f, p.hi_f);
             int8_t *dst = out + (img * (size_t)p.OH * p.OW + o) * p.N;
             if (p.N == 8) {
-                *(uint2 *)dst = make_uint2(pack4(q[0], q[1], q[2], q[3]), pack4(q[4], q[5], q[6], q[7]));
+                *(uint2 *)dst = make_uint2(pack4x<XR4>(q[0], q[1], q[2], q[3]), pack4x<XR4>(q[4], q[5], q[6], q[7]));
             } else {
-                for (int c = 0; c < p.N; ++c) dst[c] = (int8_t)q[c];
+                for (int c = 0; c < p.N; ++c) dst[c] = (int8_t)(q[c] ^ (int)(XR4 & 0xffu));
             }
         }
     }
@@ -858,7 +865,7 @@ __global__ __launch_bounds__(512) void dw_c1_lds(const int8_t *__restrict__ in, 
 // N > 64 is split over the waves of the workgroup (NSPLIT = N/64), which all read the
 // same pixels (L1/L2 hits).  HBM-bound: MFMA work is ~1/8 of the memory time.
 // ------------------------------------------------------------------------
-template <int K, int N, bool MG>
+template <int K, int N, bool MG, uint32_t XR4>
 __global__ __launch_bounds__(256) void pw_mfma(const int8_t *__restrict__ in,
                                                int8_t *__restrict__ out, PwArgs p,
                                                long long npix) {
@@ -965,7 +972,7 @@ __global__ __launch_bounds__(256) void pw_mfma(const int8_t *__restrict__ in,
                         const int q1 = requant_t<MG>(acc[1], cA[tt].y, cS[tt].y, p.lo_f, p.hi_f);
                         const int q2 = requant_t<MG>(acc[2], cA[tt].z, cS[tt].z, p.lo_f, p.hi_f);
                         const int q3 = requant_t<MG>(acc[3], cA[tt].w, cS[tt].w, p.lo_f, p.hi_f);
-                        packed[tt] = pack4(q0, q1, q2, q3);
+                        packed[tt] = pack4x<XR4>(q0, q1, q2, q3);
                     }
                     if constexpr (XPOSE) {
                         uint8_t *dstp = patch + wave * CBYTES + lpix * N + g * (NB / 4);
@@ -1018,7 +1025,7 @@ __global__ __launch_bounds__(256) void pw_mfma(const int8_t *__restrict__ in,
 // tensor, it just never leaves the CU).  Single-buffered variants issue the next step's DMA
 // right after the second barrier, so it still overlaps the pointwise phase.
 // ------------------------------------------------------------------------
-template <int H, int W, int C, int S, int N, int G, int NTHR, bool DBUF, bool MG>
+template <int H, int W, int C, int S, int N, int G, int NTHR, bool DBUF, bool MG, uint32_t XR4>
 __global__ __launch_bounds__(NTHR) void dwpw3x3(const int8_t *__restrict__ in,
                                                 int8_t *__restrict__ out, DwPwArgs p, int batch) {
     // ---- depthwise geometry (as dw3x3_nhwc) ----
@@ -1141,10 +1148,10 @@ __global__ __launch_bounds__(NTHR) void dwpw3x3(const int8_t *__restrict__ in,
 #pragma unroll
                     for (int j = 0; j < R; ++j) {
                         uint32_t *dp = (uint32_t *)mid + ((size_t)(g * OH + oy0 + j) * OW + ox0) * C4 + cg;
-                        dp[0] = pack4(requant_t<MG>(o0[j][0], dA.x, dS.x, p.dw.lo_f, p.dw.hi_f), requant_t<MG>(o0[j][1], dA.y, dS.y, p.dw.lo_f, p.dw.hi_f),
+                        dp[0] = pack4x<XR4>(requant_t<MG>(o0[j][0], dA.x, dS.x, p.dw.lo_f, p.dw.hi_f), requant_t<MG>(o0[j][1], dA.y, dS.y, p.dw.lo_f, p.dw.hi_f),
                                       requant_t<MG>(o0[j][2], dA.z, dS.z, p.dw.lo_f, p.dw.hi_f), requant_t<MG>(o0[j][3], dA.w, dS.w, p.dw.lo_f, p.dw.hi_f));
                         if (ox0 + 1 < OW)
-                            dp[C4] = pack4(requant_t<MG>(o1[j][0], dA.x, dS.x, p.dw.lo_f, p.dw.hi_f), requant_t<MG>(o1[j][1], dA.y, dS.y, p.dw.lo_f, p.dw.hi_f),
+                            dp[C4] = pack4x<XR4>(requant_t<MG>(o1[j][0], dA.x, dS.x, p.dw.lo_f, p.dw.hi_f), requant_t<MG>(o1[j][1], dA.y, dS.y, p.dw.lo_f, p.dw.hi_f),
                                            requant_t<MG>(o1[j][2], dA.z, dS.z, p.dw.lo_f, p.dw.hi_f), requant_t<MG>(o1[j][3], dA.w, dS.w, p.dw.lo_f, p.dw.hi_f));
                     }
                 }
@@ -1192,7 +1199,7 @@ __global__ __launch_bounds__(NTHR) void dwpw3x3(const int8_t *__restrict__ in,
 #pragma unroll
                     for (int ks = 0; ks < KS; ++ks)
                         acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(Aw[q][tt][ks], B[ks], acc, 0, 0, 0);
-                    packed[tt] = pack4(requant_t<MG>(acc[0], cA[tt].x, cS[tt].x, p.pw.lo_f, p.pw.hi_f),
+                    packed[tt] = pack4x<XR4>(requant_t<MG>(acc[0], cA[tt].x, cS[tt].x, p.pw.lo_f, p.pw.hi_f),
                                        requant_t<MG>(acc[1], cA[tt].y, cS[tt].y, p.pw.lo_f, p.pw.hi_f),
                                        requant_t<MG>(acc[2], cA[tt].z, cS[tt].z, p.pw.lo_f, p.pw.hi_f),
                                        requant_t<MG>(acc[3], cA[tt].w, cS[tt].w, p.pw.lo_f, p.pw.hi_f));
@@ -1685,15 +1692,26 @@ void launch_checksum(const int8_t *in, size_t n, unsigned long long *result, hip
 }
 
 // ---- fast-path dispatch tables ------------------------------------------------
-template <int H, int W, int C, int S, int G, int NTHR, bool MG>
+// the four instances of a fast kernel: {v_cvt, bit-pattern} int->f32  x  {i8, u8} element type
+#define MF_DISPATCH4(magic, xr, FN, ARGS, ...)                         \
+    do {                                                               \
+        if (xr) {                                                      \
+            if (magic) FN<__VA_ARGS__, true, 0x80808080u> ARGS;        \
+            else FN<__VA_ARGS__, false, 0x80808080u> ARGS;             \
+        } else {                                                       \
+            if (magic) FN<__VA_ARGS__, true, 0u> ARGS;                 \
+            else FN<__VA_ARGS__, false, 0u> ARGS;                      \
+        }                                                              \
+    } while (0);
+template <int H, int W, int C, int S, int G, int NTHR, bool MG, uint32_t XR4>
 static void launch_dw(const int8_t *in, int8_t *out, const DwFastArgs &a, int batch, hipStream_t s) {
     constexpr int LP = C < 16 ? 16 : C;
     constexpr int lds = 2 * G * (H + 2) * (LP + W * C + LP) + 256; // two staging buffers + read slack
     static LaunchState st;
-    const int per_cu = prepared(st, dw3x3_nhwc<H, W, C, S, G, NTHR, MG>, NTHR, lds);
+    const int per_cu = prepared(st, dw3x3_nhwc<H, W, C, S, G, NTHR, MG, XR4>, NTHR, lds);
     const int nsteps = (batch + G - 1) / G;
     const int grid = nsteps < 256 * per_cu ? nsteps : 256 * per_cu;
-    hipLaunchKernelGGL((dw3x3_nhwc<H, W, C, S, G, NTHR, MG>), dim3(grid), dim3(NTHR), lds, s, in, out, a, batch);
+    hipLaunchKernelGGL((dw3x3_nhwc<H, W, C, S, G, NTHR, MG, XR4>), dim3(grid), dim3(NTHR), lds, s, in, out, a, batch);
 }
 
 const char *dw_fast_name(int H, int W, int C, int S) {
@@ -1711,8 +1729,7 @@ bool launch_dw_fast(int H, int W, int C, int S, const int8_t *in, int8_t *out, c
         (void)idx;
 #define MF_DW(h, w, c, st, g, t)                                                \
     if (idx++ == alt && H == h && W == w && C == c && S == st) {                \
-        if (a.magic) launch_dw<h, w, c, st, g, t, true>(in, out, a, batch, s);  \
-        else launch_dw<h, w, c, st, g, t, false>(in, out, a, batch, s);         \
+        MF_DISPATCH4(a.magic, a.xr, launch_dw, (in, out, a, batch, s), h, w, c, st, g, t) \
         return true;                                                            \
     }
         MF_DW_ALT_SHAPES(MF_DW)
@@ -1720,8 +1737,7 @@ bool launch_dw_fast(int H, int W, int C, int S, const int8_t *in, int8_t *out, c
     }
 #define MF_DW(h, w, c, st, g, t)                          \
     if (H == h && W == w && C == c && S == st) {          \
-        if (a.magic) launch_dw<h, w, c, st, g, t, true>(in, out, a, batch, s); \
-        else launch_dw<h, w, c, st, g, t, false>(in, out, a, batch, s);       \
+        MF_DISPATCH4(a.magic, a.xr, launch_dw, (in, out, a, batch, s), h, w, c, st, g, t) \
         return true;                                      \
     }
     MF_DW_SHAPES(MF_DW)
@@ -1738,8 +1754,11 @@ bool dw_c1_supported(const DwC1Args &a) {
 }
 void launch_dw_c1(const int8_t *in, int8_t *out, const DwC1Args &a, size_t batch, hipStream_t s) {
     const int grid = (int)(batch < 256 * 8 ? batch : 256 * 8);
-    if (a.magic) hipLaunchKernelGGL(dw_c1_lds<true>, dim3(grid), dim3(512), dw_c1_lds_bytes(a), s, in, out, a, batch);
-    else hipLaunchKernelGGL(dw_c1_lds<false>, dim3(grid), dim3(512), dw_c1_lds_bytes(a), s, in, out, a, batch);
+    const int lds = dw_c1_lds_bytes(a);
+#define MF_C1(MG, XR) hipLaunchKernelGGL((dw_c1_lds<MG, XR>), dim3(grid), dim3(512), lds, s, in, out, a, batch)
+    if (a.xr) { if (a.magic) MF_C1(true, 0x80808080u); else MF_C1(false, 0x80808080u); }
+    else { if (a.magic) MF_C1(true, 0u); else MF_C1(false, 0u); }
+#undef MF_C1
 }
 
 const char *dw_stem_name(int H, int W, int DM, int S) {
@@ -1750,19 +1769,20 @@ bool launch_dw_stem(int H, int W, int DM, int S, const int8_t *in, int8_t *out, 
                     int batch, hipStream_t s) {
     if (H == 96 && W == 96 && DM == 8 && S == 2) {
         constexpr int G = 2, lds = 2 * G * (16 + (96 + 2) * 96);
-        static LaunchState st0, st1;
-        const int per_cu = a.magic ? prepared(st1, dw3x3_stem8<96, 96, G, true>, 256, lds)
-                                   : prepared(st0, dw3x3_stem8<96, 96, G, false>, 256, lds);
+        static LaunchState st;
+        const int per_cu = prepared(st, dw3x3_stem8<96, 96, G, false, 0u>, 256, lds); // same for every variant
         const int nsteps = (batch + G - 1) / G;
         const int grid = nsteps < 256 * per_cu ? nsteps : 256 * per_cu;
-        if (a.magic) hipLaunchKernelGGL((dw3x3_stem8<96, 96, G, true>), dim3(grid), dim3(256), lds, s, in, out, a, batch);
-        else hipLaunchKernelGGL((dw3x3_stem8<96, 96, G, false>), dim3(grid), dim3(256), lds, s, in, out, a, batch);
+#define MF_STEM(MG, XR) hipLaunchKernelGGL((dw3x3_stem8<96, 96, G, MG, XR>), dim3(grid), dim3(256), lds, s, in, out, a, batch)
+        if (a.xr) { if (a.magic) MF_STEM(true, 0x80808080u); else MF_STEM(false, 0x80808080u); }
+        else { if (a.magic) MF_STEM(true, 0u); else MF_STEM(false, 0u); }
+#undef MF_STEM
         return true;
     }
     return false;
 }
 
-template <int H, int W, int C, int S, int N, int G, int NTHR, int DB, bool MG>
+template <int H, int W, int C, int S, int N, int G, int NTHR, int DB, bool MG, uint32_t XR4>
 static void launch_dwpw_t(const int8_t *in, int8_t *out, const DwPwArgs &a, int batch, hipStream_t s) {
     constexpr int LP = C < 16 ? 16 : C;
     constexpr int OH = (H + S - 1) / S, OW = (W + S - 1) / S;
@@ -1772,10 +1792,10 @@ static void launch_dwpw_t(const int8_t *in, int8_t *out, const DwPwArgs &a, int 
     constexpr int lds = (DB ? 2 : 1) * BUF + 256 + G * OH * OW * C + 64 + patch;
     static_assert(lds <= 163840, "fused tile does not fit the LDS");
     static LaunchState st;
-    const int per_cu = prepared(st, dwpw3x3<H, W, C, S, N, G, NTHR, (DB != 0), MG>, NTHR, lds);
+    const int per_cu = prepared(st, dwpw3x3<H, W, C, S, N, G, NTHR, (DB != 0), MG, XR4>, NTHR, lds);
     const int nsteps = (batch + G - 1) / G;
     const int grid = nsteps < 256 * per_cu ? nsteps : 256 * per_cu;
-    hipLaunchKernelGGL((dwpw3x3<H, W, C, S, N, G, NTHR, (DB != 0), MG>), dim3(grid), dim3(NTHR), lds, s, in, out, a, batch);
+    hipLaunchKernelGGL((dwpw3x3<H, W, C, S, N, G, NTHR, (DB != 0), MG, XR4>), dim3(grid), dim3(NTHR), lds, s, in, out, a, batch);
 }
 const char *dwpw_name(int H, int W, int C, int S, int N) {
 #define MF_DWPW(h, w, c, s, n, g, t, d) \
@@ -1792,8 +1812,7 @@ bool launch_dwpw(int H, int W, int C, int S, int N, const int8_t *in, int8_t *ou
         (void)idx;
 #define MF_DWPW(h, w, c, st, n, g, t, d)                                        \
     if (idx++ == alt && H == h && W == w && C == c && S == st && N == n) {      \
-        if (a.dw.magic && a.pw.magic) launch_dwpw_t<h, w, c, st, n, g, t, d, true>(in, out, a, batch, s); \
-        else launch_dwpw_t<h, w, c, st, n, g, t, d, false>(in, out, a, batch, s); \
+        MF_DISPATCH4(a.dw.magic && a.pw.magic, a.pw.xr, launch_dwpw_t, (in, out, a, batch, s), h, w, c, st, n, g, t, d) \
         return true;                                                            \
     }
         MF_DWPW_ALT_SHAPES(MF_DWPW)
@@ -1801,8 +1820,7 @@ bool launch_dwpw(int H, int W, int C, int S, int N, const int8_t *in, int8_t *ou
     }
 #define MF_DWPW(h, w, c, st, n, g, t, d)                         \
     if (H == h && W == w && C == c && S == st && N == n) {       \
-        if (a.dw.magic && a.pw.magic) launch_dwpw_t<h, w, c, st, n, g, t, d, true>(in, out, a, batch, s); \
-        else launch_dwpw_t<h, w, c, st, n, g, t, d, false>(in, out, a, batch, s); \
+        MF_DISPATCH4(a.dw.magic && a.pw.magic, a.pw.xr, launch_dwpw_t, (in, out, a, batch, s), h, w, c, st, n, g, t, d) \
         return true;                                             \
     }
     MF_DWPW_SHAPES(MF_DWPW)
@@ -1823,6 +1841,10 @@ void launch_tail(const int8_t *in, int8_t *out, const TailArgs &a, size_t batch,
     }
 }
 
+template <int K, int N, bool MG, uint32_t XR4>
+static void launch_pw_t(const int8_t *in, int8_t *out, const PwArgs &a, long long npix, int grid, hipStream_t s) {
+    hipLaunchKernelGGL((pw_mfma<K, N, MG, XR4>), dim3(grid), dim3(256), 0, s, in, out, a, npix);
+}
 const char *pw_name(int K, int N) {
 #define MF_PW(k, n) \
     if (K == k && N == n) return "pw_mfma<" #k "," #n ">";
@@ -1839,8 +1861,7 @@ bool launch_pw(int K, int N, const int8_t *in, int8_t *out, const PwArgs &a, lon
         long long grid = (nchunks + SLOTS * U - 1) / (SLOTS * U);                               \
         if (grid > 256 * 8) grid = 256 * 8;                                                     \
         if (grid < 1) grid = 1;                                                                 \
-        if (a.magic) hipLaunchKernelGGL((pw_mfma<k, n, true>), dim3((int)grid), dim3(256), 0, s, in, out, a, npix); \
-        else hipLaunchKernelGGL((pw_mfma<k, n, false>), dim3((int)grid), dim3(256), 0, s, in, out, a, npix); \
+        MF_DISPATCH4(a.magic, a.xr, launch_pw_t, (in, out, a, npix, (int)grid, s), k, n)                  \
         return true;                                                                            \
     }
     MF_PW_SHAPES(MF_PW)

@@ -76,6 +76,7 @@ struct DwFastArgs {
     uint32_t izp4;      // izp replicated in 4 bytes
     float lo_f, hi_f;
     int magic;          // 1: worst-case |acc| < 2^22 -> bit-pattern int->float conversion (kernels.hip)
+    int xr;             // 0 (i8) or 0x80 (u8): see ConvArgs
 };
 // depthwise with ONE input channel and up to 8 output channels, any filter / stride (speech op 1)
 struct DwC1Args {
@@ -87,7 +88,7 @@ struct DwC1Args {
     const float *A;
     const float *S;
     const int *Kc;
-    int magic;
+    int magic, xr;
 };
 struct DwStemArgs {
     uint32_t wrow[3][8]; // [ky][c] = bytes (w[ky][0][c], w[ky][1][c], w[ky][2][c], 0)
@@ -95,7 +96,7 @@ struct DwStemArgs {
     int Kc[8];
     uint32_t izp4;
     float lo_f, hi_f;
-    int magic;
+    int magic, xr;
 };
 struct DwPwArgs;
 struct PwArgs {
@@ -104,7 +105,7 @@ struct PwArgs {
     const float *S;
     const int *Kc;
     float lo_f, hi_f;
-    int magic;
+    int magic, xr;
 };
 
 // fused DepthwiseConv2D 3x3 -> Conv2D 1x1: both argument blocks

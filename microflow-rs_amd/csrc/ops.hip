@@ -234,8 +234,8 @@ OpImpl *op_create(int device, const OpSpec &spec) {
         a.xr = xr;
         op->generic_name = dw ? "dwconv_generic" : "conv2d_generic";
 
-        // the shape-specialised kernels below store i8-domain epilogue results only
-        const bool zero_wzp = all_zero(wzp) && !s.u8;
+        // (for u8 these are the shifted zero points: the fast kernels need wzp_u8 == 128)
+        const bool zero_wzp = all_zero(wzp);
         const bool same3x3 = s.KH == 3 && s.KW == 3 && s.pad == MF_PAD_SAME && s.sh == s.sw &&
                              s.OH == (s.H + s.sh - 1) / s.sh && s.OW == (s.W + s.sw - 1) / s.sw;
         if (dw && zero_wzp && same3x3 && s.C == s.N && k::dw_fast_name(s.H, s.W, s.C, s.sh)) {
@@ -244,7 +244,7 @@ OpImpl *op_create(int device, const OpSpec &spec) {
             k::DwFastArgs &f = op->dwf;
             f.w = a.w, f.A = a.A, f.S = a.S, f.Kc = a.Kc;
             f.izp4 = 0x01010101u * (uint32_t)(uint8_t)(int8_t)s.izp;
-            f.lo_f = a.lo_f, f.hi_f = a.hi_f, f.magic = magic;
+            f.lo_f = a.lo_f, f.hi_f = a.hi_f, f.magic = magic, f.xr = xr;
         } else if (dw && zero_wzp && same3x3 && s.C == 1 && k::dw_stem_name(s.H, s.W, s.N, s.sh)) {
             op->fast = OpImpl::DW_STEM;
             op->fast_name = k::dw_stem_name(s.H, s.W, s.N, s.sh);
@@ -258,13 +258,13 @@ OpImpl *op_create(int device, const OpSpec &spec) {
                 }
             for (int c = 0; c < 8; ++c) f.A[c] = A[c], f.S[c] = S[c], f.Kc[c] = Kc[c];
             f.izp4 = 0x01010101u * (uint32_t)(uint8_t)(int8_t)s.izp;
-            f.lo_f = a.lo_f, f.hi_f = a.hi_f, f.magic = magic;
+            f.lo_f = a.lo_f, f.hi_f = a.hi_f, f.magic = magic, f.xr = xr;
         } else if (dw && zero_wzp && s.C == 1 && s.N <= 8) {
             // one input channel, few output channels, any filter: LDS-staged direct kernel
             k::DwC1Args &f = op->dwc1;
             f.H = s.H, f.W = s.W, f.N = s.N, f.KH = s.KH, f.KW = s.KW, f.sh = s.sh, f.sw = s.sw;
             f.OH = s.OH, f.OW = s.OW, f.pad_same = s.pad == MF_PAD_SAME, f.izp = s.izp;
-            f.lo_f = a.lo_f, f.hi_f = a.hi_f, f.A = a.A, f.S = a.S, f.Kc = a.Kc, f.magic = magic;
+            f.lo_f = a.lo_f, f.hi_f = a.hi_f, f.A = a.A, f.S = a.S, f.Kc = a.Kc, f.magic = magic, f.xr = xr;
             f.KG = (s.KW + 3) / 4;
             // a window row is read as KG + 1 aligned dwords starting at (row start & ~3)
             f.TWP = ((((s.OW - 1) * s.sw + 3) & ~3) + 4 * (f.KG + 1) + 3) & ~3;
@@ -289,7 +289,7 @@ OpImpl *op_create(int device, const OpSpec &spec) {
             op->d_wprep.upload(prep.data(), prep.size());
             k::PwArgs &f = op->pw;
             f.wprep = op->d_wprep.p, f.A = a.A, f.S = a.S, f.Kc = a.Kc;
-            f.lo_f = a.lo_f, f.hi_f = a.hi_f, f.magic = magic;
+            f.lo_f = a.lo_f, f.hi_f = a.hi_f, f.magic = magic, f.xr = xr;
         }
         if (getenv("MF_VERBOSE"))
             fprintf(stderr, "[microflow_amd] %s %dx%dx%d -> %d: kernel %s, worst-case |acc| %lld%s\n",

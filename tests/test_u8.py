@@ -303,6 +303,28 @@ def test_u8_models_bit_exact(mf, O, name, n):
 
 
 @pytest.mark.gpu
+def test_u8_person_detect_uses_the_fast_kernels(mf, O):
+    """A u8 model whose weight zero points are all 128 (what tools/make_u8_model.py produces from
+    the i8 person_detect) runs on the same shape-specialised and fused kernels as the i8 model,
+    instantiated with the u8 store (XR4 = 0x80808080); ragged batch, fused and layer-wise."""
+    data = _u8_model_bytes("person_detect")
+    m, om = mf.Model(data), O.Model(data)
+    rng = np.random.default_rng(23)
+    n = 37
+    xq = rng.integers(0, 256, (n, m.input_elems)).astype(np.uint8)
+    want = om.run_quantized_batch(xq)
+    assert np.array_equal(m.run_quantized(xq).reshape(n, -1), want)
+    names = [m.op(i)["kernel"] for i in range(m.num_ops)]
+    assert names[0].startswith("dw3x3_stem8") and sum(k.startswith("dwpw3x3") for k in names) == 13, names
+    m.set_fusion(False)
+    assert np.array_equal(m.run_quantized(xq).reshape(n, -1), want)
+    names = [m.op(i)["kernel"] for i in range(m.num_ops)]
+    assert sum(k.startswith("dw3x3_nhwc") for k in names) == 13 and sum(k.startswith("pw_mfma") for k in names) == 13, names
+    m.set_generic(True)
+    assert np.array_equal(m.run_quantized(xq[:5]).reshape(5, -1), want[:5])
+
+
+@pytest.mark.gpu
 def test_u8_model_device_tensors(mf, O):
     import torch
     data = _u8_model_bytes("speech")
