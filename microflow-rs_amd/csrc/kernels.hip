@@ -23,6 +23,7 @@
 #include <stdlib.h>
 
 #include <atomic>
+#include <type_traits>
 
 #include "kernels.hpp"
 
@@ -1166,7 +1167,10 @@ __global__ __launch_bounds__(NTHR) void dwpw3x3(const int8_t *__restrict__ in,
         const int npix = gvalid * OPIX;                       // valid pixels of this step
         const int nchunks = (npix + CPIX - 1) / CPIX;
         int8_t *obase = out + (size_t)step * G * OPIX * N;
-        for (int chunk = slot; chunk < nchunks; chunk += SLOTS) {
+        // One unit of pointwise work: sub-blocks [QLO, QHI) of a chunk -- compile-time bounds, so the
+        // MFMAs and epilogues of a unit stay one straight-line block.
+        auto pw_unit = [&](int chunk, auto qlo_c, auto qhi_c) {
+            constexpr int QLO = decltype(qlo_c)::value, QHI = decltype(qhi_c)::value;
             v4i B[KS];
             if constexpr (K >= 64) {
                 int pix = chunk * 16 + pcol;
@@ -1187,7 +1191,7 @@ __global__ __launch_bounds__(NTHR) void dwpw3x3(const int8_t *__restrict__ in,
                 B[0] = *(const v4i *)(mid + pix * 8);
             }
 #pragma unroll
-            for (int q = 0; q < Q; ++q) {
+            for (int q = QLO; q < QHI; ++q) {
                 int lpix;
                 if constexpr (K >= 64) lpix = pcol;
                 else if constexpr (K == 8) lpix = 2 * ((q >> 1) * 16 + pcol) + (q & 1);
@@ -1218,14 +1222,35 @@ __global__ __launch_bounds__(NTHR) void dwpw3x3(const int8_t *__restrict__ in,
             if constexpr (XPOSE) {
                 __builtin_amdgcn_wave_barrier();
                 const int cb = chunk * CBYTES, obytes = npix * N;
+                // sub-blocks [QLO, QHI) are the bytes [QLO, QHI) * CBYTES / Q of the chunk image
+                constexpr int LO = QLO * (CBYTES / Q), HI = QHI * (CBYTES / Q);
 #pragma unroll
-                for (int j = 0; j < CBYTES / 1024; ++j) {
-                    const int off = (j * 64 + lane) * 16;
-                    const uint4 v = *(const uint4 *)(lds + PATCH_OFF + wave * CBYTES + off);
-                    if (cb + off < obytes) *(uint4 *)(obase + cb + off) = v;
+                for (int j = 0; j < (HI - LO + 1023) / 1024; ++j) {
+                    const int off = LO + (j * 64 + lane) * 16;
+                    if (off < HI) {
+                        const uint4 v = *(const uint4 *)(lds + PATCH_OFF + wave * CBYTES + off);
+                        if (cb + off < obytes) *(uint4 *)(obase + cb + off) = v;
+                    }
                 }
                 __builtin_amdgcn_wave_barrier();
             }
+        };
+        // Whole chunks dealt round-robin leave the last round partly empty (18 chunks on 8 waves:
+        // 3 rounds for 2.25 rounds of work).  For K < 64 a chunk has Q >= 2 independent sub-blocks,
+        // so the unit of work is HALF a chunk (the B operand is loaded by both halves' waves): 36
+        // units on 8 waves = 4.5 half-rounds -> 5.  With an even number of slots a wave always
+        // draws the same half, i.e. it runs only one of the two code copies.
+        using std::integral_constant;
+        // (measured per shape, r01: -6 % and -9 % on the K = 16 and K = 32 stride-2 pairs, neutral on
+        // 24x24x32 stride 1; the K = 8 pair got 13 % slower, so it keeps whole chunks)
+        if constexpr (Q >= 2 && SLOTS % 2 == 0 && K >= 16) {
+            for (int u = slot; u < 2 * nchunks; u += SLOTS) {
+                if ((u & 1) == 0) pw_unit(u >> 1, integral_constant<int, 0>{}, integral_constant<int, Q / 2>{});
+                else pw_unit(u >> 1, integral_constant<int, Q / 2>{}, integral_constant<int, Q>{});
+            }
+        } else {
+            for (int chunk = slot; chunk < nchunks; chunk += SLOTS)
+                pw_unit(chunk, integral_constant<int, 0>{}, integral_constant<int, Q>{});
         }
         if constexpr (DBUF) cur ^= 1;
     }
