@@ -73,6 +73,17 @@ template <bool MG> __device__ __forceinline__ int4 magic4(int4 k) {
     return k;
 }
 
+// The shape-generic kernels also honour Rust's `NaN as i8 == 0` (a NaN can only come from
+// non-finite constants, i.e. a degenerate model); operators with non-finite constants are never
+// routed to the shape-specialised kernels (ops.hip), whose requant() skips this test.
+__device__ __forceinline__ int requant_any(int acc, float A, float S, float lo_f, float hi_f) {
+    const float x = __fadd_rn(A, __fmul_rn(S, (float)acc));
+    float r = __fadd_rn(x, __builtin_copysignf(0x1.fffffep-2f, x));
+    r = (r != r) ? 0.0f : r; // NaN -> 0, then the activation clamp like any other value
+    r = __builtin_amdgcn_fmed3f(r, lo_f, hi_f);
+    return (int)r;
+}
+
 // 4 ints in [-128,127] -> one dword of int8 (byte 0 = a)
 __device__ __forceinline__ uint32_t pack4(int a, int b, int c, int d) {
     const uint32_t lo = __builtin_amdgcn_perm((uint32_t)b, (uint32_t)a, 0x0c0c0400u);
@@ -135,7 +146,7 @@ __global__ __launch_bounds__(256) void conv2d_generic(const int8_t *__restrict__
             }
         }
         const int acc = dot - p.wzp[n] * vs + p.Kc[n];
-        out[idx] = (int8_t)(requant(acc, p.A[n], p.S[n], p.lo_f, p.hi_f) ^ p.xr);
+        out[idx] = (int8_t)(requant_any(acc, p.A[n], p.S[n], p.lo_f, p.hi_f) ^ p.xr);
     }
 }
 
@@ -166,7 +177,7 @@ __global__ __launch_bounds__(256) void dwconv_generic(const int8_t *__restrict__
             }
         }
         const int acc = dot - p.wzp[c] * vs + p.Kc[c];
-        out[idx] = (int8_t)(requant(acc, p.A[c], p.S[c], p.lo_f, p.hi_f) ^ p.xr);
+        out[idx] = (int8_t)(requant_any(acc, p.A[c], p.S[c], p.lo_f, p.hi_f) ^ p.xr);
     }
 }
 
@@ -234,7 +245,7 @@ __global__ __launch_bounds__(256) void fc_generic(const int8_t *__restrict__ in,
             }
         }
         const int acc = dot - p.wzp * rs + p.Kc[j];
-        out[idx] = (int8_t)(requant(acc, p.A[j], p.S, p.lo_f, p.hi_f) ^ p.xr);
+        out[idx] = (int8_t)(requant_any(acc, p.A[j], p.S, p.lo_f, p.hi_f) ^ p.xr);
     }
 }
 

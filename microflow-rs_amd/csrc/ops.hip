@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -142,6 +143,9 @@ int64_t fold_conv_constants(OpImpl &op, const OpSpec &s, bool depthwise, std::ve
     return vdev * max_wabs;
 }
 
+bool all_finite(const std::vector<float> &v) {
+    return std::all_of(v.begin(), v.end(), [](float x) { return std::isfinite(x); });
+}
 bool all_zero(const std::vector<int32_t> &v) {
     return std::all_of(v.begin(), v.end(), [](int32_t x) { return x == 0; });
 }
@@ -235,7 +239,8 @@ OpImpl *op_create(int device, const OpSpec &spec) {
         op->generic_name = dw ? "dwconv_generic" : "conv2d_generic";
 
         // (for u8 these are the shifted zero points: the fast kernels need wzp_u8 == 128)
-        const bool zero_wzp = all_zero(wzp);
+        // ... and finite constants (their epilogue has no NaN test)
+        const bool zero_wzp = all_zero(wzp) && all_finite(A) && all_finite(S);
         const bool same3x3 = s.KH == 3 && s.KW == 3 && s.pad == MF_PAD_SAME && s.sh == s.sw &&
                              s.OH == (s.H + s.sh - 1) / s.sh && s.OW == (s.W + s.sw - 1) / s.sw;
         if (dw && zero_wzp && same3x3 && s.C == s.N && k::dw_fast_name(s.H, s.W, s.C, s.sh)) {
@@ -347,7 +352,10 @@ OpImpl *op_create(int device, const OpSpec &spec) {
         a.lo_f = (float)lo, a.hi_f = (float)hi, a.xr = xr;
         a.w = op->d_w.as<int8_t>(), a.A = op->d_A.as<float>(), a.Kc = op->d_Kc.as<int>();
         op->generic_name = "fc_generic";
-        if (s.K % 16 == 0 && s.K >= 256 && (s.N == 1 || s.N == 2 || s.N == 4 || s.N == 8)) {
+        const bool finite = all_finite(A) && std::isfinite(a.S);
+        if (!finite) {
+            // degenerate constants: the generic kernel reproduces Rust's NaN -> 0 cast
+        } else if (s.K % 16 == 0 && s.K >= 256 && (s.N == 1 || s.N == 2 || s.N == 4 || s.N == 8)) {
             op->fast = OpImpl::FC_ROWWAVE;
             op->fast_name = "fc_rowwave<" + std::to_string(s.N) + ">";
         } else if (s.N % 128 == 0 && s.K % 128 == 0) {

@@ -482,3 +482,37 @@ def test_requantize_dense_sweep_fast_pointwise(mf, O):
         want = O.conv_2d(x[0], f, np.zeros(16, np.int8), 0, 0.05, ozp, act, 0, (1, 1), (H, W), c0, c1)
         got = op(x)[0]
         assert np.array_equal(got, want), (act, np.argwhere(got != want)[:5])
+
+
+def test_non_finite_constants_follow_rust_casts(mf, O):
+    """Degenerate models (NaN / Inf constants): Rust's `as i8` maps NaN to 0 and saturates +-Inf,
+    and the activation is applied afterwards.  Such operators are kept on the shape-generic
+    kernels, which reproduce that; the result equals the oracle's for conv, depthwise and FC."""
+    rng = np.random.default_rng(91)
+    H, W, C, N = 6, 6, 32, 32                      # a shape that normally takes the MFMA pointwise kernel
+    x = rng.integers(-128, 128, (2, H, W, C)).astype(np.int8)
+    f = rng.integers(-128, 128, (N, 1, 1, C)).astype(np.int8)
+    c0, c1 = _rand_consts(rng, N, C)
+    c0[[1, 5]] = [np.nan, -np.inf]
+    c1[[2, 7, 9]] = [np.nan, np.inf, -np.inf]
+    for act, ozp in ((0, 5), (1, -20), (3, -128)):
+        opts = mf.ops.Conv2DOptions(mf.FusedActivation(act), mf.TensorViewPadding.SAME, (1, 1))
+        op = mf.ops.prepare_conv_2d((H, W, C), f, np.zeros(N, np.int8), -128, 0.0235294122, ozp, opts, (c0, c1), (H, W))
+        assert op.kernel == "conv2d_generic"
+        want = np.stack([O.conv_2d(v, f, np.zeros(N, np.int8), -128, 0.0235294122, ozp, act, 0, (1, 1), (H, W), c0, c1) for v in x])
+        assert np.array_equal(op(x), want), act
+    w = rng.integers(-128, 128, (3, 3, C)).astype(np.int8)
+    opts = mf.ops.DepthwiseConv2DOptions(mf.FusedActivation(1), mf.TensorViewPadding.SAME, (1, 1))
+    op = mf.ops.prepare_depthwise_conv_2d((H, W, C), w, np.zeros(C, np.int8), -128, 0.05, -7, opts, (c0, c1), (H, W))
+    assert op.kernel == "dwconv_generic"
+    want = np.stack([O.depthwise_conv_2d(v, w, np.zeros(C, np.int8), -128, 0.05, -7, 1, 0, (1, 1), (H, W), c0, c1) for v in x])
+    assert np.array_equal(op(x), want)
+    xf = rng.integers(-128, 128, (128, 256)).astype(np.int8)
+    wf = rng.integers(-128, 128, (128, 256)).astype(np.int8)
+    fc0 = rng.uniform(-5, 5, 128).astype(f32)
+    fc0[3] = np.nan
+    for fc1 in (np.float32(np.nan), np.float32(np.inf), np.float32(1e-4)):
+        op = mf.ops.prepare_fully_connected(128, wf, 0, 0.05, 3, mf.ops.FullyConnectedOptions(), (fc0, fc1, np.zeros(128, np.int32), 0))
+        assert op.kernel == "fc_generic"
+        want = O.fully_connected(xf, wf, 0, 0.05, 3, 0, fc0, fc1, np.zeros(128, np.int32), 0)
+        assert np.array_equal(op(xf), want)
