@@ -82,6 +82,7 @@ struct OpImpl {
     OpSpec s; // pointers inside are NOT valid after create
     size_t in_elems = 0, out_elems = 0;
     bool force_generic = false;
+    bool finite_consts = true; // A / S all finite (the shape-specialised and fused epilogues assume it)
     std::string generic_name, fast_name;
     enum Fast { NONE, DW_NHWC, DW_STEM, DW_C1, PW_MFMA, FC_ROWWAVE, FC_MFMA } fast = NONE;
     int *d_rowsum = nullptr; // FC_MFMA with wzp != 0: per-row input sums
@@ -240,7 +241,8 @@ OpImpl *op_create(int device, const OpSpec &spec) {
 
         // (for u8 these are the shifted zero points: the fast kernels need wzp_u8 == 128)
         // ... and finite constants (their epilogue has no NaN test)
-        const bool zero_wzp = all_zero(wzp) && all_finite(A) && all_finite(S);
+        op->finite_consts = all_finite(A) && all_finite(S);
+        const bool zero_wzp = all_zero(wzp) && op->finite_consts;
         const bool same3x3 = s.KH == 3 && s.KW == 3 && s.pad == MF_PAD_SAME && s.sh == s.sw &&
                              s.OH == (s.H + s.sh - 1) / s.sh && s.OW == (s.W + s.sw - 1) / s.sw;
         if (dw && zero_wzp && same3x3 && s.C == s.N && k::dw_fast_name(s.H, s.W, s.C, s.sh)) {
@@ -520,6 +522,7 @@ FusedImpl *fused_tail_create(OpImpl *pool, OpImpl *conv, OpImpl *sm) {
     if (!pool || !conv || !sm) return nullptr;
     const OpSpec &p = pool->s, &c = conv->s, &m = sm->s;
     if (p.u8 || c.u8 || m.u8) return nullptr; // i8 epilogues only
+    if (!conv->finite_consts || !std::isfinite(p.pool_c0) || !std::isfinite(p.pool_c1)) return nullptr;
     if (p.kind != MF_OP_AVERAGE_POOL_2D || c.kind != MF_OP_CONV_2D || m.kind != MF_OP_SOFTMAX) return nullptr;
     if (p.OH != 1 || p.OW != 1) return nullptr;                       // one pooling window
     if (c.KH != 1 || c.KW != 1 || c.H != 1 || c.W != 1 || c.OH != 1 || c.OW != 1 || c.C != p.C) return nullptr;
