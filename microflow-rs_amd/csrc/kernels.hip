@@ -324,8 +324,8 @@ __global__ __launch_bounds__(256) void softmax_table(const int8_t *__restrict__ 
 __global__ __launch_bounds__(256) void quantize_f32(const float *__restrict__ in,
                                                     int8_t *__restrict__ out, size_t n, float scale,
                                                     float zp_f, float sat_lo, float sat_hi, int xr) {
-    // 4 values per thread: one 16-byte load, one 4-byte store
-    const size_t n4 = n >> 2;
+    // 4 values per thread: one 16-byte load, one 4-byte store (scalar when a pointer is not aligned for it)
+    const size_t n4 = ((((uintptr_t)in & 15) | ((uintptr_t)out & 3)) == 0) ? n >> 2 : 0;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
         const float4 v = ((const float4 *)in)[i];
         int q[4];
@@ -666,8 +666,15 @@ __global__ __launch_bounds__(NTHR) void dw3x3_nhwc(const int8_t *__restrict__ in
 // live in SGPRs.  Staging: the image is copied verbatim (contiguous 1 KiB DMAs) between
 // two izp rows; the only tap that is not covered by those rows, column -1 of the first
 // pixel pair, is patched with a select.
+// F32IN = true fuses the model-boundary quantisation (M::predict: Tensor::quantize, lib.rs:189,
+// src/quantize.rs:16-18) into the staging: `in` then points to f32 pixels, each thread loads the
+// next step's float4s into registers before the compute of this step, quantises them afterwards
+// (true division, roundf, saturating cast -- the arithmetic of quantize_f32) and writes the int8
+// tile itself, so the 4x larger f32 image crosses HBM once and no int8 copy of it ever does.
 // ------------------------------------------------------------------------
-template <int H, int W, int G, bool MG, uint32_t XR4>
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int H, int W, int G, bool MG, uint32_t XR4, bool F32IN>
 __global__ __launch_bounds__(256) void dw3x3_stem8(const int8_t *__restrict__ in,
                                                    int8_t *__restrict__ out, DwStemArgs p,
                                                    int batch) {
@@ -702,15 +709,55 @@ __global__ __launch_bounds__(256) void dw3x3_stem8(const int8_t *__restrict__ in
         }
     };
 
+    // f32 staging: float4 k of this thread is pixels 4*(k*256 + tid) .. +3 of the step's G images
+    constexpr int NF = F32IN ? G * IMG / 4 / 256 : 1;
+    static_assert(!F32IN || (G * IMG) % 1024 == 0, "f32 staging geometry");
+    f32x4 pre[NF];
+    auto load_f32 = [&](int st) {
+        const f32x4 *src = (const f32x4 *)in;
+#pragma unroll
+        for (int k = 0; k < NF; ++k) {
+            const int idx = k * 256 + tid, g = idx / (IMG / 4);
+            const size_t img = (size_t)st * G + g;
+            const size_t at = (img < (size_t)batch ? img : (size_t)batch - 1) * (IMG / 4) + idx % (IMG / 4);
+            pre[k] = src[at]; // clamped, unconditional: a ragged last step re-reads the last image
+        }
+    };
+    auto store_f32 = [&](int buf) {
+#pragma unroll
+        for (int k = 0; k < NF; ++k) {
+            const int idx = k * 256 + tid, g = idx / (IMG / 4), c = idx % (IMG / 4);
+            int q[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float t = __fadd_rn(__fdiv_rn(pre[k][e], p.in_scale), p.in_zp_f);
+                const float r = __fadd_rn(t, __builtin_copysignf(0x1.fffffep-2f, t));
+                q[e] = (r != r) ? 0 : (int)__builtin_amdgcn_fmed3f(r, p.in_sat_lo, p.in_sat_hi);
+            }
+            *(uint32_t *)(lds + buf * BUF + g * TILE + GUARD + W + c * 4) = pack4(q[0], q[1], q[2], q[3]) ^ p.in_xr4;
+        }
+    };
+
     const int nsteps = (batch + G - 1) / G;
     int step = blockIdx.x, cur = 0;
-    if (step < nsteps) stage(step, 0);
+    if constexpr (F32IN) {
+        if (step < nsteps) {
+            load_f32(step);
+            store_f32(0);
+        }
+    } else {
+        if (step < nsteps) stage(step, 0);
+    }
 
     for (; step < nsteps; step += gridDim.x, cur ^= 1) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (!F32IN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         const int next = step + gridDim.x;
-        if (next < nsteps) stage(next, cur ^ 1);
+        if constexpr (F32IN) {
+            if (next < nsteps) load_f32(next);            // in flight during the compute below
+        } else {
+            if (next < nsteps) stage(next, cur ^ 1);
+        }
 
         const uint8_t *tile = lds + cur * BUF;
         uint4 *dst = (uint4 *)out + (size_t)step * G * OH * PAIRS;
@@ -752,6 +799,9 @@ __global__ __launch_bounds__(256) void dw3x3_stem8(const int8_t *__restrict__ in
                 v.w = pack4x<XR4>(qb[4], qb[5], qb[6], qb[7]);
                 dst[o] = v;
             }
+        }
+        if constexpr (F32IN) {
+            if (next < nsteps) store_f32(cur ^ 1); // the other buffer: last read before this step's barrier
         }
     }
 }
@@ -1802,16 +1852,20 @@ const char *dw_stem_name(int H, int W, int DM, int S) {
     return nullptr;
 }
 bool launch_dw_stem(int H, int W, int DM, int S, const int8_t *in, int8_t *out, const DwStemArgs &a,
-                    int batch, hipStream_t s) {
+                    int batch, hipStream_t s, bool f32_input) {
     if (H == 96 && W == 96 && DM == 8 && S == 2) {
         constexpr int G = 2, lds = 2 * G * (16 + (96 + 2) * 96);
-        static LaunchState st;
-        const int per_cu = prepared(st, dw3x3_stem8<96, 96, G, false, 0u>, 256, lds); // same for every variant
+        static LaunchState st, stf;
+        const int per_cu = f32_input ? prepared(stf, dw3x3_stem8<96, 96, G, false, 0u, true>, 256, lds)
+                                     : prepared(st, dw3x3_stem8<96, 96, G, false, 0u, false>, 256, lds);
         const int nsteps = (batch + G - 1) / G;
         const int grid = nsteps < 256 * per_cu ? nsteps : 256 * per_cu;
-#define MF_STEM(MG, XR) hipLaunchKernelGGL((dw3x3_stem8<96, 96, G, MG, XR>), dim3(grid), dim3(256), lds, s, in, out, a, batch)
-        if (a.xr) { if (a.magic) MF_STEM(true, 0x80808080u); else MF_STEM(false, 0x80808080u); }
-        else { if (a.magic) MF_STEM(true, 0u); else MF_STEM(false, 0u); }
+#define MF_STEM(MG, XR, F) hipLaunchKernelGGL((dw3x3_stem8<96, 96, G, MG, XR, F>), dim3(grid), dim3(256), lds, s, in, out, a, batch)
+#define MF_STEM2(F)                                                                          \
+    if (a.xr) { if (a.magic) MF_STEM(true, 0x80808080u, F); else MF_STEM(false, 0x80808080u, F); } \
+    else { if (a.magic) MF_STEM(true, 0u, F); else MF_STEM(false, 0u, F); }
+        if (f32_input) { MF_STEM2(true) } else { MF_STEM2(false) }
+#undef MF_STEM2
 #undef MF_STEM
         return true;
     }

@@ -97,6 +97,9 @@ struct DwStemArgs {
     uint32_t izp4;
     float lo_f, hi_f;
     int magic, xr;
+    // f32-input variant (boundary quantisation fused into the staging): q = sat(roundf(x / in_scale + in_zp_f))
+    float in_scale, in_zp_f, in_sat_lo, in_sat_hi;
+    uint32_t in_xr4;
 };
 struct DwPwArgs;
 struct PwArgs {
@@ -210,7 +213,7 @@ bool dw_c1_supported(const DwC1Args &a);
 void launch_dw_c1(const int8_t *in, int8_t *out, const DwC1Args &a, size_t batch, hipStream_t s);
 const char *dw_stem_name(int H, int W, int DM, int S);
 bool launch_dw_stem(int H, int W, int DM, int S, const int8_t *in, int8_t *out, const DwStemArgs &a,
-                    int batch, hipStream_t s);
+                    int batch, hipStream_t s, bool f32_input = false);
 const char *dwpw_name(int H, int W, int C, int S, int N);
 bool launch_dwpw(int H, int W, int C, int S, int N, const int8_t *in, int8_t *out, const DwPwArgs &a,
                  int batch, hipStream_t s);

@@ -106,6 +106,10 @@ size_t op_in_elems(const OpImpl *op);
 size_t op_out_elems(const OpImpl *op);
 const char *op_kernel_name(const OpImpl *op);
 void op_set_generic(OpImpl *op, bool generic);
+// fuse the model-boundary quantize (f32 -> T) into this operator if it has an f32-input kernel
+bool op_set_input_quant(OpImpl *op, float scale, int zp, bool u8);
+bool op_accepts_f32(const OpImpl *op);
+void op_run_f32(OpImpl *op, const float *d_in, size_t batch, int8_t *d_out, void *stream);
 // fused DepthwiseConv2D 3x3 -> Conv2D 1x1 (borrows both operators' device buffers; nullptr when
 // the pair has no fused kernel)
 struct FusedImpl;

@@ -172,6 +172,8 @@ void model_prepare(ModelImpl *m, int device, size_t max_batch) {
             cur_scale = po.out_scale;
             cur_zp = po.out_zp;
         }
+        // peephole (0): the boundary quantize of M::predict folds into operator 0 when that is the stem
+        if (!m->ops.empty() && m->ops[0]) (void)op_set_input_quant(m->ops[0], m->pm.in_scale, m->pm.in_zp, m->pm.u8);
         // peepholes.  (1) DepthwiseConv2D 3x3 directly followed by a 1x1 Conv2D -> one fused kernel.
         // (2) AveragePool2D (1x1 output) -> Conv2D 1x1 -> [Reshape] -> Softmax -> one tail kernel.
         const size_t n = m->ops.size();
@@ -221,10 +223,25 @@ void model_set_generic(ModelImpl *m, bool generic) {
 }
 
 // run ops [0..last_op] reading from `src`; returns the buffer holding the result
-static const int8_t *run_ops(ModelImpl *m, const int8_t *src, size_t batch, int last_op, hipStream_t stream) {
+// Is the boundary quantize fused into operator 0 for this call?  (peephole: f32 input, fusion on,
+// operator 0 has an f32-input kernel)
+static bool f32_first(const ModelImpl *m, int last_op) {
+    return m->fusion && !m->generic && last_op >= 0 && !m->ops.empty() && m->ops[0] && op_accepts_f32(m->ops[0]);
+}
+
+// run ops [0..last_op]; `src_f32` != nullptr: operator 0 consumes the f32 input directly
+static const int8_t *run_ops(ModelImpl *m, const int8_t *src, size_t batch, int last_op, hipStream_t stream,
+                             const float *src_f32 = nullptr) {
     const int8_t *cur = src;
     int which = 0;
-    for (int i = 0; i <= last_op; ++i) {
+    int first = 0;
+    if (src_f32) {
+        op_run_f32(m->ops[0], src_f32, batch, m->act[0], stream);
+        cur = m->act[0];
+        which = 1;
+        first = 1;
+    }
+    for (int i = first; i <= last_op; ++i) {
         OpImpl *o = m->ops[i];
         if (!o) continue; // Reshape: alias
         int8_t *dst = m->act[which];
@@ -252,7 +269,10 @@ static void enqueue_device(ModelImpl *m, const float *in_f32, const int8_t *in_i
     const int nops = (int)pm.ops.size();
     const size_t out_elems = last_op == nops - 1 ? pm.out_elems : pm.ops[last_op].out_elems;
     const int8_t *q_in;
-    if (in_f32) { // Tensor::quantize(input, scale, zero_point)  (lib.rs:189)
+    const bool fuse_q = in_f32 && ((uintptr_t)in_f32 & 15) == 0 && f32_first(m, last_op); // (float4 loads)
+    if (fuse_q) {
+        q_in = nullptr; // operator 0 quantises while it stages (dw3x3_stem8<.., F32IN>)
+    } else if (in_f32) { // Tensor::quantize(input, scale, zero_point)  (lib.rs:189)
         dev_quantize(m->device, in_f32, batch * pm.in_elems, pm.in_scale, pm.in_zp, pm.u8, m->in_q, s);
         q_in = m->in_q;
     } else if (pm.u8) { // u8 -> internal i8 domain
@@ -261,7 +281,7 @@ static void enqueue_device(ModelImpl *m, const float *in_f32, const int8_t *in_i
     } else {
         q_in = in_i8; // consumed in place
     }
-    const int8_t *res = run_ops(m, q_in, batch, last_op, s);
+    const int8_t *res = run_ops(m, q_in, batch, last_op, s, fuse_q ? in_f32 : nullptr);
     if (out_i8) {
         if (pm.u8) dev_xor80(m->device, res, batch * out_elems, out_i8, s);
         else MF_HIP(hipMemcpyAsync(out_i8, res, batch * out_elems, hipMemcpyDeviceToDevice, s));
@@ -371,11 +391,12 @@ void model_run(ModelImpl *m, const float *in_f32, const int8_t *in_i8, size_t ba
                 MF_HIP(hipEventRecord(e, cs));
                 MF_HIP(hipStreamWaitEvent(s, e, 0));
             }
-            if (in_f32) // Tensor::quantize(input, scale, zero_point)  (lib.rs:189)
+            const bool fuse_q = in_f32 && f32_first(m, last_op);
+            if (in_f32 && !fuse_q) // Tensor::quantize(input, scale, zero_point)  (lib.rs:189)
                 dev_quantize(m->device, f, n * pm.in_elems, pm.in_scale, pm.in_zp, pm.u8, q, s);
-            else if (pm.u8)
+            else if (!in_f32 && pm.u8)
                 dev_xor80(m->device, q, n * pm.in_elems, q, s); // u8 -> internal i8 domain
-            const int8_t *res = run_ops(m, q, n, last_op, s); // predict_inner
+            const int8_t *res = run_ops(m, q, n, last_op, s, fuse_q ? f : nullptr); // predict_inner
             if (out_i8) {
                 if (pm.u8) { // internal i8 domain -> u8, in place in the scratch buffer holding the result
                     int8_t *tmp = res == q ? m->act[0] : const_cast<int8_t *>(res);

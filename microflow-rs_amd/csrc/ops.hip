@@ -82,6 +82,7 @@ struct OpImpl {
     OpSpec s; // pointers inside are NOT valid after create
     size_t in_elems = 0, out_elems = 0;
     bool force_generic = false;
+    bool accepts_f32 = false;  // op_set_input_quant succeeded: op_run_f32 may replace quantize + op_run
     bool finite_consts = true; // A / S all finite (the shape-specialised and fused epilogues assume it)
     std::string generic_name, fast_name;
     enum Fast { NONE, DW_NHWC, DW_STEM, DW_C1, PW_MFMA, FC_ROWWAVE, FC_MFMA } fast = NONE;
@@ -494,6 +495,30 @@ void op_run_external(OpImpl *op, const int8_t *d_in, size_t batch, int8_t *d_out
     k::launch_xor80(d_in, op->d_ext, n_in, s);
     op_run(op, op->d_ext, batch, d_out, stream);
     k::launch_xor80(d_out, d_out, batch * op->out_elems, s);
+    MF_HIP(hipGetLastError());
+}
+
+// Boundary quantisation fused into the first operator (M::predict on f32 input): only the stem
+// kernel has an f32-input variant.  `zp` is a value of T.
+bool op_set_input_quant(OpImpl *op, float scale, int zp, bool u8) {
+    if (op->fast != OpImpl::DW_STEM || !(scale == scale)) return false;
+    k::DwStemArgs &f = op->stem;
+    f.in_scale = scale, f.in_zp_f = (float)zp;
+    f.in_sat_lo = u8 ? 0.0f : -128.0f, f.in_sat_hi = u8 ? 255.0f : 127.0f;
+    f.in_xr4 = u8 ? 0x80808080u : 0u;
+    op->accepts_f32 = true;
+    return true;
+}
+bool op_accepts_f32(const OpImpl *op) { return op->accepts_f32 && !op->force_generic; }
+void op_run_f32(OpImpl *op, const float *d_in, size_t batch, int8_t *d_out, void *stream) {
+    if (!batch) return;
+    if (!op_accepts_f32(op)) fail(MF_ERR_UNSUPPORTED, "operator has no f32-input kernel");
+    if (!d_in || !d_out) fail(MF_ERR_INVALID_ARG, "op_run_f32: null device pointer");
+    if (batch > 0x7fffffffull / 4) fail(MF_ERR_INVALID_ARG, "batch too large for one launch");
+    const OpSpec &sp = op->s;
+    if (!k::launch_dw_stem(sp.H, sp.W, sp.N, sp.sh, (const int8_t *)d_in, d_out, op->stem, (int)batch,
+                           (hipStream_t)stream, true))
+        fail(MF_ERR_UNSUPPORTED, "f32 stem kernel missing");
     MF_HIP(hipGetLastError());
 }
 

@@ -304,3 +304,29 @@ def test_sharded_replicas_in_one_process(O, name, n, replicas):
     with pytest.raises(mf.MicroflowError):
         mf._lib.check(mf.lib().mf_models_run_quantized(
             (__import__("ctypes").c_void_p * 2)(reps[0]._h, other._h), 2, xq.ctypes.data, n, got.ctypes.data))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [1, 2, 3, 257])
+def test_f32_predict_with_quantize_fused_into_the_stem(O, n):
+    """M::predict on person_detect: with fusion on, the boundary quantize runs inside the stem
+    kernel's staging (f32 pixels in, odd batches exercise the ragged last step); with fusion off it
+    is the separate quantize_f32 kernel.  Both must equal the oracle's predict bit for bit,
+    including values that quantize to ties and beyond the int8 range."""
+    import torch
+    mf = importlib.import_module("microflow_rs_amd")
+    m = mf.model(model_path("person_detect"))
+    om = O.Model(model_path("person_detect"))
+    rng = np.random.default_rng(n)
+    q = rng.integers(-140, 140, (n, m.input_elems)).astype(np.float32)       # some saturate
+    xf = ((q - np.float32(om.in_zp)) * om.in_scale).astype(np.float32)
+    xf[:, ::7] += np.float32(0.5) * om.in_scale                                # exact .5 ties in x / scale + zp
+    xf[0, :4] = [np.nan, np.inf, -np.inf, 0.0]
+    want = np.stack([om.predict(v).reshape(-1) for v in xf[: min(n, 8)]])
+    got = m.predict(torch.as_tensor(xf).cuda()).cpu().numpy().reshape(n, -1)
+    assert np.array_equal(got[: want.shape[0]].view(np.uint32), want.view(np.uint32))
+    m.set_fusion(False)
+    ref = m.predict(torch.as_tensor(xf).cuda()).cpu().numpy().reshape(n, -1)
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+    m.set_fusion(True)
+    assert np.array_equal(m.predict(xf).reshape(n, -1).view(np.uint32), ref.view(np.uint32))   # host-fed path
