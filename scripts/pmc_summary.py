@@ -31,10 +31,12 @@ def short(name):
     if not m:
         return name[:40]
     # rocprofv3 prints bool template arguments as true/false, the library's names use 1/0; the
-    # trailing MG argument (bit-pattern int->f32 variant) is not part of the library's names
+    # trailing variant arguments (MG = bit-pattern int->f32, XR4 = element type, F32IN) are not part
+    # of the library's names
     base, args = m.group(1), (m.group(2) or "").replace(" ", "").replace("true", "1").replace("false", "0")
-    if base in ("dw3x3_nhwc", "dw3x3_stem8", "pw_mfma", "dwpw3x3") and args.count(","):
-        args = args[: args.rindex(",")] + ">"
+    keep = {"dw3x3_nhwc": 6, "pw_mfma": 2, "dwpw3x3": 8}
+    if base in keep:
+        args = "<" + ",".join(args.strip("<>").split(",")[: keep[base]]) + ">"
     if base == "dw_c1_lds":
         args = ""
     if base == "dw3x3_stem8":
