@@ -101,6 +101,14 @@ __device__ __forceinline__ uint32_t pack4x(int a, int b, int c, int d) {
 __device__ __forceinline__ int sdot4(uint32_t a, uint32_t b, int c) {
     return __builtin_amdgcn_sdot4((int)a, (int)b, c, false);
 }
+// First tap of an accumulator: d = dot4(a, b) + c with c a value that stays live (the folded
+// constant Kc).  hipcc otherwise copies c into d and uses the destructive v_dot4c (one v_mov per
+// accumulator per task); the three-address form needs no copy.
+__device__ __forceinline__ int sdot4_first(uint32_t a, uint32_t b, int c) {
+    int d;
+    asm("v_dot4_i32_i8 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
 
 __device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
     uint64_t z = x + 0x9E3779B97F4A7C15ull;
@@ -464,8 +472,13 @@ __device__ __forceinline__ void dw_s1_task(const uint8_t *base, const uint32_t (
             if (ky >= 0 && ky <= 2) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    o0[j][k] = sdot4(win[k], wA[ky][k], o0[j][k]);
-                    o1[j][k] = sdot4(win[k], wB[ky][k], o1[j][k]);
+                    if (ky == 0) { // this accumulator's first tap (compile-time)
+                        o0[j][k] = sdot4_first(win[k], wA[0][k], o0[j][k]);
+                        o1[j][k] = sdot4_first(win[k], wB[0][k], o1[j][k]);
+                    } else {
+                        o0[j][k] = sdot4(win[k], wA[ky][k], o0[j][k]);
+                        o1[j][k] = sdot4(win[k], wB[ky][k], o1[j][k]);
+                    }
                 }
             }
         }
@@ -517,8 +530,13 @@ __device__ __forceinline__ void dw_s2_task(const uint8_t *base, const uint32_t (
             if (ky >= 0 && ky <= 2) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    o0[j][k] = sdot4(win[k], wA[ky][k], o0[j][k]);
-                    o1[j][k] = sdot4(winb[k], wA[ky][k], o1[j][k]);
+                    if (ky == 0) {
+                        o0[j][k] = sdot4_first(win[k], wA[0][k], o0[j][k]);
+                        o1[j][k] = sdot4_first(winb[k], wA[0][k], o1[j][k]);
+                    } else {
+                        o0[j][k] = sdot4(win[k], wA[ky][k], o0[j][k]);
+                        o1[j][k] = sdot4(winb[k], wA[ky][k], o1[j][k]);
+                    }
                 }
             }
         }
