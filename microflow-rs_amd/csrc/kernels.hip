@@ -303,6 +303,62 @@ __global__ __launch_bounds__(256) void fc_rowwave(const int8_t *__restrict__ in,
     }
 }
 
+// fc_rowwave followed by the softmax over its N outputs (speech.tflite: FullyConnected 4000 -> 4,
+// Softmax) in one launch: the FC result of a row IS the whole [1][N] softmax tensor, so lanes
+// 0..N-1 exchange their exp-table entries by shuffles and every one of them forms the sum in the
+// reference's order (src/ops/softmax.rs:20-21) before quantising its own probability.
+template <int N>
+__global__ __launch_bounds__(256) void fc_rowwave_softmax(const int8_t *__restrict__ in, int8_t *__restrict__ out,
+                                                          FcArgs p, SoftmaxArgs sm, size_t rows) {
+    const int lane = threadIdx.x & 63;
+    const size_t wave = ((size_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+    const size_t nwaves = ((size_t)gridDim.x * 256) >> 6;
+    const int K16 = p.K >> 4;
+    for (size_t row = wave; row < rows; row += nwaves) {
+        const uint4 *x = (const uint4 *)(in + row * (size_t)p.K);
+        int dot[N], rs = 0;
+#pragma unroll
+        for (int j = 0; j < N; ++j) dot[j] = 0;
+        for (int k = lane; k < K16; k += 64) {
+            const uint4 v = x[k];
+            rs = sdot4(v.x, 0x01010101u, rs);
+            rs = sdot4(v.y, 0x01010101u, rs);
+            rs = sdot4(v.z, 0x01010101u, rs);
+            rs = sdot4(v.w, 0x01010101u, rs);
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                const uint4 w = ((const uint4 *)(p.w + (size_t)j * p.K))[k];
+                dot[j] = sdot4(v.x, w.x, dot[j]);
+                dot[j] = sdot4(v.y, w.y, dot[j]);
+                dot[j] = sdot4(v.z, w.z, dot[j]);
+                dot[j] = sdot4(v.w, w.w, dot[j]);
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            rs += __shfl_xor(rs, off, 64);
+#pragma unroll
+            for (int j = 0; j < N; ++j) dot[j] += __shfl_xor(dot[j], off, 64);
+        }
+        int d = 0;
+#pragma unroll
+        for (int j = 0; j < N; ++j) d = (lane == j) ? dot[j] : d;
+        const int ch = lane < N ? lane : 0;
+        const int acc = d - p.wzp * rs + p.Kc[ch];
+        // the FullyConnected output byte as it would be stored (i8 domain), then softmax's table index
+        const int y = (int)(int8_t)(requant(acc, p.A[ch], p.S, p.lo_f, p.hi_f) ^ p.xr);
+        const float e = sm.exp_table[y + 128];
+        float sum = 0.0f;
+#pragma unroll
+        for (int j = 0; j < N; ++j) sum = __fadd_rn(sum, __shfl(e, j, 64));
+        const float prob = __fdiv_rn(e, sum);
+        const float q = __fadd_rn(__fdiv_rn(prob, sm.oscale), sm.ozp_f);
+        const float r = __fadd_rn(q, __builtin_copysignf(0x1.fffffep-2f, q));
+        const int qi = (r != r) ? 0 : (int)__builtin_amdgcn_fmed3f(r, sm.sat_lo, sm.sat_hi);
+        if (lane < N) out[row * N + lane] = (int8_t)(qi ^ sm.xr);
+    }
+}
+
 // microflow::ops::softmax  (src/ops/softmax.rs:15-27).  One thread per inference.
 // e_k = f32(q_k) * input_scale has only 256 possible values, so expf comes from a
 // host-built table (libm's algorithm runs on the host, never the device's expf).
@@ -1774,6 +1830,16 @@ void launch_fc_mfma(const int8_t *in, int8_t *out, const FcGemmArgs &a, hipStrea
         launch_fc_mfma_t<256, 256, 2, 4, true>(in, out, a, s);
     else
         launch_fc_mfma_t<128, 128, 2, 2, false>(in, out, a, s);
+}
+bool launch_fc_rowwave_softmax(const int8_t *in, int8_t *out, const FcArgs &a, const SoftmaxArgs &sm, size_t rows,
+                               hipStream_t s) {
+    const int grid = grid_for(rows, 4);
+    switch (a.N) {
+    case 2: hipLaunchKernelGGL(fc_rowwave_softmax<2>, dim3(grid), dim3(256), 0, s, in, out, a, sm, rows); return true;
+    case 4: hipLaunchKernelGGL(fc_rowwave_softmax<4>, dim3(grid), dim3(256), 0, s, in, out, a, sm, rows); return true;
+    case 8: hipLaunchKernelGGL(fc_rowwave_softmax<8>, dim3(grid), dim3(256), 0, s, in, out, a, sm, rows); return true;
+    default: return false;
+    }
 }
 void launch_softmax(const int8_t *in, int8_t *out, const SoftmaxArgs &a, size_t batch, hipStream_t s) {
     hipLaunchKernelGGL(softmax_table, dim3(grid_for(batch)), dim3(256), 0, s, in, out, a, batch);

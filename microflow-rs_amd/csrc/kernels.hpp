@@ -195,6 +195,8 @@ void launch_dwconv_generic(const int8_t *in, int8_t *out, const ConvArgs &a, siz
 void launch_avgpool_generic(const int8_t *in, int8_t *out, const PoolArgs &a, size_t batch, hipStream_t s);
 void launch_fc_generic(const int8_t *in, int8_t *out, const FcArgs &a, size_t rows, hipStream_t s);
 bool launch_fc_rowwave(const int8_t *in, int8_t *out, const FcArgs &a, size_t rows, hipStream_t s);
+bool launch_fc_rowwave_softmax(const int8_t *in, int8_t *out, const FcArgs &a, const SoftmaxArgs &sm, size_t rows,
+                               hipStream_t s);
 // int8 MFMA GEMM (M % 128 == 0, N % 128 == 0, K % 128 == 0)
 bool fc_mfma_supported(size_t rows, int N, int K);
 void launch_fc_rowsum(const int8_t *in, int *rowsum, size_t rows, int K, hipStream_t s);

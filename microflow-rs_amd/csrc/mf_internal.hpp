@@ -116,6 +116,8 @@ struct FusedImpl;
 FusedImpl *fused_create(OpImpl *dw, OpImpl *pw);
 // fused tail: AveragePool2D (1x1 output) -> Conv2D 1x1 (N <= 8) -> Softmax (one row of N)
 FusedImpl *fused_tail_create(OpImpl *pool, OpImpl *conv, OpImpl *softmax);
+// fused FullyConnected (row-wave kernel, one row per inference) -> Softmax over its outputs
+FusedImpl *fused_fc_softmax_create(OpImpl *fc, OpImpl *softmax);
 void fused_destroy(FusedImpl *f);
 void fused_run(FusedImpl *f, const int8_t *d_in, size_t batch, int8_t *d_out, void *stream);
 const char *fused_kernel_name(const FusedImpl *f);

@@ -176,6 +176,7 @@ void model_prepare(ModelImpl *m, int device, size_t max_batch) {
         if (!m->ops.empty() && m->ops[0]) (void)op_set_input_quant(m->ops[0], m->pm.in_scale, m->pm.in_zp, m->pm.u8);
         // peepholes.  (1) DepthwiseConv2D 3x3 directly followed by a 1x1 Conv2D -> one fused kernel.
         // (2) AveragePool2D (1x1 output) -> Conv2D 1x1 -> [Reshape] -> Softmax -> one tail kernel.
+        // (3) FullyConnected (few outputs, one row) -> [Reshape] -> Softmax -> one kernel.
         const size_t n = m->ops.size();
         m->fused.assign(n, nullptr);
         m->fused_last.assign(n, -1);
@@ -187,6 +188,12 @@ void model_prepare(ModelImpl *m, int device, size_t max_batch) {
                 while (j < n && m->pm.ops[j].kind == MF_OP_RESHAPE) ++j;
                 if (j < n && m->pm.ops[j].kind == MF_OP_SOFTMAX &&
                     (m->fused[i] = fused_tail_create(m->ops[i], m->ops[i + 1], m->ops[j])))
+                    m->fused_last[i] = (int)j;
+            } else if (m->pm.ops[i].kind == MF_OP_FULLY_CONNECTED) { // (3) FC -> [Reshape] -> Softmax
+                size_t j = i + 1;
+                while (j < n && m->pm.ops[j].kind == MF_OP_RESHAPE) ++j;
+                if (j < n && m->pm.ops[j].kind == MF_OP_SOFTMAX &&
+                    (m->fused[i] = fused_fc_softmax_create(m->ops[i], m->ops[j])))
                     m->fused_last[i] = (int)j;
             }
             if (m->fused[i]) i = (size_t)m->fused_last[i]; // groups do not overlap

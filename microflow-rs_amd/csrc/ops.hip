@@ -523,7 +523,7 @@ void op_run_f32(OpImpl *op, const float *d_in, size_t batch, int8_t *d_out, void
 }
 
 struct FusedImpl {
-    enum Kind { DWPW, TAIL } kind;
+    enum Kind { DWPW, TAIL, FCSM } kind;
     OpImpl *a, *b, *c;
     k::DwPwArgs dwpw;
     k::TailArgs tail;
@@ -575,12 +575,27 @@ FusedImpl *fused_tail_create(OpImpl *pool, OpImpl *conv, OpImpl *sm) {
     return f;
 }
 
+// FullyConnected (one row per inference, the few-outputs row-wave kernel) -> [Reshape] -> Softmax
+// over exactly those outputs
+FusedImpl *fused_fc_softmax_create(OpImpl *fc, OpImpl *sm) {
+    if (!fc || !sm || fc->fast != OpImpl::FC_ROWWAVE || sm->s.kind != MF_OP_SOFTMAX) return nullptr;
+    if (fc->s.M != 1 || sm->s.M != 1 || sm->s.N != fc->s.N || fc->s.N < 2 || fc->device != sm->device) return nullptr;
+    if (fc->s.u8 != sm->s.u8) return nullptr;
+    return new FusedImpl{FusedImpl::FCSM, fc, sm, nullptr, {}, {}, "fc_rowwave_softmax<" + std::to_string(fc->s.N) + ">"};
+}
+
 void fused_destroy(FusedImpl *f) { delete f; }
 const char *fused_kernel_name(const FusedImpl *f) { return f->name.c_str(); }
 void fused_run(FusedImpl *f, const int8_t *d_in, size_t batch, int8_t *d_out, void *stream) {
     if (!batch) return;
     if (f->kind == FusedImpl::TAIL) {
         k::launch_tail(d_in, d_out, f->tail, batch, (hipStream_t)stream);
+        MF_HIP(hipGetLastError());
+        return;
+    }
+    if (f->kind == FusedImpl::FCSM) {
+        if (!k::launch_fc_rowwave_softmax(d_in, d_out, f->a->fc, f->b->sm, batch, (hipStream_t)stream))
+            fail(MF_ERR_UNSUPPORTED, "fused kernel missing");
         MF_HIP(hipGetLastError());
         return;
     }

@@ -177,6 +177,15 @@ def test_kernel_routing(models):
     assert sum(n.startswith("pw_mfma") for n in names) == 13
     assert names[28] == "conv2d_generic" and names[27] == "avgpool_generic"
     assert names[29] == "" and names[30] == "softmax_table"
+    # speech: [reshape] depthwise (one input channel) -> FullyConnected + Softmax in one launch
+    sp = models["speech"]
+    sp.prepare(1)
+    names = [sp.op(i)["kernel"] for i in range(sp.num_ops)]
+    assert "dw_c1_lds" in names and "fc_rowwave_softmax<4>" in names and names[-1].startswith("(fused"), names
+    sp.set_fusion(False)
+    names = [sp.op(i)["kernel"] for i in range(sp.num_ops)]
+    sp.set_fusion(True)
+    assert "fc_rowwave<4>" in names and names[-1] == "softmax_table", names
 
 
 @pytest.mark.parametrize("n", [1, 2, 3, 5, 8, 13, 64, 257])
