@@ -2019,6 +2019,13 @@ template <int K, int N, bool MG, uint32_t XR4>
 static void launch_pw_t(const int8_t *in, int8_t *out, const PwArgs &a, long long npix, int grid, hipStream_t s) {
     hipLaunchKernelGGL((pw_mfma<K, N, MG, XR4>), dim3(grid), dim3(256), 0, s, in, out, a, npix);
 }
+// workgroups of the grid-strided pointwise kernel (r01 sweep, MF_PW_GRID overrides): the wide early
+// layers (K < 64, most pixels) like many short-lived workgroups, the deep late ones few
+static long long pw_grid_cap(int K) {
+    static const long long forced = [] { const char *e = getenv("MF_PW_GRID"); return e ? atoll(e) : 0LL; }();
+    if (forced > 0) return forced;
+    return K < 64 ? 256LL * 32 : (K >= 128 ? 256LL * 4 : 256LL * 8);
+}
 const char *pw_name(int K, int N) {
 #define MF_PW(k, n) \
     if (K == k && N == n) return "pw_mfma<" #k "," #n ">";
@@ -2033,7 +2040,7 @@ bool launch_pw(int K, int N, const int8_t *in, int8_t *out, const PwArgs &a, lon
         constexpr int U = k >= 256 ? 2 : (k >= 64 ? 4 : 2);                                     \
         const long long nchunks = (npix + CPIX - 1) / CPIX;                                     \
         long long grid = (nchunks + SLOTS * U - 1) / (SLOTS * U);                               \
-        if (grid > 256 * 8) grid = 256 * 8;                                                     \
+        if (grid > pw_grid_cap(k)) grid = pw_grid_cap(k);                                       \
         if (grid < 1) grid = 1;                                                                 \
         MF_DISPATCH4(a.magic, a.xr, launch_pw_t, (in, out, a, npix, (int)grid, s), k, n)                  \
         return true;                                                                            \
