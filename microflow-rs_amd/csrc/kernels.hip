@@ -1001,6 +1001,13 @@ __global__ __launch_bounds__(512) void dw_c1_lds(const int8_t *__restrict__ in, 
 // N > 64 is split over the waves of the workgroup (NSPLIT = N/64), which all read the
 // same pixels (L1/L2 hits).  HBM-bound: MFMA work is ~1/8 of the memory time.
 // ------------------------------------------------------------------------
+#ifndef MF_PW_U_LO
+#define MF_PW_U_LO 2
+#define MF_PW_U_MID 4
+#define MF_PW_U_HI 2
+#endif
+// chunks each wave keeps in flight (loads of the next U issued before the first use)
+constexpr int pw_chunks_in_flight(int K) { return K >= 256 ? MF_PW_U_HI : (K >= 64 ? MF_PW_U_MID : MF_PW_U_LO); }
 template <int K, int N, bool MG, uint32_t XR4>
 __global__ __launch_bounds__(256) void pw_mfma(const int8_t *__restrict__ in,
                                                int8_t *__restrict__ out, PwArgs p,
@@ -1014,7 +1021,7 @@ __global__ __launch_bounds__(256) void pw_mfma(const int8_t *__restrict__ in,
     constexpr int SLOTS = 4 / NSPLIT;          // pixel chunks processed concurrently per WG
     // chunks per loop iteration: their loads are all issued before the first use, so a wave
     // keeps U*KS KiB in flight (one 16-pixel chunk per iteration left HBM latency exposed)
-    constexpr int U = K >= 256 ? 2 : (K >= 64 ? 4 : 2);
+    constexpr int U = pw_chunks_in_flight(K);
     // narrow outputs (N < 64) go through a per-wave LDS patch so that every global store is
     // 16 bytes per lane and a wave writes whole contiguous KiB
     constexpr bool XPOSE = TB < 4;
@@ -2037,7 +2044,7 @@ bool launch_pw(int K, int N, const int8_t *in, int8_t *out, const PwArgs &a, lon
 #define MF_PW(k, n)                                                                             \
     if (K == k && N == n) {                                                                     \
         constexpr int NB = n < 64 ? n : 64, SLOTS = 4 / (n / NB), CPIX = k < 64 ? 1024 / k : 16; \
-        constexpr int U = k >= 256 ? 2 : (k >= 64 ? 4 : 2);                                     \
+        constexpr int U = pw_chunks_in_flight(k);                                               \
         const long long nchunks = (npix + CPIX - 1) / CPIX;                                     \
         long long grid = (nchunks + SLOTS * U - 1) / (SLOTS * U);                               \
         if (grid > pw_grid_cap(k)) grid = pw_grid_cap(k);                                       \
