@@ -1,6 +1,6 @@
 """ctypes binding of libmicroflow_amd.so (include/microflow_amd.h).
 
-The library is built in-tree by microflow-rs_amd/build.py (hipcc, gfx950).  If it
+The library is built in-tree by microflow_rs_amd/build.py (hipcc, gfx950).  If it
 is missing and cannot be built, loading fails loudly -- the product has no CPU path.
 """
 import ctypes as C
@@ -134,7 +134,7 @@ def lib():
         except Exception as e:  # noqa: BLE001
             raise ImportError(
                 "libmicroflow_amd.so is missing and could not be built (%s). Run "
-                "`python microflow-rs_amd/build.py`; this package has no CPU fallback." % e)
+                "`python microflow_rs_amd/build.py`; this package has no CPU fallback." % e)
     # PyTorch-ROCm bundles its own libamdhip64; if it is going to be used in this process (device
     # memory, streams) it must be loaded FIRST so that the library binds to the same HIP runtime
     # -- two runtimes in one process see no devices.

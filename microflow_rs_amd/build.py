@@ -1,6 +1,6 @@
 """Builds libmicroflow_amd.so in-tree with hipcc for gfx950.
 
-    python microflow-rs_amd/build.py [--force]
+    python microflow_rs_amd/build.py [--force]
 
 -ffp-contract=off is part of the numerical contract: the reference (Rust) never
 fuses a multiply and an add, and hipcc does by default.
@@ -13,8 +13,9 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmicroflow_amd.so")
-SOURCES = ["capi.cpp", "hostmath.cpp", "tflite.cpp", "model.cpp", "ops.hip", "kernels.hip"]
-HEADERS = ["mf_internal.hpp", "kernels.hpp", os.path.join("..", "..", "include", "microflow_amd.h")]
+SOURCES = ["capi.cpp", "hostmath.cpp", "tflite.cpp", "model.cpp", "ops.hip", "k_generic.hip", "k_depthwise.hip",
+           "k_pointwise.hip", "k_fused.hip", "k_gemm.hip"]
+HEADERS = ["mf_internal.hpp", "kernels.hpp", "k_common.hpp", "k_dwtask.hpp", os.path.join("..", "..", "include", "microflow_amd.h")]
 # -amdgpu-mfma-vgpr-form: MFMA results land in VGPRs (gfx950's register file is unified), which
 # removes one v_accvgpr_read per accumulator element from every fused epilogue.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",

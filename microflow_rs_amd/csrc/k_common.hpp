@@ -1,0 +1,189 @@
+// k_common.hpp -- what every kernel family of libmicroflow_amd shares (gfx950 / CDNA4 only).
+//
+// The kernels live in one file per family -- k_generic.hip, k_depthwise.hip, k_pointwise.hip,
+// k_fused.hip, k_gemm.hip -- each citing the upstream file:line it implements.  All of them
+// share one arithmetic contract:
+//
+//   acc (i32)  = sum over ALL window taps of (v' - izp) * (w - wzp)
+//                with v' = izp at out-of-range taps          [== x0 - x1 - k2 + k3]
+//   y          = sat_i8(roundf((f32(ozp) + c0[c]) + c1[c] * f32(acc)))   then activation
+//
+// The device never evaluates `izp`-dependent terms per pixel: the host folds
+//   Kc[c] = -izp * sum_all_taps w[c] + T * izp * wzp[c]   (T = taps contributing to c)
+// so that acc = dot(v', w) - wzp[c] * sum(v') + Kc[c]; padding is realised by
+// filling the halo with izp, which makes every pixel -- border or interior -- run
+// the same code.  A[c] = fl32(f32(ozp) + c0[c]) and S[c] = c1[c or 0] are folded on
+// the host too, and the activation is a clamp [lo, hi] (relu: lo = ozp; relu6:
+// hi = quantize(6.0)).
+//
+// f32 rules: no contraction (this file is built with -ffp-contract=off AND uses the
+// explicit __fmul_rn/__fadd_rn/__fdiv_rn forms), int->float is v_cvt_f32_i32 (RNE),
+// roundf is trunc(x + copysign(pred(0.5), x)) which is exact for every finite x.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#include <atomic>
+#include <type_traits>
+
+#include "kernels.hpp"
+
+namespace mf {
+namespace k {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+// native vector type for register-resident staging arrays: arrays of HIP's struct-based
+// uint4 that are conditionally re-assigned are NOT promoted to registers by hipcc (they
+// end up in scratch memory); ext_vector_type arrays are.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------------
+// shared device helpers
+// ------------------------------------------------------------------------
+__device__ __forceinline__ int requant(int acc, float A, float S, float lo_f, float hi_f) {
+    // (f32(ozp) + c0) + c1 * f32(acc): two roundings, like the reference (conv_2d.rs:93-98)
+    const float x = __fadd_rn(A, __fmul_rn(S, (float)acc));
+    // libm::roundf = half away from zero = trunc(x + copysign(0x1.fffffep-2, x))
+    float r = __fadd_rn(x, __builtin_copysignf(0x1.fffffep-2f, x));
+    // saturating cast + activation clamp, done in f32 so that the int conversion below
+    // is always in range (it truncates toward zero)
+    r = __builtin_amdgcn_fmed3f(r, lo_f, hi_f);
+    return (int)r;
+}
+
+// "Magic" accumulators (MG = true): the accumulator is started at Kc + 0x4B400000, so that its
+// bit pattern read as f32 is 12582912 + acc, exactly, whenever |acc| < 2^22; f32(acc) is then
+// one v_add_f32 (full rate) instead of v_cvt_f32_i32 (half rate).  Both are exact, so the
+// epilogue's value is unchanged.  The host enables it per operator only when the worst-case
+// |acc| over ALL inputs -- max|v - izp| * sum|w - wzp| per channel -- is below 2^22 (ops.hip).
+constexpr int MF_MAGIC_I = 0x4B400000;
+template <bool MG>
+__device__ __forceinline__ int requant_t(int acc, float A, float S, float lo_f, float hi_f) {
+    if constexpr (!MG) {
+        return requant(acc, A, S, lo_f, hi_f);
+    } else {
+        const float f = __fsub_rn(__int_as_float(acc), 12582912.0f);
+        const float x = __fadd_rn(A, __fmul_rn(S, f));
+        float r = __fadd_rn(x, __builtin_copysignf(0x1.fffffep-2f, x));
+        r = __builtin_amdgcn_fmed3f(r, lo_f, hi_f);
+        return (int)r;
+    }
+}
+template <bool MG> __device__ __forceinline__ int4 magic4(int4 k) {
+    if constexpr (MG) k.x += MF_MAGIC_I, k.y += MF_MAGIC_I, k.z += MF_MAGIC_I, k.w += MF_MAGIC_I;
+    return k;
+}
+
+// The shape-generic kernels also honour Rust's `NaN as i8 == 0` (a NaN can only come from
+// non-finite constants, i.e. a degenerate model); operators with non-finite constants are never
+// routed to the shape-specialised kernels (ops.hip), whose requant() skips this test.
+__device__ __forceinline__ int requant_any(int acc, float A, float S, float lo_f, float hi_f) {
+    const float x = __fadd_rn(A, __fmul_rn(S, (float)acc));
+    float r = __fadd_rn(x, __builtin_copysignf(0x1.fffffep-2f, x));
+    r = (r != r) ? 0.0f : r; // NaN -> 0, then the activation clamp like any other value
+    r = __builtin_amdgcn_fmed3f(r, lo_f, hi_f);
+    return (int)r;
+}
+
+// 4 ints in [-128,127] -> one dword of int8 (byte 0 = a)
+__device__ __forceinline__ uint32_t pack4(int a, int b, int c, int d) {
+    const uint32_t lo = __builtin_amdgcn_perm((uint32_t)b, (uint32_t)a, 0x0c0c0400u);
+    const uint32_t hi = __builtin_amdgcn_perm((uint32_t)d, (uint32_t)c, 0x0c0c0400u);
+    return __builtin_amdgcn_perm(hi, lo, 0x05040100u);
+}
+
+// pack4 for either element type: XR4 = 0x80808080 moves u8-domain epilogue results (0..255) back
+// to the stored i8 domain (kernels.hpp), XR4 = 0 is plain i8 (the XOR disappears at compile time)
+template <uint32_t XR4>
+__device__ __forceinline__ uint32_t pack4x(int a, int b, int c, int d) {
+    return pack4(a, b, c, d) ^ XR4;
+}
+
+__device__ __forceinline__ int sdot4(uint32_t a, uint32_t b, int c) {
+    return __builtin_amdgcn_sdot4((int)a, (int)b, c, false);
+}
+// First tap of an accumulator: d = dot4(a, b) + c with c a value that stays live (the folded
+// constant Kc).  hipcc otherwise copies c into d and uses the destructive v_dot4c (one v_mov per
+// accumulator per task); the three-address form needs no copy.
+__device__ __forceinline__ int sdot4_first(uint32_t a, uint32_t b, int c) {
+    int d;
+    asm("v_dot4_i32_i8 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+    uint64_t z = x + 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+// ------------------------------------------------------------------------
+// HBM -> LDS staging for the depthwise kernels: LDS-DMA (`global_load_lds_dwordx4`,
+// gfx950), 16 bytes per lane straight into LDS with no VGPR round trip.
+//
+// Why not registers: (1) a predicated register prefetch makes hipcc branch around every
+// element and wait vmcnt(0) after each one; (2) an array of HIP's struct-based uint4 that
+// is conditionally re-assigned is not promoted to registers (it went to scratch); (3) even
+// with both fixed, hipcc flushed vmcnt(0) in the pre-header of the compute loop, i.e. the
+// prefetch never overlapped the compute.  A DMA has no destination register, so nothing
+// waits on it except the one explicit `s_waitcnt vmcnt(0)` + barrier per step below.
+// The LDS destination of a DMA instruction is wave-uniform base + lane * 16.
+// ------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void gbl_void_t;
+
+__device__ __forceinline__ void dma16(const int8_t *src_lane, uint8_t *lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((gbl_void_t *)src_lane, (lds_void_t *)lds_wave_base, 16, 0, 0);
+}
+
+// ------------------------------------------------------------------------
+// launchers (host)
+// ------------------------------------------------------------------------
+// Persistent-workgroup kernels launch exactly as many workgroups as are resident (LDS-,
+// VGPR- or wave-limited, asked of the runtime once per kernel), so every workgroup walks the
+// same number of steps and none queues behind a finished one.
+// Function attributes and occupancy are per DEVICE, and one process may drive several GPUs, so
+// each launcher keeps one slot per device (benign race: two threads may both prepare a slot).
+struct LaunchState {
+    static constexpr int MAX_DEV = 64;
+    std::atomic<int> per_cu[MAX_DEV];
+};
+template <typename Kern> static int prepared(LaunchState &st, Kern kern, int threads, int lds_bytes) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= LaunchState::MAX_DEV) dev = LaunchState::MAX_DEV - 1;
+    int n = st.per_cu[dev].load(std::memory_order_relaxed);
+    if (n > 0 && dev != LaunchState::MAX_DEV - 1) return n;
+    if (lds_bytes > 64 * 1024)
+        (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, threads, (size_t)lds_bytes) != hipSuccess || n < 1) {
+        (void)hipGetLastError();
+        n = 1;
+    }
+    st.per_cu[dev].store(n, std::memory_order_relaxed);
+    return n;
+}
+
+static inline int grid_for(size_t total, int per_block = 256, int cap = 256 * 8) {
+    size_t g = (total + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    return (int)(g < (size_t)cap ? g : (size_t)cap);
+}
+
+// ---- fast-path dispatch tables ------------------------------------------------
+// the four instances of a fast kernel: {v_cvt, bit-pattern} int->f32  x  {i8, u8} element type
+#define MF_DISPATCH4(magic, xr, FN, ARGS, ...)                         \
+    do {                                                               \
+        if (xr) {                                                      \
+            if (magic) FN<__VA_ARGS__, true, 0x80808080u> ARGS;        \
+            else FN<__VA_ARGS__, false, 0x80808080u> ARGS;             \
+        } else {                                                       \
+            if (magic) FN<__VA_ARGS__, true, 0u> ARGS;                 \
+            else FN<__VA_ARGS__, false, 0u> ARGS;                      \
+        }                                                              \
+    } while (0);
+
+} // namespace k
+} // namespace mf

@@ -1,0 +1,478 @@
+// k_depthwise.hip -- DepthwiseConv2D fast paths (src/ops/depthwise_conv_2d.rs:28-105).
+//
+// dw3x3_nhwc (3x3 SAME, any stride-1/2 NHWC shape in MF_DW_SHAPES), dw3x3_stem8 (one input channel -> 8,
+// the network stem, optionally fused with the f32 boundary quantisation) and dw_c1_lds (one input
+// channel, any filter: speech.tflite).
+// Arithmetic contract, shared device helpers and launch plumbing: k_common.hpp.
+#include "k_common.hpp"
+#include "k_dwtask.hpp"
+
+namespace mf {
+namespace k {
+
+// ------------------------------------------------------------------------
+// FAST PATH 1 -- DepthwiseConv2D 3x3, SAME, NHWC, C % 4 == 0, weight zp == 0.
+// (src/ops/depthwise_conv_2d.rs:28-105; person_detect ops 1,3,5,...,25)
+//
+// HBM-bound by construction: every input byte is read from HBM once, every output
+// byte written once.  One workgroup owns G whole images per step and double-buffers
+// them in LDS:
+//   stage  : one DMA instruction per image row (W*C <= 1 KiB) into an LDS tile whose
+//            1-pixel halo ring was pre-filled with izp once (padding == izp makes border
+//            pixels identical to interior ones).  The DMAs of step i+1 are issued right
+//            after the barrier of step i and fly during its compute.
+//   compute: lane = (pixel, 4-channel group).  The 4-channel group of a lane never
+//            changes, so its 9 tap-weight dwords live in VGPRs as 36 byte-masked
+//            copies: acc[k] += sdot4(v, w & (0xff << 8k)) is one VALU op per MAC with
+//            no unpacking of either operand.
+//   store  : one dword (4 channels) per lane, consecutive lanes = consecutive addresses.
+// LDS row layout: [LP pad][W*C bytes][LP pad], LP = max(C,16): rows start 16-byte
+// aligned and tap (ky,kx) of a lane is the constant offset ky*ROW + kx*C from its base.
+// One barrier per step: after it, every wave has finished reading the other buffer
+// (safe to overwrite) and every wave's DMAs into this buffer have landed.
+// ------------------------------------------------------------------------
+template <int H, int W, int C, int S, int G, int NTHR, bool MG, uint32_t XR4>
+__global__ __launch_bounds__(NTHR) void dw3x3_nhwc(const int8_t *__restrict__ in,
+                                                  int8_t *__restrict__ out, DwFastArgs p,
+                                                  int batch) {
+    constexpr int C4 = C / 4;
+    constexpr int OH = (H + S - 1) / S, OW = (W + S - 1) / S;
+    constexpr int LP = C < 16 ? 16 : C;
+    constexpr int ROWB = W * C;                   // payload bytes per image row
+    constexpr int ROW = LP + ROWB + LP;           // bytes per LDS row
+    constexpr int TILE = (H + 2) * ROW;           // bytes per image tile (1 halo row above/below)
+    constexpr int BUF = G * TILE;                 // one staging buffer (two are allocated)
+    constexpr int IMG = H * ROWB;                 // bytes per input image
+    constexpr int ROWCH = ROWB / 16;              // 16-byte chunks (= DMA lanes) per row
+    constexpr int NROWS = G * H;                  // DMA instructions per step
+    constexpr int NWAVE = NTHR / 64;
+    static_assert(NTHR % C4 == 0, "channel group of a lane must be loop-invariant");
+    static_assert(ROWB % 16 == 0 && ROWCH <= 64, "one DMA instruction per row");
+
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // both buffers := izp, once; the DMAs only ever rewrite the interiors
+    for (int i = tid; i < 2 * BUF / 16; i += NTHR)
+        ((uint4 *)lds)[i] = make_uint4(p.izp4, p.izp4, p.izp4, p.izp4);
+
+    // per-lane constants of this lane's channel group
+    const int cg = tid & (C4 - 1);
+    // S == 2: 9 tap dwords as 36 byte-masked copies (one sdot4 per MAC, no unpacking).
+    // S == 1: per filter row and channel the 3 taps as ONE dword (w0,w1,w2,0) and its
+    //         shifted twin (0,w0,w1,w2): a 4-pixel window transposed to per-channel dwords
+    //         then yields TWO adjacent outputs with two real 3-MAC sdot4s.
+    uint32_t wA[3][4], wB[3][4]; // (w0,w1,w2,0) and (0,w0,w1,w2) per filter row and channel; wB: stride 1 only
+    {
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const uint32_t w0 = ((const uint32_t *)p.w)[(ky * 3 + 0) * C4 + cg];
+        const uint32_t w1 = ((const uint32_t *)p.w)[(ky * 3 + 1) * C4 + cg];
+        const uint32_t w2 = ((const uint32_t *)p.w)[(ky * 3 + 2) * C4 + cg];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            wA[ky][k] = ((w0 >> (8 * k)) & 0xffu) | (((w1 >> (8 * k)) & 0xffu) << 8) |
+                        (((w2 >> (8 * k)) & 0xffu) << 16);
+            wB[ky][k] = wA[ky][k] << 8;
+        }
+    }
+    }
+    const float4 A = ((const float4 *)p.A)[cg], Sc = ((const float4 *)p.S)[cg];
+    const int4 Kc = magic4<MG>(((const int4 *)p.Kc)[cg]);
+    __syncthreads(); // halo fill complete before any DMA lands
+
+    auto stage = [&](int st, int buf) {
+#pragma unroll
+        for (int k = 0; k < (NROWS + NWAVE - 1) / NWAVE; ++k) {
+            const int r = k * NWAVE + wave;           // wave-uniform row of the step
+            const int g = r / H, y = r % H;
+            if (r < NROWS && st * G + g < batch && lane < ROWCH)
+                dma16(in + ((size_t)(st * G + g) * IMG + y * ROWB + lane * 16),
+                      lds + buf * BUF + g * TILE + (y + 1) * ROW + LP);
+        }
+    };
+
+    const int nsteps = (batch + G - 1) / G;
+    int step = blockIdx.x, cur = 0;
+    if (step < nsteps) stage(step, 0);
+
+    for (; step < nsteps; step += gridDim.x, cur ^= 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's DMAs (and old stores) done
+        __syncthreads();                                  // ... and everyone else's
+        const int next = step + gridDim.x;
+        if (next < nsteps) stage(next, cur ^ 1);          // flies during the compute below
+
+        const uint8_t *tile = lds + cur * BUF;
+        uint32_t *dst = (uint32_t *)out + (size_t)step * G * OH * OW * C4;
+        {
+            // task = R output rows x 2 adjacent pixels x 4 channels (see dw_s1_task)
+            constexpr int R = dw_rows_per_task(OH, S);
+            constexpr int OWP = (OW + 1) / 2, OHR = OH / R;
+            constexpr int TASKS = G * OHR * OWP * C4;
+            constexpr int NTASK = (TASKS + NTHR - 1) / NTHR;
+            const int gvalid = min(G, batch - step * G);
+#pragma unroll 1
+            for (int i = 0; i < NTASK; ++i) {
+                const int t = tid + NTHR * i;
+                const int pp = t / C4;
+                const int g = pp / (OHR * OWP), rem = pp % (OHR * OWP);
+                const int oy0 = R * (rem / OWP), ox0 = 2 * (rem % OWP);
+                if (t < TASKS && g < gvalid) {
+                    int o0[R][4], o1[R][4];
+                    const uint8_t *base = tile + g * TILE + (oy0 * S) * ROW + LP + (ox0 * S - 1) * C + cg * 4;
+                    if constexpr (S == 2) dw_s2_task<R, ROW, C>(base, wA, Kc, o0, o1);
+                    else dw_s1_task<R, ROW, C>(base, wA, wB, Kc, o0, o1);
+#pragma unroll
+                    for (int j = 0; j < R; ++j) {
+                        uint32_t *dp = dst + ((size_t)(g * OH + oy0 + j) * OW + ox0) * C4 + cg;
+                        dp[0] = pack4x<XR4>(requant_t<MG>(o0[j][0], A.x, Sc.x, p.lo_f, p.hi_f), requant_t<MG>(o0[j][1], A.y, Sc.y, p.lo_f, p.hi_f),
+                                      requant_t<MG>(o0[j][2], A.z, Sc.z, p.lo_f, p.hi_f), requant_t<MG>(o0[j][3], A.w, Sc.w, p.lo_f, p.hi_f));
+                        if (ox0 + 1 < OW)
+                            dp[C4] = pack4x<XR4>(requant_t<MG>(o1[j][0], A.x, Sc.x, p.lo_f, p.hi_f), requant_t<MG>(o1[j][1], A.y, Sc.y, p.lo_f, p.hi_f),
+                                           requant_t<MG>(o1[j][2], A.z, Sc.z, p.lo_f, p.hi_f), requant_t<MG>(o1[j][3], A.w, Sc.w, p.lo_f, p.hi_f));
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------
+// FAST PATH 2 -- DepthwiseConv2D 3x3 stride 2 SAME with ONE input channel and DM
+// output channels (the network stem: person_detect op 0, 96x96x1 -> 48x48x8).
+// (src/ops/depthwise_conv_2d.rs:67: every output channel reads input channel 0.)
+//
+// A lane produces two horizontally adjacent output pixels x DM=8 channels = one
+// 16-byte store.  Per filter row it reads two LDS dwords, builds the two 3-tap
+// windows with one v_perm and one shift, and issues one sdot4 per (pixel, channel,
+// row) against wave-uniform weight dwords [w(ky,0,c), w(ky,1,c), w(ky,2,c), 0] that
+// live in SGPRs.  Staging: the image is copied verbatim (contiguous 1 KiB DMAs) between
+// two izp rows; the only tap that is not covered by those rows, column -1 of the first
+// pixel pair, is patched with a select.
+// F32IN = true fuses the model-boundary quantisation (M::predict: Tensor::quantize, lib.rs:189,
+// src/quantize.rs:16-18) into the staging: `in` then points to f32 pixels, each thread loads the
+// next step's float4s into registers before the compute of this step, quantises them afterwards
+// (true division, roundf, saturating cast -- the arithmetic of quantize_f32) and writes the int8
+// tile itself, so the 4x larger f32 image crosses HBM once and no int8 copy of it ever does.
+// ------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int H, int W, int G, bool MG, uint32_t XR4, bool F32IN>
+__global__ __launch_bounds__(256) void dw3x3_stem8(const int8_t *__restrict__ in,
+                                                   int8_t *__restrict__ out, DwStemArgs p,
+                                                   int batch) {
+    constexpr int DM = 8, S = 2;
+    constexpr int OH = (H + S - 1) / S, OW = (W + S - 1) / S;
+    constexpr int GUARD = 16;                     // the j == 0 lanes read 4 bytes before a row
+    constexpr int TILE = GUARD + (H + 2) * W;     // [guard][izp row][H rows][izp row]
+    constexpr int BUF = G * TILE;
+    constexpr int IMG = H * W;
+    constexpr int NI = IMG / 1024;                // 1 KiB DMA instructions per image
+    constexpr int PAIRS = OW / 2;                 // lane tasks per output row
+    constexpr int TASKS = G * OH * PAIRS;
+    constexpr int NTASK = (TASKS + 255) / 256;
+    static_assert(IMG % 1024 == 0 && W % 16 == 0 && OW % 2 == 0 && TILE % 16 == 0, "stem geometry");
+
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int i = tid; i < 2 * BUF / 16; i += 256)
+        ((uint4 *)lds)[i] = make_uint4(p.izp4, p.izp4, p.izp4, p.izp4);
+    __syncthreads();
+
+    auto stage = [&](int st, int buf) {
+#pragma unroll
+        for (int k = 0; k < (G * NI + 3) / 4; ++k) {
+            const int r = k * 4 + wave;           // wave-uniform 1 KiB piece of the step
+            const int g = r / NI, c = r % NI;
+            if (r < G * NI && st * G + g < batch)
+                dma16(in + ((size_t)(st * G + g) * IMG + c * 1024 + lane * 16),
+                      lds + buf * BUF + g * TILE + GUARD + W + c * 1024);
+        }
+    };
+
+    // f32 staging: float4 k of this thread is pixels 4*(k*256 + tid) .. +3 of the step's G images
+    constexpr int NF = F32IN ? G * IMG / 4 / 256 : 1;
+    static_assert(!F32IN || (G * IMG) % 1024 == 0, "f32 staging geometry");
+    f32x4 pre[NF];
+    auto load_f32 = [&](int st) {
+        const f32x4 *src = (const f32x4 *)in;
+#pragma unroll
+        for (int k = 0; k < NF; ++k) {
+            const int idx = k * 256 + tid, g = idx / (IMG / 4);
+            const size_t img = (size_t)st * G + g;
+            const size_t at = (img < (size_t)batch ? img : (size_t)batch - 1) * (IMG / 4) + idx % (IMG / 4);
+            pre[k] = src[at]; // clamped, unconditional: a ragged last step re-reads the last image
+        }
+    };
+    auto store_f32 = [&](int buf) {
+#pragma unroll
+        for (int k = 0; k < NF; ++k) {
+            const int idx = k * 256 + tid, g = idx / (IMG / 4), c = idx % (IMG / 4);
+            int q[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float t = __fadd_rn(__fdiv_rn(pre[k][e], p.in_scale), p.in_zp_f);
+                const float r = __fadd_rn(t, __builtin_copysignf(0x1.fffffep-2f, t));
+                q[e] = (r != r) ? 0 : (int)__builtin_amdgcn_fmed3f(r, p.in_sat_lo, p.in_sat_hi);
+            }
+            *(uint32_t *)(lds + buf * BUF + g * TILE + GUARD + W + c * 4) = pack4(q[0], q[1], q[2], q[3]) ^ p.in_xr4;
+        }
+    };
+
+    const int nsteps = (batch + G - 1) / G;
+    int step = blockIdx.x, cur = 0;
+    if constexpr (F32IN) {
+        if (step < nsteps) {
+            load_f32(step);
+            store_f32(0);
+        }
+    } else {
+        if (step < nsteps) stage(step, 0);
+    }
+
+    for (; step < nsteps; step += gridDim.x, cur ^= 1) {
+        if constexpr (!F32IN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const int next = step + gridDim.x;
+        if constexpr (F32IN) {
+            if (next < nsteps) load_f32(next);            // in flight during the compute below
+        } else {
+            if (next < nsteps) stage(next, cur ^ 1);
+        }
+
+        const uint8_t *tile = lds + cur * BUF;
+        uint4 *dst = (uint4 *)out + (size_t)step * G * OH * PAIRS;
+        const int nvalid = min(G, batch - step * G) * OH * PAIRS;
+#pragma unroll 1
+        for (int i = 0; i < NTASK; ++i) {
+            const int o = tid + 256 * i;
+            if (o < TASKS && o < nvalid) {
+                const int g = o / (OH * PAIRS), rem = o % (OH * PAIRS);
+                const int oy = rem / PAIRS, j = rem % PAIRS;
+                // pixels ox = 2j, 2j+1 need input cols 4j-1 .. 4j+3 of rows 2oy-1 .. 2oy+1 =
+                // tile rows 2oy .. 2oy+2 (tile row 0 is the izp row): dwords at cols 4j-4 and 4j
+                const uint32_t *rowp = (const uint32_t *)(tile + g * TILE + GUARD + (oy * S) * W + 4 * j - 4);
+                uint32_t ta[3], tb[3];
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    uint32_t d0 = rowp[ky * (W / 4)];
+                    const uint32_t d1 = rowp[ky * (W / 4) + 1];
+                    d0 = j == 0 ? p.izp4 : d0;                          // column -1 is padding
+                    ta[ky] = __builtin_amdgcn_perm(d0, d1, 0x0c010007u); // [d0.b3, d1.b0, d1.b1, 0]
+                    tb[ky] = d1 >> 8;                                    // [d1.b1, d1.b2, d1.b3, 0]
+                }
+                int qa[DM], qb[DM];
+#pragma unroll
+                for (int c = 0; c < DM; ++c) {
+                    int a = p.Kc[c] + (MG ? MF_MAGIC_I : 0), b = a;
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky) {
+                        a = sdot4(ta[ky], p.wrow[ky][c], a);
+                        b = sdot4(tb[ky], p.wrow[ky][c], b);
+                    }
+                    qa[c] = requant_t<MG>(a, p.A[c], p.S[c], p.lo_f, p.hi_f);
+                    qb[c] = requant_t<MG>(b, p.A[c], p.S[c], p.lo_f, p.hi_f);
+                }
+                uint4 v;
+                v.x = pack4x<XR4>(qa[0], qa[1], qa[2], qa[3]);
+                v.y = pack4x<XR4>(qa[4], qa[5], qa[6], qa[7]);
+                v.z = pack4x<XR4>(qb[0], qb[1], qb[2], qb[3]);
+                v.w = pack4x<XR4>(qb[4], qb[5], qb[6], qb[7]);
+                dst[o] = v;
+            }
+        }
+        if constexpr (F32IN) {
+            if (next < nsteps) store_f32(cur ^ 1); // the other buffer: last read before this step's barrier
+        }
+    }
+}
+
+// ------------------------------------------------------------------------
+// FAST PATH 2b -- DepthwiseConv2D with ONE input channel, up to 8 output channels, any filter
+// size / stride / padding (speech.tflite op 1: 49x40x1 -> 25x20x8, 10x8 filter, stride 2).
+// (src/ops/depthwise_conv_2d.rs:67: every output channel reads input channel 0.)
+// With one input channel the taps of a filter row are CONSECUTIVE input bytes, so a row of the
+// window is KG = ceil(KW/4) dwords and every (filter row, 4-tap group, output channel) is one
+// real 4-MAC v_dot4: 160 dot4 per output pixel for the 10x8 filter instead of 640 multiply-adds.
+//   tile   : one workgroup stages one image in LDS inside an izp halo (SAME padding needs no
+//            per-tap test); rows are padded to a multiple of 4 bytes (+4 of over-read room).
+//   window : a thread owns one output pixel; its row start (ox*sw) is not dword aligned in
+//            general, so it reads KG+1 aligned dwords and shifts with v_alignbyte.
+//   weights: packed on the host as [ky][group][8 channels] dwords (zero beyond KW / N), read
+//            from LDS as broadcast b128s.
+// Every input byte is read from HBM once; the kernel is VALU-bound (54 MAC per byte).
+// ------------------------------------------------------------------------
+template <bool MG, uint32_t XR4>
+__global__ __launch_bounds__(512) void dw_c1_lds(const int8_t *__restrict__ in, int8_t *__restrict__ out,
+                                                 DwC1Args p, size_t batch) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const int shy = p.pad_same ? (p.KH - 1) / 2 : 0, shx = p.pad_same ? (p.KW - 1) / 2 : 0;
+    // halo'd tile covering every tap of every output pixel
+    const int TH = (p.OH - 1) * p.sh + p.KH;
+    const int TWP = p.TWP, KG = p.KG;
+    const int tile_bytes = (TH * TWP + 4 + 15) & ~15;
+    uint32_t *wl = (uint32_t *)(lds + tile_bytes);
+    const int tid = threadIdx.x;
+    for (int i = tid; i < p.KH * KG * 8; i += 512) wl[i] = p.wpack[i];
+    for (int i = TH * TWP + tid; i < tile_bytes; i += 512) lds[i] = 0; // over-read room past the last row
+    int Kc[8];
+    float A[8], S[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        Kc[c] = (c < p.N ? p.Kc[c] : 0) + (MG ? MF_MAGIC_I : 0);
+        A[c] = c < p.N ? p.A[c] : 0.0f;
+        S[c] = c < p.N ? p.S[c] : 0.0f;
+    }
+    // tile element i = tid + 512 e comes from image byte gofs[e] (or is halo: -1); the same for
+    // every image, so the divisions happen once and an image's loads are issued back to back
+    constexpr int MAXE = 8;
+    int gofs[MAXE];
+#pragma unroll
+    for (int e = 0; e < MAXE; ++e) {
+        const int i = tid + 512 * e;
+        const int ty = i / TWP, tx = i - ty * TWP;
+        const int iy = ty - shy, ix = tx - shx;
+        gofs[e] = (i < TH * TWP && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) ? iy * p.W + ix : -1;
+    }
+    for (size_t img = blockIdx.x; img < batch; img += gridDim.x) {
+        const int8_t *x = in + img * (size_t)p.H * p.W;
+        int8_t v[MAXE];
+#pragma unroll
+        for (int e = 0; e < MAXE; ++e) v[e] = x[gofs[e] < 0 ? 0 : gofs[e]]; // clamped, unconditional
+        __syncthreads(); // previous image fully consumed
+#pragma unroll
+        for (int e = 0; e < MAXE; ++e)
+            if (tid + 512 * e < TH * TWP) ((int8_t *)lds)[tid + 512 * e] = gofs[e] < 0 ? (int8_t)p.izp : v[e];
+        for (int i = tid + 512 * MAXE; i < TH * TWP; i += 512) { // tiles above 4 KiB: the plain way
+            const int ty = i / TWP, tx = i - ty * TWP;
+            const int iy = ty - shy, ix = tx - shx;
+            // columns TW .. TWP-1 only ever meet zero weights; any finite value will do
+            ((int8_t *)lds)[i] = (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) ? x[iy * p.W + ix] : (int8_t)p.izp;
+        }
+        __syncthreads();
+        for (int o = tid; o < p.OH * p.OW; o += 512) {
+            const int oy = o / p.OW, ox = o - oy * p.OW;
+            int acc[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) acc[c] = Kc[c];
+            const int base0 = (oy * p.sh) * TWP + ox * p.sw;
+            for (int ky = 0; ky < p.KH; ++ky) {
+                const int base = base0 + ky * TWP;
+                const uint32_t *row = (const uint32_t *)(lds + (base & ~3));
+                const uint32_t sh = (uint32_t)(base & 3);
+                uint32_t lo = row[0];
+                for (int g = 0; g < KG; ++g) {
+                    const uint32_t hi = row[g + 1];
+                    const uint32_t v = __builtin_amdgcn_alignbyte(hi, lo, sh); // bytes base+4g .. base+4g+3
+                    lo = hi;
+                    const uint4 w0 = *(const uint4 *)(wl + (ky * KG + g) * 8);
+                    const uint4 w1 = *(const uint4 *)(wl + (ky * KG + g) * 8 + 4);
+                    acc[0] = sdot4(v, w0.x, acc[0]), acc[1] = sdot4(v, w0.y, acc[1]);
+                    acc[2] = sdot4(v, w0.z, acc[2]), acc[3] = sdot4(v, w0.w, acc[3]);
+                    acc[4] = sdot4(v, w1.x, acc[4]), acc[5] = sdot4(v, w1.y, acc[5]);
+                    acc[6] = sdot4(v, w1.z, acc[6]), acc[7] = sdot4(v, w1.w, acc[7]);
+                }
+            }
+            int q[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) q[c] = requant_t<MG>(acc[c], A[c], S[c], p.lo_f, p.hi_f);
+            int8_t *dst = out + (img * (size_t)p.OH * p.OW + o) * p.N;
+            if (p.N == 8) {
+                *(uint2 *)dst = make_uint2(pack4x<XR4>(q[0], q[1], q[2], q[3]), pack4x<XR4>(q[4], q[5], q[6], q[7]));
+            } else {
+                for (int c = 0; c < p.N; ++c) dst[c] = (int8_t)(q[c] ^ (int)(XR4 & 0xffu));
+            }
+        }
+    }
+}
+
+// ---- launchers ----
+template <int H, int W, int C, int S, int G, int NTHR, bool MG, uint32_t XR4>
+static void launch_dw(const int8_t *in, int8_t *out, const DwFastArgs &a, int batch, hipStream_t s) {
+    constexpr int LP = C < 16 ? 16 : C;
+    constexpr int lds = 2 * G * (H + 2) * (LP + W * C + LP) + 256; // two staging buffers + read slack
+    static LaunchState st;
+    const int per_cu = prepared(st, dw3x3_nhwc<H, W, C, S, G, NTHR, MG, XR4>, NTHR, lds);
+    const int nsteps = (batch + G - 1) / G;
+    const int grid = nsteps < 256 * per_cu ? nsteps : 256 * per_cu;
+    hipLaunchKernelGGL((dw3x3_nhwc<H, W, C, S, G, NTHR, MG, XR4>), dim3(grid), dim3(NTHR), lds, s, in, out, a, batch);
+}
+
+const char *dw_fast_name(int H, int W, int C, int S) {
+#define MF_DW(h, w, c, s, g, t) \
+    if (H == h && W == w && C == c && S == s) return "dw3x3_nhwc<" #h "," #w "," #c "," #s "," #g "," #t ">";
+    MF_DW_SHAPES(MF_DW)
+#undef MF_DW
+    return nullptr;
+}
+bool launch_dw_fast(int H, int W, int C, int S, const int8_t *in, int8_t *out, const DwFastArgs &a,
+                    int batch, hipStream_t s) {
+    static const int alt = [] { const char *e = getenv("MF_DW_ALT"); return e ? atoi(e) : -1; }();
+    if (alt >= 0) { // tuning candidates, see MF_DW_ALT_SHAPES
+        int idx = 0;
+        (void)idx;
+#define MF_DW(h, w, c, st, g, t)                                                \
+    if (idx++ == alt && H == h && W == w && C == c && S == st) {                \
+        MF_DISPATCH4(a.magic, a.xr, launch_dw, (in, out, a, batch, s), h, w, c, st, g, t) \
+        return true;                                                            \
+    }
+        MF_DW_ALT_SHAPES(MF_DW)
+#undef MF_DW
+    }
+#define MF_DW(h, w, c, st, g, t)                          \
+    if (H == h && W == w && C == c && S == st) {          \
+        MF_DISPATCH4(a.magic, a.xr, launch_dw, (in, out, a, batch, s), h, w, c, st, g, t) \
+        return true;                                      \
+    }
+    MF_DW_SHAPES(MF_DW)
+#undef MF_DW
+    return false;
+}
+
+static int dw_c1_lds_bytes(const DwC1Args &a) {
+    const int TH = (a.OH - 1) * a.sh + a.KH;
+    return ((TH * a.TWP + 4 + 15) & ~15) + a.KH * a.KG * 8 * 4;
+}
+bool dw_c1_supported(const DwC1Args &a) {
+    return a.N >= 1 && a.N <= 8 && dw_c1_lds_bytes(a) <= 64 * 1024;
+}
+void launch_dw_c1(const int8_t *in, int8_t *out, const DwC1Args &a, size_t batch, hipStream_t s) {
+    const int grid = (int)(batch < 256 * 8 ? batch : 256 * 8);
+    const int lds = dw_c1_lds_bytes(a);
+#define MF_C1(MG, XR) hipLaunchKernelGGL((dw_c1_lds<MG, XR>), dim3(grid), dim3(512), lds, s, in, out, a, batch)
+    if (a.xr) { if (a.magic) MF_C1(true, 0x80808080u); else MF_C1(false, 0x80808080u); }
+    else { if (a.magic) MF_C1(true, 0u); else MF_C1(false, 0u); }
+#undef MF_C1
+}
+
+const char *dw_stem_name(int H, int W, int DM, int S) {
+    if (H == 96 && W == 96 && DM == 8 && S == 2) return "dw3x3_stem8<96,96,2>";
+    return nullptr;
+}
+bool launch_dw_stem(int H, int W, int DM, int S, const int8_t *in, int8_t *out, const DwStemArgs &a,
+                    int batch, hipStream_t s, bool f32_input) {
+    if (H == 96 && W == 96 && DM == 8 && S == 2) {
+        constexpr int G = 2, lds = 2 * G * (16 + (96 + 2) * 96);
+        static LaunchState st, stf;
+        const int per_cu = f32_input ? prepared(stf, dw3x3_stem8<96, 96, G, false, 0u, true>, 256, lds)
+                                     : prepared(st, dw3x3_stem8<96, 96, G, false, 0u, false>, 256, lds);
+        const int nsteps = (batch + G - 1) / G;
+        const int grid = nsteps < 256 * per_cu ? nsteps : 256 * per_cu;
+#define MF_STEM(MG, XR, F) hipLaunchKernelGGL((dw3x3_stem8<96, 96, G, MG, XR, F>), dim3(grid), dim3(256), lds, s, in, out, a, batch)
+#define MF_STEM2(F)                                                                          \
+    if (a.xr) { if (a.magic) MF_STEM(true, 0x80808080u, F); else MF_STEM(false, 0x80808080u, F); } \
+    else { if (a.magic) MF_STEM(true, 0u, F); else MF_STEM(false, 0u, F); }
+        if (f32_input) { MF_STEM2(true) } else { MF_STEM2(false) }
+#undef MF_STEM2
+#undef MF_STEM
+        return true;
+    }
+    return false;
+}
+
+} // namespace k
+} // namespace mf

@@ -1,0 +1,292 @@
+// k_generic.hip -- shape-generic kernels (one thread per output element) and the boundary/utility kernels.
+//
+// conv_2d / depthwise_conv_2d / average_pool_2d / fully_connected for ANY shape (API completeness, the
+// reference's unit KATs, non-zero weight zero points, in-product cross-check of the fast paths), softmax,
+// quantize / dequantize, the u8 boundary XOR, the synthetic input generator and the checksum.
+// Arithmetic contract, shared device helpers and launch plumbing: k_common.hpp.
+#include "k_common.hpp"
+
+namespace mf {
+namespace k {
+
+// ------------------------------------------------------------------------
+// Generic (any shape) kernels: one thread per output element.  They exist for
+// API completeness (the reference's unit KATs, odd filter shapes, non-zero weight
+// zero points) and as the in-product cross-check of the fast paths.
+// ------------------------------------------------------------------------
+
+// microflow::ops::conv_2d  (src/ops/conv_2d.rs:28-108)
+__global__ __launch_bounds__(256) void conv2d_generic(const int8_t *__restrict__ in,
+                                                      int8_t *__restrict__ out, ConvArgs p,
+                                                      size_t total) {
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * 256) {
+        const int n = (int)(idx % p.N);
+        size_t t = idx / p.N;
+        const int ox = (int)(t % p.OW);
+        t /= p.OW;
+        const int oy = (int)(t % p.OH);
+        const size_t img = t / p.OH;
+        const int8_t *ip = in + img * (size_t)p.H * p.W * p.C;
+        const int8_t *wp = p.w + (size_t)n * p.KH * p.KW * p.C;
+        const int shy = p.pad_same ? (p.KH - 1) / 2 : 0, shx = p.pad_same ? (p.KW - 1) / 2 : 0;
+        int dot = 0, vs = 0;
+        for (int ky = 0; ky < p.KH; ++ky) {
+            const int iy = oy * p.sh + ky - shy;
+            for (int kx = 0; kx < p.KW; ++kx) {
+                const int ix = ox * p.sw + kx - shx;
+                const bool ok = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+                const int8_t *vp = ip + ((size_t)iy * p.W + ix) * p.C;
+                const int8_t *fp = wp + ((size_t)ky * p.KW + kx) * p.C;
+                for (int c = 0; c < p.C; ++c) {
+                    const int v = ok ? (int)vp[c] : p.izp;
+                    dot += v * (int)fp[c];
+                    vs += v;
+                }
+            }
+        }
+        const int acc = dot - p.wzp[n] * vs + p.Kc[n];
+        out[idx] = (int8_t)(requant_any(acc, p.A[n], p.S[n], p.lo_f, p.hi_f) ^ p.xr);
+    }
+}
+
+// microflow::ops::depthwise_conv_2d  (src/ops/depthwise_conv_2d.rs:28-105)
+__global__ __launch_bounds__(256) void dwconv_generic(const int8_t *__restrict__ in,
+                                                      int8_t *__restrict__ out, ConvArgs p,
+                                                      size_t total) {
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * 256) {
+        const int c = (int)(idx % p.N);
+        size_t t = idx / p.N;
+        const int ox = (int)(t % p.OW);
+        t /= p.OW;
+        const int oy = (int)(t % p.OH);
+        const size_t img = t / p.OH;
+        const int ci = c < p.C ? c : 0; // v.get(c).copied().unwrap_or(v[0])  (depthwise_conv_2d.rs:67)
+        const int8_t *ip = in + img * (size_t)p.H * p.W * p.C;
+        const int shy = p.pad_same ? (p.KH - 1) / 2 : 0, shx = p.pad_same ? (p.KW - 1) / 2 : 0;
+        int dot = 0, vs = 0;
+        for (int ky = 0; ky < p.KH; ++ky) {
+            const int iy = oy * p.sh + ky - shy;
+            for (int kx = 0; kx < p.KW; ++kx) {
+                const int ix = ox * p.sw + kx - shx;
+                const bool ok = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+                const int v = ok ? (int)ip[((size_t)iy * p.W + ix) * p.C + ci] : p.izp;
+                dot += v * (int)p.w[((size_t)ky * p.KW + kx) * p.N + c];
+                vs += v;
+            }
+        }
+        const int acc = dot - p.wzp[c] * vs + p.Kc[c];
+        out[idx] = (int8_t)(requant_any(acc, p.A[c], p.S[c], p.lo_f, p.hi_f) ^ p.xr);
+    }
+}
+
+// microflow::ops::average_pool_2d  (src/ops/average_pool_2d.rs:29-66)
+//   x = (1 / f32(len)) * f32(sum over the zero-filled window);  y = roundf(c0 * x + c1)
+__global__ __launch_bounds__(256) void avgpool_generic(const int8_t *__restrict__ in,
+                                                       int8_t *__restrict__ out, PoolArgs p,
+                                                       size_t total) {
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * 256) {
+        const int c = (int)(idx % p.C);
+        size_t t = idx / p.C;
+        const int ox = (int)(t % p.OW);
+        t /= p.OW;
+        const int oy = (int)(t % p.OH);
+        const size_t img = t / p.OH;
+        const int8_t *ip = in + img * (size_t)p.H * p.W * p.C;
+        const int shy = p.pad_same ? (p.KH - 1) / 2 : 0, shx = p.pad_same ? (p.KW - 1) / 2 : 0;
+        int sum = 0, len = 0;
+        for (int ky = 0; ky < p.KH; ++ky) {
+            const int iy = oy * p.sh + ky - shy;
+            for (int kx = 0; kx < p.KW; ++kx) {
+                const int ix = ox * p.sw + kx - shx;
+                if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) {
+                    sum += (int)ip[((size_t)iy * p.W + ix) * p.C + c] + p.bias;
+                    ++len;
+                }
+            }
+        }
+        const float inv = __fdiv_rn(1.0f, (float)len);
+        const float x = __fmul_rn(inv, (float)sum);
+        const float y = __fadd_rn(__fmul_rn(p.c0, x), p.c1);
+        float r = __fadd_rn(y, __builtin_copysignf(0x1.fffffep-2f, y));
+        // NaN (len == 0) converts to 0 like Rust's `as`; fmed3 is skipped for it
+        int q = (r != r) ? 0 : (int)__builtin_amdgcn_fmed3f(r, p.sat_lo, p.sat_hi);
+        q = max(q, p.lo);
+        q = min(q, p.hi);
+        out[idx] = (int8_t)(q ^ p.xr);
+    }
+}
+
+// microflow::ops::fully_connected  (src/ops/fully_connected.rs:24-82), any M/K/N.
+// in [batch*M][K], w [N][K], out [batch*M][N].
+__global__ __launch_bounds__(256) void fc_generic(const int8_t *__restrict__ in,
+                                                  int8_t *__restrict__ out, FcArgs p,
+                                                  size_t total) {
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * 256) {
+        const int j = (int)(idx % p.N);
+        const size_t row = idx / p.N;
+        const int8_t *x = in + row * (size_t)p.K;
+        const int8_t *w = p.w + (size_t)j * p.K;
+        int dot = 0, rs = 0;
+        if ((p.K & 3) == 0) {
+            const uint32_t *x4 = (const uint32_t *)x, *w4 = (const uint32_t *)w;
+            for (int k = 0; k < p.K / 4; ++k) {
+                const uint32_t v = x4[k];
+                dot = sdot4(v, w4[k], dot);
+                rs = sdot4(v, 0x01010101u, rs);
+            }
+        } else {
+            for (int k = 0; k < p.K; ++k) {
+                dot += (int)x[k] * (int)w[k];
+                rs += (int)x[k];
+            }
+        }
+        const int acc = dot - p.wzp * rs + p.Kc[j];
+        out[idx] = (int8_t)(requant_any(acc, p.A[j], p.S, p.lo_f, p.hi_f) ^ p.xr);
+    }
+}
+
+// microflow::ops::softmax  (src/ops/softmax.rs:15-27).  One thread per inference.
+// e_k = f32(q_k) * input_scale has only 256 possible values, so expf comes from a
+// host-built table (libm's algorithm runs on the host, never the device's expf).
+// The sum runs over the whole rows x cols tensor in column-major order.
+__global__ __launch_bounds__(256) void softmax_table(const int8_t *__restrict__ in,
+                                                     int8_t *__restrict__ out, SoftmaxArgs p,
+                                                     size_t batch) {
+    for (size_t b = (size_t)blockIdx.x * 256 + threadIdx.x; b < batch;
+         b += (size_t)gridDim.x * 256) {
+        const int8_t *x = in + b * (size_t)p.rows * p.cols;
+        int8_t *y = out + b * (size_t)p.rows * p.cols;
+        float sum = 0.0f;
+        for (int j = 0; j < p.cols; ++j)
+            for (int i = 0; i < p.rows; ++i) sum = __fadd_rn(sum, p.exp_table[(int)x[i * p.cols + j] + 128]);
+        for (int i = 0; i < p.rows * p.cols; ++i) {
+            const float e = p.exp_table[(int)x[i] + 128];
+            const float prob = __fdiv_rn(e, sum);
+            const float q = __fadd_rn(__fdiv_rn(prob, p.oscale), p.ozp_f); // quantize (quantize.rs:17)
+            const float r = __fadd_rn(q, __builtin_copysignf(0x1.fffffep-2f, q));
+            const int qi = (r != r) ? 0 : (int)__builtin_amdgcn_fmed3f(r, p.sat_lo, p.sat_hi);
+            y[i] = (int8_t)(qi ^ p.xr);
+        }
+    }
+}
+
+// src/quantize.rs:16-18 over a buffer: q = sat(roundf(x / scale + f32(zp)))
+__global__ __launch_bounds__(256) void quantize_f32(const float *__restrict__ in,
+                                                    int8_t *__restrict__ out, size_t n, float scale,
+                                                    float zp_f, float sat_lo, float sat_hi, int xr) {
+    // 4 values per thread: one 16-byte load, one 4-byte store (scalar when a pointer is not aligned for it)
+    const size_t n4 = ((((uintptr_t)in & 15) | ((uintptr_t)out & 3)) == 0) ? n >> 2 : 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const float4 v = ((const float4 *)in)[i];
+        int q[4];
+        const float xs[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float t = __fadd_rn(__fdiv_rn(xs[k], scale), zp_f);
+            const float r = __fadd_rn(t, __builtin_copysignf(0x1.fffffep-2f, t));
+            q[k] = (r != r) ? 0 : (int)__builtin_amdgcn_fmed3f(r, sat_lo, sat_hi);
+        }
+        ((uint32_t *)out)[i] = pack4(q[0], q[1], q[2], q[3]) ^ (0x01010101u * (uint32_t)xr);
+    }
+    for (size_t i = (n4 << 2) + (size_t)blockIdx.x * 256 + threadIdx.x; i < n;
+         i += (size_t)gridDim.x * 256) {
+        const float t = __fadd_rn(__fdiv_rn(in[i], scale), zp_f);
+        const float r = __fadd_rn(t, __builtin_copysignf(0x1.fffffep-2f, t));
+        const int qi = (r != r) ? 0 : (int)__builtin_amdgcn_fmed3f(r, sat_lo, sat_hi);
+        out[i] = (int8_t)(qi ^ xr);
+    }
+}
+
+// u8 <-> internal i8 domain at the quantized boundary of a u8 model: byte ^ 0x80
+__global__ __launch_bounds__(256) void xor80_bytes(const int8_t *in, int8_t *out,  // may alias (in place)
+                                                   size_t n) {
+    const size_t n16 = n >> 4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) {
+        u32x4 v = ((const u32x4 *)in)[i];
+        v ^= 0x80808080u;
+        ((u32x4 *)out)[i] = v;
+    }
+    for (size_t i = (n16 << 4) + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        out[i] = (int8_t)(in[i] ^ 0x80);
+}
+
+// src/quantize.rs:27-29: x = scale * (f32(q) - f32(zp))
+__global__ __launch_bounds__(256) void dequantize_i8(const int8_t *__restrict__ in,
+                                                     float *__restrict__ out, size_t n, float scale,
+                                                     float zp_f, int raw_u8) {
+    // raw_u8: the bytes are real u8 values (ABI-level mf_dequantize_u8), not the internal domain
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const int q = raw_u8 ? (int)(uint8_t)in[i] : (int)in[i];
+        out[i] = __fmul_rn(scale, __fsub_rn((float)q, zp_f));
+    }
+}
+
+// counter-based synthetic input: 8 bytes per thread
+__global__ __launch_bounds__(256) void synth_i8(int8_t *__restrict__ out, size_t n, uint64_t seed,
+                                                uint64_t first) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const uint64_t g = first + i;
+        const uint64_t w = splitmix64(seed + (g >> 3));
+        out[i] = (int8_t)(uint8_t)(w >> ((g & 7) * 8));
+    }
+}
+
+// position-sensitive checksum: sum (u8 + 1) * splitmix64(i); one atomic per block
+__global__ __launch_bounds__(256) void checksum_i8(const int8_t *__restrict__ in, size_t n,
+                                                   unsigned long long *__restrict__ result) {
+    __shared__ unsigned long long part[256];
+    unsigned long long s = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        s += ((unsigned long long)(uint8_t)in[i] + 1ull) * splitmix64(i);
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) part[threadIdx.x] += part[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) atomicAdd(result, part[0]);
+}
+
+// ---- launchers ----
+void launch_conv2d_generic(const int8_t *in, int8_t *out, const ConvArgs &a, size_t batch, hipStream_t s) {
+    const size_t total = batch * a.OH * a.OW * a.N;
+    hipLaunchKernelGGL(conv2d_generic, dim3(grid_for(total)), dim3(256), 0, s, in, out, a, total);
+}
+void launch_dwconv_generic(const int8_t *in, int8_t *out, const ConvArgs &a, size_t batch, hipStream_t s) {
+    const size_t total = batch * a.OH * a.OW * a.N;
+    hipLaunchKernelGGL(dwconv_generic, dim3(grid_for(total)), dim3(256), 0, s, in, out, a, total);
+}
+void launch_avgpool_generic(const int8_t *in, int8_t *out, const PoolArgs &a, size_t batch, hipStream_t s) {
+    const size_t total = batch * a.OH * a.OW * a.C;
+    hipLaunchKernelGGL(avgpool_generic, dim3(grid_for(total)), dim3(256), 0, s, in, out, a, total);
+}
+void launch_fc_generic(const int8_t *in, int8_t *out, const FcArgs &a, size_t rows, hipStream_t s) {
+    const size_t total = rows * a.N;
+    hipLaunchKernelGGL(fc_generic, dim3(grid_for(total)), dim3(256), 0, s, in, out, a, total);
+}
+void launch_softmax(const int8_t *in, int8_t *out, const SoftmaxArgs &a, size_t batch, hipStream_t s) {
+    hipLaunchKernelGGL(softmax_table, dim3(grid_for(batch)), dim3(256), 0, s, in, out, a, batch);
+}
+void launch_quantize(const float *in, int8_t *out, size_t n, float scale, float zp_f, bool u8, hipStream_t s) {
+    hipLaunchKernelGGL(quantize_f32, dim3(grid_for((n + 3) / 4)), dim3(256), 0, s, in, out, n, scale, zp_f,
+                       u8 ? 0.0f : -128.0f, u8 ? 255.0f : 127.0f, u8 ? 0x80 : 0);
+}
+void launch_xor80(const int8_t *in, int8_t *out, size_t n, hipStream_t s) {
+    hipLaunchKernelGGL(xor80_bytes, dim3(grid_for((n + 15) / 16)), dim3(256), 0, s, in, out, n);
+}
+void launch_dequantize(const int8_t *in, float *out, size_t n, float scale, float zp_f, bool raw_u8, hipStream_t s) {
+    hipLaunchKernelGGL(dequantize_i8, dim3(grid_for(n)), dim3(256), 0, s, in, out, n, scale, zp_f, raw_u8 ? 1 : 0);
+}
+void launch_synth(int8_t *out, size_t n, uint64_t seed, uint64_t first, hipStream_t s) {
+    hipLaunchKernelGGL(synth_i8, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, s, out, n, seed, first);
+}
+void launch_checksum(const int8_t *in, size_t n, unsigned long long *result, hipStream_t s) {
+    hipLaunchKernelGGL(checksum_i8, dim3(grid_for(n, 256 * 16, 1024)), dim3(256), 0, s, in, n, result);
+}
+
+} // namespace k
+} // namespace mf

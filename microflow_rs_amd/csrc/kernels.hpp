@@ -1,4 +1,4 @@
-// kernels.hpp -- argument blocks and launchers of the HIP kernels (kernels.hip).
+// kernels.hpp -- argument blocks and launchers of the HIP kernels (k_generic / k_depthwise / k_pointwise / k_fused / k_gemm .hip).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stddef.h>
@@ -75,7 +75,7 @@ struct DwFastArgs {
     const int *Kc;
     uint32_t izp4;      // izp replicated in 4 bytes
     float lo_f, hi_f;
-    int magic;          // 1: worst-case |acc| < 2^22 -> bit-pattern int->float conversion (kernels.hip)
+    int magic;          // 1: worst-case |acc| < 2^22 -> bit-pattern int->float conversion (k_common.hpp)
     int xr;             // 0 (i8) or 0x80 (u8): see ConvArgs
 };
 // depthwise with ONE input channel and up to 8 output channels, any filter / stride (speech op 1)

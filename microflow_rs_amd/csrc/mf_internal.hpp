@@ -6,7 +6,7 @@
 //   tflite.cpp    minimal FlatBuffers reader for the ~10 TFLite tables the path needs
 //   hostmath.cpp  f32 constant preparation in the reference's evaluation order
 //   ops.hip       prepared operators: constant folding, kernel routing, launches
-//   kernels.hip   the HIP kernels (gfx950)
+//   k_*.hip       the HIP kernels (gfx950), one file per family; k_common.hpp shared helpers
 #pragma once
 #include <cstddef>
 #include <cstdint>

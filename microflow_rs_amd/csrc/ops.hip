@@ -1,6 +1,6 @@
 // ops.hip -- prepared operators: fold the reference's constants into the
 // per-channel device arrays the kernels consume, pick a kernel for the shape,
-// launch.  Host code only (HIP runtime API); the kernels are in kernels.hip.
+// launch.  Host code only (HIP runtime API); the kernels are in k_*.hip.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -221,7 +221,7 @@ OpImpl *op_create(int device, const OpSpec &spec) {
         std::vector<float> A, S;
         std::vector<int32_t> Kc, wzp;
         // the fast kernels may convert the accumulator to f32 by bit pattern when it provably
-        // stays below 2^22 in magnitude (requant_t<true> in kernels.hip)
+        // stays below 2^22 in magnitude (requant_t<true> in k_common.hpp)
         static const bool no_magic = getenv("MF_NO_MAGIC") != nullptr; // tests: force the convert form
         const int64_t acc_bound = fold_conv_constants(*op, s, dw, A, S, Kc, wzp);
         const int magic = !no_magic && acc_bound < (1 << 22) ? 1 : 0;

@@ -3,7 +3,7 @@
  *
  * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
- * link or call anything in oracle/.  The product (microflow-rs_amd/) never does.
+ * link or call anything in oracle/.  The product (microflow_rs_amd/) never does.
  *
  * It is a plain-C restatement of the reference's algorithm, deliberately
  * structured like the reference (per-output-pixel view extraction, per-channel

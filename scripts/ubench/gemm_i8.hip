@@ -1,5 +1,5 @@
 // gemm_i8.hip -- staging-pipeline experiments for the FullyConnected int8 MFMA GEMM
-// (microflow-rs_amd/csrc/kernels.hip: fc_mfma).  Same math as the product kernel
+// (microflow_rs_amd/csrc/k_gemm.hip: fc_mfma).  Same math as the product kernel
 // (NT GEMM, i32 accumulate, f32 requantize epilogue, packed 16-byte stores); what varies is
 // the K-step, the number of LDS buffers and the synchronisation of the LDS-DMA pipeline.
 //

@@ -44,9 +44,9 @@ def test_no_torch_types_cross_the_abi():
 
 
 def test_product_never_touches_the_oracle():
-    """oracle/ is test infrastructure: nothing under microflow-rs_amd/ may import,
+    """oracle/ is test infrastructure: nothing under microflow_rs_amd/ may import,
     link or execute it."""
-    pkg = os.path.join(ROOT, "microflow-rs_amd")
+    pkg = os.path.join(ROOT, "microflow_rs_amd")
     for dirpath, _, files in os.walk(pkg):
         for f in files:
             if f.endswith((".py", ".cpp", ".hpp", ".hip", ".h")):
