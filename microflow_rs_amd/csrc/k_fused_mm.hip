@@ -1,0 +1,415 @@
+// k_fused_mm.hip -- fused DepthwiseConv2D 3x3 -> Conv2D 1x1 with the depthwise taps on the MATRIX pipe.
+//
+// (src/ops/depthwise_conv_2d.rs:28-105 + src/ops/conv_2d.rs:28-108; same operators, same results as
+// dwpw3x3 in k_fused.hip -- only the way the depthwise accumulators are formed differs.)
+//
+// Why.  r01's fused kernels are VALU-bound, not HBM-bound: per output byte the reference's f32
+// requantisation costs ~24 VALU cycles and cannot shrink (every step is individually rounded), and
+// the depthwise multiply-adds cost as much again -- 2.75 v_perm byte transposes + 3 v_dot4 per output
+// byte -- while the MFMA pipe idles.  Here the 9 taps of 16 channels x 16 pixels are ONE K = 192
+// contraction against a block-diagonal weight matrix, i.e. three v_mfma_i32_16x16x64_i8:
+//
+//     D[channel r][pixel p] = sum over (ty, tx, c')  A[r][(ty,tx,c')] * B[(ty,tx,c')][p]
+//     A[r][(ty,tx,c')] = w[ty][tx][16q + r] if c' == r (and tx < 3) else 0      (host-built, wmm)
+//     B[(ty,tx,c')][p] = input pixel (y_p + ty - 1, x_p + tx - 1), channel 16q + c'
+//
+// In NHWC the 16 K-bytes a lane must supply -- tap (ty, tx = lane >> 4), channels 16q .. 16q+15 of
+// its pixel -- are 16 CONSECUTIVE bytes of the staged tile: one ds_read_b128, no transposes, no
+// dot4s, and the address is lane constant + compile-time unit offset (zero VALU).  15/16 of the
+// MACs multiply by zero; that is the price for using a pipe that was idle (3 MFMAs = 48 matrix-pipe
+// cycles per 256 outputs, against 92 VALU cycles for their requantisation, which stays the
+// bottleneck).  The kernel remains a byte-streaming kernel bounded by HBM / the f32 epilogue; the
+// contraction itself is NOT dense and is not priced as MFMA work anywhere.
+//
+// C = 8 (48x48x8): a 16-byte K-block is two adjacent pixels x 8 channels, so an MFMA column is a
+// PAIR of output pixels (2j, 2j+1) and the rows are (pixel parity, channel); three blocks per
+// filter row cover input pixels 2j-2 .. 2j+3.
+//
+// Work decomposition of the depthwise phase: a UNIT = 16 MFMA columns x one 16-channel group.
+// The 16 columns of a unit are a CG x CY x CX sub-grid over (image, output row, output x) chosen per
+// shape (scripts/model/dwmm_search.py) so that the lanes of every ds_read_b128 service group hit
+// distinct 16-byte bank slots; where a pixel is wider than 16 bytes the chunk index inside the
+// pixel is XOR-swizzled with low bits of x -- applied on the DMA *source* address, because a DMA
+// writes LDS linearly -- and again on the reads.  Every wave owns one channel group (its 12 VGPRs of
+// A operands and 12 of epilogue constants) and walks its units with immediates only.
+// The depthwise result goes to MID as planes [16-channel group][pixel][16 B]: the writes are
+// lane constant + immediate, and the pointwise phase's ds_read_b128 (16 consecutive pixels of one
+// plane) is conflict-free without a swizzle.  The pointwise phase is dwpw3x3's.
+#include "k_common.hpp"
+
+namespace mf {
+namespace k {
+
+namespace {
+constexpr int cgcd(int a, int b) { return b == 0 ? a : cgcd(b, a % b); }
+// tile swizzle: output bit i = input bit (nibble i of TS) - 1, nibble 0 = no bit
+template <int TS> __device__ __forceinline__ constexpr int tile_swz(int x) {
+    int r = 0;
+    if constexpr ((TS & 0xf) != 0) r |= ((x >> ((TS & 0xf) - 1)) & 1);
+    if constexpr (((TS >> 4) & 0xf) != 0) r |= ((x >> (((TS >> 4) & 0xf) - 1)) & 1) << 1;
+    if constexpr (((TS >> 8) & 0xf) != 0) r |= ((x >> (((TS >> 8) & 0xf) - 1)) & 1) << 2;
+    return r;
+}
+} // namespace
+
+// LDS bytes of one workgroup.  WPE (template parameter of the kernel) = waves per SIMD the register allocation
+// must leave room for: (workgroups the LDS admits per CU) x (waves per workgroup) / 4, chosen per shape.
+constexpr int dwmm_lds_bytes(int H, int W, int C, int S, int N, int G, int NTHR, bool DBUF, int ROWPAD) {
+    const int LP = C < 16 ? 16 : C, OH = (H + S - 1) / S, OW = (W + S - 1) / S;
+    const int BUF = G * (H + 2) * (LP + W * C + LP + ROWPAD);
+    const int NB = N < 64 ? N : 64, CPIX = C < 64 ? 1024 / C : 16;
+    const int patch = (NB / 16 < 4) ? (NTHR / 64) * CPIX * N : 0;
+    const int NPIX = G * OH * OW, P16 = (NPIX + 15) / 16 * 16;
+    const int MIDB = C == 8 ? NPIX * 8 : (C / 16) * (P16 * 16 + 16);
+    return (DBUF ? 2 : 1) * BUF + 512 + MIDB + 64 + patch;
+}
+template <int H, int W, int C, int S, int N, int G, int NTHR, bool DBUF, int CG, int CY, int ORD, int ROWPAD, int TS,
+          int WPE, bool MG, uint32_t XR4>
+__global__ __launch_bounds__(NTHR, WPE) void dwpw_mm(const int8_t *__restrict__ in, int8_t *__restrict__ out, DwPwArgs p,
+                                                int batch) {
+    // ---- depthwise geometry ----
+    constexpr bool PAIR = C == 8;                 // MFMA column = two adjacent output pixels
+    constexpr int OH = (H + S - 1) / S, OW = (W + S - 1) / S;
+    constexpr int OWC = PAIR ? OW / 2 : OW;       // columns per output row
+    constexpr int NQ = PAIR ? 1 : C / 16;         // 16-channel groups
+    constexpr int CX = 16 / (CG * CY);
+    constexpr int UG = G / CG, UY = OH / CY, UX = (OWC + CX - 1) / CX;
+    constexpr int LP = C < 16 ? 16 : C;
+    constexpr int ROWB = W * C, ROW = LP + ROWB + LP + ROWPAD, TILE = (H + 2) * ROW, BUF = G * TILE;
+    constexpr int IMG = H * ROWB, ROWCH = ROWB / 16, NROWS = G * H;
+    constexpr int NWAVE = NTHR / 64;
+    constexpr int NBUF = DBUF ? 2 : 1;
+    constexpr int OPIX = OH * OW, NPIX = G * OPIX;
+    constexpr int P16 = (NPIX + 15) / 16 * 16;
+    constexpr int PLANE = P16 * 16 + 16;          // bytes per MID plane (+16: planes start on different bank slots)
+    constexpr int MIDB = PAIR ? NPIX * 8 : NQ * PLANE;
+    static_assert(CG * CY * CX == 16 && G % CG == 0 && OH % CY == 0, "column grid");
+    static_assert(ROWB % 16 == 0 && ROWCH <= 64 && ROW % 16 == 0, "staging geometry");
+    static_assert(!PAIR || (S == 1 && OW % 2 == 0), "pair columns");
+    // units: QW channel groups per wave, PS wave groups share one channel group and split one unit dimension
+    constexpr int QW = NQ > NWAVE ? NQ / NWAVE : 1;
+    constexpr int PS = NQ >= NWAVE ? 1 : NWAVE / NQ;
+    static_assert(NQ >= NWAVE ? NQ % NWAVE == 0 : NWAVE % NQ == 0, "waves per channel group");
+    // the PS wave groups tile the unit grid: PSY x PSX x PSG of them along rows, x and images
+    constexpr int PSY = cgcd(UY, PS), PSX = cgcd(UX, PS / PSY), PSG = cgcd(UG, PS / PSY / PSX);
+    static_assert(PSY * PSX * PSG == PS, "the unit grid does not divide over the wave groups");
+    constexpr int NUG = UG / PSG, NUY = UY / PSY, NUX = UX / PSX; // units per wave and channel group
+    static_assert(QW == 1 || tile_swz<TS>(0xff) < NWAVE, "swizzle must stay inside a wave's channel-group stride");
+    static_assert(tile_swz<TS>(0xff) < (NQ > 1 ? NQ : 1) || NQ == 1, "swizzle wider than the pixel");
+    // byte strides of one unit step in the staged tile and in MID
+    constexpr int T_UG = CG * TILE, T_UY = CY * S * ROW, T_UX = PAIR ? CX * 16 : CX * S * C;
+    constexpr int M_UG = PAIR ? CG * OPIX * 8 : CG * OPIX * 16, M_UY = PAIR ? CY * OW * 8 : CY * OW * 16, M_UX = CX * 16;
+    // ---- pointwise geometry (as pw_mfma<K = C, N>) ----
+    constexpr int K = C;
+    constexpr int NB = N < 64 ? N : 64, TB = NB / 16, NSPLIT = N / NB;
+    constexpr int KS = K < 64 ? 1 : K / 64, Q = K < 64 ? 64 / K : 1;
+    constexpr int CPIX = (K < 64) ? (1024 / K) : 16;
+    constexpr int SLOTS = NWAVE / NSPLIT;
+    constexpr bool XPOSE = TB < 4;
+    constexpr int CBYTES = CPIX * N;
+    static_assert(NWAVE % NSPLIT == 0 && N % 16 == 0 && (K == 8 || K % 16 == 0), "pointwise geometry");
+    static_assert(!XPOSE || (NSPLIT == 1 && CBYTES % 1024 == 0), "transposed store geometry");
+    // LDS: [staging x NBUF][slack 512][MID (+64 slack)][patch]
+    constexpr int MID_OFF = NBUF * BUF + 512;
+    constexpr int PATCH_OFF = MID_OFF + MIDB + 64;
+
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    for (int i = tid; i < (NBUF * BUF + 512) / 16; i += NTHR)
+        ((uint4 *)lds)[i] = make_uint4(p.dw.izp4, p.dw.izp4, p.dw.izp4, p.dw.izp4);
+
+    // ---- depthwise per-lane constants ----
+    const int col = lane & 15, g = lane >> 4;
+    int cg, cy, cx;
+    {
+        // ORD: which of (image, row, x) varies fastest over the 16 columns: 0 gyx, 1 gxy, 2 ygx, 3 yxg, 4 xgy, 5 xyg
+        constexpr int D0 = (ORD == 0 || ORD == 1) ? CG : (ORD == 2 || ORD == 3) ? CY : CX;
+        constexpr int D1 = (ORD == 2 || ORD == 4) ? CG : (ORD == 0 || ORD == 5) ? CY : CX;
+        const int i0 = col % D0, i1 = (col / D0) % D1, i2 = col / (D0 * D1);
+        cg = (ORD == 0 || ORD == 1) ? i0 : (ORD == 2 || ORD == 4) ? i1 : i2;
+        cy = (ORD == 2 || ORD == 3) ? i0 : (ORD == 0 || ORD == 5) ? i1 : i2;
+        cx = (ORD == 4 || ORD == 5) ? i0 : (ORD == 1 || ORD == 3) ? i1 : i2;
+    }
+    const int q0 = NQ >= NWAVE ? wave : wave % NQ;    // this wave's (first) channel group
+    const int wp = NQ >= NWAVE ? 0 : wave / NQ;       // its position along the split unit dimension
+    const int wpy = wp % PSY, wpx = (wp / PSY) % PSX, wpg = wp / (PSY * PSX); // its place in the wave-group grid
+    const int wave_t = wpg * T_UG + wpy * T_UY + wpx * T_UX;
+    const int wave_m = wpg * M_UG + wpy * M_UY + wpx * M_UX;
+    int tbase, mbase;
+    if constexpr (PAIR) {
+        // blocks of a filter row: pixel pairs (2x-2,2x-1), (2x,2x+1), (2x+2,2x+3) [, pad]
+        tbase = cg * TILE + cy * ROW + LP + (2 * cx - 2) * 8 + g * 16 + wave_t;
+        mbase = (cg * OPIX + cy * OW) * 8 + cx * 16 + g * 4 + wave_m;
+    } else {
+        const int xl = cx * S + g - 1; // input pixel of this lane's tap column (tx = g; g == 3 meets zero weights)
+        tbase = cg * TILE + cy * S * ROW + LP + xl * C + 16 * (q0 ^ tile_swz<TS>(xl)) + wave_t;
+        mbase = q0 * PLANE + (cg * OPIX + cy * OW + cx) * 16 + g * 4 + wave_m;
+    }
+    v4i Adw[QW][3];
+    float4 dA[QW], dS[QW];
+    int4 dK[QW];
+#pragma unroll
+    for (int k = 0; k < QW; ++k) {
+        const int q = q0 + k * NWAVE;
+#pragma unroll
+        for (int ty = 0; ty < 3; ++ty) Adw[k][ty] = ((const v4i *)p.dw.wmm)[(q * 3 + ty) * 64 + lane];
+        const int ch4 = PAIR ? (g & 1) : 4 * q + g; // this lane's 4 channels start at 4 * ch4
+        dA[k] = ((const float4 *)p.dw.A)[ch4];
+        dS[k] = ((const float4 *)p.dw.S)[ch4];
+        dK[k] = magic4<MG>(((const int4 *)p.dw.Kc)[ch4]);
+    }
+
+    // ---- pointwise per-lane constants ----
+    const int pcol = lane & 15, pg = lane >> 4;
+    const int blk = wave % NSPLIT, slot = wave / NSPLIT;
+    v4i Aw[Q][TB][KS];
+#pragma unroll
+    for (int q = 0; q < Q; ++q)
+#pragma unroll
+        for (int tt = 0; tt < TB; ++tt)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+                Aw[q][tt][ks] = ((const v4i *)p.pw.wprep)[((((size_t)blk * Q + q) * TB + tt) * KS + ks) * 64 + lane];
+    float4 cA[TB], cS[TB];
+    int4 cK[TB];
+#pragma unroll
+    for (int tt = 0; tt < TB; ++tt) {
+        const int ch = blk * NB + pg * (NB / 4) + 4 * tt;
+        cA[tt] = *(const float4 *)(p.pw.A + ch);
+        cS[tt] = *(const float4 *)(p.pw.S + ch);
+        cK[tt] = magic4<MG>(*(const int4 *)(p.pw.Kc + ch));
+    }
+    __syncthreads(); // halo fill complete before any DMA lands
+
+    auto stage = [&](int st, int buf) {
+        // chunk i of a row = pixel i / NQ, 16-byte group i % NQ; it receives the source chunk whose group is
+        // XOR-swizzled with the pixel's low x bits (the tap reads undo it)
+        const int src_lane = NQ > 1 ? (lane ^ tile_swz<TS>(lane / (NQ > 1 ? NQ : 1))) : lane;
+#pragma unroll
+        for (int k = 0; k < (NROWS + NWAVE - 1) / NWAVE; ++k) {
+            const int r = k * NWAVE + wave;
+            const int gi = r / H, y = r % H;
+            if (r < NROWS && st * G + gi < batch && lane < ROWCH)
+                dma16(in + ((size_t)(st * G + gi) * IMG + y * ROWB + src_lane * 16),
+                      lds + buf * BUF + gi * TILE + (y + 1) * ROW + LP);
+        }
+    };
+
+    uint8_t *mid = lds + MID_OFF;
+    const int nsteps = (batch + G - 1) / G;
+    int step = blockIdx.x, cur = 0;
+    if (step < nsteps) stage(step, 0);
+
+    for (; step < nsteps; step += gridDim.x) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads(); // B1: staged tile complete; previous pointwise phase done with MID
+        const int next = step + gridDim.x;
+        if constexpr (DBUF) {
+            if (next < nsteps) stage(next, cur ^ 1);
+        }
+        const int gvalid = min(G, batch - step * G);
+
+        // ---------------- depthwise phase: staged tile -> MID, on the matrix pipe ----------------
+        {
+            const uint8_t *tb = lds + cur * BUF + tbase;
+            uint8_t *mb = mid + mbase;
+            // Units go through in batches of UB: the tap loads of the NEXT batch are issued before the
+            // requantisation of this one, and the UB MFMA chains of a batch are interleaved (a chain is 3
+            // dependent MFMAs; two chains issue back to back without waiting on each other).
+            constexpr int NU = NUG * NUY * NUX, NUT = QW * NU;
+            constexpr int UB = WPE >= 4 ? 1 : (NUT % 2 == 0 ? 2 : (NUT % 3 == 0 ? 3 : 1)); // 128-VGPR kernels: one chain at a time
+            auto toff_of = [](int t) constexpr {
+                const int k = t / NU, iu = t % NU;
+                // unit coordinates (the wave-group part is in tbase / mbase): interleaved over the wave groups
+                const int ug = (iu / (NUY * NUX)) * PSG, uy = ((iu / NUX) % NUY) * PSY, ux = (iu % NUX) * PSX;
+                return ug * T_UG + uy * T_UY + ux * T_UX + k * NWAVE * 16;
+            };
+            auto moff_of = [](int t) constexpr {
+                const int k = t / NU, iu = t % NU;
+                const int ug = (iu / (NUY * NUX)) * PSG, uy = ((iu / NUX) % NUY) * PSY, ux = (iu % NUX) * PSX;
+                return ug * M_UG + uy * M_UY + ux * M_UX + k * NWAVE * PLANE;
+            };
+            v4i bq[UB][3], bn[UB][3];
+#pragma unroll
+            for (int u = 0; u < UB; ++u)
+#pragma unroll
+                for (int ty = 0; ty < 3; ++ty) bq[u][ty] = *(const v4i *)(tb + toff_of(u) + ty * ROW);
+#pragma unroll
+            for (int t0 = 0; t0 < NUT; t0 += UB) {
+                v4i acc[UB];
+#pragma unroll
+                for (int u = 0; u < UB; ++u) {
+                    const int k = (t0 + u) / NU;
+                    acc[u] = v4i{dK[k].x, dK[k].y, dK[k].z, dK[k].w};
+                }
+#pragma unroll
+                for (int ty = 0; ty < 3; ++ty)
+#pragma unroll
+                    for (int u = 0; u < UB; ++u)
+                        acc[u] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Adw[(t0 + u) / NU][ty], bq[u][ty], acc[u], 0, 0, 0);
+                if (t0 + UB < NUT) {
+#pragma unroll
+                    for (int u = 0; u < UB; ++u)
+#pragma unroll
+                        for (int ty = 0; ty < 3; ++ty) bn[u][ty] = *(const v4i *)(tb + toff_of(t0 + UB + u) + ty * ROW);
+                }
+#pragma unroll
+                for (int u = 0; u < UB; ++u) {
+                    const int k = (t0 + u) / NU;
+                    const uint32_t d = pack4x<XR4>(requant_t<MG>(acc[u][0], dA[k].x, dS[k].x, p.dw.lo_f, p.dw.hi_f),
+                                                  requant_t<MG>(acc[u][1], dA[k].y, dS[k].y, p.dw.lo_f, p.dw.hi_f),
+                                                  requant_t<MG>(acc[u][2], dA[k].z, dS[k].z, p.dw.lo_f, p.dw.hi_f),
+                                                  requant_t<MG>(acc[u][3], dA[k].w, dS[k].w, p.dw.lo_f, p.dw.hi_f));
+                    const int moff = moff_of(t0 + u);
+                    if constexpr (UX * CX != OWC) { // the column grid overhangs the row: those lanes have no pixel
+                        const int ux = ((t0 + u) % NU % NUX) * PSX;
+                        if (cx + (ux + wpx) * CX < OWC) *(uint32_t *)(mb + moff) = d;
+                    } else {
+                        *(uint32_t *)(mb + moff) = d;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < UB; ++u)
+#pragma unroll
+                    for (int ty = 0; ty < 3; ++ty) bq[u][ty] = bn[u][ty];
+            }
+        }
+        __syncthreads(); // B2: MID complete; everyone is done reading the staged tile
+        if constexpr (!DBUF) {
+            if (next < nsteps) stage(next, 0); // flies during the pointwise phase
+        }
+
+        // ---------------- pointwise phase: MID -> HBM (dwpw3x3's, reading the planar MID) ----------------
+        const int npix = gvalid * OPIX;
+        const int nchunks = (npix + CPIX - 1) / CPIX;
+        int8_t *obase = out + (size_t)step * G * OPIX * N;
+        auto pw_unit = [&](int chunk, auto qlo_c, auto qhi_c) {
+            constexpr int QLO = decltype(qlo_c)::value, QHI = decltype(qhi_c)::value;
+            v4i B[KS];
+            if constexpr (K >= 64) {
+                int pix = chunk * 16 + pcol;
+                pix = pix < npix ? pix : npix - 1;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) B[ks] = *(const v4i *)(mid + (pg + 4 * ks) * PLANE + pix * 16);
+            } else if constexpr (K == 32) {
+                int pix = chunk * CPIX + (pg >> 1) * 16 + pcol;
+                pix = pix < npix ? pix : npix - 1;
+                B[0] = *(const v4i *)(mid + (pg & 1) * PLANE + pix * 16);
+            } else if constexpr (K == 16) {
+                int pix = chunk * CPIX + pg * 16 + pcol;
+                pix = pix < npix ? pix : npix - 1;
+                B[0] = *(const v4i *)(mid + pix * 16);
+            } else {
+                int pix = chunk * CPIX + 2 * (pg * 16 + pcol);
+                pix = pix + 1 < npix ? pix : npix - 2;
+                B[0] = *(const v4i *)(mid + pix * 8);
+            }
+#pragma unroll
+            for (int q = QLO; q < QHI; ++q) {
+                int lpix;
+                if constexpr (K >= 64) lpix = pcol;
+                else if constexpr (K == 8) lpix = 2 * ((q >> 1) * 16 + pcol) + (q & 1);
+                else lpix = q * 16 + pcol;
+                uint32_t packed[TB];
+#pragma unroll
+                for (int tt = 0; tt < TB; ++tt) {
+                    v4i acc = {cK[tt].x, cK[tt].y, cK[tt].z, cK[tt].w};
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks)
+                        acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(Aw[q][tt][ks], B[ks], acc, 0, 0, 0);
+                    packed[tt] = pack4x<XR4>(requant_t<MG>(acc[0], cA[tt].x, cS[tt].x, p.pw.lo_f, p.pw.hi_f),
+                                             requant_t<MG>(acc[1], cA[tt].y, cS[tt].y, p.pw.lo_f, p.pw.hi_f),
+                                             requant_t<MG>(acc[2], cA[tt].z, cS[tt].z, p.pw.lo_f, p.pw.hi_f),
+                                             requant_t<MG>(acc[3], cA[tt].w, cS[tt].w, p.pw.lo_f, p.pw.hi_f));
+                }
+                if constexpr (XPOSE) {
+                    uint8_t *dstp = lds + PATCH_OFF + wave * CBYTES + lpix * N + pg * (NB / 4);
+                    if constexpr (TB == 1) *(uint32_t *)dstp = packed[0];
+                    else *(uint2 *)dstp = make_uint2(packed[0], packed[1]);
+                } else {
+                    const int pix = chunk * CPIX + lpix;
+                    if (pix < npix)
+                        *(uint4 *)(obase + (size_t)pix * N + blk * NB + pg * 16) =
+                            make_uint4(packed[0], packed[1], packed[2], packed[3]);
+                }
+            }
+            if constexpr (XPOSE) {
+                __builtin_amdgcn_wave_barrier();
+                const int cb = chunk * CBYTES, obytes = npix * N;
+                constexpr int LO = QLO * (CBYTES / Q), HI = QHI * (CBYTES / Q);
+#pragma unroll
+                for (int j = 0; j < (HI - LO + 1023) / 1024; ++j) {
+                    const int off = LO + (j * 64 + lane) * 16;
+                    if (off < HI) {
+                        const uint4 v = *(const uint4 *)(lds + PATCH_OFF + wave * CBYTES + off);
+                        if (cb + off < obytes) *(uint4 *)(obase + cb + off) = v;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        };
+        using std::integral_constant;
+        if constexpr (Q >= 2 && SLOTS % 2 == 0 && K >= 16) { // half-chunk units (see dwpw3x3)
+            for (int u = slot; u < 2 * nchunks; u += SLOTS) {
+                if ((u & 1) == 0) pw_unit(u >> 1, integral_constant<int, 0>{}, integral_constant<int, Q / 2>{});
+                else pw_unit(u >> 1, integral_constant<int, Q / 2>{}, integral_constant<int, Q>{});
+            }
+        } else {
+            for (int chunk = slot; chunk < nchunks; chunk += SLOTS)
+                pw_unit(chunk, integral_constant<int, 0>{}, integral_constant<int, Q>{});
+        }
+        if constexpr (DBUF) cur ^= 1;
+    }
+}
+
+// ---- launchers ----
+template <int H, int W, int C, int S, int N, int G, int NTHR, int DB, int CG, int CY, int ORD, int ROWPAD, int TS, int WPE,
+          bool MG, uint32_t XR4>
+static void launch_dwpw_mm_t(const int8_t *in, int8_t *out, const DwPwArgs &a, int batch, hipStream_t s) {
+    constexpr int lds = dwmm_lds_bytes(H, W, C, S, N, G, NTHR, DB != 0, ROWPAD);
+    static_assert(lds <= 163840, "fused tile does not fit the LDS");
+    static LaunchState st;
+    const int per_cu = prepared(st, dwpw_mm<H, W, C, S, N, G, NTHR, (DB != 0), CG, CY, ORD, ROWPAD, TS, WPE, MG, XR4>, NTHR, lds);
+    const int nsteps = (batch + G - 1) / G;
+    const int grid = nsteps < 256 * per_cu ? nsteps : 256 * per_cu;
+    hipLaunchKernelGGL((dwpw_mm<H, W, C, S, N, G, NTHR, (DB != 0), CG, CY, ORD, ROWPAD, TS, WPE, MG, XR4>), dim3(grid), dim3(NTHR),
+                       lds, s, in, out, a, batch);
+}
+const char *dwpw_mm_name(int H, int W, int C, int S, int N) {
+#define MF_DWMM(h, w, c, s, n, g, t, d, cg, cy, ord, rp, ts, wpe) \
+    if (H == h && W == w && C == c && S == s && N == n) return "dwpw_mm<" #h "," #w "," #c "," #s "," #n "," #g "," #t "," #d ">";
+    MF_DWMM_SHAPES(MF_DWMM)
+#undef MF_DWMM
+    return nullptr;
+}
+bool launch_dwpw_mm(int H, int W, int C, int S, int N, const int8_t *in, int8_t *out, const DwPwArgs &a, int batch,
+                    hipStream_t s) {
+    if (!a.dw.wmm) return false;
+    static const int alt = [] { const char *e = getenv("MF_DWMM_ALT"); return e ? atoi(e) : -1; }();
+    if (alt >= 0) { // tuning candidates, see MF_DWMM_ALT_SHAPES
+        int idx = 0;
+        (void)idx;
+#define MF_DWMM(h, w, c, st, n, g, t, d, cg, cy, ord, rp, ts, wpe)                                                        \
+    if (idx++ == alt && H == h && W == w && C == c && S == st && N == n) {                                           \
+        MF_DISPATCH4(a.dw.magic && a.pw.magic, a.pw.xr, launch_dwpw_mm_t, (in, out, a, batch, s), h, w, c, st, n, g, t, d, \
+                     cg, cy, ord, rp, ts, wpe)                                                                            \
+        return true;                                                                                                 \
+    }
+        MF_DWMM_ALT_SHAPES(MF_DWMM)
+#undef MF_DWMM
+    }
+#define MF_DWMM(h, w, c, st, n, g, t, d, cg, cy, ord, rp, ts, wpe)                                                        \
+    if (H == h && W == w && C == c && S == st && N == n) {                                                           \
+        MF_DISPATCH4(a.dw.magic && a.pw.magic, a.pw.xr, launch_dwpw_mm_t, (in, out, a, batch, s), h, w, c, st, n, g, t, d, \
+                     cg, cy, ord, rp, ts, wpe)                                                                            \
+        return true;                                                                                                 \
+    }
+    MF_DWMM_SHAPES(MF_DWMM)
+#undef MF_DWMM
+    return false;
+}
+
+} // namespace k
+} // namespace mf

@@ -70,6 +70,7 @@ struct SoftmaxArgs {
 };
 struct DwFastArgs {
     const int8_t *w;    // [3][3][C]
+    const void *wmm;    // matrix-pipe form of w (k_fused_mm.hip): [C/16 or 1][3 filter rows][64 lanes] x 16 bytes
     const float *A;
     const float *S;
     const int *Kc;
@@ -178,6 +179,27 @@ struct TailArgs {
 // are dealt round-robin to the 4 SIMDs, so 6 or 9 waves leave one SIMD with 50 % more work.
 #define MF_DWPW_ALT_SHAPES(X)
 
+// The same pairs with the depthwise taps on the matrix pipe (dwpw_mm, k_fused_mm.hip): H, W, C, stride, N,
+// images per step, threads, double-buffered staging, then the column grid of a depthwise unit -- CG images x
+// CY rows x (16 / CG / CY) x-positions, ORD = which of them varies fastest over the 16 MFMA columns
+// (0 gyx, 1 gxy, 2 ygx, 3 yxg, 4 xgy, 5 xyg) -- the row pitch padding (bytes) and the tile swizzle TS
+// (nibble i = 1 + the bit of x that flips bit i of the 16-byte group index inside a pixel; 0 = none), and
+// WPE = waves per SIMD the register allocation leaves room for (workgroups the LDS admits x waves / 4).
+// Grid / padding / swizzle come from scripts/model/dwmm_search.py: every ds_read_b128 of the tap loads is
+// bank-conflict free except on the 6x6x128 pair (2-way).
+#define MF_DWMM_SHAPES(X)                                 \
+    X(48, 48, 8, 1, 16, 1, 512, 1, 1, 4, 0, 32, 0x000, 4)    \
+    X(48, 48, 16, 2, 32, 1, 768, 1, 1, 2, 0, 32, 0x000, 3)   \
+    X(24, 24, 32, 1, 32, 1, 512, 1, 1, 2, 0, 0, 0x002, 4)    \
+    X(24, 24, 32, 2, 64, 2, 256, 0, 1, 4, 0, 32, 0x002, 2)   \
+    X(12, 12, 64, 1, 64, 4, 512, 0, 1, 4, 0, 16, 0x000, 2)   \
+    X(12, 12, 64, 2, 128, 4, 256, 0, 4, 2, 0, 32, 0x021, 2)  \
+    X(6, 6, 128, 1, 128, 8, 512, 0, 4, 2, 2, 16, 0x101, 2)   \
+    X(6, 6, 128, 2, 256, 8, 512, 0, 4, 1, 3, 16, 0x321, 2)   \
+    X(3, 3, 256, 1, 256, 8, 512, 0, 4, 1, 0, 64, 0x021, 2)
+// tuning candidates (MF_DWMM_ALT=<i>), empty in the product build
+#define MF_DWMM_ALT_SHAPES(X)
+
 // (K = input channels, N = output channels) with a compiled pointwise MFMA kernel
 #define MF_PW_SHAPES(X) \
     X(8, 16)            \
@@ -219,6 +241,9 @@ bool launch_dw_stem(int H, int W, int DM, int S, const int8_t *in, int8_t *out, 
 const char *dwpw_name(int H, int W, int C, int S, int N);
 bool launch_dwpw(int H, int W, int C, int S, int N, const int8_t *in, int8_t *out, const DwPwArgs &a,
                  int batch, hipStream_t s);
+const char *dwpw_mm_name(int H, int W, int C, int S, int N);
+bool launch_dwpw_mm(int H, int W, int C, int S, int N, const int8_t *in, int8_t *out, const DwPwArgs &a,
+                    int batch, hipStream_t s);
 bool tail_supported(int C, int N, int ntaps);
 void launch_tail(const int8_t *in, int8_t *out, const TailArgs &a, size_t batch, hipStream_t s);
 const char *pw_name(int K, int N);

@@ -179,6 +179,35 @@ std::vector<int8_t> build_pw_weights(const int8_t *w /*[N][K]*/, int K, int N) {
     return out;
 }
 
+// Depthwise 3x3 weights [3][3][C] as operand A of v_mfma_i32_16x16x64_i8 for dwpw_mm (k_fused_mm.hip):
+// [group q][filter row ty][lane][16 bytes].  A lane holds row r = lane & 15 of the 16 x 64 block-diagonal
+// matrix, K-block g = lane >> 4.
+//   C >= 16: row r = channel 16q + r; block g = tap column tx = g (g == 3: padding), its 16 K-bytes are
+//            the 16 channels of that tap's pixel -> the only non-zero byte is c' == r: w[ty][g][16q + r].
+//   C == 8 : row r = (output pixel parity r >> 3, channel r & 7); block g = input pixel pair
+//            (2x-2+2g, 2x-1+2g), byte (pp, c'): non-zero for c' == channel and tap column
+//            tx = 2g + pp - 1 - parity in 0..2.
+std::vector<int8_t> build_dw_mm_weights(const int8_t *w /*[3][3][C]*/, int C) {
+    const int NQ = C == 8 ? 1 : C / 16;
+    std::vector<int8_t> out((size_t)NQ * 3 * 64 * 16, 0);
+    for (int q = 0; q < NQ; ++q)
+        for (int ty = 0; ty < 3; ++ty)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int r = lane & 15, g = lane >> 4;
+                int8_t *dst = &out[(((size_t)q * 3 + ty) * 64 + lane) * 16];
+                if (C == 8) {
+                    const int par = r >> 3, c = r & 7;
+                    for (int pp = 0; pp < 2; ++pp) {
+                        const int tx = 2 * g + pp - 1 - par;
+                        if (g < 3 && tx >= 0 && tx <= 2) dst[pp * 8 + c] = w[(ty * 3 + tx) * 8 + c];
+                    }
+                } else if (g < 3) {
+                    dst[r] = w[(ty * 3 + g) * C + 16 * q + r];
+                }
+            }
+    return out;
+}
+
 } // namespace
 
 OpImpl *op_create(int device, const OpSpec &spec) {
@@ -253,6 +282,12 @@ OpImpl *op_create(int device, const OpSpec &spec) {
             f.w = a.w, f.A = a.A, f.S = a.S, f.Kc = a.Kc;
             f.izp4 = 0x01010101u * (uint32_t)(uint8_t)(int8_t)s.izp;
             f.lo_f = a.lo_f, f.hi_f = a.hi_f, f.magic = magic, f.xr = xr;
+            f.wmm = nullptr;
+            if (s.C == 8 || s.C % 16 == 0) { // matrix-pipe form of the taps for the fused pair kernels
+                const std::vector<int8_t> prep = build_dw_mm_weights(s.weights, s.C);
+                op->d_wprep.upload(prep.data(), prep.size());
+                f.wmm = op->d_wprep.p;
+            }
         } else if (dw && zero_wzp && same3x3 && s.C == 1 && k::dw_stem_name(s.H, s.W, s.N, s.sh)) {
             op->fast = OpImpl::DW_STEM;
             op->fast_name = k::dw_stem_name(s.H, s.W, s.N, s.sh);

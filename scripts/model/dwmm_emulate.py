@@ -1,0 +1,261 @@
+#!/usr/bin/env python3
+"""Lane-level emulation of dwpw_mm's depthwise phase (k_fused_mm.hip) in numpy: the staging swizzle, the
+unit / wave decomposition, the host-built block-diagonal A operands (ops.hip: build_dw_mm_weights), the
+v_mfma_i32_16x16x64_i8 operand layouts and the planar MID, checked against a direct depthwise convolution;
+then the pointwise phase's MID reads are checked to fetch (pixel, k) at the K position the MFMA expects.
+Index arithmetic is transcribed from the kernel, formula by formula.  No GPU needed.
+
+    python scripts/model/dwmm_emulate.py            # all shapes of MF_DWMM_SHAPES
+"""
+import re
+import sys
+import os
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def shapes_from_header():
+    txt = open(os.path.join(ROOT, "microflow_rs_amd", "csrc", "kernels.hpp")).read()
+    blk = txt[txt.index("#define MF_DWMM_SHAPES(X)"):]
+    blk = blk[:blk.index("// tuning candidates")]
+    out = []
+    for m in re.finditer(r"X\(([^)]*)\)", blk):
+        vals = [int(v, 0) for v in m.group(1).split(",")]
+        out.append(tuple(vals))
+    return out
+
+
+def tile_swz(TS, x):
+    r = 0
+    for i in range(3):
+        nib = (TS >> (4 * i)) & 0xf
+        if nib:
+            r |= ((x >> (nib - 1)) & 1) << i
+    return r
+
+
+def cgcd(a, b):
+    while b:
+        a, b = b, a % b
+    return a
+
+
+def build_dw_mm_weights(w, C):
+    """w [3][3][C] int8 -> [NQ][3][64][16]"""
+    NQ = 1 if C == 8 else C // 16
+    out = np.zeros((NQ, 3, 64, 16), np.int8)
+    for q in range(NQ):
+        for ty in range(3):
+            for lane in range(64):
+                r, g = lane & 15, lane >> 4
+                if C == 8:
+                    par, c = r >> 3, r & 7
+                    for pp in range(2):
+                        tx = 2 * g + pp - 1 - par
+                        if g < 3 and 0 <= tx <= 2:
+                            out[q, ty, lane, pp * 8 + c] = w[ty, tx, c]
+                elif g < 3:
+                    out[q, ty, lane, r] = w[ty, g, 16 * q + r]
+    return out
+
+
+def mfma_16x16x64(A, B, acc):
+    """A, B: [64 lanes][16 bytes] int8; acc [64 lanes][4] int32 -> D; lane (l&15, l>>4):
+    A: row l&15, k-bytes 16*(l>>4)..; B: column l&15, k-bytes 16*(l>>4)..; D lane: column l&15, rows 4*(l>>4)+i"""
+    Am = np.zeros((16, 64), np.int64)
+    Bm = np.zeros((64, 16), np.int64)
+    for l in range(64):
+        Am[l & 15, 16 * (l >> 4):16 * (l >> 4) + 16] = A[l]
+        Bm[16 * (l >> 4):16 * (l >> 4) + 16, l & 15] = B[l]
+    D = Am @ Bm
+    out = acc.copy()
+    for l in range(64):
+        for i in range(4):
+            out[l, i] += D[4 * (l >> 4) + i, l & 15]
+    return out
+
+
+def emulate(shape, seed=0):
+    H, W, C, S, N, G, NTHR, DB, CG, CY, ORD, ROWPAD, TS = shape[:13]
+    rng = np.random.default_rng(seed)
+    PAIR = C == 8
+    OH, OW = (H + S - 1) // S, (W + S - 1) // S
+    OWC = OW // 2 if PAIR else OW
+    NQ = 1 if PAIR else C // 16
+    CX = 16 // (CG * CY)
+    UG, UY, UX = G // CG, OH // CY, (OWC + CX - 1) // CX
+    LP = 16 if C < 16 else C
+    ROWB = W * C
+    ROW = LP + ROWB + LP + ROWPAD
+    TILE = (H + 2) * ROW
+    BUF = G * TILE
+    ROWCH = ROWB // 16
+    NWAVE = NTHR // 64
+    OPIX = OH * OW
+    NPIX = G * OPIX
+    P16 = (NPIX + 15) // 16 * 16
+    PLANE = P16 * 16 + 16
+    MIDB = NPIX * 8 if PAIR else NQ * PLANE
+    assert CG * CY * CX == 16 and G % CG == 0 and OH % CY == 0
+    QW = NQ // NWAVE if NQ > NWAVE else 1
+    PS = 1 if NQ >= NWAVE else NWAVE // NQ
+    PSY = cgcd(UY, PS)
+    PSX = cgcd(UX, PS // PSY)
+    PSG = cgcd(UG, PS // PSY // PSX)
+    assert PSY * PSX * PSG == PS, "unit grid does not divide"
+    NUG, NUY, NUX = UG // PSG, UY // PSY, UX // PSX
+    assert QW == 1 or tile_swz(TS, 0xff) < NWAVE
+    assert NQ == 1 or tile_swz(TS, 0xff) < NQ
+    T_UG, T_UY, T_UX = CG * TILE, CY * S * ROW, (CX * 16 if PAIR else CX * S * C)
+    M_UG = CG * OPIX * (8 if PAIR else 16)
+    M_UY = CY * OW * (8 if PAIR else 16)
+    M_UX = CX * 16
+
+    izp = -7
+    x = rng.integers(-128, 128, (G, H, W, C), dtype=np.int8)
+    w = rng.integers(-128, 128, (3, 3, C), dtype=np.int8)
+    Kc = rng.integers(-1000, 1000, C).astype(np.int64)
+    wmm = build_dw_mm_weights(w, C)
+
+    # ---- staging (halo = izp, DMA with the source-side swizzle) ----
+    lds = np.full(BUF + 1024, izp, np.int8)
+    for gi in range(G):
+        for y in range(H):
+            row = x[gi, y].reshape(-1)
+            for lane in range(ROWCH):
+                src_lane = lane ^ tile_swz(TS, lane // NQ) if NQ > 1 else lane
+                dst = gi * TILE + (y + 1) * ROW + LP + lane * 16
+                lds[dst:dst + 16] = row[src_lane * 16:src_lane * 16 + 16]
+
+    # ---- depthwise phase ----
+    mid_acc = {}   # MID byte address of a dword -> 4 int accumulators
+    writes = 0
+    for wave in range(NWAVE):
+        q0 = wave if NQ >= NWAVE else wave % NQ
+        wp = 0 if NQ >= NWAVE else wave // NQ
+        wpy, wpx, wpg = wp % PSY, (wp // PSY) % PSX, wp // (PSY * PSX)
+        wave_t = wpg * T_UG + wpy * T_UY + wpx * T_UX
+        wave_m = wpg * M_UG + wpy * M_UY + wpx * M_UX
+        tbase = np.zeros(64, np.int64)
+        mbase = np.zeros(64, np.int64)
+        cxs = np.zeros(64, np.int64)
+        for lane in range(64):
+            col, g = lane & 15, lane >> 4
+            D0 = CG if ORD in (0, 1) else CY if ORD in (2, 3) else CX
+            D1 = CG if ORD in (2, 4) else CY if ORD in (0, 5) else CX
+            i0, i1, i2 = col % D0, (col // D0) % D1, col // (D0 * D1)
+            cg = i0 if ORD in (0, 1) else i1 if ORD in (2, 4) else i2
+            cy = i0 if ORD in (2, 3) else i1 if ORD in (0, 5) else i2
+            cx = i0 if ORD in (4, 5) else i1 if ORD in (1, 3) else i2
+            cxs[lane] = cx
+            if PAIR:
+                tbase[lane] = cg * TILE + cy * ROW + LP + (2 * cx - 2) * 8 + g * 16 + wave_t
+                mbase[lane] = (cg * OPIX + cy * OW) * 8 + cx * 16 + g * 4 + wave_m
+            else:
+                xl = cx * S + g - 1
+                tbase[lane] = cg * TILE + cy * S * ROW + LP + xl * C + 16 * (q0 ^ tile_swz(TS, xl)) + wave_t
+                mbase[lane] = q0 * PLANE + (cg * OPIX + cy * OW + cx) * 16 + g * 4 + wave_m
+        for k in range(QW):
+            q = q0 + k * NWAVE
+            for iu in range(NUG * NUY * NUX):
+                ug, uy, ux = (iu // (NUY * NUX)) * PSG, ((iu // NUX) % NUY) * PSY, (iu % NUX) * PSX
+                toff = ug * T_UG + uy * T_UY + ux * T_UX + k * NWAVE * 16
+                moff = ug * M_UG + uy * M_UY + ux * M_UX + k * NWAVE * PLANE
+                acc = np.zeros((64, 4), np.int64)
+                for lane in range(64):
+                    g = lane >> 4
+                    ch4 = (g & 1) if PAIR else 4 * q + g
+                    acc[lane] = Kc[4 * ch4:4 * ch4 + 4]
+                for ty in range(3):
+                    B = np.zeros((64, 16), np.int8)
+                    for lane in range(64):
+                        a = tbase[lane] + toff + ty * ROW
+                        assert a >= 0 and a + 16 <= len(lds), (shape, a)
+                        assert a % 16 == 0, ("unaligned b128", shape, a)
+                        B[lane] = lds[a:a + 16]
+                    acc = mfma_16x16x64(wmm[q, ty], B, acc)
+                for lane in range(64):
+                    if UX * CX != OWC and not (cxs[lane] + (ux + wpx) * CX < OWC):
+                        continue
+                    a = int(mbase[lane] + moff)
+                    assert 0 <= a and a + 4 <= MIDB, (shape, a, MIDB)
+                    assert a not in mid_acc, "MID dword written twice"
+                    mid_acc[a] = acc[lane].copy()
+                    writes += 1
+
+    # ---- reference: direct depthwise accumulators ----
+    xp = np.full((G, H + 2, W + 2, C), izp, np.int64)
+    xp[:, 1:H + 1, 1:W + 1] = x
+    ref = np.zeros((G, OH, OW, C), np.int64)
+    for ty in range(3):
+        for tx in range(3):
+            ref += xp[:, ty:ty + S * OH:S, tx:tx + S * OW:S] * w[ty, tx].astype(np.int64)
+    ref += Kc
+    # MID dword (plane q, pixel, g) or pair layout
+    n_expected = NPIX * C // 4
+    assert writes == n_expected, (shape, writes, n_expected)
+    for gi in range(G):
+        for oy in range(OH):
+            for ox in range(OW):
+                pix = (gi * OH + oy) * OW + ox
+                for c4 in range(C // 4):
+                    if PAIR:
+                        a = pix * 8 + 4 * c4
+                    else:
+                        a = (c4 // 4) * PLANE + pix * 16 + 4 * (c4 % 4)
+                    got = mid_acc[a]
+                    want = ref[gi, oy, ox, 4 * c4:4 * c4 + 4]
+                    assert np.array_equal(got, want), (shape, gi, oy, ox, c4, got, want)
+
+    # ---- pointwise phase reads: lane (pcol, pg) must fetch K-bytes [16 pg', ...) of its pixel ----
+    K = C
+    npix = NPIX
+    def mid_byte_owner(a):  # (pixel, channel) stored at MID byte a
+        if PAIR:
+            return a // 8, a % 8
+        qn, r = divmod(a, PLANE)
+        return r // 16, 16 * qn + r % 16
+    if K >= 64:
+        for chunk in range((npix + 15) // 16):
+            for ks in range(K // 64):
+                for lane in range(64):
+                    pcol, pg = lane & 15, lane >> 4
+                    pix = min(chunk * 16 + pcol, npix - 1)
+                    a = (pg + 4 * ks) * PLANE + pix * 16
+                    for i in range(16):
+                        assert mid_byte_owner(a + i) == (pix, ks * 64 + pg * 16 + i)
+    elif K == 32:
+        for chunk in range((npix + 31) // 32):
+            for lane in range(64):
+                pcol, pg = lane & 15, lane >> 4
+                pix = min(chunk * 32 + (pg >> 1) * 16 + pcol, npix - 1)
+                a = (pg & 1) * PLANE + pix * 16
+                for i in range(16):
+                    assert mid_byte_owner(a + i) == (pix, (pg & 1) * 16 + i)
+    elif K == 16:
+        for chunk in range((npix + 63) // 64):
+            for lane in range(64):
+                pcol, pg = lane & 15, lane >> 4
+                pix = min(chunk * 64 + pg * 16 + pcol, npix - 1)
+                for i in range(16):
+                    assert mid_byte_owner(pix * 16 + i) == (pix, i)
+    else:
+        for chunk in range((npix + 127) // 128):
+            for lane in range(64):
+                pcol, pg = lane & 15, lane >> 4
+                pix = chunk * 128 + 2 * (pg * 16 + pcol)
+                pix = pix if pix + 1 < npix else npix - 2
+                for i in range(16):
+                    assert mid_byte_owner(pix * 8 + i) == (pix + i // 8, i % 8)
+    lds_bytes = (2 if DB else 1) * BUF + 512 + MIDB + 64
+    NB = min(N, 64)
+    if NB // 16 < 4:
+        lds_bytes += NWAVE * (1024 // C if C < 64 else 16) * N
+    return dict(units_per_wave=QW * NUG * NUY * NUX, lds=lds_bytes, wg_per_cu=163840 // lds_bytes)
+
+
+if __name__ == "__main__":
+    for shp in shapes_from_header():
+        r = emulate(shp)
+        print("ok", shp, r)
