@@ -353,24 +353,30 @@ static void launch_dwpw_t(const int8_t *in, int8_t *out, const DwPwArgs &a, int 
     const int grid = nsteps < 256 * per_cu ? nsteps : 256 * per_cu;
     hipLaunchKernelGGL((dwpw3x3<H, W, C, S, N, G, NTHR, (DB != 0), MG, XR4>), dim3(grid), dim3(NTHR), lds, s, in, out, a, batch);
 }
-bool dwpw_prefer_mm();
+int dwpw_impl();
 const char *dwpw_name(int H, int W, int C, int S, int N) {
-    if (dwpw_prefer_mm() && dwpw_mm_name(H, W, C, S, N)) return dwpw_mm_name(H, W, C, S, N);
+    if (dwpw_impl() == 2 && dwpw_rr_name(H, W, C, S, N)) return dwpw_rr_name(H, W, C, S, N);
+    if (dwpw_impl() >= 1 && dwpw_mm_name(H, W, C, S, N)) return dwpw_mm_name(H, W, C, S, N);
 #define MF_DWPW(h, w, c, s, n, g, t, d) \
     if (H == h && W == w && C == c && S == s && N == n) return "dwpw3x3<" #h "," #w "," #c "," #s "," #n "," #g "," #t "," #d ">";
     MF_DWPW_SHAPES(MF_DWPW)
 #undef MF_DWPW
     return nullptr;
 }
-// MF_DWPW_IMPL=valu keeps the depthwise taps on the VALU (dwpw3x3, r01); default: the matrix-pipe form
-// (dwpw_mm, k_fused_mm.hip) wherever a shape has one
-bool dwpw_prefer_mm() {
-    static const bool valu = [] { const char *e = getenv("MF_DWPW_IMPL"); return e && e[0] == 'v'; }();
-    return !valu;
+// MF_DWPW_IMPL=valu keeps the depthwise taps on the VALU (dwpw3x3, r01); =mm uses the matrix-pipe form with the
+// intermediate tensor in LDS for every pair (dwpw_mm); default (2): dwpw_rr (intermediate in registers) where a
+// shape has one, else dwpw_mm, else dwpw3x3
+int dwpw_impl() {
+    static const int impl = [] {
+        const char *e = getenv("MF_DWPW_IMPL");
+        return !e ? 2 : (e[0] == 'v' ? 0 : (e[0] == 'm' ? 1 : 2));
+    }();
+    return impl;
 }
 bool launch_dwpw(int H, int W, int C, int S, int N, const int8_t *in, int8_t *out, const DwPwArgs &a,
                  int batch, hipStream_t s) {
-    if (dwpw_prefer_mm() && launch_dwpw_mm(H, W, C, S, N, in, out, a, batch, s)) return true;
+    if (dwpw_impl() == 2 && launch_dwpw_rr(H, W, C, S, N, in, out, a, batch, s)) return true;
+    if (dwpw_impl() >= 1 && launch_dwpw_mm(H, W, C, S, N, in, out, a, batch, s)) return true;
     static const int alt = [] { const char *e = getenv("MF_DWPW_ALT"); return e ? atoi(e) : -1; }();
     if (alt >= 0) {
         int idx = 0;

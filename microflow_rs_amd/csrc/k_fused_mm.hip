@@ -37,6 +37,10 @@
 // plane) is conflict-free without a swizzle.  The pointwise phase is dwpw3x3's.
 #include "k_common.hpp"
 
+#ifndef MF_RR_DIAG
+#define MF_RR_DIAG 0 // 1 / 2 / 3: diagnostics builds of dwpw_rr (no stores / no arithmetic / no HBM reads), never shipped
+#endif
+
 namespace mf {
 namespace k {
 
@@ -364,6 +368,246 @@ __global__ __launch_bounds__(NTHR, WPE) void dwpw_mm(const int8_t *__restrict__ 
     }
 }
 
+// ------------------------------------------------------------------------
+// dwpw_rr -- the same pair with the intermediate tensor kept in REGISTERS (C = 8, 16, 32).
+//
+// The depthwise MFMA leaves lane (column, g) with 4 consecutive channels of its pixel -- after the
+// reference's requantisation one packed dword.  With C <= 32 a pixel is at most two such dwords per lane,
+// and those 8 bytes ARE a valid B operand of v_mfma_i32_16x16x32_i8 (lane g supplies K-bytes 8g .. 8g+7) if
+// the pointwise weights are laid out for that K order on the host (wrr: K-byte 8g + b  <->  channel 4g + b for
+// b < 4, channel 16 + 4g + b - 4 for C = 32, zero weight otherwise).  So a wave runs a unit -- 16 MFMA
+// columns, all channels -- from the staged tile to the HBM store without touching LDS again: no MID tensor,
+// no second barrier, no transposition patch; the only workgroup barrier left is the one that publishes the
+// next staged images, and between two of them the waves drift freely (one wave's MFMAs under another's
+// requantisation).  The pointwise rows are permuted so that lane g' ends with N/4 CONSECUTIVE output bytes
+// of its pixel (8 or 16: one global store).  C = 8: columns are pixel pairs, the pointwise K covers both
+// pixels (each output row multiplies only its own pixel's half) and lane g' owns pixel parity g' >> 1,
+// channels 8 (g' & 1) .. +7.
+// ------------------------------------------------------------------------
+template <int H, int W, int C, int S, int N, int G, int NTHR, bool DBUF, int CG, int CY, int ORD, int ROWPAD, int TS,
+          int WPE, bool MG, uint32_t XR4>
+__global__ __launch_bounds__(NTHR, WPE) void dwpw_rr(const int8_t *__restrict__ in, int8_t *__restrict__ out, DwPwArgs p,
+                                                     int batch) {
+    constexpr bool PAIR = C == 8;
+    static_assert(C == 8 || C == 16 || C == 32, "register-resident pairs: C <= 32");
+    constexpr int OH = (H + S - 1) / S, OW = (W + S - 1) / S;
+    constexpr int OWC = PAIR ? OW / 2 : OW;
+    constexpr int NQ = PAIR ? 1 : C / 16;
+    constexpr int CX = 16 / (CG * CY);
+    constexpr int UG = G / CG, UY = OH / CY, UX = OWC / CX;
+    constexpr int LP = C < 16 ? 16 : C;
+    constexpr int ROWB = W * C, ROW = LP + ROWB + LP + ROWPAD, TILE = (H + 2) * ROW, BUF = G * TILE;
+    constexpr int IMG = H * ROWB, ROWCH = ROWB / 16, NROWS = G * H;
+    constexpr int NWAVE = NTHR / 64;
+    constexpr int NBUF = DBUF ? 2 : 1;
+    constexpr int OPIX = OH * OW;
+    static_assert(CG * CY * CX == 16 && G % CG == 0 && OH % CY == 0 && OWC % CX == 0, "column grid");
+    static_assert(ROWB % 16 == 0 && ROWCH <= 64 && ROW % 16 == 0, "staging geometry");
+    static_assert(!PAIR || (S == 1 && OW % 2 == 0), "pair columns");
+    static_assert(NQ == 1 || tile_swz<TS>(0xff) < NQ, "swizzle wider than the pixel");
+    // the NWAVE waves tile the unit grid
+    constexpr int PSY = cgcd(UY, NWAVE), PSX = cgcd(UX, NWAVE / PSY), PSG = cgcd(UG, NWAVE / PSY / PSX);
+    static_assert(PSY * PSX * PSG == NWAVE, "the unit grid does not divide over the waves");
+    constexpr int NUG = UG / PSG, NUY = UY / PSY, NUX = UX / PSX, NU = NUG * NUY * NUX;
+    constexpr int T_UG = CG * TILE, T_UY = CY * S * ROW, T_UX = PAIR ? CX * 16 : CX * S * C;
+    constexpr int O_UG = CG * OPIX * N, O_UY = CY * OW * N, O_UX = (PAIR ? 2 : 1) * CX * N; // output bytes per unit step
+    // pointwise: NT 16-row MFMAs per unit; a lane ends with LB consecutive output bytes
+    constexpr int NT = (PAIR ? 2 * N : N) / 16, LB = 4 * NT;
+    static_assert(LB == 8 || LB == 16, "one 8- or 16-byte store per lane");
+
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    for (int i = tid; i < (NBUF * BUF + 512) / 16; i += NTHR)
+        ((uint4 *)lds)[i] = make_uint4(p.dw.izp4, p.dw.izp4, p.dw.izp4, p.dw.izp4);
+
+    const int col = lane & 15, g = lane >> 4;
+    int cg, cy, cx;
+    {
+        constexpr int D0 = (ORD == 0 || ORD == 1) ? CG : (ORD == 2 || ORD == 3) ? CY : CX;
+        constexpr int D1 = (ORD == 2 || ORD == 4) ? CG : (ORD == 0 || ORD == 5) ? CY : CX;
+        const int i0 = col % D0, i1 = (col / D0) % D1, i2 = col / (D0 * D1);
+        cg = (ORD == 0 || ORD == 1) ? i0 : (ORD == 2 || ORD == 4) ? i1 : i2;
+        cy = (ORD == 2 || ORD == 3) ? i0 : (ORD == 0 || ORD == 5) ? i1 : i2;
+        cx = (ORD == 4 || ORD == 5) ? i0 : (ORD == 1 || ORD == 3) ? i1 : i2;
+    }
+    const int wpy = wave % PSY, wpx = (wave / PSY) % PSX, wpg = wave / (PSY * PSX);
+    const int wave_t = wpg * T_UG + wpy * T_UY + wpx * T_UX;
+    int tbase[NQ];
+    if constexpr (PAIR) {
+        tbase[0] = cg * TILE + cy * ROW + LP + (2 * cx - 2) * 8 + g * 16 + wave_t;
+    } else {
+        const int xl = cx * S + g - 1;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+            tbase[q] = cg * TILE + cy * S * ROW + LP + xl * C + 16 * (q ^ tile_swz<TS>(xl)) + wave_t;
+    }
+    // output: pixel of this lane's column (C = 8: its parity half), first of its LB channels
+    const int opar = PAIR ? (g >> 1) : 0;
+    const int n0 = PAIR ? 8 * (g & 1) : (N / 4) * g;
+    const int obase_lane = (cg * OPIX + cy * OW + (PAIR ? 2 * cx + opar : cx)) * N + n0 +
+                           wpg * O_UG + wpy * O_UY + wpx * O_UX;
+
+    v4i Adw[NQ][3];
+    float4 dA[NQ], dS[NQ];
+    int4 dK[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+#pragma unroll
+        for (int ty = 0; ty < 3; ++ty) Adw[q][ty] = ((const v4i *)p.dw.wmm)[(q * 3 + ty) * 64 + lane];
+        const int ch4 = PAIR ? (g & 1) : 4 * q + g;
+        dA[q] = ((const float4 *)p.dw.A)[ch4];
+        dS[q] = ((const float4 *)p.dw.S)[ch4];
+        dK[q] = magic4<MG>(((const int4 *)p.dw.Kc)[ch4]);
+    }
+    long Apw[NT];
+    float4 cA[NT], cS[NT];
+    int4 cK[NT];
+#pragma unroll
+    for (int m = 0; m < NT; ++m) {
+        Apw[m] = ((const long *)p.pw.wrr)[m * 64 + lane];
+        cA[m] = *(const float4 *)(p.pw.A + n0 + 4 * m);
+        cS[m] = *(const float4 *)(p.pw.S + n0 + 4 * m);
+        cK[m] = magic4<MG>(*(const int4 *)(p.pw.Kc + n0 + 4 * m));
+    }
+    __syncthreads(); // halo fill complete before any DMA lands
+
+    auto stage = [&](int st, int buf) {
+        const int src_lane = NQ > 1 ? (lane ^ tile_swz<TS>(lane / (NQ > 1 ? NQ : 1))) : lane;
+#pragma unroll
+        for (int k = 0; k < (NROWS + NWAVE - 1) / NWAVE; ++k) {
+            const int r = k * NWAVE + wave;
+            const int gi = r / H, y = r % H;
+#if MF_RR_DIAG == 3 // diagnostics build: no HBM reads
+            if (r < NROWS && st * G + gi < batch && lane < ROWCH && batch < 0)
+#else
+            if (r < NROWS && st * G + gi < batch && lane < ROWCH)
+#endif
+                dma16(in + ((size_t)(st * G + gi) * IMG + y * ROWB + src_lane * 16),
+                      lds + buf * BUF + gi * TILE + (y + 1) * ROW + LP);
+        }
+    };
+
+    const int nsteps = (batch + G - 1) / G;
+    int step = blockIdx.x, cur = 0;
+    if (step < nsteps) stage(step, 0);
+
+    for (; step < nsteps; step += gridDim.x) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads(); // the staged tile is complete; every wave is done with the buffer the next DMA overwrites
+        const int next = step + gridDim.x;
+        if constexpr (DBUF) {
+            if (next < nsteps) stage(next, cur ^ 1);
+        }
+        const int gvalid = min(G, batch - step * G);
+        const uint8_t *tb = lds + cur * BUF;
+        int8_t *ob = out + (size_t)step * G * OPIX * N + obase_lane;
+
+        constexpr int UB = (WPE >= 4 || NQ > 1) ? 1 : (NU % 2 == 0 ? 2 : (NU % 3 == 0 ? 3 : 1));
+        auto coords = [](int iu, int &ug, int &uy, int &ux) constexpr {
+            ug = (iu / (NUY * NUX)) * PSG, uy = ((iu / NUX) % NUY) * PSY, ux = (iu % NUX) * PSX;
+        };
+        auto toff_of = [&](int iu) constexpr {
+            int ug = 0, uy = 0, ux = 0;
+            coords(iu, ug, uy, ux);
+            return ug * T_UG + uy * T_UY + ux * T_UX;
+        };
+        v4i bq[UB][NQ][3], bn[UB][NQ][3];
+#pragma unroll
+        for (int u = 0; u < UB; ++u)
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                for (int ty = 0; ty < 3; ++ty) bq[u][q][ty] = *(const v4i *)(tb + tbase[q] + toff_of(u) + ty * ROW);
+#pragma unroll
+        for (int t0 = 0; t0 < NU; t0 += UB) {
+            v4i acc[UB][NQ];
+#pragma unroll
+            for (int u = 0; u < UB; ++u)
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) acc[u][q] = v4i{dK[q].x, dK[q].y, dK[q].z, dK[q].w};
+#pragma unroll
+            for (int ty = 0; ty < 3; ++ty)
+#pragma unroll
+                for (int u = 0; u < UB; ++u)
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q)
+                        acc[u][q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Adw[q][ty], bq[u][q][ty], acc[u][q], 0, 0, 0);
+            if (t0 + UB < NU) {
+#pragma unroll
+                for (int u = 0; u < UB; ++u)
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                        for (int ty = 0; ty < 3; ++ty)
+                            bn[u][q][ty] = *(const v4i *)(tb + tbase[q] + toff_of(t0 + UB + u) + ty * ROW);
+            }
+#if MF_RR_DIAG == 2 // diagnostics build: memory traffic only (stage, read the taps, store them back)
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                int ug = 0, uy = 0, ux = 0;
+                coords(t0 + u, ug, uy, ux);
+                const int ooff = ug * O_UG + uy * O_UY + ux * O_UX;
+                if (cg + (ug + wpg) * CG < gvalid) {
+                    if constexpr (LB == 8) *(uint2 *)(ob + ooff) = make_uint2(bq[u][0][0][0], bq[u][0][1][1]);
+                    else *(uint4 *)(ob + ooff) = make_uint4(bq[u][0][0][0], bq[u][0][1][1], bq[u][0][2][2], bq[u][0][0][3]);
+                }
+            }
+            if (false)
+#endif
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                // depthwise requantisation: the intermediate int8 tensor, 4 (C = 32: 8) bytes per lane
+                uint32_t d[2] = {0u, 0u};
+#pragma unroll
+                for (int q = 0; q < NQ; ++q)
+                    d[q] = pack4x<XR4>(requant_t<MG>(acc[u][q][0], dA[q].x, dS[q].x, p.dw.lo_f, p.dw.hi_f),
+                                       requant_t<MG>(acc[u][q][1], dA[q].y, dS[q].y, p.dw.lo_f, p.dw.hi_f),
+                                       requant_t<MG>(acc[u][q][2], dA[q].z, dS[q].z, p.dw.lo_f, p.dw.hi_f),
+                                       requant_t<MG>(acc[u][q][3], dA[q].w, dS[q].w, p.dw.lo_f, p.dw.hi_f));
+                // K-bytes 8g .. 8g+7 of the pointwise contraction (bytes 4..7 meet zero weights when C < 32)
+                const long bop = (long)(((unsigned long)d[1] << 32) | (unsigned long)d[0]);
+                uint32_t packed[NT];
+#pragma unroll
+                for (int m = 0; m < NT; ++m) {
+                    v4i pa = {cK[m].x, cK[m].y, cK[m].z, cK[m].w};
+                    pa = __builtin_amdgcn_mfma_i32_16x16x32_i8(Apw[m], bop, pa, 0, 0, 0);
+                    packed[m] = pack4x<XR4>(requant_t<MG>(pa[0], cA[m].x, cS[m].x, p.pw.lo_f, p.pw.hi_f),
+                                            requant_t<MG>(pa[1], cA[m].y, cS[m].y, p.pw.lo_f, p.pw.hi_f),
+                                            requant_t<MG>(pa[2], cA[m].z, cS[m].z, p.pw.lo_f, p.pw.hi_f),
+                                            requant_t<MG>(pa[3], cA[m].w, cS[m].w, p.pw.lo_f, p.pw.hi_f));
+                }
+                int ug = 0, uy = 0, ux = 0;
+                coords(t0 + u, ug, uy, ux);
+                const int ooff = ug * O_UG + uy * O_UY + ux * O_UX;
+#if MF_RR_DIAG == 1 // diagnostics build: no stores (the result is kept alive through a never-true condition)
+                if (packed[0] == 0x12345678u && batch < 0)
+#else
+                if (cg + (ug + wpg) * CG < gvalid) // a ragged last step stages fewer than G images
+#endif
+                {
+                    if constexpr (LB == 8) *(uint2 *)(ob + ooff) = make_uint2(packed[0], packed[1]);
+                    else *(uint4 *)(ob + ooff) = make_uint4(packed[0], packed[1], packed[2], packed[3]);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < UB; ++u)
+#pragma unroll
+                for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                    for (int ty = 0; ty < 3; ++ty) bq[u][q][ty] = bn[u][q][ty];
+        }
+        if constexpr (DBUF) {
+            cur ^= 1;
+        } else {
+            // single staging buffer: everyone must be done reading it before the next DMA lands
+            __syncthreads();
+            if (next < nsteps) stage(next, 0);
+        }
+    }
+}
+
 // ---- launchers ----
 template <int H, int W, int C, int S, int N, int G, int NTHR, int DB, int CG, int CY, int ORD, int ROWPAD, int TS, int WPE,
           bool MG, uint32_t XR4>
@@ -408,6 +652,53 @@ bool launch_dwpw_mm(int H, int W, int C, int S, int N, const int8_t *in, int8_t 
     }
     MF_DWMM_SHAPES(MF_DWMM)
 #undef MF_DWMM
+    return false;
+}
+
+template <int H, int W, int C, int S, int N, int G, int NTHR, int DB, int CG, int CY, int ORD, int ROWPAD, int TS, int WPE,
+          bool MG, uint32_t XR4>
+static void launch_dwpw_rr_t(const int8_t *in, int8_t *out, const DwPwArgs &a, int batch, hipStream_t s) {
+    constexpr int LP = C < 16 ? 16 : C;
+    constexpr int lds = (DB ? 2 : 1) * G * (H + 2) * (LP + W * C + LP + ROWPAD) + 512;
+    static_assert(lds <= 163840, "staged tiles do not fit the LDS");
+    static LaunchState st;
+    const int per_cu = prepared(st, dwpw_rr<H, W, C, S, N, G, NTHR, (DB != 0), CG, CY, ORD, ROWPAD, TS, WPE, MG, XR4>, NTHR, lds);
+    const int nsteps = (batch + G - 1) / G;
+    const int grid = nsteps < 256 * per_cu ? nsteps : 256 * per_cu;
+    hipLaunchKernelGGL((dwpw_rr<H, W, C, S, N, G, NTHR, (DB != 0), CG, CY, ORD, ROWPAD, TS, WPE, MG, XR4>), dim3(grid), dim3(NTHR),
+                       lds, s, in, out, a, batch);
+}
+const char *dwpw_rr_name(int H, int W, int C, int S, int N) {
+#define MF_DWRR(h, w, c, s, n, g, t, d, cg, cy, ord, rp, ts, wpe) \
+    if (H == h && W == w && C == c && S == s && N == n) return "dwpw_rr<" #h "," #w "," #c "," #s "," #n "," #g "," #t "," #d ">";
+    MF_DWRR_SHAPES(MF_DWRR)
+#undef MF_DWRR
+    return nullptr;
+}
+bool launch_dwpw_rr(int H, int W, int C, int S, int N, const int8_t *in, int8_t *out, const DwPwArgs &a, int batch,
+                    hipStream_t s) {
+    if (!a.dw.wmm || !a.pw.wrr) return false;
+    static const int alt = [] { const char *e = getenv("MF_DWRR_ALT"); return e ? atoi(e) : -1; }();
+    if (alt >= 0) { // tuning candidates, see MF_DWRR_ALT_SHAPES
+        int idx = 0;
+        (void)idx;
+#define MF_DWRR(h, w, c, st, n, g, t, d, cg, cy, ord, rp, ts, wpe)                                                   \
+    if (idx++ == alt && H == h && W == w && C == c && S == st && N == n) {                                           \
+        MF_DISPATCH4(a.dw.magic && a.pw.magic, a.pw.xr, launch_dwpw_rr_t, (in, out, a, batch, s), h, w, c, st, n, g, t, d, \
+                     cg, cy, ord, rp, ts, wpe)                                                                       \
+        return true;                                                                                                 \
+    }
+        MF_DWRR_ALT_SHAPES(MF_DWRR)
+#undef MF_DWRR
+    }
+#define MF_DWRR(h, w, c, st, n, g, t, d, cg, cy, ord, rp, ts, wpe)                                                   \
+    if (H == h && W == w && C == c && S == st && N == n) {                                                           \
+        MF_DISPATCH4(a.dw.magic && a.pw.magic, a.pw.xr, launch_dwpw_rr_t, (in, out, a, batch, s), h, w, c, st, n, g, t, d, \
+                     cg, cy, ord, rp, ts, wpe)                                                                       \
+        return true;                                                                                                 \
+    }
+    MF_DWRR_SHAPES(MF_DWRR)
+#undef MF_DWRR
     return false;
 }
 

@@ -105,6 +105,7 @@ struct DwStemArgs {
 struct DwPwArgs;
 struct PwArgs {
     const void *wprep;  // [blk][q][tile][kstep][lane] x 16 bytes, MFMA operand-A layout
+    const void *wrr;    // register-resident pairs (dwpw_rr): [16-row tile][lane] x 8 bytes, or nullptr
     const float *A;
     const float *S;
     const int *Kc;
@@ -200,6 +201,25 @@ struct TailArgs {
 // tuning candidates (MF_DWMM_ALT=<i>), empty in the product build
 #define MF_DWMM_ALT_SHAPES(X)
 
+// Pairs with C <= 32 whose intermediate tensor stays in registers (dwpw_rr, k_fused_mm.hip); same columns.
+#define MF_DWRR_SHAPES(X)                                   \
+    X(48, 48, 8, 1, 16, 1, 512, 1, 1, 4, 0, 32, 0x000, 4)   \
+    X(48, 48, 16, 2, 32, 1, 768, 1, 1, 2, 0, 32, 0x000, 3)  \
+    X(24, 24, 32, 1, 32, 1, 256, 1, 1, 2, 0, 0, 0x002, 3)   \
+    X(24, 24, 32, 2, 64, 1, 192, 1, 1, 4, 0, 32, 0x002, 2)
+#define MF_DWRR_ALT_SHAPES(X)                               \
+    X(48, 48, 8, 1, 16, 1, 256, 1, 1, 4, 0, 32, 0x000, 3)   \
+    X(48, 48, 8, 1, 16, 1, 512, 0, 1, 4, 0, 32, 0x000, 4)   \
+    X(48, 48, 8, 1, 16, 1, 256, 0, 1, 4, 0, 32, 0x000, 4)   \
+    X(48, 48, 16, 2, 32, 1, 256, 1, 1, 2, 0, 32, 0x000, 2)  \
+    X(48, 48, 16, 2, 32, 1, 768, 0, 1, 2, 0, 32, 0x000, 4)  \
+    X(48, 48, 16, 2, 32, 1, 256, 0, 1, 2, 0, 32, 0x000, 3)  \
+    X(24, 24, 32, 1, 32, 1, 768, 1, 1, 2, 0, 0, 0x002, 4)   \
+    X(24, 24, 32, 1, 32, 1, 256, 0, 1, 2, 0, 0, 0x002, 4)   \
+    X(24, 24, 32, 1, 32, 2, 512, 0, 1, 2, 0, 0, 0x002, 4)   \
+    X(24, 24, 32, 2, 64, 1, 192, 0, 1, 4, 0, 32, 0x002, 3)  \
+    X(24, 24, 32, 2, 64, 2, 384, 0, 1, 4, 0, 32, 0x002, 3)
+
 // (K = input channels, N = output channels) with a compiled pointwise MFMA kernel
 #define MF_PW_SHAPES(X) \
     X(8, 16)            \
@@ -243,6 +263,9 @@ bool launch_dwpw(int H, int W, int C, int S, int N, const int8_t *in, int8_t *ou
                  int batch, hipStream_t s);
 const char *dwpw_mm_name(int H, int W, int C, int S, int N);
 bool launch_dwpw_mm(int H, int W, int C, int S, int N, const int8_t *in, int8_t *out, const DwPwArgs &a,
+                    int batch, hipStream_t s);
+const char *dwpw_rr_name(int H, int W, int C, int S, int N);
+bool launch_dwpw_rr(int H, int W, int C, int S, int N, const int8_t *in, int8_t *out, const DwPwArgs &a,
                     int batch, hipStream_t s);
 bool tail_supported(int C, int N, int ntaps);
 void launch_tail(const int8_t *in, int8_t *out, const TailArgs &a, size_t batch, hipStream_t s);

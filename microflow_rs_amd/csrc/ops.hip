@@ -91,7 +91,7 @@ struct OpImpl {
     int8_t *d_ext = nullptr; // op_run_external on a u8 operator: input moved to the i8 domain
     size_t ext_cap = 0;
 
-    DevBuf d_w, d_wzp, d_A, d_S, d_Kc, d_wprep, d_table;
+    DevBuf d_w, d_wzp, d_A, d_S, d_Kc, d_wprep, d_wrr, d_table;
     k::DwC1Args dwc1{};
     k::ConvArgs conv{};
     k::PoolArgs pool{};
@@ -205,6 +205,38 @@ std::vector<int8_t> build_dw_mm_weights(const int8_t *w /*[3][3][C]*/, int C) {
                     dst[r] = w[(ty * 3 + g) * C + 16 * q + r];
                 }
             }
+    return out;
+}
+
+// Pointwise weights [N][K] as operands A of v_mfma_i32_16x16x32_i8 for dwpw_rr (k_fused_mm.hip), whose B operand
+// is the depthwise result as it sits in registers: [16-row tile m][lane][8 bytes].  Lane (r = lane & 15,
+// g = lane >> 4) holds K-bytes 8g .. 8g+7 of MFMA row r.
+//   rows : row 4g' + i of tile m is output channel (N/4) g' + 4m + i, so that lane g' of the result owns N/4
+//          consecutive output bytes.  K = 8: rows are (pixel parity g' >> 1, channel 8 (g' & 1) + 4m + i).
+//   K    : byte b < 4 is input channel 4g + b (K = 8: channel 4 (g & 1) + b of the pixel with parity g >> 1, used
+//          only by the rows of that pixel); byte b >= 4 is channel 16 + 4g + b - 4 when K = 32, else unused.
+std::vector<int8_t> build_pw_rr_weights(const int8_t *w /*[N][K]*/, int K, int N) {
+    const bool pair = K == 8;
+    const int NT = (pair ? 2 * N : N) / 16;
+    std::vector<int8_t> out((size_t)NT * 64 * 8, 0);
+    for (int m = 0; m < NT; ++m)
+        for (int lane = 0; lane < 64; ++lane) {
+            const int r = lane & 15, g = lane >> 4;
+            const int gr = r >> 2, i = r & 3;
+            const int n = pair ? 8 * (gr & 1) + 4 * m + i : (N / 4) * gr + 4 * m + i;
+            int8_t *dst = &out[((size_t)m * 64 + lane) * 8];
+            for (int b = 0; b < 8; ++b) {
+                int k = -1;
+                if (pair) {
+                    if (b < 4 && (g >> 1) == (gr >> 1)) k = 4 * (g & 1) + b;
+                } else if (b < 4) {
+                    k = 4 * g + b;
+                } else if (K == 32) {
+                    k = 16 + 4 * g + (b - 4);
+                }
+                dst[b] = k >= 0 ? w[(size_t)n * K + k] : (int8_t)0;
+            }
+        }
     return out;
 }
 
@@ -333,6 +365,12 @@ OpImpl *op_create(int device, const OpSpec &spec) {
             k::PwArgs &f = op->pw;
             f.wprep = op->d_wprep.p, f.A = a.A, f.S = a.S, f.Kc = a.Kc;
             f.lo_f = a.lo_f, f.hi_f = a.hi_f, f.magic = magic, f.xr = xr;
+            f.wrr = nullptr;
+            if ((s.C == 8 || s.C == 16 || s.C == 32) && (s.C == 8 ? 2 * s.N : s.N) % 16 == 0) {
+                const std::vector<int8_t> rr = build_pw_rr_weights(s.weights, s.C, s.N);
+                op->d_wrr.upload(rr.data(), rr.size());
+                f.wrr = op->d_wrr.p;
+            }
         }
         if (getenv("MF_VERBOSE"))
             fprintf(stderr, "[microflow_amd] %s %dx%dx%d -> %d: kernel %s, worst-case |acc| %lld%s\n",

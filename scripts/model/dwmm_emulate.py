@@ -255,7 +255,180 @@ def emulate(shape, seed=0):
     return dict(units_per_wave=QW * NUG * NUY * NUX, lds=lds_bytes, wg_per_cu=163840 // lds_bytes)
 
 
+def rr_shapes_from_header():
+    txt = open(os.path.join(ROOT, "microflow_rs_amd", "csrc", "kernels.hpp")).read()
+    out = []
+    for name in ("#define MF_DWRR_SHAPES(X)", "#define MF_DWRR_ALT_SHAPES(X)"):
+        blk = txt[txt.index(name) + len(name):]
+        lines = []
+        for l in blk.split("\n"):
+            lines.append(l)
+            if not l.rstrip().endswith("\\"):
+                break
+        for m in re.finditer(r"X\(([^)]*)\)", "\n".join(lines)):
+            out.append(tuple(int(v, 0) for v in m.group(1).split(",")))
+    return out
+
+
+def build_pw_rr_weights(w, K, N):
+    """w [N][K] int8 -> [NT][64][8]   (ops.hip: build_pw_rr_weights)"""
+    pair = K == 8
+    NT = (2 * N if pair else N) // 16
+    out = np.zeros((NT, 64, 8), np.int8)
+    for m in range(NT):
+        for lane in range(64):
+            r, g = lane & 15, lane >> 4
+            gr, i = r >> 2, r & 3
+            n = 8 * (gr & 1) + 4 * m + i if pair else (N // 4) * gr + 4 * m + i
+            for b in range(8):
+                k = -1
+                if pair:
+                    if b < 4 and (g >> 1) == (gr >> 1):
+                        k = 4 * (g & 1) + b
+                elif b < 4:
+                    k = 4 * g + b
+                elif K == 32:
+                    k = 16 + 4 * g + (b - 4)
+                if k >= 0:
+                    out[m, lane, b] = w[n, k]
+    return out
+
+
+def mfma_16x16x32(A, B, acc):
+    Am = np.zeros((16, 32), np.int64)
+    Bm = np.zeros((32, 16), np.int64)
+    for l in range(64):
+        Am[l & 15, 8 * (l >> 4):8 * (l >> 4) + 8] = A[l]
+        Bm[8 * (l >> 4):8 * (l >> 4) + 8, l & 15] = B[l]
+    D = Am @ Bm
+    out = acc.copy()
+    for l in range(64):
+        for i in range(4):
+            out[l, i] += D[4 * (l >> 4) + i, l & 15]
+    return out
+
+
+def fake_requant(acc):
+    """any deterministic int32 -> int8 map will do for checking the data flow"""
+    return np.clip(acc >> 6, -128, 127).astype(np.int8)
+
+
+def emulate_rr(shape, seed=1):
+    H, W, C, S, N, G, NTHR, DB, CG, CY, ORD, ROWPAD, TS = shape[:13]
+    rng = np.random.default_rng(seed)
+    PAIR = C == 8
+    OH, OW = (H + S - 1) // S, (W + S - 1) // S
+    OWC = OW // 2 if PAIR else OW
+    NQ = 1 if PAIR else C // 16
+    CX = 16 // (CG * CY)
+    UG, UY, UX = G // CG, OH // CY, OWC // CX
+    assert CG * CY * CX == 16 and G % CG == 0 and OH % CY == 0 and OWC % CX == 0
+    LP = 16 if C < 16 else C
+    ROWB = W * C
+    ROW = LP + ROWB + LP + ROWPAD
+    TILE = (H + 2) * ROW
+    BUF = G * TILE
+    ROWCH = ROWB // 16
+    NWAVE = NTHR // 64
+    OPIX = OH * OW
+    PSY = cgcd(UY, NWAVE)
+    PSX = cgcd(UX, NWAVE // PSY)
+    PSG = cgcd(UG, NWAVE // PSY // PSX)
+    assert PSY * PSX * PSG == NWAVE, "unit grid does not divide over the waves"
+    NUG, NUY, NUX = UG // PSG, UY // PSY, UX // PSX
+    NU = NUG * NUY * NUX
+    T_UG, T_UY, T_UX = CG * TILE, CY * S * ROW, (CX * 16 if PAIR else CX * S * C)
+    O_UG, O_UY, O_UX = CG * OPIX * N, CY * OW * N, (2 if PAIR else 1) * CX * N
+    NT = (2 * N if PAIR else N) // 16
+    LB = 4 * NT
+    assert LB in (8, 16)
+    izp = 5
+    x = rng.integers(-128, 128, (G, H, W, C), dtype=np.int8)
+    w = rng.integers(-128, 128, (3, 3, C), dtype=np.int8)
+    wp = rng.integers(-128, 128, (N, C), dtype=np.int8)
+    Kc = rng.integers(-1000, 1000, C).astype(np.int64)
+    Kp = rng.integers(-1000, 1000, N).astype(np.int64)
+    wmm = build_dw_mm_weights(w, C)
+    wrr = build_pw_rr_weights(wp, C, N)
+    lds = np.full(BUF + 1024, izp, np.int8)
+    for gi in range(G):
+        for y in range(H):
+            row = x[gi, y].reshape(-1)
+            for lane in range(ROWCH):
+                src_lane = lane ^ tile_swz(TS, lane // NQ) if NQ > 1 else lane
+                dst = gi * TILE + (y + 1) * ROW + LP + lane * 16
+                lds[dst:dst + 16] = row[src_lane * 16:src_lane * 16 + 16]
+    out_acc = np.full((G * OPIX * N,), np.iinfo(np.int64).min, np.int64)
+    for wave in range(NWAVE):
+        wpy, wpx, wpg = wave % PSY, (wave // PSY) % PSX, wave // (PSY * PSX)
+        wave_t = wpg * T_UG + wpy * T_UY + wpx * T_UX
+        tbase = np.zeros((NQ, 64), np.int64)
+        obase = np.zeros(64, np.int64)
+        n0s = np.zeros(64, np.int64)
+        for lane in range(64):
+            col, g = lane & 15, lane >> 4
+            D0 = CG if ORD in (0, 1) else CY if ORD in (2, 3) else CX
+            D1 = CG if ORD in (2, 4) else CY if ORD in (0, 5) else CX
+            i0, i1, i2 = col % D0, (col // D0) % D1, col // (D0 * D1)
+            cg = i0 if ORD in (0, 1) else i1 if ORD in (2, 4) else i2
+            cy = i0 if ORD in (2, 3) else i1 if ORD in (0, 5) else i2
+            cx = i0 if ORD in (4, 5) else i1 if ORD in (1, 3) else i2
+            if PAIR:
+                tbase[0, lane] = cg * TILE + cy * ROW + LP + (2 * cx - 2) * 8 + g * 16 + wave_t
+            else:
+                xl = cx * S + g - 1
+                for q in range(NQ):
+                    tbase[q, lane] = cg * TILE + cy * S * ROW + LP + xl * C + 16 * (q ^ tile_swz(TS, xl)) + wave_t
+            opar = (g >> 1) if PAIR else 0
+            n0 = 8 * (g & 1) if PAIR else (N // 4) * g
+            n0s[lane] = n0
+            obase[lane] = ((cg * OPIX + cy * OW + (2 * cx + opar if PAIR else cx)) * N + n0 +
+                           wpg * O_UG + wpy * O_UY + wpx * O_UX)
+        for iu in range(NU):
+            ug, uy, ux = (iu // (NUY * NUX)) * PSG, ((iu // NUX) % NUY) * PSY, (iu % NUX) * PSX
+            toff = ug * T_UG + uy * T_UY + ux * T_UX
+            d = np.zeros((64, 8), np.int8)
+            for q in range(NQ):
+                acc = np.zeros((64, 4), np.int64)
+                for lane in range(64):
+                    g = lane >> 4
+                    ch4 = (g & 1) if PAIR else 4 * q + g
+                    acc[lane] = Kc[4 * ch4:4 * ch4 + 4]
+                for ty in range(3):
+                    B = np.zeros((64, 16), np.int8)
+                    for lane in range(64):
+                        a = tbase[q, lane] + toff + ty * ROW
+                        assert a % 16 == 0 and a >= 0
+                        B[lane] = lds[a:a + 16]
+                    acc = mfma_16x16x64(wmm[q, ty], B, acc)
+                d[:, 4 * q:4 * q + 4] = fake_requant(acc)
+            ooff = ug * O_UG + uy * O_UY + ux * O_UX
+            for m in range(NT):
+                pa = np.zeros((64, 4), np.int64)
+                for lane in range(64):
+                    pa[lane] = Kp[n0s[lane] + 4 * m:n0s[lane] + 4 * m + 4]
+                pa = mfma_16x16x32(wrr[m], d, pa)
+                for lane in range(64):
+                    a = int(obase[lane] + ooff + 4 * m)
+                    assert np.all(out_acc[a:a + 4] == np.iinfo(np.int64).min), "output written twice"
+                    out_acc[a:a + 4] = pa[lane]
+    # reference
+    xp = np.full((G, H + 2, W + 2, C), izp, np.int64)
+    xp[:, 1:H + 1, 1:W + 1] = x
+    ref = np.zeros((G, OH, OW, C), np.int64)
+    for ty in range(3):
+        for tx in range(3):
+            ref += xp[:, ty:ty + S * OH:S, tx:tx + S * OW:S] * w[ty, tx].astype(np.int64)
+    mid = fake_requant(ref + Kc).astype(np.int64)
+    want = (mid.reshape(-1, C) @ wp.astype(np.int64).T + Kp).reshape(-1)
+    assert np.array_equal(out_acc, want), (shape, np.flatnonzero(out_acc != want)[:10])
+    lds_bytes = (2 if DB else 1) * BUF + 512
+    return dict(units_per_wave=NU, lds=lds_bytes, wg_per_cu=163840 // lds_bytes)
+
+
 if __name__ == "__main__":
+    for shp in rr_shapes_from_header():
+        print("ok rr", shp, emulate_rr(shp))
     for shp in shapes_from_header():
         r = emulate(shp)
         print("ok", shp, r)

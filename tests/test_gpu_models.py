@@ -166,7 +166,11 @@ def test_kernel_routing(models):
     m.prepare(1)
     names = [m.op(i)["kernel"] for i in range(m.num_ops)]
     assert names[0].startswith("dw3x3_stem8")
-    assert sum(n.startswith("dwpw3x3") for n in names) == 13          # fused depthwise + 1x1 conv pairs
+    # fused depthwise + 1x1 conv pairs: dwpw_rr / dwpw_mm (taps on the matrix pipe) or, with
+    # MF_DWPW_IMPL=valu, r01's dwpw3x3
+    assert sum(n.startswith(("dwpw_rr", "dwpw_mm", "dwpw3x3")) for n in names) == 13
+    if not os.environ.get("MF_DWPW_IMPL"):
+        assert sum(n.startswith("dwpw_rr") for n in names) == 4 and sum(n.startswith("dwpw_mm") for n in names) == 9
     assert sum(n.startswith("(fused") for n in names) == 13 + 2
     assert names[27] == "tail_pool_head_softmax<2>"                   # pool + head conv + softmax
     assert names[28].startswith("(fused") and names[29] == "" and names[30].startswith("(fused")
