@@ -1,29 +1,31 @@
 #!/usr/bin/env python3
 """bench.py -- throughput of the quantized-operator hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload person_detect|speech]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+        N > 1 launches N ranks itself (torch.distributed.run, one rank per GPU over RCCL); the same
+        file also runs under an external launcher (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the env).
+    python bench.py --workload speech|fc4096        # one of the other BASELINE configs as the headline
 
-Workload (BASELINE.json): person_detect.tflite, int8, 65536 independent inferences per
-GPU (configs[2]; configs[3] = the same shard on each of 8 GPUs, i.e. weak scaling).
-One "step" = one pass of predict_inner (all 29 kernels: 14 DepthwiseConv2D, 14 Conv2D,
-AveragePool2D, Softmax) over the GPU's batch, int8 in -> int8 out, with the synthetic
-input batch already resident in HBM when the timed region starts.
-
-The JSON line carries, beside the driver's contract fields:
-  roofline     : the dominant kernel (largest share of the step) -- achieved algorithmic
-                 GB/s from HIP-event timing on the launch stream vs the 8 TB/s HBM peak
-  kernels      : the same figure for every operator of the step
-  depthwise    : the 14 DepthwiseConv2D kernels aggregated (the north-star target)
-  cpu_baseline : the reference-faithful C restatement (oracle/, "port") timed on this
-                 box's host cores over a bounded sample of the same input stream
+Workload (BASELINE.json): person_detect.tflite, int8, 65536 independent inferences per GPU (configs[2];
+configs[3] = the same shard on each of 8 GPUs: weak scaling, no data-path collective).  One "step" = one
+pass of predict_inner (31 operators: 14 DepthwiseConv2D, 14 Conv2D, AveragePool2D, Reshape, Softmax) over
+the GPU's batch, int8 in -> int8 out, with the synthetic input batch resident in HBM when the timed region
+starts.  `value` follows the driver's contract: W untimed steps, then exactly K steps between two
+barrier + synchronize fences, wall clock, max over ranks.  Beside it the line carries
+  event_median : the same step timed per iteration with HIP events on the launch stream, median
+  roofline     : the dominant kernel -- algorithmic bytes / its median HIP-event duration vs the 8 TB/s HBM peak
+  kernels      : the same figure for every launch of the step; layerwise: with the fusions switched off
+  cpu_baseline : the reference-faithful C restatement (oracle/, "port", gcc -O3) on this box's host cores
   parity       : sampled bit-exact comparison of the GPU outputs with that oracle
+  speech       : BASELINE config 2 (speech.tflite, batch 4096) -- VALU-bound, priced against the v_dot4 rate
+  fc4096       : BASELINE config 5 (FullyConnected 4096^3 through predict_inner) -- int8 MFMA roofline, with
+                 weight zero point 0 and != 0
 """
 import argparse
-import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -40,7 +42,55 @@ WORKLOADS = {
     # BASELINE config 5: generated single-op FullyConnected model, one [4096,4096] input per step
     "fc4096": (None, 5, 1),
 }
-INT8_MFMA_PEAK_TOPS = 5033.0  # dense int8 = 2x the ~2.5 PF dense bf16 MFMA peak (MI355X_MICROARCH.md)
+# int8 MFMA peaks (TOP/s, dense).  The guide gives no spec figure for int8: "I8 >= 3944 TOPS (16x16x64,
+# ~2x the bf16 rate)" is its measured floor; 5033 = 2 x the ~2.5 PF dense bf16 peak is the nominal figure.
+INT8_MFMA_PEAK_NOMINAL = 5033.0
+INT8_MFMA_PEAK_GUIDE_FLOOR = 3944.0
+# v_dot4_i32_i8 issue rate measured on this chip (scripts/ubench/inst_rates.hip): 0.55 T wave-inst/s
+# x 64 lanes x 4 MAC = 140.8 TMAC/s -- the ceiling of a dot4-bound kernel (speech's depthwise)
+DOT4_PEAK_TMACS = 140.8
+PARITY_NOTE = ("bit-exact vs the restated CPU oracle (oracle/mf_oracle.c, pinned to every reference KAT; "
+               "softmax's expf is pinned at the reference's 9 points only)")
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without an external launcher: one rank per GPU under
+    torch.distributed.run, rendezvous on 127.0.0.1."""
+    import torch
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < args.gpus:
+        raise SystemExit("bench.py --gpus %d: only %d GPU device(s) visible on this box" % (args.gpus, have))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def median(xs):
+    xs = sorted(xs)
+    n = len(xs)
+    return xs[n // 2] if n % 2 else 0.5 * (xs[n // 2 - 1] + xs[n // 2])
+
+
+def event_times(torch, step, iters):
+    """per-iteration durations (ms) of `step` from HIP event pairs on the current (= launch) stream"""
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    for a, b in evs:
+        a.record()
+        step()
+        b.record()
+    torch.cuda.synchronize()
+    return [a.elapsed_time(b) for a, b in evs]
 
 
 def main():
@@ -51,9 +101,13 @@ def main():
     ap.add_argument("--workload", default="person_detect", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the BASELINE size)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-host-fed", action="store_true", help="skip the PCIe-inclusive (host-fed) leg")
+    ap.add_argument("--no-host-fed", action="store_true", help="skip the PCIe-inclusive and f32 legs")
+    ap.add_argument("--no-extra", action="store_true", help="skip the speech / fc4096 sub-records")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
 
     import torch
     import torch.distributed as dist
@@ -61,12 +115,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("launch with torch.distributed.run for --gpus > 1")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit("bench.py: rank %d has no GPU (only %d device(s) visible)" % (rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -79,10 +133,14 @@ def main():
     from microflow_rs_amd.shard import gather_checksums, max_over_ranks, shard_range
     from tests.synth import SEED
 
+    ctx = dict(args=args, mf=mf, _lib=_lib, torch=torch, dist=dist, world=world, rank=rank, local_rank=local_rank,
+               synth_i8=synth_i8, checksum_i8=checksum_i8, SEED=SEED)
     fname, cfg, base_batch = WORKLOADS[args.workload]
     B = args.batch or base_batch
     if args.workload == "fc4096":
-        return bench_fc4096(args, mf, _lib, torch, world, rank, local_rank)
+        result = headline_from_sub(args, fc4096_record(ctx, args.steps, args.warmup, wzp=0), world)
+        finish(ctx, result)
+        return
     m = mf.model(os.path.join(ROOT, "models", fname))
     m.prepare(B, device=local_rank)
     L = _lib.lib()
@@ -115,15 +173,22 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = B * world / (elapsed / args.steps)
 
+    # the same step, one HIP event pair per iteration on the launch stream: median
+    ev = event_times(torch, step, max(20, args.steps))
+    ev_med = median(ev)
+    if world > 1:
+        ev_med = max_over_ranks(dist, ev_med, device="cuda")
+
     # output checksums of every shard (outside the timed region; RCCL all_gather of 8 bytes)
     ck = checksum_i8(y)
     cks = [ck]
     if world > 1:
         cks = gather_checksums(dist, ck, device="cuda")
+        dist.barrier()
 
     result = None
     if rank == 0:
-        # ---- per-kernel HIP-event timing on the launch stream ----
+        # ---- per-kernel HIP-event timing on the launch stream (median over the iterations) ----
         iters = max(5, min(args.steps, 20))
 
         def kernel_table():
@@ -176,9 +241,12 @@ def main():
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["frac"], "traffic": traffic,
                     "traffic_source": traffic_src,
                     "ms": dom["ms"], "algorithmic_bytes": dom["bytes"],
-                    "method": "HIP events on the launch stream, avg of %d launches" % iters}
+                    "method": "HIP events on the launch stream, median of %d launches" % iters}
+        step_bytes = sum(k["bytes"] for k in kernels)
+        whole_step = {"algorithmic_bytes": step_bytes, "GBps": round(step_bytes / (ev_med * 1e-3) / 1e9, 1),
+                      "frac": round(step_bytes / (ev_med * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
 
-        # the same step with the DW+PW fusion switched off: one kernel per reference operator
+        # the same step with the fusions switched off: one kernel per reference operator
         # (the layer-wise DepthwiseConv2D / Conv2D roofline figures of BASELINE.json's targets)
         m.set_fusion(False)
         lw_ms, lw_kernels = kernel_table()
@@ -195,14 +263,14 @@ def main():
         parity_ok = bool(np.array_equal(ys, om.run_quantized_batch(xs)))
 
         cpu = cpu_mt = None
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline:
             cpu = cpu_baseline(om, x.reshape(count, -1), args.cpu_seconds)
             cpu_mt = cpu_baseline_all_cores(om, x.reshape(count, -1))
 
         # ---- PCIe-inclusive rate (never `value`): the same batch fed from pinned host memory,
         # H2D of the inputs and D2H of the outputs inside the timed region (MF_MEM_HOST) ----
         host_fed = None
-        if world == 1 and not args.no_host_fed:
+        if not args.no_host_fed:
             xh = torch.empty(x.shape, dtype=torch.int8).pin_memory()
             xh.copy_(x)
             yh = torch.empty(y.shape, dtype=torch.int8).pin_memory()
@@ -218,10 +286,11 @@ def main():
                         "bit_exact_vs_device_path": bool(torch.equal(yh, y.cpu())),
                         "note": "pinned host buffers through mf_model_run_quantized(MF_MEM_HOST): the batch "
                                 "is cut into ~64 MB chunks whose H2D copies overlap the previous chunk's compute"}
+            del xh, yh
 
         # ---- the f32 entry point (M::predict): quantize -> ops -> dequantize, device-resident ----
         predict_f32 = None
-        if world == 1 and not args.no_host_fed:
+        if not args.no_host_fed:
             xf = (x.reshape(count, -1).float() - float(m.input_zero_point)) * float(m.input_scale)
             yf = torch.empty((count, m.output_elems), dtype=torch.float32, device="cuda")
             run_f = lambda: _lib.check(L.mf_model_predict(  # noqa: E731
@@ -249,6 +318,10 @@ def main():
                                    % (fname, B), "per_gpu_batch": B, "global_batch": B * world,
                        "parallelism": "batch shard x%d, no data-path collective" % world},
             "roofline": roofline,
+            "event_median": {"ms_per_step": round(ev_med, 4), "value": round(B * world / (ev_med * 1e-3), 1),
+                             "iterations": len(ev), "min_ms": round(min(ev), 4), "max_ms": round(max(ev), 4),
+                             "note": "HIP event pair per step on the launch stream, median; max over ranks"},
+            "whole_step": whole_step,
             "fused_dwpw": agg(kernels, "depthwise_conv_2d+conv_2d"),
             "depthwise": layerwise["depthwise"], "conv_2d": layerwise["conv_2d"],
             "event_ms_per_step": round(avg_ms, 4),
@@ -258,70 +331,144 @@ def main():
             "cpu_baseline_all_cores": cpu_mt,
             "host_fed": host_fed,
             "predict_f32": predict_f32,
-            "parity": {"bit_exact_vs_oracle": parity_ok, "sampled_images": len(idx),
+            "parity": {"bit_exact_vs_oracle": parity_ok, "what": PARITY_NOTE, "sampled_images": len(idx),
                        "output_checksums": ["%016x" % c for c in cks]},
         }
+        x = y = m = None
+        torch.cuda.empty_cache()
+        if args.workload == "person_detect" and not args.no_extra:
+            # the other single-GPU BASELINE configs, driver-visible in the same line
+            result["speech"] = speech_record(ctx)
+            result["fc4096"] = fc4096_record(ctx, 10, 2, wzp=0)
+            result["fc4096_wzp"] = fc4096_record(ctx, 10, 2, wzp=-3)
         if not parity_ok:
             result["value"] = 0.0
             result["error"] = "GPU outputs differ from the CPU oracle: number withheld"
+    finish(ctx, result)
+
+
+def finish(ctx, result):
+    dist, world, rank = ctx["dist"], ctx["world"], ctx["rank"]
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(result))
-        if not result["parity"]["bit_exact_vs_oracle"]:
+        ok = result.get("parity", {}).get("bit_exact_vs_oracle", False)
+        for sub in ("speech", "fc4096", "fc4096_wzp"):
+            if sub in result and not result[sub]["parity"]["bit_exact_vs_oracle"]:
+                ok = False
+        if not ok:
             sys.exit(1)
 
 
-def bench_fc4096(args, mf, _lib, torch, world, rank, local_rank):
-    """FullyConnected 4096x4096x4096 through the model API: one step = one predict_inner over a
-    [4096, 4096] int8 input (one dense int8 GEMM + fused requantize epilogue)."""
+def headline_from_sub(args, rec, world):
+    """--workload fc4096: promote the sub-record to a headline-shaped line"""
+    out = {"metric": rec["metric"], "value": rec["value"], "unit": rec["unit"], "n_gpus": world, "steps": rec["steps"],
+           "warmup": rec["warmup"], "ms_per_step": rec["ms_per_step"], "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "i8", "data": "synthetic", "config": rec["config"]}
+    out.update({k: v for k, v in rec.items() if k not in out})
+    return out
+
+
+def speech_record(ctx):
+    """BASELINE config 2: speech.tflite (TinyConv), batch 4096, device-resident int8 -> int8."""
+    mf, _lib, torch, synth_i8, SEED = ctx["mf"], ctx["_lib"], ctx["torch"], ctx["synth_i8"], ctx["SEED"]
+    from oracle import oracle as O
+    path = os.path.join(ROOT, "models", "speech.tflite")
+    B = 4096
+    m = mf.model(path)
+    m.prepare(B, device=ctx["local_rank"])
+    L = _lib.lib()
+    _lib.check(L.mf_model_set_stream(m._h, torch.cuda.current_stream().cuda_stream))
+    x = synth_i8(SEED + 2, 0, B * m.input_elems)
+    y = torch.empty(B * m.output_elems, dtype=torch.int8, device="cuda")
+    step = lambda: _lib.check(L.mf_model_run_quantized(m._h, x.data_ptr(), B, y.data_ptr(), _lib.MF_MEM_DEVICE))  # noqa: E731
+    for _ in range(5):
+        step()
+    torch.cuda.synchronize()
+    ev = event_times(torch, step, 50)
+    ms = median(ev)
+    _, per_op = m.time_device(x, y, B, warmup=2, iters=20)
+    descs = [m.op(i) for i in range(m.num_ops)]
+    kernels = [{"op": i, "kernel": d["kernel"], "ms": round(per_op[i], 5)} for i, d in enumerate(descs)
+               if d["kernel"] and not d["kernel"].startswith("(fused")]
+    # the depthwise conv is 320 000 MAC / inference (10 x 8 taps x 25 x 20 x 8); the FullyConnected 16 000
+    dw = next((k for k in kernels if k["kernel"].startswith(("dw_c1", "speech"))), kernels[0])
+    macs = 320000.0 * B + (16000.0 * B if dw["kernel"].startswith("speech") else 0.0)
+    tmacs = macs / (dw["ms"] * 1e-3) / 1e12 if dw["ms"] > 0 else 0.0
+    nbytes = (m.input_elems + m.output_elems) * B  # model input + output: the fully fused lower bound
+    om = O.Model(path)
+    idx = list(range(0, B, 257))
+    ok = bool(np.array_equal(y.reshape(B, -1)[idx].cpu().numpy(), om.run_quantized_batch(x.reshape(B, -1)[idx].cpu().numpy())))
+    return {"metric": "inferences/sec (int8) for speech.tflite", "value": round(B / (ms * 1e-3), 1), "unit": "inferences/s",
+            "ms_per_step": round(ms, 5), "config": {"workload": "speech.tflite batch=%d, predict_inner int8->int8" % B},
+            "kernels": kernels,
+            "roofline": {"bound": "valu", "kernel": dw["kernel"], "achieved": round(tmacs, 2), "peak": DOT4_PEAK_TMACS,
+                         "unit": "TMAC/s", "frac": round(tmacs / DOT4_PEAK_TMACS, 4), "ms": dw["ms"],
+                         "note": "54 MAC per input byte: bounded by the v_dot4_i32_i8 issue rate (measured, "
+                                 "scripts/ubench), not by HBM",
+                         "hbm_GBps": round(nbytes / (ms * 1e-3) / 1e9, 1), "hbm_frac": round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+            "timing": "HIP events on the launch stream, median of %d steps" % len(ev),
+            "parity": {"bit_exact_vs_oracle": ok, "sampled_images": len(idx)}}
+
+
+def fc4096_record(ctx, steps, warmup, wzp=0):
+    """BASELINE config 5: FullyConnected 4096x4096x4096 through the model API: one step = one predict_inner
+    over a [4096, 4096] int8 input (one dense int8 GEMM + fused requantize epilogue; with a non-zero weight
+    zero point also the row-sum pre-pass of src/ops/fully_connected.rs:60-72)."""
+    mf, _lib, torch = ctx["mf"], ctx["_lib"], ctx["torch"]
     from tools.make_fc_model import synthetic_fc
     from oracle import oracle as O
     M = K = N = 4096
-    blob = synthetic_fc(M, K, N, wzp=0, seed=5)
+    blob = synthetic_fc(M, K, N, wzp=wzp, seed=5)
     m = mf.model(blob)
-    m.prepare(1, device=local_rank)
+    m.prepare(1, device=ctx["local_rank"])
     L = _lib.lib()
     _lib.check(L.mf_model_set_stream(m._h, torch.cuda.current_stream().cuda_stream))
-    g = torch.Generator(device="cuda").manual_seed(1234 + rank)
+    g = torch.Generator(device="cuda").manual_seed(1234 + ctx["rank"])
     x = torch.randint(-128, 128, (M, K), dtype=torch.int8, device="cuda", generator=g)  # random operands
     y = torch.empty(M * N, dtype=torch.int8, device="cuda")
-    for _ in range(args.warmup):
-        _lib.check(L.mf_model_run_quantized(m._h, x.data_ptr(), 1, y.data_ptr(), _lib.MF_MEM_DEVICE))
+    step = lambda: _lib.check(L.mf_model_run_quantized(m._h, x.data_ptr(), 1, y.data_ptr(), _lib.MF_MEM_DEVICE))  # noqa: E731
+    for _ in range(warmup):
+        step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        _lib.check(L.mf_model_run_quantized(m._h, x.data_ptr(), 1, y.data_ptr(), _lib.MF_MEM_DEVICE))
+    for _ in range(steps):
+        step()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    avg_ms, per_op = m.time_device(x, y, 1, warmup=1, iters=max(5, min(args.steps, 20)))
+    ev = event_times(torch, step, max(20, steps))
+    ms = median(ev)
     ops = 2.0 * M * K * N
-    tops = ops / (per_op[0] * 1e-3) / 1e12
-    rows = [0, 777, 4095]
-    om = O.Model(synthetic_fc(len(rows), K, N, wzp=0, seed=5))
+    tops = ops / (ms * 1e-3) / 1e12
+    rows = sorted(set([0, 777, 4095] + list(range(5, M, 131))))[:40]
+    om = O.Model(synthetic_fc(len(rows), K, N, wzp=wzp, seed=5))
     want = om.run_quantized(x[rows].cpu().numpy()).reshape(len(rows), N)
     ok = bool(np.array_equal(y.reshape(M, N)[rows].cpu().numpy(), want))
-    result = {
+    return {
         "metric": "int8 GEMM TOP/s, FullyConnected 4096x4096x4096 via predict_inner",
-        "value": round(ops / (elapsed / args.steps) / 1e12, 1), "unit": "TOP/s", "n_gpus": 1,
-        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "i8",
-        "data": "synthetic", "config": {"workload": "FullyConnected int8 M=K=N=4096 (generated single-op .tflite)"},
+        "value": round(ops / (elapsed / steps) / 1e12, 1), "unit": "TOP/s",
+        "steps": steps, "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 4),
+        "config": {"workload": "FullyConnected int8 M=K=N=4096 (generated single-op .tflite), weight zero point %d, "
+                               "uniform random int8 operands" % wzp},
         "roofline": {"bound": "mfma", "kernel": m.op(0)["kernel"], "achieved": round(tops, 1),
-                     "peak": INT8_MFMA_PEAK_TOPS, "unit": "TOP/s", "frac": round(tops / INT8_MFMA_PEAK_TOPS, 4),
-                     "traffic": None, "ms": round(per_op[0], 4), "algorithmic_ops": ops,
-                     "method": "HIP events on the launch stream"},
+                     "peak": INT8_MFMA_PEAK_NOMINAL, "unit": "TOP/s", "frac": round(tops / INT8_MFMA_PEAK_NOMINAL, 4),
+                     "peak_guide_floor": INT8_MFMA_PEAK_GUIDE_FLOOR,
+                     "frac_of_guide_floor": round(tops / INT8_MFMA_PEAK_GUIDE_FLOOR, 4),
+                     "traffic": None, "ms": round(ms, 4), "algorithmic_ops": ops,
+                     "method": "HIP events on the launch stream, median of %d steps (whole predict_inner: GEMM"
+                               "%s)" % (len(ev), " + row-sum pre-pass" if wzp else ""),
+                     "peak_note": "5033 = 2 x the ~2.5 PF dense bf16 MFMA peak (nominal); 3944 = the guide's measured "
+                                  "int8 floor (MI355X_MICROARCH.md)"},
         "parity": {"bit_exact_vs_oracle": ok, "sampled_rows": len(rows)},
     }
-    print(json.dumps(result))
-    if not ok:
-        sys.exit(1)
 
 
 def cpu_baseline(om, x_dev_rows, seconds):
     """Time the oracle (oracle/mf_oracle.c: scalar restatement of the reference algorithm,
-    gcc -O2, one thread) on this box's host over a bounded sample of the same stream."""
+    gcc -O3, one thread) on this box's host over a bounded sample of the same stream."""
+    from oracle import oracle as O
     probe = x_dev_rows[:8].cpu().numpy()
     t0 = time.perf_counter()
     om.run_quantized_batch(probe)
@@ -341,6 +488,7 @@ def cpu_baseline(om, x_dev_rows, seconds):
         pass
     return {"value": round(n / dt, 2), "unit": "inferences/s", "cores": 1, "kind": "port",
             "sample": "%d images of the same synthetic stream, 1 thread, %.1f s" % (n, dt),
+            "build": "gcc " + " ".join(O.CFLAGS),
             "host": {"cpu": cpu_model, "logical_cores": os.cpu_count()},
             "note": "C restatement of the reference algorithm (oracle/), not the Rust binary"}
 

@@ -78,7 +78,7 @@ int mf_preprocess_conv_2d(float input_scale, int n, const int32_t *bias, const f
     MF_TRY({
         MF_NEED(bias && bias_scale && bias_zero_point && filter_scale && c0 && c1 && n > 0 &&
                 nbq > 0 && nfq > 0);
-        mf::h_preprocess_conv(input_scale, n, bias, bias_scale, bias_zero_point, nbq, filter_scale,
+        mf::h_preprocess_conv(input_scale, n, bias, bias_scale, nbq, bias_zero_point, nbq, filter_scale,
                               nfq, output_scale, c0, c1);
     })
 }

@@ -135,13 +135,14 @@ void h_preprocess_fc(float iscale, int izp, int in_shape1, const int8_t *w, bool
 }
 
 // microflow-macros/src/ops/conv_2d.rs:100-113, depthwise_conv_2d.rs:106-119
-void h_preprocess_conv(float iscale, int n, const int32_t *bias, const float *bscale,
-                       const int32_t *bzp, int nbq, const float *fscale, int nfq, float oscale,
+void h_preprocess_conv(float iscale, int n, const int32_t *bias, const float *bscale, int nbs,
+                       const int32_t *bzp, int nbz, const float *fscale, int nfq, float oscale,
                        float *c0, float *c1) {
     for (int b = 0; b < n; ++b) {
-        const int q = b < nbq ? b : 0;
-        volatile float ratio = bscale[q] / oscale;
-        volatile float d = (float)wrap_sub(bias[b], bzp[q]);
+        // biases.scale.get(b).unwrap_or(scale[0]) and zero_point.get(b).unwrap_or(zp[0]): each array
+        // falls back on its own (conv_2d.rs:100-108)
+        volatile float ratio = bscale[b < nbs ? b : 0] / oscale;
+        volatile float d = (float)wrap_sub(bias[b], bzp[b < nbz ? b : 0]);
         c0[b] = ratio * d;
     }
     for (int b = 0; b < nfq; ++b) {

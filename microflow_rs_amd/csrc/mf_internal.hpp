@@ -36,8 +36,8 @@ int h_quantize_t(float x, float scale, int zp, bool u8); // either element type
 void h_preprocess_fc(float iscale, int izp, int in_shape1, const int8_t *w, bool u8, int K, int N,
                      float wscale, int wzp, const int32_t *bias, float bscale, int32_t bzp,
                      float oscale, float *c0, float *c1, int32_t *c2, int32_t *c3);
-void h_preprocess_conv(float iscale, int n, const int32_t *bias, const float *bscale,
-                       const int32_t *bzp, int nbq, const float *fscale, int nfq, float oscale,
+void h_preprocess_conv(float iscale, int n, const int32_t *bias, const float *bscale, int nbs,
+                       const int32_t *bzp, int nbz, const float *fscale, int nfq, float oscale,
                        float *c0, float *c1);
 void h_preprocess_pool(float iscale, int izp, float oscale, int ozp, float *c0, float *c1);
 

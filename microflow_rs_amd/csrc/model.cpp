@@ -138,15 +138,26 @@ void model_prepare(ModelImpl *m, int device, size_t max_batch) {
     dev_require(device);
     if (m->prepared && m->device != device)
         fail(MF_ERR_INVALID_ARG, "model already prepared on another device");
-    m->device = device;
     if (!m->prepared) {
+        // Everything is built in locals and committed only when all of it exists: a failure half way
+        // (a HIP error, OOM, a geometry the operator rejects) leaves the model unprepared and retryable,
+        // on this or another device.
+        struct Pending {
+            std::vector<OpImpl *> ops;
+            std::vector<FusedImpl *> fused;
+            ~Pending() {
+                for (FusedImpl *f : fused) fused_destroy(f);
+                for (OpImpl *o : ops) op_destroy(o);
+            }
+        } pend;
+        std::vector<OpImpl *> &ops = pend.ops;
         // predict_inner's running tensor: every op stamps its output scale / zero point on
         // it (Tensor::new(output, output_scale, output_zero_point)); Reshape keeps them.
         float cur_scale = m->pm.in_scale;
         int cur_zp = m->pm.in_zp;
         for (const ParsedOp &po : m->pm.ops) {
             if (po.kind == MF_OP_RESHAPE) {
-                m->ops.push_back(nullptr);
+                ops.push_back(nullptr);
                 continue;
             }
             OpSpec s;
@@ -168,36 +179,43 @@ void model_prepare(ModelImpl *m, int device, size_t max_batch) {
             s.c2 = po.c2.empty() ? nullptr : po.c2.data();
             s.c3 = po.c3;
             if (po.kind == MF_OP_AVERAGE_POOL_2D) s.pool_c0 = po.c0[0], s.pool_c1 = po.c1[0];
-            m->ops.push_back(op_create(device, s));
+            ops.push_back(nullptr); // reserve the slot first: a throwing push_back must not leak the operator
+            ops.back() = op_create(device, s);
             cur_scale = po.out_scale;
             cur_zp = po.out_zp;
         }
         // peephole (0): the boundary quantize of M::predict folds into operator 0 when that is the stem
-        if (!m->ops.empty() && m->ops[0]) (void)op_set_input_quant(m->ops[0], m->pm.in_scale, m->pm.in_zp, m->pm.u8);
+        if (!ops.empty() && ops[0]) (void)op_set_input_quant(ops[0], m->pm.in_scale, m->pm.in_zp, m->pm.u8);
         // peepholes.  (1) DepthwiseConv2D 3x3 directly followed by a 1x1 Conv2D -> one fused kernel.
         // (2) AveragePool2D (1x1 output) -> Conv2D 1x1 -> [Reshape] -> Softmax -> one tail kernel.
         // (3) FullyConnected (few outputs, one row) -> [Reshape] -> Softmax -> one kernel.
-        const size_t n = m->ops.size();
-        m->fused.assign(n, nullptr);
-        m->fused_last.assign(n, -1);
+        const size_t n = ops.size();
+        std::vector<FusedImpl *> &fused = pend.fused;
+        fused.assign(n, nullptr);
+        std::vector<int> fused_last(n, -1);
         for (size_t i = 0; i + 1 < n; ++i) {
             if (m->pm.ops[i].kind == MF_OP_DEPTHWISE_CONV_2D && m->pm.ops[i + 1].kind == MF_OP_CONV_2D) {
-                if ((m->fused[i] = fused_create(m->ops[i], m->ops[i + 1]))) m->fused_last[i] = (int)i + 1;
+                if ((fused[i] = fused_create(ops[i], ops[i + 1]))) fused_last[i] = (int)i + 1;
             } else if (m->pm.ops[i].kind == MF_OP_AVERAGE_POOL_2D && m->pm.ops[i + 1].kind == MF_OP_CONV_2D) {
                 size_t j = i + 2;
                 while (j < n && m->pm.ops[j].kind == MF_OP_RESHAPE) ++j;
                 if (j < n && m->pm.ops[j].kind == MF_OP_SOFTMAX &&
-                    (m->fused[i] = fused_tail_create(m->ops[i], m->ops[i + 1], m->ops[j])))
-                    m->fused_last[i] = (int)j;
+                    (fused[i] = fused_tail_create(ops[i], ops[i + 1], ops[j])))
+                    fused_last[i] = (int)j;
             } else if (m->pm.ops[i].kind == MF_OP_FULLY_CONNECTED) { // (3) FC -> [Reshape] -> Softmax
                 size_t j = i + 1;
                 while (j < n && m->pm.ops[j].kind == MF_OP_RESHAPE) ++j;
                 if (j < n && m->pm.ops[j].kind == MF_OP_SOFTMAX &&
-                    (m->fused[i] = fused_fc_softmax_create(m->ops[i], m->ops[j])))
-                    m->fused_last[i] = (int)j;
+                    (fused[i] = fused_fc_softmax_create(ops[i], ops[j])))
+                    fused_last[i] = (int)j;
             }
-            if (m->fused[i]) i = (size_t)m->fused_last[i]; // groups do not overlap
+            if (fused[i]) i = (size_t)fused_last[i]; // groups do not overlap
         }
+        // commit (nothing below throws)
+        m->device = device;
+        m->ops.swap(pend.ops);
+        m->fused.swap(pend.fused);
+        m->fused_last.swap(fused_last);
         m->prepared = true;
         model_set_generic(m, m->generic);
     }
@@ -450,7 +468,7 @@ void model_time_device(ModelImpl *m, const int8_t *d_in, size_t batch, int8_t *d
     if (per_op_ms) { // second sweep: one event pair per op, on the same stream
         std::vector<hipEvent_t> ev((size_t)nops + 1);
         for (auto &e : ev) MF_HIP(hipEventCreate(&e));
-        std::vector<double> acc((size_t)nops, 0.0);
+        std::vector<std::vector<float>> samples((size_t)nops); // per operator: one duration per iteration
         for (int it = 0; it < iters; ++it) {
             const int8_t *cur = d_in;
             int which = 0;
@@ -479,10 +497,15 @@ void model_time_device(ModelImpl *m, const int8_t *d_in, size_t batch, int8_t *d
             for (int i = 0; i < nops; ++i) {
                 float t = 0;
                 MF_HIP(hipEventElapsedTime(&t, ev[(size_t)i], ev[(size_t)i + 1]));
-                acc[(size_t)i] += t;
+                samples[(size_t)i].push_back(t);
             }
         }
-        for (int i = 0; i < nops; ++i) per_op_ms[i] = (float)(acc[(size_t)i] / iters);
+        for (int i = 0; i < nops; ++i) { // median over the iterations
+            std::vector<float> &v = samples[(size_t)i];
+            std::sort(v.begin(), v.end());
+            const size_t n = v.size();
+            per_op_ms[i] = n % 2 ? v[n / 2] : 0.5f * (v[n / 2 - 1] + v[n / 2]);
+        }
         for (auto &e : ev) (void)hipEventDestroy(e);
     }
     (void)hipEventDestroy(e0);

@@ -84,9 +84,12 @@ struct TensorInfo {
     std::vector<int64_t> zp;
     const uint8_t *data = nullptr;
     size_t data_len = 0;
-    size_t elems() const {
+    size_t elems() const { // dimensions are <= 2^24 each (read_tensor): cap the product well below size_t overflow
         size_t n = 1;
-        for (int s : shape) n *= (size_t)s;
+        for (int s : shape) {
+            n *= (size_t)s;
+            if (n > ((size_t)1 << 40)) fail(MF_ERR_INVALID_MODEL, "invalid model: tensor too large");
+        }
         return n;
     }
 };
@@ -223,6 +226,18 @@ ParsedModel parse_tflite(const uint8_t *data, size_t len) {
         pm.out_elems = t.elems();
     }
     pm.max_elems = pm.in_elems;
+    // The macro threads ONE running value through the operators (`let input = op(input, ...)`,
+    // lib.rs:130-151), so operator i consumes operator i-1's result whatever tensor indices the file
+    // names; a shape disagreement is a Rust type error there.  Here it would make a kernel read its
+    // input with the wrong per-inference stride, so the chain is checked: tensor index, or at least the
+    // same shape, from the graph input through every operator to the graph output.
+    int32_t prev_index = g_in.get<int32_t>(0);
+    std::vector<int> prev_shape(pm.in_shape, pm.in_shape + pm.in_rank);
+    auto same_tensor = [](std::vector<int> a, std::vector<int> b) {
+        if (a.size() == 1) a.insert(a.begin(), 1);
+        if (b.size() == 1) b.insert(b.begin(), 1);
+        return a == b;
+    };
 
     for (uint32_t oi = 0; oi < operators.size(); ++oi) { // lib.rs:130-151
         // Operator { opcode_index:0 inputs:1 outputs:2 builtin_options_type:3 builtin_options:4 }
@@ -236,6 +251,11 @@ ParsedModel parse_tflite(const uint8_t *data, size_t len) {
         if (!ins.size() || !outs.size()) fail(MF_ERR_INVALID_MODEL, "invalid model: operator without tensors");
         TensorInfo in = read_tensor(tensors, buffers, ins.get<int32_t>(0));
         TensorInfo out = read_tensor(tensors, buffers, outs.get<int32_t>(0));
+        if (ins.get<int32_t>(0) != prev_index && !same_tensor(in.shape, prev_shape))
+            fail(MF_ERR_UNSUPPORTED, "operator " + std::to_string(oi) + " does not consume the previous operator's "
+                                     "output (or the model input): only linear operator chains are supported");
+        prev_index = outs.get<int32_t>(0);
+        prev_shape = out.shape;
         ParsedOp po;
         po.kind = code;
 
@@ -311,10 +331,10 @@ ParsedModel parse_tflite(const uint8_t *data, size_t len) {
             std::memcpy(bias.data(), b.data, (size_t)po.N * 4);
             std::vector<int32_t> bzp;
             for (int64_t z : b.zp) bzp.push_back((int32_t)z);
-            const int nbq = (int)std::min(b.scale.size(), bzp.size());
             po.c0.resize(po.N), po.c1.resize(w.scale.size());
-            h_preprocess_conv(in.scale[0], po.N, bias.data(), b.scale.data(), bzp.data(), nbq, w.scale.data(),
-                              (int)w.scale.size(), out.scale[0], po.c0.data(), po.c1.data());
+            h_preprocess_conv(in.scale[0], po.N, bias.data(), b.scale.data(), (int)b.scale.size(), bzp.data(),
+                              (int)bzp.size(), w.scale.data(), (int)w.scale.size(), out.scale[0], po.c0.data(),
+                              po.c1.data());
             break;
         }
         case MF_OP_AVERAGE_POOL_2D: { // microflow-macros/src/ops/average_pool_2d.rs:47-66
@@ -364,7 +384,14 @@ ParsedModel parse_tflite(const uint8_t *data, size_t len) {
             fail(MF_ERR_UNSUPPORTED, "unsupported operator: " + std::to_string(code)); // lib.rs:148
         }
         if (po.out_elems > pm.max_elems) pm.max_elems = po.out_elems;
+        if (po.in_elems > pm.max_elems) pm.max_elems = po.in_elems;
         pm.ops.push_back(std::move(po));
+    }
+    {
+        std::vector<int> gout(pm.out_shape, pm.out_shape + pm.out_rank);
+        if (!operators.size() || (prev_index != g_out.get<int32_t>(0) && !same_tensor(prev_shape, gout)))
+            fail(MF_ERR_UNSUPPORTED, "the model output is not the last operator's output: only linear operator "
+                                     "chains are supported");
     }
     return pm;
 }

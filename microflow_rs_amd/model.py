@@ -126,6 +126,15 @@ class Model:
             out = np.empty((batch, out_elems), out_np_dtype)
             fin = (lambda: out.reshape(trailing) if single else out.reshape((batch,) + trailing))
             return a.ctypes.data_as(C.c_void_p), batch, _lib.MF_MEM_HOST, out.ctypes.data_as(C.c_void_p), fin, a
+        # a device tensor is passed by pointer: its dtype and device must be exactly what the kernels read
+        want = torch.float32 if np_dtype == np.float32 else self._tdtype()
+        if x.dtype != want:
+            raise TypeError("device input must be a %s tensor, got %s (no implicit cast of device memory)"
+                            % (want, x.dtype))
+        if self._device is None and not self._prepared:
+            self._device = x.device.index       # an unprepared model follows its first device input
+        if self._device is not None and x.device.index != self._device:
+            raise ValueError("input lives on cuda:%s but the model belongs to cuda:%s" % (x.device.index, self._device))
         xt = x.contiguous()
         if xt.numel() % elems:
             raise ValueError("input has %d elements, expected a multiple of %d" % (xt.numel(), elems))

@@ -125,12 +125,14 @@ int8_t orc_sat_i8(float x) { return orc_sat(x); }
 /* ======================================================================= */
 
 /* microflow-macros/src/ops/conv_2d.rs:100-113 and depthwise_conv_2d.rs:106-119 */
-void orc_preprocess_conv(float iscale, int n, const int32_t *bias, const float *bscale,
-                         const int32_t *bzp, int nbq, const float *fscale, int nfq, float oscale,
-                         float *c0, float *c1) {
+/* biases.scale.get(b).unwrap_or(scale[0]) and biases.zero_point.get(b).unwrap_or(zero_point[0]) fall back
+ * independently (conv_2d.rs:100-108): nbs scales, nbz zero points */
+static void preprocess_conv_int(float iscale, int n, const int32_t *bias, const float *bscale, int nbs,
+                                const int32_t *bzp, int nbz, const float *fscale, int nfq, float oscale,
+                                float *c0, float *c1) {
     for (int b = 0; b < n; ++b) {
-        float bs = b < nbq ? bscale[b] : bscale[0];
-        int32_t bz = b < nbq ? bzp[b] : bzp[0];
+        float bs = b < nbs ? bscale[b] : bscale[0];
+        int32_t bz = b < nbz ? bzp[b] : bzp[0];
         float r = bs / oscale;
         c0[b] = r * (float)wsub(bias[b], bz);
     }
@@ -138,6 +140,11 @@ void orc_preprocess_conv(float iscale, int n, const int32_t *bias, const float *
         float p = iscale * fscale[b];
         c1[b] = p / oscale;
     }
+}
+void orc_preprocess_conv(float iscale, int n, const int32_t *bias, const float *bscale,
+                         const int32_t *bzp, int nbq, const float *fscale, int nfq, float oscale,
+                         float *c0, float *c1) {
+    preprocess_conv_int(iscale, n, bias, bscale, nbq, bzp, nbq, fscale, nfq, oscale, c0, c1);
 }
 
 /* microflow-macros/src/ops/average_pool_2d.rs:77-83 */
@@ -505,14 +512,13 @@ orc_model *orc_model_load(const uint8_t *buf, size_t len, const char **err) {
             for (int i = 0; i < tw.nzp; ++i) o->wzp[i] = (int8_t)tw.zp[i];
             int32_t *bias = (int32_t *)malloc(sizeof(int32_t) * (size_t)n0);
             memcpy(bias, tb.data, sizeof(int32_t) * (size_t)n0);
-            int nbq = tb.nscale < tb.nzp ? tb.nscale : tb.nzp;
             int32_t *bz = (int32_t *)malloc(sizeof(int32_t) * (size_t)tb.nzp);
             for (int i = 0; i < tb.nzp; ++i) bz[i] = (int32_t)tb.zp[i];
             o->c0 = (float *)malloc(sizeof(float) * (size_t)n0);
             o->c1 = (float *)malloc(sizeof(float) * (size_t)tw.nscale);
             o->info.n_c0 = n0;
             o->info.n_c1 = tw.nscale;
-            orc_preprocess_conv(tin.scale[0], n0, bias, tb.scale, bz, nbq, tw.scale, tw.nscale,
+            preprocess_conv_int(tin.scale[0], n0, bias, tb.scale, tb.nscale, bz, tb.nzp, tw.scale, tw.nscale,
                                 tout.scale[0], o->c0, o->c1);
             free(bias);
             free(bz);

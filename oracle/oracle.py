@@ -22,6 +22,11 @@ OP_NAMES = {1: "average_pool_2d", 3: "conv_2d", 4: "depthwise_conv_2d", 9: "full
             22: "reshape", 25: "softmax"}
 
 
+# -O3 as SURVEY.md 8d asks of the CPU baseline; -ffp-contract=off / no fast-math keep every f32 operation
+# individually rounded (value-safe at any -O level), so the same build serves as checker and as baseline
+CFLAGS = ["-O3", "-std=c11", "-fPIC", "-ffp-contract=off", "-fno-fast-math"]
+
+
 def build(force=False):
     """Compile oracle/libmf_oracle.so with gcc (seconds)."""
     src = os.path.join(_HERE, "mf_oracle.c")
@@ -29,9 +34,7 @@ def build(force=False):
     if (not force and os.path.exists(_SO)
             and os.path.getmtime(_SO) >= max(os.path.getmtime(d) for d in deps)):
         return _SO
-    subprocess.check_call(
-        ["gcc", "-O2", "-std=c11", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-shared",
-         "-o", _SO, src, "-lm"])
+    subprocess.check_call(["gcc"] + CFLAGS + ["-shared", "-o", _SO, src, "-lm"])
     return _SO
 
 

@@ -343,3 +343,87 @@ def test_f32_predict_with_quantize_fused_into_the_stem(O, n):
     assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
     m.set_fusion(True)
     assert np.array_equal(m.predict(xf).reshape(n, -1).view(np.uint32), ref.view(np.uint32))   # host-fed path
+
+
+@pytest.mark.parametrize("wzp", [0, -3], ids=["wzp0", "wzp-3"])
+def test_fully_connected_4096_cubed_through_predict_inner(mf, O, wzp):
+    """BASELINE config 5 at full size (M = K = N = 4096, the 256x256-tile staggered GEMM) through the
+    model API, weight zero point 0 and != 0 (the x.1 / c3 terms of src/ops/fully_connected.rs:60-72).
+    Rows 0..63 are crafted: row r is +127 where weight row r is positive and -128 elsewhere, so that
+    accumulator (r, r) = 255 * sum of the positive weights ~ 3.3e7 > 2^24, where f32(acc) really rounds
+    (v_cvt_f32_i32, to nearest even; src/ops/fully_connected.rs:68-72 `as f32`); bias[r] cancels that
+    accumulator to within a few hundred and c1 = 1/8, so the rounding of the conversion is visible in the
+    int8 output instead of disappearing in the saturation.  Rows 64..67 are all +127 / all -128 /
+    alternating; the rest are uniform random.  128 rows are compared with the oracle."""
+    import torch
+    from tools.make_fc_model import fc_model
+    M = K = N = 4096
+    rng = np.random.default_rng(4096 + wzp)
+    w = rng.integers(-128, 128, (N, K), dtype=np.int8)
+    x = rng.integers(-128, 128, (M, K), dtype=np.int8)
+    ncraft = 64
+    x[:ncraft] = np.where(w[:ncraft] > wzp, 127, -128).astype(np.int8)
+    x[64], x[65] = 127, -128
+    x[66] = np.where(np.arange(K) % 2 == 0, 127, -128)
+    x[67] = np.where(np.arange(K) % 2 == 0, -128, 127)
+    izp = -128
+    acc_diag = ((x[:ncraft].astype(np.int64) - izp) * (w[:ncraft].astype(np.int64) - wzp)).sum(axis=1)
+    assert acc_diag.min() > (1 << 24)
+    bias = rng.integers(-4096, 4096, N).astype(np.int64)
+    bias[:ncraft] = -acc_diag + rng.integers(-300, 300, ncraft)
+    in_s, w_s, out_s = 1.0 / 128, 1.0 / 128, 1.0 / 2048            # c1 = in_s * w_s / out_s = 1/8
+    quants = ((in_s, izp), (w_s, wzp), (in_s * w_s, 0), (out_s, 3))
+    m = mf.model(fc_model(M, K, N, w, bias.astype(np.int32), *quants))
+    m.prepare(1)
+    assert m.op(0)["kernel"] == "fc_mfma"
+    xd = torch.from_numpy(x).cuda()
+    y = m.run_quantized(xd.reshape((1, M, K))).reshape(M, N).cpu().numpy()
+    rows = sorted(set(list(range(68)) + [int(r) for r in rng.integers(68, M, 60)]))
+    om = O.Model(fc_model(len(rows), K, N, w, bias.astype(np.int32), *quants))
+    want = om.run_quantized(x[rows]).reshape(len(rows), N)
+    assert np.array_equal(y[rows], want), np.argwhere(y[rows] != want)[:5]
+    # the crafted diagonal really sits in the unsaturated range (else the test would prove nothing)
+    diag = y[np.arange(ncraft), np.arange(ncraft)]
+    assert np.all(np.abs(diag.astype(int)) < 120) and len(np.unique(diag)) > 20
+    # and truncating instead of rounding the int -> f32 conversion would change some of those outputs
+    f_rne = acc_diag.astype(np.float32)
+    f_trunc = (acc_diag - (acc_diag % 2)).astype(np.float32)       # ulp = 2 in [2^24, 2^25)
+    if acc_diag.max() < (1 << 25):
+        assert np.any(f_rne != f_trunc)
+
+
+def test_models_run_quantized_over_all_devices(mf, O):
+    """Single-process sharding entry point (mf_models_run_quantized) over EVERY GPU of the box: one replica
+    per device, contiguous shards, no collective.  Skips itself on a 1-GPU box (the multi-replica form on
+    one device is covered by test_run_sharded_replicas)."""
+    import torch
+    ndev = torch.cuda.device_count()
+    if ndev < 2:
+        pytest.skip("one GPU visible")
+    n = 64 * ndev + 5                                              # ragged over the devices
+    base = mf.model(model_path("person_detect"))
+    x = synth_i8(3, 4242, n, base.input_elems).reshape((n,) + base.input_shape)
+    replicas = [mf.model(model_path("person_detect"), device=d) for d in range(ndev)]
+    got = mf.run_sharded(replicas, x)
+    want = O.Model(model_path("person_detect")).run_quantized_batch(x.reshape(n, -1))
+    assert np.array_equal(got.reshape(n, -1), want)
+
+
+def test_device_inputs_are_type_checked(mf):
+    """A device tensor is passed by pointer, so a wrong dtype would be reinterpreted (or read out of
+    bounds): predict wants float32, the quantized entry points the model's element type."""
+    import torch
+    m = mf.model(model_path("sine"))
+    m.prepare(4)
+    xf = torch.full((4, 1, 1), 0.5, device="cuda")
+    assert m.predict(xf).shape[0] == 4
+    for bad in (xf.half(), xf.double(), xf.to(torch.int32)):
+        with pytest.raises(TypeError):
+            m.predict(bad)
+    xq = torch.zeros((4, 1, 1), dtype=torch.int8, device="cuda")
+    assert m.run_quantized(xq).shape[0] == 4
+    for bad in (xq.to(torch.int32), xq.float(), xq.to(torch.uint8)):
+        with pytest.raises(TypeError):
+            m.run_quantized(bad)
+        with pytest.raises(TypeError):
+            m.predict_quantized(bad)

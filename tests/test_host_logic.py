@@ -142,3 +142,57 @@ def test_bad_arguments_return_status_codes():
     assert L.mf_op_input_elems(None) == 0
     L.mf_op_destroy(None)
     L.mf_model_destroy(None)
+
+
+def _writer():
+    import sys
+    tools = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools")
+    if tools not in sys.path:
+        sys.path.insert(0, tools)
+    import tflite_writer
+    return tflite_writer
+
+
+def test_operators_must_chain():
+    """The macro threads one running value through the operators; a file whose operator reads some other
+    tensor of a different shape does not type-check there and must not reach the kernels here."""
+    tw = _writer()
+    rng = np.random.default_rng(1)
+    pool = dict(op="average_pool_2d", filter=(2, 2), padding="valid", strides=(2, 2), act=None,
+                out_shape=(1, 2, 2, 4), out_q=(0.1, 0))
+    sm = dict(op="softmax", out_shape=(1, 16), out_q=(1 / 256, -128))
+    rs = dict(op="reshape", out_shape=(1, 16), out_q=(0.1, 0))
+    good = tw.build_model((1, 4, 4, 4), (0.1, 0), [pool, rs, sm])
+    assert _create(good)[0] == 0
+    # the pool's input is a detached tensor of another shape
+    bad = tw.build_model((1, 4, 4, 4), (0.1, 0), [dict(pool, detach_input=(1, 6, 6, 4), out_shape=(1, 3, 3, 4)),
+                                                  dict(rs, out_shape=(1, 36)), dict(sm, out_shape=(1, 36))])
+    st, msg = _create(bad)
+    assert st == _lib.MF_ERR_UNSUPPORTED and "linear operator chains" in msg
+    # a middle operator re-reads a tensor shaped like the model input (a branch)
+    bad = tw.build_model((1, 4, 4, 4), (0.1, 0), [pool, dict(pool, detach_input=(1, 4, 4, 4)), rs, sm])
+    st, msg = _create(bad)
+    assert st == _lib.MF_ERR_UNSUPPORTED and "linear operator chains" in msg
+    # a detached tensor of the SAME shape is what the running value would be anyway: accepted
+    ok = tw.build_model((1, 4, 4, 4), (0.1, 0), [dict(pool, detach_input=(1, 4, 4, 4)), rs, sm])
+    assert _create(ok)[0] == 0
+
+
+def test_bias_scale_and_zero_point_fall_back_independently(O):
+    """biases.scale.get(b).unwrap_or(scale[0]) and biases.zero_point.get(b).unwrap_or(zero_point[0])
+    (microflow-macros/src/ops/conv_2d.rs:100-108): N bias scales with ONE zero point keep their own scales."""
+    tw = _writer()
+    rng = np.random.default_rng(7)
+    N, Cin = 4, 3
+    bias = rng.integers(-500, 500, N).astype(np.int32)
+    bscale = np.array([0.01, 0.02, 0.03, 0.04], f32)
+    layer = dict(op="conv_2d", filters=rng.integers(-128, 128, (N, 1, 1, Cin)).astype(np.int8), fscale=[0.5], fzp=[0],
+                 bias=bias, bscale=bscale, bzp=[7], padding="same", strides=(1, 1), act=None,
+                 out_shape=(1, 2, 2, N), out_q=(0.25, 1))
+    blob = tw.build_model((1, 2, 2, Cin), (0.1, 0), [layer, dict(op="reshape", out_shape=(1, 4 * N), out_q=(0.25, 1))])
+    m = mf.model(blob)
+    c0 = m.op_constants(0)[0]
+    want = np.array([f32(f32(bscale[b]) / f32(0.25)) * f32(int(bias[b]) - 7) for b in range(N)], f32)
+    assert np.array_equal(c0, want), (c0, want)
+    om = O.Model(blob)
+    assert np.array_equal(om.op_constants(0)[0], want)

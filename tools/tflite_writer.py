@@ -63,6 +63,8 @@ def build_model(input_shape, input_q, layers, elem=INT8):
     wdt = np.uint8 if elem == UINT8 else np.int8
     for L in layers:
         op = L["op"]
+        if "detach_input" in L:  # negative tests: this operator reads a fresh tensor instead of the running one
+            cur = add_tensor(L["detach_input"], elem, 0, input_q[0], input_q[1])
         if op not in used_ops:
             used_ops.append(op)
         oc = used_ops.index(op)
