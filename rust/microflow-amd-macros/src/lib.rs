@@ -18,7 +18,18 @@ pub fn model(args: TokenStream, item: TokenStream) -> TokenStream {
     let path = parse_macro_input!(args as LitStr);
     let item = parse_macro_input!(item as ItemStruct);
     let ident = &item.ident;
-    let bytes = std::fs::read(path.value()).unwrap_or_else(|_| {
+    // The reference reads the file at expansion time relative to the crate root (the compiler's working
+    // directory under cargo, microflow-macros/src/lib.rs:50).  `include_bytes!` below would resolve a
+    // relative path against the INVOKING SOURCE FILE instead, so the same absolute path is used for both.
+    let full = {
+        let given = std::path::PathBuf::from(path.value());
+        if given.is_absolute() {
+            given
+        } else {
+            std::path::PathBuf::from(std::env::var("CARGO_MANIFEST_DIR").unwrap_or_else(|_| ".".into())).join(given)
+        }
+    };
+    let bytes = std::fs::read(&full).unwrap_or_else(|_| {
         panic!("couldn't find '{}', please provide a valid path", path.value()) // lib.rs:50-55
     });
     let (ishape, oshape, is_u8) = shapes::model_io_shapes(&bytes)
@@ -33,40 +44,39 @@ pub fn model(args: TokenStream, item: TokenStream) -> TokenStream {
         2 => (quote!(Buffer2D), quote!(unflatten_2d)),
         _ => (quote!(Buffer4D), quote!(unflatten_4d)),
     };
-    let p = path.value();
+    let p = full.to_string_lossy().into_owned(); // absolute: the same file the shapes were read from
     quote! {
         #item
         impl #ident {
-            fn handle() -> std::sync::MutexGuard<'static, microflow_amd::Model> {
-                static M: once_cell::sync::Lazy<std::sync::Mutex<microflow_amd::Model>> =
-                    once_cell::sync::Lazy::new(|| std::sync::Mutex::new(
-                        microflow_amd::Model::new(include_bytes!(#p), 0)));
-                M.lock().unwrap()
-            }
-            pub fn predict(input: microflow_amd::buffer::#ibuf<f32, #(#ishape),*>)
-                -> microflow_amd::buffer::#obuf<f32, #(#oshape),*> {
-                let v = microflow_amd::layout::#flatten(&input);
-                microflow_amd::layout::#unflatten(&Self::handle().predict(&v, 1))
-            }
-            pub fn predict_quantized(input: microflow_amd::buffer::#ibuf<#qty, #(#ishape),*>)
-                -> microflow_amd::buffer::#obuf<f32, #(#oshape),*> {
-                let v = microflow_amd::layout::#flatten(&input);
-                microflow_amd::layout::#unflatten(&Self::handle().#qcall(&v, 1))
-            }
-            fn all_devices() -> std::sync::MutexGuard<'static, microflow_amd::ModelSet> {
+            /// ONE replica set per model type -- replica d lives on GPU d; `predict` uses replica 0,
+            /// `predict_batch` all of them (no second copy of the model on GPU 0).
+            fn replicas() -> std::sync::MutexGuard<'static, microflow_amd::ModelSet> {
                 static S: once_cell::sync::Lazy<std::sync::Mutex<microflow_amd::ModelSet>> =
                     once_cell::sync::Lazy::new(|| std::sync::Mutex::new(
                         microflow_amd::ModelSet::new(include_bytes!(#p))));
                 S.lock().unwrap()
             }
+            pub fn predict(input: microflow_amd::buffer::#ibuf<f32, #(#ishape),*>)
+                -> microflow_amd::buffer::#obuf<f32, #(#oshape),*> {
+                let v = microflow_amd::layout::#flatten(&input);
+                microflow_amd::layout::#unflatten(&Self::replicas().first().predict(&v, 1))
+            }
+            pub fn predict_quantized(input: microflow_amd::buffer::#ibuf<#qty, #(#ishape),*>)
+                -> microflow_amd::buffer::#obuf<f32, #(#oshape),*> {
+                let v = microflow_amd::layout::#flatten(&input);
+                microflow_amd::layout::#unflatten(&Self::replicas().first().#qcall(&v, 1))
+            }
             /// New surface: B independent inferences, sharded over every visible GPU
             /// (one launch sequence per device; no collective).
             pub fn predict_batch(inputs: &[microflow_amd::buffer::#ibuf<f32, #(#ishape),*>])
                 -> Vec<microflow_amd::buffer::#obuf<f32, #(#oshape),*>> {
+                if inputs.is_empty() {
+                    return Vec::new();
+                }
                 let mut v = Vec::new();
                 for i in inputs { v.extend(microflow_amd::layout::#flatten(i)); }
-                let out = Self::all_devices().predict(&v, inputs.len());
-                let n = out.len() / inputs.len().max(1);
+                let out = Self::replicas().predict(&v, inputs.len());
+                let n = out.len() / inputs.len();
                 out.chunks(n).map(|c| microflow_amd::layout::#unflatten(c)).collect()
             }
         }

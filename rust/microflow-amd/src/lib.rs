@@ -80,14 +80,23 @@ fn check(status: c_int) {
 }
 
 impl Model {
-    /// `bytes` = the .tflite embedded with `include_bytes!` by the macro.
-    pub fn new(bytes: &'static [u8], device: i32) -> Self {
+    /// `bytes` = the .tflite embedded with `include_bytes!` by the macro.  Model errors (the reference's
+    /// compile-time `abort_call_site!` cases) panic with the same texts; a device that cannot be prepared
+    /// is reported to the caller.
+    pub fn try_new(bytes: &'static [u8], device: i32) -> Result<Self, String> {
         let mut raw = std::ptr::null_mut();
         check(unsafe { mf_model_create(bytes.as_ptr(), bytes.len(), &mut raw) });
         let mut info = mf_model_info::default();
         check(unsafe { mf_model_get_info(raw, &mut info) });
-        check(unsafe { mf_model_prepare(raw, device, 1) });
-        Model { raw, info }
+        let m = Model { raw, info }; // from here on Drop releases the handle
+        let st = unsafe { mf_model_prepare(m.raw, device, 1) };
+        if st != MF_OK {
+            return Err(unsafe { std::ffi::CStr::from_ptr(mf_last_error()) }.to_string_lossy().into_owned());
+        }
+        Ok(m)
+    }
+    pub fn new(bytes: &'static [u8], device: i32) -> Self {
+        Self::try_new(bytes, device).unwrap_or_else(|e| panic!("microflow-amd: device {device}: {e}"))
     }
     /// `input`: batch x input_elems in the ABI layout (row-major / NHWC).
     pub fn predict(&mut self, input: &[f32], batch: usize) -> Vec<f32> {
@@ -120,14 +129,30 @@ pub struct ModelSet {
     replicas: Vec<Model>,
 }
 impl ModelSet {
+    /// One replica on every GPU that can be prepared; a device that fails (busy, out of memory) is left
+    /// out instead of taking the process down.  Panics only when NO device works.
     pub fn new(bytes: &'static [u8]) -> Self {
         let n = unsafe { mf_device_count() }.max(1);
-        ModelSet { replicas: (0..n).map(|d| Model::new(bytes, d)).collect() }
+        let mut errors = Vec::new();
+        let replicas: Vec<Model> = (0..n)
+            .filter_map(|d| Model::try_new(bytes, d).map_err(|e| errors.push(format!("device {d}: {e}"))).ok())
+            .collect();
+        if replicas.is_empty() {
+            panic!("microflow-amd: no usable GPU ({})", errors.join("; "));
+        }
+        ModelSet { replicas }
+    }
+    /// the replica single inferences run on
+    pub fn first(&mut self) -> &mut Model {
+        &mut self.replicas[0]
     }
     pub fn predict(&mut self, input: &[f32], batch: usize) -> Vec<f32> {
         let info = self.replicas[0].info;
         assert_eq!(input.len(), batch * info.input_elems);
         let mut out = vec![0f32; batch * info.output_elems];
+        if batch == 0 {
+            return out;
+        }
         let raws: Vec<*mut mf_model> = self.replicas.iter().map(|m| m.raw).collect();
         check(unsafe { mf_models_predict(raws.as_ptr(), raws.len() as c_int, input.as_ptr(), batch, out.as_mut_ptr()) });
         out
