@@ -257,7 +257,7 @@ def main():
         # ---- parity: sampled bit-exact comparison with the CPU oracle ----
         from oracle import oracle as O
         om = O.Model(os.path.join(ROOT, "models", fname))
-        idx = sorted(set([0, 1, count // 3, count // 2, count - 2, count - 1]))
+        idx = sorted(set([0, 1, count // 3, count // 2, count - 2, count - 1] + list(range(7, count, max(1, count // 42)))))[:48]
         xs = x.reshape(count, -1)[idx].cpu().numpy()
         ys = y.reshape(count, -1)[idx].cpu().numpy()
         parity_ok = bool(np.array_equal(ys, om.run_quantized_batch(xs)))

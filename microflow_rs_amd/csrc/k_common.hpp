@@ -93,6 +93,42 @@ __device__ __forceinline__ uint32_t pack4(int a, int b, int c, int d) {
     return __builtin_amdgcn_perm(hi, lo, 0x05040100u);
 }
 
+// Requantise four accumulators and pack the four results into one dword in 4 instructions instead of 7: the
+// float -> int conversion of each clamped value writes its low byte straight into byte k of the destination
+// (SDWA destination select, other bytes preserved), so no separate v_perm packing (3 per dword) is needed.
+// Same arithmetic as requant_t followed by pack4: the conversion truncates a value already clamped to the
+// element type's range, whose two's-complement low byte is the stored byte.
+#ifndef MF_SDWA_PACK
+#define MF_SDWA_PACK 1 // 0: v_cvt + v_perm packing (A/B switch)
+#endif
+template <bool MG> __device__ __forceinline__ float requant_clamped(int acc, float A, float S, float lo_f, float hi_f) {
+    float f;
+    if constexpr (MG) f = __fsub_rn(__int_as_float(acc), 12582912.0f);
+    else f = (float)acc;
+    const float x = __fadd_rn(A, __fmul_rn(S, f));
+    const float r = __fadd_rn(x, __builtin_copysignf(0x1.fffffep-2f, x));
+    return __builtin_amdgcn_fmed3f(r, lo_f, hi_f);
+}
+__device__ __forceinline__ uint32_t cvt_pack4(float r0, float r1, float r2, float r3) {
+    uint32_t d;
+    asm("v_cvt_i32_f32_sdwa %0, %1 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:DWORD" : "=v"(d) : "v"(r0));
+    asm("v_cvt_i32_f32_sdwa %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(d) : "v"(r1));
+    asm("v_cvt_i32_f32_sdwa %0, %1 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(d) : "v"(r2));
+    asm("v_cvt_i32_f32_sdwa %0, %1 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(d) : "v"(r3));
+    return d;
+}
+template <bool MG, uint32_t XR4>
+__device__ __forceinline__ uint32_t requant_pack4(int a0, int a1, int a2, int a3, const float4 &A, const float4 &S,
+                                                  float lo_f, float hi_f) {
+#if MF_SDWA_PACK
+    return cvt_pack4(requant_clamped<MG>(a0, A.x, S.x, lo_f, hi_f), requant_clamped<MG>(a1, A.y, S.y, lo_f, hi_f),
+                     requant_clamped<MG>(a2, A.z, S.z, lo_f, hi_f), requant_clamped<MG>(a3, A.w, S.w, lo_f, hi_f)) ^ XR4;
+#else
+    return pack4(requant_t<MG>(a0, A.x, S.x, lo_f, hi_f), requant_t<MG>(a1, A.y, S.y, lo_f, hi_f),
+                 requant_t<MG>(a2, A.z, S.z, lo_f, hi_f), requant_t<MG>(a3, A.w, S.w, lo_f, hi_f)) ^ XR4;
+#endif
+}
+
 // pack4 for either element type: XR4 = 0x80808080 moves u8-domain epilogue results (0..255) back
 // to the stored i8 domain (kernels.hpp), XR4 = 0 is plain i8 (the XOR disappears at compile time)
 template <uint32_t XR4>

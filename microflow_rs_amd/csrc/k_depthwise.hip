@@ -127,11 +127,9 @@ __global__ __launch_bounds__(NTHR) void dw3x3_nhwc(const int8_t *__restrict__ in
 #pragma unroll
                     for (int j = 0; j < R; ++j) {
                         uint32_t *dp = dst + ((size_t)(g * OH + oy0 + j) * OW + ox0) * C4 + cg;
-                        dp[0] = pack4x<XR4>(requant_t<MG>(o0[j][0], A.x, Sc.x, p.lo_f, p.hi_f), requant_t<MG>(o0[j][1], A.y, Sc.y, p.lo_f, p.hi_f),
-                                      requant_t<MG>(o0[j][2], A.z, Sc.z, p.lo_f, p.hi_f), requant_t<MG>(o0[j][3], A.w, Sc.w, p.lo_f, p.hi_f));
+                        dp[0] = requant_pack4<MG, XR4>(o0[j][0], o0[j][1], o0[j][2], o0[j][3], A, Sc, p.lo_f, p.hi_f);
                         if (ox0 + 1 < OW)
-                            dp[C4] = pack4x<XR4>(requant_t<MG>(o1[j][0], A.x, Sc.x, p.lo_f, p.hi_f), requant_t<MG>(o1[j][1], A.y, Sc.y, p.lo_f, p.hi_f),
-                                           requant_t<MG>(o1[j][2], A.z, Sc.z, p.lo_f, p.hi_f), requant_t<MG>(o1[j][3], A.w, Sc.w, p.lo_f, p.hi_f));
+                            dp[C4] = requant_pack4<MG, XR4>(o1[j][0], o1[j][1], o1[j][2], o1[j][3], A, Sc, p.lo_f, p.hi_f);
                     }
                 }
             }

@@ -150,11 +150,9 @@ __global__ __launch_bounds__(NTHR) void dwpw3x3(const int8_t *__restrict__ in,
 #pragma unroll
                     for (int j = 0; j < R; ++j) {
                         uint32_t *dp = (uint32_t *)mid + ((size_t)(g * OH + oy0 + j) * OW + ox0) * C4 + cg;
-                        dp[0] = pack4x<XR4>(requant_t<MG>(o0[j][0], dA.x, dS.x, p.dw.lo_f, p.dw.hi_f), requant_t<MG>(o0[j][1], dA.y, dS.y, p.dw.lo_f, p.dw.hi_f),
-                                      requant_t<MG>(o0[j][2], dA.z, dS.z, p.dw.lo_f, p.dw.hi_f), requant_t<MG>(o0[j][3], dA.w, dS.w, p.dw.lo_f, p.dw.hi_f));
+                        dp[0] = requant_pack4<MG, XR4>(o0[j][0], o0[j][1], o0[j][2], o0[j][3], dA, dS, p.dw.lo_f, p.dw.hi_f);
                         if (ox0 + 1 < OW)
-                            dp[C4] = pack4x<XR4>(requant_t<MG>(o1[j][0], dA.x, dS.x, p.dw.lo_f, p.dw.hi_f), requant_t<MG>(o1[j][1], dA.y, dS.y, p.dw.lo_f, p.dw.hi_f),
-                                           requant_t<MG>(o1[j][2], dA.z, dS.z, p.dw.lo_f, p.dw.hi_f), requant_t<MG>(o1[j][3], dA.w, dS.w, p.dw.lo_f, p.dw.hi_f));
+                            dp[C4] = requant_pack4<MG, XR4>(o1[j][0], o1[j][1], o1[j][2], o1[j][3], dA, dS, p.dw.lo_f, p.dw.hi_f);
                     }
                 }
             }
@@ -204,10 +202,7 @@ __global__ __launch_bounds__(NTHR) void dwpw3x3(const int8_t *__restrict__ in,
 #pragma unroll
                     for (int ks = 0; ks < KS; ++ks)
                         acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(Aw[q][tt][ks], B[ks], acc, 0, 0, 0);
-                    packed[tt] = pack4x<XR4>(requant_t<MG>(acc[0], cA[tt].x, cS[tt].x, p.pw.lo_f, p.pw.hi_f),
-                                       requant_t<MG>(acc[1], cA[tt].y, cS[tt].y, p.pw.lo_f, p.pw.hi_f),
-                                       requant_t<MG>(acc[2], cA[tt].z, cS[tt].z, p.pw.lo_f, p.pw.hi_f),
-                                       requant_t<MG>(acc[3], cA[tt].w, cS[tt].w, p.pw.lo_f, p.pw.hi_f));
+                    packed[tt] = requant_pack4<MG, XR4>(acc[0], acc[1], acc[2], acc[3], cA[tt], cS[tt], p.pw.lo_f, p.pw.hi_f);
                 }
                 if constexpr (XPOSE) {
                     uint8_t *dstp = lds + PATCH_OFF + wave * CBYTES + lpix * N + pg * (NB / 4);

@@ -262,10 +262,7 @@ __global__ __launch_bounds__(NTHR, WPE) void dwpw_mm(const int8_t *__restrict__ 
 #pragma unroll
                 for (int u = 0; u < UB; ++u) {
                     const int k = (t0 + u) / NU;
-                    const uint32_t d = pack4x<XR4>(requant_t<MG>(acc[u][0], dA[k].x, dS[k].x, p.dw.lo_f, p.dw.hi_f),
-                                                  requant_t<MG>(acc[u][1], dA[k].y, dS[k].y, p.dw.lo_f, p.dw.hi_f),
-                                                  requant_t<MG>(acc[u][2], dA[k].z, dS[k].z, p.dw.lo_f, p.dw.hi_f),
-                                                  requant_t<MG>(acc[u][3], dA[k].w, dS[k].w, p.dw.lo_f, p.dw.hi_f));
+                    const uint32_t d = requant_pack4<MG, XR4>(acc[u][0], acc[u][1], acc[u][2], acc[u][3], dA[k], dS[k], p.dw.lo_f, p.dw.hi_f);
                     const int moff = moff_of(t0 + u);
                     if constexpr (UX * CX != OWC) { // the column grid overhangs the row: those lanes have no pixel
                         const int ux = ((t0 + u) % NU % NUX) * PSX;
@@ -323,10 +320,7 @@ __global__ __launch_bounds__(NTHR, WPE) void dwpw_mm(const int8_t *__restrict__ 
 #pragma unroll
                     for (int ks = 0; ks < KS; ++ks)
                         acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(Aw[q][tt][ks], B[ks], acc, 0, 0, 0);
-                    packed[tt] = pack4x<XR4>(requant_t<MG>(acc[0], cA[tt].x, cS[tt].x, p.pw.lo_f, p.pw.hi_f),
-                                             requant_t<MG>(acc[1], cA[tt].y, cS[tt].y, p.pw.lo_f, p.pw.hi_f),
-                                             requant_t<MG>(acc[2], cA[tt].z, cS[tt].z, p.pw.lo_f, p.pw.hi_f),
-                                             requant_t<MG>(acc[3], cA[tt].w, cS[tt].w, p.pw.lo_f, p.pw.hi_f));
+                    packed[tt] = requant_pack4<MG, XR4>(acc[0], acc[1], acc[2], acc[3], cA[tt], cS[tt], p.pw.lo_f, p.pw.hi_f);
                 }
                 if constexpr (XPOSE) {
                     uint8_t *dstp = lds + PATCH_OFF + wave * CBYTES + lpix * N + pg * (NB / 4);
@@ -384,11 +378,15 @@ __global__ __launch_bounds__(NTHR, WPE) void dwpw_mm(const int8_t *__restrict__ 
 // pixels (each output row multiplies only its own pixel's half) and lane g' owns pixel parity g' >> 1,
 // channels 8 (g' & 1) .. +7.
 // ------------------------------------------------------------------------
-template <int H, int W, int C, int S, int N, int G, int NTHR, bool DBUF, int CG, int CY, int ORD, int ROWPAD, int TS,
+template <int H, int W, int C, int S, int N, int G, int NTHR, int DB, int CG, int CY, int ORD, int ROWPAD, int TS,
           int WPE, bool MG, uint32_t XR4>
 __global__ __launch_bounds__(NTHR, WPE) void dwpw_rr(const int8_t *__restrict__ in, int8_t *__restrict__ out, DwPwArgs p,
                                                      int batch) {
     constexpr bool PAIR = C == 8;
+    // DB: 0 one staging buffer, 1 two, 2 two + a LOADER wave: the last wave of the workgroup issues every DMA and
+    // is the only one that waits for them, so the compute waves never execute `s_waitcnt vmcnt(0)` -- which on
+    // this ISA also waits for their own output STORES to drain (loads and stores share the counter).
+    constexpr bool DBUF = DB != 0, LOADER = DB == 2;
     static_assert(C == 8 || C == 16 || C == 32, "register-resident pairs: C <= 32");
     constexpr int OH = (H + S - 1) / S, OW = (W + S - 1) / S;
     constexpr int OWC = PAIR ? OW / 2 : OW;
@@ -398,7 +396,7 @@ __global__ __launch_bounds__(NTHR, WPE) void dwpw_rr(const int8_t *__restrict__ 
     constexpr int LP = C < 16 ? 16 : C;
     constexpr int ROWB = W * C, ROW = LP + ROWB + LP + ROWPAD, TILE = (H + 2) * ROW, BUF = G * TILE;
     constexpr int IMG = H * ROWB, ROWCH = ROWB / 16, NROWS = G * H;
-    constexpr int NWAVE = NTHR / 64;
+    constexpr int NWAVE = NTHR / 64 - (LOADER ? 1 : 0); // compute waves
     constexpr int NBUF = DBUF ? 2 : 1;
     constexpr int OPIX = OH * OW;
     static_assert(CG * CY * CX == 16 && G % CG == 0 && OH % CY == 0 && OWC % CX == 0, "column grid");
@@ -475,9 +473,10 @@ __global__ __launch_bounds__(NTHR, WPE) void dwpw_rr(const int8_t *__restrict__ 
 
     auto stage = [&](int st, int buf) {
         const int src_lane = NQ > 1 ? (lane ^ tile_swz<TS>(lane / (NQ > 1 ? NQ : 1))) : lane;
+        constexpr int NISSUE = LOADER ? 1 : NWAVE; // waves sharing the rows of a step
 #pragma unroll
-        for (int k = 0; k < (NROWS + NWAVE - 1) / NWAVE; ++k) {
-            const int r = k * NWAVE + wave;
+        for (int k = 0; k < (NROWS + NISSUE - 1) / NISSUE; ++k) {
+            const int r = LOADER ? k : k * NWAVE + wave;
             const int gi = r / H, y = r % H;
 #if MF_RR_DIAG == 3 // diagnostics build: no HBM reads
             if (r < NROWS && st * G + gi < batch && lane < ROWCH && batch < 0)
@@ -491,13 +490,26 @@ __global__ __launch_bounds__(NTHR, WPE) void dwpw_rr(const int8_t *__restrict__ 
 
     const int nsteps = (batch + G - 1) / G;
     int step = blockIdx.x, cur = 0;
-    if (step < nsteps) stage(step, 0);
+    if constexpr (LOADER) {
+        if (wave == NWAVE) { // the loader wave: same barrier sequence as the compute waves, no arithmetic
+            if (step < nsteps) stage(step, 0);
+            for (; step < nsteps; step += gridDim.x, cur ^= 1) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this step's tile has landed
+                __syncthreads();                                  // ... and the compute waves left the other buffer
+                const int next = step + gridDim.x;
+                if (next < nsteps) stage(next, cur ^ 1);
+            }
+            return;
+        }
+    } else {
+        if (step < nsteps) stage(step, 0);
+    }
 
     for (; step < nsteps; step += gridDim.x) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (!LOADER) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads(); // the staged tile is complete; every wave is done with the buffer the next DMA overwrites
         const int next = step + gridDim.x;
-        if constexpr (DBUF) {
+        if constexpr (DBUF && !LOADER) {
             if (next < nsteps) stage(next, cur ^ 1);
         }
         const int gvalid = min(G, batch - step * G);
@@ -562,6 +574,9 @@ __global__ __launch_bounds__(NTHR, WPE) void dwpw_rr(const int8_t *__restrict__ 
                 uint32_t d[2] = {0u, 0u};
 #pragma unroll
                 for (int q = 0; q < NQ; ++q)
+                    // v_perm packing here, not requant_pack4: this dword is an MFMA operand a few instructions later,
+                    // and a VGPR byte written through SDWA is not forwarded to the matrix pipe in time (measured:
+                    // stale operands, wrong results) -- stores and LDS writes read it correctly
                     d[q] = pack4x<XR4>(requant_t<MG>(acc[u][q][0], dA[q].x, dS[q].x, p.dw.lo_f, p.dw.hi_f),
                                        requant_t<MG>(acc[u][q][1], dA[q].y, dS[q].y, p.dw.lo_f, p.dw.hi_f),
                                        requant_t<MG>(acc[u][q][2], dA[q].z, dS[q].z, p.dw.lo_f, p.dw.hi_f),
@@ -573,10 +588,7 @@ __global__ __launch_bounds__(NTHR, WPE) void dwpw_rr(const int8_t *__restrict__ 
                 for (int m = 0; m < NT; ++m) {
                     v4i pa = {cK[m].x, cK[m].y, cK[m].z, cK[m].w};
                     pa = __builtin_amdgcn_mfma_i32_16x16x32_i8(Apw[m], bop, pa, 0, 0, 0);
-                    packed[m] = pack4x<XR4>(requant_t<MG>(pa[0], cA[m].x, cS[m].x, p.pw.lo_f, p.pw.hi_f),
-                                            requant_t<MG>(pa[1], cA[m].y, cS[m].y, p.pw.lo_f, p.pw.hi_f),
-                                            requant_t<MG>(pa[2], cA[m].z, cS[m].z, p.pw.lo_f, p.pw.hi_f),
-                                            requant_t<MG>(pa[3], cA[m].w, cS[m].w, p.pw.lo_f, p.pw.hi_f));
+                    packed[m] = requant_pack4<MG, XR4>(pa[0], pa[1], pa[2], pa[3], cA[m], cS[m], p.pw.lo_f, p.pw.hi_f);
                 }
                 int ug = 0, uy = 0, ux = 0;
                 coords(t0 + u, ug, uy, ux);
@@ -662,10 +674,10 @@ static void launch_dwpw_rr_t(const int8_t *in, int8_t *out, const DwPwArgs &a, i
     constexpr int lds = (DB ? 2 : 1) * G * (H + 2) * (LP + W * C + LP + ROWPAD) + 512;
     static_assert(lds <= 163840, "staged tiles do not fit the LDS");
     static LaunchState st;
-    const int per_cu = prepared(st, dwpw_rr<H, W, C, S, N, G, NTHR, (DB != 0), CG, CY, ORD, ROWPAD, TS, WPE, MG, XR4>, NTHR, lds);
+    const int per_cu = prepared(st, dwpw_rr<H, W, C, S, N, G, NTHR, DB, CG, CY, ORD, ROWPAD, TS, WPE, MG, XR4>, NTHR, lds);
     const int nsteps = (batch + G - 1) / G;
     const int grid = nsteps < 256 * per_cu ? nsteps : 256 * per_cu;
-    hipLaunchKernelGGL((dwpw_rr<H, W, C, S, N, G, NTHR, (DB != 0), CG, CY, ORD, ROWPAD, TS, WPE, MG, XR4>), dim3(grid), dim3(NTHR),
+    hipLaunchKernelGGL((dwpw_rr<H, W, C, S, N, G, NTHR, DB, CG, CY, ORD, ROWPAD, TS, WPE, MG, XR4>), dim3(grid), dim3(NTHR),
                        lds, s, in, out, a, batch);
 }
 const char *dwpw_rr_name(int H, int W, int C, int S, int N) {

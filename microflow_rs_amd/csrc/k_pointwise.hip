@@ -138,11 +138,7 @@ __global__ __launch_bounds__(256) void pw_mfma(const int8_t *__restrict__ in,
 #pragma unroll
                         for (int ks = 0; ks < KS; ++ks)
                             acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(Aw[q][tt][ks], B[u][ks], acc, 0, 0, 0);
-                        const int q0 = requant_t<MG>(acc[0], cA[tt].x, cS[tt].x, p.lo_f, p.hi_f);
-                        const int q1 = requant_t<MG>(acc[1], cA[tt].y, cS[tt].y, p.lo_f, p.hi_f);
-                        const int q2 = requant_t<MG>(acc[2], cA[tt].z, cS[tt].z, p.lo_f, p.hi_f);
-                        const int q3 = requant_t<MG>(acc[3], cA[tt].w, cS[tt].w, p.lo_f, p.hi_f);
-                        packed[tt] = pack4x<XR4>(q0, q1, q2, q3);
+                        packed[tt] = requant_pack4<MG, XR4>(acc[0], acc[1], acc[2], acc[3], cA[tt], cS[tt], p.lo_f, p.hi_f);
                     }
                     if constexpr (XPOSE) {
                         uint8_t *dstp = patch + wave * CBYTES + lpix * N + g * (NB / 4);

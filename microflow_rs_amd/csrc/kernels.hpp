@@ -199,7 +199,16 @@ struct TailArgs {
     X(6, 6, 128, 2, 256, 8, 512, 0, 4, 1, 3, 16, 0x321, 2)   \
     X(3, 3, 256, 1, 256, 8, 512, 0, 4, 1, 0, 64, 0x021, 2)
 // tuning candidates (MF_DWMM_ALT=<i>), empty in the product build
-#define MF_DWMM_ALT_SHAPES(X)
+#define MF_DWMM_ALT_SHAPES(X)                             \
+    X(12, 12, 64, 1, 64, 2, 256, 0, 1, 4, 0, 16, 0x000, 3)   \
+    X(12, 12, 64, 1, 64, 2, 512, 0, 1, 4, 0, 16, 0x000, 4)   \
+    X(12, 12, 64, 1, 64, 1, 256, 1, 1, 4, 0, 16, 0x000, 3)   \
+    X(6, 6, 128, 1, 128, 4, 256, 0, 4, 2, 2, 16, 0x001, 3)   \
+    X(6, 6, 128, 1, 128, 4, 512, 0, 4, 2, 2, 16, 0x101, 3)   \
+    X(6, 6, 128, 1, 128, 8, 1024, 0, 4, 2, 2, 16, 0x101, 4)  \
+    X(6, 6, 128, 2, 256, 4, 256, 0, 4, 1, 3, 16, 0x021, 3)   \
+    X(3, 3, 256, 1, 256, 4, 256, 0, 4, 1, 0, 64, 0x021, 2)   \
+    X(3, 3, 256, 1, 256, 4, 512, 0, 4, 1, 0, 64, 0x021, 2)
 
 // Pairs with C <= 32 whose intermediate tensor stays in registers (dwpw_rr, k_fused_mm.hip); same columns.
 #define MF_DWRR_SHAPES(X)                                   \
@@ -208,17 +217,13 @@ struct TailArgs {
     X(24, 24, 32, 1, 32, 1, 256, 1, 1, 2, 0, 0, 0x002, 3)   \
     X(24, 24, 32, 2, 64, 1, 192, 1, 1, 4, 0, 32, 0x002, 2)
 #define MF_DWRR_ALT_SHAPES(X)                               \
-    X(48, 48, 8, 1, 16, 1, 256, 1, 1, 4, 0, 32, 0x000, 3)   \
-    X(48, 48, 8, 1, 16, 1, 512, 0, 1, 4, 0, 32, 0x000, 4)   \
-    X(48, 48, 8, 1, 16, 1, 256, 0, 1, 4, 0, 32, 0x000, 4)   \
-    X(48, 48, 16, 2, 32, 1, 256, 1, 1, 2, 0, 32, 0x000, 2)  \
-    X(48, 48, 16, 2, 32, 1, 768, 0, 1, 2, 0, 32, 0x000, 4)  \
-    X(48, 48, 16, 2, 32, 1, 256, 0, 1, 2, 0, 32, 0x000, 3)  \
-    X(24, 24, 32, 1, 32, 1, 768, 1, 1, 2, 0, 0, 0x002, 4)   \
-    X(24, 24, 32, 1, 32, 1, 256, 0, 1, 2, 0, 0, 0x002, 4)   \
-    X(24, 24, 32, 1, 32, 2, 512, 0, 1, 2, 0, 0, 0x002, 4)   \
-    X(24, 24, 32, 2, 64, 1, 192, 0, 1, 4, 0, 32, 0x002, 3)  \
-    X(24, 24, 32, 2, 64, 2, 384, 0, 1, 4, 0, 32, 0x002, 3)
+    X(48, 48, 8, 1, 16, 1, 576, 2, 1, 4, 0, 32, 0x000, 4)   \
+    X(48, 48, 8, 1, 16, 1, 320, 2, 1, 4, 0, 32, 0x000, 3)   \
+    X(48, 48, 16, 2, 32, 1, 832, 2, 1, 2, 0, 32, 0x000, 3)  \
+    X(48, 48, 16, 2, 32, 1, 320, 2, 1, 2, 0, 32, 0x000, 2)  \
+    X(24, 24, 32, 1, 32, 1, 320, 2, 1, 2, 0, 0, 0x002, 3)   \
+    X(24, 24, 32, 1, 32, 1, 832, 2, 1, 2, 0, 0, 0x002, 4)   \
+    X(24, 24, 32, 2, 64, 1, 256, 2, 1, 4, 0, 32, 0x002, 2)
 
 // (K = input channels, N = output channels) with a compiled pointwise MFMA kernel
 #define MF_PW_SHAPES(X) \

@@ -329,7 +329,7 @@ def emulate_rr(shape, seed=1):
     TILE = (H + 2) * ROW
     BUF = G * TILE
     ROWCH = ROWB // 16
-    NWAVE = NTHR // 64
+    NWAVE = NTHR // 64 - (1 if DB == 2 else 0)   # DB == 2: the last wave only loads
     OPIX = OH * OW
     PSY = cgcd(UY, NWAVE)
     PSX = cgcd(UX, NWAVE // PSY)

@@ -1,0 +1,94 @@
+// Microbenchmark: cost of the requantisation epilogue (per packed dword = 4 output bytes) on gfx950, for the
+// packing variants tried in k_common.hpp.  No memory traffic in the loop: this is the VALU floor of every
+// fast kernel.  Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off epi_rate.hip -o epi_rate
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <vector>
+
+#define ITERS 4096
+#define NG 8 // independent dword groups per iteration
+
+__device__ __forceinline__ uint32_t pack4(int a, int b, int c, int d) {
+    const uint32_t lo = __builtin_amdgcn_perm((uint32_t)b, (uint32_t)a, 0x0c0c0400u);
+    const uint32_t hi = __builtin_amdgcn_perm((uint32_t)d, (uint32_t)c, 0x0c0c0400u);
+    return __builtin_amdgcn_perm(hi, lo, 0x05040100u);
+}
+__device__ __forceinline__ float rq(int acc, float A, float S, float lo, float hi) {
+    const float f = __fsub_rn(__int_as_float(acc), 12582912.0f);
+    const float x = __fadd_rn(A, __fmul_rn(S, f));
+    const float r = __fadd_rn(x, __builtin_copysignf(0x1.fffffep-2f, x));
+    return __builtin_amdgcn_fmed3f(r, lo, hi);
+}
+
+template <int V>
+__global__ __launch_bounds__(256) void bench(uint32_t *out, int seed, float A, float S, float lo, float hi) {
+    int acc[NG][4];
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[g][k] = 0x4B400000 + (int)(threadIdx.x * 37 + g * 11 + k * 3 + seed) % 4000;
+    uint32_t sum = 0;
+    for (int it = 0; it < ITERS; ++it) {
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            uint32_t d = 0;
+            if (V == 0) { // requant + v_cvt + 3 v_perm (r01)
+                d = pack4((int)rq(acc[g][0], A, S, lo, hi), (int)rq(acc[g][1], A, S, lo, hi), (int)rq(acc[g][2], A, S, lo, hi),
+                          (int)rq(acc[g][3], A, S, lo, hi));
+            } else if (V == 1) { // SDWA cvt into byte k, dependent chain, s_nop between
+                const float r0 = rq(acc[g][0], A, S, lo, hi), r1 = rq(acc[g][1], A, S, lo, hi), r2 = rq(acc[g][2], A, S, lo, hi),
+                            r3 = rq(acc[g][3], A, S, lo, hi);
+                asm("v_cvt_i32_f32_sdwa %0, %1 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:DWORD\n\ts_nop 0\n\t"
+                    "v_cvt_i32_f32_sdwa %0, %2 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD\n\ts_nop 0\n\t"
+                    "v_cvt_i32_f32_sdwa %0, %3 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD\n\ts_nop 0\n\t"
+                    "v_cvt_i32_f32_sdwa %0, %4 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:DWORD\n\ts_nop 0"
+                    : "=&v"(d) : "v"(r0), "v"(r1), "v"(r2), "v"(r3));
+            } else if (V == 2) { // requant only (no conversion, no packing): lower bound of the float part
+                d = __float_as_uint(rq(acc[g][0], A, S, lo, hi)) ^ __float_as_uint(rq(acc[g][1], A, S, lo, hi)) ^
+                    __float_as_uint(rq(acc[g][2], A, S, lo, hi)) ^ __float_as_uint(rq(acc[g][3], A, S, lo, hi));
+            } else if (V == 3) { // v_cvt_pk_u8_f32: truncating conversion + [0,255] clamp + byte insert (u8 domain only)
+                const float r0 = rq(acc[g][0], A, S, lo, hi), r1 = rq(acc[g][1], A, S, lo, hi), r2 = rq(acc[g][2], A, S, lo, hi),
+                            r3 = rq(acc[g][3], A, S, lo, hi);
+                asm("v_cvt_pk_u8_f32 %0, %1, 0, 0\n\t"
+                    "v_cvt_pk_u8_f32 %0, %2, 1, %0\n\t"
+                    "v_cvt_pk_u8_f32 %0, %3, 2, %0\n\t"
+                    "v_cvt_pk_u8_f32 %0, %4, 3, %0"
+                    : "=&v"(d) : "v"(r0), "v"(r1), "v"(r2), "v"(r3));
+            }
+            sum += d;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[g][k] += 1; // one full-rate op per value keeps the loop body live
+        }
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = sum;
+}
+
+template <int V> static double run(uint32_t *d, const char *name, double base_extra) {
+    const int grid = 256 * 8; // 8 blocks of 4 waves per CU = 8 waves per SIMD
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0), hipEventCreate(&e1);
+    hipLaunchKernelGGL(bench<V>, dim3(grid), dim3(256), 0, 0, d, 1, 0.5f, 0.01f, -128.0f, 127.0f);
+    hipEventRecord(e0);
+    for (int r = 0; r < 5; ++r) hipLaunchKernelGGL(bench<V>, dim3(grid), dim3(256), 0, 0, d, r, 0.5f, 0.01f, -128.0f, 127.0f);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    const double groups = 5.0 * grid * 4 /*waves*/ * ITERS * NG;       // wave-level dword groups
+    const double ns_per_group_simd = ms * 1e6 / (groups / 1024.0);      // per SIMD
+    std::printf("%-34s %8.3f ms  %6.2f ns per dword-group per SIMD (%.1f per byte)  [loop overhead included]\n", name, ms,
+                ns_per_group_simd, ns_per_group_simd / 4);
+    (void)base_extra;
+    return ns_per_group_simd;
+}
+
+int main() {
+    uint32_t *d;
+    hipMalloc(&d, 256 * 8 * 256 * 4);
+    run<2>(d, "requant only (no cvt/pack)", 0);
+    run<0>(d, "requant + cvt + 3 v_perm (r01)", 0);
+    run<1>(d, "requant + SDWA cvt (s_nop)", 0);
+    run<3>(d, "requant + v_cvt_pk_u8_f32", 0);
+    return 0;
+}
