@@ -174,6 +174,17 @@ __device__ __forceinline__ void dma16(const int8_t *src_lane, uint8_t *lds_wave_
     __builtin_amdgcn_global_load_lds((gbl_void_t *)src_lane, (lds_void_t *)lds_wave_base, 16, 0, 0);
 }
 
+// ---- helpers of the matrix-pipe depthwise kernels (k_fused_mm.hip, k_stage.hip) ----
+constexpr int cgcd(int a, int b) { return b == 0 ? a : cgcd(b, a % b); }
+// tile swizzle: output bit i = input bit (nibble i of TS) - 1, nibble 0 = no bit
+template <int TS> __device__ __forceinline__ constexpr int tile_swz(int x) {
+    int r = 0;
+    if constexpr ((TS & 0xf) != 0) r |= ((x >> ((TS & 0xf) - 1)) & 1);
+    if constexpr (((TS >> 4) & 0xf) != 0) r |= ((x >> (((TS >> 4) & 0xf) - 1)) & 1) << 1;
+    if constexpr (((TS >> 8) & 0xf) != 0) r |= ((x >> (((TS >> 8) & 0xf) - 1)) & 1) << 2;
+    return r;
+}
+
 // ------------------------------------------------------------------------
 // launchers (host)
 // ------------------------------------------------------------------------

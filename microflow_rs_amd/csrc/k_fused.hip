@@ -5,6 +5,7 @@
 // Arithmetic contract, shared device helpers and launch plumbing: k_common.hpp.
 #include "k_common.hpp"
 #include "k_dwtask.hpp"
+#include "k_tail.hpp"
 
 namespace mf {
 namespace k {
@@ -270,66 +271,8 @@ __global__ __launch_bounds__(256) void tail_pool_head_softmax(const int8_t *__re
     const int lane = threadIdx.x & 63;
     const size_t wave = ((size_t)blockIdx.x * 256 + threadIdx.x) >> 6;
     const size_t nwaves = ((size_t)gridDim.x * 256) >> 6;
-    const int C4 = p.C >> 2;
     const size_t img_elems = (size_t)p.H * p.W * p.C;
-    for (size_t b = wave; b < batch; b += nwaves) {
-        const int8_t *x = in + b * img_elems;
-        int dot[N], vs = 0;
-#pragma unroll
-        for (int n = 0; n < N; ++n) dot[n] = 0;
-        for (int c4 = lane; c4 < C4; c4 += 64) {
-            // ---- average pool of 4 channels ----
-            int s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-            for (int t = 0; t < p.ntaps; ++t) {
-                const uint32_t v = *(const uint32_t *)(x + p.tap_off[t] + 4 * c4);
-                s0 = sdot4(v, 0x00000001u, s0);
-                s1 = sdot4(v, 0x00000100u, s1);
-                s2 = sdot4(v, 0x00010000u, s2);
-                s3 = sdot4(v, 0x01000000u, s3);
-            }
-            int q[4];
-            const int sums[4] = {s0, s1, s2, s3};
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float xf = __fmul_rn(p.inv_len, (float)sums[k]);           // (1/len) * f32(sum)
-                const float y = __fadd_rn(__fmul_rn(p.pool_c0, xf), p.pool_c1);  // c0 * x + c1
-                const float r = __fadd_rn(y, __builtin_copysignf(0x1.fffffep-2f, y));
-                int v = (r != r) ? 0 : (int)__builtin_amdgcn_fmed3f(r, -128.0f, 127.0f);
-                v = max(v, p.pool_lo);
-                q[k] = min(v, p.pool_hi);
-            }
-            const uint32_t qp = pack4(q[0], q[1], q[2], q[3]);
-            // ---- this lane's share of the head dot products ----
-            vs = sdot4(qp, 0x01010101u, vs);
-#pragma unroll
-            for (int n = 0; n < N; ++n)
-                dot[n] = sdot4(qp, *(const uint32_t *)(p.w + (size_t)n * p.C + 4 * c4), dot[n]);
-        }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            vs += __shfl_xor(vs, off, 64);
-#pragma unroll
-            for (int n = 0; n < N; ++n) dot[n] += __shfl_xor(dot[n], off, 64);
-        }
-        // ---- head epilogue (all lanes compute all N: cheap and keeps the softmax uniform) ----
-        int h[N];
-        float e[N], sum = 0.0f;
-#pragma unroll
-        for (int n = 0; n < N; ++n) {
-            const int acc = dot[n] - p.wzp[n] * vs + p.Kc[n];
-            h[n] = requant(acc, p.A[n], p.S[n], p.lo_f, p.hi_f);
-            e[n] = p.exp_table[h[n] + 128];
-            sum = __fadd_rn(sum, e[n]); // one row: column-major order == index order
-        }
-#pragma unroll
-        for (int n = 0; n < N; ++n) {
-            const float prob = __fdiv_rn(e[n], sum);
-            const float qf = __fadd_rn(__fdiv_rn(prob, p.sm_oscale), p.sm_ozp_f);
-            const float r = __fadd_rn(qf, __builtin_copysignf(0x1.fffffep-2f, qf));
-            const int y = (r != r) ? 0 : (int)__builtin_amdgcn_fmed3f(r, -128.0f, 127.0f);
-            if (lane == n) out[b * N + n] = (int8_t)y;
-        }
-    }
+    for (size_t b = wave; b < batch; b += nwaves) tail_one<N>(in + b * img_elems, out + b * N, p, lane);
 }
 
 // ---- launchers ----

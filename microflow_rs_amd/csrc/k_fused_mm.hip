@@ -44,17 +44,6 @@
 namespace mf {
 namespace k {
 
-namespace {
-constexpr int cgcd(int a, int b) { return b == 0 ? a : cgcd(b, a % b); }
-// tile swizzle: output bit i = input bit (nibble i of TS) - 1, nibble 0 = no bit
-template <int TS> __device__ __forceinline__ constexpr int tile_swz(int x) {
-    int r = 0;
-    if constexpr ((TS & 0xf) != 0) r |= ((x >> ((TS & 0xf) - 1)) & 1);
-    if constexpr (((TS >> 4) & 0xf) != 0) r |= ((x >> (((TS >> 4) & 0xf) - 1)) & 1) << 1;
-    if constexpr (((TS >> 8) & 0xf) != 0) r |= ((x >> (((TS >> 8) & 0xf) - 1)) & 1) << 2;
-    return r;
-}
-} // namespace
 
 // LDS bytes of one workgroup.  WPE (template parameter of the kernel) = waves per SIMD the register allocation
 // must leave room for: (workgroups the LDS admits per CU) x (waves per workgroup) / 4, chosen per shape.

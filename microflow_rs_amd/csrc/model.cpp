@@ -38,6 +38,10 @@ struct ModelImpl {
     // the pool -> head conv -> [reshape] -> softmax tail)
     std::vector<FusedImpl *> fused;
     std::vector<int> fused_last;
+    // second level: ops stage_first .. stage_last (seven consecutive pair groups + the tail group) as ONE
+    // persistent kernel (k_stage.hip); the pair groups inside stay available for mf_model_run_until
+    FusedImpl *stage = nullptr;
+    int stage_first = -1, stage_last = -1;
     bool fusion = true;
     size_t cap_batch = 0;
     int8_t *act[2] = {nullptr, nullptr};
@@ -73,6 +77,7 @@ struct ModelImpl {
         drop_graph();
         if (cap_stream) (void)hipStreamDestroy(cap_stream);
         if (copy_stream) (void)hipStreamDestroy(copy_stream);
+        if (stage) fused_destroy(stage); // borrows the pair groups' buffers: first
         for (FusedImpl *f : fused) fused_destroy(f);
         for (OpImpl *o : ops) op_destroy(o);
         free_buffers();
@@ -106,6 +111,9 @@ const ParsedModel &model_parsed(const ModelImpl *m) { return m->pm; }
 static bool fused_at(const ModelImpl *m, int i) {
     return m->fusion && !m->generic && i >= 0 && i < (int)m->fused.size() && m->fused[(size_t)i];
 }
+static bool stage_at(const ModelImpl *m, int i, int last_op) {
+    return m->stage && m->fusion && !m->generic && i == m->stage_first && m->stage_last <= last_op;
+}
 // index of the fused group that swallows op i (without being its first op), or -1
 static int fused_owner(const ModelImpl *m, int i) {
     for (int j = i - 1; j >= 0 && j >= i - 4; --j)
@@ -114,6 +122,9 @@ static int fused_owner(const ModelImpl *m, int i) {
 }
 const char *model_op_kernel(const ModelImpl *m, int i) {
     if (!m->prepared || i < 0 || i >= (int)m->ops.size() || !m->ops[i]) return "";
+    if (stage_at(m, i, (int)m->ops.size() - 1)) return fused_kernel_name(m->stage);
+    if (m->stage && m->fusion && !m->generic && i > m->stage_first && i <= m->stage_last)
+        return "(fused into the previous operator)";
     if (fused_at(m, i)) return fused_kernel_name(m->fused[(size_t)i]);
     if (fused_owner(m, i) >= 0) return "(fused into the previous operator)";
     return op_kernel_name(m->ops[i]);
@@ -211,7 +222,32 @@ void model_prepare(ModelImpl *m, int device, size_t max_batch) {
             }
             if (fused[i]) i = (size_t)fused_last[i]; // groups do not overlap
         }
+        // (4) seven consecutive pair groups followed by the tail group -> the late-stage kernel, if their shapes
+        // are the ones it is written for (ops.hip: fused_stage_create)
+        FusedImpl *stage = nullptr;
+        int stage_first = -1, stage_last = -1;
+        for (size_t i = 0; i + 14 < n && !stage; ++i) {
+            FusedImpl *pairs[7];
+            bool ok = true;
+            for (int k = 0; k < 7 && ok; ++k) {
+                const size_t a = i + 2 * (size_t)k;
+                ok = fused[a] && fused_last[a] == (int)a + 1;
+                pairs[k] = fused[a];
+            }
+            const size_t t = i + 14;
+            if (ok && fused[t] && fused_last[t] > (int)t + 1 && (stage = fused_stage_create(pairs, 7, fused[t])))
+                stage_first = (int)i, stage_last = fused_last[t];
+        }
+        struct StageGuard {
+            FusedImpl *&s;
+            bool keep = false;
+            ~StageGuard() {
+                if (!keep && s) fused_destroy(s);
+            }
+        } sg{stage};
         // commit (nothing below throws)
+        sg.keep = true;
+        m->stage = stage, m->stage_first = stage_first, m->stage_last = stage_last;
         m->device = device;
         m->ops.swap(pend.ops);
         m->fused.swap(pend.fused);
@@ -274,7 +310,10 @@ static const int8_t *run_ops(ModelImpl *m, const int8_t *src, size_t batch, int 
             which ^= 1;
             dst = m->act[which];
         }
-        if (fused_at(m, i) && m->fused_last[(size_t)i] <= last_op) { // the whole group in one launch
+        if (stage_at(m, i, last_op)) { // the whole late stage in one launch
+            fused_run(m->stage, cur, batch, dst, stream);
+            i = m->stage_last;
+        } else if (fused_at(m, i) && m->fused_last[(size_t)i] <= last_op) { // the whole group in one launch
             fused_run(m->fused[(size_t)i], cur, batch, dst, stream);
             i = m->fused_last[(size_t)i];
         } else {
@@ -481,7 +520,11 @@ void model_time_device(ModelImpl *m, const int8_t *d_in, size_t batch, int8_t *d
                         which ^= 1;
                         dst = m->act[which];
                     }
-                    if (fused_at(m, i)) { // the group is timed as one unit (index i), its other ops 0
+                    if (stage_at(m, i, nops - 1)) { // the stage is timed as one unit (index i), its other ops 0
+                        fused_run(m->stage, cur, batch, dst, s);
+                        for (int j = i; j < m->stage_last; ++j) MF_HIP(hipEventRecord(ev[(size_t)j + 1], s));
+                        i = m->stage_last;
+                    } else if (fused_at(m, i)) { // the group is timed as one unit (index i), its other ops 0
                         fused_run(m->fused[(size_t)i], cur, batch, dst, s);
                         for (int j = i; j < m->fused_last[(size_t)i]; ++j) MF_HIP(hipEventRecord(ev[(size_t)j + 1], s));
                         i = m->fused_last[(size_t)i];

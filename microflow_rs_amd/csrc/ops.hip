@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -596,11 +597,14 @@ void op_run_f32(OpImpl *op, const float *d_in, size_t batch, int8_t *d_out, void
 }
 
 struct FusedImpl {
-    enum Kind { DWPW, TAIL, FCSM } kind;
+    enum Kind { DWPW, TAIL, FCSM, STAGE } kind;
     OpImpl *a, *b, *c;
     k::DwPwArgs dwpw;
     k::TailArgs tail;
     std::string name;
+    // STAGE: the whole late stage in one kernel
+    k::StageArgs stage{};
+    std::vector<std::unique_ptr<DevBuf>> stage_w; // pointwise weights in the stage kernel's operand layout
 };
 
 FusedImpl *fused_create(OpImpl *dw, OpImpl *pw) {
@@ -657,10 +661,73 @@ FusedImpl *fused_fc_softmax_create(OpImpl *fc, OpImpl *sm) {
     return new FusedImpl{FusedImpl::FCSM, fc, sm, nullptr, {}, {}, "fc_rowwave_softmax<" + std::to_string(fc->s.N) + ">"};
 }
 
+// Pointwise weights [N][K] as operands A of v_mfma_i32_16x16x64_i8 for the stage kernel: [tile][k-step][lane][16 B],
+// row r = lane & 15 of tile tt is output channel 16 tt + r, K-bytes 64 ks + 16 (lane >> 4) .. + 15
+static std::vector<int8_t> build_pw_plain_weights(const int8_t *w, int K, int N) {
+    const int KS = K / 64, NT = N / 16;
+    std::vector<int8_t> out((size_t)NT * KS * 64 * 16);
+    for (int tt = 0; tt < NT; ++tt)
+        for (int ks = 0; ks < KS; ++ks)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int r = lane & 15, g = lane >> 4;
+                std::memcpy(&out[(((size_t)tt * KS + ks) * 64 + lane) * 16], w + (size_t)(16 * tt + r) * K + 64 * ks + 16 * g, 16);
+            }
+    return out;
+}
+
+// The late stage of a MobileNet-v1 style network (k_stage.hip): pairs[0..4] DepthwiseConv2D 3x3 s1 + Conv2D 1x1 on
+// 6x6x128, pairs[5] the stride-2 pair 6x6x128 -> 3x3x256, pairs[6] the pair on 3x3x256, then the fused tail.
+// `pairs` / `tail` are the already created groups; returns nullptr when the shapes are not exactly that.
+FusedImpl *fused_stage_create(FusedImpl *const *pairs, int npairs, FusedImpl *tail) {
+    static const bool off = getenv("MF_NO_STAGE") != nullptr;
+    if (off || npairs != 7 || !tail || tail->kind != FusedImpl::TAIL) return nullptr;
+    const int want[7][5] = {{6, 128, 1, 128, 0}, {6, 128, 1, 128, 0}, {6, 128, 1, 128, 0}, {6, 128, 1, 128, 0},
+                            {6, 128, 1, 128, 0}, {6, 128, 2, 256, 0}, {3, 256, 1, 256, 0}};
+    for (int i = 0; i < 7; ++i) {
+        const FusedImpl *f = pairs[i];
+        if (!f || f->kind != FusedImpl::DWPW) return nullptr;
+        const OpSpec &d = f->a->s, &q = f->b->s;
+        if (d.H != want[i][0] || d.W != want[i][0] || d.C != want[i][1] || d.sh != want[i][2] || q.N != want[i][3]) return nullptr;
+        if (d.u8 || !f->dwpw.dw.magic || !f->dwpw.pw.magic || !f->dwpw.dw.wmm) return nullptr; // i8, bit-pattern epilogues
+        if (f->dwpw.dw.izp4 != pairs[0]->dwpw.dw.izp4 || f->a->device != pairs[0]->a->device) return nullptr;
+    }
+    if (tail->tail.H != 3 || tail->tail.W != 3 || tail->tail.C != 256 || (tail->tail.N != 2 && tail->tail.N != 4)) return nullptr;
+    std::unique_ptr<FusedImpl> s(new FusedImpl{FusedImpl::STAGE, pairs[0]->a, tail->c, nullptr, {}, {}, "late_stage_6x6x128<4,512,5>"});
+    k::StagePair table[7];
+    for (int i = 0; i < 7; ++i) {
+        const FusedImpl *f = pairs[i];
+        k::StagePair &sp = table[i];
+        sp.dw_wmm = f->dwpw.dw.wmm, sp.dwA = f->dwpw.dw.A, sp.dwS = f->dwpw.dw.S, sp.dwK = f->dwpw.dw.Kc;
+        sp.dw_lo = f->dwpw.dw.lo_f, sp.dw_hi = f->dwpw.dw.hi_f;
+        const OpSpec &q = f->b->s;
+        std::vector<int8_t> host((size_t)q.N * q.C);
+        MF_HIP(hipMemcpy(host.data(), f->b->conv.w, host.size(), hipMemcpyDeviceToHost)); // [N][1][1][C] as uploaded
+        const std::vector<int8_t> prep = build_pw_plain_weights(host.data(), q.C, q.N);
+        s->stage_w.emplace_back(new DevBuf);
+        s->stage_w.back()->upload(prep.data(), prep.size());
+        sp.pw_w = s->stage_w.back()->p;
+        sp.pwA = f->dwpw.pw.A, sp.pwS = f->dwpw.pw.S, sp.pwK = f->dwpw.pw.Kc;
+        sp.pw_lo = f->dwpw.pw.lo_f, sp.pw_hi = f->dwpw.pw.hi_f;
+    }
+    s->stage_w.emplace_back(new DevBuf);
+    s->stage_w.back()->upload(table, sizeof(table));
+    s->stage.pairs = (const k::StagePair *)s->stage_w.back()->p;
+    s->stage.tail = tail->tail;
+    s->stage.izp4 = pairs[0]->dwpw.dw.izp4;
+    return s.release();
+}
+
 void fused_destroy(FusedImpl *f) { delete f; }
 const char *fused_kernel_name(const FusedImpl *f) { return f->name.c_str(); }
 void fused_run(FusedImpl *f, const int8_t *d_in, size_t batch, int8_t *d_out, void *stream) {
     if (!batch) return;
+    if (f->kind == FusedImpl::STAGE) {
+        if (batch > 0x7fffffffull / 4) fail(MF_ERR_INVALID_ARG, "batch too large for one launch");
+        if (!k::launch_late_stage(d_in, d_out, f->stage, (int)batch, (hipStream_t)stream))
+            fail(MF_ERR_UNSUPPORTED, "stage kernel missing");
+        MF_HIP(hipGetLastError());
+        return;
+    }
     if (f->kind == FusedImpl::TAIL) {
         k::launch_tail(d_in, d_out, f->tail, batch, (hipStream_t)stream);
         MF_HIP(hipGetLastError());

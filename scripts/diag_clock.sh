@@ -6,7 +6,7 @@ export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/diag_clock
 mkdir -p $OUT
 cp microflow_rs_amd/libmicroflow_amd.so /tmp/lib_good.so
-for d in 0 1; do
+for d in ${DIAGS:-0 1}; do
   if [ $d != 0 ]; then MF_EXTRA_HIPCC_FLAGS="-DMF_RR_DIAG=$d" python microflow_rs_amd/build.py --force > /tmp/build_$d.log 2>&1; fi
   rm -rf $OUT/pmc_$d
   (cd /tmp && timeout 600 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU --kernel-trace --output-format csv -d $OUT/pmc_$d -- \
@@ -17,7 +17,7 @@ from collections import defaultdict
 acc = defaultdict(lambda: defaultdict(list)); dur = defaultdict(list)
 for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        m = re.search(r"mf::k::(dwpw_[a-z]+<[^>]*>|dw3x3_stem8<[^>]*>)", r["Kernel_Name"])
+        m = re.search(r"mf::k::(dwpw_[a-z]+<[^>]*>|dw3x3_stem8<[^>]*>|late_stage[a-z0-9_]*<[^>]*>)", r["Kernel_Name"])
         if not m: continue
         k = m.group(1).replace(" ", "")[:28]
         acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
