@@ -8,7 +8,8 @@
 // intermediate tensor is the reference's int8 tensor, requantised with the reference's arithmetic -- it just
 // lives in LDS.
 //
-// A step (G = 4 images per workgroup) is a fixed sequence of phases separated by workgroup barriers:
+// A step (G = 4 images per workgroup) is a fixed sequence of phases; a workgroup barrier follows every DEPTHWISE
+// phase only (pointwise(L) -> depthwise(L+1) needs none: a wave reads back the channels it wrote, see below):
 //     depthwise (tile -> MID)   as in dwpw_mm: taps on the matrix pipe, unit = 16 columns x 16 channels,
 //                               wave w owns channel group w (and w + 8 when C = 256)
 //     pointwise (MID -> tile)   wave w owns output channels 16w .. 16w+15 (and 16(w+8) ..) for ALL pixels: its A
@@ -26,6 +27,10 @@
 
 namespace mf {
 namespace k {
+
+#ifndef MF_STAGE_SB
+#define MF_STAGE_SB 1 // items between two scheduling barriers in the 9-item phases (tuning)
+#endif
 
 namespace {
 struct DwW {        // depthwise operands of one 16-channel group
@@ -52,17 +57,23 @@ __global__ __launch_bounds__(NTHR, 4) void late_stage_6x6x128(const int8_t *__re
     constexpr int PIX6 = 36, PIX3 = 9, NP6 = G * PIX6, NP3 = G * PIX3;
     constexpr int PLANE6 = NP6 * 16 + 16, PLANE3 = NP3 * 16 + 16; // MID planes [16-channel group][pixel][16 B]
     constexpr int IMG6 = PIX6 * 128;
-    constexpr int OFF_T3 = G * TILE6 + 512;
-    constexpr int OFF_M = OFF_T3 + G * TILE3 + 512;
-    constexpr int OFF_X3 = OFF_M + 16 * PLANE3; // [pixel][256] input of the tail, behind the 3x3x256 MID planes
-    constexpr int MBYTES = (8 * PLANE6 > 16 * PLANE3 + NP3 * 256) ? 8 * PLANE6 : 16 * PLANE3 + NP3 * 256;
-    static_assert(OFF_M + MBYTES <= 81920, "two workgroups per CU");
+    // LDS regions.  B: MID of the even 6x6 pairs, later the 3x3x256 halo tile.  A: MID of the odd 6x6 pairs, later
+    // the 3x3x256 MID planes followed by [3x3x128 MID planes | the tail's plain [pixel][256] input] (the second
+    // takes over when the first is dead).  Two MID buffers let a wave run pointwise(L) -> depthwise(L+1) without a
+    // barrier: it only reads the channels it wrote itself, and writes the buffer nobody is still reading.
+    constexpr int OFF_B = G * TILE6 + 512, OFF_T3 = OFF_B;
+    constexpr int BBYTES = G * TILE3 > 8 * PLANE6 ? G * TILE3 : 8 * PLANE6;
+    constexpr int OFF_A = OFF_B + BBYTES + 512;
+    constexpr int OFF_M3B = OFF_A, OFF_M3A = OFF_A + 16 * PLANE3, OFF_X3 = OFF_M3A;
+    constexpr int ABYTES = (8 * PLANE6 > 16 * PLANE3 + NP3 * 256) ? 8 * PLANE6 : 16 * PLANE3 + NP3 * 256;
+    static_assert(OFF_A + ABYTES <= 81920, "two workgroups per CU");
+    static_assert(NREP % 2 == 1, "the last 6x6 pair must use region B's MID (region A is the stride-2 pair's)");
 
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-    for (int i = tid; i < OFF_M / 16; i += NTHR) ((uint4 *)lds)[i] = make_uint4(p.izp4, p.izp4, p.izp4, p.izp4);
+    for (int i = tid; i < OFF_A / 16; i += NTHR) ((uint4 *)lds)[i] = make_uint4(p.izp4, p.izp4, p.izp4, p.izp4);
 
     // ---- lane constants ----
     const int col = lane & 15, g = lane >> 4;
@@ -165,7 +176,7 @@ __global__ __launch_bounds__(NTHR, 4) void late_stage_6x6x128(const int8_t *__re
         acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(w.A[1], t.b[1], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(w.A[2], t.b[2], acc, 0, 0, 0);
         const uint32_t d = requant_pack4<true, 0u>(acc[0], acc[1], acc[2], acc[3], w.a, w.s, lo, hi);
-        if (valid) *(uint32_t *)(lds + OFF_M + maddr) = d;
+        if (valid) *(uint32_t *)(lds + maddr) = d;
     };
     // three units one row step apart (the 3x3 outputs): taddr / maddr advance by trow / 48 bytes
     auto dw_rows3 = [&](const DwW &w, int taddr, int trow, int rowpitch, int maddr, float lo, float hi, bool valid) {
@@ -179,6 +190,17 @@ __global__ __launch_bounds__(NTHR, 4) void late_stage_6x6x128(const int8_t *__re
             cur = nxt;
         }
     };
+
+    // Region B serves as a MID buffer during the 6x6 pairs, which overwrites the halo of the 3x3x256 tile living
+    // there afterwards.  Every wave therefore re-fills, for ITS two channel groups (the only ones it will read), the
+    // 16 halo pixel slots of each image -- one slot per lane: rows 0 and 4 (x = -1 .. 3), x = -1 and 3 of rows 1 .. 3.
+    int h3;
+    {
+        const int img = lane >> 4, sl = lane & 15;
+        const int row = sl < 5 ? 0 : (sl < 10 ? 4 : 1 + (sl - 10) / 2);
+        const int x = sl < 5 ? sl - 1 : (sl < 10 ? sl - 6 : (((sl - 10) & 1) ? 3 : -1));
+        h3 = OFF_T3 + img * TILE3 + row * ROW3 + LP3 + x * 256 + 16 * (wave ^ tile_swz<TS3>(x));
+    }
 
     auto stage = [&](int st) { // G images, 6 rows each, one 768-byte DMA per row, group index swizzled like TS6
         const int src_lane = lane ^ tile_swz<TS6>(lane >> 3);
@@ -205,41 +227,46 @@ __global__ __launch_bounds__(NTHR, 4) void late_stage_6x6x128(const int8_t *__re
 
         // ---------------- NREP pairs on 6x6x128 ----------------
         for (int rep = 0; rep < NREP; ++rep) {
-            const PwW<2> wp = load_pw2(rep, wave); // lands during the depthwise phase
+            const int mid = (rep & 1) ? OFF_A : OFF_B; // this pair's MID buffer
+            const PwW<2> wp = load_pw2(rep, wave);     // lands during the depthwise phase
             {
                 const float lo = pairs[rep].dw_lo, hi = pairs[rep].dw_hi;
+                const int mb = mid + mb6;
                 Taps cur = dw_load(tb6, ROW6);
 #pragma unroll
                 for (int u = 0; u < 9; ++u) {
                     Taps nxt = cur;
                     if (u < 8) nxt = dw_load(tb6 + ((u + 1) / 3) * 2 * ROW6 + ((u + 1) % 3) * 2 * 128, ROW6);
-                    dw_finish(wd, cur, mb6 + ((u / 3) * 12 + (u % 3) * 2) * 16, lo, hi, true);
-                    __builtin_amdgcn_sched_barrier(0);
+                    dw_finish(wd, cur, mb + ((u / 3) * 12 + (u % 3) * 2) * 16, lo, hi, true);
+                    if (u % MF_STAGE_SB == MF_STAGE_SB - 1) __builtin_amdgcn_sched_barrier(0);
                     cur = nxt;
                 }
             }
-            __syncthreads(); // MID complete; the tile may be overwritten
+            __syncthreads(); // MID complete (every channel group); every wave is done reading the tile
             wd = load_dw(rep + 1, wave); // the next pair's depthwise (pair NREP = the stride-2 pair), lands during the pointwise phase
             {
                 const float lo = pairs[rep].pw_lo, hi = pairs[rep].pw_hi;
-                v4i b0 = *(const v4i *)(lds + OFF_M + pg * PLANE6 + pcol * 16);
-                v4i b1 = *(const v4i *)(lds + OFF_M + (pg + 4) * PLANE6 + pcol * 16);
+                const int rb = mid + pg * PLANE6 + pcol * 16;
+                v4i b0 = *(const v4i *)(lds + rb);
+                v4i b1 = *(const v4i *)(lds + rb + 4 * PLANE6);
 #pragma unroll
                 for (int c = 0; c < 9; ++c) {
                     v4i n0 = b0, n1 = b1;
                     if (c < 8) {
-                        n0 = *(const v4i *)(lds + OFF_M + pg * PLANE6 + ((c + 1) * 16 + pcol) * 16);
-                        n1 = *(const v4i *)(lds + OFF_M + (pg + 4) * PLANE6 + ((c + 1) * 16 + pcol) * 16);
+                        n0 = *(const v4i *)(lds + rb + (c + 1) * 256);
+                        n1 = *(const v4i *)(lds + rb + 4 * PLANE6 + (c + 1) * 256);
                     }
                     v4i acc = {wp.k.x, wp.k.y, wp.k.z, wp.k.w};
                     acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(wp.A[0], b0, acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(wp.A[1], b1, acc, 0, 0, 0);
                     *(uint32_t *)(lds + o6[c]) = requant_pack4<true, 0u>(acc[0], acc[1], acc[2], acc[3], wp.a, wp.s, lo, hi);
-                    __builtin_amdgcn_sched_barrier(0);
+                    if (c % MF_STAGE_SB == MF_STAGE_SB - 1) __builtin_amdgcn_sched_barrier(0);
                     b0 = n0, b1 = n1;
                 }
             }
-            __syncthreads(); // the next depthwise's input tile is complete
+            // NO barrier: the next depthwise of this wave reads channel group `wave` of the tile -- exactly the bytes
+            // this wave has just written (LDS operations of a wave complete in order) -- and writes the other MID buffer
+            asm volatile("" ::: "memory");
         }
 
         // ---------------- stride-2 pair: 6x6x128 -> 3x3x128 -> 3x3x256 ----------------
@@ -248,12 +275,17 @@ __global__ __launch_bounds__(NTHR, 4) void late_stage_6x6x128(const int8_t *__re
         PwW<2> wp2 = load_pw2(NREP, wave);
         {
             const float lo = pairs[NREP].dw_lo, hi = pairs[NREP].dw_hi;
-            dw_rows3(wd, tb6s, 2 * ROW6, ROW6, mb3, lo, hi, b_valid);
+            dw_rows3(wd, tb6s, 2 * ROW6, ROW6, OFF_M3A + mb3, lo, hi, b_valid);
         }
-        __syncthreads(); // 3x3x128 MID complete; the 6x6 tile is dead
+        __syncthreads(); // 3x3x128 MID complete; the 6x6 tile and the last 6x6 MID (region B) are dead
         {
             const int next = step + gridDim.x;
-            if (next < nsteps) stage(next); // flies during the remaining four phases
+            if (next < nsteps) stage(next); // flies during the remaining phases
+        }
+        {
+            const uint4 z = make_uint4(p.izp4, p.izp4, p.izp4, p.izp4);
+            *(uint4 *)(lds + h3) = z;       // channel group `wave`
+            *(uint4 *)(lds + h3 + 128) = z; // channel group `wave + 8`
         }
         auto pw24 = [&](const PwW<2> &w, int t) {
             const float lo = pairs[NREP].pw_lo, hi = pairs[NREP].pw_hi;
@@ -261,8 +293,8 @@ __global__ __launch_bounds__(NTHR, 4) void late_stage_6x6x128(const int8_t *__re
             for (int c = 0; c < 3; ++c) {
                 int pix = c * 16 + pcol;
                 pix = pix < NP3 ? pix : NP3 - 1;
-                const v4i b0 = *(const v4i *)(lds + OFF_M + pg * PLANE3 + pix * 16);
-                const v4i b1 = *(const v4i *)(lds + OFF_M + (pg + 4) * PLANE3 + pix * 16);
+                const v4i b0 = *(const v4i *)(lds + OFF_M3A + pg * PLANE3 + pix * 16);
+                const v4i b1 = *(const v4i *)(lds + OFF_M3A + (pg + 4) * PLANE3 + pix * 16);
                 v4i acc = {w.k.x, w.k.y, w.k.z, w.k.w};
                 acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(w.A[0], b0, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(w.A[1], b1, acc, 0, 0, 0);
@@ -276,16 +308,16 @@ __global__ __launch_bounds__(NTHR, 4) void late_stage_6x6x128(const int8_t *__re
             wd = load_dw(NREP + 1, wave);
             pw24(wb, 1);
         }
-        __syncthreads(); // the 3x3x256 tile is complete
+        asm volatile("" ::: "memory"); // no barrier: channel groups wave and wave + 8 of the 3x3x256 tile are this wave's own
 
         // ---------------- pair on 3x3x256 ----------------
         {
             const float lo = pairs[NREP + 1].dw_lo, hi = pairs[NREP + 1].dw_hi;
             const DwW wdb = load_dw(NREP + 1, wave + 8);
-            dw_rows3(wd, tb3, ROW3, ROW3, mb3, lo, hi, b_valid);
+            dw_rows3(wd, tb3, ROW3, ROW3, OFF_M3B + mb3, lo, hi, b_valid);
             const PwW<4> wqa = load_pw4(NREP + 1, wave);
-            dw_rows3(wdb, tb3 + 8 * 16, ROW3, ROW3, mb3 + 8 * PLANE3, lo, hi, b_valid);
-            __syncthreads(); // 3x3x256 MID complete
+            dw_rows3(wdb, tb3 + 8 * 16, ROW3, ROW3, OFF_M3B + mb3 + 8 * PLANE3, lo, hi, b_valid);
+            __syncthreads(); // 3x3x256 MID complete; the 3x3x128 MID is dead (its space becomes the tail's input)
             auto pw26 = [&](const PwW<4> &w, int tt) {
                 const float plo = pairs[NREP + 1].pw_lo, phi = pairs[NREP + 1].pw_hi;
 #pragma unroll
@@ -296,7 +328,7 @@ __global__ __launch_bounds__(NTHR, 4) void late_stage_6x6x128(const int8_t *__re
                     v4i acc = {w.k.x, w.k.y, w.k.z, w.k.w};
 #pragma unroll
                     for (int ks = 0; ks < 4; ++ks) {
-                        const v4i b = *(const v4i *)(lds + OFF_M + (pg + 4 * ks) * PLANE3 + pix * 16);
+                        const v4i b = *(const v4i *)(lds + OFF_M3B + (pg + 4 * ks) * PLANE3 + pix * 16);
                         acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(w.A[ks], b, acc, 0, 0, 0);
                     }
                     const uint32_t d = requant_pack4<true, 0u>(acc[0], acc[1], acc[2], acc[3], w.a, w.s, plo, phi);
