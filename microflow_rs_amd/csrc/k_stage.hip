@@ -25,11 +25,23 @@
 #include "k_common.hpp"
 #include "k_tail.hpp"
 
+#include <cstdio>
+
 namespace mf {
 namespace k {
 
+#ifndef MF_STAGE_DIAG
+#define MF_STAGE_DIAG 0
+#endif
 #ifndef MF_STAGE_SB
 #define MF_STAGE_SB 1 // items between two scheduling barriers in the 9-item phases (tuning)
+#endif
+
+#if MF_STAGE_DIAG == 2 // diagnostics build: cycle stamps of block 0 / wave 0 at every phase boundary of its 2nd step
+__device__ long long g_stage_trace[32];
+#define MF_TR(k) do { if (blockIdx.x == 0 && wave == 0 && lane == 0 && trace_step == 1) g_stage_trace[k] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define MF_TR(k) do { } while (0)
 #endif
 
 namespace {
@@ -50,12 +62,15 @@ __global__ __launch_bounds__(NTHR, 4) void late_stage_6x6x128(const int8_t *__re
                                                               StageArgs p, int batch) {
     static_assert(G == 4 && NTHR == 512, "column grids below are written for 4 images and 8 waves");
     constexpr int NWAVE = 8;
-    // 6x6x128 halo tile (the layout of dwpw_mm<6,6,128,...>: column grid 4 images x 2 rows x 2 x, y fastest)
-    constexpr int LP6 = 128, ROW6 = 128 + 768 + 128 + 16, TILE6 = 8 * ROW6, TS6 = 0x101;
+    // 6x6x128 halo tile.  Depthwise column grid: 2 rows x 2 x x 4 images (y fastest).  Row pitch +32, image pitch
+    // +64 and the group index XOR (x & 1) make every tap read conflict-free and the other three access patterns of
+    // a pair 1.5x / 2x / 1x their ideal LDS cycles (scripts/model/stage_banks.py: 270 cycles per wave and pair
+    // against 464 for the dwpw_mm<6,6,128> layout this kernel started with).
+    constexpr int LP6 = 128, ROW6 = 128 + 768 + 128 + 32, TILE6 = 8 * ROW6 + 64, TS6 = 0x001;
     // 3x3x256 halo tile (column grid 4 images x 1 row x 4 x: one x position is padding)
     constexpr int LP3 = 256, ROW3 = 256 + 768 + 256 + 64, TILE3 = 5 * ROW3, TS3 = 0x021;
     constexpr int PIX6 = 36, PIX3 = 9, NP6 = G * PIX6, NP3 = G * PIX3;
-    constexpr int PLANE6 = NP6 * 16 + 16, PLANE3 = NP3 * 16 + 16; // MID planes [16-channel group][pixel][16 B]
+    constexpr int PLANE6 = NP6 * 16, PLANE3 = NP3 * 16; // MID planes [16-channel group][pixel][16 B]
     constexpr int IMG6 = PIX6 * 128;
     // LDS regions.  B: MID of the even 6x6 pairs, later the 3x3x256 halo tile.  A: MID of the odd 6x6 pairs, later
     // the 3x3x256 MID planes followed by [3x3x128 MID planes | the tail's plain [pixel][256] input] (the second
@@ -77,8 +92,8 @@ __global__ __launch_bounds__(NTHR, 4) void late_stage_6x6x128(const int8_t *__re
 
     // ---- lane constants ----
     const int col = lane & 15, g = lane >> 4;
-    // depthwise 6x6 stride 1: columns = (row parity cy, image cg, x parity cx), units = 3 row pairs x 3 x pairs
-    const int a_cy = col & 1, a_cg = (col >> 1) & 3, a_cx = col >> 3;
+    // depthwise 6x6 stride 1: columns = (row parity cy, x parity cx, image cg), units = 3 row pairs x 3 x pairs
+    const int a_cy = col & 1, a_cx = (col >> 1) & 1, a_cg = col >> 2;
     const int a_xl = a_cx + g - 1;
     const int tb6 = a_cg * TILE6 + a_cy * ROW6 + LP6 + a_xl * 128 + 16 * (wave ^ tile_swz<TS6>(a_xl));
     const int mb6 = wave * PLANE6 + (a_cg * PIX6 + a_cy * 6 + a_cx) * 16 + 4 * g;
@@ -133,7 +148,7 @@ __global__ __launch_bounds__(NTHR, 4) void late_stage_6x6x128(const int8_t *__re
         for (int ty = 0; ty < 3; ++ty) w.A[ty] = ld16((const uint8_t *)sp.dw_wmm + (q * 3 + ty) * 1024, l16);
         w.a = ldf4((const uint8_t *)sp.dwA + q * 64, g16);
         w.s = ldf4((const uint8_t *)sp.dwS + q * 64, g16);
-        w.k = magic4<true>(ldi4((const uint8_t *)sp.dwK + q * 64, g16));
+        w.k = ldi4((const uint8_t *)sp.dwK + q * 64, g16); // (the host added the bit-pattern offset: no dependent VALU here)
         return w;
     };
     auto load_pw2 = [&](int pair, int tt) {
@@ -143,7 +158,7 @@ __global__ __launch_bounds__(NTHR, 4) void late_stage_6x6x128(const int8_t *__re
         for (int ks = 0; ks < 2; ++ks) w.A[ks] = ld16((const uint8_t *)sp.pw_w + (tt * 2 + ks) * 1024, l16);
         w.a = ldf4((const uint8_t *)sp.pwA + tt * 64, pg16);
         w.s = ldf4((const uint8_t *)sp.pwS + tt * 64, pg16);
-        w.k = magic4<true>(ldi4((const uint8_t *)sp.pwK + tt * 64, pg16));
+        w.k = ldi4((const uint8_t *)sp.pwK + tt * 64, pg16);
         return w;
     };
     auto load_pw4 = [&](int pair, int tt) {
@@ -153,7 +168,7 @@ __global__ __launch_bounds__(NTHR, 4) void late_stage_6x6x128(const int8_t *__re
         for (int ks = 0; ks < 4; ++ks) w.A[ks] = ld16((const uint8_t *)sp.pw_w + (tt * 4 + ks) * 1024, l16);
         w.a = ldf4((const uint8_t *)sp.pwA + tt * 64, pg16);
         w.s = ldf4((const uint8_t *)sp.pwS + tt * 64, pg16);
-        w.k = magic4<true>(ldi4((const uint8_t *)sp.pwK + tt * 64, pg16));
+        w.k = ldi4((const uint8_t *)sp.pwK + tt * 64, pg16);
         return w;
     };
     // Items (depthwise units, pointwise chunks) run as a two-deep software pipeline: the operand loads of item
@@ -178,17 +193,45 @@ __global__ __launch_bounds__(NTHR, 4) void late_stage_6x6x128(const int8_t *__re
         const uint32_t d = requant_pack4<true, 0u>(acc[0], acc[1], acc[2], acc[3], w.a, w.s, lo, hi);
         if (valid) *(uint32_t *)(lds + maddr) = d;
     };
+    // Depthwise items i = 0 .. N-1 at tile offsets taddr + toff(i), MID offsets maddr + moff(i), as a three-stage
+    // pipeline: the taps of item i + 2 are loaded, the three MFMAs of item i + 1 are issued BETWEEN the pieces of item
+    // i's requantisation (an MFMA is asynchronous: its ~40 cycles pass under the next ~16 VALU instructions instead
+    // of stalling the wave, which executes in order), then item i's packed dword is written.
+    auto dw_pipe = [&](auto n_c, const DwW &w, int taddr, int rowpitch, int maddr, float lo, float hi, bool valid, auto toff,
+                       auto moff) {
+        constexpr int NI = decltype(n_c)::value;
+        Taps t1 = dw_load(taddr + toff(0), rowpitch), t2 = t1;
+        if (NI > 1) t2 = dw_load(taddr + toff(1), rowpitch);
+        v4i acc = {w.k.x, w.k.y, w.k.z, w.k.w};
+        acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(w.A[0], t1.b[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(w.A[1], t1.b[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(w.A[2], t1.b[2], acc, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const bool more = i + 1 < NI;
+            Taps t3 = t2;
+            if (i + 2 < NI) t3 = dw_load(taddr + toff(i + 2), rowpitch);
+            v4i nxt = {w.k.x, w.k.y, w.k.z, w.k.w};
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) nxt = __builtin_amdgcn_mfma_i32_16x16x64_i8(w.A[0], t2.b[0], nxt, 0, 0, 0);
+            const float r0 = requant_clamped<true>(acc[0], w.a.x, w.s.x, lo, hi);
+            const float r1 = requant_clamped<true>(acc[1], w.a.y, w.s.y, lo, hi);
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) nxt = __builtin_amdgcn_mfma_i32_16x16x64_i8(w.A[1], t2.b[1], nxt, 0, 0, 0);
+            const float r2 = requant_clamped<true>(acc[2], w.a.z, w.s.z, lo, hi);
+            const float r3 = requant_clamped<true>(acc[3], w.a.w, w.s.w, lo, hi);
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) nxt = __builtin_amdgcn_mfma_i32_16x16x64_i8(w.A[2], t2.b[2], nxt, 0, 0, 0);
+            const uint32_t d = cvt_pack4(r0, r1, r2, r3);
+            if (valid) *(uint32_t *)(lds + maddr + moff(i)) = d;
+            __builtin_amdgcn_sched_barrier(0);
+            acc = nxt, t2 = t3;
+        }
+    };
     // three units one row step apart (the 3x3 outputs): taddr / maddr advance by trow / 48 bytes
     auto dw_rows3 = [&](const DwW &w, int taddr, int trow, int rowpitch, int maddr, float lo, float hi, bool valid) {
-        Taps cur = dw_load(taddr, rowpitch);
-#pragma unroll
-        for (int uy = 0; uy < 3; ++uy) {
-            Taps nxt = cur;
-            if (uy < 2) nxt = dw_load(taddr + (uy + 1) * trow, rowpitch);
-            dw_finish(w, cur, maddr + uy * 3 * 16, lo, hi, valid);
-            __builtin_amdgcn_sched_barrier(0);
-            cur = nxt;
-        }
+        dw_pipe(std::integral_constant<int, 3>{}, w, taddr, rowpitch, maddr, lo, hi, valid, [trow](int u) { return u * trow; },
+                [](int u) { return u * 3 * 16; });
     };
 
     // Region B serves as a MID buffer during the 6x6 pairs, which overwrites the halo of the 3x3x256 tile living
@@ -218,52 +261,75 @@ __global__ __launch_bounds__(NTHR, 4) void late_stage_6x6x128(const int8_t *__re
     int step = blockIdx.x;
     if (step < nsteps) stage(step);
     DwW wd = load_dw(0, wave);
+#if MF_STAGE_DIAG == 1
+    const PwW<2> wp_diag = load_pw2(0, wave);
+#endif
 
+#if MF_STAGE_DIAG == 2
+    int trace_step = 0;
+#endif
     for (; step < nsteps; step += gridDim.x) {
+        MF_TR(24);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads(); // this step's images are in the 6x6 tile; the previous step's tail is done with its input
         asm volatile("" : "+s"(pairs));
         const int gvalid = min(G, batch - step * G);
+        MF_TR(0);
 
         // ---------------- NREP pairs on 6x6x128 ----------------
         for (int rep = 0; rep < NREP; ++rep) {
             const int mid = (rep & 1) ? OFF_A : OFF_B; // this pair's MID buffer
+#if MF_STAGE_DIAG == 1 // diagnostics build (wrong results): no per-pair operand fetches inside the 6x6 loop
+            const PwW<2> wp = wp_diag;
+#else
             const PwW<2> wp = load_pw2(rep, wave);     // lands during the depthwise phase
+#endif
             {
                 const float lo = pairs[rep].dw_lo, hi = pairs[rep].dw_hi;
                 const int mb = mid + mb6;
-                Taps cur = dw_load(tb6, ROW6);
-#pragma unroll
-                for (int u = 0; u < 9; ++u) {
-                    Taps nxt = cur;
-                    if (u < 8) nxt = dw_load(tb6 + ((u + 1) / 3) * 2 * ROW6 + ((u + 1) % 3) * 2 * 128, ROW6);
-                    dw_finish(wd, cur, mb + ((u / 3) * 12 + (u % 3) * 2) * 16, lo, hi, true);
-                    if (u % MF_STAGE_SB == MF_STAGE_SB - 1) __builtin_amdgcn_sched_barrier(0);
-                    cur = nxt;
-                }
+                dw_pipe(std::integral_constant<int, 9>{}, wd, tb6, ROW6, mb, lo, hi, true,
+                        [](int u) { return (u / 3) * 2 * ROW6 + (u % 3) * 2 * 128; },
+                        [](int u) { return ((u / 3) * 12 + (u % 3) * 2) * 16; });
             }
+            MF_TR(1 + 3 * rep);
             __syncthreads(); // MID complete (every channel group); every wave is done reading the tile
+            MF_TR(2 + 3 * rep);
+#if MF_STAGE_DIAG != 1
             wd = load_dw(rep + 1, wave); // the next pair's depthwise (pair NREP = the stride-2 pair), lands during the pointwise phase
+#endif
             {
                 const float lo = pairs[rep].pw_lo, hi = pairs[rep].pw_hi;
                 const int rb = mid + pg * PLANE6 + pcol * 16;
-                v4i b0 = *(const v4i *)(lds + rb);
-                v4i b1 = *(const v4i *)(lds + rb + 4 * PLANE6);
+                // same pipeline: operands of chunk c + 2 loaded, the two MFMAs of chunk c + 1 between the halves of
+                // chunk c's requantisation
+                v4i b0 = *(const v4i *)(lds + rb), b1 = *(const v4i *)(lds + rb + 4 * PLANE6);
+                v4i c0 = *(const v4i *)(lds + rb + 256), c1 = *(const v4i *)(lds + rb + 4 * PLANE6 + 256);
+                v4i acc = {wp.k.x, wp.k.y, wp.k.z, wp.k.w};
+                acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(wp.A[0], b0, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(wp.A[1], b1, acc, 0, 0, 0);
 #pragma unroll
                 for (int c = 0; c < 9; ++c) {
-                    v4i n0 = b0, n1 = b1;
-                    if (c < 8) {
-                        n0 = *(const v4i *)(lds + rb + (c + 1) * 256);
-                        n1 = *(const v4i *)(lds + rb + 4 * PLANE6 + (c + 1) * 256);
+                    const bool more = c + 1 < 9;
+                    v4i e0 = c0, e1 = c1;
+                    if (c + 2 < 9) {
+                        e0 = *(const v4i *)(lds + rb + (c + 2) * 256);
+                        e1 = *(const v4i *)(lds + rb + 4 * PLANE6 + (c + 2) * 256);
                     }
-                    v4i acc = {wp.k.x, wp.k.y, wp.k.z, wp.k.w};
-                    acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(wp.A[0], b0, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(wp.A[1], b1, acc, 0, 0, 0);
-                    *(uint32_t *)(lds + o6[c]) = requant_pack4<true, 0u>(acc[0], acc[1], acc[2], acc[3], wp.a, wp.s, lo, hi);
-                    if (c % MF_STAGE_SB == MF_STAGE_SB - 1) __builtin_amdgcn_sched_barrier(0);
-                    b0 = n0, b1 = n1;
+                    v4i nxt = {wp.k.x, wp.k.y, wp.k.z, wp.k.w};
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (more) nxt = __builtin_amdgcn_mfma_i32_16x16x64_i8(wp.A[0], c0, nxt, 0, 0, 0);
+                    const float r0 = requant_clamped<true>(acc[0], wp.a.x, wp.s.x, lo, hi);
+                    const float r1 = requant_clamped<true>(acc[1], wp.a.y, wp.s.y, lo, hi);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (more) nxt = __builtin_amdgcn_mfma_i32_16x16x64_i8(wp.A[1], c1, nxt, 0, 0, 0);
+                    const float r2 = requant_clamped<true>(acc[2], wp.a.z, wp.s.z, lo, hi);
+                    const float r3 = requant_clamped<true>(acc[3], wp.a.w, wp.s.w, lo, hi);
+                    *(uint32_t *)(lds + o6[c]) = cvt_pack4(r0, r1, r2, r3);
+                    __builtin_amdgcn_sched_barrier(0);
+                    acc = nxt, c0 = e0, c1 = e1;
                 }
             }
+            MF_TR(3 + 3 * rep);
             // NO barrier: the next depthwise of this wave reads channel group `wave` of the tile -- exactly the bytes
             // this wave has just written (LDS operations of a wave complete in order) -- and writes the other MID buffer
             asm volatile("" ::: "memory");
@@ -277,7 +343,9 @@ __global__ __launch_bounds__(NTHR, 4) void late_stage_6x6x128(const int8_t *__re
             const float lo = pairs[NREP].dw_lo, hi = pairs[NREP].dw_hi;
             dw_rows3(wd, tb6s, 2 * ROW6, ROW6, OFF_M3A + mb3, lo, hi, b_valid);
         }
+        MF_TR(16);
         __syncthreads(); // 3x3x128 MID complete; the 6x6 tile and the last 6x6 MID (region B) are dead
+        MF_TR(17);
         {
             const int next = step + gridDim.x;
             if (next < nsteps) stage(next); // flies during the remaining phases
@@ -308,6 +376,7 @@ __global__ __launch_bounds__(NTHR, 4) void late_stage_6x6x128(const int8_t *__re
             wd = load_dw(NREP + 1, wave);
             pw24(wb, 1);
         }
+        MF_TR(18);
         asm volatile("" ::: "memory"); // no barrier: channel groups wave and wave + 8 of the 3x3x256 tile are this wave's own
 
         // ---------------- pair on 3x3x256 ----------------
@@ -317,7 +386,9 @@ __global__ __launch_bounds__(NTHR, 4) void late_stage_6x6x128(const int8_t *__re
             dw_rows3(wd, tb3, ROW3, ROW3, OFF_M3B + mb3, lo, hi, b_valid);
             const PwW<4> wqa = load_pw4(NREP + 1, wave);
             dw_rows3(wdb, tb3 + 8 * 16, ROW3, ROW3, OFF_M3B + mb3 + 8 * PLANE3, lo, hi, b_valid);
+            MF_TR(19);
             __syncthreads(); // 3x3x256 MID complete; the 3x3x128 MID is dead (its space becomes the tail's input)
+            MF_TR(20);
             auto pw26 = [&](const PwW<4> &w, int tt) {
                 const float plo = pairs[NREP + 1].pw_lo, phi = pairs[NREP + 1].pw_hi;
 #pragma unroll
@@ -340,18 +411,27 @@ __global__ __launch_bounds__(NTHR, 4) void late_stage_6x6x128(const int8_t *__re
             wd = load_dw(0, wave); // for the next step
             pw26(wqb, wave + 8);
         }
+        MF_TR(21);
         __syncthreads(); // the tail's input is complete
+        MF_TR(22);
 
         // ---------------- tail: pool + head + softmax, one wave per image ----------------
         if (wave < gvalid)
             tail_one<NOUT>((const int8_t *)lds + OFF_X3 + wave * PIX3 * 256, out + ((size_t)step * G + wave) * NOUT, p.tail, lane);
+        MF_TR(23);
+#if MF_STAGE_DIAG == 2
+        ++trace_step;
+#endif
     }
 }
 
 // ---- launcher ----
 bool launch_late_stage(const int8_t *in, int8_t *out, const StageArgs &a, int batch, hipStream_t s) {
     constexpr int G = 4, NTHR = 512, NREP = 5;
-    constexpr int lds = 80 * 1024;
+#ifndef MF_STAGE_LDS_KB
+#define MF_STAGE_LDS_KB 80 // (tuning: 100 forces one workgroup per CU)
+#endif
+    constexpr int lds = MF_STAGE_LDS_KB * 1024;
     static LaunchState st2, st4;
     const int nsteps = (batch + G - 1) / G;
 #define MF_STAGE(NOUT, ST)                                                                                       \
@@ -361,6 +441,23 @@ bool launch_late_stage(const int8_t *in, int8_t *out, const StageArgs &a, int ba
         hipLaunchKernelGGL((late_stage_6x6x128<G, NTHR, NREP, NOUT>), dim3(grid), dim3(NTHR), lds, s, in, out, a, batch); \
         return true;                                                                                              \
     }
+#if MF_STAGE_DIAG == 2
+    {
+        static int calls = 0;
+        if (++calls == 3 && a.tail.N == 2) {
+            const int per_cu = prepared(st2, late_stage_6x6x128<G, NTHR, NREP, 2>, NTHR, lds);
+            const int grid = nsteps < 256 * per_cu ? nsteps : 256 * per_cu;
+            hipLaunchKernelGGL((late_stage_6x6x128<G, NTHR, NREP, 2>), dim3(grid), dim3(NTHR), lds, s, in, out, a, batch);
+            (void)hipStreamSynchronize(s);
+            long long h[32];
+            (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_stage_trace), sizeof(h));
+            fprintf(stderr, "[stage trace] grid %d per_cu %d; cycles since step start:", grid, per_cu);
+            for (int i = 0; i < 25; ++i) fprintf(stderr, " %d:%lld", i, h[i] - h[24]);
+            fprintf(stderr, "\n");
+            return true;
+        }
+    }
+#endif
     if (a.tail.N == 2) MF_STAGE(2, st2)
     if (a.tail.N == 4) MF_STAGE(4, st4)
 #undef MF_STAGE

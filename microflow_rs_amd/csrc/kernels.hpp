@@ -142,7 +142,8 @@ struct TailArgs {
 struct StagePair {
     const void *dw_wmm;      // depthwise taps, matrix-pipe form (DwFastArgs::wmm)
     const float *dwA, *dwS;
-    const int *dwK;
+    const int *dwK;          // folded constants + 0x4B400000 (the bit-pattern int->float offset, added on the host so
+                             // that an operand fetch has no dependent instruction and can stay in flight)
     float dw_lo, dw_hi;
     const void *pw_w;        // pointwise weights [N/16][K/64][64 lanes] x 16 bytes: row r of tile tt = channel 16 tt + r
     const float *pwA, *pwS;

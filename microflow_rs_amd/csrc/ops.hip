@@ -697,7 +697,16 @@ FusedImpl *fused_stage_create(FusedImpl *const *pairs, int npairs, FusedImpl *ta
     for (int i = 0; i < 7; ++i) {
         const FusedImpl *f = pairs[i];
         k::StagePair &sp = table[i];
-        sp.dw_wmm = f->dwpw.dw.wmm, sp.dwA = f->dwpw.dw.A, sp.dwS = f->dwpw.dw.S, sp.dwK = f->dwpw.dw.Kc;
+        // Kc + the bit-pattern offset of requant_t<true> (k_common.hpp), as separate arrays for this kernel
+        auto with_magic = [&](const int *d_kc, int n) {
+            std::vector<int32_t> h((size_t)n);
+            MF_HIP(hipMemcpy(h.data(), d_kc, h.size() * 4, hipMemcpyDeviceToHost));
+            for (int32_t &v : h) v = wrap_add(v, 0x4B400000);
+            s->stage_w.emplace_back(new DevBuf);
+            s->stage_w.back()->upload(h.data(), h.size() * 4);
+            return (const int *)s->stage_w.back()->p;
+        };
+        sp.dw_wmm = f->dwpw.dw.wmm, sp.dwA = f->dwpw.dw.A, sp.dwS = f->dwpw.dw.S, sp.dwK = with_magic(f->dwpw.dw.Kc, f->a->s.N);
         sp.dw_lo = f->dwpw.dw.lo_f, sp.dw_hi = f->dwpw.dw.hi_f;
         const OpSpec &q = f->b->s;
         std::vector<int8_t> host((size_t)q.N * q.C);
@@ -706,7 +715,7 @@ FusedImpl *fused_stage_create(FusedImpl *const *pairs, int npairs, FusedImpl *ta
         s->stage_w.emplace_back(new DevBuf);
         s->stage_w.back()->upload(prep.data(), prep.size());
         sp.pw_w = s->stage_w.back()->p;
-        sp.pwA = f->dwpw.pw.A, sp.pwS = f->dwpw.pw.S, sp.pwK = f->dwpw.pw.Kc;
+        sp.pwA = f->dwpw.pw.A, sp.pwS = f->dwpw.pw.S, sp.pwK = with_magic(f->dwpw.pw.Kc, q.N);
         sp.pw_lo = f->dwpw.pw.lo_f, sp.pw_hi = f->dwpw.pw.hi_f;
     }
     s->stage_w.emplace_back(new DevBuf);
