@@ -223,7 +223,7 @@ def main():
                 rq_gbs = rq / (per_op[i] * 1e-3) / 1e9 if per_op[i] > 0 else 0.0
                 nops_in_group = sum(1 for j in range(i, last + 1) if descs[j]["name"] != "reshape")
                 bound = "valu" if nops_in_group > 3 else "hbm"  # a multi-layer group keeps its tensors on chip
-                rows.append({"op": i, "kind": kind if nops_in_group <= 3 else "late_stage(%d ops)" % nops_in_group,
+                rows.append({"op": i, "kind": kind if nops_in_group <= 3 else "stage(%d ops)" % nops_in_group,
                              "kernel": d["kernel"], "ms": round(per_op[i], 4), "bound": bound,
                              "bytes": nbytes, "GBps": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4),
                              "requant_bytes": rq, "requant_GBps": round(rq_gbs, 1),

@@ -137,8 +137,7 @@ struct TailArgs {
     float sm_oscale, sm_ozp_f;
 };
 
-// late stage as one persistent kernel (k_stage.hip): NREP pairs on 6x6x128, the stride-2 pair to 3x3x256, the pair
-// on 3x3x256, then the tail
+// a run of identical depthwise + pointwise pairs on a small tensor as one persistent kernel (k_stage.hip)
 struct StagePair {
     const void *dw_wmm;      // depthwise taps, matrix-pipe form (DwFastArgs::wmm)
     const float *dwA, *dwS;
@@ -147,13 +146,12 @@ struct StagePair {
     float dw_lo, dw_hi;
     const void *pw_w;        // pointwise weights [N/16][K/64][64 lanes] x 16 bytes: row r of tile tt = channel 16 tt + r
     const float *pwA, *pwS;
-    const int *pwK;
+    const int *pwK;          // + 0x4B400000, like dwK
     float pw_lo, pw_hi;
 };
 struct StageArgs {
-    const StagePair *pairs;  // [7], in device memory
-    TailArgs tail;
-    uint32_t izp4;           // zero point of every depthwise input of the stage (they must agree: one halo fill)
+    const StagePair *pairs;  // [number of pairs], in device memory
+    uint32_t izp4;           // zero point of every depthwise input of the run (they must agree: one halo fill)
 };
 
 // shapes with a compiled fast depthwise kernel: H, W, C, stride, images per step, threads per
@@ -291,7 +289,8 @@ bool launch_dwpw_mm(int H, int W, int C, int S, int N, const int8_t *in, int8_t 
 const char *dwpw_rr_name(int H, int W, int C, int S, int N);
 bool launch_dwpw_rr(int H, int W, int C, int S, int N, const int8_t *in, int8_t *out, const DwPwArgs &a,
                     int batch, hipStream_t s);
-bool launch_late_stage(const int8_t *in, int8_t *out, const StageArgs &a, int batch, hipStream_t s);
+const char *stage_name(int H, int W, int C, int npairs);
+bool launch_stage(int H, int W, int C, int npairs, const int8_t *in, int8_t *out, const StageArgs &a, int batch, hipStream_t s);
 bool tail_supported(int C, int N, int ntaps);
 void launch_tail(const int8_t *in, int8_t *out, const TailArgs &a, size_t batch, hipStream_t s);
 const char *pw_name(int K, int N);

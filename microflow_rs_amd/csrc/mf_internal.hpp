@@ -118,9 +118,9 @@ FusedImpl *fused_create(OpImpl *dw, OpImpl *pw);
 FusedImpl *fused_tail_create(OpImpl *pool, OpImpl *conv, OpImpl *softmax);
 // fused FullyConnected (row-wave kernel, one row per inference) -> Softmax over its outputs
 FusedImpl *fused_fc_softmax_create(OpImpl *fc, OpImpl *softmax);
-// the late stage of a MobileNet-v1 style network as one kernel, built from 7 existing pair groups + the tail group
-// (borrows their device buffers: destroy it before them); nullptr when the shapes do not match
-FusedImpl *fused_stage_create(FusedImpl *const *pairs, int npairs, FusedImpl *tail);
+// a run of identical depthwise + pointwise pair groups as one persistent kernel (borrows their device buffers:
+// destroy it before them); nullptr when no stage kernel exists for the shape / count
+FusedImpl *fused_stage_create(FusedImpl *const *pairs, int npairs);
 void fused_destroy(FusedImpl *f);
 void fused_run(FusedImpl *f, const int8_t *d_in, size_t batch, int8_t *d_out, void *stream);
 const char *fused_kernel_name(const FusedImpl *f);

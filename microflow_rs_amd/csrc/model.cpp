@@ -38,8 +38,8 @@ struct ModelImpl {
     // the pool -> head conv -> [reshape] -> softmax tail)
     std::vector<FusedImpl *> fused;
     std::vector<int> fused_last;
-    // second level: ops stage_first .. stage_last (seven consecutive pair groups + the tail group) as ONE
-    // persistent kernel (k_stage.hip); the pair groups inside stay available for mf_model_run_until
+    // second level: ops stage_first .. stage_last (a run of identical pair groups) as ONE persistent kernel
+    // (k_stage.hip); the pair groups inside stay available for mf_model_run_until
     FusedImpl *stage = nullptr;
     int stage_first = -1, stage_last = -1;
     bool fusion = true;
@@ -222,21 +222,23 @@ void model_prepare(ModelImpl *m, int device, size_t max_batch) {
             }
             if (fused[i]) i = (size_t)fused_last[i]; // groups do not overlap
         }
-        // (4) seven consecutive pair groups followed by the tail group -> the late-stage kernel, if their shapes
-        // are the ones it is written for (ops.hip: fused_stage_create)
+        // (4) the longest run of consecutive pair groups on one tensor shape -> a persistent stage kernel, if one
+        // exists for that shape and count (ops.hip: fused_stage_create)
         FusedImpl *stage = nullptr;
         int stage_first = -1, stage_last = -1;
-        for (size_t i = 0; i + 14 < n && !stage; ++i) {
-            FusedImpl *pairs[7];
-            bool ok = true;
-            for (int k = 0; k < 7 && ok; ++k) {
-                const size_t a = i + 2 * (size_t)k;
-                ok = fused[a] && fused_last[a] == (int)a + 1;
-                pairs[k] = fused[a];
+        for (size_t i = 0; i + 1 < n && !stage; ++i) {
+            if (!fused[i] || fused_last[i] != (int)i + 1) continue;
+            std::vector<FusedImpl *> run;
+            size_t a = i;
+            while (a + 1 < n && fused[a] && fused_last[a] == (int)a + 1 && m->pm.ops[a].H == m->pm.ops[i].H &&
+                   m->pm.ops[a].W == m->pm.ops[i].W && m->pm.ops[a].C == m->pm.ops[i].C &&
+                   m->pm.ops[a + 1].N == m->pm.ops[i].C && m->pm.ops[a].sh == 1) {
+                run.push_back(fused[a]);
+                a += 2;
             }
-            const size_t t = i + 14;
-            if (ok && fused[t] && fused_last[t] > (int)t + 1 && (stage = fused_stage_create(pairs, 7, fused[t])))
-                stage_first = (int)i, stage_last = fused_last[t];
+            if (run.size() >= 2 && (stage = fused_stage_create(run.data(), (int)run.size())))
+                stage_first = (int)i, stage_last = (int)a - 1;
+            if (!run.empty()) i = a - 1; // continue after the run
         }
         struct StageGuard {
             FusedImpl *&s;

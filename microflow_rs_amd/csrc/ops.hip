@@ -604,7 +604,8 @@ struct FusedImpl {
     std::string name;
     // STAGE: the whole late stage in one kernel
     k::StageArgs stage{};
-    std::vector<std::unique_ptr<DevBuf>> stage_w; // pointwise weights in the stage kernel's operand layout
+    int stage_pairs = 0;
+    std::vector<std::unique_ptr<DevBuf>> stage_w; // the stage kernel's own operand arrays and its pair table
 };
 
 FusedImpl *fused_create(OpImpl *dw, OpImpl *pw) {
@@ -675,28 +676,29 @@ static std::vector<int8_t> build_pw_plain_weights(const int8_t *w, int K, int N)
     return out;
 }
 
-// The late stage of a MobileNet-v1 style network (k_stage.hip): pairs[0..4] DepthwiseConv2D 3x3 s1 + Conv2D 1x1 on
-// 6x6x128, pairs[5] the stride-2 pair 6x6x128 -> 3x3x256, pairs[6] the pair on 3x3x256, then the fused tail.
-// `pairs` / `tail` are the already created groups; returns nullptr when the shapes are not exactly that.
-FusedImpl *fused_stage_create(FusedImpl *const *pairs, int npairs, FusedImpl *tail) {
+// A run of `npairs` identical DepthwiseConv2D 3x3 (stride 1) + Conv2D 1x1 pairs on one small tensor as one persistent
+// kernel (k_stage.hip: five pairs on 6x6x128 = person_detect ops 13..22).  `pairs` are the already created pair
+// groups; returns nullptr when no stage kernel exists for them.
+FusedImpl *fused_stage_create(FusedImpl *const *pairs, int npairs) {
     static const bool off = getenv("MF_NO_STAGE") != nullptr;
-    if (off || npairs != 7 || !tail || tail->kind != FusedImpl::TAIL) return nullptr;
-    const int want[7][5] = {{6, 128, 1, 128, 0}, {6, 128, 1, 128, 0}, {6, 128, 1, 128, 0}, {6, 128, 1, 128, 0},
-                            {6, 128, 1, 128, 0}, {6, 128, 2, 256, 0}, {3, 256, 1, 256, 0}};
-    for (int i = 0; i < 7; ++i) {
+    if (off || npairs < 2 || !pairs[0] || pairs[0]->kind != FusedImpl::DWPW) return nullptr;
+    const OpSpec &d0 = pairs[0]->a->s;
+    const char *nm = k::stage_name(d0.H, d0.W, d0.C, npairs);
+    if (!nm) return nullptr;
+    for (int i = 0; i < npairs; ++i) {
         const FusedImpl *f = pairs[i];
         if (!f || f->kind != FusedImpl::DWPW) return nullptr;
         const OpSpec &d = f->a->s, &q = f->b->s;
-        if (d.H != want[i][0] || d.W != want[i][0] || d.C != want[i][1] || d.sh != want[i][2] || q.N != want[i][3]) return nullptr;
+        if (d.H != d0.H || d.W != d0.W || d.C != d0.C || d.sh != 1 || q.N != d0.C) return nullptr; // same tensor in and out
         if (d.u8 || !f->dwpw.dw.magic || !f->dwpw.pw.magic || !f->dwpw.dw.wmm) return nullptr; // i8, bit-pattern epilogues
         if (f->dwpw.dw.izp4 != pairs[0]->dwpw.dw.izp4 || f->a->device != pairs[0]->a->device) return nullptr;
     }
-    if (tail->tail.H != 3 || tail->tail.W != 3 || tail->tail.C != 256 || (tail->tail.N != 2 && tail->tail.N != 4)) return nullptr;
-    std::unique_ptr<FusedImpl> s(new FusedImpl{FusedImpl::STAGE, pairs[0]->a, tail->c, nullptr, {}, {}, "late_stage_6x6x128<4,512,5>"});
-    k::StagePair table[7];
-    for (int i = 0; i < 7; ++i) {
+    std::unique_ptr<FusedImpl> s(new FusedImpl{FusedImpl::STAGE, pairs[0]->a, pairs[npairs - 1]->b, nullptr, {}, {}, nm});
+    s->stage_pairs = npairs;
+    std::vector<k::StagePair> table((size_t)npairs);
+    for (int i = 0; i < npairs; ++i) {
         const FusedImpl *f = pairs[i];
-        k::StagePair &sp = table[i];
+        k::StagePair &sp = table[(size_t)i];
         // Kc + the bit-pattern offset of requant_t<true> (k_common.hpp), as separate arrays for this kernel
         auto with_magic = [&](const int *d_kc, int n) {
             std::vector<int32_t> h((size_t)n);
@@ -719,9 +721,8 @@ FusedImpl *fused_stage_create(FusedImpl *const *pairs, int npairs, FusedImpl *ta
         sp.pw_lo = f->dwpw.pw.lo_f, sp.pw_hi = f->dwpw.pw.hi_f;
     }
     s->stage_w.emplace_back(new DevBuf);
-    s->stage_w.back()->upload(table, sizeof(table));
+    s->stage_w.back()->upload(table.data(), table.size() * sizeof(k::StagePair));
     s->stage.pairs = (const k::StagePair *)s->stage_w.back()->p;
-    s->stage.tail = tail->tail;
     s->stage.izp4 = pairs[0]->dwpw.dw.izp4;
     return s.release();
 }
@@ -732,7 +733,8 @@ void fused_run(FusedImpl *f, const int8_t *d_in, size_t batch, int8_t *d_out, vo
     if (!batch) return;
     if (f->kind == FusedImpl::STAGE) {
         if (batch > 0x7fffffffull / 4) fail(MF_ERR_INVALID_ARG, "batch too large for one launch");
-        if (!k::launch_late_stage(d_in, d_out, f->stage, (int)batch, (hipStream_t)stream))
+        const OpSpec &d = f->a->s;
+        if (!k::launch_stage(d.H, d.W, d.C, f->stage_pairs, d_in, d_out, f->stage, (int)batch, (hipStream_t)stream))
             fail(MF_ERR_UNSUPPORTED, "stage kernel missing");
         MF_HIP(hipGetLastError());
         return;

@@ -17,7 +17,7 @@ from collections import defaultdict
 acc = defaultdict(lambda: defaultdict(list)); dur = defaultdict(list)
 for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        m = re.search(r"mf::k::(dwpw_[a-z]+<[^>]*>|dw3x3_stem8<[^>]*>|late_stage[a-z0-9_]*<[^>]*>)", r["Kernel_Name"])
+        m = re.search(r"mf::k::(dwpw_[a-z]+<[^>]*>|dw3x3_stem8<[^>]*>|stage_[a-z0-9_]*<[^>]*>)", r["Kernel_Name"])
         if not m: continue
         k = m.group(1).replace(" ", "")[:28]
         acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))

@@ -167,14 +167,16 @@ def test_kernel_routing(models):
     names = [m.op(i)["kernel"] for i in range(m.num_ops)]
     assert names[0].startswith("dw3x3_stem8")
     # fused depthwise + 1x1 conv pairs: dwpw_rr / dwpw_mm (taps on the matrix pipe) or, with
-    # MF_DWPW_IMPL=valu, r01's dwpw3x3; the seven late pairs + the tail are ONE kernel (MF_NO_STAGE=1: not)
+    # MF_DWPW_IMPL=valu, r01's dwpw3x3; the five 6x6x128 pairs (ops 13..22) are ONE persistent kernel
+    # (MF_NO_STAGE=1: not)
     npairs = sum(n.startswith(("dwpw_rr", "dwpw_mm", "dwpw3x3")) for n in names)
     if os.environ.get("MF_NO_STAGE"):
         assert npairs == 13 and sum(n.startswith("(fused") for n in names) == 13 + 2
-        assert names[27] == "tail_pool_head_softmax<2>"               # pool + head conv + softmax
     else:
-        assert npairs == 6 and names[13].startswith("late_stage_6x6x128")
-        assert all(n.startswith("(fused") for i, n in enumerate(names[14:], 14) if i != 29), names
+        assert npairs == 8 and names[13].startswith("stage_6x6x128"), names
+        assert all(n.startswith("(fused") for n in names[14:23]), names
+        assert names[23].startswith("dwpw_") and names[25].startswith("dwpw_"), names
+    assert names[27] == "tail_pool_head_softmax<2>"                   # pool + head conv + softmax
     assert names[28].startswith("(fused") and names[29] == "" and names[30].startswith("(fused")
     if not os.environ.get("MF_DWPW_IMPL"):
         assert sum(n.startswith("dwpw_rr") for n in names) == 4
