@@ -137,6 +137,40 @@ struct TailArgs {
     float sm_oscale, sm_ozp_f;
 };
 
+// DepthwiseConv2D (one input channel) -> FullyConnected -> Softmax in one launch (k_dwfc.hip): speech.tflite ops 1..3.
+// Geometry of the one compiled instance; the kernel's comment explains the layout.
+struct DwFcGeom {
+    static constexpr int H = 49, W = 40, KH = 10, KW = 8, S = 2, OH = 25, OW = 20;
+    static constexpr int IMGS = 16;                 // images per workgroup step = the 16 MFMA columns
+    static constexpr int PT = (KH - 1) / 2, PL = (KW - 1) / 2; // SAME padding: rows above / columns left of the image
+    static constexpr int XO = 4;                    // tile byte of image column 0 (dword aligned staging)
+    static constexpr int E0 = XO - PL;              // window of pixel ox starts at tile byte S * ox + E0
+    static constexpr int NM = OW / 4, NT = (OH + 1) / 2, NU = NT * NM; // 8-byte groups per row, row pairs, units per shift
+    static constexpr int ROWS = 4 * (NT - 1) + 12;  // tile rows read by the last row pair
+    static constexpr int RP = 56;                   // row pitch, bytes (>= 8 (NM - 1) + 16; 14 words: see bank note)
+    static constexpr int TILE = ((ROWS * RP + 15) / 32) * 32 + 16; // image pitch = 16 mod 32 bytes (4 mod 8 words)
+    static constexpr int FCW_BYTES = 4 * NU * 64;   // FullyConnected weights table
+    static_assert(S == 2 && KW == 8 && OW % 4 == 0 && KH + S <= 12, "dwc1_fc_softmax: window / row-pair scheme");
+    static_assert(8 * (NM - 1) + 16 <= RP && XO + W <= RP && TILE >= ROWS * RP && PT + H <= ROWS, "dwc1_fc_softmax: tile");
+};
+struct DwFcArgs {
+    const void *wA;          // [4 shifts][3 k-steps][64 lanes] x 16 B: depthwise taps as MFMA operand A
+    const void *wfc;         // [4 shifts][NU][4 lane groups][4 outputs] dwords of FullyConnected weights
+    const float *dwA, *dwS;
+    const int *dwKc;
+    float dw_lo, dw_hi;
+    uint32_t izp4;
+    int magic, xr;           // of the depthwise operator
+    FcArgs fc;
+    SoftmaxArgs sm;
+};
+#ifndef MF_DWFC_THREADS
+#define MF_DWFC_THREADS 512
+#endif
+bool dwfc_supported(int H, int W, int KH, int KW, int sh, int sw, int OH, int OW, int DM, int NFC);
+const char *dwfc_name();
+void launch_dwfc(const int8_t *in, int8_t *out, const DwFcArgs &a, size_t batch, hipStream_t s);
+
 // a run of identical depthwise + pointwise pairs on a small tensor as one persistent kernel (k_stage.hip)
 struct StagePair {
     const void *dw_wmm;      // depthwise taps, matrix-pipe form (DwFastArgs::wmm)

@@ -121,6 +121,8 @@ FusedImpl *fused_fc_softmax_create(OpImpl *fc, OpImpl *softmax);
 // a run of identical depthwise + pointwise pair groups as one persistent kernel (borrows their device buffers:
 // destroy it before them); nullptr when no stage kernel exists for the shape / count
 FusedImpl *fused_stage_create(FusedImpl *const *pairs, int npairs);
+// one-input-channel DepthwiseConv2D + the FullyConnected/Softmax group as one kernel (second level, like the stage)
+FusedImpl *fused_dwfc_create(OpImpl *dw, FusedImpl *fc_softmax);
 void fused_destroy(FusedImpl *f);
 void fused_run(FusedImpl *f, const int8_t *d_in, size_t batch, int8_t *d_out, void *stream);
 const char *fused_kernel_name(const FusedImpl *f);

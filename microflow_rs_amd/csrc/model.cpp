@@ -240,6 +240,14 @@ void model_prepare(ModelImpl *m, int device, size_t max_batch) {
                 stage_first = (int)i, stage_last = (int)a - 1;
             if (!run.empty()) i = a - 1; // continue after the run
         }
+        // (5) DepthwiseConv2D with one input channel -> [Reshape] -> the FullyConnected + Softmax group -> one kernel
+        for (size_t i = 0; i + 1 < n && !stage; ++i) {
+            if (!ops[i] || fused[i] || m->pm.ops[i].kind != MF_OP_DEPTHWISE_CONV_2D) continue;
+            size_t j = i + 1;
+            while (j < n && m->pm.ops[j].kind == MF_OP_RESHAPE) ++j;
+            if (j < n && fused[j] && (stage = fused_dwfc_create(ops[i], fused[j])))
+                stage_first = (int)i, stage_last = fused_last[j];
+        }
         struct StageGuard {
             FusedImpl *&s;
             bool keep = false;

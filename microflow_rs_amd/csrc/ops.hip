@@ -597,7 +597,7 @@ void op_run_f32(OpImpl *op, const float *d_in, size_t batch, int8_t *d_out, void
 }
 
 struct FusedImpl {
-    enum Kind { DWPW, TAIL, FCSM, STAGE } kind;
+    enum Kind { DWPW, TAIL, FCSM, STAGE, DWFC } kind;
     OpImpl *a, *b, *c;
     k::DwPwArgs dwpw;
     k::TailArgs tail;
@@ -606,6 +606,8 @@ struct FusedImpl {
     k::StageArgs stage{};
     int stage_pairs = 0;
     std::vector<std::unique_ptr<DevBuf>> stage_w; // the stage kernel's own operand arrays and its pair table
+    // DWFC: one-input-channel depthwise -> FullyConnected -> Softmax in one kernel (operand tables in stage_w)
+    k::DwFcArgs dwfc{};
 };
 
 FusedImpl *fused_create(OpImpl *dw, OpImpl *pw) {
@@ -727,6 +729,66 @@ FusedImpl *fused_stage_create(FusedImpl *const *pairs, int npairs) {
     return s.release();
 }
 
+// DepthwiseConv2D with one input channel (the dw_c1_lds operator) -> [Reshape] -> FullyConnected + Softmax group, as
+// one kernel (k_dwfc.hip; speech.tflite ops 1..3).  Second level like the stage: the operator and the group inside
+// stay available for mf_model_run_until.  nullptr when the shapes are not the compiled instance.
+FusedImpl *fused_dwfc_create(OpImpl *dw, FusedImpl *fcsm) {
+    static const bool off = getenv("MF_NO_DWFC") != nullptr;
+    if (off || !dw || !fcsm || dw->fast != OpImpl::DW_C1 || fcsm->kind != FusedImpl::FCSM) return nullptr;
+    OpImpl *fc = fcsm->a, *sm = fcsm->b;
+    const OpSpec &d = dw->s, &q = fc->s;
+    using Gm = k::DwFcGeom;
+    if (!k::dwfc_supported(d.H, d.W, d.KH, d.KW, d.sh, d.sw, d.OH, d.OW, d.N, q.N)) return nullptr;
+    if (d.pad != MF_PAD_SAME || d.C != 1 || q.M != 1 || q.K != d.OH * d.OW * d.N || dw->device != fc->device) return nullptr;
+    if (d.u8 != q.u8) return nullptr;
+    std::unique_ptr<FusedImpl> f(new FusedImpl{FusedImpl::DWFC, dw, fc, sm, {}, {}, k::dwfc_name()});
+    // both operators' weights as they were uploaded (i8 domain): the depthwise taps from dw_c1_lds's packed form
+    // [ky][4-tap group][8 channels] dwords, the FullyConnected matrix [N][K]
+    const k::DwC1Args &c1 = dw->dwc1;
+    std::vector<uint32_t> wp((size_t)Gm::KH * c1.KG * 8);
+    MF_HIP(hipMemcpy(wp.data(), c1.wpack, wp.size() * 4, hipMemcpyDeviceToHost));
+    auto dw_w = [&](int ky, int kx, int c) { return (int8_t)(wp[((size_t)ky * c1.KG + kx / 4) * 8 + c] >> (8 * (kx & 3))); };
+    std::vector<int8_t> fc_w((size_t)q.N * q.K);
+    MF_HIP(hipMemcpy(fc_w.data(), fc->fc.w, fc_w.size(), hipMemcpyDeviceToHost));
+    // operand A: taps of filter row ky = (4k + g) - 2p at byte b = kx + 2s + E0 of the 16-byte window, for row
+    // r = (p, c) of the accumulator tile; zero elsewhere
+    std::vector<int8_t> wa((size_t)4 * 3 * 64 * 16, 0);
+    for (int sft = 0; sft < 4; ++sft)
+        for (int kk = 0; kk < 3; ++kk)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int r = lane & 15, g = lane >> 4, p = r >> 3, c = r & 7;
+                const int ky = 4 * kk + g - Gm::S * p;
+                if (ky < 0 || ky >= Gm::KH) continue;
+                for (int kx = 0; kx < Gm::KW; ++kx)
+                    wa[(((size_t)sft * 3 + kk) * 64 + lane) * 16 + (size_t)(kx + Gm::S * sft + Gm::E0)] =
+                        dw_w(ky, kx, c);
+            }
+    // FullyConnected weights per (shift, unit = (t, m), lane group g = (p, channel half), output n): the 4 weights
+    // that meet this lane's packed dword = pixel (2t + p, 4m + s), channels 4 (g & 1) .. + 3 of the NHWC flattening
+    std::vector<int8_t> wf((size_t)Gm::FCW_BYTES, 0);
+    for (int sft = 0; sft < 4; ++sft)
+        for (int u = 0; u < Gm::NU; ++u)
+            for (int g = 0; g < 4; ++g) {
+                const int t = u / Gm::NM, m = u % Gm::NM, oy = 2 * t + (g >> 1), ox = 4 * m + sft;
+                if (oy >= Gm::OH) continue;
+                const size_t k0 = ((size_t)oy * Gm::OW + ox) * 8 + 4 * (size_t)(g & 1);
+                for (int n = 0; n < 4; ++n)
+                    for (int b = 0; b < 4; ++b)
+                        wf[((((size_t)sft * Gm::NU + u) * 4 + g) * 4 + n) * 4 + b] = fc_w[(size_t)n * q.K + k0 + b];
+            }
+    f->stage_w.emplace_back(new DevBuf);
+    f->stage_w.back()->upload(wa.data(), wa.size());
+    f->dwfc.wA = f->stage_w.back()->p;
+    f->stage_w.emplace_back(new DevBuf);
+    f->stage_w.back()->upload(wf.data(), wf.size());
+    f->dwfc.wfc = f->stage_w.back()->p;
+    f->dwfc.dwA = c1.A, f->dwfc.dwS = c1.S, f->dwfc.dwKc = c1.Kc, f->dwfc.dw_lo = c1.lo_f, f->dwfc.dw_hi = c1.hi_f;
+    f->dwfc.izp4 = 0x01010101u * (uint32_t)(uint8_t)(int8_t)c1.izp;
+    f->dwfc.magic = c1.magic, f->dwfc.xr = c1.xr;
+    f->dwfc.fc = fc->fc, f->dwfc.sm = sm->sm;
+    return f.release();
+}
+
 void fused_destroy(FusedImpl *f) { delete f; }
 const char *fused_kernel_name(const FusedImpl *f) { return f->name.c_str(); }
 void fused_run(FusedImpl *f, const int8_t *d_in, size_t batch, int8_t *d_out, void *stream) {
@@ -741,6 +803,11 @@ void fused_run(FusedImpl *f, const int8_t *d_in, size_t batch, int8_t *d_out, vo
     }
     if (f->kind == FusedImpl::TAIL) {
         k::launch_tail(d_in, d_out, f->tail, batch, (hipStream_t)stream);
+        MF_HIP(hipGetLastError());
+        return;
+    }
+    if (f->kind == FusedImpl::DWFC) {
+        if (batch) k::launch_dwfc(d_in, d_out, f->dwfc, batch, (hipStream_t)stream);
         MF_HIP(hipGetLastError());
         return;
     }

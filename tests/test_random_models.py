@@ -72,3 +72,48 @@ def test_random_model_runs_bit_exact(O, case):
     pf = m.predict_quantized(xq).reshape(n, -1)
     wf = np.stack([om.predict_quantized(x).reshape(-1) for x in xq])
     assert np.array_equal(pf.view(np.uint32), wf.view(np.uint32))
+
+
+SPEECH_CASES = [(0, tw.INT8, 0, True, "relu"), (1, tw.INT8, 5, True, "relu"), (2, tw.UINT8, -3, False, "relu6"),
+                (3, tw.INT8, 0, False, "none"), (4, tw.UINT8, 0, True, "relu")]
+
+
+@pytest.mark.parametrize("case", SPEECH_CASES, ids=lambda c: "s%d-%s-wzp%d" % (c[0], "u8" if c[1] == tw.UINT8 else "i8", c[2]))
+def test_speech_like_parse_matches_oracle(O, case):
+    mf = importlib.import_module("microflow_rs_amd")
+    blob = tw.speech_like(np.random.default_rng(2000 + case[0]), *case[1:])
+    pm, om = mf.Model(blob), O.Model(blob)
+    assert pm.num_ops == om.num_ops == 4 and pm.input_elems == 1960 and pm.output_elems == 4
+    for i in range(pm.num_ops):
+        a, b = pm.op_constants(i), om.op_constants(i)
+        for x, y in zip(a[:3], b[:3]):
+            assert np.array_equal(np.asarray(x).view(np.int32), np.asarray(y).view(np.int32)), i
+        assert a[3] == b[3]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", SPEECH_CASES, ids=lambda c: "s%d-%s-wzp%d" % (c[0], "u8" if c[1] == tw.UINT8 else "i8", c[2]))
+def test_speech_like_one_launch_bit_exact(O, case):
+    """The speech-shaped network as ONE launch (k_dwfc.hip: depthwise taps on the matrix pipe -> FullyConnected ->
+    Softmax), against the oracle and against the operator-by-operator path, for batch sizes around the 16 images of
+    a workgroup step; incl. the FullyConnected weight zero point (row-sum term) speech.tflite itself never has."""
+    mf = importlib.import_module("microflow_rs_amd")
+    blob = tw.speech_like(np.random.default_rng(2000 + case[0]), *case[1:])
+    m, om = mf.Model(blob), O.Model(blob)
+    m.prepare(1)
+    names = [m.op(i)["kernel"] for i in range(m.num_ops)]
+    if not os.environ.get("MF_NO_DWFC"):
+        assert names[1].startswith("dwc1_fc_softmax"), names
+    rng = np.random.default_rng(case[0])
+    lo, hi = (0, 256) if m.dtype == np.uint8 else (-128, 128)
+    for n in (1, 15, 16, 17, 33, 200):
+        xq = rng.integers(lo, hi, (n, m.input_elems)).astype(m.dtype)
+        if n == 17:
+            xq[3], xq[4] = lo, hi - 1  # constant extremes
+        got = m.run_quantized(xq).reshape(n, -1)
+        m.set_fusion(False)
+        layerwise = m.run_quantized(xq).reshape(n, -1)
+        m.set_fusion(True)
+        assert np.array_equal(got, layerwise), n
+        k = min(n, 24)
+        assert np.array_equal(got[:k], om.run_quantized_batch(xq[:k])), n

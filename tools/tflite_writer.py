@@ -186,3 +186,25 @@ def random_cnn(rng, elem=INT8, per_channel=True, wzp_nonzero=False, tail="fc"):
         classes = int(np.prod(L["out_shape"]))
     layers.append(dict(op="softmax", out_shape=(1, classes), out_q=(1.0 / 256.0, lo)))
     return build_model((1, H, W, C), in_q, layers, elem)
+
+
+def speech_like(rng, elem=INT8, fc_wzp=0, per_channel=True, act="relu"):
+    """The layer structure and shapes of speech.tflite (TinyConv: Reshape -> DepthwiseConv2D 10x8 stride 2 SAME with one
+    input channel and 8 output channels -> FullyConnected 4000 -> 4 -> Softmax) with random weights and quantization,
+    incl. a non-zero FullyConnected weight zero point, which the shipped model does not have."""
+    lo, hi = (0, 256) if elem == UINT8 else (-128, 128)
+    mid = (lo + hi) // 2
+    in_q = (float(np.float32(rng.uniform(0.02, 0.08))), int(rng.integers(lo, lo + 40)))
+    dsc = rng.uniform(0.002, 0.01, 8 if per_channel else 1).astype(np.float32)
+    dzp = np.full(8 if per_channel else 1, mid)
+    dw_out = (float(np.float32(rng.uniform(0.05, 0.2))), int(lo if act in ("relu", "relu6") else rng.integers(lo + 20, hi - 20)))
+    layers = [dict(op="reshape", out_shape=(1, 49, 40, 1), out_q=in_q),
+              dict(op="depthwise_conv_2d", weights=rng.integers(lo, hi, (1, 10, 8, 8)), fscale=dsc, fzp=dzp,
+                   bias=rng.integers(-2000, 2000, 8), bscale=(dsc * np.float32(in_q[0])).astype(np.float32),
+                   bzp=np.zeros_like(dzp), padding="same", strides=(2, 2), act=act, out_shape=(1, 25, 20, 8), out_q=dw_out)]
+    fsc = np.float32(rng.uniform(0.001, 0.004))
+    layers.append(dict(op="fully_connected", weights=rng.integers(lo, hi, (4, 4000)), wscale=[fsc], wzp=[mid + fc_wzp],
+                       bias=rng.integers(-3000, 3000, 4), bscale=[fsc * np.float32(dw_out[0])], bzp=[0], act="none",
+                       out_shape=(1, 4), out_q=(float(np.float32(rng.uniform(0.3, 0.9))), int(rng.integers(lo + 60, hi - 60)))))
+    layers.append(dict(op="softmax", out_shape=(1, 4), out_q=(1.0 / 256.0, lo)))
+    return build_model((1, 1960), in_q, layers, elem)
