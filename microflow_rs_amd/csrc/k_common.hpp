@@ -109,13 +109,32 @@ template <bool MG> __device__ __forceinline__ float requant_clamped(int acc, flo
     const float r = __fadd_rn(x, __builtin_copysignf(0x1.fffffep-2f, x));
     return __builtin_amdgcn_fmed3f(r, lo_f, hi_f);
 }
+// gfx950 has a destination-forwarding hazard on partial (dst_sel) writes: an instruction that reads a VGPR in the
+// issue slot right after an SDWA byte write of it may see the old value (observed: an MFMA fed such a dword).  hipcc
+// pads this for its own instructions but cannot see into inline asm, so the four conversions are ONE asm block with
+// an independent instruction (s_nop) after each: nothing the compiler schedules next to it can break the rule.
 __device__ __forceinline__ uint32_t cvt_pack4(float r0, float r1, float r2, float r3) {
     uint32_t d;
-    asm("v_cvt_i32_f32_sdwa %0, %1 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:DWORD" : "=v"(d) : "v"(r0));
-    asm("v_cvt_i32_f32_sdwa %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(d) : "v"(r1));
-    asm("v_cvt_i32_f32_sdwa %0, %1 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(d) : "v"(r2));
-    asm("v_cvt_i32_f32_sdwa %0, %1 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(d) : "v"(r3));
+    asm("v_cvt_i32_f32_sdwa %0, %1 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:DWORD\n\ts_nop 0\n\t"
+        "v_cvt_i32_f32_sdwa %0, %2 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD\n\ts_nop 0\n\t"
+        "v_cvt_i32_f32_sdwa %0, %3 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD\n\ts_nop 0\n\t"
+        "v_cvt_i32_f32_sdwa %0, %4 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:DWORD\n\ts_nop 0"
+        : "=&v"(d) : "v"(r0), "v"(r1), "v"(r2), "v"(r3));
     return d;
+}
+// Two dwords at once: the two chains alternate, so each write's successor is the other chain's (independent)
+// conversion and only the very last write needs the s_nop -- 1 idle slot per 8 bytes instead of 4 per 4.
+__device__ __forceinline__ void cvt_pack4x2(float a0, float a1, float a2, float a3, float b0, float b1, float b2, float b3,
+                                            uint32_t &da, uint32_t &db) {
+    asm("v_cvt_i32_f32_sdwa %0, %2 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:DWORD\n\t"
+        "v_cvt_i32_f32_sdwa %1, %6 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:DWORD\n\t"
+        "v_cvt_i32_f32_sdwa %0, %3 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD\n\t"
+        "v_cvt_i32_f32_sdwa %1, %7 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD\n\t"
+        "v_cvt_i32_f32_sdwa %0, %4 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD\n\t"
+        "v_cvt_i32_f32_sdwa %1, %8 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD\n\t"
+        "v_cvt_i32_f32_sdwa %0, %5 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:DWORD\n\t"
+        "v_cvt_i32_f32_sdwa %1, %9 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:DWORD\n\ts_nop 0"
+        : "=&v"(da), "=&v"(db) : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(b0), "v"(b1), "v"(b2), "v"(b3));
 }
 template <bool MG, uint32_t XR4>
 __device__ __forceinline__ uint32_t requant_pack4(int a0, int a1, int a2, int a3, const float4 &A, const float4 &S,
@@ -126,6 +145,22 @@ __device__ __forceinline__ uint32_t requant_pack4(int a0, int a1, int a2, int a3
 #else
     return pack4(requant_t<MG>(a0, A.x, S.x, lo_f, hi_f), requant_t<MG>(a1, A.y, S.y, lo_f, hi_f),
                  requant_t<MG>(a2, A.z, S.z, lo_f, hi_f), requant_t<MG>(a3, A.w, S.w, lo_f, hi_f)) ^ XR4;
+#endif
+}
+
+// requant_pack4 of two accumulator quads (two dwords) with the alternating conversion chains of cvt_pack4x2
+template <bool MG, uint32_t XR4>
+__device__ __forceinline__ void requant_pack4x2(const v4i &a, const float4 &aA, const float4 &aS, const v4i &b, const float4 &bA,
+                                                const float4 &bS, float lo_f, float hi_f, uint32_t &da, uint32_t &db) {
+#if MF_SDWA_PACK
+    cvt_pack4x2(requant_clamped<MG>(a[0], aA.x, aS.x, lo_f, hi_f), requant_clamped<MG>(a[1], aA.y, aS.y, lo_f, hi_f),
+                requant_clamped<MG>(a[2], aA.z, aS.z, lo_f, hi_f), requant_clamped<MG>(a[3], aA.w, aS.w, lo_f, hi_f),
+                requant_clamped<MG>(b[0], bA.x, bS.x, lo_f, hi_f), requant_clamped<MG>(b[1], bA.y, bS.y, lo_f, hi_f),
+                requant_clamped<MG>(b[2], bA.z, bS.z, lo_f, hi_f), requant_clamped<MG>(b[3], bA.w, bS.w, lo_f, hi_f), da, db);
+    da ^= XR4, db ^= XR4;
+#else
+    da = requant_pack4<MG, XR4>(a[0], a[1], a[2], a[3], aA, aS, lo_f, hi_f);
+    db = requant_pack4<MG, XR4>(b[0], b[1], b[2], b[3], bA, bS, lo_f, hi_f);
 #endif
 }
 

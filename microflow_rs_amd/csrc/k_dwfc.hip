@@ -17,14 +17,18 @@
 //   K bytes  : lane group g of k-step k supplies tile row 4t + 4k + g, bytes [8m, 8m+16): the 8-tap window of pixel
 //              ox = 4m + s starts at byte 8m + 2s + 1 of it, wherever s is -- the operand A (weights) is built on the
 //              host per s in 0..3 with the taps at that byte offset and zeros elsewhere.  The activation read is
-//              therefore always an ALIGNED 16 bytes (one ds_read2_b64), no byte shifting on the device at all.
+//              therefore always an ALIGNED 16 bytes (one ds_read2_b64), no byte shifting on the device at all, and ONE
+//              read serves the four pixels 4m .. 4m+3: a unit (t, m) is 3 operand reads and 4 x 3 MFMAs.
 //   tile     : per image [60 rows][56 B] at a pitch of 3376 B, inside a halo of the input zero point (written once);
 //              image column 0 sits at byte 4 of a row so that staging is dword writes.  Pitches chosen so that the
 //              32 lanes of a b64 read pass hit 64 distinct banks: (image * 844 + g * 14) mod 64 are disjoint pairs.
-//   epilogue : a lane holds 4 channels of one pixel of one image: requantise, pack (bytes as the depthwise operator
-//              would store them), and feed the FullyConnected at once: 4 v_dot4 against that pixel's weights (LDS
-//              table, one broadcast b128 per lane group).  The depthwise output never exists in memory.
-//   tail     : partial sums -> lane groups (2 shuffles) -> waves (LDS) -> 64 threads finish (image, output):
+//              Two tile sets: the next 16 images are written while this step's are being read.
+//   epilogue : a lane holds, per pixel, 4 channels of one image: requantise and pack (bytes as the depthwise operator
+//              would store them).  The 4 dwords of a unit's 4 pixels are exactly one lane's 16 K-bytes of operand B
+//              of a further MFMA, whose operand A holds the FullyConnected weights of those 64 activations in rows
+//              0..3 and ones in row 4 (the row sum the weight zero point needs): the FullyConnected is one more MFMA
+//              per unit, accumulated across the wave's units.  The depthwise output never exists in memory.
+//   tail     : accumulator rows 0..4 -> LDS per wave -> 64 threads finish (image, output): sum over waves,
 //              requantise, softmax over the 4 outputs in the reference's order, store 64 bytes.
 // HBM traffic: input + 4 output bytes per inference; the kernel is bounded by the requantisation VALU work.
 #include "k_common.hpp"
@@ -33,45 +37,82 @@ namespace mf {
 namespace k {
 
 typedef int v2i __attribute__((ext_vector_type(2)));
+#ifndef MF_DWFC_DIAG
+#define MF_DWFC_DIAG 0 // 1: cycle stamps of block 0 / wave 0 at the phase boundaries of its first two steps (never shipped)
+#endif
+#ifndef MF_DWFC_WPE
+#define MF_DWFC_WPE 2  // waves per SIMD the register budget allows (launch bound)
+#endif
+
+#if MF_DWFC_DIAG
+__device__ long long g_dwfc_trace[32];
+#define MF_TR(k) do { if (blockIdx.x == 0 && wave == 0 && lane == 0 && trace_step < 2) g_dwfc_trace[(k) + 8 * trace_step] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define MF_TR(k) do { } while (0)
+#endif
 
 template <int NTHR, bool MG, uint32_t XR4, bool WZP>
-__global__ __launch_bounds__(NTHR) void dwc1_fc_softmax(const int8_t *__restrict__ in, int8_t *__restrict__ out, DwFcArgs p,
+__global__ __launch_bounds__(NTHR, MF_DWFC_WPE) void dwc1_fc_softmax(const int8_t *__restrict__ in, int8_t *__restrict__ out, DwFcArgs p,
                                                         size_t batch) {
     using Gm = DwFcGeom;
-    constexpr int NW = NTHR / 64, PARTS = NW / 4; // waves; waves per tap shift s
+    constexpr int NW = NTHR / 64;
     constexpr int HW = Gm::H * Gm::W;
     constexpr int NCH = Gm::IMGS * HW / 16;                               // 16-byte chunks of one step's input
     constexpr int NE = (NCH + NTHR - 1) / NTHR;
+    constexpr int SET = Gm::IMGS * Gm::TILE;                              // one tile set
     static_assert(HW % 8 == 0 && Gm::W % 4 == 0 && (Gm::IMGS * HW) % 16 == 0, "staging granularity");
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    uint8_t *fcw = lds + Gm::IMGS * Gm::TILE;                             // [4 s][NU][4 g][4 n] dwords
-    int *part = (int *)(fcw + Gm::FCW_BYTES);                             // [NW][16 images][8]: 4 sums, row sum
+    uint8_t *fcw = lds + 2 * SET;                                         // [NU][4 g][5 rows][16 B]
+    int *part = (int *)(fcw + Gm::FCW_BYTES);                             // [2][NW][16 images][8]: 4 sums, row sum
+    float *expt = (float *)(part + 2 * NW * 16 * 8);                      // softmax's 256-entry table
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int col = lane & 15, g = lane >> 4;
-    const int s = wave & 3, part_i = wave >> 2;
+#if MF_DWFC_DIAG
+    int trace_step = 0;
+    if (blockIdx.x == 0 && tid == 0) g_dwfc_trace[31] = (long long)__builtin_readcyclecounter();
+#endif
 
     for (int i = tid; i < Gm::FCW_BYTES / 16; i += NTHR) ((uint4 *)fcw)[i] = ((const uint4 *)p.wfc)[i];
-    for (int i = tid; i < Gm::IMGS * Gm::TILE / 16; i += NTHR) ((uint4 *)lds)[i] = make_uint4(p.izp4, p.izp4, p.izp4, p.izp4);
-    v4i Aw[3];
+    for (int i = tid; i < 2 * SET / 16; i += NTHR) ((uint4 *)lds)[i] = make_uint4(p.izp4, p.izp4, p.izp4, p.izp4);
+    for (int i = tid; i < 256; i += NTHR) expt[i] = p.sm.exp_table[i];
+    v4i Aw[4][3];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) Aw[k] = ((const v4i *)p.wA)[(s * 3 + k) * 64 + lane];
+    for (int sft = 0; sft < 4; ++sft)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) Aw[sft][k] = ((const v4i *)p.wA)[(sft * 3 + k) * 64 + lane];
     const int cq = (g & 1) * 4; // this lane's channels within the pixel
     const float4 cA = *(const float4 *)(p.dwA + cq), cS = *(const float4 *)(p.dwS + cq);
     const int4 cK = magic4<MG>(*(const int4 *)(p.dwKc + cq));
-    // units (t, m) of this wave: an equal share of the NU = NT * NM of its tap shift
-    constexpr int PER = (Gm::NU + PARTS - 1) / PARTS;
-    const int j0 = part_i * PER, j1 = (j0 + PER < Gm::NU) ? j0 + PER : Gm::NU;
-    const uint8_t *tb = lds + col * Gm::TILE + g * Gm::RP;
-    const uint8_t *fw = fcw + (size_t)s * Gm::NU * 64 + g * 16;
+    const int fcK = p.fc.Kc[lane & 3];  // the finishing threads' (tid < 64) output n = lane & 3
+    const float fcA = p.fc.A[lane & 3];
+    // units (t, m) of this wave: wave, wave + NW, ...
+    const int ni = (Gm::NU - wave + NW - 1) / NW;
+    const int tb_off = col * Gm::TILE + g * Gm::RP;
+    const bool frow = col < 5;                                           // rows of the FullyConnected operand A that exist
+    const uint8_t *fw = fcw + (g * 5 + (frow ? col : 0)) * 16;
+    auto loadB = [&](const uint8_t *tb, int j, v4i (&B)[3]) {
+        const int t = j / Gm::NM, m = j - t * Gm::NM;
+        const uint8_t *a = tb + (4 * t) * Gm::RP + 8 * m;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const v2i b0 = *(const v2i *)(a + (4 * k) * Gm::RP), b1 = *(const v2i *)(a + (4 * k) * Gm::RP + 8);
+            B[k] = (v4i){b0.x, b0.y, b1.x, b1.y};
+        }
+    };
+    auto loadF = [&](int j) {
+        v4i f = {0, 0, 0, 0};
+        if (frow) f = *(const v4i *)(fw + j * 320);
+        return f;
+    };
 
     const size_t nblk = (batch + Gm::IMGS - 1) / Gm::IMGS;
-    for (size_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
-        // ---- stage 16 images: contiguous in HBM, 16 B per lane ----
+    // 16 images are contiguous in HBM: 16 B per lane, clamped at the end of the batch
+    uint4 v[NE];
+    auto load_images = [&](size_t blk) {
         const int8_t *src = in + blk * (size_t)(Gm::IMGS * HW);
         const size_t left = (batch - blk * Gm::IMGS) * (size_t)HW;
         const int limit = left < (size_t)(Gm::IMGS * HW) ? (int)left : Gm::IMGS * HW; // valid bytes (multiple of 8)
-        uint4 v[NE];
 #pragma unroll
         for (int e = 0; e < NE; ++e) {
             const int off = (tid + NTHR * e) * 16;
@@ -82,7 +123,8 @@ __global__ __launch_bounds__(NTHR) void dwc1_fc_softmax(const int8_t *__restrict
                 v[e].x = h.x, v[e].y = h.y;
             }
         }
-        __syncthreads(); // halo / table written (first step); previous step's tiles and partial sums consumed
+    };
+    auto write_images = [&](uint8_t *set) {
 #pragma unroll
         for (int e = 0; e < NE; ++e) {
             const int c = tid + NTHR * e;
@@ -93,75 +135,72 @@ __global__ __launch_bounds__(NTHR) void dwc1_fc_softmax(const int8_t *__restrict
                     const int d = 4 * c + q;                       // dword of the 16-image block
                     const int img = d / (HW / 4), r = d - img * (HW / 4);
                     const int row = r / (Gm::W / 4), cw = r - row * (Gm::W / 4);
-                    *(uint32_t *)(lds + img * Gm::TILE + (row + Gm::PT) * Gm::RP + Gm::XO + 4 * cw) = w4[q];
+                    *(uint32_t *)(set + img * Gm::TILE + (row + Gm::PT) * Gm::RP + Gm::XO + 4 * cw) = w4[q];
                 }
             }
         }
-        __syncthreads();
-
-        // ---- depthwise taps (MFMA) -> requantise -> FullyConnected partial sums ----
-        int fc[4] = {0, 0, 0, 0}, rs = 0;
-        constexpr int UB = 3;
-        for (int j = j0; j < j1; j += UB) {
-            v4i B[UB][3];
+    };
+    if (blockIdx.x >= nblk) return;
+    load_images(blockIdx.x);
+    __syncthreads(); // halo and tables written
+    MF_TR(0);
+    write_images(lds);
+    if (blockIdx.x + gridDim.x < nblk) load_images(blockIdx.x + gridDim.x);
+    __syncthreads();
+    MF_TR(1);
+    int cur = 0;
+    for (size_t blk = blockIdx.x; blk < nblk; blk += gridDim.x, cur ^= 1) {
+        // ---- depthwise taps (MFMA) -> requantise -> FullyConnected (MFMA) on tile set `cur` ----
+        const uint8_t *tb = lds + cur * SET + tb_off;
+        v4i facc = {0, 0, 0, 0};
+        v4i B[3], Bn[3], F, Fn;
+        loadB(tb, wave, B);
+        F = loadF(wave);
+        for (int i = 0; i < ni; ++i) {
+            const int jn = wave + NW * (i + 1 < ni ? i + 1 : i); // next unit (harmless re-read at the end)
+            loadB(tb, jn, Bn);
+            Fn = loadF(jn);
+            v4i acc[4];
 #pragma unroll
-            for (int u = 0; u < UB; ++u) {
-                const int jj = (j + u < j1) ? j + u : j1 - 1;
-                const int t = jj / Gm::NM, m = jj - t * Gm::NM;
-                const uint8_t *a = tb + (4 * t) * Gm::RP + 8 * m;
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    const v2i b0 = *(const v2i *)(a + (4 * k) * Gm::RP), b1 = *(const v2i *)(a + (4 * k) * Gm::RP + 8);
-                    B[u][k] = (v4i){b0.x, b0.y, b1.x, b1.y};
-                }
-            }
-            v4i acc[UB];
-#pragma unroll
-            for (int u = 0; u < UB; ++u) acc[u] = (v4i){cK.x, cK.y, cK.z, cK.w};
+            for (int sft = 0; sft < 4; ++sft) acc[sft] = (v4i){cK.x, cK.y, cK.z, cK.w};
 #pragma unroll
             for (int k = 0; k < 3; ++k)
 #pragma unroll
-                for (int u = 0; u < UB; ++u) acc[u] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Aw[k], B[u][k], acc[u], 0, 0, 0);
+                for (int sft = 0; sft < 4; ++sft)
+                    acc[sft] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Aw[sft][k], B[k], acc[sft], 0, 0, 0);
+            uint32_t q0, q1, q2, q3; // pixels 4m .. 4m+3, this lane's 4 channels
+            requant_pack4x2<MG, XR4>(acc[0], cA, cS, acc[1], cA, cS, p.dw_lo, p.dw_hi, q0, q1);
+            requant_pack4x2<MG, XR4>(acc[2], cA, cS, acc[3], cA, cS, p.dw_lo, p.dw_hi, q2, q3);
+            facc = __builtin_amdgcn_mfma_i32_16x16x64_i8(F, (v4i){(int)q0, (int)q1, (int)q2, (int)q3}, facc, 0, 0, 0);
 #pragma unroll
-            for (int u = 0; u < UB; ++u) {
-                if (j + u < j1) { // wave-uniform
-                    const int jj = j + u;
-                    const uint32_t q = requant_pack4<MG, XR4>(acc[u][0], acc[u][1], acc[u][2], acc[u][3], cA, cS, p.dw_lo, p.dw_hi);
-                    const uint4 wv = *(const uint4 *)(fw + jj * 64);
-                    fc[0] = sdot4(q, wv.x, fc[0]), fc[1] = sdot4(q, wv.y, fc[1]);
-                    fc[2] = sdot4(q, wv.z, fc[2]), fc[3] = sdot4(q, wv.w, fc[3]);
-                    if constexpr (WZP) { // row sum of the FullyConnected input: pixel row 2t + p must exist
-                        const int t = jj / Gm::NM;
-                        rs = sdot4(q, (2 * t + (g >> 1) < Gm::OH) ? 0x01010101u : 0u, rs);
-                    }
-                }
-            }
+            for (int k = 0; k < 3; ++k) B[k] = Bn[k];
+            F = Fn;
         }
-        // lane groups of one image, then the waves
-#pragma unroll
-        for (int n = 0; n < 4; ++n) {
-            fc[n] += __shfl_xor(fc[n], 16, 64);
-            fc[n] += __shfl_xor(fc[n], 32, 64);
+        MF_TR(2);
+        // accumulator rows: lane group 0 holds outputs 0..3 of image `col`, lane group 1 row 4 = the row sum
+        int *pw = part + ((cur * NW + wave) * 16 + col) * 8;
+        if (g == 0) *(int4 *)pw = make_int4(facc[0], facc[1], facc[2], facc[3]);
+        if (g == 1) pw[4] = facc[0];
+        // the other tile set was last read one step ago (before the previous barrier): stage the next images now
+        if (blk + gridDim.x < nblk) {
+            write_images(lds + (cur ^ 1) * SET);
+            if (blk + 2 * (size_t)gridDim.x < nblk) load_images(blk + 2 * (size_t)gridDim.x);
         }
-        if constexpr (WZP) rs += __shfl_xor(rs, 16, 64), rs += __shfl_xor(rs, 32, 64);
-        if (g == 0) {
-            int *dst = part + (wave * 16 + col) * 8;
-            *(int4 *)dst = make_int4(fc[0], fc[1], fc[2], fc[3]);
-            dst[4] = rs;
-        }
-        __syncthreads();
+        MF_TR(3);
+        __syncthreads(); // partial sums and the next tile set are visible
+        MF_TR(4);
         if (tid < 64) { // (image, output) = (lane >> 2, lane & 3)
             const int img = lane >> 2, n = lane & 3;
             int d = 0, r = 0;
 #pragma unroll
             for (int w = 0; w < NW; ++w) {
-                d += part[(w * 16 + img) * 8 + n];
-                if constexpr (WZP) r += part[(w * 16 + img) * 8 + 4];
+                d += part[((cur * NW + w) * 16 + img) * 8 + n];
+                if constexpr (WZP) r += part[((cur * NW + w) * 16 + img) * 8 + 4];
             }
-            const int acc = d - p.fc.wzp * r + p.fc.Kc[n];
+            const int acc = d - p.fc.wzp * r + fcK;
             // the FullyConnected output byte as it would be stored (i8 domain), then softmax's table index
-            const int y = (int)(int8_t)(requant(acc, p.fc.A[n], p.fc.S, p.fc.lo_f, p.fc.hi_f) ^ p.fc.xr);
-            const float e = p.sm.exp_table[y + 128];
+            const int y = (int)(int8_t)(requant(acc, fcA, p.fc.S, p.fc.lo_f, p.fc.hi_f) ^ p.fc.xr);
+            const float e = expt[y + 128];
             float sum = 0.0f;
 #pragma unroll
             for (int jn = 0; jn < 4; ++jn) sum = __fadd_rn(sum, __shfl(e, (lane & ~3) + jn, 64)); // softmax.rs:20-21 order
@@ -172,6 +211,10 @@ __global__ __launch_bounds__(NTHR) void dwc1_fc_softmax(const int8_t *__restrict
             const size_t image = blk * Gm::IMGS + img;
             if (image < batch) out[image * 4 + n] = (int8_t)(qi ^ p.sm.xr);
         }
+        MF_TR(5);
+#if MF_DWFC_DIAG
+        ++trace_step;
+#endif
     }
 }
 
@@ -184,7 +227,7 @@ const char *dwfc_name() { return "dwc1_fc_softmax<49,40,10,8,2>"; }
 void launch_dwfc(const int8_t *in, int8_t *out, const DwFcArgs &a, size_t batch, hipStream_t s) {
     using Gm = DwFcGeom;
     constexpr int NTHR = MF_DWFC_THREADS;
-    constexpr int lds = Gm::IMGS * Gm::TILE + Gm::FCW_BYTES + (NTHR / 64) * 16 * 8 * 4;
+    constexpr int lds = 2 * Gm::IMGS * Gm::TILE + Gm::FCW_BYTES + 2 * (NTHR / 64) * 16 * 8 * 4 + 256 * 4;
     const size_t nblk = (batch + Gm::IMGS - 1) / Gm::IMGS;
     const bool wz = a.fc.wzp != 0;
 #define MF_DWFC(MG, XR, WZ)                                                                           \
@@ -201,6 +244,19 @@ void launch_dwfc(const int8_t *in, int8_t *out, const DwFcArgs &a, size_t batch,
     else { if (a.magic) { MF_DWFC2(true, 0u); } else { MF_DWFC2(false, 0u); } }
 #undef MF_DWFC2
 #undef MF_DWFC
+#if MF_DWFC_DIAG
+    {
+        static int calls = 0;
+        if (++calls == 12 || calls == 40) {
+            (void)hipStreamSynchronize(s);
+            long long h[32];
+            (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_dwfc_trace), sizeof(h));
+            fprintf(stderr, "[dwfc trace] batch %zu; cycles since kernel entry:", batch);
+            for (int i = 0; i < 16; ++i) fprintf(stderr, " %d:%lld", i, h[i] - h[31]);
+            fprintf(stderr, "\n");
+        }
+    }
+#endif
 }
 
 } // namespace k

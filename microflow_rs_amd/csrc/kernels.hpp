@@ -149,13 +149,13 @@ struct DwFcGeom {
     static constexpr int ROWS = 4 * (NT - 1) + 12;  // tile rows read by the last row pair
     static constexpr int RP = 56;                   // row pitch, bytes (>= 8 (NM - 1) + 16; 14 words: see bank note)
     static constexpr int TILE = ((ROWS * RP + 15) / 32) * 32 + 16; // image pitch = 16 mod 32 bytes (4 mod 8 words)
-    static constexpr int FCW_BYTES = 4 * NU * 64;   // FullyConnected weights table
+    static constexpr int FCW_BYTES = NU * 4 * 5 * 16; // FullyConnected operand A, rows 0..4 only: [unit][lane group][row][16 B]
     static_assert(S == 2 && KW == 8 && OW % 4 == 0 && KH + S <= 12, "dwc1_fc_softmax: window / row-pair scheme");
     static_assert(8 * (NM - 1) + 16 <= RP && XO + W <= RP && TILE >= ROWS * RP && PT + H <= ROWS, "dwc1_fc_softmax: tile");
 };
 struct DwFcArgs {
     const void *wA;          // [4 shifts][3 k-steps][64 lanes] x 16 B: depthwise taps as MFMA operand A
-    const void *wfc;         // [4 shifts][NU][4 lane groups][4 outputs] dwords of FullyConnected weights
+    const void *wfc;         // [NU][4 lane groups][5 rows][16 B]: FullyConnected weights (rows 0..3), ones (row 4)
     const float *dwA, *dwS;
     const int *dwKc;
     float dw_lo, dw_hi;

@@ -763,19 +763,22 @@ FusedImpl *fused_dwfc_create(OpImpl *dw, FusedImpl *fcsm) {
                     wa[(((size_t)sft * 3 + kk) * 64 + lane) * 16 + (size_t)(kx + Gm::S * sft + Gm::E0)] =
                         dw_w(ky, kx, c);
             }
-    // FullyConnected weights per (shift, unit = (t, m), lane group g = (p, channel half), output n): the 4 weights
-    // that meet this lane's packed dword = pixel (2t + p, 4m + s), channels 4 (g & 1) .. + 3 of the NHWC flattening
+    // FullyConnected as operand A of one more MFMA per unit (t, m): lane group g = (p, channel half) holds, for row
+    // n < 4, the weights of the 16 activations it packs -- pixels (2t + p, 4m + s), s = 0..3, channels 4 (g & 1) .. + 3
+    // of the NHWC flattening -- and for row 4 ones (the row sum); nothing for pixel rows beyond the image
     std::vector<int8_t> wf((size_t)Gm::FCW_BYTES, 0);
-    for (int sft = 0; sft < 4; ++sft)
-        for (int u = 0; u < Gm::NU; ++u)
-            for (int g = 0; g < 4; ++g) {
-                const int t = u / Gm::NM, m = u % Gm::NM, oy = 2 * t + (g >> 1), ox = 4 * m + sft;
-                if (oy >= Gm::OH) continue;
-                const size_t k0 = ((size_t)oy * Gm::OW + ox) * 8 + 4 * (size_t)(g & 1);
-                for (int n = 0; n < 4; ++n)
-                    for (int b = 0; b < 4; ++b)
-                        wf[((((size_t)sft * Gm::NU + u) * 4 + g) * 4 + n) * 4 + b] = fc_w[(size_t)n * q.K + k0 + b];
+    for (int u = 0; u < Gm::NU; ++u)
+        for (int g = 0; g < 4; ++g) {
+            const int t = u / Gm::NM, m = u % Gm::NM, oy = 2 * t + (g >> 1);
+            if (oy >= Gm::OH) continue;
+            for (int sft = 0; sft < 4; ++sft) {
+                const size_t k0 = ((size_t)oy * Gm::OW + 4 * m + sft) * 8 + 4 * (size_t)(g & 1);
+                for (int b = 0; b < 4; ++b) {
+                    for (int n = 0; n < 4; ++n) wf[(((size_t)u * 4 + g) * 5 + n) * 16 + 4 * sft + b] = fc_w[(size_t)n * q.K + k0 + b];
+                    wf[(((size_t)u * 4 + g) * 5 + 4) * 16 + 4 * sft + b] = 1;
+                }
             }
+        }
     f->stage_w.emplace_back(new DevBuf);
     f->stage_w.back()->upload(wa.data(), wa.size());
     f->dwfc.wA = f->stage_w.back()->p;
