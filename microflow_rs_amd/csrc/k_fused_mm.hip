@@ -41,6 +41,10 @@
 #define MF_RR_DIAG 0 // 1 / 2 / 3: diagnostics builds of dwpw_rr (no stores / no arithmetic / no HBM reads), never shipped
 #endif
 
+#ifndef MF_RR_PERM_PACK
+#define MF_RR_PERM_PACK 0 // 1: v_cvt + v_perm packing of the intermediate (A/B switch)
+#endif
+
 namespace mf {
 namespace k {
 
@@ -563,13 +567,17 @@ __global__ __launch_bounds__(NTHR, WPE) void dwpw_rr(const int8_t *__restrict__ 
                 uint32_t d[2] = {0u, 0u};
 #pragma unroll
                 for (int q = 0; q < NQ; ++q)
-                    // v_perm packing here, not requant_pack4: this dword is an MFMA operand a few instructions later,
-                    // and a VGPR byte written through SDWA is not forwarded to the matrix pipe in time (measured:
-                    // stale operands, wrong results) -- stores and LDS writes read it correctly
+#if MF_RR_PERM_PACK
                     d[q] = pack4x<XR4>(requant_t<MG>(acc[u][q][0], dA[q].x, dS[q].x, p.dw.lo_f, p.dw.hi_f),
                                        requant_t<MG>(acc[u][q][1], dA[q].y, dS[q].y, p.dw.lo_f, p.dw.hi_f),
                                        requant_t<MG>(acc[u][q][2], dA[q].z, dS[q].z, p.dw.lo_f, p.dw.hi_f),
                                        requant_t<MG>(acc[u][q][3], dA[q].w, dS[q].w, p.dw.lo_f, p.dw.hi_f));
+#else
+                    // this dword is an MFMA operand a few instructions later: the SDWA byte writes must not be the
+                    // instruction right before their reader (k_common.hpp: cvt_pack4 ends with an independent slot)
+                    d[q] = requant_pack4<MG, XR4>(acc[u][q][0], acc[u][q][1], acc[u][q][2], acc[u][q][3], dA[q], dS[q],
+                                                  p.dw.lo_f, p.dw.hi_f);
+#endif
                 // K-bytes 8g .. 8g+7 of the pointwise contraction (bytes 4..7 meet zero weights when C < 32)
                 const long bop = (long)(((unsigned long)d[1] << 32) | (unsigned long)d[0]);
                 uint32_t packed[NT];
