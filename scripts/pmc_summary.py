@@ -6,7 +6,7 @@
 Units and corrections (MI355X_MICROARCH.md, HBM section): FETCH_SIZE / WRITE_SIZE are in KiB
 as derived from the L2's memory-side request counters; on gfx950 FETCH_SIZE reports exactly
 half of the bytes of a wide (16 B/lane) coalesced streaming read, so it is doubled here.
-WRITE_SIZE is reported as is (uncalibrated).  Values are per launch (mean over launches).
+WRITE_SIZE is reported as is (uncalibrated).  Values are per launch (median over launches).
 """
 import csv
 import glob
@@ -34,11 +34,14 @@ def short(name):
     # trailing variant arguments (MG = bit-pattern int->f32, XR4 = element type, F32IN) are not part
     # of the library's names
     base, args = m.group(1), (m.group(2) or "").replace(" ", "").replace("true", "1").replace("false", "0")
-    keep = {"dw3x3_nhwc": 6, "pw_mfma": 2, "dwpw3x3": 8}
+    keep = {"dw3x3_nhwc": 6, "pw_mfma": 2, "dwpw3x3": 8, "dwpw_rr": 8, "dwpw_mm": 8, "stage_6x6x128": 3,
+            "tail_pool_head_softmax": 1, "fc_rowwave": 1, "fc_rowwave_softmax": 1}
     if base in keep:
         args = "<" + ",".join(args.strip("<>").split(",")[: keep[base]]) + ">"
     if base == "dw_c1_lds":
         args = ""
+    if base == "dwc1_fc_softmax":
+        args = "<49,40,10,8,2>"
     if base == "dw3x3_stem8":
         args = "<96,96,2>"
     return base + args
@@ -60,8 +63,10 @@ def main():
     for name in sorted(set(fetch) | set(write)):
         if "mf::k::" not in name:
             continue
-        f = sum(fetch.get(name, [0])) / max(len(fetch.get(name, [])), 1) * 1024 * 2
-        w = sum(write.get(name, [0])) / max(len(write.get(name, [])), 1) * 1024
+        # median over launches: the bench's parity checks launch the same kernels on a few images as well
+        med = lambda v: sorted(v)[len(v) // 2] if v else 0.0  # noqa: E731
+        f = med(fetch.get(name, [])) * 1024 * 2
+        w = med(write.get(name, [])) * 1024
         s = short(name)
         e = {"kernel": s, "launches": len(fetch.get(name, [])), "fetch_bytes": int(f), "write_bytes": int(w),
              "traffic_bytes": int(f + w)}
