@@ -300,15 +300,20 @@ static bool f32_first(const ModelImpl *m, int last_op) {
     return m->fusion && !m->generic && last_op >= 0 && !m->ops.empty() && m->ops[0] && op_accepts_f32(m->ops[0]);
 }
 
-// run ops [0..last_op]; `src_f32` != nullptr: operator 0 consumes the f32 input directly
+// run ops [0..last_op]; `src_f32` != nullptr: operator 0 consumes the f32 input directly.  `final_dst` != nullptr: the
+// launch that produces operator last_op's tensor writes it there instead of into an activation buffer (no copy of
+// the result afterwards: 16 MB per step for the 4096^3 FullyConnected); the return value says where the result is.
 static const int8_t *run_ops(ModelImpl *m, const int8_t *src, size_t batch, int last_op, hipStream_t stream,
-                             const float *src_f32 = nullptr) {
+                             const float *src_f32 = nullptr, int8_t *final_dst = nullptr) {
     const int8_t *cur = src;
     int which = 0;
     int first = 0;
+    // the last operator that launches anything (trailing Reshapes alias its output)
+    int last_real = last_op;
+    while (last_real >= 0 && !m->ops[last_real]) --last_real;
     if (src_f32) {
-        op_run_f32(m->ops[0], src_f32, batch, m->act[0], stream);
-        cur = m->act[0];
+        op_run_f32(m->ops[0], src_f32, batch, (final_dst && last_real == 0) ? final_dst : m->act[0], stream);
+        cur = (final_dst && last_real == 0) ? final_dst : m->act[0];
         which = 1;
         first = 1;
     }
@@ -320,15 +325,18 @@ static const int8_t *run_ops(ModelImpl *m, const int8_t *src, size_t batch, int 
             which ^= 1;
             dst = m->act[which];
         }
-        if (stage_at(m, i, last_op)) { // the whole late stage in one launch
+        const bool staged = stage_at(m, i, last_op);
+        const bool grouped = !staged && fused_at(m, i) && m->fused_last[(size_t)i] <= last_op;
+        const int end = staged ? m->stage_last : (grouped ? m->fused_last[(size_t)i] : i);
+        if (final_dst && end >= last_real) dst = final_dst;
+        if (staged) { // a whole run of groups in one launch
             fused_run(m->stage, cur, batch, dst, stream);
-            i = m->stage_last;
-        } else if (fused_at(m, i) && m->fused_last[(size_t)i] <= last_op) { // the whole group in one launch
+        } else if (grouped) { // the whole group in one launch
             fused_run(m->fused[(size_t)i], cur, batch, dst, stream);
-            i = m->fused_last[(size_t)i];
         } else {
             op_run(o, cur, batch, dst, stream);
         }
+        i = end;
         cur = dst;
         which ^= 1;
     }
@@ -355,10 +363,11 @@ static void enqueue_device(ModelImpl *m, const float *in_f32, const int8_t *in_i
     } else {
         q_in = in_i8; // consumed in place
     }
-    const int8_t *res = run_ops(m, q_in, batch, last_op, s, fuse_q ? in_f32 : nullptr);
+    // an i8 model's result is written straight into the caller's buffer by the last launch
+    const int8_t *res = run_ops(m, q_in, batch, last_op, s, fuse_q ? in_f32 : nullptr, (out_i8 && !pm.u8 && ((uintptr_t)out_i8 & 15) == 0) ? out_i8 : nullptr); // (16-byte vector stores)
     if (out_i8) {
         if (pm.u8) dev_xor80(m->device, res, batch * out_elems, out_i8, s);
-        else MF_HIP(hipMemcpyAsync(out_i8, res, batch * out_elems, hipMemcpyDeviceToDevice, s));
+        else if (res != out_i8) MF_HIP(hipMemcpyAsync(out_i8, res, batch * out_elems, hipMemcpyDeviceToDevice, s));
     } else { // .dequantize()  (lib.rs:190) with the parameters the last op stamped on the tensor
         float oscale = pm.out_scale;
         int ozp = pm.out_zp;

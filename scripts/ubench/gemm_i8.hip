@@ -6,6 +6,7 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -mllvm -amdgpu-mfma-vgpr-form=1 \
 //         scripts/ubench/gemm_i8.hip -o scripts/ubench/gemm_i8 && scripts/ubench/gemm_i8 [M N K]
 #include <hip/hip_runtime.h>
+#include <type_traits>
 
 #include <cstdint>
 #include <cstdio>
@@ -215,7 +216,63 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm(const int8_t *__restrict__ 
     };
 
     const int nk = K / BK;
-    if constexpr (MODE == 5 || MODE == 6) {
+    if constexpr (MODE == 7) {
+        // FOUR waves (one per SIMD), each a 128 x 128 register tile (256 accumulator VGPRs): no second wave to hide
+        // behind, so everything else is issued in the shadow of the wave's own MFMAs, in program order: between two
+        // MFMAs of sub-step ks sits one ds_read of sub-step ks+1 (fragments double-buffered in registers, across
+        // tile boundaries too) or one LDS-DMA piece of a later tile.  One barrier per K-tile, B(kt), at the start of
+        // the tile's LAST sub-step: by then every wave has read all of tile kt (its last fragments were loaded during
+        // the previous sub-step), so (a) buffer kt & 1 is free for the DMAs of tile kt+2 and (b) with vmcnt(0) in front
+        // of it tile kt+1 -- issued one tile time earlier -- is complete for everyone, and its first fragments can be
+        // loaded during this last sub-step.
+        constexpr int KS = BK / 32, PIECES = XP + WP, HALF = PIECES / 2;
+        static_assert(KS == 4 && NBUF == 2 && MT * NT == 16 && PIECES <= 16, "MODE 7 plan");
+        v4i fa[2][NT], fb[2][MT];
+        // DMA == 0: no pieces; 1 / 2: first / second half of tile kt_dma's pieces.  Nothing in a slot is conditional
+        // at run time (a tile index past the end is clamped: the re-staged buffer is never read again).
+        auto slot = [&](const v4i (&a)[NT], const v4i (&b)[MT], v4i (&an)[NT], v4i (&bn)[MT], const uint8_t *lbn, int ksn,
+                        int kt_dma, int buf_dma, auto dma_tag) {
+            constexpr int DMA = decltype(dma_tag)::value;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const int m = nt * MT + mt;
+                    acc[nt][mt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[nt], b[mt], acc[nt][mt], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (m < MT) {
+                        bn[m] = *(const v4i *)(lbn + xoff[m] + (((ksn * 2 + half) ^ xkey[m]) << 4));
+                    } else if (m < MT + NT) {
+                        an[m - MT] = *(const v4i *)(lbn + woff[m - MT] + (((ksn * 2 + half) ^ wkey[m - MT]) << 4));
+                    } else if (DMA != 0 && m - MT - NT < HALF) {
+                        stage_piece(kt_dma, buf_dma, (DMA - 1) * HALF + m - MT - NT);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+        };
+        using std::integral_constant;
+        const int last = nk - 1;
+        stage(0, 0);
+#pragma unroll
+        for (int q = 0; q < HALF; ++q) stage_piece(1 < nk ? 1 : last, 1, q);
+        wait_vm<HALF>();
+        __builtin_amdgcn_s_barrier();
+        load_frags(lds, 0, fa[0], fb[0]);
+        for (int kt = 0; kt < nk; ++kt) {
+            const int cur = kt & 1;
+            const uint8_t *lb = lds + cur * BUF, *lo = lds + (cur ^ 1) * BUF;
+            const int k1 = kt + 1 < nk ? kt + 1 : last, k2 = kt + 2 < nk ? kt + 2 : last;
+            // tile kt+1: second half of its pieces (the first half went out in the previous tile's last sub-step)
+            slot(fa[0], fb[0], fa[1], fb[1], lb, 1, k1, cur ^ 1, integral_constant<int, 2>{});
+            slot(fa[1], fb[1], fa[0], fb[0], lb, 2, 0, 0, integral_constant<int, 0>{});
+            slot(fa[0], fb[0], fa[1], fb[1], lb, 3, 0, 0, integral_constant<int, 0>{});
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier(); // B(kt)
+            __builtin_amdgcn_sched_barrier(0);
+            slot(fa[1], fb[1], fa[0], fb[0], lo, 0, k2, cur, integral_constant<int, 1>{});
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else if constexpr (MODE == 5 || MODE == 6) {
         constexpr int KS = BK / 32, PIECES = XP + WP;
         constexpr int SUB = MODE == 5 ? 1 : 2;       // k-substeps per phase
         constexpr int PH = KS / SUB;                 // phases per tile
@@ -524,6 +581,9 @@ int main(int argc, char **argv) {
     }
     printf("int8 GEMM M=%d N=%d K=%d (NT), random operands, fused requantize epilogue\n", M, N, K);
     for (int rep = 0; rep < 1; ++rep) {
+    run<256, 256, 2, 2, 128, 2, 7>("256x256 4 waves x 128x128, frags 1 substep ahead", dX, dY, a, ref.data(), r0, nrows, iters);
+    run<256, 256, 2, 2, 128, 2, 0>("256x256 4 waves x 128x128, syncthreads", dX, dY, a, ref.data(), r0, nrows, iters);
+    run<256, 256, 2, 2, 128, 2, 3>("256x256 4 waves x 128x128, frag db within tile", dX, dY, a, ref.data(), r0, nrows, iters);
     run<256, 256, 2, 4, 128, 2, 0>("256x256 BK128 2buf syncthreads (product)", dX, dY, a, ref.data(), r0, nrows, iters);
     run<256, 256, 2, 4, 128, 2, 4>("256x256 BK128 2buf staggered wave groups", dX, dY, a, ref.data(), r0, nrows, iters);
     run<256, 256, 2, 4, 128, 2, 5>("256x256 staggered, DMA inside MFMA sections", dX, dY, a, ref.data(), r0, nrows, iters);
