@@ -226,6 +226,18 @@ template <int TS> __device__ __forceinline__ constexpr int tile_swz(int x) {
 // Persistent-workgroup kernels launch exactly as many workgroups as are resident (LDS-,
 // VGPR- or wave-limited, asked of the runtime once per kernel), so every workgroup walks the
 // same number of steps and none queues behind a finished one.
+// 4 x 4 transpose between four registers and the four 16-lane groups of a wave: on return register i of lane
+// group g holds what register g of lane group i held (v_permlane32_swap: lanes 32..63 of the first <-> lanes 0..31 of
+// the second operand; v_permlane16_swap: odd 16-lane rows of the first <-> even rows of the second).
+__device__ __forceinline__ void lane_group_transpose4(uint32_t &r0, uint32_t &r1, uint32_t &r2, uint32_t &r3) {
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    u32x2 t;
+    t = __builtin_amdgcn_permlane32_swap(r0, r2, false, false), r0 = t[0], r2 = t[1];
+    t = __builtin_amdgcn_permlane32_swap(r1, r3, false, false), r1 = t[0], r3 = t[1];
+    t = __builtin_amdgcn_permlane16_swap(r0, r1, false, false), r0 = t[0], r1 = t[1];
+    t = __builtin_amdgcn_permlane16_swap(r2, r3, false, false), r2 = t[0], r3 = t[1];
+}
+
 // Function attributes and occupancy are per DEVICE, and one process may drive several GPUs, so
 // each launcher keeps one slot per device (benign race: two threads may both prepare a slot).
 struct LaunchState {

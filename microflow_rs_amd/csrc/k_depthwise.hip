@@ -290,6 +290,122 @@ __global__ __launch_bounds__(256) void dw3x3_stem8(const int8_t *__restrict__ in
 }
 
 // ------------------------------------------------------------------------
+// FAST PATH 2a' -- the same stem with its 9 taps on the matrix pipe (dw3x3_stem8_mm; int8 input).
+// dw3x3_stem8 spends 6 v_dot4 (half rate) per 8 output bytes before the requantisation; here the taps of
+// 16 pixel pairs x (2 pixels x 8 channels) are ONE v_mfma_i32_16x16x32_i8:
+//   column j  : pixel pair (2j, 2j+1) of an output row; its 3x3 windows span input columns 4j-1 .. 4j+3
+//   K bytes   : lane group g = filter row ky (g = 3: zero weights); the lane's 8 bytes are the ALIGNED dwords at
+//               columns 4j-4 and 4j of tile row 2oy + ky (one ds_read2_b32): pixel 2j uses bytes 3..5, pixel 2j+1
+//               bytes 5..7 -- the weights sit at those byte positions of operand A (DwStemArgs::wmm, host-built)
+//   rows      : (pixel of the pair, channel) -> a lane ends with 4 consecutive channels of one pixel = one packed
+//               dword; the 64 dwords of a tile are 256 contiguous output bytes
+//   tiles     : the 24 pairs x 2 rows of an output row pair are exactly 3 tiles; a wave walks row pairs, all lane
+//               offsets are three per-type constants
+// Same tile, staging and (reference) padding as dw3x3_stem8; what is left on the VALU is the requantisation.
+// ------------------------------------------------------------------------
+template <int H, int W, int G, bool MG, uint32_t XR4>
+__global__ __launch_bounds__(256) void dw3x3_stem8_mm(const int8_t *__restrict__ in, int8_t *__restrict__ out, DwStemArgs p,
+                                                      int batch) {
+    constexpr int S = 2;
+    constexpr int OH = (H + S - 1) / S, OW = (W + S - 1) / S;
+    constexpr int GUARD = 16;
+    constexpr int TILE = GUARD + (H + 2) * W;     // [guard][izp row][H rows][izp row]
+    constexpr int BUF = G * TILE;
+    constexpr int IMG = H * W;
+    constexpr int NI = IMG / 1024;                // 1 KiB DMA instructions per image
+    constexpr int PAIRS = OW / 2;                 // pixel pairs per output row
+    constexpr int RP = OH / 2;                    // output row pairs per image (3 tiles each)
+    constexpr int WPI = 4 / G;                    // waves per image
+    constexpr int RPW = RP / WPI;                 // row pairs per wave
+    static_assert(IMG % 1024 == 0 && W % 16 == 0 && PAIRS == 24 && OH % 2 == 0 && TILE % 16 == 0, "stem geometry");
+    static_assert((G == 1 || G == 2 || G == 4) && RP % WPI == 0, "wave split");
+
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int col = lane & 15, g = lane >> 4;
+    for (int i = tid; i < 2 * BUF / 16; i += 256)
+        ((uint4 *)lds)[i] = make_uint4(p.izp4, p.izp4, p.izp4, p.izp4);
+    const long Aw = (long)(((unsigned long)p.wmm[lane][1] << 32) | (unsigned long)p.wmm[lane][0]);
+    const int cq = (g & 1) * 4; // this lane's channels within its pixel
+    const float4 cA = make_float4(p.A[cq], p.A[cq + 1], p.A[cq + 2], p.A[cq + 3]);
+    const float4 cS = make_float4(p.S[cq], p.S[cq + 1], p.S[cq + 2], p.S[cq + 3]);
+    const v4i cK = {p.Kc[cq] + (MG ? MF_MAGIC_I : 0), p.Kc[cq + 1] + (MG ? MF_MAGIC_I : 0), p.Kc[cq + 2] + (MG ? MF_MAGIC_I : 0),
+                    p.Kc[cq + 3] + (MG ? MF_MAGIC_I : 0)};
+    // the three tile types of a row pair (rows r0, r0 + 1; 24 pairs each): pairs 0..15 of r0 | 16..23 of r0 and
+    // 0..7 of r0 + 1 | 8..23 of r0 + 1.  Lane byte offset of its operand inside the image tile, relative to the
+    // row pair: tile row 2 oy + ky (tile row 0 is the izp row = input row -1), column 4j - 4
+    int off[3];
+    bool first[3]; // j == 0: column -1 is padding
+    {
+        const int oy1 = col >= 8 ? 1 : 0, j1 = col >= 8 ? col - 8 : 16 + col;
+        off[0] = GUARD + g * W + 4 * col - 4;
+        off[1] = GUARD + (2 * oy1 + g) * W + 4 * j1 - 4;
+        off[2] = GUARD + (2 + g) * W + 4 * (8 + col) - 4;
+        first[0] = col == 0, first[1] = col == 8, first[2] = false;
+    }
+    const int img_g = wave / WPI, rp0 = (wave % WPI) * RPW;
+    __syncthreads();
+
+    auto stage = [&](int st, int buf) {
+#pragma unroll
+        for (int k = 0; k < (G * NI + 3) / 4; ++k) {
+            const int r = k * 4 + wave;           // wave-uniform 1 KiB piece of the step
+            const int gg = r / NI, c = r % NI;
+            if (r < G * NI && st * G + gg < batch)
+                dma16(in + ((size_t)(st * G + gg) * IMG + c * 1024 + lane * 16),
+                      lds + buf * BUF + gg * TILE + GUARD + W + c * 1024);
+        }
+    };
+
+    const int nsteps = (batch + G - 1) / G;
+    int step = blockIdx.x, cur = 0;
+    if (step < nsteps) stage(step, 0);
+    for (; step < nsteps; step += gridDim.x, cur ^= 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const int next = step + gridDim.x;
+        if (next < nsteps) stage(next, cur ^ 1);
+        if (step * G + img_g >= batch) continue; // (wave-uniform; no barrier below)
+
+        const uint8_t *tile = lds + cur * BUF + img_g * TILE + (2 * rp0) * S * W; // row pair rp: output rows 2rp, 2rp+1
+        uint4 *dst = (uint4 *)out + ((size_t)(step * G + img_g) * OH * PAIRS + (size_t)(2 * rp0) * PAIRS) + g * 16 + col;
+        // per row pair: 3 tiles = 48 pixel pairs = 768 output bytes.  Four row pairs = 12 tiles per iteration; the
+        // four dwords of a pixel pair sit in the four lane groups of ONE tile, so tiles are taken in groups of four
+        // and transposed across the lane groups (2 x 2 v_permlane swaps): lane (col, g) then holds all 16 bytes of
+        // pair `col` of the group's tile g -> one 16-byte store per lane, 256 contiguous bytes per 16 lanes
+        static_assert(RPW % 4 == 0, "row pairs per wave in fours");
+#pragma unroll 1
+        for (int it = 0; it < RPW / 4; ++it) {
+            const uint8_t *t0 = tile + it * (16 * W); // 4 row pairs = 8 output rows = 16 input rows further down
+            long B[12];
+#pragma unroll
+            for (int n = 0; n < 12; ++n) {
+                const uint32_t *q = (const uint32_t *)(t0 + (n / 3) * (4 * W) + off[n % 3]);
+                uint32_t d0 = q[0];
+                const uint32_t d1 = q[1];
+                d0 = first[n % 3] ? p.izp4 : d0;
+                B[n] = (long)(((unsigned long)d1 << 32) | (unsigned long)d0);
+            }
+            uint32_t q[12];
+#pragma unroll
+            for (int n = 0; n < 12; n += 2) {
+                const v4i a0 = __builtin_amdgcn_mfma_i32_16x16x32_i8(Aw, B[n], cK, 0, 0, 0);
+                const v4i a1 = __builtin_amdgcn_mfma_i32_16x16x32_i8(Aw, B[n + 1], cK, 0, 0, 0);
+                requant_pack4x2<MG, XR4>(a0, cA, cS, a1, cA, cS, p.lo_f, p.hi_f, q[n], q[n + 1]);
+            }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                uint32_t r0 = q[4 * k], r1 = q[4 * k + 1], r2 = q[4 * k + 2], r3 = q[4 * k + 3];
+                lane_group_transpose4(r0, r1, r2, r3);
+                dst[(size_t)it * 192 + (4 * k) * 16] = make_uint4(r0, r1, r2, r3); // tile 4k + g: + g * 16 is in dst
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------
 // FAST PATH 2b -- DepthwiseConv2D with ONE input channel, up to 8 output channels, any filter
 // size / stride / padding (speech.tflite op 1: 49x40x1 -> 25x20x8, 10x8 filter, stride 2).
 // (src/ops/depthwise_conv_2d.rs:67: every output channel reads input channel 0.)
@@ -464,6 +580,17 @@ bool launch_dw_stem(int H, int W, int DM, int S, const int8_t *in, int8_t *out, 
 #define MF_STEM2(F)                                                                          \
     if (a.xr) { if (a.magic) MF_STEM(true, 0x80808080u, F); else MF_STEM(false, 0x80808080u, F); } \
     else { if (a.magic) MF_STEM(true, 0u, F); else MF_STEM(false, 0u, F); }
+        static const bool valu = [] { const char *e = getenv("MF_STEM_IMPL"); return e && e[0] == 'v'; }();
+        if (!f32_input && !valu) { // int8 input: taps on the matrix pipe
+            static LaunchState stm;
+            const int pcu = prepared(stm, dw3x3_stem8_mm<96, 96, G, false, 0u>, 256, lds);
+            const int gridm = nsteps < 256 * pcu ? nsteps : 256 * pcu;
+#define MF_STEMM(MG, XR) hipLaunchKernelGGL((dw3x3_stem8_mm<96, 96, G, MG, XR>), dim3(gridm), dim3(256), lds, s, in, out, a, batch)
+            if (a.xr) { if (a.magic) MF_STEMM(true, 0x80808080u); else MF_STEMM(false, 0x80808080u); }
+            else { if (a.magic) MF_STEMM(true, 0u); else MF_STEMM(false, 0u); }
+#undef MF_STEMM
+            return true;
+        }
         if (f32_input) { MF_STEM2(true) } else { MF_STEM2(false) }
 #undef MF_STEM2
 #undef MF_STEM

@@ -93,6 +93,7 @@ struct DwC1Args {
 };
 struct DwStemArgs {
     uint32_t wrow[3][8]; // [ky][c] = bytes (w[ky][0][c], w[ky][1][c], w[ky][2][c], 0)
+    uint32_t wmm[64][2]; // the same taps as operand A of v_mfma_i32_16x16x32_i8 (dw3x3_stem8_mm): lane -> 8 K-bytes
     float A[8], S[8];
     int Kc[8];
     uint32_t izp4;

@@ -332,6 +332,17 @@ OpImpl *op_create(int device, const OpSpec &spec) {
                         d |= (uint32_t)(uint8_t)s.weights[((size_t)ky * 3 + kx) * s.N + c] << (8 * kx);
                     f.wrow[ky][c] = d;
                 }
+            // matrix-pipe form: accumulator row r = (p, c) = pixel 2j + p of a pixel pair, channel c; lane group g
+            // = filter row; the lane's 8 K-bytes are input columns 4j-4 .. 4j+3 of that row, of which pixel 2j uses
+            // bytes 3..5 and pixel 2j+1 bytes 5..7
+            for (int lane = 0; lane < 64; ++lane) {
+                const int r = lane & 15, g = lane >> 4, pp = r >> 3, c = r & 7;
+                uint8_t b[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (g < 3)
+                    for (int kx = 0; kx < 3; ++kx) b[3 + 2 * pp + kx] = (uint8_t)s.weights[((size_t)g * 3 + kx) * s.N + c];
+                f.wmm[lane][0] = (uint32_t)b[0] | (uint32_t)b[1] << 8 | (uint32_t)b[2] << 16 | (uint32_t)b[3] << 24;
+                f.wmm[lane][1] = (uint32_t)b[4] | (uint32_t)b[5] << 8 | (uint32_t)b[6] << 16 | (uint32_t)b[7] << 24;
+            }
             for (int c = 0; c < 8; ++c) f.A[c] = A[c], f.S[c] = S[c], f.Kc[c] = Kc[c];
             f.izp4 = 0x01010101u * (uint32_t)(uint8_t)(int8_t)s.izp;
             f.lo_f = a.lo_f, f.hi_f = a.hi_f, f.magic = magic, f.xr = xr;

@@ -18,7 +18,11 @@ wzp = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 m = mf.model(synthetic_fc(M, K, N, wzp=wzp, seed=5))
 m.prepare(1, device=0)
 L = _lib.lib()
+if os.environ.get("MF_OWN_STREAM"):
+    own = torch.cuda.Stream()
+    torch.cuda.set_stream(own)
 _lib.check(L.mf_model_set_stream(m._h, torch.cuda.current_stream().cuda_stream))
+print("stream handle", torch.cuda.current_stream().cuda_stream)
 x = torch.randint(-128, 128, (M, K), dtype=torch.int8, device="cuda")
 y = torch.empty(M * N, dtype=torch.int8, device="cuda")
 step = lambda: L.mf_model_run_quantized(m._h, x.data_ptr(), 1, y.data_ptr(), _lib.MF_MEM_DEVICE)  # noqa: E731
