@@ -84,7 +84,16 @@ names = ["SQ_WAVE_CYCLES","SQ_BUSY_CYCLES","SQ_WAIT_ANY","SQ_WAIT_INST_ANY","SQ_
 with open("gpurun_out/sq_summary.csv", "w") as o:
     o.write("kernel," + ",".join(names) + "\n")
     for k in sorted(acc):
-        o.write(k + "," + ",".join("%.0f" % (sum(acc[k][n]) / max(len(acc[k][n]), 1)) for n in names) + "\n")
+        o.write('"' + k + '",' + ",".join("%.0f" % (sum(acc[k][n]) / max(len(acc[k][n]), 1)) for n in names) + "\n")
 print(open("gpurun_out/sq_summary.csv").read())
 PY
+fi
+if [[ $STEPS == *fcprof* ]]; then
+  # kernel stats of the 4096^3 FullyConnected workload alone (BASELINE config 5)
+  rm -rf $OUT/prof_fc
+  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/$OUT/prof_fc" -- \
+      python "$OLDPWD/bench.py" --workload fc4096 --steps 50 --warmup 5 > "$OLDPWD/$OUT/prof_fc_bench.json" 2> "$OLDPWD/$OUT/prof_fc.err")
+  echo "fc rocprof exit $?"
+  f=$(find $OUT/prof_fc -name "*kernel_stats.csv" | head -1)
+  [ -n "$f" ] && grep -i "fc_mfma\|fc_rowsum\|Name" "$f" | cut -c1-200
 fi

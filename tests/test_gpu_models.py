@@ -160,6 +160,27 @@ def test_speech_batch_4096(mf, models, O):
     assert np.array_equal(y[idx].cpu().numpy().reshape(len(idx), -1), want)
 
 
+def test_speech_batch_65536(mf, models, O):
+    """speech at the throughput batch (16 steps per workgroup of the one-launch kernel, ragged tail included):
+    sampled inferences against the oracle, the first 4096 against a batch-4096 run, one launch vs operator by operator."""
+    from microflow_rs_amd.model import synth_i8 as dsynth
+    m = models["speech"]
+    B = 65536 + 7  # not a multiple of the 16 images of a workgroup step
+    x = dsynth(SEED + 3, 0, B * m.input_elems).reshape((B,) + m.input_shape)
+    y = m.run_quantized(x).reshape(B, -1)
+    o = O.Model(model_path("speech"))
+    idx = list(range(0, B, 2111)) + [B - 8, B - 7, B - 1]
+    want = o.run_quantized_batch(x[idx].cpu().numpy().reshape(len(idx), -1))
+    assert np.array_equal(y[idx].cpu().numpy(), want)
+    assert np.array_equal(y[:4096].cpu().numpy(), m.run_quantized(x[:4096]).reshape(4096, -1).cpu().numpy())
+    m.set_fusion(False)
+    try:
+        z = m.run_quantized(x).reshape(B, -1)
+    finally:
+        m.set_fusion(True)
+    assert np.array_equal(y.cpu().numpy(), z.cpu().numpy())
+
+
 def test_kernel_routing(models):
     """The fast HIP kernels are the ones that run for person_detect."""
     m = models["person_detect"]
