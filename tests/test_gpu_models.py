@@ -457,3 +457,25 @@ def test_device_inputs_are_type_checked(mf):
             m.run_quantized(bad)
         with pytest.raises(TypeError):
             m.predict_quantized(bad)
+
+
+@pytest.mark.parametrize("name,batch", [("sine", 3), ("speech", 1), ("speech", 21), ("person_detect", 1), ("person_detect", 5)])
+def test_last_launch_writes_exactly_the_result(mf, name, batch):
+    """mf_model_run_quantized with device buffers: the last launch writes the result straight into the caller's
+    buffer (no copy).  Nothing outside [out, out + batch * output_elems) may be touched, whatever vector width the
+    kernel stores with, and an unaligned output pointer must still work (copy path)."""
+    import torch
+    from microflow_rs_amd import _lib
+    m = mf.Model(model_path(name), device=0)
+    m.prepare(batch)
+    L = _lib.lib()
+    n_out = batch * m.output_elems
+    x = torch.randint(-128, 128, (batch * m.input_elems,), dtype=torch.int8, device="cuda")
+    want = m.run_quantized(x.reshape((batch,) + m.input_shape)).reshape(-1).cpu().numpy()
+    for lead in (256, 3):  # 16-byte aligned (direct write) / unaligned (copy)
+        buf = torch.full((lead + n_out + 256,), 0x5A, dtype=torch.int8, device="cuda")
+        _lib.check(L.mf_model_run_quantized(m._h, x.data_ptr(), batch, buf.data_ptr() + lead, _lib.MF_MEM_DEVICE))
+        torch.cuda.synchronize()
+        got = buf.cpu().numpy()
+        assert np.array_equal(got[lead:lead + n_out], want), (name, lead)
+        assert (got[:lead] == 0x5A).all() and (got[lead + n_out:] == 0x5A).all(), (name, lead)
