@@ -196,7 +196,7 @@ def test_kernel_routing(models):
     else:
         assert npairs == 8 and names[13].startswith("stage_6x6x128"), names
         assert all(n.startswith("(fused") for n in names[14:23]), names
-        assert names[23].startswith("dwpw_") and names[25].startswith("dwpw_"), names
+        assert names[23].startswith("dwpw") and names[25].startswith("dwpw"), names
     assert names[27] == "tail_pool_head_softmax<2>"                   # pool + head conv + softmax
     assert names[28].startswith("(fused") and names[29] == "" and names[30].startswith("(fused")
     if not os.environ.get("MF_DWPW_IMPL"):
