@@ -102,8 +102,8 @@ def event_times(torch, step, iters):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="person_detect", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the BASELINE size)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

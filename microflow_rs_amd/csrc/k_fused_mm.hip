@@ -37,10 +37,6 @@
 // plane) is conflict-free without a swizzle.  The pointwise phase is dwpw3x3's.
 #include "k_common.hpp"
 
-#ifndef MF_RR_DIAG
-#define MF_RR_DIAG 0 // 1 / 2 / 3: diagnostics builds of dwpw_rr (no stores / no arithmetic / no HBM reads), never shipped
-#endif
-
 #ifndef MF_RR_PERM_PACK
 #define MF_RR_PERM_PACK 0 // 1: v_cvt + v_perm packing of the intermediate (A/B switch)
 #endif
@@ -376,10 +372,9 @@ template <int H, int W, int C, int S, int N, int G, int NTHR, int DB, int CG, in
 __global__ __launch_bounds__(NTHR, WPE) void dwpw_rr(const int8_t *__restrict__ in, int8_t *__restrict__ out, DwPwArgs p,
                                                      int batch) {
     constexpr bool PAIR = C == 8;
-    // DB: 0 one staging buffer, 1 two, 2 two + a LOADER wave: the last wave of the workgroup issues every DMA and
-    // is the only one that waits for them, so the compute waves never execute `s_waitcnt vmcnt(0)` -- which on
-    // this ISA also waits for their own output STORES to drain (loads and stores share the counter).
-    constexpr bool DBUF = DB != 0, LOADER = DB == 2;
+    // DB: 0 one staging buffer, 1 two.  (A dedicated loader wave -- the only wave that waits for the DMAs, so that the
+    // compute waves' `s_waitcnt vmcnt(0)` never waits for their own output stores -- was measured: no gain.)
+    constexpr bool DBUF = DB != 0;
     static_assert(C == 8 || C == 16 || C == 32, "register-resident pairs: C <= 32");
     constexpr int OH = (H + S - 1) / S, OW = (W + S - 1) / S;
     constexpr int OWC = PAIR ? OW / 2 : OW;
@@ -389,7 +384,7 @@ __global__ __launch_bounds__(NTHR, WPE) void dwpw_rr(const int8_t *__restrict__ 
     constexpr int LP = C < 16 ? 16 : C;
     constexpr int ROWB = W * C, ROW = LP + ROWB + LP + ROWPAD, TILE = (H + 2) * ROW, BUF = G * TILE;
     constexpr int IMG = H * ROWB, ROWCH = ROWB / 16, NROWS = G * H;
-    constexpr int NWAVE = NTHR / 64 - (LOADER ? 1 : 0); // compute waves
+    constexpr int NWAVE = NTHR / 64;
     constexpr int NBUF = DBUF ? 2 : 1;
     constexpr int OPIX = OH * OW;
     static_assert(CG * CY * CX == 16 && G % CG == 0 && OH % CY == 0 && OWC % CX == 0, "column grid");
@@ -466,16 +461,11 @@ __global__ __launch_bounds__(NTHR, WPE) void dwpw_rr(const int8_t *__restrict__ 
 
     auto stage = [&](int st, int buf) {
         const int src_lane = NQ > 1 ? (lane ^ tile_swz<TS>(lane / (NQ > 1 ? NQ : 1))) : lane;
-        constexpr int NISSUE = LOADER ? 1 : NWAVE; // waves sharing the rows of a step
 #pragma unroll
-        for (int k = 0; k < (NROWS + NISSUE - 1) / NISSUE; ++k) {
-            const int r = LOADER ? k : k * NWAVE + wave;
+        for (int k = 0; k < (NROWS + NWAVE - 1) / NWAVE; ++k) {
+            const int r = k * NWAVE + wave;
             const int gi = r / H, y = r % H;
-#if MF_RR_DIAG == 3 // diagnostics build: no HBM reads
-            if (r < NROWS && st * G + gi < batch && lane < ROWCH && batch < 0)
-#else
             if (r < NROWS && st * G + gi < batch && lane < ROWCH)
-#endif
                 dma16(in + ((size_t)(st * G + gi) * IMG + y * ROWB + src_lane * 16),
                       lds + buf * BUF + gi * TILE + (y + 1) * ROW + LP);
         }
@@ -483,26 +473,13 @@ __global__ __launch_bounds__(NTHR, WPE) void dwpw_rr(const int8_t *__restrict__ 
 
     const int nsteps = (batch + G - 1) / G;
     int step = blockIdx.x, cur = 0;
-    if constexpr (LOADER) {
-        if (wave == NWAVE) { // the loader wave: same barrier sequence as the compute waves, no arithmetic
-            if (step < nsteps) stage(step, 0);
-            for (; step < nsteps; step += gridDim.x, cur ^= 1) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this step's tile has landed
-                __syncthreads();                                  // ... and the compute waves left the other buffer
-                const int next = step + gridDim.x;
-                if (next < nsteps) stage(next, cur ^ 1);
-            }
-            return;
-        }
-    } else {
-        if (step < nsteps) stage(step, 0);
-    }
+    if (step < nsteps) stage(step, 0);
 
     for (; step < nsteps; step += gridDim.x) {
-        if constexpr (!LOADER) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads(); // the staged tile is complete; every wave is done with the buffer the next DMA overwrites
         const int next = step + gridDim.x;
-        if constexpr (DBUF && !LOADER) {
+        if constexpr (DBUF) {
             if (next < nsteps) stage(next, cur ^ 1);
         }
         const int gvalid = min(G, batch - step * G);
@@ -548,19 +525,6 @@ __global__ __launch_bounds__(NTHR, WPE) void dwpw_rr(const int8_t *__restrict__ 
                         for (int ty = 0; ty < 3; ++ty)
                             bn[u][q][ty] = *(const v4i *)(tb + tbase[q] + toff_of(t0 + UB + u) + ty * ROW);
             }
-#if MF_RR_DIAG == 2 // diagnostics build: memory traffic only (stage, read the taps, store them back)
-#pragma unroll
-            for (int u = 0; u < UB; ++u) {
-                int ug = 0, uy = 0, ux = 0;
-                coords(t0 + u, ug, uy, ux);
-                const int ooff = ug * O_UG + uy * O_UY + ux * O_UX;
-                if (cg + (ug + wpg) * CG < gvalid) {
-                    if constexpr (LB == 8) *(uint2 *)(ob + ooff) = make_uint2(bq[u][0][0][0], bq[u][0][1][1]);
-                    else *(uint4 *)(ob + ooff) = make_uint4(bq[u][0][0][0], bq[u][0][1][1], bq[u][0][2][2], bq[u][0][0][3]);
-                }
-            }
-            if (false)
-#endif
 #pragma unroll
             for (int u = 0; u < UB; ++u) {
                 // depthwise requantisation: the intermediate int8 tensor, 4 (C = 32: 8) bytes per lane
@@ -590,11 +554,7 @@ __global__ __launch_bounds__(NTHR, WPE) void dwpw_rr(const int8_t *__restrict__ 
                 int ug = 0, uy = 0, ux = 0;
                 coords(t0 + u, ug, uy, ux);
                 const int ooff = ug * O_UG + uy * O_UY + ux * O_UX;
-#if MF_RR_DIAG == 1 // diagnostics build: no stores (the result is kept alive through a never-true condition)
-                if (packed[0] == 0x12345678u && batch < 0)
-#else
                 if (cg + (ug + wpg) * CG < gvalid) // a ragged last step stages fewer than G images
-#endif
                 {
                     if constexpr (LB == 8) *(uint2 *)(ob + ooff) = make_uint2(packed[0], packed[1]);
                     else *(uint4 *)(ob + ooff) = make_uint4(packed[0], packed[1], packed[2], packed[3]);

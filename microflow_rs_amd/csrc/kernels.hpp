@@ -268,14 +268,10 @@ struct StageArgs {
     X(48, 48, 16, 2, 32, 1, 768, 1, 1, 2, 0, 32, 0x000, 3)  \
     X(24, 24, 32, 1, 32, 1, 256, 1, 1, 2, 0, 0, 0x002, 3)   \
     X(24, 24, 32, 2, 64, 1, 192, 1, 1, 4, 0, 32, 0x002, 2)
+// tuning candidates (MF_DWRR_ALT=<index>): thread counts around the shipped ones
 #define MF_DWRR_ALT_SHAPES(X)                               \
-    X(48, 48, 8, 1, 16, 1, 576, 2, 1, 4, 0, 32, 0x000, 4)   \
-    X(48, 48, 8, 1, 16, 1, 320, 2, 1, 4, 0, 32, 0x000, 3)   \
-    X(48, 48, 16, 2, 32, 1, 832, 2, 1, 2, 0, 32, 0x000, 3)  \
-    X(48, 48, 16, 2, 32, 1, 320, 2, 1, 2, 0, 32, 0x000, 2)  \
-    X(24, 24, 32, 1, 32, 1, 320, 2, 1, 2, 0, 0, 0x002, 3)   \
-    X(24, 24, 32, 1, 32, 1, 832, 2, 1, 2, 0, 0, 0x002, 4)   \
-    X(24, 24, 32, 2, 64, 1, 256, 2, 1, 4, 0, 32, 0x002, 2)
+    X(48, 48, 8, 1, 16, 1, 256, 1, 1, 4, 0, 32, 0x000, 4)   \
+    X(24, 24, 32, 1, 32, 1, 128, 1, 1, 2, 0, 0, 0x002, 3)
 
 // (K = input channels, N = output channels) with a compiled pointwise MFMA kernel
 #define MF_PW_SHAPES(X) \
