@@ -1,0 +1,238 @@
+// k_tail3.hip -- the end of a MobileNet-v1 style network in ONE launch (person_detect ops 25..30):
+//   DepthwiseConv2D 3x3 stride 1 on 3x3x256 -> Conv2D 1x1 256 -> 256 -> AveragePool2D over all 9 pixels ->
+//   Conv2D 1x1 256 -> N (head) -> [Reshape] -> Softmax
+// (src/ops/depthwise_conv_2d.rs:28-105, src/ops/conv_2d.rs:28-108, src/ops/average_pool_2d.rs:29-66,
+//  src/ops/softmax.rs:15-27)
+//
+// Arithmetic contract, shared device helpers and launch plumbing: k_common.hpp.
+//
+// A 3x3 tensor has 9 pixels: tiles of 16 PIXELS (dwpw_mm) leave MFMA columns idle and a step of 8 images is too
+// little work between two barriers.  Here the 16 columns of every MFMA are 16 IMAGES (as in k_dwfc.hip): every
+// column does the same thing at the same pixel, all addresses are (lane constant) + (compile-time offset), no
+// column is ever idle, and a workgroup step is 16 images.
+//   waves    : 16; wave w owns 16-channel group w of the depthwise conv and output tile w (16 channels) of the
+//              pointwise conv, with both operand sets (3 + 4 MFMA A registers) and epilogue constants in registers.
+//   depthwise: unit = (pixel, channel group): 3 MFMAs (taps on the matrix pipe, k_fused_mm.hip); operand B of lane
+//              (image, kx) is the 16 channels of input pixel (y + ky - 1, x + kx - 1) -- one ds_read_b128; a row
+//              or a column outside the tensor is read from a 17th, all-zero-point image slot (row: compile-time,
+//              column: one per-lane select per x, hoisted).  Result -> requantise -> MID
+//              [image][pixel][256] in LDS.
+//   pointwise: per pixel 4 K-steps of one MFMA each, operand B straight from MID; the requantised outputs are not
+//              stored at all: AveragePool2D over the whole 3x3 tensor is the sum over the 9 units a lane runs, kept
+//              in registers (the int8 values, exactly as the reference's pool input).
+//   tail     : pool epilogue, the lane's share of the head dot products (4 channels x N), lane-group and wave
+//              reduction through LDS, 16 threads finish head epilogue + table softmax for their image.
+// HBM traffic: 2304 B in, N bytes out per inference.  Image pitch 2320 B: the 16 lanes of a b128 service group hit
+// 16 distinct 16-byte bank slots (2320 / 4 = 4 mod 64 words).
+#include "k_common.hpp"
+
+#ifndef MF_TAIL3_DIAG
+#define MF_TAIL3_DIAG 0 // 1: cycle stamps of block 0 / wave 0 at the phase boundaries of its first two steps (never shipped)
+#endif
+
+namespace mf {
+namespace k {
+
+#if MF_TAIL3_DIAG
+__device__ long long g_tail3_trace[32];
+#define MF_TR(k) do { if (blockIdx.x == 0 && wave == (MF_TAIL3_DIAG - 1) && lane == 0 && trace_step < 2) g_tail3_trace[(k) + 8 * trace_step] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define MF_TR(k) do { } while (0)
+#endif
+
+template <int N, int NTHR>
+__global__ __launch_bounds__(NTHR) void pair3_tail(const int8_t *__restrict__ in, int8_t *__restrict__ out, PairTailArgs p,
+                                                   size_t batch) {
+    constexpr int IMGS = 16, PIX = 9, C = 256, IMG = PIX * C;
+    constexpr int XP = IMG + 16;                           // image pitch in LDS (X3 and MID)
+    constexpr int NW = NTHR / 64;
+    static_assert(NW == 16 && C / 16 == NW, "one channel group and one output tile per wave");
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    constexpr int SET = 16 * XP;                           // one set of 16 staged images
+    uint8_t *x3 = lds;                                     // [2 sets][16][XP] + one all-zero-point image slot
+    uint8_t *zslot = lds + 2 * SET;
+    uint8_t *mid = zslot + XP;                             // [16][XP]
+    int *part = (int *)(mid + 16 * XP);                    // [2][16 images][4]: head sums + value sum, added up by LDS atomics
+    float *expt = (float *)(part + 2 * 16 * 4);            // softmax's 256-entry table
+    int *hci = (int *)(expt + 256);                        // head constants [N][4]: wzp, Kc, A, S (kept out of registers)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int col = lane & 15, g = lane >> 4;
+#if MF_TAIL3_DIAG
+    int trace_step = 0;
+    if (blockIdx.x == 0 && tid == 0) g_tail3_trace[31] = (long long)__builtin_readcyclecounter();
+#endif
+
+    for (int i = tid; i < XP / 16; i += NTHR) ((uint4 *)zslot)[i] = make_uint4(p.izp4, p.izp4, p.izp4, p.izp4);
+    if (tid < 2 * 16 * 4) part[tid] = 0;
+    for (int i = tid; i < 256; i += NTHR) expt[i] = p.tail.exp_table[i];
+    if (tid < N) {
+        hci[4 * tid] = p.tail.wzp[tid], hci[4 * tid + 1] = p.tail.Kc[tid];
+        hci[4 * tid + 2] = __float_as_int(p.tail.A[tid]), hci[4 * tid + 3] = __float_as_int(p.tail.S[tid]);
+    }
+    // operands and constants of this wave's channel group / output tile (channels 16 wave + 4 g .. + 3 for this lane)
+    v4i Adw[3], Apw[4];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) Adw[ky] = ((const v4i *)p.dw_wmm)[(wave * 3 + ky) * 64 + lane];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) Apw[ks] = ((const v4i *)p.pw_w)[(wave * 4 + ks) * 64 + lane];
+    const int ch = 16 * wave + 4 * g;
+    const float4 dA = *(const float4 *)(p.dwA + ch), dS = *(const float4 *)(p.dwS + ch);
+    const int4 dK4 = *(const int4 *)(p.dwK + ch);
+    const v4i dK = {dK4.x, dK4.y, dK4.z, dK4.w};
+    const float4 pA = *(const float4 *)(p.pwA + ch), pS = *(const float4 *)(p.pwS + ch);
+    const int4 pK4 = *(const int4 *)(p.pwK + ch);
+    const v4i pK = {pK4.x, pK4.y, pK4.z, pK4.w};
+    uint32_t hw[N];
+#pragma unroll
+    for (int n = 0; n < N; ++n) hw[n] = *(const uint32_t *)(p.tail.w + (size_t)n * C + ch);
+    // lane part of the depthwise operand address for output column x: input column x + g - 1, or the zero-point slot
+    int laneoff[3];
+#pragma unroll
+    for (int x = 0; x < 3; ++x) {
+        const int cx = x + g - 1;
+        laneoff[x] = (cx >= 0 && cx <= 2) ? col * XP + cx * C : -1; // (-1: the zero-point slot, see below)
+    }
+
+    const size_t nblk = (batch + IMGS - 1) / IMGS;
+    // staging by LDS-DMA, no registers: an image is 2304 B = two 1 KiB pieces + one of 256 B (16 lanes); 48 pieces per
+    // step, 3 per wave.  A ragged last step re-reads the last image.
+    auto stage = [&](size_t blk, int set) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int j = wave + NW * k, img = j / 3, piece = j - img * 3;
+            size_t image = blk * IMGS + img;
+            image = image < batch ? image : batch - 1;
+            if (piece < 2 || lane < 16)
+                dma16(in + image * IMG + piece * 1024 + lane * 16, x3 + set * SET + img * XP + piece * 1024);
+        }
+    };
+    if (blockIdx.x >= nblk) return;
+    stage(blockIdx.x, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads(); // zero-point slot, tables, zeroed sums and the first images are in place
+    int cur = 0;
+    for (size_t blk = blockIdx.x; blk < nblk; blk += gridDim.x, cur ^= 1) {
+        // the other image set was last read before the previous step's barriers: refill it, a whole step ahead
+        if (blk + gridDim.x < nblk) stage(blk + gridDim.x, cur ^ 1);
+        const uint8_t *xs = x3 + cur * SET;
+        MF_TR(0);
+        // ---- depthwise 3x3: channel group `wave`, all 9 pixels ----
+#pragma unroll
+        for (int px = 0; px < PIX; ++px) {
+            const int y = px / 3, x = px % 3;
+            v4i acc = dK;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int iy = y + ky - 1;
+                // a row outside the tensor: the zero-point slot too (compile-time choice)
+                const uint8_t *src = (laneoff[x] >= 0 && iy >= 0 && iy <= 2) ? xs + laneoff[x] + iy * (3 * C) : zslot;
+                const v4i B = *(const v4i *)(src + 16 * wave);
+                acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(Adw[ky], B, acc, 0, 0, 0);
+            }
+            *(uint32_t *)(mid + col * XP + px * C + ch) =
+                requant_pack4<true, 0u>(acc[0], acc[1], acc[2], acc[3], dA, dS, p.dw_lo, p.dw_hi);
+        }
+        MF_TR(1);
+        __syncthreads(); // MID complete
+        MF_TR(2);
+        MF_TR(3);
+        // ---- pointwise 256 -> 256: output tile `wave`; AveragePool2D = the sum over the 9 pixels ----
+        int pool[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int px = 0; px < PIX; ++px) {
+            v4i acc = pK;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const v4i B = *(const v4i *)(mid + col * XP + px * C + 64 * ks + 16 * g);
+                acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(Apw[ks], B, acc, 0, 0, 0);
+            }
+            pool[0] += (int)requant_clamped<true>(acc[0], pA.x, pS.x, p.pw_lo, p.pw_hi);
+            pool[1] += (int)requant_clamped<true>(acc[1], pA.y, pS.y, p.pw_lo, p.pw_hi);
+            pool[2] += (int)requant_clamped<true>(acc[2], pA.z, pS.z, p.pw_lo, p.pw_hi);
+            pool[3] += (int)requant_clamped<true>(acc[3], pA.w, pS.w, p.pw_lo, p.pw_hi);
+        }
+        MF_TR(4);
+        // ---- pool epilogue (average_pool_2d.rs:52-57) and this lane's share of the head dot products ----
+        int q[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float xf = __fmul_rn(p.tail.inv_len, (float)pool[k]);                     // (1/len) * f32(sum)
+            const float yv = __fadd_rn(__fmul_rn(p.tail.pool_c0, xf), p.tail.pool_c1);      // c0 * x + c1
+            const float r = __fadd_rn(yv, __builtin_copysignf(0x1.fffffep-2f, yv));
+            int vq = (r != r) ? 0 : (int)__builtin_amdgcn_fmed3f(r, -128.0f, 127.0f);
+            vq = max(vq, p.tail.pool_lo);
+            q[k] = min(vq, p.tail.pool_hi);
+        }
+        const uint32_t qp = pack4(q[0], q[1], q[2], q[3]);
+        int dot[N], vs = sdot4(qp, 0x01010101u, 0);
+#pragma unroll
+        for (int n = 0; n < N; ++n) dot[n] = sdot4(qp, hw[n], 0);
+        // lane groups of one image, then the waves
+        vs += __shfl_xor(vs, 16, 64), vs += __shfl_xor(vs, 32, 64);
+#pragma unroll
+        for (int n = 0; n < N; ++n) dot[n] += __shfl_xor(dot[n], 16, 64), dot[n] += __shfl_xor(dot[n], 32, 64);
+        if (g == 0) { // 16 waves add into the step's 16 x (N + 1) sums
+            int *dst = part + (cur * 16 + col) * 4;
+#pragma unroll
+            for (int n = 0; n < N; ++n) atomicAdd(dst + n, dot[n]);
+            atomicAdd(dst + N, vs);
+        }
+        MF_TR(5);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's pieces of the next step have landed
+        __syncthreads(); // sums complete; MID consumed; the next images are in place for everyone
+        MF_TR(6);
+        if (tid < 16 * N) { // head epilogue + softmax: thread (image, n) = (tid / N, tid % N)  (conv_2d.rs:93-98, softmax.rs:20-27)
+            const int img = tid / N, n = tid - img * N;
+            int *src = part + (cur * 16 + img) * 4;
+            const int acc = src[n] - hci[4 * n] * src[N] + hci[4 * n + 1];
+            const int h = requant(acc, __int_as_float(hci[4 * n + 2]), __int_as_float(hci[4 * n + 3]), p.tail.lo_f, p.tail.hi_f);
+            const float e = expt[h + 128];
+            float sum = 0.0f;
+#pragma unroll
+            for (int j = 0; j < N; ++j) sum = __fadd_rn(sum, __shfl(e, img * N + j, 64)); // one row: index order
+            const float prob = __fdiv_rn(e, sum);
+            const float qf = __fadd_rn(__fdiv_rn(prob, p.tail.sm_oscale), p.tail.sm_ozp_f);
+            const float r = __fadd_rn(qf, __builtin_copysignf(0x1.fffffep-2f, qf));
+            const size_t image = blk * IMGS + img;
+            if (image < batch) out[image * N + n] = (int8_t)((r != r) ? 0 : (int)__builtin_amdgcn_fmed3f(r, -128.0f, 127.0f));
+            // (the sums of this buffer are next added to two steps from now, after two more barriers)
+            __builtin_amdgcn_wave_barrier();
+            src[n] = 0;
+            if (n == 0) src[N] = 0;
+        }
+        MF_TR(7);
+#if MF_TAIL3_DIAG
+        ++trace_step;
+#endif
+    }
+}
+
+bool pair_tail_supported(int H, int W, int C, int N_pw, int N_head, int ntaps) {
+    return H == 3 && W == 3 && C == 256 && N_pw == 256 && N_head == 2 && ntaps == 9;
+}
+const char *pair_tail_name() { return "pair3_tail<3,3,256,2>"; }
+void launch_pair_tail(const int8_t *in, int8_t *out, const PairTailArgs &a, size_t batch, hipStream_t s) {
+    constexpr int NTHR = 1024, XP = 9 * 256 + 16;
+    constexpr int lds = (2 * 16 + 1 + 16) * XP + 2 * 16 * 4 * 4 + 256 * 4 + 2 * 4 * 4;
+    static LaunchState st;
+    const int per_cu = prepared(st, pair3_tail<2, NTHR>, NTHR, lds);
+    const size_t nblk = (batch + 15) / 16, cap = (size_t)256 * per_cu;
+    hipLaunchKernelGGL((pair3_tail<2, NTHR>), dim3((unsigned)(nblk < cap ? nblk : cap)), dim3(NTHR), lds, s, in, out, a, batch);
+#if MF_TAIL3_DIAG
+    {
+        static int calls = 0;
+        if (++calls == 12) {
+            (void)hipStreamSynchronize(s);
+            long long h[32];
+            (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_tail3_trace), sizeof(h));
+            fprintf(stderr, "[tail3 trace] batch %zu per_cu %d; cycles since kernel entry:", batch, per_cu);
+            for (int i = 0; i < 16; ++i) fprintf(stderr, " %d:%lld", i, h[i] - h[31]);
+            fprintf(stderr, "\n");
+        }
+    }
+#endif
+}
+
+} // namespace k
+} // namespace mf

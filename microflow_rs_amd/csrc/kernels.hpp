@@ -172,6 +172,24 @@ bool dwfc_supported(int H, int W, int KH, int KW, int sh, int sw, int OH, int OW
 const char *dwfc_name();
 void launch_dwfc(const int8_t *in, int8_t *out, const DwFcArgs &a, size_t batch, hipStream_t s);
 
+// DepthwiseConv2D 3x3 + Conv2D 1x1 on a 3x3x256 tensor + AveragePool2D + head Conv2D + Softmax in one launch
+// (k_tail3.hip: person_detect ops 25..30)
+struct PairTailArgs {
+    const void *dw_wmm;      // depthwise taps, matrix-pipe form (DwFastArgs::wmm)
+    const float *dwA, *dwS;
+    const int *dwK;          // folded constants + 0x4B400000 (bit-pattern int->float offset, added on the host)
+    float dw_lo, dw_hi;
+    uint32_t izp4;
+    const void *pw_w;        // pointwise weights [N/16][K/64][64 lanes] x 16 bytes (row r of tile tt = channel 16 tt + r)
+    const float *pwA, *pwS;
+    const int *pwK;          // + 0x4B400000
+    float pw_lo, pw_hi;
+    TailArgs tail;
+};
+bool pair_tail_supported(int H, int W, int C, int N_pw, int N_head, int ntaps);
+const char *pair_tail_name();
+void launch_pair_tail(const int8_t *in, int8_t *out, const PairTailArgs &a, size_t batch, hipStream_t s);
+
 // a run of identical depthwise + pointwise pairs on a small tensor as one persistent kernel (k_stage.hip)
 struct StagePair {
     const void *dw_wmm;      // depthwise taps, matrix-pipe form (DwFastArgs::wmm)

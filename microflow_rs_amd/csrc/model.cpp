@@ -38,10 +38,14 @@ struct ModelImpl {
     // the pool -> head conv -> [reshape] -> softmax tail)
     std::vector<FusedImpl *> fused;
     std::vector<int> fused_last;
-    // second level: ops stage_first .. stage_last (a run of identical pair groups) as ONE persistent kernel
-    // (k_stage.hip); the pair groups inside stay available for mf_model_run_until
-    FusedImpl *stage = nullptr;
-    int stage_first = -1, stage_last = -1;
+    // second level: ops first .. last (several first-level groups / operators) as ONE kernel: a run of identical pair
+    // groups (k_stage.hip), a one-input-channel depthwise + FullyConnected + Softmax (k_dwfc.hip), the last pair + the
+    // tail (k_tail3.hip).  They do not overlap; what is inside stays available for mf_model_run_until.
+    struct Stage {
+        FusedImpl *f;
+        int first, last;
+    };
+    std::vector<Stage> stages;
     bool fusion = true;
     size_t cap_batch = 0;
     int8_t *act[2] = {nullptr, nullptr};
@@ -77,7 +81,7 @@ struct ModelImpl {
         drop_graph();
         if (cap_stream) (void)hipStreamDestroy(cap_stream);
         if (copy_stream) (void)hipStreamDestroy(copy_stream);
-        if (stage) fused_destroy(stage); // borrows the pair groups' buffers: first
+        for (const Stage &st : stages) fused_destroy(st.f); // they borrow the groups' buffers: first
         for (FusedImpl *f : fused) fused_destroy(f);
         for (OpImpl *o : ops) op_destroy(o);
         free_buffers();
@@ -111,8 +115,12 @@ const ParsedModel &model_parsed(const ModelImpl *m) { return m->pm; }
 static bool fused_at(const ModelImpl *m, int i) {
     return m->fusion && !m->generic && i >= 0 && i < (int)m->fused.size() && m->fused[(size_t)i];
 }
-static bool stage_at(const ModelImpl *m, int i, int last_op) {
-    return m->stage && m->fusion && !m->generic && i == m->stage_first && m->stage_last <= last_op;
+// the second-level group that starts at op i and ends at or before last_op, if any
+static const ModelImpl::Stage *stage_at(const ModelImpl *m, int i, int last_op) {
+    if (!m->fusion || m->generic) return nullptr;
+    for (const ModelImpl::Stage &st : m->stages)
+        if (st.first == i && st.last <= last_op) return &st;
+    return nullptr;
 }
 // index of the fused group that swallows op i (without being its first op), or -1
 static int fused_owner(const ModelImpl *m, int i) {
@@ -122,9 +130,10 @@ static int fused_owner(const ModelImpl *m, int i) {
 }
 const char *model_op_kernel(const ModelImpl *m, int i) {
     if (!m->prepared || i < 0 || i >= (int)m->ops.size() || !m->ops[i]) return "";
-    if (stage_at(m, i, (int)m->ops.size() - 1)) return fused_kernel_name(m->stage);
-    if (m->stage && m->fusion && !m->generic && i > m->stage_first && i <= m->stage_last)
-        return "(fused into the previous operator)";
+    if (const ModelImpl::Stage *st = stage_at(m, i, (int)m->ops.size() - 1)) return fused_kernel_name(st->f);
+    if (m->fusion && !m->generic)
+        for (const ModelImpl::Stage &st : m->stages)
+            if (i > st.first && i <= st.last) return "(fused into the previous operator)";
     if (fused_at(m, i)) return fused_kernel_name(m->fused[(size_t)i]);
     if (fused_owner(m, i) >= 0) return "(fused into the previous operator)";
     return op_kernel_name(m->ops[i]);
@@ -222,11 +231,21 @@ void model_prepare(ModelImpl *m, int device, size_t max_batch) {
             }
             if (fused[i]) i = (size_t)fused_last[i]; // groups do not overlap
         }
-        // (4) the longest run of consecutive pair groups on one tensor shape -> a persistent stage kernel, if one
-        // exists for that shape and count (ops.hip: fused_stage_create)
-        FusedImpl *stage = nullptr;
-        int stage_first = -1, stage_last = -1;
-        for (size_t i = 0; i + 1 < n && !stage; ++i) {
+        // second level (the guard destroys what was built if anything below throws)
+        struct StageGuard {
+            std::vector<ModelImpl::Stage> v;
+            ~StageGuard() {
+                for (const ModelImpl::Stage &st : v) fused_destroy(st.f);
+            }
+        } sg;
+        auto covered = [&](size_t i) {
+            for (const ModelImpl::Stage &st : sg.v)
+                if ((int)i >= st.first && (int)i <= st.last) return true;
+            return false;
+        };
+        // (4) runs of consecutive pair groups on one tensor shape -> a persistent stage kernel, if one exists for that
+        // shape and count (ops.hip: fused_stage_create)
+        for (size_t i = 0; i + 1 < n; ++i) {
             if (!fused[i] || fused_last[i] != (int)i + 1) continue;
             std::vector<FusedImpl *> run;
             size_t a = i;
@@ -236,28 +255,27 @@ void model_prepare(ModelImpl *m, int device, size_t max_batch) {
                 run.push_back(fused[a]);
                 a += 2;
             }
-            if (run.size() >= 2 && (stage = fused_stage_create(run.data(), (int)run.size())))
-                stage_first = (int)i, stage_last = (int)a - 1;
+            if (run.size() >= 2)
+                if (FusedImpl *f = fused_stage_create(run.data(), (int)run.size())) sg.v.push_back({f, (int)i, (int)a - 1});
             if (!run.empty()) i = a - 1; // continue after the run
         }
         // (5) DepthwiseConv2D with one input channel -> [Reshape] -> the FullyConnected + Softmax group -> one kernel
-        for (size_t i = 0; i + 1 < n && !stage; ++i) {
-            if (!ops[i] || fused[i] || m->pm.ops[i].kind != MF_OP_DEPTHWISE_CONV_2D) continue;
+        for (size_t i = 0; i + 1 < n; ++i) {
+            if (!ops[i] || fused[i] || covered(i) || m->pm.ops[i].kind != MF_OP_DEPTHWISE_CONV_2D) continue;
             size_t j = i + 1;
             while (j < n && m->pm.ops[j].kind == MF_OP_RESHAPE) ++j;
-            if (j < n && fused[j] && (stage = fused_dwfc_create(ops[i], fused[j])))
-                stage_first = (int)i, stage_last = fused_last[j];
+            if (j < n && fused[j] && !covered(j))
+                if (FusedImpl *f = fused_dwfc_create(ops[i], fused[j])) sg.v.push_back({f, (int)i, fused_last[j]});
         }
-        struct StageGuard {
-            FusedImpl *&s;
-            bool keep = false;
-            ~StageGuard() {
-                if (!keep && s) fused_destroy(s);
-            }
-        } sg{stage};
+        // (6) the last pair group directly followed by the tail group -> one kernel (ops.hip: fused_pair_tail_create)
+        for (size_t i = 0; i + 2 < n; ++i) {
+            if (!fused[i] || fused_last[i] != (int)i + 1 || covered(i)) continue;
+            const size_t j = i + 2;
+            if (fused[j] && !covered(j))
+                if (FusedImpl *f = fused_pair_tail_create(fused[i], fused[j])) sg.v.push_back({f, (int)i, fused_last[j]});
+        }
         // commit (nothing below throws)
-        sg.keep = true;
-        m->stage = stage, m->stage_first = stage_first, m->stage_last = stage_last;
+        m->stages.swap(sg.v);
         m->device = device;
         m->ops.swap(pend.ops);
         m->fused.swap(pend.fused);
@@ -325,12 +343,12 @@ static const int8_t *run_ops(ModelImpl *m, const int8_t *src, size_t batch, int 
             which ^= 1;
             dst = m->act[which];
         }
-        const bool staged = stage_at(m, i, last_op);
+        const ModelImpl::Stage *staged = stage_at(m, i, last_op);
         const bool grouped = !staged && fused_at(m, i) && m->fused_last[(size_t)i] <= last_op;
-        const int end = staged ? m->stage_last : (grouped ? m->fused_last[(size_t)i] : i);
+        const int end = staged ? staged->last : (grouped ? m->fused_last[(size_t)i] : i);
         if (final_dst && end >= last_real) dst = final_dst;
-        if (staged) { // a whole run of groups in one launch
-            fused_run(m->stage, cur, batch, dst, stream);
+        if (staged) { // several groups in one launch
+            fused_run(staged->f, cur, batch, dst, stream);
         } else if (grouped) { // the whole group in one launch
             fused_run(m->fused[(size_t)i], cur, batch, dst, stream);
         } else {
@@ -539,10 +557,10 @@ void model_time_device(ModelImpl *m, const int8_t *d_in, size_t batch, int8_t *d
                         which ^= 1;
                         dst = m->act[which];
                     }
-                    if (stage_at(m, i, nops - 1)) { // the stage is timed as one unit (index i), its other ops 0
-                        fused_run(m->stage, cur, batch, dst, s);
-                        for (int j = i; j < m->stage_last; ++j) MF_HIP(hipEventRecord(ev[(size_t)j + 1], s));
-                        i = m->stage_last;
+                    if (const ModelImpl::Stage *st = stage_at(m, i, nops - 1)) { // timed as one unit (index i), its other ops 0
+                        fused_run(st->f, cur, batch, dst, s);
+                        for (int j = i; j < st->last; ++j) MF_HIP(hipEventRecord(ev[(size_t)j + 1], s));
+                        i = st->last;
                     } else if (fused_at(m, i)) { // the group is timed as one unit (index i), its other ops 0
                         fused_run(m->fused[(size_t)i], cur, batch, dst, s);
                         for (int j = i; j < m->fused_last[(size_t)i]; ++j) MF_HIP(hipEventRecord(ev[(size_t)j + 1], s));

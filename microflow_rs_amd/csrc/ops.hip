@@ -608,7 +608,7 @@ void op_run_f32(OpImpl *op, const float *d_in, size_t batch, int8_t *d_out, void
 }
 
 struct FusedImpl {
-    enum Kind { DWPW, TAIL, FCSM, STAGE, DWFC } kind;
+    enum Kind { DWPW, TAIL, FCSM, STAGE, DWFC, PAIRTAIL } kind;
     OpImpl *a, *b, *c;
     k::DwPwArgs dwpw;
     k::TailArgs tail;
@@ -619,6 +619,8 @@ struct FusedImpl {
     std::vector<std::unique_ptr<DevBuf>> stage_w; // the stage kernel's own operand arrays and its pair table
     // DWFC: one-input-channel depthwise -> FullyConnected -> Softmax in one kernel (operand tables in stage_w)
     k::DwFcArgs dwfc{};
+    // PAIRTAIL: the last pair + the tail in one kernel (operand arrays in stage_w)
+    k::PairTailArgs pairtail{};
 };
 
 FusedImpl *fused_create(OpImpl *dw, OpImpl *pw) {
@@ -803,6 +805,41 @@ FusedImpl *fused_dwfc_create(OpImpl *dw, FusedImpl *fcsm) {
     return f.release();
 }
 
+// The last pair group (DepthwiseConv2D 3x3 stride 1 + Conv2D 1x1 on 3x3x256) followed by the tail group
+// (AveragePool2D over the whole tensor -> head Conv2D -> Softmax) as one kernel (k_tail3.hip).  Second level like the
+// stage; nullptr when the shapes are not the compiled instance.
+FusedImpl *fused_pair_tail_create(FusedImpl *pair, FusedImpl *tail) {
+    static const bool off = getenv("MF_NO_PAIRTAIL") != nullptr;
+    if (off || !pair || !tail || pair->kind != FusedImpl::DWPW || tail->kind != FusedImpl::TAIL) return nullptr;
+    const OpSpec &d = pair->a->s, &q = pair->b->s;
+    const k::TailArgs &t = tail->tail;
+    if (!k::pair_tail_supported(d.H, d.W, d.C, q.N, t.N, t.ntaps) || d.sh != 1 || d.sw != 1 || d.u8) return nullptr;
+    if (t.H != d.OH || t.W != d.OW || t.C != q.N || pair->a->device != tail->a->device) return nullptr;
+    if (!pair->dwpw.dw.magic || !pair->dwpw.pw.magic || !pair->dwpw.dw.wmm) return nullptr; // bit-pattern epilogues
+    std::unique_ptr<FusedImpl> f(new FusedImpl{FusedImpl::PAIRTAIL, pair->a, tail->b, tail->c, {}, {}, k::pair_tail_name()});
+    auto with_magic = [&](const int *d_kc, int n) { // Kc + the bit-pattern offset of requant_t<true> (k_common.hpp)
+        std::vector<int32_t> h((size_t)n);
+        MF_HIP(hipMemcpy(h.data(), d_kc, h.size() * 4, hipMemcpyDeviceToHost));
+        for (int32_t &v : h) v = wrap_add(v, 0x4B400000);
+        f->stage_w.emplace_back(new DevBuf);
+        f->stage_w.back()->upload(h.data(), h.size() * 4);
+        return (const int *)f->stage_w.back()->p;
+    };
+    k::PairTailArgs &a = f->pairtail;
+    a.dw_wmm = pair->dwpw.dw.wmm, a.dwA = pair->dwpw.dw.A, a.dwS = pair->dwpw.dw.S, a.dwK = with_magic(pair->dwpw.dw.Kc, d.N);
+    a.dw_lo = pair->dwpw.dw.lo_f, a.dw_hi = pair->dwpw.dw.hi_f, a.izp4 = pair->dwpw.dw.izp4;
+    std::vector<int8_t> host((size_t)q.N * q.C);
+    MF_HIP(hipMemcpy(host.data(), pair->b->conv.w, host.size(), hipMemcpyDeviceToHost)); // [N][1][1][C] as uploaded
+    const std::vector<int8_t> prep = build_pw_plain_weights(host.data(), q.C, q.N);
+    f->stage_w.emplace_back(new DevBuf);
+    f->stage_w.back()->upload(prep.data(), prep.size());
+    a.pw_w = f->stage_w.back()->p;
+    a.pwA = pair->dwpw.pw.A, a.pwS = pair->dwpw.pw.S, a.pwK = with_magic(pair->dwpw.pw.Kc, q.N);
+    a.pw_lo = pair->dwpw.pw.lo_f, a.pw_hi = pair->dwpw.pw.hi_f;
+    a.tail = t;
+    return f.release();
+}
+
 void fused_destroy(FusedImpl *f) { delete f; }
 const char *fused_kernel_name(const FusedImpl *f) { return f->name.c_str(); }
 void fused_run(FusedImpl *f, const int8_t *d_in, size_t batch, int8_t *d_out, void *stream) {
@@ -817,6 +854,11 @@ void fused_run(FusedImpl *f, const int8_t *d_in, size_t batch, int8_t *d_out, vo
     }
     if (f->kind == FusedImpl::TAIL) {
         k::launch_tail(d_in, d_out, f->tail, batch, (hipStream_t)stream);
+        MF_HIP(hipGetLastError());
+        return;
+    }
+    if (f->kind == FusedImpl::PAIRTAIL) {
+        if (batch) k::launch_pair_tail(d_in, d_out, f->pairtail, batch, (hipStream_t)stream);
         MF_HIP(hipGetLastError());
         return;
     }

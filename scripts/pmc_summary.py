@@ -40,6 +40,8 @@ def short(name):
         args = "<" + ",".join(args.strip("<>").split(",")[: keep[base]]) + ">"
     if base == "dw_c1_lds":
         args = ""
+    if base == "pair3_tail":
+        args = "<3,3,256,2>"
     if base == "dwc1_fc_softmax":
         args = "<49,40,10,8,2>"
     if base == "dw3x3_stem8_mm":  # the int8-input stem (matrix-pipe taps): the library calls both stems dw3x3_stem8<96,96,2>
