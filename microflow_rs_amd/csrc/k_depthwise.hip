@@ -303,7 +303,7 @@ __global__ __launch_bounds__(256) void dw3x3_stem8(const int8_t *__restrict__ in
 //               offsets are three per-type constants
 // Same tile, staging and (reference) padding as dw3x3_stem8; what is left on the VALU is the requantisation.
 // ------------------------------------------------------------------------
-template <int H, int W, int G, bool MG, uint32_t XR4>
+template <int H, int W, int G, bool MG, uint32_t XR4, bool F32IN>
 __global__ __launch_bounds__(256) void dw3x3_stem8_mm(const int8_t *__restrict__ in, int8_t *__restrict__ out, DwStemArgs p,
                                                       int batch) {
     constexpr int S = 2;
@@ -359,15 +359,56 @@ __global__ __launch_bounds__(256) void dw3x3_stem8_mm(const int8_t *__restrict__
         }
     };
 
+    // f32 staging (F32IN; same arithmetic and order as dw3x3_stem8's): float4 k of this thread is pixels
+    // 4 (k * 256 + tid) .. + 3 of the step's G images, loaded before this step's compute, quantised and written after it
+    constexpr int NF = F32IN ? G * IMG / 4 / 256 : 1;
+    static_assert(!F32IN || (G * IMG) % 1024 == 0, "f32 staging geometry");
+    f32x4 pre[NF];
+    auto load_f32 = [&](int st) {
+        const f32x4 *src = (const f32x4 *)in;
+#pragma unroll
+        for (int k = 0; k < NF; ++k) {
+            const int idx = k * 256 + tid, gg = idx / (IMG / 4);
+            const size_t img = (size_t)st * G + gg;
+            const size_t at = (img < (size_t)batch ? img : (size_t)batch - 1) * (IMG / 4) + idx % (IMG / 4);
+            pre[k] = src[at]; // clamped, unconditional: a ragged last step re-reads the last image
+        }
+    };
+    auto store_f32 = [&](int buf) {
+#pragma unroll
+        for (int k = 0; k < NF; ++k) {
+            const int idx = k * 256 + tid, gg = idx / (IMG / 4), c = idx % (IMG / 4);
+            int qv[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float t = __fadd_rn(__fdiv_rn(pre[k][e], p.in_scale), p.in_zp_f);
+                const float r = __fadd_rn(t, __builtin_copysignf(0x1.fffffep-2f, t));
+                qv[e] = (r != r) ? 0 : (int)__builtin_amdgcn_fmed3f(r, p.in_sat_lo, p.in_sat_hi);
+            }
+            *(uint32_t *)(lds + buf * BUF + gg * TILE + GUARD + W + c * 4) = pack4(qv[0], qv[1], qv[2], qv[3]) ^ p.in_xr4;
+        }
+    };
+
     const int nsteps = (batch + G - 1) / G;
     int step = blockIdx.x, cur = 0;
-    if (step < nsteps) stage(step, 0);
+    if constexpr (F32IN) {
+        if (step < nsteps) {
+            load_f32(step);
+            store_f32(0);
+        }
+    } else {
+        if (step < nsteps) stage(step, 0);
+    }
     for (; step < nsteps; step += gridDim.x, cur ^= 1) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (!F32IN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         const int next = step + gridDim.x;
-        if (next < nsteps) stage(next, cur ^ 1);
-        if (step * G + img_g >= batch) continue; // (wave-uniform; no barrier below)
+        if constexpr (F32IN) {
+            if (next < nsteps) load_f32(next); // in flight during the compute below
+        } else {
+            if (next < nsteps) stage(next, cur ^ 1);
+        }
+        if (step * G + img_g < batch) { // (wave-uniform)
 
         const uint8_t *tile = lds + cur * BUF + img_g * TILE + (2 * rp0) * S * W; // row pair rp: output rows 2rp, 2rp+1
         uint4 *dst = (uint4 *)out + ((size_t)(step * G + img_g) * OH * PAIRS + (size_t)(2 * rp0) * PAIRS) + g * 16 + col;
@@ -401,6 +442,10 @@ __global__ __launch_bounds__(256) void dw3x3_stem8_mm(const int8_t *__restrict__
                 lane_group_transpose4(r0, r1, r2, r3);
                 dst[(size_t)it * 192 + (4 * k) * 16] = make_uint4(r0, r1, r2, r3); // tile 4k + g: + g * 16 is in dst
             }
+        }
+        }
+        if constexpr (F32IN) {
+            if (next < nsteps) store_f32(cur ^ 1); // the other buffer: last read before this step's barrier
         }
     }
 }
@@ -581,13 +626,17 @@ bool launch_dw_stem(int H, int W, int DM, int S, const int8_t *in, int8_t *out, 
     if (a.xr) { if (a.magic) MF_STEM(true, 0x80808080u, F); else MF_STEM(false, 0x80808080u, F); } \
     else { if (a.magic) MF_STEM(true, 0u, F); else MF_STEM(false, 0u, F); }
         static const bool valu = [] { const char *e = getenv("MF_STEM_IMPL"); return e && e[0] == 'v'; }();
-        if (!f32_input && !valu) { // int8 input: taps on the matrix pipe
-            static LaunchState stm;
-            const int pcu = prepared(stm, dw3x3_stem8_mm<96, 96, G, false, 0u>, 256, lds);
+        if (!valu) { // taps on the matrix pipe
+            static LaunchState stm, stmf;
+            const int pcu = f32_input ? prepared(stmf, dw3x3_stem8_mm<96, 96, G, false, 0u, true>, 256, lds)
+                                      : prepared(stm, dw3x3_stem8_mm<96, 96, G, false, 0u, false>, 256, lds);
             const int gridm = nsteps < 256 * pcu ? nsteps : 256 * pcu;
-#define MF_STEMM(MG, XR) hipLaunchKernelGGL((dw3x3_stem8_mm<96, 96, G, MG, XR>), dim3(gridm), dim3(256), lds, s, in, out, a, batch)
-            if (a.xr) { if (a.magic) MF_STEMM(true, 0x80808080u); else MF_STEMM(false, 0x80808080u); }
-            else { if (a.magic) MF_STEMM(true, 0u); else MF_STEMM(false, 0u); }
+#define MF_STEMM(MG, XR, F) hipLaunchKernelGGL((dw3x3_stem8_mm<96, 96, G, MG, XR, F>), dim3(gridm), dim3(256), lds, s, in, out, a, batch)
+#define MF_STEMM2(F)                                                                               \
+    if (a.xr) { if (a.magic) MF_STEMM(true, 0x80808080u, F); else MF_STEMM(false, 0x80808080u, F); } \
+    else { if (a.magic) MF_STEMM(true, 0u, F); else MF_STEMM(false, 0u, F); }
+            if (f32_input) { MF_STEMM2(true) } else { MF_STEMM2(false) }
+#undef MF_STEMM2
 #undef MF_STEMM
             return true;
         }

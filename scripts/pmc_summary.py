@@ -44,8 +44,8 @@ def short(name):
         args = "<3,3,256,2>"
     if base == "dwc1_fc_softmax":
         args = "<49,40,10,8,2>"
-    if base == "dw3x3_stem8_mm":  # the int8-input stem (matrix-pipe taps): the library calls both stems dw3x3_stem8<96,96,2>
-        base, args = "dw3x3_stem8", "<96,96,2>"
+    if base == "dw3x3_stem8_mm":  # matrix-pipe taps: the library calls both stems dw3x3_stem8<96,96,2>
+        base, args = "dw3x3_stem8", "<96,96,2>" + (" (f32 input)" if args.endswith(",1>") else "")
     elif base == "dw3x3_stem8":   # VALU-tap stem: what remains in use is its f32-input variant (M::predict)
         args = "<96,96,2> (VALU taps%s)" % (", f32 input" if args.endswith(",1>") else "")
     return base + args
