@@ -56,8 +56,10 @@ constexpr int dwmm_lds_bytes(int H, int W, int C, int S, int N, int G, int NTHR,
     const int MIDB = C == 8 ? NPIX * 8 : (C / 16) * (P16 * 16 + 16);
     return (DBUF ? 2 : 1) * BUF + 512 + MIDB + 64 + patch;
 }
+// DWONLY: the depthwise operator alone (layer-wise execution): the pointwise phase is replaced by a copy of MID --
+// which then IS the operator's output tensor -- to HBM with 16-byte loads and stores.
 template <int H, int W, int C, int S, int N, int G, int NTHR, bool DBUF, int CG, int CY, int ORD, int ROWPAD, int TS,
-          int WPE, bool MG, uint32_t XR4>
+          int WPE, bool MG, uint32_t XR4, bool DWONLY>
 __global__ __launch_bounds__(NTHR, WPE) void dwpw_mm(const int8_t *__restrict__ in, int8_t *__restrict__ out, DwPwArgs p,
                                                 int batch) {
     // ---- depthwise geometry ----
@@ -158,21 +160,23 @@ __global__ __launch_bounds__(NTHR, WPE) void dwpw_mm(const int8_t *__restrict__ 
     const int pcol = lane & 15, pg = lane >> 4;
     const int blk = wave % NSPLIT, slot = wave / NSPLIT;
     v4i Aw[Q][TB][KS];
-#pragma unroll
-    for (int q = 0; q < Q; ++q)
-#pragma unroll
-        for (int tt = 0; tt < TB; ++tt)
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks)
-                Aw[q][tt][ks] = ((const v4i *)p.pw.wprep)[((((size_t)blk * Q + q) * TB + tt) * KS + ks) * 64 + lane];
     float4 cA[TB], cS[TB];
     int4 cK[TB];
+    if constexpr (!DWONLY) {
 #pragma unroll
-    for (int tt = 0; tt < TB; ++tt) {
-        const int ch = blk * NB + pg * (NB / 4) + 4 * tt;
-        cA[tt] = *(const float4 *)(p.pw.A + ch);
-        cS[tt] = *(const float4 *)(p.pw.S + ch);
-        cK[tt] = magic4<MG>(*(const int4 *)(p.pw.Kc + ch));
+        for (int q = 0; q < Q; ++q)
+#pragma unroll
+            for (int tt = 0; tt < TB; ++tt)
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks)
+                    Aw[q][tt][ks] = ((const v4i *)p.pw.wprep)[((((size_t)blk * Q + q) * TB + tt) * KS + ks) * 64 + lane];
+#pragma unroll
+        for (int tt = 0; tt < TB; ++tt) {
+            const int ch = blk * NB + pg * (NB / 4) + 4 * tt;
+            cA[tt] = *(const float4 *)(p.pw.A + ch);
+            cS[tt] = *(const float4 *)(p.pw.S + ch);
+            cK[tt] = magic4<MG>(*(const int4 *)(p.pw.Kc + ch));
+        }
     }
     __syncthreads(); // halo fill complete before any DMA lands
 
@@ -271,6 +275,19 @@ __global__ __launch_bounds__(NTHR, WPE) void dwpw_mm(const int8_t *__restrict__ 
             if (next < nsteps) stage(next, 0); // flies during the pointwise phase
         }
 
+        if constexpr (DWONLY) {
+            // ---------------- the depthwise operator alone: MID -> HBM ----------------
+            const int npix = gvalid * OPIX;
+            int8_t *ob = out + (size_t)step * G * OPIX * C;
+            if constexpr (PAIR) { // MID is [pixel][8 bytes]: the output tensor itself (OPIX is even)
+                for (int i = tid; i < npix / 2; i += NTHR) *(uint4 *)(ob + i * 16) = *(const uint4 *)(mid + i * 16);
+            } else {              // planar [16-channel group][pixel][16 bytes] -> [pixel][C]
+                for (int e = tid; e < npix * NQ; e += NTHR)
+                    *(uint4 *)(ob + (size_t)e * 16) = *(const uint4 *)(mid + (e % NQ) * PLANE + (e / NQ) * 16);
+            }
+            if constexpr (DBUF) cur ^= 1;
+            continue;
+        }
         // ---------------- pointwise phase: MID -> HBM (dwpw3x3's, reading the planar MID) ----------------
         const int npix = gvalid * OPIX;
         const int nchunks = (npix + CPIX - 1) / CPIX;
@@ -584,11 +601,50 @@ static void launch_dwpw_mm_t(const int8_t *in, int8_t *out, const DwPwArgs &a, i
     constexpr int lds = dwmm_lds_bytes(H, W, C, S, N, G, NTHR, DB != 0, ROWPAD);
     static_assert(lds <= 163840, "fused tile does not fit the LDS");
     static LaunchState st;
-    const int per_cu = prepared(st, dwpw_mm<H, W, C, S, N, G, NTHR, (DB != 0), CG, CY, ORD, ROWPAD, TS, WPE, MG, XR4>, NTHR, lds);
+    const int per_cu = prepared(st, dwpw_mm<H, W, C, S, N, G, NTHR, (DB != 0), CG, CY, ORD, ROWPAD, TS, WPE, MG, XR4, false>, NTHR, lds);
     const int nsteps = (batch + G - 1) / G;
     const int grid = nsteps < 256 * per_cu ? nsteps : 256 * per_cu;
-    hipLaunchKernelGGL((dwpw_mm<H, W, C, S, N, G, NTHR, (DB != 0), CG, CY, ORD, ROWPAD, TS, WPE, MG, XR4>), dim3(grid), dim3(NTHR),
+    hipLaunchKernelGGL((dwpw_mm<H, W, C, S, N, G, NTHR, (DB != 0), CG, CY, ORD, ROWPAD, TS, WPE, MG, XR4, false>), dim3(grid), dim3(NTHR),
                        lds, s, in, out, a, batch);
+}
+// the depthwise operator alone (DWONLY instance of the same shape)
+template <int H, int W, int C, int S, int N, int G, int NTHR, int DB, int CG, int CY, int ORD, int ROWPAD, int TS, int WPE,
+          bool MG, uint32_t XR4>
+static void launch_dw_mm_t(const int8_t *in, int8_t *out, const DwPwArgs &a, int batch, hipStream_t s) {
+    constexpr int lds = dwmm_lds_bytes(H, W, C, S, N, G, NTHR, DB != 0, ROWPAD);
+    static LaunchState st;
+    const int per_cu = prepared(st, dwpw_mm<H, W, C, S, N, G, NTHR, (DB != 0), CG, CY, ORD, ROWPAD, TS, WPE, MG, XR4, true>, NTHR, lds);
+    const int nsteps = (batch + G - 1) / G;
+    const int grid = nsteps < 256 * per_cu ? nsteps : 256 * per_cu;
+    hipLaunchKernelGGL((dwpw_mm<H, W, C, S, N, G, NTHR, (DB != 0), CG, CY, ORD, ROWPAD, TS, WPE, MG, XR4, true>), dim3(grid), dim3(NTHR),
+                       lds, s, in, out, a, batch);
+}
+// Measured per shape against dw3x3_nhwc (v_dot4 taps, no MID round trip): the matrix-pipe form wins on the three
+// large early layers (48x48x8: 0.54 -> 0.48 ms, 48x48x16 s2: 0.60 -> 0.57, 24x24x32: 0.49 -> 0.47) and loses on
+// the small late ones (12x12x64: 0.26 -> 0.36, 6x6x128: 0.135 -> 0.185: two barriers per small step), so only
+// those three are instantiated.
+constexpr bool dw_mm_layerwise(int h, int s) { return h >= 48 || (h >= 24 && s == 1); }
+const char *dw_mm_name(int H, int W, int C, int S) {
+#define MF_DWMM(h, w, c, s, n, g, t, d, cg, cy, ord, rp, ts, wpe) \
+    if (dw_mm_layerwise(h, s) && H == h && W == w && C == c && S == s) return "dw3x3_mm<" #h "," #w "," #c "," #s "," #g "," #t ">";
+    MF_DWMM_SHAPES(MF_DWMM)
+#undef MF_DWMM
+    return nullptr;
+}
+bool launch_dw_mm(int H, int W, int C, int S, const int8_t *in, int8_t *out, const DwFastArgs &dw, int batch, hipStream_t s) {
+    if (!dw.wmm) return false;
+    DwPwArgs a{};
+    a.dw = dw;
+#define MF_DWMM(h, w, c, st, n, g, t, d, cg, cy, ord, rp, ts, wpe)                                                  \
+    if constexpr (dw_mm_layerwise(h, st)) {                                                                        \
+        if (H == h && W == w && C == c && S == st) {                                                               \
+            MF_DISPATCH4(dw.magic, dw.xr, launch_dw_mm_t, (in, out, a, batch, s), h, w, c, st, n, g, t, d, cg, cy, ord, rp, ts, wpe) \
+            return true;                                                                                           \
+        }                                                                                                          \
+    }
+    MF_DWMM_SHAPES(MF_DWMM)
+#undef MF_DWMM
+    return false;
 }
 const char *dwpw_mm_name(int H, int W, int C, int S, int N) {
 #define MF_DWMM(h, w, c, s, n, g, t, d, cg, cy, ord, rp, ts, wpe) \

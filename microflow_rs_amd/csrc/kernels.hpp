@@ -333,6 +333,9 @@ const char *dwpw_name(int H, int W, int C, int S, int N);
 bool launch_dwpw(int H, int W, int C, int S, int N, const int8_t *in, int8_t *out, const DwPwArgs &a,
                  int batch, hipStream_t s);
 const char *dwpw_mm_name(int H, int W, int C, int S, int N);
+// the depthwise operator alone with its taps on the matrix pipe (layer-wise execution; same shapes as dwpw_mm)
+const char *dw_mm_name(int H, int W, int C, int S);
+bool launch_dw_mm(int H, int W, int C, int S, const int8_t *in, int8_t *out, const DwFastArgs &dw, int batch, hipStream_t s);
 bool launch_dwpw_mm(int H, int W, int C, int S, int N, const int8_t *in, int8_t *out, const DwPwArgs &a,
                     int batch, hipStream_t s);
 const char *dwpw_rr_name(int H, int W, int C, int S, int N);

@@ -243,6 +243,13 @@ std::vector<int8_t> build_pw_rr_weights(const int8_t *w /*[N][K]*/, int K, int N
 
 } // namespace
 
+// layer-wise DepthwiseConv2D 3x3: taps on the matrix pipe (dwpw_mm's depthwise phase, k_fused_mm.hip) unless
+// MF_DW_IMPL=valu asks for the v_dot4 kernels (dw3x3_nhwc)
+static bool dw_taps_on_matrix_pipe() {
+    static const bool valu = [] { const char *e = getenv("MF_DW_IMPL"); return e && e[0] == 'v'; }();
+    return !valu;
+}
+
 OpImpl *op_create(int device, const OpSpec &spec) {
     dev_require(device);
     std::unique_ptr<OpImpl> op(new OpImpl);
@@ -320,6 +327,7 @@ OpImpl *op_create(int device, const OpSpec &spec) {
                 const std::vector<int8_t> prep = build_dw_mm_weights(s.weights, s.C);
                 op->d_wprep.upload(prep.data(), prep.size());
                 f.wmm = op->d_wprep.p;
+                if (dw_taps_on_matrix_pipe() && k::dw_mm_name(s.H, s.W, s.C, s.sh)) op->fast_name = k::dw_mm_name(s.H, s.W, s.C, s.sh);
             }
         } else if (dw && zero_wzp && same3x3 && s.C == 1 && k::dw_stem_name(s.H, s.W, s.N, s.sh)) {
             op->fast = OpImpl::DW_STEM;
@@ -508,7 +516,8 @@ void op_run(OpImpl *op, const int8_t *d_in, size_t batch, int8_t *d_out, void *s
         if (batch > 0x7fffffffull / 4) fail(MF_ERR_INVALID_ARG, "batch too large for one launch");
         switch (op->fast) {
         case OpImpl::DW_NHWC:
-            done = k::launch_dw_fast(sp.H, sp.W, sp.C, sp.sh, d_in, d_out, op->dwf, (int)batch, s);
+            done = (dw_taps_on_matrix_pipe() && k::launch_dw_mm(sp.H, sp.W, sp.C, sp.sh, d_in, d_out, op->dwf, (int)batch, s)) ||
+                   k::launch_dw_fast(sp.H, sp.W, sp.C, sp.sh, d_in, d_out, op->dwf, (int)batch, s);
             break;
         case OpImpl::DW_STEM:
             done = k::launch_dw_stem(sp.H, sp.W, sp.N, sp.sh, d_in, d_out, op->stem, (int)batch, s);

@@ -36,6 +36,9 @@ def short(name):
     base, args = m.group(1), (m.group(2) or "").replace(" ", "").replace("true", "1").replace("false", "0")
     keep = {"dw3x3_nhwc": 6, "pw_mfma": 2, "dwpw3x3": 8, "dwpw_rr": 8, "dwpw_mm": 8, "stage_6x6x128": 3,
             "tail_pool_head_softmax": 1, "fc_rowwave": 1, "fc_rowwave_softmax": 1}
+    if base == "dwpw_mm" and args.endswith(",1>") and args.count(",") >= 16:  # DWONLY instance = the layer-wise depthwise op
+        a = args.strip("<>").split(",")
+        return "dw3x3_mm<%s>" % ",".join(a[:4] + a[5:7])
     if base in keep:
         args = "<" + ",".join(args.strip("<>").split(",")[: keep[base]]) + ">"
     if base == "dw_c1_lds":

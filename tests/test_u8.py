@@ -319,7 +319,7 @@ def test_u8_person_detect_uses_the_fast_kernels(mf, O):
     m.set_fusion(False)
     assert np.array_equal(m.run_quantized(xq).reshape(n, -1), want)
     names = [m.op(i)["kernel"] for i in range(m.num_ops)]
-    assert sum(k.startswith("dw3x3_nhwc") for k in names) == 13 and sum(k.startswith("pw_mfma") for k in names) == 13, names
+    assert sum(k.startswith(("dw3x3_mm", "dw3x3_nhwc")) for k in names) == 13 and sum(k.startswith("pw_mfma") for k in names) == 13, names
     m.set_generic(True)
     assert np.array_equal(m.run_quantized(xq[:5]).reshape(5, -1), want[:5])
 
