@@ -32,12 +32,12 @@ __device__ __forceinline__ void tail_one(const int8_t *x, int8_t *y, const TailA
         const int sums[4] = {s0, s1, s2, s3};
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const float xf = __fmul_rn(p.inv_len, (float)sums[k]);           // (1/len) * f32(sum)
+            const float xf = __fmul_rn(p.inv_len, (float)(sums[k] + p.pool_bias * p.ntaps)); // (1/len) * f32(sum of values)
             const float yv = __fadd_rn(__fmul_rn(p.pool_c0, xf), p.pool_c1); // c0 * x + c1
             const float r = __fadd_rn(yv, __builtin_copysignf(0x1.fffffep-2f, yv));
-            int v = (r != r) ? 0 : (int)__builtin_amdgcn_fmed3f(r, -128.0f, 127.0f);
+            int v = (r != r) ? 0 : (int)__builtin_amdgcn_fmed3f(r, p.pool_sat_lo, p.pool_sat_hi);
             v = max(v, p.pool_lo);
-            q[k] = min(v, p.pool_hi);
+            q[k] = min(v, p.pool_hi) ^ p.xr; // the stored byte (pack4 keeps the low byte)
         }
         const uint32_t qp = pack4(q[0], q[1], q[2], q[3]);
         // ---- this lane's share of the head dot products ----
@@ -59,7 +59,7 @@ __device__ __forceinline__ void tail_one(const int8_t *x, int8_t *y, const TailA
     for (int n = 0; n < N; ++n) {
         const int acc = dot[n] - p.wzp[n] * vs + p.Kc[n];
         h[n] = requant(acc, p.A[n], p.S[n], p.lo_f, p.hi_f);
-        e[n] = p.exp_table[h[n] + 128];
+        e[n] = p.exp_table[(int)(int8_t)(h[n] ^ p.xr) + 128]; // table index = stored byte + 128
         sum = __fadd_rn(sum, e[n]); // one row: column-major order == index order
     }
 #pragma unroll
@@ -67,8 +67,8 @@ __device__ __forceinline__ void tail_one(const int8_t *x, int8_t *y, const TailA
         const float prob = __fdiv_rn(e[n], sum);
         const float qf = __fadd_rn(__fdiv_rn(prob, p.sm_oscale), p.sm_ozp_f);
         const float r = __fadd_rn(qf, __builtin_copysignf(0x1.fffffep-2f, qf));
-        const int yq = (r != r) ? 0 : (int)__builtin_amdgcn_fmed3f(r, -128.0f, 127.0f);
-        if (lane == n) y[n] = (int8_t)yq;
+        const int yq = (r != r) ? 0 : (int)__builtin_amdgcn_fmed3f(r, p.sm_sat_lo, p.sm_sat_hi);
+        if (lane == n) y[n] = (int8_t)(yq ^ p.xr);
     }
 }
 

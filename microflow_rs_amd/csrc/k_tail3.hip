@@ -19,7 +19,7 @@
 //              [image][pixel][256] in LDS.
 //   pointwise: per pixel 4 K-steps of one MFMA each, operand B straight from MID; the requantised outputs are not
 //              stored at all: AveragePool2D over the whole 3x3 tensor is the sum over the 9 units a lane runs, kept
-//              in registers (the int8 values, exactly as the reference's pool input).
+//              in registers (the element values -- i8 or u8 -- exactly as the reference's pool input).
 //   tail     : pool epilogue, the lane's share of the head dot products (4 channels x N), lane-group and wave
 //              reduction through LDS, 16 threads finish head epilogue + table softmax for their image.
 // HBM traffic: 2304 B in, N bytes out per inference.  Image pitch 2320 B: the 16 lanes of a b128 service group hit
@@ -40,7 +40,7 @@ __device__ long long g_tail3_trace[32];
 #define MF_TR(k) do { } while (0)
 #endif
 
-template <int N, int NTHR>
+template <int N, int NTHR, uint32_t XR4>
 __global__ __launch_bounds__(NTHR) void pair3_tail(const int8_t *__restrict__ in, int8_t *__restrict__ out, PairTailArgs p,
                                                    size_t batch) {
     constexpr int IMGS = 16, PIX = 9, C = 256, IMG = PIX * C;
@@ -131,7 +131,7 @@ __global__ __launch_bounds__(NTHR) void pair3_tail(const int8_t *__restrict__ in
                 acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(Adw[ky], B, acc, 0, 0, 0);
             }
             *(uint32_t *)(mid + col * XP + px * C + ch) =
-                requant_pack4<true, 0u>(acc[0], acc[1], acc[2], acc[3], dA, dS, p.dw_lo, p.dw_hi);
+                requant_pack4<true, XR4>(acc[0], acc[1], acc[2], acc[3], dA, dS, p.dw_lo, p.dw_hi);
         }
         MF_TR(1);
         __syncthreads(); // MID complete
@@ -160,9 +160,9 @@ __global__ __launch_bounds__(NTHR) void pair3_tail(const int8_t *__restrict__ in
             const float xf = __fmul_rn(p.tail.inv_len, (float)pool[k]);                     // (1/len) * f32(sum)
             const float yv = __fadd_rn(__fmul_rn(p.tail.pool_c0, xf), p.tail.pool_c1);      // c0 * x + c1
             const float r = __fadd_rn(yv, __builtin_copysignf(0x1.fffffep-2f, yv));
-            int vq = (r != r) ? 0 : (int)__builtin_amdgcn_fmed3f(r, -128.0f, 127.0f);
+            int vq = (r != r) ? 0 : (int)__builtin_amdgcn_fmed3f(r, p.tail.pool_sat_lo, p.tail.pool_sat_hi);
             vq = max(vq, p.tail.pool_lo);
-            q[k] = min(vq, p.tail.pool_hi);
+            q[k] = min(vq, p.tail.pool_hi) ^ p.tail.xr; // the stored byte (pack4 keeps the low byte)
         }
         const uint32_t qp = pack4(q[0], q[1], q[2], q[3]);
         int dot[N], vs = sdot4(qp, 0x01010101u, 0);
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(NTHR) void pair3_tail(const int8_t *__restrict__ in
             int *src = part + (cur * 16 + img) * 4;
             const int acc = src[n] - hci[4 * n] * src[N] + hci[4 * n + 1];
             const int h = requant(acc, __int_as_float(hci[4 * n + 2]), __int_as_float(hci[4 * n + 3]), p.tail.lo_f, p.tail.hi_f);
-            const float e = expt[h + 128];
+            const float e = expt[(int)(int8_t)(h ^ p.tail.xr) + 128]; // table index = stored byte + 128
             float sum = 0.0f;
 #pragma unroll
             for (int j = 0; j < N; ++j) sum = __fadd_rn(sum, __shfl(e, img * N + j, 64)); // one row: index order
@@ -195,7 +195,8 @@ __global__ __launch_bounds__(NTHR) void pair3_tail(const int8_t *__restrict__ in
             const float qf = __fadd_rn(__fdiv_rn(prob, p.tail.sm_oscale), p.tail.sm_ozp_f);
             const float r = __fadd_rn(qf, __builtin_copysignf(0x1.fffffep-2f, qf));
             const size_t image = blk * IMGS + img;
-            if (image < batch) out[image * N + n] = (int8_t)((r != r) ? 0 : (int)__builtin_amdgcn_fmed3f(r, -128.0f, 127.0f));
+            if (image < batch)
+                out[image * N + n] = (int8_t)(((r != r) ? 0 : (int)__builtin_amdgcn_fmed3f(r, p.tail.sm_sat_lo, p.tail.sm_sat_hi)) ^ p.tail.xr);
             // (the sums of this buffer are next added to two steps from now, after two more barriers)
             __builtin_amdgcn_wave_barrier();
             src[n] = 0;
@@ -215,10 +216,19 @@ const char *pair_tail_name() { return "pair3_tail<3,3,256,2>"; }
 void launch_pair_tail(const int8_t *in, int8_t *out, const PairTailArgs &a, size_t batch, hipStream_t s) {
     constexpr int NTHR = 1024, XP = 9 * 256 + 16;
     constexpr int lds = (2 * 16 + 1 + 16) * XP + 2 * 16 * 4 * 4 + 256 * 4 + 2 * 4 * 4;
-    static LaunchState st;
-    const int per_cu = prepared(st, pair3_tail<2, NTHR>, NTHR, lds);
-    const size_t nblk = (batch + 15) / 16, cap = (size_t)256 * per_cu;
-    hipLaunchKernelGGL((pair3_tail<2, NTHR>), dim3((unsigned)(nblk < cap ? nblk : cap)), dim3(NTHR), lds, s, in, out, a, batch);
+    const size_t nblk = (batch + 15) / 16;
+    int per_cu = 1;
+    if (a.tail.xr) {
+        static LaunchState st;
+        per_cu = prepared(st, pair3_tail<2, NTHR, 0x80808080u>, NTHR, lds);
+        const size_t cap = (size_t)256 * per_cu;
+        hipLaunchKernelGGL((pair3_tail<2, NTHR, 0x80808080u>), dim3((unsigned)(nblk < cap ? nblk : cap)), dim3(NTHR), lds, s, in, out, a, batch);
+    } else {
+        static LaunchState st;
+        per_cu = prepared(st, pair3_tail<2, NTHR, 0u>, NTHR, lds);
+        const size_t cap = (size_t)256 * per_cu;
+        hipLaunchKernelGGL((pair3_tail<2, NTHR, 0u>), dim3((unsigned)(nblk < cap ? nblk : cap)), dim3(NTHR), lds, s, in, out, a, batch);
+    }
 #if MF_TAIL3_DIAG
     {
         static int calls = 0;

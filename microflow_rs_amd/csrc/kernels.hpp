@@ -136,6 +136,11 @@ struct TailArgs {
     float lo_f, hi_f;        // head activation clamp
     const float *exp_table;  // softmax table [256]
     float sm_oscale, sm_ozp_f;
+    // element type: 0 / 128 added per pooled tap (stored byte -> value), the `as T` saturation ranges, and the byte
+    // flip between the value domain and the stored i8 domain (0 for i8, 0x80 for u8: see ConvArgs)
+    int pool_bias;
+    float pool_sat_lo, pool_sat_hi, sm_sat_lo, sm_sat_hi;
+    int xr;
 };
 
 // DepthwiseConv2D (one input channel) -> FullyConnected -> Softmax in one launch (k_dwfc.hip): speech.tflite ops 1..3.

@@ -648,7 +648,7 @@ FusedImpl *fused_create(OpImpl *dw, OpImpl *pw) {
 FusedImpl *fused_tail_create(OpImpl *pool, OpImpl *conv, OpImpl *sm) {
     if (!pool || !conv || !sm) return nullptr;
     const OpSpec &p = pool->s, &c = conv->s, &m = sm->s;
-    if (p.u8 || c.u8 || m.u8) return nullptr; // i8 epilogues only
+    if (p.u8 != c.u8 || c.u8 != m.u8) return nullptr;
     if (!conv->finite_consts || !std::isfinite(p.pool_c0) || !std::isfinite(p.pool_c1)) return nullptr;
     if (p.kind != MF_OP_AVERAGE_POOL_2D || c.kind != MF_OP_CONV_2D || m.kind != MF_OP_SOFTMAX) return nullptr;
     if (p.OH != 1 || p.OW != 1) return nullptr;                       // one pooling window
@@ -674,6 +674,8 @@ FusedImpl *fused_tail_create(OpImpl *pool, OpImpl *conv, OpImpl *sm) {
     t.w = conv->conv.w, t.wzp = conv->conv.wzp, t.A = conv->conv.A, t.S = conv->conv.S, t.Kc = conv->conv.Kc;
     t.lo_f = conv->conv.lo_f, t.hi_f = conv->conv.hi_f;
     t.exp_table = sm->sm.exp_table, t.sm_oscale = sm->sm.oscale, t.sm_ozp_f = sm->sm.ozp_f;
+    t.pool_bias = pool->pool.bias, t.pool_sat_lo = pool->pool.sat_lo, t.pool_sat_hi = pool->pool.sat_hi;
+    t.sm_sat_lo = sm->sm.sat_lo, t.sm_sat_hi = sm->sm.sat_hi, t.xr = pool->pool.xr;
     return f;
 }
 
@@ -822,7 +824,8 @@ FusedImpl *fused_pair_tail_create(FusedImpl *pair, FusedImpl *tail) {
     if (off || !pair || !tail || pair->kind != FusedImpl::DWPW || tail->kind != FusedImpl::TAIL) return nullptr;
     const OpSpec &d = pair->a->s, &q = pair->b->s;
     const k::TailArgs &t = tail->tail;
-    if (!k::pair_tail_supported(d.H, d.W, d.C, q.N, t.N, t.ntaps) || d.sh != 1 || d.sw != 1 || d.u8) return nullptr;
+    if (!k::pair_tail_supported(d.H, d.W, d.C, q.N, t.N, t.ntaps) || d.sh != 1 || d.sw != 1 || d.u8 != pair->b->s.u8) return nullptr;
+    if ((d.u8 ? 0x80 : 0) != t.xr) return nullptr;
     if (t.H != d.OH || t.W != d.OW || t.C != q.N || pair->a->device != tail->a->device) return nullptr;
     if (!pair->dwpw.dw.magic || !pair->dwpw.pw.magic || !pair->dwpw.dw.wmm) return nullptr; // bit-pattern epilogues
     std::unique_ptr<FusedImpl> f(new FusedImpl{FusedImpl::PAIRTAIL, pair->a, tail->b, tail->c, {}, {}, k::pair_tail_name()});
