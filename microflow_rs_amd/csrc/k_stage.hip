@@ -64,7 +64,7 @@ struct Taps {
 };
 } // namespace
 
-template <int G, int NTHR, int NREP>
+template <int G, int NTHR, int NREP, uint32_t XR4>
 __global__ __launch_bounds__(NTHR, 4) void stage_6x6x128(const int8_t *__restrict__ in, int8_t *__restrict__ out, StageArgs p,
                                                          int batch) {
     static_assert(G == 4 && NTHR == 512, "the column grid below is written for 4 images and 8 waves");
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(NTHR, 4) void stage_6x6x128(const int8_t *__restric
                     const float r3 = requant_clamped<true>(acc[3], wd.a.w, wd.s.w, lo, hi);
                     __builtin_amdgcn_sched_barrier(0);
                     if (more) nxt = __builtin_amdgcn_mfma_i32_16x16x64_i8(wd.A[2], t2.b[2], nxt, 0, 0, 0);
-                    *(uint32_t *)(lds + mb + moff(u)) = cvt_pack4(r0, r1, r2, r3);
+                    *(uint32_t *)(lds + mb + moff(u)) = cvt_pack4(r0, r1, r2, r3) ^ XR4;
                     __builtin_amdgcn_sched_barrier(0);
                     acc = nxt, t2 = t3;
                 }
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(NTHR, 4) void stage_6x6x128(const int8_t *__restric
                     if (more) nxt = __builtin_amdgcn_mfma_i32_16x16x64_i8(wp.A[1], c1, nxt, 0, 0, 0);
                     const float r2 = requant_clamped<true>(acc[2], wp.a.z, wp.s.z, lo, hi);
                     const float r3 = requant_clamped<true>(acc[3], wp.a.w, wp.s.w, lo, hi);
-                    const uint32_t d = cvt_pack4(r0, r1, r2, r3);
+                    const uint32_t d = cvt_pack4(r0, r1, r2, r3) ^ XR4;
                     if (last) *(uint32_t *)(lds + oplain + c * 2048) = d;
                     else *(uint32_t *)(lds + o6[c]) = d;
                     __builtin_amdgcn_sched_barrier(0);
@@ -287,9 +287,17 @@ bool launch_stage(int H, int W, int C, int npairs, const int8_t *in, int8_t *out
     constexpr int lds = MF_STAGE_LDS_KB * 1024;
     static LaunchState st;
     const int nsteps = (batch + G - 1) / G;
-    const int per_cu = prepared(st, stage_6x6x128<G, NTHR, NREP>, NTHR, lds);
-    const int grid = nsteps < 256 * per_cu ? nsteps : 256 * per_cu;
-    hipLaunchKernelGGL((stage_6x6x128<G, NTHR, NREP>), dim3(grid), dim3(NTHR), lds, s, in, out, a, batch);
+    int per_cu, grid;
+    if (a.xr4) { // u8 element type: the stored byte is the value ^ 0x80 (XR4, see kernels.hpp)
+        static LaunchState stu;
+        per_cu = prepared(stu, stage_6x6x128<G, NTHR, NREP, 0x80808080u>, NTHR, lds);
+        grid = nsteps < 256 * per_cu ? nsteps : 256 * per_cu;
+        hipLaunchKernelGGL((stage_6x6x128<G, NTHR, NREP, 0x80808080u>), dim3(grid), dim3(NTHR), lds, s, in, out, a, batch);
+    } else {
+        per_cu = prepared(st, stage_6x6x128<G, NTHR, NREP, 0u>, NTHR, lds);
+        grid = nsteps < 256 * per_cu ? nsteps : 256 * per_cu;
+        hipLaunchKernelGGL((stage_6x6x128<G, NTHR, NREP, 0u>), dim3(grid), dim3(NTHR), lds, s, in, out, a, batch);
+    }
 #if MF_STAGE_DIAG == 2
     {
         static int calls = 0;

@@ -210,6 +210,7 @@ struct StagePair {
 struct StageArgs {
     const StagePair *pairs;  // [number of pairs], in device memory
     uint32_t izp4;           // zero point of every depthwise input of the run (they must agree: one halo fill)
+    uint32_t xr4;            // 0 (i8) or 0x80808080 (u8): XOR of every stored dword
 };
 
 // shapes with a compiled fast depthwise kernel: H, W, C, stride, images per step, threads per

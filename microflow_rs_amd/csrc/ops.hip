@@ -716,7 +716,7 @@ FusedImpl *fused_stage_create(FusedImpl *const *pairs, int npairs) {
         if (!f || f->kind != FusedImpl::DWPW) return nullptr;
         const OpSpec &d = f->a->s, &q = f->b->s;
         if (d.H != d0.H || d.W != d0.W || d.C != d0.C || d.sh != 1 || q.N != d0.C) return nullptr; // same tensor in and out
-        if (d.u8 || !f->dwpw.dw.magic || !f->dwpw.pw.magic || !f->dwpw.dw.wmm) return nullptr; // i8, bit-pattern epilogues
+        if (d.u8 != d0.u8 || q.u8 != d0.u8 || !f->dwpw.dw.magic || !f->dwpw.pw.magic || !f->dwpw.dw.wmm) return nullptr; // bit-pattern epilogues
         if (f->dwpw.dw.izp4 != pairs[0]->dwpw.dw.izp4 || f->a->device != pairs[0]->a->device) return nullptr;
     }
     std::unique_ptr<FusedImpl> s(new FusedImpl{FusedImpl::STAGE, pairs[0]->a, pairs[npairs - 1]->b, nullptr, {}, {}, nm});
@@ -750,6 +750,7 @@ FusedImpl *fused_stage_create(FusedImpl *const *pairs, int npairs) {
     s->stage_w.back()->upload(table.data(), table.size() * sizeof(k::StagePair));
     s->stage.pairs = (const k::StagePair *)s->stage_w.back()->p;
     s->stage.izp4 = pairs[0]->dwpw.dw.izp4;
+    s->stage.xr4 = d0.u8 ? 0x80808080u : 0u;
     return s.release();
 }
 

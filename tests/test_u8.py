@@ -315,10 +315,15 @@ def test_u8_person_detect_uses_the_fast_kernels(mf, O):
     want = om.run_quantized_batch(xq)
     assert np.array_equal(m.run_quantized(xq).reshape(n, -1), want)
     names = [m.op(i)["kernel"] for i in range(m.num_ops)]
-    # 13 pairs: 12 pair kernels + the last pair inside pair3_tail (with the u8 pool / head / softmax epilogues)
-    assert names[0].startswith("dw3x3_stem8") and sum(k.startswith(("dwpw_rr", "dwpw_mm", "dwpw3x3", "pair3_tail")) for k in names) == 13, names
+    # 13 pairs: pair kernels, five of them inside the stage kernel, the last inside pair3_tail (all with the u8 store)
+    assert names[0].startswith("dw3x3_stem8"), names
+    npairs = sum(k.startswith(("dwpw_rr", "dwpw_mm", "dwpw3x3")) for k in names)
+    npairs += 5 * sum(k.startswith("stage_6x6x128") for k in names) + sum(k.startswith("pair3_tail") for k in names)
+    assert npairs == 13, names
     if not os.environ.get("MF_NO_PAIRTAIL") and os.environ.get("MF_DWPW_IMPL") != "valu":
         assert names[25].startswith("pair3_tail"), names
+    if not os.environ.get("MF_NO_STAGE"):
+        assert names[13].startswith("stage_6x6x128"), names
     m.set_fusion(False)
     assert np.array_equal(m.run_quantized(xq).reshape(n, -1), want)
     names = [m.op(i)["kernel"] for i in range(m.num_ops)]
