@@ -531,6 +531,12 @@ int mf_synth_i8(int device, uint64_t seed, uint64_t first_byte, size_t n, int8_t
         mf::dev_synth_i8(device, seed, first_byte, n, d_output, stream);
     })
 }
+int mf_verify_quant_div(int device, float scale, float reciprocal, int zero_point, int is_u8, uint64_t *mismatches) {
+    MF_TRY({
+        MF_NEED(mismatches);
+        *mismatches = mf::dev_verify_quant_div(device, scale, reciprocal, zero_point, is_u8 != 0);
+    })
+}
 int mf_checksum_i8(int device, const int8_t *d_input, size_t n, uint64_t *checksum, void *stream) {
     MF_TRY({
         MF_NEED(checksum && (n == 0 || d_input));

@@ -226,6 +226,20 @@ template <int TS> __device__ __forceinline__ constexpr int tile_swz(int x) {
 // Persistent-workgroup kernels launch exactly as many workgroups as are resident (LDS-,
 // VGPR- or wave-limited, asked of the runtime once per kernel), so every workgroup walks the
 // same number of steps and none queues behind a finished one.
+// x / scale of the boundary quantisation (src/quantize.rs:16-18), correctly rounded, in 3 instructions instead of the
+// ~10 of the IEEE division expansion: q0 = x * r, e = fma(-scale, q0, x) (the exact remainder), q = fma(e, r, q0), with
+// r = 1 / scale rounded on the host (Markstein's correction step).  `fast` is set only after the host has VERIFIED,
+// exhaustively over all 2^32 input bit patterns, that the quantised byte is the same as with the true division for
+// this (scale, zero point, element type): ops.hip quant_div_verified / k_generic.hip verify_quant_div.  Infinities
+// and NaNs (q not finite) take the true division.
+__device__ __forceinline__ float quant_div(float x, float scale, float rcp, bool fast) {
+    if (!fast) return __fdiv_rn(x, scale);
+    const float q0 = __fmul_rn(x, rcp);
+    float q = __fmaf_rn(__fmaf_rn(-scale, q0, x), rcp, q0);
+    if (!(__builtin_fabsf(q) <= 3.0e38f)) q = __fdiv_rn(x, scale);
+    return q;
+}
+
 // 4 x 4 transpose between four registers and the four 16-lane groups of a wave: on return register i of lane
 // group g holds what register g of lane group i held (v_permlane32_swap: lanes 32..63 of the first <-> lanes 0..31 of
 // the second operand; v_permlane16_swap: odd 16-lane rows of the first <-> even rows of the second).

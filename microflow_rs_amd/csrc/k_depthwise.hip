@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256) void dw3x3_stem8(const int8_t *__restrict__ in
             int q[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float t = __fadd_rn(__fdiv_rn(pre[k][e], p.in_scale), p.in_zp_f);
+                const float t = __fadd_rn(quant_div(pre[k][e], p.in_scale, p.in_rcp, p.in_fast != 0), p.in_zp_f);
                 const float r = __fadd_rn(t, __builtin_copysignf(0x1.fffffep-2f, t));
                 q[e] = (r != r) ? 0 : (int)__builtin_amdgcn_fmed3f(r, p.in_sat_lo, p.in_sat_hi);
             }
@@ -381,7 +381,7 @@ __global__ __launch_bounds__(256) void dw3x3_stem8_mm(const int8_t *__restrict__
             int qv[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float t = __fadd_rn(__fdiv_rn(pre[k][e], p.in_scale), p.in_zp_f);
+                const float t = __fadd_rn(quant_div(pre[k][e], p.in_scale, p.in_rcp, p.in_fast != 0), p.in_zp_f);
                 const float r = __fadd_rn(t, __builtin_copysignf(0x1.fffffep-2f, t));
                 qv[e] = (r != r) ? 0 : (int)__builtin_amdgcn_fmed3f(r, p.in_sat_lo, p.in_sat_hi);
             }

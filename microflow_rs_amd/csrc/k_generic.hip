@@ -201,6 +201,26 @@ __global__ __launch_bounds__(256) void quantize_f32(const float *__restrict__ in
     }
 }
 
+// Exhaustive check behind quant_div's fast form (k_common.hpp): every one of the 2^32 float bit patterns is quantised
+// with the true division and with the 3-instruction form; *bad receives the number of patterns whose BYTE differs.
+__global__ __launch_bounds__(256) void verify_quant_div_kernel(float scale, float rcp, float zp_f, float sat_lo, float sat_hi,
+                                                               unsigned long long *bad) {
+    const unsigned long long stride = (unsigned long long)gridDim.x * 256;
+    unsigned cnt = 0;
+    for (unsigned long long b = (unsigned long long)blockIdx.x * 256 + threadIdx.x; b < (1ull << 32); b += stride) {
+        const float x = __uint_as_float((uint32_t)b);
+        int q[2];
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+            const float t = __fadd_rn(quant_div(x, scale, rcp, v == 1), zp_f);
+            const float r = __fadd_rn(t, __builtin_copysignf(0x1.fffffep-2f, t));
+            q[v] = (r != r) ? 0 : (int)__builtin_amdgcn_fmed3f(r, sat_lo, sat_hi);
+        }
+        cnt += q[0] != q[1];
+    }
+    if (cnt) atomicAdd(bad, (unsigned long long)cnt);
+}
+
 // u8 <-> internal i8 domain at the quantized boundary of a u8 model: byte ^ 0x80
 __global__ __launch_bounds__(256) void xor80_bytes(const int8_t *in, int8_t *out,  // may alias (in place)
                                                    size_t n) {
@@ -270,6 +290,16 @@ void launch_fc_generic(const int8_t *in, int8_t *out, const FcArgs &a, size_t ro
 }
 void launch_softmax(const int8_t *in, int8_t *out, const SoftmaxArgs &a, size_t batch, hipStream_t s) {
     hipLaunchKernelGGL(softmax_table, dim3(grid_for(batch)), dim3(256), 0, s, in, out, a, batch);
+}
+unsigned long long verify_quant_div(float scale, float rcp, float zp_f, float sat_lo, float sat_hi, hipStream_t s) {
+    unsigned long long *d = nullptr, h = ~0ull;
+    if (hipMalloc((void **)&d, sizeof(h)) != hipSuccess) return h;
+    if (hipMemsetAsync(d, 0, sizeof(h), s) == hipSuccess) {
+        hipLaunchKernelGGL(verify_quant_div_kernel, dim3(256 * 16), dim3(256), 0, s, scale, rcp, zp_f, sat_lo, sat_hi, d);
+        if (hipMemcpyAsync(&h, d, sizeof(h), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) h = ~0ull;
+    }
+    (void)hipFree(d);
+    return h;
 }
 void launch_quantize(const float *in, int8_t *out, size_t n, float scale, float zp_f, bool u8, hipStream_t s) {
     hipLaunchKernelGGL(quantize_f32, dim3(grid_for((n + 3) / 4)), dim3(256), 0, s, in, out, n, scale, zp_f,

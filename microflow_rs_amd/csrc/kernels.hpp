@@ -102,6 +102,8 @@ struct DwStemArgs {
     // f32-input variant (boundary quantisation fused into the staging): q = sat(roundf(x / in_scale + in_zp_f))
     float in_scale, in_zp_f, in_sat_lo, in_sat_hi;
     uint32_t in_xr4;
+    float in_rcp;        // 1 / in_scale (rounded) for quant_div
+    int in_fast;         // 1: the 3-instruction division was verified for these parameters (k_common.hpp: quant_div)
 };
 struct DwPwArgs;
 struct PwArgs {
@@ -321,6 +323,9 @@ bool fc_mfma_supported(size_t rows, int N, int K);
 void launch_fc_rowsum(const int8_t *in, int *rowsum, size_t rows, int K, hipStream_t s);
 void launch_fc_mfma(const int8_t *in, int8_t *out, const FcGemmArgs &a, hipStream_t s);
 void launch_softmax(const int8_t *in, int8_t *out, const SoftmaxArgs &a, size_t batch, hipStream_t s);
+// number of float bit patterns (of all 2^32) whose quantised byte differs between quant_div's fast form and the true
+// division, for these parameters; synchronises the stream
+unsigned long long verify_quant_div(float scale, float rcp, float zp_f, float sat_lo, float sat_hi, hipStream_t s);
 void launch_quantize(const float *in, int8_t *out, size_t n, float scale, float zp_f, bool u8, hipStream_t s);
 void launch_xor80(const int8_t *in, int8_t *out, size_t n, hipStream_t s);
 void launch_dequantize(const int8_t *in, float *out, size_t n, float scale, float zp_f, bool raw_u8, hipStream_t s);

@@ -139,6 +139,8 @@ void dev_dequantize_u8_raw(int device, const uint8_t *d_in, size_t n, float scal
 void dev_xor80(int device, const int8_t *d_in, size_t n, int8_t *d_out, void *stream);
 void dev_synth_i8(int device, uint64_t seed, uint64_t first, size_t n, int8_t *d_out, void *stream);
 uint64_t dev_checksum_i8(int device, const int8_t *d_in, size_t n, void *stream);
+// exhaustive check of the 3-instruction boundary-quantisation division (k_common.hpp: quant_div): mismatching bytes
+uint64_t dev_verify_quant_div(int device, float scale, float rcp, int zp, bool u8);
 int dev_count();
 void dev_require(int device); // throws MF_ERR_NO_DEVICE
 

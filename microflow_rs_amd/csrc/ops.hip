@@ -14,6 +14,9 @@
 
 #include "kernels.hpp"
 #include "mf_internal.hpp"
+#include <array>
+#include <mutex>
+#include <map>
 
 namespace mf {
 
@@ -594,12 +597,34 @@ void op_run_external(OpImpl *op, const int8_t *d_in, size_t batch, int8_t *d_out
 
 // Boundary quantisation fused into the first operator (M::predict on f32 input): only the stem
 // kernel has an f32-input variant.  `zp` is a value of T.
+// quant_div (k_common.hpp): true when the fast form gives the same byte as the true division for EVERY float input
+static bool quant_div_verified(int device, float scale, float rcp, float zp_f, float sat_lo, float sat_hi) {
+    static const bool off = getenv("MF_NO_FAST_QUANT_DIV") != nullptr;
+    if (off || !std::isfinite(scale) || !std::isfinite(rcp) || scale == 0.0f) return false;
+    static std::mutex mu;
+    static std::map<std::array<uint32_t, 4>, bool> cache;
+    uint32_t kb[4];
+    memcpy(&kb[0], &scale, 4), memcpy(&kb[1], &zp_f, 4), memcpy(&kb[2], &sat_lo, 4), memcpy(&kb[3], &sat_hi, 4);
+    const std::array<uint32_t, 4> key{kb[0], kb[1], kb[2], kb[3]};
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = cache.find(key);
+    if (it != cache.end()) return it->second;
+    MF_HIP(hipSetDevice(device));
+    const bool ok = k::verify_quant_div(scale, rcp, zp_f, sat_lo, sat_hi, nullptr) == 0;
+    if (getenv("MF_VERBOSE")) fprintf(stderr, "[microflow_amd] boundary quantisation: 3-instruction division %s for scale %g\n", ok ? "verified" : "REJECTED", (double)scale);
+    cache[key] = ok;
+    return ok;
+}
 bool op_set_input_quant(OpImpl *op, float scale, int zp, bool u8) {
     if (op->fast != OpImpl::DW_STEM || !(scale == scale)) return false;
     k::DwStemArgs &f = op->stem;
     f.in_scale = scale, f.in_zp_f = (float)zp;
     f.in_sat_lo = u8 ? 0.0f : -128.0f, f.in_sat_hi = u8 ? 255.0f : 127.0f;
     f.in_xr4 = u8 ? 0x80808080u : 0u;
+    // the 3-instruction division of the boundary quantisation, if it is exact for these parameters (checked over all
+    // 2^32 inputs on the device, a few ms, once per parameter set and process)
+    f.in_rcp = (float)(1.0 / (double)scale);
+    f.in_fast = quant_div_verified(op->device, scale, f.in_rcp, f.in_zp_f, f.in_sat_lo, f.in_sat_hi) ? 1 : 0;
     op->accepts_f32 = true;
     return true;
 }
@@ -926,6 +951,11 @@ void dev_synth_i8(int device, uint64_t seed, uint64_t first, size_t n, int8_t *d
     if (!n) return;
     k::launch_synth(d_out, n, seed, first, (hipStream_t)stream);
     MF_HIP(hipGetLastError());
+}
+uint64_t dev_verify_quant_div(int device, float scale, float rcp, int zp, bool u8) {
+    dev_require(device);
+    MF_HIP(hipSetDevice(device));
+    return k::verify_quant_div(scale, rcp, (float)zp, u8 ? 0.0f : -128.0f, u8 ? 255.0f : 127.0f, nullptr);
 }
 uint64_t dev_checksum_i8(int device, const int8_t *d_in, size_t n, void *stream) {
     dev_require(device);

@@ -482,3 +482,35 @@ def test_last_launch_writes_exactly_the_result(mf, name, batch):
         got = buf.cpu().numpy()
         assert np.array_equal(got[lead:lead + n_out], want), (name, lead)
         assert (got[:lead] == 0x5A).all() and (got[lead + n_out:] == 0x5A).all(), (name, lead)
+
+
+def test_boundary_quantisation_fast_division_is_exact(mf, O):
+    """M::predict quantises x / scale + zp with a true division (src/quantize.rs:16-18).  The f32-input stem runs it
+    as x * r + two fused corrections -- only after checking ALL 2^32 float inputs give the same byte.  Re-run that
+    check for the three models' input parameters, show that it does catch a wrong reciprocal, and compare predict()
+    with the oracle on inputs sitting on and next to every rounding boundary."""
+    import ctypes as C
+    from microflow_rs_amd import _lib
+    L = _lib.lib()
+    bad = C.c_uint64(123)
+    for name in ("sine", "speech", "person_detect"):
+        om = O.Model(model_path(name))
+        scale, zp = np.float32(om.in_scale), int(om.in_zp)
+        rcp = np.float32(1.0 / np.float64(scale))
+        _lib.check(L.mf_verify_quant_div(0, C.c_float(scale), C.c_float(rcp), zp, 0, C.byref(bad)))
+        assert bad.value == 0, (name, bad.value)
+    _lib.check(L.mf_verify_quant_div(0, C.c_float(scale), C.c_float(rcp * np.float32(1.0001)), zp, 0, C.byref(bad)))
+    assert bad.value > 0  # the checker is not vacuous
+    # predict() of person_detect (f32 input, quantisation fused into the stem) on boundary inputs
+    m = mf.Model(model_path("person_detect"), device=0)
+    om = O.Model(model_path("person_detect"))
+    scale, zp = np.float32(om.in_scale), np.float32(om.in_zp)
+    ks = np.arange(-130, 131, dtype=np.float32) + np.float32(0.5)
+    ties = ((ks - zp) * scale).astype(np.float32)
+    cands = np.concatenate([ties, np.nextafter(ties, np.float32(np.inf)), np.nextafter(ties, np.float32(-np.inf)),
+                            np.array([0.0, -0.0, 1e-40, -1e-40, 3e38, -3e38], dtype=np.float32)])
+    rng = np.random.default_rng(5)
+    x = rng.choice(cands, size=(4, m.input_elems)).astype(np.float32)
+    got = m.predict(x.reshape((4,) + m.input_shape)).reshape(4, -1)
+    want = np.stack([om.predict(v).reshape(-1) for v in x])
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
