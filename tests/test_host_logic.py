@@ -196,3 +196,38 @@ def test_bias_scale_and_zero_point_fall_back_independently(O):
     assert np.array_equal(c0, want), (c0, want)
     om = O.Model(blob)
     assert np.array_equal(om.op_constants(0)[0], want)
+
+
+def test_parser_survives_corrupted_models():
+    """The .tflite reader on corrupted input: byte flips in the tables, random bytes anywhere, truncations, wild
+    32-bit offsets / sizes.  Every variant must either parse (and describe all its operators) or be rejected with an
+    error -- never crash or read out of bounds (the macro's compile-time aborts become status codes here,
+    microflow-macros/src/lib.rs:51-57)."""
+    import random
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rnd = random.Random(7)
+    parsed = rejected = 0
+    for name in ("sine", "speech", "person_detect"):
+        data = open(os.path.join(root, "models", name + ".tflite"), "rb").read()
+        n = len(data)
+        for it in range(240):
+            d = bytearray(data)
+            mode = it % 4
+            if mode == 0:
+                for _ in range(rnd.randint(1, 8)):
+                    d[rnd.randrange(min(n, 4096))] = rnd.randrange(256)
+            elif mode == 1:
+                for _ in range(rnd.randint(1, 8)):
+                    d[rnd.randrange(n)] = rnd.randrange(256)
+            elif mode == 2:
+                d = d[: rnd.randrange(8, n)]
+            else:
+                p = rnd.randrange(n - 4)
+                d[p:p + 4] = rnd.randrange(2 ** 32).to_bytes(4, "little")
+            try:
+                m = mf.Model(bytes(d))
+                assert all(isinstance(m.op(i), dict) for i in range(m.num_ops))
+                parsed += 1
+            except mf.MicroflowError:
+                rejected += 1
+    assert parsed + rejected == 720 and rejected > 100
