@@ -191,13 +191,14 @@ def test_kernel_routing(models):
     # MF_DWPW_IMPL=valu, r01's dwpw3x3; the five 6x6x128 pairs (ops 13..22) are ONE persistent kernel
     # (MF_NO_STAGE=1: not)
     npairs = sum(n.startswith(("dwpw_rr", "dwpw_mm", "dwpw3x3")) for n in names)
+    pair_tail = not (os.environ.get("MF_NO_PAIRTAIL") or os.environ.get("MF_DWPW_IMPL") == "valu")
     if os.environ.get("MF_NO_STAGE"):
-        assert npairs == 13 and sum(n.startswith("(fused") for n in names) == 13 + 2
+        assert npairs == (12 if pair_tail else 13), names
     else:
         assert npairs in (7, 8) and names[13].startswith("stage_6x6x128"), names
         assert all(n.startswith("(fused") for n in names[14:23]), names
         assert names[23].startswith("dwpw") and names[25].startswith(("dwpw", "pair3_tail")), names
-    if os.environ.get("MF_NO_PAIRTAIL") or os.environ.get("MF_DWPW_IMPL") == "valu":
+    if not pair_tail:
         assert names[27] == "tail_pool_head_softmax<2>"               # pool + head conv + softmax
     else:  # the last pair (ops 25, 26) + the tail (27..30) in one launch
         assert names[25].startswith("pair3_tail") and all(n.startswith("(fused") or n == "" for n in names[26:]), names
