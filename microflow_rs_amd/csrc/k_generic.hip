@@ -119,6 +119,50 @@ __global__ __launch_bounds__(256) void avgpool_generic(const int8_t *__restrict_
     }
 }
 
+// The same operator with 4 channels per thread (C % 4 == 0): a tap of a window is one dword of 4 consecutive channels,
+// summed per byte with masked v_dot4; consecutive lanes take consecutive channel quads of one output pixel, so every
+// wave-level load is a contiguous 256-byte row piece and every store a packed dword.  Same arithmetic, value by value.
+__global__ __launch_bounds__(256) void avgpool_c4(const int8_t *__restrict__ in, int8_t *__restrict__ out, PoolArgs p,
+                                                  size_t total4) {
+    const int C4 = p.C >> 2;
+    const int shy = p.pad_same ? (p.KH - 1) / 2 : 0, shx = p.pad_same ? (p.KW - 1) / 2 : 0;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total4; idx += (size_t)gridDim.x * 256) {
+        const int c4 = (int)(idx % C4);
+        size_t t = idx / C4;
+        const int ox = (int)(t % p.OW);
+        t /= p.OW;
+        const int oy = (int)(t % p.OH);
+        const size_t img = t / p.OH;
+        const int8_t *ip = in + img * (size_t)p.H * p.W * p.C + 4 * c4;
+        int s0 = 0, s1 = 0, s2 = 0, s3 = 0, len = 0;
+        for (int ky = 0; ky < p.KH; ++ky) {
+            const int iy = oy * p.sh + ky - shy;
+            for (int kx = 0; kx < p.KW; ++kx) {
+                const int ix = ox * p.sw + kx - shx;
+                if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) {
+                    const uint32_t v = *(const uint32_t *)(ip + ((size_t)iy * p.W + ix) * p.C);
+                    s0 = sdot4(v, 0x00000001u, s0), s1 = sdot4(v, 0x00000100u, s1);
+                    s2 = sdot4(v, 0x00010000u, s2), s3 = sdot4(v, 0x01000000u, s3);
+                    ++len;
+                }
+            }
+        }
+        const float inv = __fdiv_rn(1.0f, (float)len);
+        const int sums[4] = {s0, s1, s2, s3};
+        int q[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float x = __fmul_rn(inv, (float)(sums[k] + p.bias * len));
+            const float y = __fadd_rn(__fmul_rn(p.c0, x), p.c1);
+            const float r = __fadd_rn(y, __builtin_copysignf(0x1.fffffep-2f, y));
+            int v = (r != r) ? 0 : (int)__builtin_amdgcn_fmed3f(r, p.sat_lo, p.sat_hi); // NaN (len == 0) -> 0
+            v = max(v, p.lo);
+            q[k] = min(v, p.hi);
+        }
+        ((uint32_t *)out)[idx] = pack4(q[0], q[1], q[2], q[3]) ^ (0x01010101u * (uint32_t)p.xr);
+    }
+}
+
 // microflow::ops::fully_connected  (src/ops/fully_connected.rs:24-82), any M/K/N.
 // in [batch*M][K], w [N][K], out [batch*M][N].
 __global__ __launch_bounds__(256) void fc_generic(const int8_t *__restrict__ in,
@@ -279,6 +323,10 @@ void launch_conv2d_generic(const int8_t *in, int8_t *out, const ConvArgs &a, siz
 void launch_dwconv_generic(const int8_t *in, int8_t *out, const ConvArgs &a, size_t batch, hipStream_t s) {
     const size_t total = batch * a.OH * a.OW * a.N;
     hipLaunchKernelGGL(dwconv_generic, dim3(grid_for(total)), dim3(256), 0, s, in, out, a, total);
+}
+void launch_avgpool_c4(const int8_t *in, int8_t *out, const PoolArgs &a, size_t batch, hipStream_t s) {
+    const size_t total4 = batch * a.OH * a.OW * (a.C / 4);
+    hipLaunchKernelGGL(avgpool_c4, dim3(grid_for(total4)), dim3(256), 0, s, in, out, a, total4);
 }
 void launch_avgpool_generic(const int8_t *in, int8_t *out, const PoolArgs &a, size_t batch, hipStream_t s) {
     const size_t total = batch * a.OH * a.OW * a.C;

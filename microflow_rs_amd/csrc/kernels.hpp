@@ -316,6 +316,7 @@ struct StageArgs {
 void launch_conv2d_generic(const int8_t *in, int8_t *out, const ConvArgs &a, size_t batch, hipStream_t s);
 void launch_dwconv_generic(const int8_t *in, int8_t *out, const ConvArgs &a, size_t batch, hipStream_t s);
 void launch_avgpool_generic(const int8_t *in, int8_t *out, const PoolArgs &a, size_t batch, hipStream_t s);
+void launch_avgpool_c4(const int8_t *in, int8_t *out, const PoolArgs &a, size_t batch, hipStream_t s); // C % 4 == 0
 void launch_fc_generic(const int8_t *in, int8_t *out, const FcArgs &a, size_t rows, hipStream_t s);
 bool launch_fc_rowwave(const int8_t *in, int8_t *out, const FcArgs &a, size_t rows, hipStream_t s);
 bool launch_fc_rowwave_softmax(const int8_t *in, int8_t *out, const FcArgs &a, const SoftmaxArgs &sm, size_t rows,

@@ -89,7 +89,7 @@ struct OpImpl {
     bool accepts_f32 = false;  // op_set_input_quant succeeded: op_run_f32 may replace quantize + op_run
     bool finite_consts = true; // A / S all finite (the shape-specialised and fused epilogues assume it)
     std::string generic_name, fast_name;
-    enum Fast { NONE, DW_NHWC, DW_STEM, DW_C1, PW_MFMA, FC_ROWWAVE, FC_MFMA } fast = NONE;
+    enum Fast { NONE, DW_NHWC, DW_STEM, DW_C1, PW_MFMA, FC_ROWWAVE, FC_MFMA, POOL_C4 } fast = NONE;
     int *d_rowsum = nullptr; // FC_MFMA with wzp != 0: per-row input sums
     size_t rowsum_cap = 0;
     int8_t *d_ext = nullptr; // op_run_external on a u8 operator: input moved to the i8 domain
@@ -418,6 +418,7 @@ OpImpl *op_create(int device, const OpSpec &spec) {
         a.bias = beta, a.xr = xr;
         a.sat_lo = s.u8 ? 0.0f : -128.0f, a.sat_hi = s.u8 ? 255.0f : 127.0f;
         op->generic_name = "avgpool_generic";
+        if (s.C % 4 == 0) op->fast = OpImpl::POOL_C4, op->fast_name = "avgpool_c4"; // 4 channels per thread, dword loads
         break;
     }
     case MF_OP_FULLY_CONNECTED: {
@@ -524,6 +525,10 @@ void op_run(OpImpl *op, const int8_t *d_in, size_t batch, int8_t *d_out, void *s
             break;
         case OpImpl::DW_STEM:
             done = k::launch_dw_stem(sp.H, sp.W, sp.N, sp.sh, d_in, d_out, op->stem, (int)batch, s);
+            break;
+        case OpImpl::POOL_C4:
+            k::launch_avgpool_c4(d_in, d_out, op->pool, batch, s);
+            done = true;
             break;
         case OpImpl::DW_C1:
             k::launch_dw_c1(d_in, d_out, op->dwc1, batch, s);
