@@ -222,7 +222,9 @@ def main():
                 rq = sum(descs[j]["out_elems"] for j in range(i, last + 1) if descs[j]["name"] not in ("reshape",)) * count
                 rq_gbs = rq / (per_op[i] * 1e-3) / 1e9 if per_op[i] > 0 else 0.0
                 nops_in_group = sum(1 for j in range(i, last + 1) if descs[j]["name"] != "reshape")
-                bound = "valu" if nops_in_group > 3 else "hbm"  # a multi-layer group keeps its tensors on chip
+                # the binding roof is the one that gives the longer time floor: HBM for the algorithmic bytes, or the
+                # VALU for the bytes that go through the reference's f32 requantisation
+                bound = "valu" if rq / REQUANT_PEAK_GBS > nbytes / HBM_PEAK_GBS else "hbm"
                 rows.append({"op": i, "kind": kind if nops_in_group <= 3 else "stage(%d ops)" % nops_in_group,
                              "kernel": d["kernel"], "ms": round(per_op[i], 4), "bound": bound,
                              "bytes": nbytes, "GBps": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4),
@@ -241,8 +243,9 @@ def main():
         avg_ms, kernels = kernel_table()
         longest = max(kernels, key=lambda k: k["ms"])
         # `roofline` prices an HBM-bound kernel against HBM: the longest one of those.  If the longest launch of
-        # the step is the on-chip late-stage kernel (VALU-bound by construction: 4.6 KB in, 2 B out per inference),
-        # it is reported beside it against the requantisation ceiling (`longest_kernel`).
+        # the step is VALU-bound (the on-chip stage kernel: 4.6 KB in and out per inference for ten operators; the
+        # stride-1 pairs, whose requantised bytes equal their HBM bytes while the requantisation ceiling is below the
+        # HBM roof), it is reported beside it against the requantisation ceiling (`longest_kernel`).
         dom = max((k for k in kernels if k["bound"] == "hbm"), key=lambda k: k["ms"])
         # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
         # (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; scripts/pmc_summary.py), if the batch matches
@@ -259,14 +262,17 @@ def main():
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["frac"], "traffic": traffic,
                     "traffic_source": traffic_src,
                     "ms": dom["ms"], "algorithmic_bytes": dom["bytes"],
-                    "method": "HIP events on the launch stream, median of %d launches" % iters}
+                    "method": "HIP events on the launch stream, median of %d launches" % iters,
+                    "note": "the longest HBM-bound launch of the step; per kernel, `bound` in `kernels` is the roof with the "
+                            "longer time floor (algorithmic bytes / 8 TB/s vs requantised bytes / %.0f GB/s); launches that "
+                            "are VALU-bound are priced in `longest_kernel` and per kernel in `requant_frac`" % REQUANT_PEAK_GBS}
         longest_kernel = None
         if longest is not dom:
             longest_kernel = {"bound": "valu", "kernel": longest["kernel"], "op": longest["op"], "ms": longest["ms"],
                               "achieved": longest["requant_GBps"], "peak": REQUANT_PEAK_GBS, "unit": "GB/s of requantised int8",
                               "frac": longest["requant_frac"], "hbm_GBps": longest["GBps"], "hbm_frac": longest["frac"],
-                              "note": "every intermediate tensor of these operators stays in LDS; bounded by the reference's f32 "
-                                      "requantisation (8 VALU instructions per byte), ceiling measured by scripts/ubench/epi_rate.hip"}
+                              "note": "bounded by the reference's f32 requantisation of every int8 tensor the launch produces, on chip "
+                                      "or not (7-8 VALU instructions per byte); ceiling measured by scripts/ubench/epi_rate.hip"}
         step_bytes = sum(k["bytes"] for k in kernels)
         whole_step = {"algorithmic_bytes": step_bytes, "GBps": round(step_bytes / (ev_med * 1e-3) / 1e9, 1),
                       "frac": round(step_bytes / (ev_med * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
