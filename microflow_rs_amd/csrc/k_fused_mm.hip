@@ -503,7 +503,9 @@ __global__ __launch_bounds__(NTHR, WPE) void dwpw_rr(const int8_t *__restrict__ 
         const uint8_t *tb = lds + cur * BUF;
         int8_t *ob = out + (size_t)step * G * OPIX * N + obase_lane;
 
-        constexpr int UB = (WPE >= 4 || NQ > 1) ? 1 : (NU % 2 == 0 ? 2 : (NU % 3 == 0 ? 3 : 1));
+        // units in flight per wave.  (r02 same-session A/B of 1 / 2 / 3 per kernel: no effect anywhere except the stride-2
+        // pair with two channel groups, 24x24x32: 3 units 0.352 -> 0.341 ms.)
+        constexpr int UB = (S == 2 && NQ > 1 && NU % 3 == 0) ? 3 : (WPE >= 4 || NQ > 1) ? 1 : (NU % 2 == 0 ? 2 : (NU % 3 == 0 ? 3 : 1));
         auto coords = [](int iu, int &ug, int &uy, int &ux) constexpr {
             ug = (iu / (NUY * NUX)) * PSG, uy = ((iu / NUX) % NUY) * PSY, ux = (iu % NUX) * PSX;
         };
