@@ -294,7 +294,7 @@ struct StageArgs {
     X(48, 48, 16, 2, 32, 1, 768, 1, 1, 2, 0, 32, 0x000, 3)  \
     X(24, 24, 32, 1, 32, 1, 256, 1, 1, 2, 0, 0, 0x002, 3)   \
     X(24, 24, 32, 2, 64, 1, 192, 1, 1, 4, 0, 32, 0x002, 2)
-// tuning candidates (MF_DWRR_ALT=<index>, scripts/tune_rr.sh).  Last sweep (r02): 192 / 384 / 768 threads, one
+// tuning candidates (MF_DWRR_ALT=<index>, scripts/tune_fused.sh MF_DWRR_ALT 2).  Last sweep (r02): 192 / 384 / 768 threads, one
 // staging buffer, 2 / 4 waves per SIMD for 24x24x32 and 256 / 384 / 768 threads, 3 waves per SIMD for 48x48x8 were
 // all 3 .. 50 % slower than the shipped rows; two of them are kept here as the template for the next sweep.
 #define MF_DWRR_ALT_SHAPES(X)                               \
