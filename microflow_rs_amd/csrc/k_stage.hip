@@ -104,7 +104,10 @@ __global__ __launch_bounds__(NTHR, 4) void stage_6x6x128(const int8_t *__restric
         const int pix = c * 16 + pcol, img = pix / PIX6, r = pix % PIX6, y = r / 6, x = r % 6;
         o6[c] = img * TILE6 + (y + 1) * ROW6 + LP6 + x * 128 + 16 * (wave ^ tile_swz<TS6>(x)) + 4 * pg;
     }
-    const int oplain = OFF_A + pcol * 128 + 16 * wave + 4 * pg; // ... and in the last pair's plain output (+ 2048 per chunk)
+    // ... and in the last pair's plain [pixel][128] output (+ 2048 per chunk).  The 16 lanes of a column group write the
+    // same 16-byte slot of 16 consecutive pixels, 128 bytes apart = one bank: the slot index is XOR-ed with the pixel's
+    // low 3 bits (16-way -> 2-way conflict; the copy to HBM below undoes it).
+    const int oplain = OFF_A + pcol * 128 + 16 * (wave ^ (pcol & 7)) + 4 * pg;
 
     // The pair table is read with SCALAR loads (constant address space): a phase's operand fetches then wait for a
     // scalar-cache hit, not for a vector load of their own pointers.  The pointer is re-laundered every step so that
@@ -268,7 +271,10 @@ __global__ __launch_bounds__(NTHR, 4) void stage_6x6x128(const int8_t *__restric
         {
             const int nbytes = gvalid * PIX6 * 128;
             int8_t *dst = out + (size_t)step * G * PIX6 * 128;
-            for (int i = tid * 16; i < nbytes; i += NTHR * 16) *(uint4 *)(dst + i) = *(const uint4 *)(lds + OFF_A + i);
+            for (int i = tid * 16; i < nbytes; i += NTHR * 16) {
+                const int pix = i >> 7, slot = (i >> 4) & 7;
+                *(uint4 *)(dst + i) = *(const uint4 *)(lds + OFF_A + pix * 128 + 16 * (slot ^ (pix & 7)));
+            }
         }
         MF_TR(17);
 #if MF_STAGE_DIAG == 2
