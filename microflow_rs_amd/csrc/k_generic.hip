@@ -50,6 +50,42 @@ __global__ __launch_bounds__(256) void conv2d_generic(const int8_t *__restrict__
     }
 }
 
+// The same operator for a 1x1 filter with few outputs (N <= 8, C % 4 == 0; person_detect's head: 256 -> 2): the
+// pixels of the batch are the rows of a [rows][C] matrix; one wavefront per row, 4 channels per lane and step
+// (coalesced dword loads), v_dot4 against the N filter rows, butterfly reduction, lanes 0..N-1 finish the epilogue.
+// Every input byte is read once; same arithmetic as conv2d_generic, value by value (a 1x1 window has no padding).
+__global__ __launch_bounds__(256) void conv1x1_rowwave(const int8_t *__restrict__ in, int8_t *__restrict__ out, ConvArgs p,
+                                                       size_t rows) {
+    const int lane = threadIdx.x & 63;
+    const size_t wave = ((size_t)blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = ((size_t)gridDim.x * 256) >> 6;
+    const int C4 = p.C >> 2;
+    for (size_t row = wave; row < rows; row += nwaves) {
+        const uint32_t *x = (const uint32_t *)(in + row * (size_t)p.C);
+        int dot[8] = {0, 0, 0, 0, 0, 0, 0, 0}, vs = 0;
+        for (int c4 = lane; c4 < C4; c4 += 64) {
+            const uint32_t v = x[c4];
+            vs = sdot4(v, 0x01010101u, vs);
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (j < p.N) dot[j] = sdot4(v, ((const uint32_t *)(p.w + (size_t)j * p.C))[c4], dot[j]);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            vs += __shfl_xor(vs, off, 64);
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (j < p.N) dot[j] += __shfl_xor(dot[j], off, 64);
+        }
+        int d = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) d = (lane == j) ? dot[j] : d;
+        if (lane < p.N) {
+            const int acc = d - p.wzp[lane] * vs + p.Kc[lane];
+            out[row * p.N + lane] = (int8_t)(requant_any(acc, p.A[lane], p.S[lane], p.lo_f, p.hi_f) ^ p.xr);
+        }
+    }
+}
+
 // microflow::ops::depthwise_conv_2d  (src/ops/depthwise_conv_2d.rs:28-105)
 __global__ __launch_bounds__(256) void dwconv_generic(const int8_t *__restrict__ in,
                                                       int8_t *__restrict__ out, ConvArgs p,
@@ -319,6 +355,13 @@ __global__ __launch_bounds__(256) void checksum_i8(const int8_t *__restrict__ in
 void launch_conv2d_generic(const int8_t *in, int8_t *out, const ConvArgs &a, size_t batch, hipStream_t s) {
     const size_t total = batch * a.OH * a.OW * a.N;
     hipLaunchKernelGGL(conv2d_generic, dim3(grid_for(total)), dim3(256), 0, s, in, out, a, total);
+}
+bool conv1x1_rowwave_supported(const ConvArgs &a) {
+    return a.KH == 1 && a.KW == 1 && a.sh == 1 && a.sw == 1 && a.OH == a.H && a.OW == a.W && a.N >= 1 && a.N <= 8 && a.C % 4 == 0;
+}
+void launch_conv1x1_rowwave(const int8_t *in, int8_t *out, const ConvArgs &a, size_t batch, hipStream_t s) {
+    const size_t rows = batch * a.H * a.W;
+    hipLaunchKernelGGL(conv1x1_rowwave, dim3(grid_for(rows, 4)), dim3(256), 0, s, in, out, a, rows);
 }
 void launch_dwconv_generic(const int8_t *in, int8_t *out, const ConvArgs &a, size_t batch, hipStream_t s) {
     const size_t total = batch * a.OH * a.OW * a.N;

@@ -315,6 +315,8 @@ struct StageArgs {
 
 void launch_conv2d_generic(const int8_t *in, int8_t *out, const ConvArgs &a, size_t batch, hipStream_t s);
 void launch_dwconv_generic(const int8_t *in, int8_t *out, const ConvArgs &a, size_t batch, hipStream_t s);
+bool conv1x1_rowwave_supported(const ConvArgs &a); // 1x1 filter, stride 1, N <= 8, C % 4 == 0
+void launch_conv1x1_rowwave(const int8_t *in, int8_t *out, const ConvArgs &a, size_t batch, hipStream_t s);
 void launch_avgpool_generic(const int8_t *in, int8_t *out, const PoolArgs &a, size_t batch, hipStream_t s);
 void launch_avgpool_c4(const int8_t *in, int8_t *out, const PoolArgs &a, size_t batch, hipStream_t s); // C % 4 == 0
 void launch_fc_generic(const int8_t *in, int8_t *out, const FcArgs &a, size_t rows, hipStream_t s);

@@ -89,7 +89,7 @@ struct OpImpl {
     bool accepts_f32 = false;  // op_set_input_quant succeeded: op_run_f32 may replace quantize + op_run
     bool finite_consts = true; // A / S all finite (the shape-specialised and fused epilogues assume it)
     std::string generic_name, fast_name;
-    enum Fast { NONE, DW_NHWC, DW_STEM, DW_C1, PW_MFMA, FC_ROWWAVE, FC_MFMA, POOL_C4 } fast = NONE;
+    enum Fast { NONE, DW_NHWC, DW_STEM, DW_C1, PW_MFMA, FC_ROWWAVE, FC_MFMA, POOL_C4, CONV1X1_ROW } fast = NONE;
     int *d_rowsum = nullptr; // FC_MFMA with wzp != 0: per-row input sums
     size_t rowsum_cap = 0;
     int8_t *d_ext = nullptr; // op_run_external on a u8 operator: input moved to the i8 domain
@@ -395,6 +395,8 @@ OpImpl *op_create(int device, const OpSpec &spec) {
                 f.wrr = op->d_wrr.p;
             }
         }
+        if (op->fast == OpImpl::NONE && !dw && k::conv1x1_rowwave_supported(a)) // few outputs: one wavefront per pixel
+            op->fast = OpImpl::CONV1X1_ROW, op->fast_name = "conv1x1_rowwave";
         if (getenv("MF_VERBOSE"))
             fprintf(stderr, "[microflow_amd] %s %dx%dx%d -> %d: kernel %s, worst-case |acc| %lld%s\n",
                     dw ? "depthwise_conv_2d" : "conv_2d", s.H, s.W, s.C, s.N,
@@ -525,6 +527,10 @@ void op_run(OpImpl *op, const int8_t *d_in, size_t batch, int8_t *d_out, void *s
             break;
         case OpImpl::DW_STEM:
             done = k::launch_dw_stem(sp.H, sp.W, sp.N, sp.sh, d_in, d_out, op->stem, (int)batch, s);
+            break;
+        case OpImpl::CONV1X1_ROW:
+            k::launch_conv1x1_rowwave(d_in, d_out, op->conv, batch, s);
+            done = true;
             break;
         case OpImpl::POOL_C4:
             k::launch_avgpool_c4(d_in, d_out, op->pool, batch, s);

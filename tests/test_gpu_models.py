@@ -210,7 +210,7 @@ def test_kernel_routing(models):
     m.set_fusion(True)
     assert sum(n.startswith(("dw3x3_mm", "dw3x3_nhwc")) for n in names) == 13  # matrix-pipe taps (MF_DW_IMPL=valu: v_dot4)
     assert sum(n.startswith("pw_mfma") for n in names) == 13
-    assert names[28] == "conv2d_generic" and names[27] == "avgpool_c4"
+    assert names[28] == "conv1x1_rowwave" and names[27] == "avgpool_c4"
     assert names[29] == "" and names[30] == "softmax_table"
     # speech: [reshape] depthwise (one input channel) -> FullyConnected + Softmax in one launch
     sp = models["speech"]

@@ -484,6 +484,28 @@ def test_requantize_dense_sweep_fast_pointwise(mf, O):
         assert np.array_equal(got, want), (act, np.argwhere(got != want)[:5])
 
 
+@pytest.mark.parametrize("case", [(1, 1, 256, 2, True), (3, 3, 64, 8, True), (2, 5, 12, 3, False), (4, 4, 4, 1, True)],
+                         ids=lambda c: "x".join(map(str, c[:4])))
+def test_conv_1x1_few_outputs_rowwave(mf, O, case):
+    """Conv2D 1x1 with N <= 8 outputs (the head conv of person_detect: 256 -> 2) on its row-wave kernel: non-zero
+    filter zero points (the value-sum term), per-channel and per-tensor constants, a NaN constant, ragged batch."""
+    H, W, C, N, pc = case
+    rng = np.random.default_rng(1000 + C + N)
+    batch = 37
+    x = rng.integers(-128, 128, (batch, H, W, C)).astype(np.int8)
+    f = rng.integers(-128, 128, (N, 1, 1, C)).astype(np.int8)
+    fzp = rng.integers(-30, 30, N if pc else 1).astype(np.int8)
+    izp, oscale, ozp, act = int(rng.integers(-128, 128)), 0.05, int(rng.integers(-100, 100)), int(rng.integers(0, 2))
+    c0, c1 = _rand_consts(rng, N, C, per_channel=pc)
+    if N >= 3:
+        c0[1] = np.nan
+    opts = mf.ops.Conv2DOptions(mf.FusedActivation(act), mf.TensorViewPadding.SAME, (1, 1))
+    op = mf.ops.prepare_conv_2d((H, W, C), f, fzp, izp, oscale, ozp, opts, (c0, c1), (H, W))
+    assert op.kernel == "conv1x1_rowwave"
+    want = np.stack([O.conv_2d(x[i], f, fzp, izp, oscale, ozp, act, 0, (1, 1), (H, W), c0, c1) for i in range(batch)])
+    assert np.array_equal(op(x), want)
+
+
 def test_non_finite_constants_follow_rust_casts(mf, O):
     """Degenerate models (NaN / Inf constants): Rust's `as i8` maps NaN to 0 and saturates +-Inf,
     and the activation is applied afterwards.  Such operators are kept on the shape-generic
