@@ -180,10 +180,12 @@ static void launch_pw_t(const int8_t *in, int8_t *out, const PwArgs &a, long lon
 }
 // workgroups of the grid-strided pointwise kernel (r01 sweep, MF_PW_GRID overrides): the wide early
 // layers (K < 64, most pixels) like many short-lived workgroups, the deep late ones few
-static long long pw_grid_cap(int K) {
+static long long pw_grid_cap(int K, int N) {
     static const long long forced = [] { const char *e = getenv("MF_PW_GRID"); return e ? atoll(e) : 0LL; }();
     if (forced > 0) return forced;
-    return K < 64 ? 256LL * 32 : (K >= 128 ? 256LL * 4 : 256LL * 8);
+    // r02 sweep (256 x {2 .. 64}, same session): K >= 128: x2 beats x4 by 4 - 8 %; K < 64 with N <= 32: x64 beats x32 by
+    // 2 - 12 %; the rest stays
+    return K < 64 ? (N <= 32 ? 256LL * 64 : 256LL * 32) : (K >= 128 ? 256LL * 2 : 256LL * 8);
 }
 const char *pw_name(int K, int N) {
 #define MF_PW(k, n) \
@@ -199,7 +201,7 @@ bool launch_pw(int K, int N, const int8_t *in, int8_t *out, const PwArgs &a, lon
         constexpr int U = pw_chunks_in_flight(k);                                               \
         const long long nchunks = (npix + CPIX - 1) / CPIX;                                     \
         long long grid = (nchunks + SLOTS * U - 1) / (SLOTS * U);                               \
-        if (grid > pw_grid_cap(k)) grid = pw_grid_cap(k);                                       \
+        if (grid > pw_grid_cap(k, n)) grid = pw_grid_cap(k, n);                                 \
         if (grid < 1) grid = 1;                                                                 \
         MF_DISPATCH4(a.magic, a.xr, launch_pw_t, (in, out, a, npix, (int)grid, s), k, n)                  \
         return true;                                                                            \
