@@ -105,6 +105,9 @@ SIGNATURES = {
     "mf_synth_i8": (C.c_int, [C.c_int, C.c_uint64, C.c_uint64, C.c_size_t, _vp, _vp]),
     "mf_checksum_i8": (C.c_int, [C.c_int, _vp, C.c_size_t, C.POINTER(C.c_uint64), _vp]),
     "mf_verify_quant_div": (C.c_int, [C.c_int, C.c_float, C.c_float, C.c_int, C.c_int, C.POINTER(C.c_uint64)]),
+    "mf_selftest_rounding": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint64)]),
+    "mf_selftest_requant": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int,
+                                      C.POINTER(C.c_uint64)]),
     "mf_model_time_device": (C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_int, C.c_int,
                                        C.POINTER(C.c_float), _vp]),
 }

@@ -23,6 +23,11 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
 FLAGS += os.environ.get("MF_EXTRA_HIPCC_FLAGS", "").split()  # kernel-tuning experiments (-DMF_...=n)
 
 
+# measurement tool, not product: the requantisation-rate microbenchmark bench.py runs beside its timed region
+UBENCH_SRC = os.path.join(HERE, "..", "scripts", "ubench", "epi_rate.hip")
+UBENCH_LIB = os.path.join(HERE, "..", "scripts", "ubench", "libepi_rate.so")
+
+
 def hipcc():
     exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(exe):
@@ -38,7 +43,18 @@ def stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def build_ubench(force=False):
+    deps = [UBENCH_SRC, os.path.join(CSRC, "k_common.hpp"), os.path.join(CSRC, "kernels.hpp")]
+    if (not force and os.path.exists(UBENCH_LIB)
+            and os.path.getmtime(UBENCH_LIB) >= max(os.path.getmtime(d) for d in deps)):
+        return UBENCH_LIB
+    subprocess.check_call([hipcc()] + [f for f in FLAGS if f != "-Wall"] + ["-Wno-unused-value", "-DMF_UBENCH_LIB", "-shared", "-x", "hip",
+                                                    UBENCH_SRC, "-o", UBENCH_LIB])
+    return UBENCH_LIB
+
+
 def build(force=False, verbose=False):
+    build_ubench(force)
     if not force and not stale():
         return LIB
     objdir = os.path.join(HERE, "build")

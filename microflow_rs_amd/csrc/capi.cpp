@@ -537,6 +537,18 @@ int mf_verify_quant_div(int device, float scale, float reciprocal, int zero_poin
         *mismatches = mf::dev_verify_quant_div(device, scale, reciprocal, zero_point, is_u8 != 0);
     })
 }
+int mf_selftest_rounding(int device, int mode, int is_u8, int lo, int hi, uint64_t *mismatches) {
+    MF_TRY({
+        MF_NEED(mismatches);
+        *mismatches = mf::dev_selftest_epilogue(device, mode, is_u8 != 0, false, 0.0f, 0.0f, lo, hi);
+    })
+}
+int mf_selftest_requant(int device, int mode, int is_u8, float A, float S, int lo, int hi, uint64_t *mismatches) {
+    MF_TRY({
+        MF_NEED(mismatches);
+        *mismatches = mf::dev_selftest_epilogue(device, mode, is_u8 != 0, true, A, S, lo, hi);
+    })
+}
 int mf_checksum_i8(int device, const int8_t *d_input, size_t n, uint64_t *checksum, void *stream) {
     MF_TRY({
         MF_NEED(checksum && (n == 0 || d_input));

@@ -58,9 +58,14 @@ __device__ __forceinline__ int requant(int acc, float A, float S, float lo_f, fl
 // epilogue's value is unchanged.  The host enables it per operator only when the worst-case
 // |acc| over ALL inputs -- max|v - izp| * sum|w - wzp| per channel -- is below 2^22 (ops.hip).
 constexpr int MF_MAGIC_I = 0x4B400000;
-template <bool MG>
+// MG (template parameter of every fast kernel) = the epilogue mode the host chose for the operator(s) of a launch:
+//   0  accumulator converted with v_cvt_f32_i32                         (|acc| may reach 2^22)
+//   1  bit-pattern int -> f32 (above)
+//   2  = 1, and the clamp [lo, hi] is exactly the element type's range and |x| < 2^15 for every input, so that the
+//      clamp is done by a saturating pack (v_sat_pk_u8_i16) instead of v_med3_f32 (requant_pack4 below)
+template <int MG>
 __device__ __forceinline__ int requant_t(int acc, float A, float S, float lo_f, float hi_f) {
-    if constexpr (!MG) {
+    if constexpr (MG == 0) {
         return requant(acc, A, S, lo_f, hi_f);
     } else {
         const float f = __fsub_rn(__int_as_float(acc), 12582912.0f);
@@ -70,8 +75,8 @@ __device__ __forceinline__ int requant_t(int acc, float A, float S, float lo_f, 
         return (int)r;
     }
 }
-template <bool MG> __device__ __forceinline__ int4 magic4(int4 k) {
-    if constexpr (MG) k.x += MF_MAGIC_I, k.y += MF_MAGIC_I, k.z += MF_MAGIC_I, k.w += MF_MAGIC_I;
+template <int MG> __device__ __forceinline__ int4 magic4(int4 k) {
+    if constexpr (MG != 0) k.x += MF_MAGIC_I, k.y += MF_MAGIC_I, k.z += MF_MAGIC_I, k.w += MF_MAGIC_I;
     return k;
 }
 
@@ -93,19 +98,45 @@ __device__ __forceinline__ uint32_t pack4(int a, int b, int c, int d) {
     return __builtin_amdgcn_perm(hi, lo, 0x05040100u);
 }
 
-// Requantise four accumulators and pack the four results into one dword in 4 instructions instead of 7: the
-// float -> int conversion of each clamped value writes its low byte straight into byte k of the destination
-// (SDWA destination select, other bytes preserved), so no separate v_perm packing (3 per dword) is needed.
-// Same arithmetic as requant_t followed by pack4: the conversion truncates a value already clamped to the
-// element type's range, whose two's-complement low byte is the stored byte.
-#ifndef MF_SDWA_PACK
-#define MF_SDWA_PACK 1 // 0: v_cvt + v_perm packing (A/B switch)
+// ------------------------------------------------------------------------
+// The epilogue of the fast kernels: four accumulators -> one packed dword.
+//
+// x = fl(A + fl(S * f32(acc))) is the reference's value (two roundings, conv_2d.rs:93-98); what follows it in the
+// reference is roundf (half away from zero), the activation clamp and `as T`.  Three exact forms of that tail:
+//
+// MF_EPI == 0 (round 2): r = x + copysign(pred(0.5), x); v_med3_f32; v_cvt_i32_f32 (truncating) with an SDWA byte
+//   destination.  v_bfi, v_med3 and v_cvt issue at half rate on gfx950: 10 issue units per byte.
+//
+// MF_EPI == 1, "sticky bit": roundf(x) == RNE_int(x | 1) for every finite x with |x| < 2^22, where `x | 1` sets the
+//   lowest mantissa bit.  Proof sketch: a tie k + 1/2 has an even mantissa (its ulp is < 1/2), so the OR moves it one
+//   ulp AWAY from zero and round-to-nearest then goes away from zero, as roundf does; a non-tie x with an even
+//   mantissa moves by one ulp towards the next float of the same sign, and the nearest tie (even mantissa, at least
+//   two ulps away) is not reached; odd mantissas are unchanged; 0 becomes a denormal that rounds to 0.  RNE_int itself
+//   is the f32 addition of 1.5 * 2^23, whose result's low mantissa bits are the two's-complement integer, so the
+//   low BYTE of the sum -- written to its place in the dword by the SDWA destination select of that same v_add_f32 --
+//   is the stored value.  The clamp moves in front (clamping to integers commutes with rounding to integers):
+//   v_sub (bit pattern -> f32), v_mul, v_add, v_med3, v_or, v_add_sdwa: 7 issue units per byte.
+//   mf_selftest_rounding (k_generic.hip) checks the identity over all 2^32 bit patterns on the device.
+//
+// MG == 2 (host: clamp == the element type's whole range, |x| < 2^15): the magic constant carries +128 (i8), the low
+//   16 bits of two sums are written into the halves of one dword, and v_sat_pk_u8_i16 saturates both to [0, 255] =
+//   the clamp; XOR 0x80 per byte returns to the stored i8 domain.  No v_med3: 6.25 issue units per byte.
+// ------------------------------------------------------------------------
+#ifndef MF_EPI
+#define MF_EPI 1
 #endif
-template <bool MG> __device__ __forceinline__ float requant_clamped(int acc, float A, float S, float lo_f, float hi_f) {
+#ifndef MF_SDWA_PACK
+#define MF_SDWA_PACK 1 // 0: v_cvt + v_perm packing (A/B switch, MF_EPI == 0 only)
+#endif
+template <int MG> __device__ __forceinline__ float requant_x(int acc, float A, float S) {
     float f;
-    if constexpr (MG) f = __fsub_rn(__int_as_float(acc), 12582912.0f);
+    if constexpr (MG != 0) f = __fsub_rn(__int_as_float(acc), 12582912.0f);
     else f = (float)acc;
-    const float x = __fadd_rn(A, __fmul_rn(S, f));
+    return __fadd_rn(A, __fmul_rn(S, f));
+}
+// round 2's pre-conversion value: x + copysign(pred(0.5), x), clamped (truncation by the conversion follows)
+template <int MG> __device__ __forceinline__ float requant_clamped(int acc, float A, float S, float lo_f, float hi_f) {
+    const float x = requant_x<MG>(acc, A, S);
     const float r = __fadd_rn(x, __builtin_copysignf(0x1.fffffep-2f, x));
     return __builtin_amdgcn_fmed3f(r, lo_f, hi_f);
 }
@@ -136,31 +167,156 @@ __device__ __forceinline__ void cvt_pack4x2(float a0, float a1, float a2, float 
         "v_cvt_i32_f32_sdwa %1, %9 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:DWORD\n\ts_nop 0"
         : "=&v"(da), "=&v"(db) : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(b0), "v"(b1), "v"(b2), "v"(b3));
 }
-template <bool MG, uint32_t XR4>
+
+// ---- sticky-bit forms ----
+// RNE_int of four values (|v| < 2^22, lowest mantissa bit set) into the four bytes of a dword: the low byte of
+// v + 1.5 * 2^23.  Every SDWA write is followed by an independent instruction (the OR of a later value / s_nop).
+__device__ __forceinline__ uint32_t rne_pack4(float r0, float r1, float r2, float r3) {
+    uint32_t d;
+    const float M = 12582912.0f;
+    asm("v_or_b32 %1, 1, %1\n\t"
+        "v_or_b32 %2, 1, %2\n\t"
+        "v_add_f32_sdwa %0, %1, %5 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD\n\t"
+        "v_or_b32 %3, 1, %3\n\t"
+        "v_add_f32_sdwa %0, %2, %5 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
+        "v_or_b32 %4, 1, %4\n\t"
+        "v_add_f32_sdwa %0, %3, %5 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
+        "s_nop 0\n\t"
+        "v_add_f32_sdwa %0, %4, %5 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
+        "s_nop 0"
+        : "=&v"(d), "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3) : "v"(M));
+    return d;
+}
+__device__ __forceinline__ void rne_pack4x2(float a0, float a1, float a2, float a3, float b0, float b1, float b2, float b3,
+                                            uint32_t &da, uint32_t &db) {
+    const float M = 12582912.0f;
+    asm("v_or_b32 %2, 1, %2\n\t"
+        "v_or_b32 %6, 1, %6\n\t"
+        "v_or_b32 %3, 1, %3\n\t"
+        "v_add_f32_sdwa %0, %2, %10 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD\n\t"
+        "v_or_b32 %7, 1, %7\n\t"
+        "v_add_f32_sdwa %1, %6, %10 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD\n\t"
+        "v_or_b32 %4, 1, %4\n\t"
+        "v_add_f32_sdwa %0, %3, %10 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
+        "v_or_b32 %8, 1, %8\n\t"
+        "v_add_f32_sdwa %1, %7, %10 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
+        "v_or_b32 %5, 1, %5\n\t"
+        "v_add_f32_sdwa %0, %4, %10 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
+        "v_or_b32 %9, 1, %9\n\t"
+        "v_add_f32_sdwa %1, %8, %10 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
+        "v_add_f32_sdwa %0, %5, %10 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
+        "v_add_f32_sdwa %1, %9, %10 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
+        "s_nop 0"
+        : "=&v"(da), "=&v"(db), "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3)
+        : "v"(M));
+}
+// MG == 2: the same rounding with the clamp done by a saturating pack.  MS = 1.5 * 2^23 + (128 for i8, 0 for u8):
+// the low 16 bits of v + MS are the value in the u8 domain as an i16 (|v| < 2^15), two of them per dword;
+// v_sat_pk_u8_i16 clamps both to [0, 255] and packs them into 16 bits.  Result: four u8-domain bytes.
+__device__ __forceinline__ uint32_t sat_pack4(float r0, float r1, float r2, float r3, float MS) {
+    uint32_t d, p, q;
+    asm("v_or_b32 %3, 1, %3\n\t"
+        "v_or_b32 %5, 1, %5\n\t"
+        "v_add_f32_sdwa %1, %3, %7 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD\n\t"
+        "v_or_b32 %4, 1, %4\n\t"
+        "v_add_f32_sdwa %2, %5, %7 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD\n\t"
+        "v_or_b32 %6, 1, %6\n\t"
+        "v_add_f32_sdwa %1, %4, %7 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
+        "v_add_f32_sdwa %2, %6, %7 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
+        "v_sat_pk_u8_i16_sdwa %0, %1 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:DWORD\n\t"
+        "s_nop 0\n\t"
+        "v_sat_pk_u8_i16_sdwa %0, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD\n\t"
+        "s_nop 0"
+        : "=&v"(d), "=&v"(p), "=&v"(q), "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3) : "v"(MS));
+    return d;
+}
+__device__ __forceinline__ void sat_pack4x2(float a0, float a1, float a2, float a3, float b0, float b1, float b2, float b3,
+                                            float MS, uint32_t &da, uint32_t &db) {
+    uint32_t p, q, r, s;
+    asm("v_or_b32 %6, 1, %6\n\t"
+        "v_or_b32 %8, 1, %8\n\t"
+        "v_or_b32 %10, 1, %10\n\t"
+        "v_add_f32_sdwa %2, %6, %14 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD\n\t"
+        "v_or_b32 %12, 1, %12\n\t"
+        "v_add_f32_sdwa %3, %8, %14 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD\n\t"
+        "v_or_b32 %7, 1, %7\n\t"
+        "v_add_f32_sdwa %4, %10, %14 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD\n\t"
+        "v_or_b32 %9, 1, %9\n\t"
+        "v_add_f32_sdwa %5, %12, %14 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD\n\t"
+        "v_or_b32 %11, 1, %11\n\t"
+        "v_add_f32_sdwa %2, %7, %14 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
+        "v_or_b32 %13, 1, %13\n\t"
+        "v_add_f32_sdwa %3, %9, %14 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
+        "v_add_f32_sdwa %4, %11, %14 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
+        "v_add_f32_sdwa %5, %13, %14 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
+        "v_sat_pk_u8_i16_sdwa %0, %2 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:DWORD\n\t"
+        "v_sat_pk_u8_i16_sdwa %1, %4 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:DWORD\n\t"
+        "v_sat_pk_u8_i16_sdwa %0, %3 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD\n\t"
+        "v_sat_pk_u8_i16_sdwa %1, %5 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD\n\t"
+        "s_nop 0"
+        : "=&v"(da), "=&v"(db), "=&v"(p), "=&v"(q), "=&v"(r), "=&v"(s), "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(b0),
+          "+v"(b1), "+v"(b2), "+v"(b3)
+        : "v"(MS));
+}
+
+// The value an epilogue hands to its pack (epi_pack4 / epi_pack4x2): kernels that interleave the epilogue with MFMAs
+// by hand (k_stage.hip, k_tail3.hip) call the two halves themselves.
+template <int MG> __device__ __forceinline__ float epi_value(int acc, float A, float S, float lo_f, float hi_f) {
+#if MF_EPI == 0
+    return requant_clamped<MG>(acc, A, S, lo_f, hi_f);
+#else
+    if constexpr (MG == 2) return requant_x<MG>(acc, A, S); // clamp = the saturating pack
+    else return __builtin_amdgcn_fmed3f(requant_x<MG>(acc, A, S), lo_f, hi_f);
+#endif
+}
+template <int MG, uint32_t XR4> __device__ __forceinline__ uint32_t epi_pack4(float r0, float r1, float r2, float r3) {
+#if MF_EPI == 0
+    return cvt_pack4(r0, r1, r2, r3) ^ XR4;
+#else
+    if constexpr (MG == 2) return sat_pack4(r0, r1, r2, r3, XR4 ? 12582912.0f : 12583040.0f) ^ 0x80808080u;
+    else return rne_pack4(r0, r1, r2, r3) ^ XR4;
+#endif
+}
+template <int MG, uint32_t XR4>
+__device__ __forceinline__ void epi_pack4x2(float a0, float a1, float a2, float a3, float b0, float b1, float b2, float b3,
+                                            uint32_t &da, uint32_t &db) {
+#if MF_EPI == 0
+    cvt_pack4x2(a0, a1, a2, a3, b0, b1, b2, b3, da, db);
+    da ^= XR4, db ^= XR4;
+#else
+    if constexpr (MG == 2) {
+        sat_pack4x2(a0, a1, a2, a3, b0, b1, b2, b3, XR4 ? 12582912.0f : 12583040.0f, da, db);
+        da ^= 0x80808080u, db ^= 0x80808080u;
+    } else {
+        rne_pack4x2(a0, a1, a2, a3, b0, b1, b2, b3, da, db);
+        da ^= XR4, db ^= XR4;
+    }
+#endif
+}
+template <int MG, uint32_t XR4>
 __device__ __forceinline__ uint32_t requant_pack4(int a0, int a1, int a2, int a3, const float4 &A, const float4 &S,
                                                   float lo_f, float hi_f) {
-#if MF_SDWA_PACK
-    return cvt_pack4(requant_clamped<MG>(a0, A.x, S.x, lo_f, hi_f), requant_clamped<MG>(a1, A.y, S.y, lo_f, hi_f),
-                     requant_clamped<MG>(a2, A.z, S.z, lo_f, hi_f), requant_clamped<MG>(a3, A.w, S.w, lo_f, hi_f)) ^ XR4;
-#else
+#if MF_EPI == 0 && !MF_SDWA_PACK
     return pack4(requant_t<MG>(a0, A.x, S.x, lo_f, hi_f), requant_t<MG>(a1, A.y, S.y, lo_f, hi_f),
                  requant_t<MG>(a2, A.z, S.z, lo_f, hi_f), requant_t<MG>(a3, A.w, S.w, lo_f, hi_f)) ^ XR4;
+#else
+    return epi_pack4<MG, XR4>(epi_value<MG>(a0, A.x, S.x, lo_f, hi_f), epi_value<MG>(a1, A.y, S.y, lo_f, hi_f),
+                              epi_value<MG>(a2, A.z, S.z, lo_f, hi_f), epi_value<MG>(a3, A.w, S.w, lo_f, hi_f));
 #endif
 }
 
-// requant_pack4 of two accumulator quads (two dwords) with the alternating conversion chains of cvt_pack4x2
-template <bool MG, uint32_t XR4>
+// requant_pack4 of two accumulator quads (two dwords) with the alternating chains of the x2 packs
+template <int MG, uint32_t XR4>
 __device__ __forceinline__ void requant_pack4x2(const v4i &a, const float4 &aA, const float4 &aS, const v4i &b, const float4 &bA,
                                                 const float4 &bS, float lo_f, float hi_f, uint32_t &da, uint32_t &db) {
-#if MF_SDWA_PACK
-    cvt_pack4x2(requant_clamped<MG>(a[0], aA.x, aS.x, lo_f, hi_f), requant_clamped<MG>(a[1], aA.y, aS.y, lo_f, hi_f),
-                requant_clamped<MG>(a[2], aA.z, aS.z, lo_f, hi_f), requant_clamped<MG>(a[3], aA.w, aS.w, lo_f, hi_f),
-                requant_clamped<MG>(b[0], bA.x, bS.x, lo_f, hi_f), requant_clamped<MG>(b[1], bA.y, bS.y, lo_f, hi_f),
-                requant_clamped<MG>(b[2], bA.z, bS.z, lo_f, hi_f), requant_clamped<MG>(b[3], bA.w, bS.w, lo_f, hi_f), da, db);
-    da ^= XR4, db ^= XR4;
-#else
+#if MF_EPI == 0 && !MF_SDWA_PACK
     da = requant_pack4<MG, XR4>(a[0], a[1], a[2], a[3], aA, aS, lo_f, hi_f);
     db = requant_pack4<MG, XR4>(b[0], b[1], b[2], b[3], bA, bS, lo_f, hi_f);
+#else
+    epi_pack4x2<MG, XR4>(epi_value<MG>(a[0], aA.x, aS.x, lo_f, hi_f), epi_value<MG>(a[1], aA.y, aS.y, lo_f, hi_f),
+                         epi_value<MG>(a[2], aA.z, aS.z, lo_f, hi_f), epi_value<MG>(a[3], aA.w, aS.w, lo_f, hi_f),
+                         epi_value<MG>(b[0], bA.x, bS.x, lo_f, hi_f), epi_value<MG>(b[1], bA.y, bS.y, lo_f, hi_f),
+                         epi_value<MG>(b[2], bA.z, bS.z, lo_f, hi_f), epi_value<MG>(b[3], bA.w, bS.w, lo_f, hi_f), da, db);
 #endif
 }
 
@@ -281,15 +437,18 @@ static inline int grid_for(size_t total, int per_block = 256, int cap = 256 * 8)
 }
 
 // ---- fast-path dispatch tables ------------------------------------------------
-// the four instances of a fast kernel: {v_cvt, bit-pattern} int->f32  x  {i8, u8} element type
+// the six instances of a fast kernel: epilogue mode MG in {0, 1, 2} (requant_t above)  x  {i8, u8} element type
 #define MF_DISPATCH4(magic, xr, FN, ARGS, ...)                         \
     do {                                                               \
+        const int mg_ = (magic);                                       \
         if (xr) {                                                      \
-            if (magic) FN<__VA_ARGS__, true, 0x80808080u> ARGS;        \
-            else FN<__VA_ARGS__, false, 0x80808080u> ARGS;             \
+            if (mg_ == 2) FN<__VA_ARGS__, 2, 0x80808080u> ARGS;        \
+            else if (mg_) FN<__VA_ARGS__, 1, 0x80808080u> ARGS;        \
+            else FN<__VA_ARGS__, 0, 0x80808080u> ARGS;                 \
         } else {                                                       \
-            if (magic) FN<__VA_ARGS__, true, 0u> ARGS;                 \
-            else FN<__VA_ARGS__, false, 0u> ARGS;                      \
+            if (mg_ == 2) FN<__VA_ARGS__, 2, 0u> ARGS;                 \
+            else if (mg_) FN<__VA_ARGS__, 1, 0u> ARGS;                 \
+            else FN<__VA_ARGS__, 0, 0u> ARGS;                          \
         }                                                              \
     } while (0);
 

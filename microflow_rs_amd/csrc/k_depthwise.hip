@@ -31,7 +31,7 @@ namespace k {
 // One barrier per step: after it, every wave has finished reading the other buffer
 // (safe to overwrite) and every wave's DMAs into this buffer have landed.
 // ------------------------------------------------------------------------
-template <int H, int W, int C, int S, int G, int NTHR, bool MG, uint32_t XR4>
+template <int H, int W, int C, int S, int G, int NTHR, int MG, uint32_t XR4>
 __global__ __launch_bounds__(NTHR) void dw3x3_nhwc(const int8_t *__restrict__ in,
                                                   int8_t *__restrict__ out, DwFastArgs p,
                                                   int batch) {
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(NTHR) void dw3x3_nhwc(const int8_t *__restrict__ in
 // ------------------------------------------------------------------------
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int H, int W, int G, bool MG, uint32_t XR4, bool F32IN>
+template <int H, int W, int G, int MG, uint32_t XR4, bool F32IN>
 __global__ __launch_bounds__(256) void dw3x3_stem8(const int8_t *__restrict__ in,
                                                    int8_t *__restrict__ out, DwStemArgs p,
                                                    int batch) {
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(256) void dw3x3_stem8(const int8_t *__restrict__ in
                 int qa[DM], qb[DM];
 #pragma unroll
                 for (int c = 0; c < DM; ++c) {
-                    int a = p.Kc[c] + (MG ? MF_MAGIC_I : 0), b = a;
+                    int a = p.Kc[c] + (MG != 0 ? MF_MAGIC_I : 0), b = a;
 #pragma unroll
                     for (int ky = 0; ky < 3; ++ky) {
                         a = sdot4(ta[ky], p.wrow[ky][c], a);
@@ -303,7 +303,7 @@ __global__ __launch_bounds__(256) void dw3x3_stem8(const int8_t *__restrict__ in
 //               offsets are three per-type constants
 // Same tile, staging and (reference) padding as dw3x3_stem8; what is left on the VALU is the requantisation.
 // ------------------------------------------------------------------------
-template <int H, int W, int G, bool MG, uint32_t XR4, bool F32IN>
+template <int H, int W, int G, int MG, uint32_t XR4, bool F32IN>
 __global__ __launch_bounds__(256) void dw3x3_stem8_mm(const int8_t *__restrict__ in, int8_t *__restrict__ out, DwStemArgs p,
                                                       int batch) {
     constexpr int S = 2;
@@ -465,7 +465,7 @@ __global__ __launch_bounds__(256) void dw3x3_stem8_mm(const int8_t *__restrict__
 //            from LDS as broadcast b128s.
 // Every input byte is read from HBM once; the kernel is VALU-bound (54 MAC per byte).
 // ------------------------------------------------------------------------
-template <bool MG, uint32_t XR4>
+template <int MG, uint32_t XR4>
 __global__ __launch_bounds__(512) void dw_c1_lds(const int8_t *__restrict__ in, int8_t *__restrict__ out,
                                                  DwC1Args p, size_t batch) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -550,7 +550,7 @@ __global__ __launch_bounds__(512) void dw_c1_lds(const int8_t *__restrict__ in, 
 }
 
 // ---- launchers ----
-template <int H, int W, int C, int S, int G, int NTHR, bool MG, uint32_t XR4>
+template <int H, int W, int C, int S, int G, int NTHR, int MG, uint32_t XR4>
 static void launch_dw(const int8_t *in, int8_t *out, const DwFastArgs &a, int batch, hipStream_t s) {
     constexpr int LP = C < 16 ? 16 : C;
     constexpr int lds = 2 * G * (H + 2) * (LP + W * C + LP) + 256; // two staging buffers + read slack
@@ -633,8 +633,8 @@ bool launch_dw_stem(int H, int W, int DM, int S, const int8_t *in, int8_t *out, 
             const int gridm = nsteps < 256 * pcu ? nsteps : 256 * pcu;
 #define MF_STEMM(MG, XR, F) hipLaunchKernelGGL((dw3x3_stem8_mm<96, 96, G, MG, XR, F>), dim3(gridm), dim3(256), lds, s, in, out, a, batch)
 #define MF_STEMM2(F)                                                                               \
-    if (a.xr) { if (a.magic) MF_STEMM(true, 0x80808080u, F); else MF_STEMM(false, 0x80808080u, F); } \
-    else { if (a.magic) MF_STEMM(true, 0u, F); else MF_STEMM(false, 0u, F); }
+    if (a.xr) { if (a.magic == 2) MF_STEMM(2, 0x80808080u, F); else if (a.magic) MF_STEMM(1, 0x80808080u, F); else MF_STEMM(0, 0x80808080u, F); } \
+    else { if (a.magic == 2) MF_STEMM(2, 0u, F); else if (a.magic) MF_STEMM(1, 0u, F); else MF_STEMM(0, 0u, F); }
             if (f32_input) { MF_STEMM2(true) } else { MF_STEMM2(false) }
 #undef MF_STEMM2
 #undef MF_STEMM

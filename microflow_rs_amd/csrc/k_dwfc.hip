@@ -51,7 +51,7 @@ __device__ long long g_dwfc_trace[32];
 #define MF_TR(k) do { } while (0)
 #endif
 
-template <int NTHR, bool MG, uint32_t XR4, bool WZP>
+template <int NTHR, int MG, uint32_t XR4, bool WZP>
 __global__ __launch_bounds__(NTHR, MF_DWFC_WPE) void dwc1_fc_softmax(const int8_t *__restrict__ in, int8_t *__restrict__ out, DwFcArgs p,
                                                         size_t batch) {
     using Gm = DwFcGeom;
@@ -240,8 +240,8 @@ void launch_dwfc(const int8_t *in, int8_t *out, const DwFcArgs &a, size_t batch,
     } while (0)
 #define MF_DWFC2(MG, XR) \
     if (wz) MF_DWFC(MG, XR, true); else MF_DWFC(MG, XR, false)
-    if (a.xr) { if (a.magic) { MF_DWFC2(true, 0x80808080u); } else { MF_DWFC2(false, 0x80808080u); } }
-    else { if (a.magic) { MF_DWFC2(true, 0u); } else { MF_DWFC2(false, 0u); } }
+    if (a.xr) { if (a.magic == 2) { MF_DWFC2(2, 0x80808080u); } else if (a.magic) { MF_DWFC2(1, 0x80808080u); } else { MF_DWFC2(0, 0x80808080u); } }
+    else { if (a.magic == 2) { MF_DWFC2(2, 0u); } else if (a.magic) { MF_DWFC2(1, 0u); } else { MF_DWFC2(0, 0u); } }
 #undef MF_DWFC2
 #undef MF_DWFC
 #if MF_DWFC_DIAG

@@ -28,7 +28,7 @@ namespace k {
 // tensor, it just never leaves the CU).  Single-buffered variants issue the next step's DMA
 // right after the second barrier, so it still overlaps the pointwise phase.
 // ------------------------------------------------------------------------
-template <int H, int W, int C, int S, int N, int G, int NTHR, bool DBUF, bool MG, uint32_t XR4>
+template <int H, int W, int C, int S, int N, int G, int NTHR, bool DBUF, int MG, uint32_t XR4>
 __global__ __launch_bounds__(NTHR) void dwpw3x3(const int8_t *__restrict__ in,
                                                 int8_t *__restrict__ out, DwPwArgs p, int batch) {
     // ---- depthwise geometry (as dw3x3_nhwc) ----
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(256) void tail_pool_head_softmax(const int8_t *__re
 }
 
 // ---- launchers ----
-template <int H, int W, int C, int S, int N, int G, int NTHR, int DB, bool MG, uint32_t XR4>
+template <int H, int W, int C, int S, int N, int G, int NTHR, int DB, int MG, uint32_t XR4>
 static void launch_dwpw_t(const int8_t *in, int8_t *out, const DwPwArgs &a, int batch, hipStream_t s) {
     constexpr int LP = C < 16 ? 16 : C;
     constexpr int OH = (H + S - 1) / S, OW = (W + S - 1) / S;
@@ -321,7 +321,7 @@ bool launch_dwpw(int H, int W, int C, int S, int N, const int8_t *in, int8_t *ou
         (void)idx;
 #define MF_DWPW(h, w, c, st, n, g, t, d)                                        \
     if (idx++ == alt && H == h && W == w && C == c && S == st && N == n) {      \
-        MF_DISPATCH4(a.dw.magic && a.pw.magic, a.pw.xr, launch_dwpw_t, (in, out, a, batch, s), h, w, c, st, n, g, t, d) \
+        MF_DISPATCH4(a.dw.magic < a.pw.magic ? a.dw.magic : a.pw.magic, a.pw.xr, launch_dwpw_t, (in, out, a, batch, s), h, w, c, st, n, g, t, d) \
         return true;                                                            \
     }
         MF_DWPW_ALT_SHAPES(MF_DWPW)
@@ -329,7 +329,7 @@ bool launch_dwpw(int H, int W, int C, int S, int N, const int8_t *in, int8_t *ou
     }
 #define MF_DWPW(h, w, c, st, n, g, t, d)                         \
     if (H == h && W == w && C == c && S == st && N == n) {       \
-        MF_DISPATCH4(a.dw.magic && a.pw.magic, a.pw.xr, launch_dwpw_t, (in, out, a, batch, s), h, w, c, st, n, g, t, d) \
+        MF_DISPATCH4(a.dw.magic < a.pw.magic ? a.dw.magic : a.pw.magic, a.pw.xr, launch_dwpw_t, (in, out, a, batch, s), h, w, c, st, n, g, t, d) \
         return true;                                             \
     }
     MF_DWPW_SHAPES(MF_DWPW)

@@ -59,7 +59,7 @@ constexpr int dwmm_lds_bytes(int H, int W, int C, int S, int N, int G, int NTHR,
 // DWONLY: the depthwise operator alone (layer-wise execution): the pointwise phase is replaced by a copy of MID --
 // which then IS the operator's output tensor -- to HBM with 16-byte loads and stores.
 template <int H, int W, int C, int S, int N, int G, int NTHR, bool DBUF, int CG, int CY, int ORD, int ROWPAD, int TS,
-          int WPE, bool MG, uint32_t XR4, bool DWONLY>
+          int WPE, int MG, uint32_t XR4, bool DWONLY>
 __global__ __launch_bounds__(NTHR, WPE) void dwpw_mm(const int8_t *__restrict__ in, int8_t *__restrict__ out, DwPwArgs p,
                                                 int batch) {
     // ---- depthwise geometry ----
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(NTHR, WPE) void dwpw_mm(const int8_t *__restrict__ 
 // channels 8 (g' & 1) .. +7.
 // ------------------------------------------------------------------------
 template <int H, int W, int C, int S, int N, int G, int NTHR, int DB, int CG, int CY, int ORD, int ROWPAD, int TS,
-          int WPE, bool MG, uint32_t XR4>
+          int WPE, int MG, uint32_t XR4>
 __global__ __launch_bounds__(NTHR, WPE) void dwpw_rr(const int8_t *__restrict__ in, int8_t *__restrict__ out, DwPwArgs p,
                                                      int batch) {
     constexpr bool PAIR = C == 8;
@@ -598,7 +598,7 @@ __global__ __launch_bounds__(NTHR, WPE) void dwpw_rr(const int8_t *__restrict__ 
 
 // ---- launchers ----
 template <int H, int W, int C, int S, int N, int G, int NTHR, int DB, int CG, int CY, int ORD, int ROWPAD, int TS, int WPE,
-          bool MG, uint32_t XR4>
+          int MG, uint32_t XR4>
 static void launch_dwpw_mm_t(const int8_t *in, int8_t *out, const DwPwArgs &a, int batch, hipStream_t s) {
     constexpr int lds = dwmm_lds_bytes(H, W, C, S, N, G, NTHR, DB != 0, ROWPAD);
     static_assert(lds <= 163840, "fused tile does not fit the LDS");
@@ -611,7 +611,7 @@ static void launch_dwpw_mm_t(const int8_t *in, int8_t *out, const DwPwArgs &a, i
 }
 // the depthwise operator alone (DWONLY instance of the same shape)
 template <int H, int W, int C, int S, int N, int G, int NTHR, int DB, int CG, int CY, int ORD, int ROWPAD, int TS, int WPE,
-          bool MG, uint32_t XR4>
+          int MG, uint32_t XR4>
 static void launch_dw_mm_t(const int8_t *in, int8_t *out, const DwPwArgs &a, int batch, hipStream_t s) {
     constexpr int lds = dwmm_lds_bytes(H, W, C, S, N, G, NTHR, DB != 0, ROWPAD);
     static LaunchState st;
@@ -664,7 +664,7 @@ bool launch_dwpw_mm(int H, int W, int C, int S, int N, const int8_t *in, int8_t 
         (void)idx;
 #define MF_DWMM(h, w, c, st, n, g, t, d, cg, cy, ord, rp, ts, wpe)                                                        \
     if (idx++ == alt && H == h && W == w && C == c && S == st && N == n) {                                           \
-        MF_DISPATCH4(a.dw.magic && a.pw.magic, a.pw.xr, launch_dwpw_mm_t, (in, out, a, batch, s), h, w, c, st, n, g, t, d, \
+        MF_DISPATCH4(a.dw.magic < a.pw.magic ? a.dw.magic : a.pw.magic, a.pw.xr, launch_dwpw_mm_t, (in, out, a, batch, s), h, w, c, st, n, g, t, d, \
                      cg, cy, ord, rp, ts, wpe)                                                                            \
         return true;                                                                                                 \
     }
@@ -673,7 +673,7 @@ bool launch_dwpw_mm(int H, int W, int C, int S, int N, const int8_t *in, int8_t 
     }
 #define MF_DWMM(h, w, c, st, n, g, t, d, cg, cy, ord, rp, ts, wpe)                                                        \
     if (H == h && W == w && C == c && S == st && N == n) {                                                           \
-        MF_DISPATCH4(a.dw.magic && a.pw.magic, a.pw.xr, launch_dwpw_mm_t, (in, out, a, batch, s), h, w, c, st, n, g, t, d, \
+        MF_DISPATCH4(a.dw.magic < a.pw.magic ? a.dw.magic : a.pw.magic, a.pw.xr, launch_dwpw_mm_t, (in, out, a, batch, s), h, w, c, st, n, g, t, d, \
                      cg, cy, ord, rp, ts, wpe)                                                                            \
         return true;                                                                                                 \
     }
@@ -683,7 +683,7 @@ bool launch_dwpw_mm(int H, int W, int C, int S, int N, const int8_t *in, int8_t 
 }
 
 template <int H, int W, int C, int S, int N, int G, int NTHR, int DB, int CG, int CY, int ORD, int ROWPAD, int TS, int WPE,
-          bool MG, uint32_t XR4>
+          int MG, uint32_t XR4>
 static void launch_dwpw_rr_t(const int8_t *in, int8_t *out, const DwPwArgs &a, int batch, hipStream_t s) {
     constexpr int LP = C < 16 ? 16 : C;
     constexpr int lds = (DB ? 2 : 1) * G * (H + 2) * (LP + W * C + LP + ROWPAD) + 512;
@@ -711,7 +711,7 @@ bool launch_dwpw_rr(int H, int W, int C, int S, int N, const int8_t *in, int8_t 
         (void)idx;
 #define MF_DWRR(h, w, c, st, n, g, t, d, cg, cy, ord, rp, ts, wpe)                                                   \
     if (idx++ == alt && H == h && W == w && C == c && S == st && N == n) {                                           \
-        MF_DISPATCH4(a.dw.magic && a.pw.magic, a.pw.xr, launch_dwpw_rr_t, (in, out, a, batch, s), h, w, c, st, n, g, t, d, \
+        MF_DISPATCH4(a.dw.magic < a.pw.magic ? a.dw.magic : a.pw.magic, a.pw.xr, launch_dwpw_rr_t, (in, out, a, batch, s), h, w, c, st, n, g, t, d, \
                      cg, cy, ord, rp, ts, wpe)                                                                       \
         return true;                                                                                                 \
     }
@@ -720,7 +720,7 @@ bool launch_dwpw_rr(int H, int W, int C, int S, int N, const int8_t *in, int8_t 
     }
 #define MF_DWRR(h, w, c, st, n, g, t, d, cg, cy, ord, rp, ts, wpe)                                                   \
     if (H == h && W == w && C == c && S == st && N == n) {                                                           \
-        MF_DISPATCH4(a.dw.magic && a.pw.magic, a.pw.xr, launch_dwpw_rr_t, (in, out, a, batch, s), h, w, c, st, n, g, t, d, \
+        MF_DISPATCH4(a.dw.magic < a.pw.magic ? a.dw.magic : a.pw.magic, a.pw.xr, launch_dwpw_rr_t, (in, out, a, batch, s), h, w, c, st, n, g, t, d, \
                      cg, cy, ord, rp, ts, wpe)                                                                       \
         return true;                                                                                                 \
     }

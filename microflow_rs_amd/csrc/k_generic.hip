@@ -382,15 +382,127 @@ void launch_fc_generic(const int8_t *in, int8_t *out, const FcArgs &a, size_t ro
 void launch_softmax(const int8_t *in, int8_t *out, const SoftmaxArgs &a, size_t batch, hipStream_t s) {
     hipLaunchKernelGGL(softmax_table, dim3(grid_for(batch)), dim3(256), 0, s, in, out, a, batch);
 }
+// ~0 = the check itself could not run (allocation / launch / copy failed); the sticky error is consumed here
 unsigned long long verify_quant_div(float scale, float rcp, float zp_f, float sat_lo, float sat_hi, hipStream_t s) {
     unsigned long long *d = nullptr, h = ~0ull;
-    if (hipMalloc((void **)&d, sizeof(h)) != hipSuccess) return h;
+    if (hipMalloc((void **)&d, sizeof(h)) != hipSuccess) {
+        (void)hipGetLastError();
+        return h;
+    }
     if (hipMemsetAsync(d, 0, sizeof(h), s) == hipSuccess) {
         hipLaunchKernelGGL(verify_quant_div_kernel, dim3(256 * 16), dim3(256), 0, s, scale, rcp, zp_f, sat_lo, sat_hi, d);
-        if (hipMemcpyAsync(&h, d, sizeof(h), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) h = ~0ull;
+        if (hipGetLastError() != hipSuccess || hipMemcpyAsync(&h, d, sizeof(h), hipMemcpyDeviceToHost, s) != hipSuccess ||
+            hipStreamSynchronize(s) != hipSuccess) {
+            (void)hipGetLastError();
+            h = ~0ull;
+        }
     }
     (void)hipFree(d);
     return h;
+}
+
+// ---- self-tests of the epilogue forms of k_common.hpp (mf_selftest_rounding / mf_selftest_requant) ----
+// Reference tail of the epilogue on a value x (= round 2's form, read against libm::roundf + `as T`):
+__device__ __forceinline__ uint32_t tail_ref(float x, float lo, float hi, uint32_t xr) {
+    const float r = __fadd_rn(x, __builtin_copysignf(0x1.fffffep-2f, x));
+    return ((uint32_t)(int)__builtin_amdgcn_fmed3f(r, lo, hi) & 0xffu) ^ xr;
+}
+// mode 1: v_med3 + sticky-bit RNE pack; mode 2: saturating pack (whole range of the element type)
+template <int MODE, uint32_t XR4> __device__ __forceinline__ uint32_t tail_new4(float x0, float x1, float x2, float x3, float lo, float hi) {
+    if constexpr (MODE == 2) return sat_pack4(x0, x1, x2, x3, XR4 ? 12582912.0f : 12583040.0f) ^ 0x80808080u;
+    else if constexpr (MODE == 3) // negative control: round-to-nearest-EVEN without the sticky bit (differs from roundf on ties)
+        return pack4((int)__builtin_rintf(__builtin_amdgcn_fmed3f(x0, lo, hi)), (int)__builtin_rintf(__builtin_amdgcn_fmed3f(x1, lo, hi)),
+                     (int)__builtin_rintf(__builtin_amdgcn_fmed3f(x2, lo, hi)), (int)__builtin_rintf(__builtin_amdgcn_fmed3f(x3, lo, hi))) ^ XR4;
+    else return rne_pack4(__builtin_amdgcn_fmed3f(x0, lo, hi), __builtin_amdgcn_fmed3f(x1, lo, hi), __builtin_amdgcn_fmed3f(x2, lo, hi),
+                          __builtin_amdgcn_fmed3f(x3, lo, hi)) ^ XR4;
+}
+// every float bit pattern as x (four per thread and pass); patterns outside the form's domain (|x| >= 2^22, mode 2:
+// |x| >= 30000; NaN) are replaced by 0.5
+template <int MODE, uint32_t XR4>
+__global__ __launch_bounds__(256) void selftest_rounding_kernel(float lo, float hi, unsigned long long *bad) {
+    const unsigned long long stride = (unsigned long long)gridDim.x * 256;
+    const float lim = MODE == 2 ? 30000.0f : 4194304.0f;
+    unsigned cnt = 0;
+    for (unsigned long long b = (unsigned long long)blockIdx.x * 256 + threadIdx.x; b < (1ull << 30); b += stride) {
+        float x[4];
+        uint32_t want = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            x[k] = __uint_as_float((uint32_t)(b * 4 + k));
+            if (!(__builtin_fabsf(x[k]) < lim)) x[k] = 0.5f;
+            want |= tail_ref(x[k], lo, hi, XR4 & 0xffu) << (8 * k);
+        }
+        const uint32_t got = tail_new4<MODE, XR4>(x[0], x[1], x[2], x[3], lo, hi);
+        const uint32_t d = got ^ want;
+        cnt += (d & 0xffu ? 1 : 0) + (d & 0xff00u ? 1 : 0) + (d & 0xff0000u ? 1 : 0) + (d & 0xff000000u ? 1 : 0);
+    }
+    if (cnt) atomicAdd(bad, (unsigned long long)cnt);
+}
+// the whole epilogue (requant_pack4, as the kernels call it) against requant_t + pack4 for every accumulator in
+// (-2^22, 2^22) (mode 2: those with |x| < 30000) at one (A, S)
+template <int MODE, uint32_t XR4>
+__global__ __launch_bounds__(256) void selftest_requant_kernel(float A, float S, float lo, float hi, unsigned long long *bad) {
+    const long long stride = (long long)gridDim.x * 256;
+    unsigned cnt = 0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < (1ll << 21); i += stride) {
+        int acc[4];
+        uint32_t want = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            int a = (int)(i * 4 + k) - (1 << 22) + 1;
+            if (MODE == 2 && !(__builtin_fabsf(__fadd_rn(A, __fmul_rn(S, (float)a))) < 30000.0f)) a = 0;
+            acc[k] = a + MF_MAGIC_I;
+            want |= ((uint32_t)requant_t<1>(acc[k], A, S, lo, hi) & 0xffu) << (8 * k);
+        }
+        want ^= XR4;
+        const uint32_t got = requant_pack4<MODE, XR4>(acc[0], acc[1], acc[2], acc[3], make_float4(A, A, A, A), make_float4(S, S, S, S), lo, hi);
+        const uint32_t d = got ^ want;
+        cnt += (d & 0xffu ? 1 : 0) + (d & 0xff00u ? 1 : 0) + (d & 0xff0000u ? 1 : 0) + (d & 0xff000000u ? 1 : 0);
+    }
+    if (cnt) atomicAdd(bad, (unsigned long long)cnt);
+}
+template <typename Launch> static unsigned long long run_selftest(hipStream_t s, Launch launch) {
+    unsigned long long *d = nullptr, h = ~0ull;
+    if (hipMalloc((void **)&d, sizeof(h)) != hipSuccess) {
+        (void)hipGetLastError();
+        return h;
+    }
+    if (hipMemsetAsync(d, 0, sizeof(h), s) == hipSuccess) {
+        launch(d);
+        if (hipGetLastError() != hipSuccess || hipMemcpyAsync(&h, d, sizeof(h), hipMemcpyDeviceToHost, s) != hipSuccess ||
+            hipStreamSynchronize(s) != hipSuccess) {
+            (void)hipGetLastError();
+            h = ~0ull;
+        }
+    }
+    (void)hipFree(d);
+    return h;
+}
+unsigned long long selftest_rounding(int mode, bool u8, float lo, float hi, hipStream_t s) {
+    return run_selftest(s, [&](unsigned long long *d) {
+        const dim3 g(256 * 16), b(256);
+        if (mode == 2) {
+            if (u8) hipLaunchKernelGGL((selftest_rounding_kernel<2, 0x80808080u>), g, b, 0, s, lo, hi, d);
+            else hipLaunchKernelGGL((selftest_rounding_kernel<2, 0u>), g, b, 0, s, lo, hi, d);
+        } else if (mode == 3) {
+            hipLaunchKernelGGL((selftest_rounding_kernel<3, 0u>), g, b, 0, s, lo, hi, d);
+        } else {
+            if (u8) hipLaunchKernelGGL((selftest_rounding_kernel<1, 0x80808080u>), g, b, 0, s, lo, hi, d);
+            else hipLaunchKernelGGL((selftest_rounding_kernel<1, 0u>), g, b, 0, s, lo, hi, d);
+        }
+    });
+}
+unsigned long long selftest_requant(int mode, bool u8, float A, float S, float lo, float hi, hipStream_t s) {
+    return run_selftest(s, [&](unsigned long long *d) {
+        const dim3 g(256 * 8), b(256);
+        if (mode == 2) {
+            if (u8) hipLaunchKernelGGL((selftest_requant_kernel<2, 0x80808080u>), g, b, 0, s, A, S, lo, hi, d);
+            else hipLaunchKernelGGL((selftest_requant_kernel<2, 0u>), g, b, 0, s, A, S, lo, hi, d);
+        } else {
+            if (u8) hipLaunchKernelGGL((selftest_requant_kernel<1, 0x80808080u>), g, b, 0, s, A, S, lo, hi, d);
+            else hipLaunchKernelGGL((selftest_requant_kernel<1, 0u>), g, b, 0, s, A, S, lo, hi, d);
+        }
+    });
 }
 void launch_quantize(const float *in, int8_t *out, size_t n, float scale, float zp_f, bool u8, hipStream_t s) {
     hipLaunchKernelGGL(quantize_f32, dim3(grid_for((n + 3) / 4)), dim3(256), 0, s, in, out, n, scale, zp_f,

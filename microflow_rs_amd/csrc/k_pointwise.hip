@@ -35,7 +35,7 @@ namespace k {
 #endif
 // chunks each wave keeps in flight (loads of the next U issued before the first use)
 constexpr int pw_chunks_in_flight(int K) { return K >= 256 ? MF_PW_U_HI : (K >= 64 ? MF_PW_U_MID : MF_PW_U_LO); }
-template <int K, int N, bool MG, uint32_t XR4>
+template <int K, int N, int MG, uint32_t XR4>
 __global__ __launch_bounds__(256) void pw_mfma(const int8_t *__restrict__ in,
                                                int8_t *__restrict__ out, PwArgs p,
                                                long long npix) {
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256) void pw_mfma(const int8_t *__restrict__ in,
 }
 
 // ---- launchers ----
-template <int K, int N, bool MG, uint32_t XR4>
+template <int K, int N, int MG, uint32_t XR4>
 static void launch_pw_t(const int8_t *in, int8_t *out, const PwArgs &a, long long npix, int grid, hipStream_t s) {
     hipLaunchKernelGGL((pw_mfma<K, N, MG, XR4>), dim3(grid), dim3(256), 0, s, in, out, a, npix);
 }

@@ -64,7 +64,7 @@ struct Taps {
 };
 } // namespace
 
-template <int G, int NTHR, int NREP, uint32_t XR4>
+template <int G, int NTHR, int NREP, int MG, uint32_t XR4>
 __global__ __launch_bounds__(NTHR, 4) void stage_6x6x128(const int8_t *__restrict__ in, int8_t *__restrict__ out, StageArgs p,
                                                          int batch) {
     static_assert(G == 4 && NTHR == 512, "the column grid below is written for 4 images and 8 waves");
@@ -205,15 +205,15 @@ __global__ __launch_bounds__(NTHR, 4) void stage_6x6x128(const int8_t *__restric
                     v4i nxt = {wd.k.x, wd.k.y, wd.k.z, wd.k.w};
                     __builtin_amdgcn_sched_barrier(0);
                     if (more) nxt = __builtin_amdgcn_mfma_i32_16x16x64_i8(wd.A[0], t2.b[0], nxt, 0, 0, 0);
-                    const float r0 = requant_clamped<true>(acc[0], wd.a.x, wd.s.x, lo, hi);
-                    const float r1 = requant_clamped<true>(acc[1], wd.a.y, wd.s.y, lo, hi);
+                    const float r0 = epi_value<MG>(acc[0], wd.a.x, wd.s.x, lo, hi);
+                    const float r1 = epi_value<MG>(acc[1], wd.a.y, wd.s.y, lo, hi);
                     __builtin_amdgcn_sched_barrier(0);
                     if (more) nxt = __builtin_amdgcn_mfma_i32_16x16x64_i8(wd.A[1], t2.b[1], nxt, 0, 0, 0);
-                    const float r2 = requant_clamped<true>(acc[2], wd.a.z, wd.s.z, lo, hi);
-                    const float r3 = requant_clamped<true>(acc[3], wd.a.w, wd.s.w, lo, hi);
+                    const float r2 = epi_value<MG>(acc[2], wd.a.z, wd.s.z, lo, hi);
+                    const float r3 = epi_value<MG>(acc[3], wd.a.w, wd.s.w, lo, hi);
                     __builtin_amdgcn_sched_barrier(0);
                     if (more) nxt = __builtin_amdgcn_mfma_i32_16x16x64_i8(wd.A[2], t2.b[2], nxt, 0, 0, 0);
-                    *(uint32_t *)(lds + mb + moff(u)) = cvt_pack4(r0, r1, r2, r3) ^ XR4;
+                    *(uint32_t *)(lds + mb + moff(u)) = epi_pack4<MG, XR4>(r0, r1, r2, r3);
                     __builtin_amdgcn_sched_barrier(0);
                     acc = nxt, t2 = t3;
                 }
@@ -247,13 +247,13 @@ __global__ __launch_bounds__(NTHR, 4) void stage_6x6x128(const int8_t *__restric
                     v4i nxt = {wp.k.x, wp.k.y, wp.k.z, wp.k.w};
                     __builtin_amdgcn_sched_barrier(0);
                     if (more) nxt = __builtin_amdgcn_mfma_i32_16x16x64_i8(wp.A[0], c0, nxt, 0, 0, 0);
-                    const float r0 = requant_clamped<true>(acc[0], wp.a.x, wp.s.x, lo, hi);
-                    const float r1 = requant_clamped<true>(acc[1], wp.a.y, wp.s.y, lo, hi);
+                    const float r0 = epi_value<MG>(acc[0], wp.a.x, wp.s.x, lo, hi);
+                    const float r1 = epi_value<MG>(acc[1], wp.a.y, wp.s.y, lo, hi);
                     __builtin_amdgcn_sched_barrier(0);
                     if (more) nxt = __builtin_amdgcn_mfma_i32_16x16x64_i8(wp.A[1], c1, nxt, 0, 0, 0);
-                    const float r2 = requant_clamped<true>(acc[2], wp.a.z, wp.s.z, lo, hi);
-                    const float r3 = requant_clamped<true>(acc[3], wp.a.w, wp.s.w, lo, hi);
-                    const uint32_t d = cvt_pack4(r0, r1, r2, r3) ^ XR4;
+                    const float r2 = epi_value<MG>(acc[2], wp.a.z, wp.s.z, lo, hi);
+                    const float r3 = epi_value<MG>(acc[3], wp.a.w, wp.s.w, lo, hi);
+                    const uint32_t d = epi_pack4<MG, XR4>(r0, r1, r2, r3);
                     if (last) *(uint32_t *)(lds + oplain + c * 2048) = d;
                     else *(uint32_t *)(lds + o6[c]) = d;
                     __builtin_amdgcn_sched_barrier(0);
@@ -291,19 +291,22 @@ bool launch_stage(int H, int W, int C, int npairs, const int8_t *in, int8_t *out
     if (!stage_name(H, W, C, npairs)) return false;
     constexpr int G = 4, NTHR = 512, NREP = 5;
     constexpr int lds = MF_STAGE_LDS_KB * 1024;
-    static LaunchState st;
     const int nsteps = (batch + G - 1) / G;
-    int per_cu, grid;
+    int per_cu = 0, grid = 0;
+    // epilogue mode (k_common.hpp): 2 when every clamp of the run is the element type's whole range, else 1
+#define MF_STAGE_GO(MG, XR)                                                                                        \
+    do {                                                                                                           \
+        static LaunchState st_;                                                                                    \
+        per_cu = prepared(st_, stage_6x6x128<G, NTHR, NREP, MG, XR>, NTHR, lds);                                   \
+        grid = nsteps < 256 * per_cu ? nsteps : 256 * per_cu;                                                      \
+        hipLaunchKernelGGL((stage_6x6x128<G, NTHR, NREP, MG, XR>), dim3(grid), dim3(NTHR), lds, s, in, out, a, batch); \
+    } while (0)
     if (a.xr4) { // u8 element type: the stored byte is the value ^ 0x80 (XR4, see kernels.hpp)
-        static LaunchState stu;
-        per_cu = prepared(stu, stage_6x6x128<G, NTHR, NREP, 0x80808080u>, NTHR, lds);
-        grid = nsteps < 256 * per_cu ? nsteps : 256 * per_cu;
-        hipLaunchKernelGGL((stage_6x6x128<G, NTHR, NREP, 0x80808080u>), dim3(grid), dim3(NTHR), lds, s, in, out, a, batch);
+        if (a.mode == 2) MF_STAGE_GO(2, 0x80808080u); else MF_STAGE_GO(1, 0x80808080u);
     } else {
-        per_cu = prepared(st, stage_6x6x128<G, NTHR, NREP, 0u>, NTHR, lds);
-        grid = nsteps < 256 * per_cu ? nsteps : 256 * per_cu;
-        hipLaunchKernelGGL((stage_6x6x128<G, NTHR, NREP, 0u>), dim3(grid), dim3(NTHR), lds, s, in, out, a, batch);
+        if (a.mode == 2) MF_STAGE_GO(2, 0u); else MF_STAGE_GO(1, 0u);
     }
+#undef MF_STAGE_GO
 #if MF_STAGE_DIAG == 2
     {
         static int calls = 0;

@@ -76,7 +76,8 @@ struct DwFastArgs {
     const int *Kc;
     uint32_t izp4;      // izp replicated in 4 bytes
     float lo_f, hi_f;
-    int magic;          // 1: worst-case |acc| < 2^22 -> bit-pattern int->float conversion (k_common.hpp)
+    int magic;          // epilogue mode (k_common.hpp requant_t): 1: worst-case |acc| < 2^22 -> bit-pattern int->float
+                        // conversion; 2: also clamp == the element type's range and |x| < 2^15 -> saturating pack
     int xr;             // 0 (i8) or 0x80 (u8): see ConvArgs
 };
 // depthwise with ONE input channel and up to 8 output channels, any filter / stride (speech op 1)
@@ -213,6 +214,7 @@ struct StageArgs {
     const StagePair *pairs;  // [number of pairs], in device memory
     uint32_t izp4;           // zero point of every depthwise input of the run (they must agree: one halo fill)
     uint32_t xr4;            // 0 (i8) or 0x80808080 (u8): XOR of every stored dword
+    int mode;                // epilogue mode of the whole run (k_common.hpp): 1, or 2 when every clamp is the type's range
 };
 
 // shapes with a compiled fast depthwise kernel: H, W, C, stride, images per step, threads per
@@ -331,6 +333,10 @@ void launch_softmax(const int8_t *in, int8_t *out, const SoftmaxArgs &a, size_t 
 // number of float bit patterns (of all 2^32) whose quantised byte differs between quant_div's fast form and the true
 // division, for these parameters; synchronises the stream
 unsigned long long verify_quant_div(float scale, float rcp, float zp_f, float sat_lo, float sat_hi, hipStream_t s);
+// self-tests of the epilogue forms (k_common.hpp): number of bytes that differ from round 2's form (a) over every float bit
+// pattern taken as the pre-rounding value x, (b) over every accumulator in (-2^22, 2^22) at one (A, S); ~0 = could not run
+unsigned long long selftest_rounding(int mode, bool u8, float lo, float hi, hipStream_t s);
+unsigned long long selftest_requant(int mode, bool u8, float A, float S, float lo, float hi, hipStream_t s);
 void launch_quantize(const float *in, int8_t *out, size_t n, float scale, float zp_f, bool u8, hipStream_t s);
 void launch_xor80(const int8_t *in, int8_t *out, size_t n, hipStream_t s);
 void launch_dequantize(const int8_t *in, float *out, size_t n, float scale, float zp_f, bool raw_u8, hipStream_t s);

@@ -141,6 +141,7 @@ void dev_synth_i8(int device, uint64_t seed, uint64_t first, size_t n, int8_t *d
 uint64_t dev_checksum_i8(int device, const int8_t *d_in, size_t n, void *stream);
 // exhaustive check of the 3-instruction boundary-quantisation division (k_common.hpp: quant_div): mismatching bytes
 uint64_t dev_verify_quant_div(int device, float scale, float rcp, int zp, bool u8);
+uint64_t dev_selftest_epilogue(int device, int mode, bool u8, bool have_as, float A, float S, int lo, int hi);
 int dev_count();
 void dev_require(int device); // throws MF_ERR_NO_DEVICE
 

@@ -296,7 +296,16 @@ OpImpl *op_create(int device, const OpSpec &spec) {
         // stays below 2^22 in magnitude (requant_t<true> in k_common.hpp)
         static const bool no_magic = getenv("MF_NO_MAGIC") != nullptr; // tests: force the convert form
         const int64_t acc_bound = fold_conv_constants(*op, s, dw, A, S, Kc, wzp);
-        const int magic = !no_magic && acc_bound < (1 << 22) ? 1 : 0;
+        int magic = !no_magic && acc_bound < (1 << 22) ? 1 : 0;
+        // mode 2 (k_common.hpp): the clamp is the element type's whole range (so a saturating pack can do it) and
+        // |x| = |A + S * acc| stays below 2^15 for every input (so x + 128 fits the i16 the pack saturates from)
+        static const bool no_sat = getenv("MF_NO_SAT_PACK") != nullptr; // tests: force the v_med3 form
+        if (magic && !no_sat && lo == (s.u8 ? 0 : -128) && hi == (s.u8 ? 255 : 127) && all_finite(A) && all_finite(S)) {
+            double xmax = 0.0;
+            for (int c = 0; c < s.N; ++c)
+                xmax = std::max(xmax, std::fabs((double)A[(size_t)c]) + std::fabs((double)S[(size_t)c]) * (double)acc_bound);
+            if (xmax < 30000.0) magic = 2;
+        }
         const size_t wbytes = dw ? (size_t)s.KH * s.KW * s.N : (size_t)s.N * s.KH * s.KW * s.C;
         op->d_w.upload(s.weights, wbytes);
         op->d_wzp.upload(wzp.data(), wzp.size() * 4);
@@ -401,7 +410,7 @@ OpImpl *op_create(int device, const OpSpec &spec) {
             fprintf(stderr, "[microflow_amd] %s %dx%dx%d -> %d: kernel %s, worst-case |acc| %lld%s\n",
                     dw ? "depthwise_conv_2d" : "conv_2d", s.H, s.W, s.C, s.N,
                     op->fast != OpImpl::NONE ? op->fast_name.c_str() : op->generic_name.c_str(),
-                    (long long)acc_bound, op->fast != OpImpl::NONE && magic ? " (bit-pattern int->f32)" : "");
+                    (long long)acc_bound, op->fast == OpImpl::NONE || !magic ? "" : magic == 2 ? " (bit-pattern int->f32, saturating pack)" : " (bit-pattern int->f32)");
         break;
     }
     case MF_OP_AVERAGE_POOL_2D: {
@@ -621,7 +630,9 @@ static bool quant_div_verified(int device, float scale, float rcp, float zp_f, f
     auto it = cache.find(key);
     if (it != cache.end()) return it->second;
     MF_HIP(hipSetDevice(device));
-    const bool ok = k::verify_quant_div(scale, rcp, zp_f, sat_lo, sat_hi, nullptr) == 0;
+    const unsigned long long bad = k::verify_quant_div(scale, rcp, zp_f, sat_lo, sat_hi, nullptr);
+    if (bad == ~0ull) return false; // the check itself could not run: keep the true division now, try again next time
+    const bool ok = bad == 0;
     if (getenv("MF_VERBOSE")) fprintf(stderr, "[microflow_amd] boundary quantisation: 3-instruction division %s for scale %g\n", ok ? "verified" : "REJECTED", (double)scale);
     cache[key] = ok;
     return ok;
@@ -787,6 +798,9 @@ FusedImpl *fused_stage_create(FusedImpl *const *pairs, int npairs) {
     s->stage.pairs = (const k::StagePair *)s->stage_w.back()->p;
     s->stage.izp4 = pairs[0]->dwpw.dw.izp4;
     s->stage.xr4 = d0.u8 ? 0x80808080u : 0u;
+    s->stage.mode = 2; // the saturating-pack epilogue needs it of every operator of the run
+    for (int i = 0; i < npairs; ++i)
+        if (pairs[i]->dwpw.dw.magic != 2 || pairs[i]->dwpw.pw.magic != 2) s->stage.mode = 1;
     return s.release();
 }
 
@@ -962,6 +976,22 @@ void dev_synth_i8(int device, uint64_t seed, uint64_t first, size_t n, int8_t *d
     if (!n) return;
     k::launch_synth(d_out, n, seed, first, (hipStream_t)stream);
     MF_HIP(hipGetLastError());
+}
+uint64_t dev_selftest_epilogue(int device, int mode, bool u8, bool have_as, float A, float S, int lo, int hi) {
+    dev_require(device);
+    if (mode == 3 && !have_as && !u8) { // negative control of the rounding check: plain round-to-nearest-even (must mismatch)
+        const unsigned long long r3 = k::selftest_rounding(3, false, (float)lo, (float)hi, nullptr);
+        if (r3 == ~0ull) fail(MF_ERR_HIP, "selftest kernel could not run");
+        return r3;
+    }
+    if ((mode != 1 && mode != 2) || lo > hi || lo < (u8 ? 0 : -128) || hi > (u8 ? 255 : 127))
+        fail(MF_ERR_INVALID_ARG, "selftest: mode 1 or 2 and a clamp inside the element type's range");
+    if (mode == 2 && (lo != (u8 ? 0 : -128) || hi != (u8 ? 255 : 127)))
+        fail(MF_ERR_INVALID_ARG, "selftest: the saturating pack (mode 2) is only ever used with the whole range as clamp");
+    const unsigned long long r = have_as ? k::selftest_requant(mode, u8, A, S, (float)lo, (float)hi, nullptr)
+                                         : k::selftest_rounding(mode, u8, (float)lo, (float)hi, nullptr);
+    if (r == ~0ull) fail(MF_ERR_HIP, "selftest kernel could not run");
+    return r;
 }
 uint64_t dev_verify_quant_div(int device, float scale, float rcp, int zp, bool u8) {
     dev_require(device);

@@ -1,19 +1,20 @@
 // Microbenchmark: cost of the requantisation epilogue (per packed dword = 4 output bytes) on gfx950, for the
 // packing variants tried in k_common.hpp.  No memory traffic in the loop: this is the VALU floor of every
 // fast kernel.  Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off epi_rate.hip -o epi_rate
+// Also built as scripts/ubench/libepi_rate.so (microflow_rs_amd/build.py): bench.py calls mf_ubench_requant_ns() outside its
+// timed region and prices the VALU-bound kernels against the rate measured in the same run.
+// Variants 4 / 5 are the library's own requant_pack4<1> / <2> (k_common.hpp), i.e. exactly what the kernels execute.
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
 #include <vector>
 
+#include "../../microflow_rs_amd/csrc/k_common.hpp"
+
 #define ITERS 4096
 #define NG 8 // independent dword groups per iteration
 
-__device__ __forceinline__ uint32_t pack4(int a, int b, int c, int d) {
-    const uint32_t lo = __builtin_amdgcn_perm((uint32_t)b, (uint32_t)a, 0x0c0c0400u);
-    const uint32_t hi = __builtin_amdgcn_perm((uint32_t)d, (uint32_t)c, 0x0c0c0400u);
-    return __builtin_amdgcn_perm(hi, lo, 0x05040100u);
-}
+using mf::k::pack4;
 __device__ __forceinline__ float rq(int acc, float A, float S, float lo, float hi) {
     const float f = __fsub_rn(__int_as_float(acc), 12582912.0f);
     const float x = __fadd_rn(A, __fmul_rn(S, f));
@@ -56,6 +57,25 @@ __global__ __launch_bounds__(256) void bench(uint32_t *out, int seed, float A, f
                     "v_cvt_pk_u8_f32 %0, %4, 3, %0"
                     : "=&v"(d) : "v"(r0), "v"(r1), "v"(r2), "v"(r3));
             }
+            else if (V == 4) { // sticky-bit RNE + v_med3 (epilogue mode 1)
+                d = mf::k::requant_pack4<1, 0u>(acc[g][0], acc[g][1], acc[g][2], acc[g][3], make_float4(A, A, A, A), make_float4(S, S, S, S), lo, hi);
+            } else if (V == 5) { // sticky-bit RNE + saturating pack (epilogue mode 2)
+                d = mf::k::requant_pack4<2, 0u>(acc[g][0], acc[g][1], acc[g][2], acc[g][3], make_float4(A, A, A, A), make_float4(S, S, S, S), lo, hi);
+            } else if (V == 6) { // two dwords at a time, mode 1
+                if (g & 1) {
+                    uint32_t da, db;
+                    const mf::k::v4i a0 = {acc[g - 1][0], acc[g - 1][1], acc[g - 1][2], acc[g - 1][3]}, a1 = {acc[g][0], acc[g][1], acc[g][2], acc[g][3]};
+                    mf::k::requant_pack4x2<1, 0u>(a0, make_float4(A, A, A, A), make_float4(S, S, S, S), a1, make_float4(A, A, A, A), make_float4(S, S, S, S), lo, hi, da, db);
+                    d = da + db;
+                }
+            } else if (V == 7) { // two dwords at a time, mode 2
+                if (g & 1) {
+                    uint32_t da, db;
+                    const mf::k::v4i a0 = {acc[g - 1][0], acc[g - 1][1], acc[g - 1][2], acc[g - 1][3]}, a1 = {acc[g][0], acc[g][1], acc[g][2], acc[g][3]};
+                    mf::k::requant_pack4x2<2, 0u>(a0, make_float4(A, A, A, A), make_float4(S, S, S, S), a1, make_float4(A, A, A, A), make_float4(S, S, S, S), lo, hi, da, db);
+                    d = da + db;
+                }
+            }
             sum += d;
 #pragma unroll
             for (int k = 0; k < 4; ++k) acc[g][k] += 1; // one full-rate op per value keeps the loop body live
@@ -64,6 +84,7 @@ __global__ __launch_bounds__(256) void bench(uint32_t *out, int seed, float A, f
     out[blockIdx.x * 256 + threadIdx.x] = sum;
 }
 
+static bool g_quiet = false;
 template <int V> static double run(uint32_t *d, const char *name, double base_extra) {
     const int grid = 256 * 8; // 8 blocks of 4 waves per CU = 8 waves per SIMD
     hipEvent_t e0, e1;
@@ -77,18 +98,44 @@ template <int V> static double run(uint32_t *d, const char *name, double base_ex
     hipEventElapsedTime(&ms, e0, e1);
     const double groups = 5.0 * grid * 4 /*waves*/ * ITERS * NG;       // wave-level dword groups
     const double ns_per_group_simd = ms * 1e6 / (groups / 1024.0);      // per SIMD
-    std::printf("%-34s %8.3f ms  %6.2f ns per dword-group per SIMD (%.1f per byte)  [loop overhead included]\n", name, ms,
+    if (!g_quiet) std::printf("%-34s %8.3f ms  %6.2f ns per dword-group per SIMD (%.1f per byte)  [loop overhead included]\n", name, ms,
                 ns_per_group_simd, ns_per_group_simd / 4);
     (void)base_extra;
     return ns_per_group_simd;
 }
 
+// ns per packed dword (4 output bytes) per SIMD of variant v (4: epilogue mode 1, 5: mode 2, 1: round 2's form), loop
+// overhead included (one v_add per value); < 0 on failure.  The chip-wide rate is 1024 SIMDs * 4 bytes / that.
+extern "C" double mf_ubench_requant_ns(int variant) {
+    uint32_t *d = nullptr;
+    if (hipMalloc(&d, 256 * 8 * 256 * 4) != hipSuccess) return -1.0;
+    g_quiet = true;
+    double ns = -1.0;
+    switch (variant) {
+    case 1: ns = run<1>(d, "", 0); break;
+    case 4: ns = run<4>(d, "", 0); break;
+    case 5: ns = run<5>(d, "", 0); break;
+    case 6: ns = run<6>(d, "", 0); break;
+    case 7: ns = run<7>(d, "", 0); break;
+    default: break;
+    }
+    g_quiet = false;
+    if (hipDeviceSynchronize() != hipSuccess) ns = -1.0;
+    (void)hipFree(d);
+    return ns;
+}
+#ifndef MF_UBENCH_LIB
 int main() {
     uint32_t *d;
     hipMalloc(&d, 256 * 8 * 256 * 4);
     run<2>(d, "requant only (no cvt/pack)", 0);
     run<0>(d, "requant + cvt + 3 v_perm (r01)", 0);
-    run<1>(d, "requant + SDWA cvt (s_nop)", 0);
+    run<1>(d, "requant + SDWA cvt (r02)", 0);
     run<3>(d, "requant + v_cvt_pk_u8_f32", 0);
+    run<4>(d, "mode 1: med3 + sticky RNE pack", 0);
+    run<5>(d, "mode 2: sticky RNE + sat pack", 0);
+    run<6>(d, "mode 1, two dwords per block", 0);
+    run<7>(d, "mode 2, two dwords per block", 0);
     return 0;
 }
+#endif

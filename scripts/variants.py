@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Kernel-tuning helper.  HERE (no GPU): build variant libraries of ONE source file with extra -D flags,
     python scripts/variants.py build k_dwfc.hip a="-DMF_DWFC_UB=2" b="-DMF_DWFC_THREADS=1024 -DMF_DWFC_UB=2" ...
+(source "ALL" = every .hip file, for a switch that lives in a shared header: build ALL r02epi="-DMF_EPI=0")
 -> microflow_rs_amd/variants/lib_<tag>.so (git-ignored, travels with gpurun).  On the GPU box:
     python scripts/variants.py run "<command>"
 runs <command> once per variant with that library swapped in for libmicroflow_amd.so, then restores the original."""
@@ -25,19 +26,27 @@ def build(src, variants):
         os.remove(f)
     objdir = os.path.join(PKG, "build")
     procs = []
+    srcs = [f for f in B.SOURCES if f.endswith(".hip")] if src == "ALL" else [src]  # ALL: a flag that lives in a shared header
     for tag, flags in variants:
-        obj = os.path.join(VDIR, "%s.%s.o" % (src, tag))
-        cmd = [B.hipcc()] + B.FLAGS + flags.split() + ["-x", "hip", "-c", os.path.join(B.CSRC, src), "-o", obj]
-        procs.append((tag, flags, obj, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
-    for tag, flags, obj, p in procs:
+        for one in srcs:
+            obj = os.path.join(VDIR, "%s.%s.o" % (one, tag))
+            cmd = [B.hipcc()] + B.FLAGS + flags.split() + ["-x", "hip", "-c", os.path.join(B.CSRC, one), "-o", obj]
+            procs.append((tag, flags, one, obj, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    failed = set()
+    for tag, flags, one, obj, p in procs:
         out, _ = p.communicate()
         if p.returncode != 0:
             sys.stderr.write(out.decode(errors="replace"))
-            print("variant %s failed" % tag)
+            print("variant %s failed (%s)" % (tag, one))
+            failed.add(tag)
+    for tag, flags in variants:
+        if tag in failed:
             continue
-        objs = [obj if s == src else os.path.join(objdir, s + ".o") for s in B.SOURCES]
+        mine = {one: obj for t, _, one, obj, _ in procs if t == tag}
+        objs = [mine.get(s, os.path.join(objdir, s + ".o")) for s in B.SOURCES]
         subprocess.check_call([B.hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", os.path.join(VDIR, "lib_%s.so" % tag)] + objs)
-        os.remove(obj)
+        for obj in mine.values():
+            os.remove(obj)
         print("built", tag, flags)
 
 

@@ -538,3 +538,75 @@ def test_non_finite_constants_follow_rust_casts(mf, O):
         assert op.kernel == "fc_generic"
         want = O.fully_connected(xf, wf, 0, 0.05, 3, 0, fc0, fc1, np.zeros(128, np.int32), 0)
         assert np.array_equal(op(xf), want)
+
+
+# ---- the epilogue forms of the fast kernels (k_common.hpp) -----------------------------
+def test_epilogue_rounding_identity_exhaustive(mf):
+    """roundf(x) (libm, half away from zero) == round-to-nearest-even of x with its lowest mantissa bit set, followed
+    by the clamp / `as T`: checked on the device over EVERY float bit pattern in the form's domain, for the v_med3 form
+    (mode 1, several clamps, both element types) and the saturating-pack form (mode 2, whole range).  Mode 3 is the
+    negative control -- the same without the mantissa bit -- and must report the ties it gets wrong."""
+    import ctypes as C
+    from microflow_rs_amd import _lib
+    L = _lib.lib()
+    bad = C.c_uint64(77)
+    for mode, u8, lo, hi in ((1, 0, -128, 127), (1, 0, -128, 100), (1, 0, -7, 127), (1, 0, 3, 3), (1, 1, 0, 255),
+                             (1, 1, 128, 200), (2, 0, -128, 127), (2, 1, 0, 255)):
+        _lib.check(L.mf_selftest_rounding(0, mode, u8, lo, hi, C.byref(bad)))
+        assert bad.value == 0, (mode, u8, lo, hi, bad.value)
+    _lib.check(L.mf_selftest_rounding(0, 3, 0, -128, 127, C.byref(bad)))
+    assert bad.value >= 255, bad.value     # every tie k + 0.5 with k even and positive (or odd and negative), at least
+    assert L.mf_selftest_rounding(0, 2, 0, -128, 100, C.byref(bad)) == _lib.MF_ERR_INVALID_ARG  # mode 2: whole range only
+
+
+def test_epilogue_requant_every_accumulator(mf, O):
+    """The whole epilogue as the kernels call it (requant_pack4, modes 1 and 2) against the plain form for every
+    accumulator in (-2^22, 2^22), at the (A, S) of person_detect's channels with the most rounding ties, at extreme
+    scales, and at constants that put x exactly on ties."""
+    import ctypes as C
+    from microflow_rs_amd import _lib
+    L = _lib.lib()
+    bad = C.c_uint64(77)
+    cases = [(-127.5, 0.5), (-128.0, 0.25), (0.5, 1.0), (-3.25, 0.001953125), (-127.31, 0.0021), (12.7, 3.1e-5),
+             (-100.0, 0.31964308), (-128.0, 0.00053977553), (5.0, 0.007), (-64.03125, 0.015625)]
+    from tests.conftest import model_path
+    om = O.Model(model_path("person_detect"))
+    for i in (1, 2, 12, 24, 26):
+        c0, c1 = om.op_constants(i)[:2]
+        ozp = om.ops[i]["out_zp"]
+        for c in (0, len(c0) // 2, len(c0) - 1):
+            cases.append((float(f32(f32(ozp) + f32(c0[c]))), float(c1[c if c < len(c1) else 0])))
+    for A, S in cases:
+        for mode, u8, lo, hi in ((1, 0, -128, 127), (1, 0, -128, 90), (2, 0, -128, 127), (1, 1, 0, 255), (2, 1, 0, 255)):
+            a = A + (128.0 if u8 else 0.0)
+            _lib.check(L.mf_selftest_requant(0, mode, u8, C.c_float(a), C.c_float(S), lo, hi, C.byref(bad)))
+            assert bad.value == 0, (A, S, mode, u8, lo, hi, bad.value)
+
+
+_NO_SAT_SCRIPT = r"""
+import sys, numpy as np
+sys.path.insert(0, {root!r})
+import microflow_rs_amd as mf
+from oracle import oracle as O
+from tests.synth import synth_i8
+for name, cfg, n in (("person_detect", 3, 5), ("speech", 2, 9)):
+    path = {root!r} + "/models/" + name + ".tflite"
+    m, om = mf.model(path), O.Model(path)
+    x = synth_i8(cfg, 0, n, m.input_elems)
+    assert np.array_equal(m.run_quantized(x).reshape(n, -1), om.run_quantized_batch(x)), name
+    m.set_fusion(False)
+    assert np.array_equal(m.run_quantized(x).reshape(n, -1), om.run_quantized_batch(x)), name
+print("no-sat ok")
+"""
+
+
+def test_models_without_saturating_pack():
+    """MF_NO_SAT_PACK=1 keeps every fast kernel on the v_med3 form of the epilogue (mode 1; the form used whenever an
+    operator's clamp is narrower than its element type, e.g. relu6 with a small output scale): same results."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MF_NO_SAT_PACK="1")
+    r = subprocess.run([sys.executable, "-c", _NO_SAT_SCRIPT.format(root=root)], env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0 and "no-sat ok" in r.stdout, r.stdout + r.stderr
