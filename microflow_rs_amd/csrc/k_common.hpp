@@ -22,6 +22,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 
 #include <atomic>
@@ -363,6 +364,106 @@ typedef __attribute__((address_space(1))) const void gbl_void_t;
 
 __device__ __forceinline__ void dma16(const int8_t *src_lane, uint8_t *lds_wave_base) {
     __builtin_amdgcn_global_load_lds((gbl_void_t *)src_lane, (lds_void_t *)lds_wave_base, 16, 0, 0);
+}
+
+// ------------------------------------------------------------------------
+// Dynamic step queue of the persistent kernels.
+//
+// A persistent kernel launches exactly the resident workgroups and walks "steps" (G images each).  With the steps
+// dealt statically (step += gridDim.x) the workgroups of one CU do NOT finish together: the CU's VALU issue is
+// arbitrated by wave age, so the workgroup that was dispatched first runs ahead and the younger one finishes up to
+// 1.4x later -- alone on its CU, at less than half the CU's throughput (measured on the stage kernel, round 3: half of
+// the 512 workgroups ended at 560-590 us, the other half at 780-820 us).  Here only the first two steps of a workgroup
+// are static; every further step index is drawn from a device counter, two iterations ahead so that the next step's
+// staging DMA can still be issued a whole step early.  The last workgroup to leave resets the counters, so a launch
+// needs no memset.  `ctr` = DynSteps::INTS ints in device memory, zero before the first launch.
+// ------------------------------------------------------------------------
+#ifndef MF_DYNQ
+#define MF_DYNQ 1 // 0: static striding (A/B switch)
+#endif
+struct DynSteps {
+    static constexpr int HEADS = 8, PITCH = 32, INTS = HEADS * PITCH + PITCH; // 8 counters on their own 128-byte lines + [done]
+    int *slot; // LDS: two ints
+    int *ctr;  // device: ctr[h * PITCH] = draws from head h; ctr[HEADS * PITCH] = workgroups finished
+    int step, nxt, nn, it, fetched;
+    int K, nheads, head;                  // steps per draw; counters in use (1 or 8) and this workgroup's
+    int pool_next, pool_left, sel, write_at;
+    // cfg = K | nheads << 8 (dq_config below).  A draw is a chunk of K consecutive steps and has K iterations to return.
+    // One device-wide counter sustains ~90 draws per microsecond (MI355X_MICROARCH.md) while the kernels with one-image
+    // steps run 200 steps per microsecond, and a returning device-scope atomic takes 1-3 us under load -- as long as one
+    // of their steps; hence K > 1 and/or 8 counters for those (workgroup b draws from head b % 8: workgroups are dealt
+    // round-robin over the 8 XCDs, so a head is mostly one XCD's line; head h's d-th draw starts at step
+    // 2 grid + K (8 d + h)).  Kernels with long steps use one counter and K = 1, which balances best.
+    // Call before the kernel's first __syncthreads().
+    __device__ __forceinline__ void init(uint8_t *lds_slot, int *counters, int tid, int cfg) {
+        slot = (int *)lds_slot, ctr = counters, step = blockIdx.x, nxt = blockIdx.x + gridDim.x, nn = 0, it = 0, fetched = 0;
+        K = cfg & 0xff, nheads = cfg >> 8, head = nheads > 1 ? blockIdx.x % nheads : 0; // K == 0: static striding
+        pool_next = 0, pool_left = 0, sel = 0, write_at = -1;
+        if (MF_DYNQ && K != 0 && tid == 0) slot[0] = draw();
+    }
+    __device__ __forceinline__ int draw() { return 2 * (int)gridDim.x + K * (nheads * atomicAdd(ctr + head * PITCH, 1) + head); }
+    // right after the barrier at the top of an iteration
+    __device__ __forceinline__ void top(int tid) {
+        if (MF_DYNQ && K != 0) {
+            if (pool_left == 0) { // start the chunk drawn earlier, draw the one after it (due K iterations from now)
+                nn = __builtin_amdgcn_readfirstlane(slot[sel]);
+                pool_next = nn + 1, pool_left = K - 1, sel ^= 1, write_at = it + K - 1;
+                if (tid == 0) fetched = draw();
+            } else {
+                nn = pool_next++, --pool_left;
+            }
+        }
+    }
+    // end of an iteration (before the next iteration's barrier)
+    __device__ __forceinline__ void advance(int tid) {
+        if (MF_DYNQ && K != 0) {
+            if (it == write_at && tid == 0) slot[sel] = fetched;
+            step = nxt, nxt = nn, ++it;
+        } else {
+            step = nxt, nxt += gridDim.x;
+        }
+    }
+    __device__ __forceinline__ void finish(int tid) {
+        if (MF_DYNQ && K != 0 && tid == 0 && atomicAdd(ctr + HEADS * PITCH, 1) == (int)gridDim.x - 1) {
+#pragma unroll
+            for (int h = 0; h <= HEADS; ++h) ctr[h * PITCH] = 0;
+        }
+    }
+};
+// Queue configuration of a launch: `est_us` = the launch's expected duration (its bytes over the rates the kernels reach).
+unsigned long dq_next_launch(); // (k_generic.hip) one process-wide counter of queue launches, for MF_DQ_CFGS
+static inline int dq_config(int nsteps, int grid, double est_us) {
+    // tuning: MF_DQ_CFG = K | heads << 8 for every launch (0x100 = static striding).  With MF_DQ_TUNE set it is re-read per
+    // launch, and MF_DQ_CFGS = "c0,c1,..." gives the k-th queue launch of the process configuration c[k % n] (0 = automatic)
+    static const bool tune = getenv("MF_DQ_TUNE") != nullptr;
+    static const int forced0 = [] { const char *e = getenv("MF_DQ_CFG"); return e ? (int)strtol(e, nullptr, 0) : 0; }();
+    int forced = forced0;
+    if (tune) {
+        const unsigned long launches = dq_next_launch();
+        const char *e = getenv("MF_DQ_CFG"), *l = getenv("MF_DQ_CFGS");
+        forced = e ? (int)strtol(e, nullptr, 0) : 0;
+        if (l && *l) {
+            int n = 1;
+            for (const char *q = l; *q; ++q) n += *q == ',';
+            int k = (int)(launches % (unsigned long)n);
+            const char *q = l;
+            while (k > 0 && *q) k -= *q++ == ',';
+            forced = (int)strtol(q, nullptr, 0);
+        }
+    }
+    if (forced) return forced;
+    const double t_step = est_us * grid / (nsteps > 0 ? nsteps : 1);   // one workgroup's step, us
+    const int K = t_step >= 8.0 ? 1 : (t_step >= 4.0 ? 2 : 4);
+    const double draws_per_us = nsteps / (K * (est_us > 1.0 ? est_us : 1.0));
+    const int cfg = K | (draws_per_us > 60.0 ? 8 : 1) << 8;
+    static const bool verbose = getenv("MF_DQ_VERBOSE") != nullptr;
+    if (verbose) fprintf(stderr, "[microflow_amd] step queue: %d steps on %d workgroups, est %.0f us -> cfg 0x%x\n", nsteps, grid, est_us, cfg);
+    return cfg;
+}
+// expected duration of a depthwise / pair launch from its HBM bytes and requantised bytes (4.5 and 4.0 TB/s: what the kernels reach)
+static inline double dq_est_us(double hbm_bytes, double requant_bytes) {
+    const double a = hbm_bytes / 4.5e6, b = requant_bytes / 4.0e6;
+    return a > b ? a : b;
 }
 
 // ---- helpers of the matrix-pipe depthwise kernels (k_fused_mm.hip, k_stage.hip) ----

@@ -81,6 +81,8 @@ __global__ __launch_bounds__(NTHR) void dw3x3_nhwc(const int8_t *__restrict__ in
     }
     const float4 A = ((const float4 *)p.A)[cg], Sc = ((const float4 *)p.S)[cg];
     const int4 Kc = magic4<MG>(((const int4 *)p.Kc)[cg]);
+    DynSteps dq;
+    dq.init(lds + 2 * BUF + 256, p.queue, tid, p.qcfg); // (the launcher allocates 16 bytes behind the read slack)
     __syncthreads(); // halo fill complete before any DMA lands
 
     auto stage = [&](int st, int buf) {
@@ -95,13 +97,15 @@ __global__ __launch_bounds__(NTHR) void dw3x3_nhwc(const int8_t *__restrict__ in
     };
 
     const int nsteps = (batch + G - 1) / G;
-    int step = blockIdx.x, cur = 0;
-    if (step < nsteps) stage(step, 0);
+    int cur = 0;
+    if (dq.step < nsteps) stage(dq.step, 0);
 
-    for (; step < nsteps; step += gridDim.x, cur ^= 1) {
+    for (; dq.step < nsteps; dq.advance(tid), cur ^= 1) {
+        const int step = dq.step;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's DMAs (and old stores) done
         __syncthreads();                                  // ... and everyone else's
-        const int next = step + gridDim.x;
+        dq.top(tid);
+        const int next = dq.nxt;
         if (next < nsteps) stage(next, cur ^ 1);          // flies during the compute below
 
         const uint8_t *tile = lds + cur * BUF;
@@ -135,6 +139,7 @@ __global__ __launch_bounds__(NTHR) void dw3x3_nhwc(const int8_t *__restrict__ in
             }
         }
     }
+    dq.finish(tid);
 }
 
 // ------------------------------------------------------------------------
@@ -179,6 +184,8 @@ __global__ __launch_bounds__(256) void dw3x3_stem8(const int8_t *__restrict__ in
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     for (int i = tid; i < 2 * BUF / 16; i += 256)
         ((uint4 *)lds)[i] = make_uint4(p.izp4, p.izp4, p.izp4, p.izp4);
+    DynSteps dq;
+    dq.init(lds + 2 * BUF, p.queue, tid, p.qcfg); // (16 bytes behind the two staging buffers)
     __syncthreads();
 
     auto stage = [&](int st, int buf) {
@@ -222,20 +229,22 @@ __global__ __launch_bounds__(256) void dw3x3_stem8(const int8_t *__restrict__ in
     };
 
     const int nsteps = (batch + G - 1) / G;
-    int step = blockIdx.x, cur = 0;
+    int cur = 0;
     if constexpr (F32IN) {
-        if (step < nsteps) {
-            load_f32(step);
+        if (dq.step < nsteps) {
+            load_f32(dq.step);
             store_f32(0);
         }
     } else {
-        if (step < nsteps) stage(step, 0);
+        if (dq.step < nsteps) stage(dq.step, 0);
     }
 
-    for (; step < nsteps; step += gridDim.x, cur ^= 1) {
+    for (; dq.step < nsteps; dq.advance(tid), cur ^= 1) {
+        const int step = dq.step;
         if constexpr (!F32IN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        const int next = step + gridDim.x;
+        dq.top(tid);
+        const int next = dq.nxt;
         if constexpr (F32IN) {
             if (next < nsteps) load_f32(next);            // in flight during the compute below
         } else {
@@ -287,6 +296,7 @@ __global__ __launch_bounds__(256) void dw3x3_stem8(const int8_t *__restrict__ in
             if (next < nsteps) store_f32(cur ^ 1); // the other buffer: last read before this step's barrier
         }
     }
+    dq.finish(tid);
 }
 
 // ------------------------------------------------------------------------
@@ -346,6 +356,8 @@ __global__ __launch_bounds__(256) void dw3x3_stem8_mm(const int8_t *__restrict__
         first[0] = col == 0, first[1] = col == 8, first[2] = false;
     }
     const int img_g = wave / WPI, rp0 = (wave % WPI) * RPW;
+    DynSteps dq;
+    dq.init(lds + 2 * BUF, p.queue, tid, p.qcfg); // (16 bytes behind the two staging buffers)
     __syncthreads();
 
     auto stage = [&](int st, int buf) {
@@ -390,19 +402,21 @@ __global__ __launch_bounds__(256) void dw3x3_stem8_mm(const int8_t *__restrict__
     };
 
     const int nsteps = (batch + G - 1) / G;
-    int step = blockIdx.x, cur = 0;
+    int cur = 0;
     if constexpr (F32IN) {
-        if (step < nsteps) {
-            load_f32(step);
+        if (dq.step < nsteps) {
+            load_f32(dq.step);
             store_f32(0);
         }
     } else {
-        if (step < nsteps) stage(step, 0);
+        if (dq.step < nsteps) stage(dq.step, 0);
     }
-    for (; step < nsteps; step += gridDim.x, cur ^= 1) {
+    for (; dq.step < nsteps; dq.advance(tid), cur ^= 1) {
+        const int step = dq.step;
         if constexpr (!F32IN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        const int next = step + gridDim.x;
+        dq.top(tid);
+        const int next = dq.nxt;
         if constexpr (F32IN) {
             if (next < nsteps) load_f32(next); // in flight during the compute below
         } else {
@@ -448,6 +462,7 @@ __global__ __launch_bounds__(256) void dw3x3_stem8_mm(const int8_t *__restrict__
             if (next < nsteps) store_f32(cur ^ 1); // the other buffer: last read before this step's barrier
         }
     }
+    dq.finish(tid);
 }
 
 // ------------------------------------------------------------------------
@@ -553,12 +568,15 @@ __global__ __launch_bounds__(512) void dw_c1_lds(const int8_t *__restrict__ in, 
 template <int H, int W, int C, int S, int G, int NTHR, int MG, uint32_t XR4>
 static void launch_dw(const int8_t *in, int8_t *out, const DwFastArgs &a, int batch, hipStream_t s) {
     constexpr int LP = C < 16 ? 16 : C;
-    constexpr int lds = 2 * G * (H + 2) * (LP + W * C + LP) + 256; // two staging buffers + read slack
+    constexpr int lds = 2 * G * (H + 2) * (LP + W * C + LP) + 256 + 16; // two staging buffers + read slack + step queue
     static LaunchState st;
     const int per_cu = prepared(st, dw3x3_nhwc<H, W, C, S, G, NTHR, MG, XR4>, NTHR, lds);
     const int nsteps = (batch + G - 1) / G;
     const int grid = nsteps < 256 * per_cu ? nsteps : 256 * per_cu;
-    hipLaunchKernelGGL((dw3x3_nhwc<H, W, C, S, G, NTHR, MG, XR4>), dim3(grid), dim3(NTHR), lds, s, in, out, a, batch);
+    constexpr int OPIX = ((H + S - 1) / S) * ((W + S - 1) / S);
+    DwFastArgs b = a;
+    b.qcfg = dq_config(nsteps, grid, dq_est_us((double)batch * (H * W * C + OPIX * C), (double)batch * OPIX * C));
+    hipLaunchKernelGGL((dw3x3_nhwc<H, W, C, S, G, NTHR, MG, XR4>), dim3(grid), dim3(NTHR), lds, s, in, out, b, batch);
 }
 
 const char *dw_fast_name(int H, int W, int C, int S) {
@@ -612,10 +630,12 @@ const char *dw_stem_name(int H, int W, int DM, int S) {
     if (H == 96 && W == 96 && DM == 8 && S == 2) return "dw3x3_stem8<96,96,2>";
     return nullptr;
 }
-bool launch_dw_stem(int H, int W, int DM, int S, const int8_t *in, int8_t *out, const DwStemArgs &a,
+bool launch_dw_stem(int H, int W, int DM, int S, const int8_t *in, int8_t *out, const DwStemArgs &a_in,
                     int batch, hipStream_t s, bool f32_input) {
     if (H == 96 && W == 96 && DM == 8 && S == 2) {
-        constexpr int G = 2, lds = 2 * G * (16 + (96 + 2) * 96);
+        constexpr int G = 2, lds = 2 * G * (16 + (96 + 2) * 96) + 16; // + step queue
+        DwStemArgs a = a_in;
+        a.qcfg = dq_config((batch + G - 1) / G, 512, dq_est_us((double)batch * (96 * 96 * (f32_input ? 4 : 1) + 48 * 48 * 8), (double)batch * 48 * 48 * 8));
         static LaunchState st, stf;
         const int per_cu = f32_input ? prepared(stf, dw3x3_stem8<96, 96, G, false, 0u, true>, 256, lds)
                                      : prepared(st, dw3x3_stem8<96, 96, G, false, 0u, false>, 256, lds);

@@ -56,10 +56,13 @@ __global__ __launch_bounds__(NTHR) void dwpw3x3(const int8_t *__restrict__ in,
     // LDS: [staging x NBUF][slack 256][MID (+64 slack)][patch]
     constexpr int MID_OFF = NBUF * BUF + 256;
     constexpr int PATCH_OFF = MID_OFF + MIDB + 64;
+    constexpr int DQ_OFF = PATCH_OFF + (XPOSE ? NWAVE * CBYTES : 0); // the step queue's two ints
 
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    DynSteps dq;
+    dq.init(lds + DQ_OFF, p.dw.queue, tid, p.dw.qcfg);
 
     for (int i = tid; i < (NBUF * BUF + 256) / 16; i += NTHR)
         ((uint4 *)lds)[i] = make_uint4(p.dw.izp4, p.dw.izp4, p.dw.izp4, p.dw.izp4);
@@ -119,13 +122,15 @@ __global__ __launch_bounds__(NTHR) void dwpw3x3(const int8_t *__restrict__ in,
 
     uint8_t *mid = lds + MID_OFF;
     const int nsteps = (batch + G - 1) / G;
-    int step = blockIdx.x, cur = 0;
-    if (step < nsteps) stage(step, 0);
+    int cur = 0;
+    if (dq.step < nsteps) stage(dq.step, 0);
 
-    for (; step < nsteps; step += gridDim.x) {
+    for (; dq.step < nsteps; dq.advance(tid)) {
+        const int step = dq.step;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads(); // B1: staged tile complete; previous pointwise phase done with MID
-        const int next = step + gridDim.x;
+        dq.top(tid);
+        const int next = dq.nxt;
         if constexpr (DBUF) {
             if (next < nsteps) stage(next, cur ^ 1);
         }
@@ -251,6 +256,7 @@ __global__ __launch_bounds__(NTHR) void dwpw3x3(const int8_t *__restrict__ in,
         }
         if constexpr (DBUF) cur ^= 1;
     }
+    dq.finish(tid);
 }
 
 // ------------------------------------------------------------------------
@@ -283,13 +289,15 @@ static void launch_dwpw_t(const int8_t *in, int8_t *out, const DwPwArgs &a, int 
     constexpr int BUF = G * (H + 2) * (LP + W * C + LP);
     constexpr int NB = N < 64 ? N : 64, CPIX = C < 64 ? 1024 / C : 16;
     constexpr int patch = (NB / 16 < 4) ? (NTHR / 64) * CPIX * N : 0;
-    constexpr int lds = (DB ? 2 : 1) * BUF + 256 + G * OH * OW * C + 64 + patch;
+    constexpr int lds = (DB ? 2 : 1) * BUF + 256 + G * OH * OW * C + 64 + patch + 16; // + step queue
     static_assert(lds <= 163840, "fused tile does not fit the LDS");
     static LaunchState st;
     const int per_cu = prepared(st, dwpw3x3<H, W, C, S, N, G, NTHR, (DB != 0), MG, XR4>, NTHR, lds);
     const int nsteps = (batch + G - 1) / G;
     const int grid = nsteps < 256 * per_cu ? nsteps : 256 * per_cu;
-    hipLaunchKernelGGL((dwpw3x3<H, W, C, S, N, G, NTHR, (DB != 0), MG, XR4>), dim3(grid), dim3(NTHR), lds, s, in, out, a, batch);
+    DwPwArgs b = a;
+    b.dw.qcfg = dq_config(nsteps, grid, dq_est_us((double)batch * (H * W * C + OH * OW * N), (double)batch * OH * OW * (C + N)));
+    hipLaunchKernelGGL((dwpw3x3<H, W, C, S, N, G, NTHR, (DB != 0), MG, XR4>), dim3(grid), dim3(NTHR), lds, s, in, out, b, batch);
 }
 int dwpw_impl();
 const char *dwpw_name(int H, int W, int C, int S, int N) {

@@ -54,7 +54,7 @@ constexpr int dwmm_lds_bytes(int H, int W, int C, int S, int N, int G, int NTHR,
     const int patch = (NB / 16 < 4) ? (NTHR / 64) * CPIX * N : 0;
     const int NPIX = G * OH * OW, P16 = (NPIX + 15) / 16 * 16;
     const int MIDB = C == 8 ? NPIX * 8 : (C / 16) * (P16 * 16 + 16);
-    return (DBUF ? 2 : 1) * BUF + 512 + MIDB + 64 + patch;
+    return (DBUF ? 2 : 1) * BUF + 512 + MIDB + 64 + patch + 16; // (+ 16: the step queue's two ints)
 }
 // DWONLY: the depthwise operator alone (layer-wise execution): the pointwise phase is replaced by a copy of MID --
 // which then IS the operator's output tensor -- to HBM with 16-byte loads and stores.
@@ -107,10 +107,13 @@ __global__ __launch_bounds__(NTHR, WPE) void dwpw_mm(const int8_t *__restrict__ 
     // LDS: [staging x NBUF][slack 512][MID (+64 slack)][patch]
     constexpr int MID_OFF = NBUF * BUF + 512;
     constexpr int PATCH_OFF = MID_OFF + MIDB + 64;
+    constexpr int DQ_OFF = dwmm_lds_bytes(H, W, C, S, N, G, NTHR, DBUF, ROWPAD) - 16;
 
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    DynSteps dq;
+    dq.init(lds + DQ_OFF, p.dw.queue, tid, p.dw.qcfg);
 
     for (int i = tid; i < (NBUF * BUF + 512) / 16; i += NTHR)
         ((uint4 *)lds)[i] = make_uint4(p.dw.izp4, p.dw.izp4, p.dw.izp4, p.dw.izp4);
@@ -196,13 +199,15 @@ __global__ __launch_bounds__(NTHR, WPE) void dwpw_mm(const int8_t *__restrict__ 
 
     uint8_t *mid = lds + MID_OFF;
     const int nsteps = (batch + G - 1) / G;
-    int step = blockIdx.x, cur = 0;
-    if (step < nsteps) stage(step, 0);
+    int cur = 0;
+    if (dq.step < nsteps) stage(dq.step, 0);
 
-    for (; step < nsteps; step += gridDim.x) {
+    for (; dq.step < nsteps; dq.advance(tid)) {
+        const int step = dq.step;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads(); // B1: staged tile complete; previous pointwise phase done with MID
-        const int next = step + gridDim.x;
+        dq.top(tid);
+        const int next = dq.nxt;
         if constexpr (DBUF) {
             if (next < nsteps) stage(next, cur ^ 1);
         }
@@ -366,6 +371,7 @@ __global__ __launch_bounds__(NTHR, WPE) void dwpw_mm(const int8_t *__restrict__ 
         }
         if constexpr (DBUF) cur ^= 1;
     }
+    dq.finish(tid);
 }
 
 // ------------------------------------------------------------------------
@@ -421,6 +427,8 @@ __global__ __launch_bounds__(NTHR, WPE) void dwpw_rr(const int8_t *__restrict__ 
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    DynSteps dq;
+    dq.init(lds + NBUF * BUF + 512, p.dw.queue, tid, p.dw.qcfg); // (16 bytes behind the staging buffers' slack)
 
     for (int i = tid; i < (NBUF * BUF + 512) / 16; i += NTHR)
         ((uint4 *)lds)[i] = make_uint4(p.dw.izp4, p.dw.izp4, p.dw.izp4, p.dw.izp4);
@@ -489,13 +497,15 @@ __global__ __launch_bounds__(NTHR, WPE) void dwpw_rr(const int8_t *__restrict__ 
     };
 
     const int nsteps = (batch + G - 1) / G;
-    int step = blockIdx.x, cur = 0;
-    if (step < nsteps) stage(step, 0);
+    int cur = 0;
+    if (dq.step < nsteps) stage(dq.step, 0);
 
-    for (; step < nsteps; step += gridDim.x) {
+    for (; dq.step < nsteps; dq.advance(tid)) {
+        const int step = dq.step;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads(); // the staged tile is complete; every wave is done with the buffer the next DMA overwrites
-        const int next = step + gridDim.x;
+        dq.top(tid);
+        const int next = dq.nxt;
         if constexpr (DBUF) {
             if (next < nsteps) stage(next, cur ^ 1);
         }
@@ -594,6 +604,7 @@ __global__ __launch_bounds__(NTHR, WPE) void dwpw_rr(const int8_t *__restrict__ 
             if (next < nsteps) stage(next, 0);
         }
     }
+    dq.finish(tid);
 }
 
 // ---- launchers ----
@@ -606,8 +617,11 @@ static void launch_dwpw_mm_t(const int8_t *in, int8_t *out, const DwPwArgs &a, i
     const int per_cu = prepared(st, dwpw_mm<H, W, C, S, N, G, NTHR, (DB != 0), CG, CY, ORD, ROWPAD, TS, WPE, MG, XR4, false>, NTHR, lds);
     const int nsteps = (batch + G - 1) / G;
     const int grid = nsteps < 256 * per_cu ? nsteps : 256 * per_cu;
+    constexpr int OPIX = ((H + S - 1) / S) * ((W + S - 1) / S);
+    DwPwArgs b = a;
+    b.dw.qcfg = dq_config(nsteps, grid, dq_est_us((double)batch * (H * W * C + OPIX * N), (double)batch * OPIX * (C + N)));
     hipLaunchKernelGGL((dwpw_mm<H, W, C, S, N, G, NTHR, (DB != 0), CG, CY, ORD, ROWPAD, TS, WPE, MG, XR4, false>), dim3(grid), dim3(NTHR),
-                       lds, s, in, out, a, batch);
+                       lds, s, in, out, b, batch);
 }
 // the depthwise operator alone (DWONLY instance of the same shape)
 template <int H, int W, int C, int S, int N, int G, int NTHR, int DB, int CG, int CY, int ORD, int ROWPAD, int TS, int WPE,
@@ -618,8 +632,11 @@ static void launch_dw_mm_t(const int8_t *in, int8_t *out, const DwPwArgs &a, int
     const int per_cu = prepared(st, dwpw_mm<H, W, C, S, N, G, NTHR, (DB != 0), CG, CY, ORD, ROWPAD, TS, WPE, MG, XR4, true>, NTHR, lds);
     const int nsteps = (batch + G - 1) / G;
     const int grid = nsteps < 256 * per_cu ? nsteps : 256 * per_cu;
+    constexpr int OPIX = ((H + S - 1) / S) * ((W + S - 1) / S);
+    DwPwArgs b = a;
+    b.dw.qcfg = dq_config(nsteps, grid, dq_est_us((double)batch * (H * W * C + OPIX * C), (double)batch * OPIX * C));
     hipLaunchKernelGGL((dwpw_mm<H, W, C, S, N, G, NTHR, (DB != 0), CG, CY, ORD, ROWPAD, TS, WPE, MG, XR4, true>), dim3(grid), dim3(NTHR),
-                       lds, s, in, out, a, batch);
+                       lds, s, in, out, b, batch);
 }
 // Measured per shape against dw3x3_nhwc (v_dot4 taps, no MID round trip): the matrix-pipe form wins on the three
 // large early layers (48x48x8: 0.54 -> 0.48 ms, 48x48x16 s2: 0.60 -> 0.57, 24x24x32: 0.49 -> 0.47) and loses on
@@ -686,14 +703,17 @@ template <int H, int W, int C, int S, int N, int G, int NTHR, int DB, int CG, in
           int MG, uint32_t XR4>
 static void launch_dwpw_rr_t(const int8_t *in, int8_t *out, const DwPwArgs &a, int batch, hipStream_t s) {
     constexpr int LP = C < 16 ? 16 : C;
-    constexpr int lds = (DB ? 2 : 1) * G * (H + 2) * (LP + W * C + LP + ROWPAD) + 512;
+    constexpr int lds = (DB ? 2 : 1) * G * (H + 2) * (LP + W * C + LP + ROWPAD) + 512 + 16; // + step queue
     static_assert(lds <= 163840, "staged tiles do not fit the LDS");
     static LaunchState st;
     const int per_cu = prepared(st, dwpw_rr<H, W, C, S, N, G, NTHR, DB, CG, CY, ORD, ROWPAD, TS, WPE, MG, XR4>, NTHR, lds);
     const int nsteps = (batch + G - 1) / G;
     const int grid = nsteps < 256 * per_cu ? nsteps : 256 * per_cu;
+    constexpr int OPIX = ((H + S - 1) / S) * ((W + S - 1) / S);
+    DwPwArgs b = a;
+    b.dw.qcfg = dq_config(nsteps, grid, dq_est_us((double)batch * (H * W * C + OPIX * N), (double)batch * OPIX * (C + N)));
     hipLaunchKernelGGL((dwpw_rr<H, W, C, S, N, G, NTHR, DB, CG, CY, ORD, ROWPAD, TS, WPE, MG, XR4>), dim3(grid), dim3(NTHR),
-                       lds, s, in, out, a, batch);
+                       lds, s, in, out, b, batch);
 }
 const char *dwpw_rr_name(int H, int W, int C, int S, int N) {
 #define MF_DWRR(h, w, c, s, n, g, t, d, cg, cy, ord, rp, ts, wpe) \

@@ -478,6 +478,10 @@ template <typename Launch> static unsigned long long run_selftest(hipStream_t s,
     (void)hipFree(d);
     return h;
 }
+unsigned long dq_next_launch() {
+    static std::atomic<unsigned long> n{0};
+    return n.fetch_add(1);
+}
 unsigned long long selftest_rounding(int mode, bool u8, float lo, float hi, hipStream_t s) {
     return run_selftest(s, [&](unsigned long long *d) {
         const dim3 g(256 * 16), b(256);

@@ -43,6 +43,7 @@ namespace k {
 
 #if MF_STAGE_DIAG == 2
 __device__ long long g_stage_trace[32];
+__device__ long long g_stage_blk[1024][2]; // 100 MHz clock at entry / exit of every workgroup
 #define MF_TR(k) do { if (blockIdx.x == 0 && wave == 0 && lane == 0 && trace_step == 1) g_stage_trace[k] = (long long)__builtin_readcyclecounter(); } while (0)
 #else
 #define MF_TR(k) do { } while (0)
@@ -80,7 +81,8 @@ __global__ __launch_bounds__(NTHR, 4) void stage_6x6x128(const int8_t *__restric
     constexpr int IMG6 = PIX6 * 128;
     constexpr int OFF_B = G * TILE6 + 512;     // MID of the even pairs
     constexpr int OFF_A = OFF_B + 8 * PLANE6;  // MID of the odd pairs; the last pair's plain [pixel][128] output
-    static_assert(OFF_A + 8 * PLANE6 <= MF_STAGE_LDS_KB * 1024, "LDS budget");
+    constexpr int OFF_Q = OFF_A + 8 * PLANE6;  // the step queue's two ints
+    static_assert(OFF_Q + 16 <= MF_STAGE_LDS_KB * 1024, "LDS budget");
     static_assert(NP6 * 128 == 8 * PLANE6, "the plain output fills region A exactly");
 
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -166,19 +168,27 @@ __global__ __launch_bounds__(NTHR, 4) void stage_6x6x128(const int8_t *__restric
         }
     };
 
+    DynSteps dq;
+    dq.init(lds + OFF_Q, p.queue, tid, p.qcfg);
     __syncthreads(); // halo fill complete before any DMA lands
     const int nsteps = (batch + G - 1) / G;
-    int step = blockIdx.x;
-    if (step < nsteps) stage(step);
+    if (dq.step < nsteps) stage(dq.step);
     DwW wd = load_dw(0);
 
 #if MF_STAGE_DIAG == 2
     int trace_step = 0;
+    if (wave == 0 && lane == 0 && blockIdx.x < 1024) g_stage_blk[blockIdx.x][0] = (long long)__builtin_amdgcn_s_memrealtime();
+    if (blockIdx.x == 0 && wave == 0 && lane == 0) {
+        g_stage_trace[25] = (long long)__builtin_readcyclecounter();
+        g_stage_trace[27] = (long long)__builtin_amdgcn_s_memrealtime();
+    }
 #endif
-    for (; step < nsteps; step += gridDim.x) {
+    for (; dq.step < nsteps; dq.advance(tid)) {
+        const int step = dq.step;
         MF_TR(24);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads(); // this step's images are in the tile; the previous step's output has been copied out of region A
+        dq.top(tid);
         asm volatile("" : "+s"(pairs));
         const int gvalid = min(G, batch - step * G);
         MF_TR(0);
@@ -223,7 +233,7 @@ __global__ __launch_bounds__(NTHR, 4) void stage_6x6x128(const int8_t *__restric
             MF_TR(2 + 3 * rep);
             const bool last = rep == NREP - 1;
             if (last) {
-                const int next = step + gridDim.x;
+                const int next = dq.nxt;
                 if (next < nsteps) stage(next); // the tile is dead: the next step's images fly under the last pointwise phase
             }
             wd = load_dw(last ? 0 : rep + 1); // the next depthwise's operands land during the pointwise phase
@@ -281,15 +291,26 @@ __global__ __launch_bounds__(NTHR, 4) void stage_6x6x128(const int8_t *__restric
         ++trace_step;
 #endif
     }
+    dq.finish(tid);
+#if MF_STAGE_DIAG == 2
+    if (wave == 0 && lane == 0 && blockIdx.x < 1024) g_stage_blk[blockIdx.x][1] = (long long)__builtin_amdgcn_s_memrealtime();
+    if (blockIdx.x == 0 && wave == 0 && lane == 0) {
+        g_stage_trace[26] = (long long)__builtin_readcyclecounter();
+        g_stage_trace[28] = (long long)__builtin_amdgcn_s_memrealtime();
+        g_stage_trace[29] = trace_step;
+    }
+#endif
 }
 
 // ---- launcher ----
 const char *stage_name(int H, int W, int C, int npairs) {
     return (H == 6 && W == 6 && C == 128 && npairs == 5) ? "stage_6x6x128<4,512,5>" : nullptr;
 }
-bool launch_stage(int H, int W, int C, int npairs, const int8_t *in, int8_t *out, const StageArgs &a, int batch, hipStream_t s) {
+bool launch_stage(int H, int W, int C, int npairs, const int8_t *in, int8_t *out, const StageArgs &a_in, int batch, hipStream_t s) {
     if (!stage_name(H, W, C, npairs)) return false;
     constexpr int G = 4, NTHR = 512, NREP = 5;
+    StageArgs a = a_in;
+    a.qcfg = dq_config((batch + G - 1) / G, 512, dq_est_us((double)batch * 2 * H * W * C, (double)batch * 2 * NREP * H * W * C));
     constexpr int lds = MF_STAGE_LDS_KB * 1024;
     const int nsteps = (batch + G - 1) / G;
     int per_cu = 0, grid = 0;
@@ -316,6 +337,14 @@ bool launch_stage(int H, int W, int C, int npairs, const int8_t *in, int8_t *out
             (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_stage_trace), sizeof(h));
             fprintf(stderr, "[stage trace] grid %d per_cu %d; cycles since step start:", grid, per_cu);
             for (int i = 0; i < 18; ++i) fprintf(stderr, " %d:%lld", i, h[i] - h[24]);
+            fprintf(stderr, " | kernel: %lld shader cycles, %lld ticks of the 100 MHz clock, %lld steps; prologue %lld cycles\n", h[26] - h[25], h[28] - h[27], h[29],
+                    h[24] - h[25]);
+            static long long hb[1024][2];
+            (void)hipMemcpyFromSymbol(hb, HIP_SYMBOL(g_stage_blk), sizeof(hb));
+            long long t0 = hb[0][0];
+            for (int i = 0; i < grid && i < 1024; ++i) t0 = hb[i][0] < t0 ? hb[i][0] : t0;
+            fprintf(stderr, "[stage blocks] start/end in us since the first start:");
+            for (int i = 0; i < grid && i < 1024; i += 1) fprintf(stderr, " %d:%.1f-%.1f", i, (hb[i][0] - t0) * 0.01, (hb[i][1] - t0) * 0.01);
             fprintf(stderr, "\n");
         }
     }

@@ -68,6 +68,7 @@ struct SoftmaxArgs {
     float sat_lo, sat_hi;
     int xr;
 };
+constexpr int DYNQ_INTS = 8 * 32 + 32; // = DynSteps::INTS (k_common.hpp): the counters of one dynamic step queue
 struct DwFastArgs {
     const int8_t *w;    // [3][3][C]
     const void *wmm;    // matrix-pipe form of w (k_fused_mm.hip): [C/16 or 1][3 filter rows][64 lanes] x 16 bytes
@@ -79,6 +80,8 @@ struct DwFastArgs {
     int magic;          // epilogue mode (k_common.hpp requant_t): 1: worst-case |acc| < 2^22 -> bit-pattern int->float
                         // conversion; 2: also clamp == the element type's range and |x| < 2^15 -> saturating pack
     int xr;             // 0 (i8) or 0x80 (u8): see ConvArgs
+    int *queue;         // dynamic step queue of the persistent kernels (k_common.hpp DynSteps): DYNQ_INTS zeroed device ints
+    int qcfg;           // its configuration for this launch (set by the launcher: dq_config)
 };
 // depthwise with ONE input channel and up to 8 output channels, any filter / stride (speech op 1)
 struct DwC1Args {
@@ -105,6 +108,8 @@ struct DwStemArgs {
     uint32_t in_xr4;
     float in_rcp;        // 1 / in_scale (rounded) for quant_div
     int in_fast;         // 1: the 3-instruction division was verified for these parameters (k_common.hpp: quant_div)
+    int *queue;          // dynamic step queue (k_common.hpp DynSteps)
+    int qcfg;            // set by the launcher (dq_config)
 };
 struct DwPwArgs;
 struct PwArgs {
@@ -214,6 +219,8 @@ struct StageArgs {
     const StagePair *pairs;  // [number of pairs], in device memory
     uint32_t izp4;           // zero point of every depthwise input of the run (they must agree: one halo fill)
     uint32_t xr4;            // 0 (i8) or 0x80808080 (u8): XOR of every stored dword
+    int *queue;              // dynamic step queue (k_common.hpp DynSteps)
+    int qcfg;                // set by the launcher (dq_config)
     int mode;                // epilogue mode of the whole run (k_common.hpp): 1, or 2 when every clamp is the type's range
 };
 

@@ -96,6 +96,7 @@ struct OpImpl {
     size_t ext_cap = 0;
 
     DevBuf d_w, d_wzp, d_A, d_S, d_Kc, d_wprep, d_wrr, d_table;
+    DevBuf d_queue; // zeroed counters: the dynamic step queue of the persistent kernels launched for this operator (k_common.hpp)
     k::DwC1Args dwc1{};
     k::ConvArgs conv{};
     k::PoolArgs pool{};
@@ -312,6 +313,10 @@ OpImpl *op_create(int device, const OpSpec &spec) {
         op->d_A.upload(A.data(), A.size() * 4);
         op->d_S.upload(S.data(), S.size() * 4);
         op->d_Kc.upload(Kc.data(), Kc.size() * 4);
+        {
+            const std::vector<int> zeros((size_t)k::DYNQ_INTS, 0);
+            op->d_queue.upload(zeros.data(), zeros.size() * sizeof(int));
+        }
         k::ConvArgs &a = op->conv;
         a.H = s.H, a.W = s.W, a.C = s.C, a.N = s.N, a.KH = s.KH, a.KW = s.KW, a.sh = s.sh, a.sw = s.sw;
         a.OH = s.OH, a.OW = s.OW, a.pad_same = s.pad == MF_PAD_SAME, a.izp = s.izp;
@@ -335,6 +340,7 @@ OpImpl *op_create(int device, const OpSpec &spec) {
             f.izp4 = 0x01010101u * (uint32_t)(uint8_t)(int8_t)s.izp;
             f.lo_f = a.lo_f, f.hi_f = a.hi_f, f.magic = magic, f.xr = xr;
             f.wmm = nullptr;
+            f.queue = (int *)op->d_queue.p;
             if (s.C == 8 || s.C % 16 == 0) { // matrix-pipe form of the taps for the fused pair kernels
                 const std::vector<int8_t> prep = build_dw_mm_weights(s.weights, s.C);
                 op->d_wprep.upload(prep.data(), prep.size());
@@ -345,6 +351,7 @@ OpImpl *op_create(int device, const OpSpec &spec) {
             op->fast = OpImpl::DW_STEM;
             op->fast_name = k::dw_stem_name(s.H, s.W, s.N, s.sh);
             k::DwStemArgs &f = op->stem;
+            f.queue = (int *)op->d_queue.p;
             for (int ky = 0; ky < 3; ++ky)
                 for (int c = 0; c < 8; ++c) {
                     uint32_t d = 0;
@@ -798,6 +805,7 @@ FusedImpl *fused_stage_create(FusedImpl *const *pairs, int npairs) {
     s->stage.pairs = (const k::StagePair *)s->stage_w.back()->p;
     s->stage.izp4 = pairs[0]->dwpw.dw.izp4;
     s->stage.xr4 = d0.u8 ? 0x80808080u : 0u;
+    s->stage.queue = pairs[0]->dwpw.dw.queue;
     s->stage.mode = 2; // the saturating-pack epilogue needs it of every operator of the run
     for (int i = 0; i < npairs; ++i)
         if (pairs[i]->dwpw.dw.magic != 2 || pairs[i]->dwpw.pw.magic != 2) s->stage.mode = 1;

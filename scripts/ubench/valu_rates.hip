@@ -51,6 +51,21 @@ __global__ __launch_bounds__(256) void bench(uint32_t *out, uint32_t seed) {
             if (OP == 25) asm volatile("v_xor_b32 %0, %1, %2" : "=v"(a[i]) : "v"(a[i]), "v"(w));
             if (OP == 26) asm volatile("v_max_f32 %0, %1, %2" : "=v"(f[i]) : "v"(f[i]), "v"(g));
             if (OP == 27) asm volatile("v_max_i32 %0, %1, %2" : "=v"(a[i]) : "v"(a[i]), "v"(w));
+            if (OP == 29) asm volatile("v_or_b32 %0, 1, %1" : "=v"(a[i]) : "v"(a[i]));
+            if (OP == 30) asm volatile("v_add_f32_sdwa %0, %1, %2 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(a[i]) : "v"(f[i]), "v"(g));
+            if (OP == 31) asm volatile("v_add_f32_sdwa %0, %1, %2 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD" : "=v"(a[i]) : "v"(a[i]), "v"(g));
+            if (OP == 32) asm volatile("v_sat_pk_u8_i16_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(a[i]) : "v"(w));
+            if (OP == 33) asm volatile("v_cvt_i32_f32_sdwa %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(a[i]) : "v"(f[i]));
+            if (OP == 34) asm volatile("v_and_b32 %0, %1, %2" : "=v"(a[i]) : "v"(a[i]), "v"(w));
+            if (OP == 35) asm volatile("v_add_u32 %0, %1, %2" : "=v"(a[i]) : "v"(a[i]), "v"(w));
+            if (OP == 36) asm volatile("v_add_f32 %0, %1, %2" : "=v"(f[i]) : "v"(f[i]), "v"(g));
+            if (OP == 37) asm volatile("v_add_f32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD" : "=v"(f[i]) : "v"(f[i]), "v"(g));
+            if (OP == 38) asm volatile("v_mov_b32_sdwa %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_0" : "+v"(a[i]) : "v"(w));
+            if (OP == 39) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(f[i]) : "v"(g), "v"(f[i]));
+            if (OP == 40) asm volatile("v_cndmask_b32 %0, %1, %2, vcc" : "=v"(a[i]) : "v"(a[i]), "v"(w) : );
+            if (OP == 41) asm volatile("v_min_f32 %0, %1, %2" : "=v"(f[i]) : "v"(f[i]), "v"(g));
+            if (OP == 42) asm volatile("v_rndne_f32 %0, %1" : "=v"(f[i]) : "v"(f[i]));
+            if (OP == 43) asm volatile("v_lshlrev_b32 %0, 3, %1" : "=v"(a[i]) : "v"(a[i]));
             if (OP == 28) asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(*(double *)&f[i & ~1]) : "v"(*(double *)&f[i & ~1]), "v"(*(double *)&f[i & ~1]));
         }
         if (OP == 7) { h = -h; }
@@ -106,5 +121,20 @@ int main() {
     run<25>("v_xor_b32", 1, b);
     run<26>("v_max_f32", 1, b);
     run<27>("v_max_i32", 1, b);
+    run<29>("v_or_b32 x, 1", 1, b);
+    run<30>("v_add_f32_sdwa BYTE_1 preserve", 1, b);
+    run<31>("v_add_f32_sdwa WORD_0 pad", 1, b);
+    run<32>("v_sat_pk_u8_i16_sdwa WORD_1", 1, b);
+    run<33>("v_cvt_i32_f32_sdwa BYTE_1", 1, b);
+    run<34>("v_and_b32", 1, b);
+    run<35>("v_add_u32", 1, b);
+    run<36>("v_add_f32 (asm)", 1, b);
+    run<37>("v_add_f32_sdwa DWORD", 1, b);
+    run<38>("v_mov_b32_sdwa byte insert", 1, b);
+    run<39>("v_fmac_f32", 1, b);
+    run<40>("v_cndmask_b32", 1, b);
+    run<41>("v_min_f32", 1, b);
+    run<42>("v_rndne_f32", 1, b);
+    run<43>("v_lshlrev_b32", 1, b);
     return 0;
 }
