@@ -35,12 +35,41 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 achievable)
-# The reference's f32 requantisation (two individually rounded operations, roundf, clamp, convert) is 8 VALU
-# instructions per output byte and cannot be fused or shortened.  Its measured ceiling on this chip with nothing else
-# in the loop (scripts/ubench/epi_rate.hip, profiles/r02/epi_rate.txt): 43.8 ns per 256-byte wave group per SIMD
-# = 5 985 GB/s of requantised bytes over the 1024 SIMDs.  A kernel that keeps its intermediate tensors on chip (the
-# late-stage kernel) is bounded by this, not by HBM.
-REQUANT_PEAK_GBS = 5985.0
+# The reference's f32 requantisation (two individually rounded operations, roundf, clamp, `as T`) costs 5.75 - 6 VALU
+# instructions per output byte in its shortest exact form (k_common.hpp).  Its ceiling on this chip with nothing else in
+# the loop is MEASURED in every run, outside the timed region, by scripts/ubench/epi_rate.hip (libepi_rate.so, built by
+# __graft_entry__.build(); it executes the library's own requant_pack4): ns per 256-byte wave group per SIMD ->
+# GB/s of requantised bytes over the 1024 SIMDs.  A kernel that keeps its intermediate tensors on chip (the late-stage
+# kernel) is bounded by this, not by HBM.  The literal below is only the fallback when the ubench cannot run
+# (profiles/r03: 39.8 ns -> 6 590 GB/s for the saturating-pack form person_detect's operators use).
+REQUANT_PEAK_GBS = 6590.0
+REQUANT_CEILING = None  # filled by measure_requant_ceiling()
+
+
+def measure_requant_ceiling():
+    """Run the requantisation microbenchmark on the current device (a few hundred ms) and make its result the ceiling
+    every `valu_frac` / `requant_frac` of this run is priced against."""
+    global REQUANT_PEAK_GBS, REQUANT_CEILING
+    import ctypes
+    rec = {"source": "scripts/ubench/epi_rate.hip (libepi_rate.so), measured in this run outside the timed region",
+           "unit": "GB/s of requantised int8 over 1024 SIMDs", "loop_overhead": "one v_add per value is part of the loop",
+           "forms": {}}
+    try:
+        lib = ctypes.CDLL(os.path.join(ROOT, "scripts", "ubench", "libepi_rate.so"))
+        lib.mf_ubench_requant_ns.restype = ctypes.c_double
+        lib.mf_ubench_requant_ns.argtypes = [ctypes.c_int]
+        for name, v in (("mode2_saturating_pack", 5), ("mode1_med3", 4), ("round2_form", 1)):
+            ns = lib.mf_ubench_requant_ns(v)  # 1 warm-up + 5 timed launches of ~0.7 ms each
+            if ns > 0:
+                rec["forms"][name] = {"ns_per_256B_wave_group_per_simd": round(ns, 2), "GBps": round(1024 * 256 / ns, 1)}
+        if "mode2_saturating_pack" in rec["forms"]:
+            REQUANT_PEAK_GBS = rec["forms"]["mode2_saturating_pack"]["GBps"]
+            rec["used"] = "mode2_saturating_pack"
+    except OSError as e:
+        rec["error"] = "libepi_rate.so not loadable (%s): literal fallback" % e
+    rec["GBps"] = REQUANT_PEAK_GBS
+    REQUANT_CEILING = rec
+    return rec
 WORKLOADS = {
     # name: (model file, BASELINE config index used as stream id, per-GPU batch)
     "person_detect": ("person_detect.tflite", 3, 65536),
@@ -72,7 +101,7 @@ def self_launch(args):
     torch.distributed.run, rendezvous on 127.0.0.1."""
     import torch
     have = torch.cuda.device_count() if torch.cuda.is_available() else 0
-    if have < args.gpus:
+    if have < args.gpus and not (args.share_device and have >= 1):
         raise SystemExit("bench.py --gpus %d: only %d GPU device(s) visible on this box" % (args.gpus, have))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
            "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
@@ -80,6 +109,20 @@ def self_launch(args):
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "4")
     raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def pmc_traffic(kernel, count):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/pmc_traffic_latest.json =
+    scripts/pmc_summary.py over separate --pmc FETCH_SIZE / WRITE_SIZE passes of this same command)."""
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")))
+        if count is None or pmc.get("per_gpu_batch") == count:
+            for k in pmc["kernels"]:
+                if k["kernel"] == kernel or (kernel == "fc_mfma" and k["kernel"].startswith("fc_mfma<")):
+                    return k["traffic_bytes"], "profiles/pmc_traffic_latest.json"
+    except (OSError, ValueError, KeyError):
+        pass
+    return None, None
 
 
 def median(xs):
@@ -110,6 +153,10 @@ def main():
     ap.add_argument("--no-host-fed", action="store_true", help="skip the PCIe-inclusive and f32 legs")
     ap.add_argument("--no-extra", action="store_true", help="skip the speech / fc4096 sub-records")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend of the N > 1 path (nccl = RCCL; gloo: tests on a 1-GPU box)")
+    ap.add_argument("--share-device", action="store_true",
+                    help="every rank uses GPU 0 (only with --backend gloo: exercises the real multi-rank launch path on one GPU)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -125,13 +172,20 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    if args.share_device:
+        if args.backend != "gloo":
+            raise SystemExit("--share-device needs --backend gloo (RCCL refuses two ranks on one device)")
+        local_rank = 0
     if local_rank >= torch.cuda.device_count():
         raise SystemExit("bench.py: rank %d has no GPU (only %d device(s) visible)" % (rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
+    coll_dev = "cuda" if args.backend == "nccl" else "cpu"  # where the three tiny collectives' tensors live
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     import microflow_rs_amd as mf
     from microflow_rs_amd import _lib
@@ -175,7 +229,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        elapsed = max_over_ranks(dist, elapsed, device="cuda")
+        elapsed = max_over_ranks(dist, elapsed, device=coll_dev)
     ms_per_step = elapsed / args.steps * 1e3
     value = B * world / (elapsed / args.steps)
 
@@ -183,17 +237,23 @@ def main():
     ev = event_times(torch, step, max(20, args.steps))
     ev_med = median(ev)
     if world > 1:
-        ev_med = max_over_ranks(dist, ev_med, device="cuda")
+        ev_med = max_over_ranks(dist, ev_med, device=coll_dev)
 
     # output checksums of every shard (outside the timed region; RCCL all_gather of 8 bytes)
     ck = checksum_i8(y)
     cks = [ck]
     if world > 1:
-        cks = gather_checksums(dist, ck, device="cuda")
+        cks = gather_checksums(dist, ck, device=coll_dev)
+        # The distributed part of the run ends HERE: everything below (per-kernel tables, parity, CPU baseline, the
+        # other workloads) is rank 0's alone and takes tens of seconds, so the process group is torn down first
+        # instead of leaving the other ranks parked in a collective.
         dist.barrier()
+        dist.destroy_process_group()
+        ctx["group_closed"] = True
 
     result = None
     if rank == 0:
+        measure_requant_ceiling()
         # ---- per-kernel HIP-event timing on the launch stream (median over the iterations) ----
         iters = max(5, min(args.steps, 20))
 
@@ -228,8 +288,10 @@ def main():
                 rows.append({"op": i, "kind": kind if nops_in_group <= 3 else "stage(%d ops)" % nops_in_group,
                              "kernel": d["kernel"], "ms": round(per_op[i], 4), "bound": bound,
                              "bytes": nbytes, "GBps": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4),
+                             "hbm_frac": round(gbs / HBM_PEAK_GBS, 4),
                              "requant_bytes": rq, "requant_GBps": round(rq_gbs, 1),
-                             "requant_frac": round(rq_gbs / REQUANT_PEAK_GBS, 4)})
+                             "requant_frac": round(rq_gbs / REQUANT_PEAK_GBS, 4),
+                             "valu_frac": round(rq_gbs / REQUANT_PEAK_GBS, 4)})
             return avg_ms, rows
 
         def agg(rows, kind):
@@ -241,41 +303,37 @@ def main():
                     "frac": round(gbs / HBM_PEAK_GBS, 4)}
 
         avg_ms, kernels = kernel_table()
-        longest = max(kernels, key=lambda k: k["ms"])
-        # `roofline` prices an HBM-bound kernel against HBM: the longest one of those.  If the longest launch of
-        # the step is VALU-bound (the on-chip stage kernel: 4.6 KB in and out per inference for ten operators; the
-        # stride-1 pairs, whose requantised bytes equal their HBM bytes while the requantisation ceiling is below the
-        # HBM roof), it is reported beside it against the requantisation ceiling (`longest_kernel`).
-        dom = max((k for k in kernels if k["bound"] == "hbm"), key=lambda k: k["ms"])
+        # `roofline` = the LONGEST launch of the step, whatever bounds it, with both fractions: algorithmic bytes / time
+        # against the 8 TB/s HBM peak (`frac` = `hbm_frac`) and requantised bytes / time against the requantisation
+        # ceiling measured in this run (`valu_frac`); `bound` names the roof with the longer time floor.
+        dom = max(kernels, key=lambda k: k["ms"])
         # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
         # (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; scripts/pmc_summary.py), if the batch matches
-        traffic, traffic_src = None, None
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")))
-            if pmc.get("per_gpu_batch") == count:
-                for k in pmc["kernels"]:
-                    if k["kernel"] == dom["kernel"]:
-                        traffic, traffic_src = k["traffic_bytes"], "profiles/pmc_traffic_latest.json"
-        except (OSError, ValueError, KeyError):
-            pass
-        roofline = {"bound": "hbm", "kernel": dom["kernel"], "op": dom["op"], "achieved": dom["GBps"],
-                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["frac"], "traffic": traffic,
-                    "traffic_source": traffic_src,
-                    "ms": dom["ms"], "algorithmic_bytes": dom["bytes"],
+        traffic, traffic_src = pmc_traffic(dom["kernel"], count)
+        roofline = {"bound": dom["bound"], "kernel": dom["kernel"], "op": dom["op"], "kind": dom["kind"], "ms": dom["ms"],
+                    "achieved": dom["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["frac"],
+                    "hbm_frac": dom["hbm_frac"], "valu_frac": dom["valu_frac"],
+                    "requant_GBps": dom["requant_GBps"], "requant_peak_GBps": REQUANT_PEAK_GBS,
+                    "algorithmic_bytes": dom["bytes"], "requant_bytes": dom["requant_bytes"],
+                    "traffic": traffic, "traffic_source": traffic_src,
                     "method": "HIP events on the launch stream, median of %d launches" % iters,
-                    "note": "the longest HBM-bound launch of the step; per kernel, `bound` in `kernels` is the roof with the "
-                            "longer time floor (algorithmic bytes / 8 TB/s vs requantised bytes / %.0f GB/s); launches that "
-                            "are VALU-bound are priced in `longest_kernel` and per kernel in `requant_frac`" % REQUANT_PEAK_GBS}
-        longest_kernel = None
-        if longest is not dom:
-            longest_kernel = {"bound": "valu", "kernel": longest["kernel"], "op": longest["op"], "ms": longest["ms"],
-                              "achieved": longest["requant_GBps"], "peak": REQUANT_PEAK_GBS, "unit": "GB/s of requantised int8",
-                              "frac": longest["requant_frac"], "hbm_GBps": longest["GBps"], "hbm_frac": longest["frac"],
-                              "note": "bounded by the reference's f32 requantisation of every int8 tensor the launch produces, on chip "
-                                      "or not (7-8 VALU instructions per byte); ceiling measured by scripts/ubench/epi_rate.hip"}
+                    "note": "the longest launch of the step.  achieved / peak / frac: algorithmic bytes per launch / its "
+                            "duration vs the 8 TB/s HBM peak; valu_frac: every int8 byte the launch requantises (on chip or "
+                            "not) / its duration vs the requantisation ceiling measured in this run (`requant_ceiling`); "
+                            "`bound` = the roof with the longer time floor"}
         step_bytes = sum(k["bytes"] for k in kernels)
-        whole_step = {"algorithmic_bytes": step_bytes, "GBps": round(step_bytes / (ev_med * 1e-3) / 1e9, 1),
-                      "frac": round(step_bytes / (ev_med * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        step_rq = sum(k["requant_bytes"] for k in kernels)
+        floor_ms = sum(max(k["bytes"] / HBM_PEAK_GBS, k["requant_bytes"] / REQUANT_PEAK_GBS) for k in kernels) / 1e6
+        whole_step = {"ms": round(ev_med, 4), "launches": len(kernels),
+                      "algorithmic_bytes": step_bytes, "GBps": round(step_bytes / (ev_med * 1e-3) / 1e9, 1),
+                      "frac": round(step_bytes / (ev_med * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                      "hbm_frac": round(step_bytes / (ev_med * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                      "requant_bytes": step_rq, "requant_GBps": round(step_rq / (ev_med * 1e-3) / 1e9, 1),
+                      "valu_frac": round(step_rq / (ev_med * 1e-3) / 1e9 / REQUANT_PEAK_GBS, 4),
+                      "roof_floor_ms": round(floor_ms, 4), "frac_of_roof_floor": round(floor_ms / ev_med, 4),
+                      "note": "all launches of the timed step: their algorithmic bytes / the step's median time vs 8 TB/s, their "
+                              "requantised bytes / the same time vs the measured ceiling; roof_floor_ms = sum over launches of "
+                              "max(bytes / 8 TB/s, requantised bytes / ceiling)"}
 
         # the same step with the fusions switched off: one kernel per reference operator
         # (the layer-wise DepthwiseConv2D / Conv2D roofline figures of BASELINE.json's targets)
@@ -366,18 +424,16 @@ def main():
             "vs_baseline": None, "dtype": "i8", "data": "synthetic",
             "config": {"workload": "%s batch=%d per GPU, predict_inner int8->int8, inputs resident in HBM"
                                    % (fname, B), "per_gpu_batch": B, "global_batch": B * world,
-                       "parallelism": "batch shard x%d, no data-path collective" % world},
+                       "parallelism": "batch shard x%d, no data-path collective" % world,
+                       "backend": (args.backend if world > 1 else None),
+                       "shards": [list(shard_range(B * world, r, world)) for r in range(world)]},
             "roofline": roofline,
-            "longest_kernel": longest_kernel,
+            "requant_ceiling": REQUANT_CEILING,
             "event_median": {"ms_per_step": round(ev_med, 4), "value": round(B * world / (ev_med * 1e-3), 1),
                              "iterations": len(ev), "min_ms": round(min(ev), 4), "max_ms": round(max(ev), 4),
                              "note": "HIP event pair per step on the launch stream, median; max over ranks"},
             "whole_step": whole_step,
             "fused_dwpw": agg(kernels, "depthwise_conv_2d+conv_2d"),
-            "requant_step": {"bytes": sum(k["requant_bytes"] for k in kernels),
-                             "GBps": round(sum(k["requant_bytes"] for k in kernels) / (ev_med * 1e-3) / 1e9, 1),
-                             "frac": round(sum(k["requant_bytes"] for k in kernels) / (ev_med * 1e-3) / 1e9 / REQUANT_PEAK_GBS, 4),
-                             "note": "all int8 bytes the step requantises / its median time, vs the requantisation ceiling"},
             "depthwise": layerwise["depthwise"], "conv_2d": layerwise["conv_2d"],
             "event_ms_per_step": round(avg_ms, 4),
             "kernels": kernels,
@@ -406,7 +462,7 @@ def main():
 
 def finish(ctx, result):
     dist, world, rank = ctx["dist"], ctx["world"], ctx["rank"]
-    if world > 1:
+    if world > 1 and not ctx.get("group_closed"):
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
@@ -523,7 +579,13 @@ def fc4096_record(ctx, steps, warmup, wzp=0):
     om = O.Model(synthetic_fc(len(rows), K, N, wzp=wzp, seed=5))
     want = om.run_quantized(x[rows].cpu().numpy()).reshape(len(rows), N)
     ok = bool(np.array_equal(y.reshape(M, N)[rows].cpu().numpy(), want))
+    crosscheck = None
+    if wzp == 0:
+        w_nk = torch.from_numpy(np.random.default_rng(5).integers(-128, 128, (N, K), dtype=np.int8)).cuda()  # = synthetic_fc's W
+        crosscheck = int8_gemm_crosscheck(torch, x, w_nk)
+        del w_nk
     return {
+        "crosscheck": crosscheck,
         "metric": "int8 GEMM TOP/s, FullyConnected 4096x4096x4096 via predict_inner",
         "value": round(ops / (elapsed / steps) / 1e12, 1), "unit": "TOP/s",
         "steps": steps, "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 4),
@@ -533,13 +595,73 @@ def fc4096_record(ctx, steps, warmup, wzp=0):
                      "peak": INT8_MFMA_PEAK_NOMINAL, "unit": "TOP/s", "frac": round(tops / INT8_MFMA_PEAK_NOMINAL, 4),
                      "peak_guide_floor": INT8_MFMA_PEAK_GUIDE_FLOOR,
                      "frac_of_guide_floor": round(tops / INT8_MFMA_PEAK_GUIDE_FLOOR, 4),
-                     "traffic": None, "ms": round(ms, 4), "algorithmic_ops": ops,
+                     "traffic": pmc_traffic("fc_mfma", None)[0], "traffic_source": pmc_traffic("fc_mfma", None)[1],
+                     "algorithmic_bytes": M * K + N * K + M * N,
+                     "ms": round(ms, 4), "algorithmic_ops": ops,
                      "method": "HIP events on the launch stream, median of %d steps (whole predict_inner: GEMM"
                                "%s)" % (len(ev), " + row-sum pre-pass" if wzp else ""),
                      "peak_note": "5033 = 2 x the ~2.5 PF dense bf16 MFMA peak (nominal); 3944 = the guide's measured "
                                   "int8 floor (MI355X_MICROARCH.md)"},
         "parity": {"bit_exact_vs_oracle": ok, "sampled_rows": len(rows)},
     }
+
+
+def int8_gemm_crosscheck(torch, x, w_nk, iters=20):
+    """What does a vendor int8 GEMM sustain on this chip on the SAME random operands?  (SURVEY.md 7 allows the BLAS
+    libraries as a cross-check; nothing here is linked into libmicroflow_amd.so.)  Tries torch._int_mm (hipBLASLt) and
+    rocBLAS gemm_ex through ctypes; int8 x int8 -> int32, NT layout like the FullyConnected kernel (both K-contiguous)."""
+    M, K = x.shape
+    N = w_nk.shape[0]
+    ops = 2.0 * M * K * N
+    out = {"operands": "the step's own x [%d,%d] and W [%d,%d] (uniform random int8)" % (M, K, N, K), "results": {}}
+    rows = [0, 1, M // 2, M - 1]
+    want = x[rows].cpu().numpy().astype(np.int32) @ w_nk.cpu().numpy().astype(np.int32).T
+
+    def timed(fn):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        return median(event_times(torch, fn, iters))
+
+    try:
+        wt = w_nk.t()  # [K, N] view, column-major = W's own memory
+        c = torch._int_mm(x, wt)
+        ok = bool(np.array_equal(c[rows].cpu().numpy(), want))
+        ms = timed(lambda: torch._int_mm(x, wt))
+        out["results"]["torch._int_mm"] = {"ms": round(ms, 4), "TOPs": round(ops / (ms * 1e-3) / 1e12, 1), "correct": ok,
+                                           "epilogue": "none (int32 out, 4x the output bytes of the fused kernel)"}
+    except Exception as e:  # noqa: BLE001
+        out["results"]["torch._int_mm"] = {"error": str(e)[:200]}
+    try:
+        import ctypes
+        rb = ctypes.CDLL("librocblas.so")
+        h = ctypes.c_void_p()
+        assert rb.rocblas_create_handle(ctypes.byref(h)) == 0
+        rb.rocblas_set_stream(h, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        c32 = torch.empty((M, N), dtype=torch.int32, device="cuda")
+        alpha, beta = ctypes.c_int32(1), ctypes.c_int32(0)
+        I8, I32, OP_N, OP_T = 160, 162, 111, 112  # rocblas_datatype_i8_r / i32_r, rocblas_operation_none / transpose
+        # column-major C^T [N, M] = W [N, K] (as A^T of a K x N column-major matrix) * X^T: A = W memory (K x N, lda K,
+        # transposed), B = X memory (K x M, ldb K, not transposed), C memory = row-major [M, N]
+        def gemm():
+            return rb.rocblas_gemm_ex(h, OP_T, OP_N, N, M, K, ctypes.byref(alpha),
+                                      ctypes.c_void_p(w_nk.data_ptr()), I8, K, ctypes.c_void_p(x.data_ptr()), I8, K,
+                                      ctypes.byref(beta), ctypes.c_void_p(c32.data_ptr()), I32, N,
+                                      ctypes.c_void_p(c32.data_ptr()), I32, N, I32, 0, 0, 0)
+        st = gemm()
+        torch.cuda.synchronize()
+        if st != 0:
+            raise RuntimeError("rocblas_gemm_ex status %d" % st)
+        ok = bool(np.array_equal(c32[rows].cpu().numpy(), want))
+        ms = timed(gemm)
+        out["results"]["rocblas_gemm_ex"] = {"ms": round(ms, 4), "TOPs": round(ops / (ms * 1e-3) / 1e12, 1), "correct": ok,
+                                             "epilogue": "none (int32 out)"}
+        rb.rocblas_destroy_handle(h)
+    except Exception as e:  # noqa: BLE001
+        out["results"]["rocblas_gemm_ex"] = {"error": str(e)[:200]}
+    best = [v["TOPs"] for v in out["results"].values() if v.get("correct")]
+    out["best_TOPs"] = max(best) if best else None
+    return out
 
 
 def cpu_baseline(om, x_dev_rows, seconds):

@@ -378,11 +378,23 @@ static void enqueue_device(ModelImpl *m, const float *in_f32, const int8_t *in_i
     } else if (pm.u8) { // u8 -> internal i8 domain
         dev_xor80(m->device, in_i8, batch * pm.in_elems, m->in_q, s);
         q_in = m->in_q;
+    } else if (((uintptr_t)in_i8 & 15) != 0) { // the fast kernels read 16-byte words: realign an odd caller pointer
+        MF_HIP(hipMemcpyAsync(m->in_q, in_i8, batch * pm.in_elems, hipMemcpyDeviceToDevice, s));
+        q_in = m->in_q;
     } else {
         q_in = in_i8; // consumed in place
     }
-    // an i8 model's result is written straight into the caller's buffer by the last launch
-    const int8_t *res = run_ops(m, q_in, batch, last_op, s, fuse_q ? in_f32 : nullptr, (out_i8 && !pm.u8 && ((uintptr_t)out_i8 & 15) == 0) ? out_i8 : nullptr); // (16-byte vector stores)
+    // An i8 model's result is written straight into the caller's buffer by the last launch -- unless that buffer overlaps
+    // the caller's input, which the first launch may still be reading (in_i8 is consumed in place): a model that is ONE
+    // launch would then read and write the same memory.  Overlapping buffers take the activation buffer + copy path.
+    int8_t *direct = (out_i8 && !pm.u8 && ((uintptr_t)out_i8 & 15) == 0) ? out_i8 : nullptr; // (16-byte vector stores)
+    if (direct) {
+        const uintptr_t ob = (uintptr_t)out_i8, oe = ob + batch * out_elems;
+        const uintptr_t ib = (uintptr_t)(in_f32 ? (const void *)in_f32 : (const void *)in_i8);
+        const uintptr_t ie = ib + batch * pm.in_elems * (in_f32 ? sizeof(float) : 1);
+        if (ob < ie && ib < oe) direct = nullptr;
+    }
+    const int8_t *res = run_ops(m, q_in, batch, last_op, s, fuse_q ? in_f32 : nullptr, direct);
     if (out_i8) {
         if (pm.u8) dev_xor80(m->device, res, batch * out_elems, out_i8, s);
         else if (res != out_i8) MF_HIP(hipMemcpyAsync(out_i8, res, batch * out_elems, hipMemcpyDeviceToDevice, s));

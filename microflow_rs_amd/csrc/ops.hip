@@ -532,7 +532,10 @@ void op_run(OpImpl *op, const int8_t *d_in, size_t batch, int8_t *d_out, void *s
     if (!d_in || !d_out) fail(MF_ERR_INVALID_ARG, "op_run: null device pointer");
     hipStream_t s = (hipStream_t)stream;
     const OpSpec &sp = op->s;
-    const bool fast = op->fast != OpImpl::NONE && !op->force_generic;
+    // the fast kernels move 4- and 16-byte words (vector loads, LDS-DMA, packed stores): buffers that are not 16-byte
+    // aligned -- an offset into a larger allocation handed to mf_op_run -- take the byte-wise shape-generic kernels
+    const bool aligned = (((uintptr_t)d_in | (uintptr_t)d_out) & 15) == 0;
+    const bool fast = op->fast != OpImpl::NONE && !op->force_generic && aligned;
     bool done = false;
     if (fast) {
         if (batch > 0x7fffffffull / 4) fail(MF_ERR_INVALID_ARG, "batch too large for one launch");

@@ -28,7 +28,7 @@ if [[ $STEPS == all || $STEPS == *bench* ]]; then
 import json
 try:
     r = json.loads(open("gpurun_out/bench.json").read().strip().splitlines()[-1])
-    print("value", r["value"], r["unit"], "ms/step", r["ms_per_step"], "roofline", r["roofline"])
+    print("value", r["value"], r["unit"], "ms/step", r["ms_per_step"], "roofline", r["roofline"]); print("whole_step", r["whole_step"]); print("ceiling", r["requant_ceiling"]); print("fc4096", {k: v for k, v in r.get("fc4096", {}).items() if k in ("value", "crosscheck", "roofline")})
     print("fused", r.get("fused_dwpw"))
     print("layerwise ms", r["layerwise"]["ms_per_step"], "depthwise", r["depthwise"], "conv", r["conv_2d"])
     for k in r["kernels"]:

@@ -11,7 +11,9 @@
 
 #include "../../microflow_rs_amd/csrc/k_common.hpp"
 
-#define ITERS 4096
+#ifndef ITERS
+#define ITERS 4096 // (the library build uses 256: the whole measurement then costs bench.py ~15 ms of GPU time)
+#endif
 #define NG 8 // independent dword groups per iteration
 
 using mf::k::pack4;

@@ -1,0 +1,44 @@
+"""bench.py's real multi-rank launch path, on the one GPU a test box has: `--gpus 2` self-launches two ranks under
+torch.distributed.run exactly as the driver's 8-GPU line does; `--backend gloo --share-device` only swaps RCCL (which
+refuses two ranks on one device) for gloo and puts both ranks on GPU 0.  Everything else -- rendezvous, shard ranges,
+the barrier + max-over-ranks timing, the checksum gather, the teardown before rank 0's single-rank extras -- is the
+code an 8-GPU node runs."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from tests.conftest import ROOT, model_path
+from tests.synth import layer_checksum, synth_i8
+
+pytestmark = pytest.mark.gpu
+
+
+def test_bench_two_ranks_share_one_device(O):
+    per_gpu, world = 64, 2
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "3", "--warmup", "1",
+           "--batch", str(per_gpu), "--no-extra", "--no-cpu-baseline", "--no-host-fed", "--backend", "gloo", "--share-device"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]          # rank 0 prints ONE line, the other rank none
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == world and rec["steps"] == 3 and rec["warmup"] == 1
+    assert rec["config"]["per_gpu_batch"] == per_gpu and rec["config"]["global_batch"] == world * per_gpu
+    assert rec["config"]["shards"] == [[0, per_gpu], [per_gpu, per_gpu]] and rec["config"]["backend"] == "gloo"
+    assert rec["scaling"] == "weak" and rec["parity"]["bit_exact_vs_oracle"] is True
+    assert abs(rec["value"] - world * per_gpu / (rec["ms_per_step"] * 1e-3)) <= 1e-3 * rec["value"]
+    # every shard's output checksum against the oracle's run over the same slice of the global stream
+    from microflow_rs_amd.shard import shard_range
+    om = O.Model(model_path("person_detect"))
+    want = []
+    for rank in range(world):
+        first, count = shard_range(world * per_gpu, rank, world)
+        y = om.run_quantized_batch(synth_i8(3, first, count, om.in_elems))
+        want.append("%016x" % (int(layer_checksum(y)) & 0x7FFFFFFFFFFFFFFF))
+    assert rec["parity"]["output_checksums"] == want
+    assert want[0] != want[1]
