@@ -168,7 +168,7 @@ __global__ __launch_bounds__(64 * WM * WN) void fc_mfma(const int8_t *__restrict
     // mapped to a PM x PN patch, which needs only PM X-panels + PN W-panels per k-step
     // through that XCD's L2 instead of ~1 + PM*PN for a row-major order.
     constexpr int PM = (BM == 128) ? 8 : 4, PN = 8;           // 64 resident 128^2 tiles, 32 256^2 tiles
-    const int tiles_m = p.M / BM, tiles_n = p.N / BN;
+    const int tiles_m = (p.M + BM - 1) / BM, tiles_n = p.N / BN; // a ragged last row tile re-reads row M-1 and stores nothing for it
     int tm, tn;
     {
         const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;   // j-th block of this XCD
@@ -182,8 +182,13 @@ __global__ __launch_bounds__(64 * WM * WN) void fc_mfma(const int8_t *__restrict
         }
     }
     const int K = p.K;
-    const int8_t *Xt = X + (size_t)tm * BM * K;
     const int8_t *Wt = p.w + (size_t)tn * BN * K;
+    // row `row` of this workgroup's X tile: rows past the matrix (ragged M) alias the last row -- their products are
+    // computed and dropped
+    auto xrow = [&](int row) {
+        const int g = tm * BM + row;
+        return X + (size_t)(g < p.M ? g : p.M - 1) * K;
+    };
 
     // DMA piece i (1 KiB) of a tile = rows 8i .. 8i+7; lane -> (row, swizzled 16-byte slot)
     auto stage = [&](int kt, int buf) {
@@ -191,7 +196,7 @@ __global__ __launch_bounds__(64 * WM * WN) void fc_mfma(const int8_t *__restrict
 #pragma unroll
         for (int j = 0; j < XP; ++j) {
             const int i = wave * XP + j, row = 8 * i + r8;
-            dma16(Xt + (size_t)row * K + (size_t)kt * BK + ((s8 ^ key(row)) << 4), lds + buf * BUF + i * 1024);
+            dma16(xrow(row) + (size_t)kt * BK + ((s8 ^ key(row)) << 4), lds + buf * BUF + i * 1024);
         }
 #pragma unroll
         for (int j = 0; j < WP; ++j) {
@@ -281,7 +286,7 @@ __global__ __launch_bounds__(64 * WM * WN) void fc_mfma(const int8_t *__restrict
             const int r8 = lane >> 3, s8 = lane & 7;
             if (j < XP) {
                 const int i = wave * XP + j, row = 8 * i + r8;
-                dma16(Xt + (size_t)row * K + (size_t)kt * BK + ((s8 ^ key(row)) << 4), lds + buf * BUF + i * 1024);
+                dma16(xrow(row) + (size_t)kt * BK + ((s8 ^ key(row)) << 4), lds + buf * BUF + i * 1024);
             } else {
                 const int i = wave * WP + (j - XP), row = 8 * i + r8;
                 dma16(Wt + (size_t)row * K + (size_t)kt * BK + ((s8 ^ key(row)) << 4), lds + buf * BUF + XT + i * 1024);
@@ -348,6 +353,7 @@ __global__ __launch_bounds__(64 * WM * WN) void fc_mfma(const int8_t *__restrict
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const int m = tm * BM + wm * (BM / WM) + mt * 32 + rho;
+            if (m >= p.M) continue; // ragged last row tile
             const int corr = p.rowsum ? p.wzp * p.rowsum[m] : 0; // x1 = wzp * row-sum of the input
             uint32_t d[4];
 #pragma unroll
@@ -398,7 +404,8 @@ bool launch_fc_rowwave(const int8_t *in, int8_t *out, const FcArgs &a, size_t ro
     }
 }
 bool fc_mfma_supported(size_t rows, int N, int K) {
-    return rows > 0 && rows % 128 == 0 && N % 128 == 0 && K % 128 == 0 && rows / 128 * (size_t)(N / 128) < (1u << 30);
+    // any row count from half a tile up (a ragged last tile is masked); N and K in whole 128s
+    return rows >= 64 && N % 128 == 0 && K % 128 == 0 && (rows + 127) / 128 * (size_t)(N / 128) < (1u << 30);
 }
 void launch_fc_rowsum(const int8_t *in, int *rowsum, size_t rows, int K, hipStream_t s) {
     hipLaunchKernelGGL(fc_rowsum, dim3(grid_for(rows, 4)), dim3(256), 0, s, in, rowsum, rows, K);
@@ -408,14 +415,14 @@ static void launch_fc_mfma_t(const int8_t *in, int8_t *out, const FcGemmArgs &a,
     constexpr int lds = 2 * (BM + BN) * 128;
     static LaunchState st;
     (void)prepared(st, fc_mfma<BM, BN, WM, WN, STAGGER>, 64 * WM * WN, lds);
-    const int grid = (a.M / BM) * (a.N / BN);
+    const int grid = ((a.M + BM - 1) / BM) * (a.N / BN);
     hipLaunchKernelGGL((fc_mfma<BM, BN, WM, WN, STAGGER>), dim3(grid), dim3(64 * WM * WN), lds, s, in, out, a);
 }
 void launch_fc_mfma(const int8_t *in, int8_t *out, const FcGemmArgs &a, hipStream_t s) {
     static const int force = [] { const char *e = getenv("MF_FC_TILE"); return e ? atoi(e) : 0; }();
     // 256 x 256 tiles halve the L2 -> LDS traffic per MAC; they need >= 256 tiles to fill the chip
-    const bool big = a.M % 256 == 0 && a.N % 256 == 0 && (size_t)(a.M / 256) * (a.N / 256) >= 192;
-    if ((big && force != 128) || (force == 256 && a.M % 256 == 0 && a.N % 256 == 0))
+    const bool big = a.N % 256 == 0 && (size_t)((a.M + 255) / 256) * (a.N / 256) >= 192;
+    if ((big && force != 128) || (force == 256 && a.N % 256 == 0))
         launch_fc_mfma_t<256, 256, 2, 4, true>(in, out, a, s);
     else
         launch_fc_mfma_t<128, 128, 2, 2, false>(in, out, a, s);

@@ -332,7 +332,7 @@ void launch_fc_generic(const int8_t *in, int8_t *out, const FcArgs &a, size_t ro
 bool launch_fc_rowwave(const int8_t *in, int8_t *out, const FcArgs &a, size_t rows, hipStream_t s);
 bool launch_fc_rowwave_softmax(const int8_t *in, int8_t *out, const FcArgs &a, const SoftmaxArgs &sm, size_t rows,
                                hipStream_t s);
-// int8 MFMA GEMM (M % 128 == 0, N % 128 == 0, K % 128 == 0)
+// int8 MFMA GEMM (M >= 64 rows -- a ragged last row tile is masked --, N % 128 == 0, K % 128 == 0)
 bool fc_mfma_supported(size_t rows, int N, int K);
 void launch_fc_rowsum(const int8_t *in, int *rowsum, size_t rows, int K, hipStream_t s);
 void launch_fc_mfma(const int8_t *in, int8_t *out, const FcGemmArgs &a, hipStream_t s);

@@ -567,7 +567,7 @@ void op_run(OpImpl *op, const int8_t *d_in, size_t batch, int8_t *d_out, void *s
             break;
         case OpImpl::FC_MFMA: {
             const size_t rows = batch * sp.M;
-            if (!k::fc_mfma_supported(rows, sp.N, sp.K)) break; // ragged row count: generic kernel
+            if (!k::fc_mfma_supported(rows, sp.N, sp.K)) break; // fewer than 64 rows: generic kernel
             k::FcGemmArgs g{};
             g.w = op->fc.w, g.A = op->fc.A, g.Kc = op->fc.Kc, g.wzp = op->fc.wzp, g.S = op->fc.S;
             g.lo_f = op->fc.lo_f, g.hi_f = op->fc.hi_f, g.M = (int)rows, g.N = sp.N, g.K = sp.K;

@@ -485,6 +485,49 @@ def test_last_launch_writes_exactly_the_result(mf, name, batch):
         assert (got[:lead] == 0x5A).all() and (got[lead + n_out:] == 0x5A).all(), (name, lead)
 
 
+@pytest.mark.parametrize("name,batch", [("speech", 21), ("person_detect", 5)])
+def test_unaligned_caller_input_pointer(mf, name, batch):
+    """A device input pointer that is not 16-byte aligned (an offset into a larger allocation): the fast kernels read
+    16-byte words, so the runtime realigns it instead of handing it to them."""
+    import torch
+    from microflow_rs_amd import _lib
+    m = mf.Model(model_path(name), device=0)
+    m.prepare(batch)
+    L = _lib.lib()
+    n_in = batch * m.input_elems
+    x0 = torch.randint(-128, 128, (n_in,), dtype=torch.int8, device="cuda")
+    big = torch.zeros(n_in + 64, dtype=torch.int8, device="cuda")
+    want = m.run_quantized(x0.reshape((batch,) + m.input_shape)).reshape(-1)
+    for lead in (3, 8):
+        big[lead:lead + n_in] = x0
+        out = torch.empty(batch * m.output_elems, dtype=torch.int8, device="cuda")
+        _lib.check(L.mf_model_run_quantized(m._h, big.data_ptr() + lead, batch, out.data_ptr(), _lib.MF_MEM_DEVICE))
+        torch.cuda.synchronize()
+        assert torch.equal(out, want), (name, lead)
+
+
+def test_single_launch_model_with_overlapping_buffers(mf):
+    """A model that is ONE launch (a single FullyConnected GEMM) called with the output buffer ON TOP of the input
+    buffer: the last launch normally writes straight into the caller's buffer, which here is still being read -- the
+    runtime must detect the overlap and go through its own activation buffer."""
+    import torch
+    from microflow_rs_amd import _lib
+    from tools.make_fc_model import synthetic_fc
+    M = K = N = 512
+    m = mf.model(synthetic_fc(M, K, N, wzp=0, seed=9))
+    m.prepare(1)
+    assert m.op(0)["kernel"] == "fc_mfma"
+    L = _lib.lib()
+    x = torch.randint(-128, 128, (M * K,), dtype=torch.int8, device="cuda")
+    want = m.run_quantized(x.reshape(1, M, K)).reshape(-1).clone()
+    for shift in (0, 4096):  # exactly in place / partially overlapping
+        buf = torch.zeros(M * K + M * N, dtype=torch.int8, device="cuda")
+        buf[shift:shift + M * K] = x
+        _lib.check(L.mf_model_run_quantized(m._h, buf.data_ptr() + shift, 1, buf.data_ptr(), _lib.MF_MEM_DEVICE))
+        torch.cuda.synchronize()
+        assert torch.equal(buf[:M * N], want), shift
+
+
 def test_boundary_quantisation_fast_division_is_exact(mf, O):
     """M::predict quantises x / scale + zp with a true division (src/quantize.rs:16-18).  The f32-input stem runs it
     as x * r + two fused corrections -- only after checking ALL 2^32 float inputs give the same byte.  Re-run that

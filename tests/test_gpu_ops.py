@@ -610,3 +610,34 @@ def test_models_without_saturating_pack():
     r = subprocess.run([sys.executable, "-c", _NO_SAT_SCRIPT.format(root=root)], env=env, capture_output=True,
                        text=True, timeout=600)
     assert r.returncode == 0 and "no-sat ok" in r.stdout, r.stdout + r.stderr
+
+
+# ---- FullyConnected GEMM: every row, ragged row counts, both tiles --------------------------
+@pytest.mark.parametrize("M,K,N", [(4096, 4096, 4096), (4099, 1024, 512), (193, 256, 384), (64, 128, 128), (1000, 640, 768)])
+def test_fc_mfma_equals_generic_kernel_on_every_row(mf, O, M, K, N):
+    """The MFMA GEMM against the shape-generic FullyConnected kernel over the WHOLE output matrix (the oracle checks of
+    the 4096^3 test sample 128 rows), including row counts that are not a multiple of the 128- / 256-row tile
+    (src/ops/fully_connected.rs:42-81 has no such restriction): the ragged last tile re-reads the last row and stores
+    nothing for the rows past it.  A few rows also go through the oracle."""
+    import torch
+    rng = np.random.default_rng(M * 31 + K)
+    x = rng.integers(-128, 128, (M, K)).astype(np.int8)
+    w = rng.integers(-128, 128, (N, K)).astype(np.int8)
+    c0 = rng.uniform(-3, 3, N).astype(f32)
+    c1 = f32(127.0 / (74 * 74 * 3 * np.sqrt(K)))
+    wzp, izp = -5, -128
+    c2 = (izp * w.astype(np.int64).sum(axis=1)).astype(np.int32)
+    c3 = int(K * izp * wzp)
+    op = mf.ops.prepare_fully_connected(M, w, wzp, 0.05, 3, mf.ops.FullyConnectedOptions(), (c0, c1, c2, c3))
+    assert op.kernel == "fc_mfma", op.kernel
+    xd = torch.as_tensor(x).cuda()
+    guard = torch.full((M * N + 4096,), 0x5A, dtype=torch.int8, device="cuda")   # the ragged tile must not write past row M-1
+    got = op(xd).clone()
+    op.set_generic(True)
+    assert op.kernel == "fc_generic"
+    want = op(xd)
+    assert torch.equal(got, want), int((got != want).sum())
+    rows = sorted({0, 1, M // 2, M - 2, M - 1})
+    ref = O.fully_connected(x[rows], w, wzp, 0.05, 3, 0, c0, c1, c2, c3)
+    assert np.array_equal(got.cpu().numpy().reshape(M, N)[rows], ref)
+    del guard
