@@ -355,15 +355,9 @@ def main():
         # blobs) spread the outputs over the whole range: they go through the same handle as one extra small batch.
         structured_ok, n_struct, n_distinct = True, 0, 0
         if m.input_elems == 96 * 96:
-            yy, xx = np.mgrid[0:96, 0:96]
-            imgs = [np.full((96, 96), v) for v in (-128, -90, -40, -1, 0, 37, 90, 127)]
-            imgs += [xx * 2.66 - 128, yy * 2.66 - 128, (xx + yy) * 1.33 - 128, 127 - xx * 2.66]
-            imgs += [np.where(((xx // k) + (yy // k)) % 2 == 0, 100, -100) for k in (1, 4, 16)]
-            imgs += [120 * np.exp(-((xx - cx) ** 2 + (yy - cy) ** 2) / (2.0 * sg * sg)) - 100
-                     for cx, cy, sg in ((48, 48, 10), (20, 70, 18), (70, 30, 30), (48, 48, 40), (10, 10, 6))]
-            rng = np.random.default_rng(11)
-            imgs += [np.clip(im + rng.normal(0, 12, (96, 96)), -128, 127) for im in imgs[8:16]]
-            xs2 = np.clip(np.round(np.stack(imgs)), -128, 127).astype(np.int8).reshape(len(imgs), -1)
+            from tests.synth import structured_images
+            xs2 = structured_images(96)
+            imgs = xs2
             want2 = om.run_quantized_batch(xs2)
             got2 = m.run_quantized(torch.from_numpy(xs2).cuda().reshape((len(imgs),) + m.input_shape)).reshape(len(imgs), -1).cpu().numpy()
             structured_ok = bool(np.array_equal(got2, want2))

@@ -104,6 +104,7 @@ SIGNATURES = {
     "mf_model_graph_launches": (C.c_ulonglong, [_vp]),
     "mf_synth_i8": (C.c_int, [C.c_int, C.c_uint64, C.c_uint64, C.c_size_t, _vp, _vp]),
     "mf_checksum_i8": (C.c_int, [C.c_int, _vp, C.c_size_t, C.POINTER(C.c_uint64), _vp]),
+    "mf_preprocess_softmax": (C.c_int, [C.c_float, C.c_int, _vp]),
     "mf_verify_quant_div": (C.c_int, [C.c_int, C.c_float, C.c_float, C.c_int, C.c_int, C.POINTER(C.c_uint64)]),
     "mf_selftest_rounding": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint64)]),
     "mf_selftest_requant": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int,

@@ -108,6 +108,13 @@ int mf_preprocess_average_pool_2d_u8(float input_scale, uint8_t input_zero_point
     })
 }
 
+int mf_preprocess_softmax(float input_scale, int is_u8, float *exp_table) {
+    MF_TRY({
+        MF_NEED(exp_table);
+        mf::h_softmax_table(input_scale, is_u8 != 0, exp_table);
+    })
+}
+
 // ---- 2. prepared operators ----------------------------------------------------
 static int check_act_arg(int a) {
     if (a != MF_ACT_NONE && a != MF_ACT_RELU && a != MF_ACT_RELU6)

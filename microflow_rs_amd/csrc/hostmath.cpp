@@ -70,6 +70,15 @@ int h_quantize_t(float x, float scale, int zp, bool u8) {
 // expf of the `libm` 0.2 crate (musl expf.c lineage): used on the HOST to build the
 // 256-entry exp table each softmax op needs (softmax inputs are int8, so only 256
 // arguments exist per op; src/ops/softmax.rs:20-21).  f32 throughout.
+// the 256 values expf(f32(q) * input_scale) a Softmax over int8 (or u8) inputs can meet (src/ops/softmax.rs:20-21):
+// entry = stored byte + 128 for i8 (q = entry - 128), the value itself for u8
+void h_softmax_table(float in_scale, bool u8, float *table256) {
+    for (int i = 0; i < 256; ++i) {
+        volatile float e = (float)(u8 ? i : i - 128) * in_scale;
+        table256[i] = h_expf(e);
+    }
+}
+
 float h_expf(float x) {
     const float LN2_HI = from_bits(0x3f317200u), LN2_LO = from_bits(0x35bfbe8eu);
     const float INV_LN2 = from_bits(0x3fb8aa3bu);

@@ -30,6 +30,7 @@ void set_last_error(const std::string &msg);
 // with -ffp-contract=off.
 float h_roundf(float x);                              // round half away from zero
 float h_expf(float x);                                // libm 0.2 (musl-derived) expf
+void h_softmax_table(float in_scale, bool u8, float *table256); // expf over the 256 possible Softmax inputs
 int8_t h_sat_i8(float x);                             // Rust `as i8`
 int8_t h_quantize(float x, float scale, int8_t zp);   // src/quantize.rs:16-18
 int h_quantize_t(float x, float scale, int zp, bool u8); // either element type

@@ -490,10 +490,7 @@ OpImpl *op_create(int device, const OpSpec &spec) {
         // (src/ops/softmax.rs:20-21), libm's algorithm evaluated on the host
         // (entry = stored byte + 128, which is q + 128 for i8 and q itself for u8)
         std::vector<float> table(256);
-        for (int i = 0; i < 256; ++i) {
-            volatile float e = (float)(s.u8 ? i : i - 128) * s.in_scale;
-            table[(size_t)i] = h_expf(e);
-        }
+        h_softmax_table(s.in_scale, s.u8, table.data());
         op->d_table.upload(table.data(), 256 * 4);
         k::SoftmaxArgs &a = op->sm;
         a.rows = s.M, a.cols = s.N, a.oscale = s.oscale, a.ozp_f = (float)s.ozp;

@@ -40,3 +40,19 @@ def layer_checksum(a):
     with np.errstate(over="ignore"):
         w = splitmix64(np.arange(u.size, dtype=np.uint64))
         return np.uint64(((u + np.uint64(1)) * w).sum(dtype=np.uint64))
+
+
+def structured_images(side=96):
+    """int8 [28, side*side]: constant levels, ramps, checkerboards, Gaussian blobs and noisy versions of them.
+    Uniform-noise inputs drive person_detect into nearly the same output for every image, which makes the final bytes a
+    weak witness of the late layers; these spread the outputs over the whole range (bench.py and the full-size test)."""
+    yy, xx = np.mgrid[0:side, 0:side]
+    k = (side - 1) / 255.0 * 0 + 255.0 / (side - 1)
+    imgs = [np.full((side, side), v) for v in (-128, -90, -40, -1, 0, 37, 90, 127)]
+    imgs += [xx * k - 128, yy * k - 128, (xx + yy) * k / 2 - 128, 127 - xx * k]
+    imgs += [np.where(((xx // c) + (yy // c)) % 2 == 0, 100, -100) for c in (1, 4, 16)]
+    imgs += [120 * np.exp(-((xx - cx * side) ** 2 + (yy - cy * side) ** 2) / (2.0 * (sg * side) ** 2)) - 100
+             for cx, cy, sg in ((0.5, 0.5, 0.1), (0.2, 0.73, 0.19), (0.73, 0.31, 0.31), (0.5, 0.5, 0.42), (0.1, 0.1, 0.06))]
+    rng = np.random.default_rng(11)
+    imgs += [np.clip(im + rng.normal(0, 12, (side, side)), -128, 127) for im in imgs[8:16]]
+    return np.clip(np.round(np.stack(imgs)), -128, 127).astype(np.int8).reshape(len(imgs), -1)

@@ -125,14 +125,24 @@ def test_full_size_properties(mf, models, O):
     m = models["person_detect"]
     B = 65536
     x = dsynth(SEED + 3, 0, B * m.input_elems).reshape((B,) + m.input_shape)
+    # 28 structured images (levels, ramps, checkerboards, blobs: they exercise the late layers, which noise barely
+    # does) planted across the batch, including the first / last image of a workgroup step and of the batch
+    from tests.synth import structured_images
+    st = structured_images(96)
+    spots = [0, 1, 2, 3, 4, 7, 8, 15, 16, 17, 255, 256, 4095, 4096, 16383, 16384, 21845, 32767, 32768, 40000, 43690,
+             49151, 49152, 60000, 65532, 65533, 65534, 65535][: len(st)]
+    x[spots] = torch.from_numpy(st).cuda().reshape((len(st),) + m.input_shape)
     y = m.run_quantized(x)
     m.sync()
     full = checksum_i8(y)
-    # sampled oracle check
-    idx = [0, 1, 777, 32767, 32768, 65535]
+    # sampled oracle check: the structured images + 68 noise images spread over the batch
+    idx = sorted(set(spots + [5, 777, 1023, 1024, 30000, 65531] + list(range(11, B, B // 62))))
+    assert len(idx) >= 96
     o = O.Model(model_path("person_detect"))
     xs = x[idx].cpu().numpy().reshape(len(idx), -1)
-    assert np.array_equal(y[idx].cpu().numpy().reshape(len(idx), -1), o.run_quantized_batch(xs))
+    want = o.run_quantized_batch(xs)
+    assert np.array_equal(y[idx].cpu().numpy().reshape(len(idx), -1), want)
+    assert len({tuple(r) for r in want.tolist()}) >= 20     # the sample really spreads over many different outputs
     # shard recombination (the multi-GPU decomposition on one device)
     y0 = m.run_quantized(x[: B // 2])
     y1 = m.run_quantized(x[B // 2:])
