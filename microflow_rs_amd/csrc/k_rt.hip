@@ -1,0 +1,367 @@
+// k_rt.hip -- the RUN-TIME-GEOMETRY fast kernels: DepthwiseConv2D 3x3 and Conv2D 1x1 for ANY height, width and
+// (multiple-of-4 / multiple-of-16) channel count, with or without weight zero points.
+//
+// (src/ops/depthwise_conv_2d.rs:28-105, src/ops/conv_2d.rs:28-108.)  The reference compiles for any shape -- its
+// shapes are const generics (depthwise_conv_2d.rs:28-49, conv_2d.rs:28-49).  The kernels in k_depthwise.hip /
+// k_pointwise.hip / k_fused*.hip are instantiated per (H, W, C, stride[, N]) row of the tables in kernels.hpp -- tuned
+// for person_detect.tflite.  An operator whose shape is in no table lands HERE instead of on the byte-wise `*_generic`
+// kernels: same staging (LDS-DMA into halo'd tiles), same v_perm / v_dot4 tap arithmetic, same MFMA pixel matrix, same
+// epilogue -- but every extent is a kernel argument, a large image is cut into row bands, and the weights of the 1x1
+// convolution live in LDS instead of registers.  Arithmetic contract and helpers: k_common.hpp.
+#include "k_common.hpp"
+
+namespace mf {
+namespace k {
+
+// ------------------------------------------------------------------------
+// dw3x3_rt -- DepthwiseConv2D 3x3, SAME, stride 1 or 2 (both axes), NHWC, C % 4 == 0.
+//
+//   step    : G whole images (small tensors) or ONE band of BH output rows of one image (large tensors); the dynamic
+//             step queue of k_common.hpp deals the steps.
+//   staging : the input rows a step needs (+ the halo rows above / below) by LDS-DMA, 1 KiB pieces, into tiles whose
+//             side pads hold the input zero point; a row outside the image is written with the zero point instead
+//             (band mode) or was filled once (whole-image mode).  Double buffered: the DMAs of the next step fly during
+//             this step's taps.
+//   task    : 2 output rows x 2 adjacent output pixels x 4 channels per lane (the dw_s1 / dw_s2 tasks of k_dwtask.hpp
+//             with the row pitch and the pixel pitch in registers).  A lane's 4 channels never change (the active
+//             thread count is a multiple of C / 4), so its 9 tap weights are registers.
+//   WZ      : non-zero weight zero points (depthwise_conv_2d.rs:57-63, :70-75): acc -= wzp[c] * sum of the window, the
+//             window sum being one more v_dot4 per filter row against the byte mask of the taps.
+// ------------------------------------------------------------------------
+template <int S, bool WZ, int MG, uint32_t XR4>
+__global__ __launch_bounds__(512) void dw3x3_rt(const int8_t *__restrict__ in, int8_t *__restrict__ out, DwRtArgs p, int batch) {
+    constexpr int NTHR = 512, NWAVE = 8, R = 2;
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int C = p.C, C4 = C >> 2, ROW = p.ROW, LP = p.LP, TILE = p.TILE, BUF = p.BUF, G = p.G, RB = p.RB;
+    const int H = p.H, OH = p.OH, OW = p.OW, ROWB = p.W * C, BH = p.BH, NBANDS = p.NBANDS;
+    const int OWP = (OW + 1) >> 1, OHR = BH >> 1;
+
+    DynSteps dq;
+    dq.init(lds + 2 * BUF + 256, p.dw.queue, tid, p.dw.qcfg);
+    for (int i = tid; i < (2 * BUF + 256) / 16; i += NTHR) ((uint4 *)lds)[i] = make_uint4(p.dw.izp4, p.dw.izp4, p.dw.izp4, p.dw.izp4);
+
+    // ---- per-lane constants ----
+    const int PPT = NTHR / C4;                       // pixel-pair tasks per pass of the workgroup
+    const bool active = tid < PPT * C4;
+    const int cg = tid % C4, pp0 = tid / C4;
+    uint32_t wA[3][4], wB[3][4];                     // (w0,w1,w2,0) and (0,w0,w1,w2) per filter row and channel (wB: stride 1)
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const uint32_t w0 = ((const uint32_t *)p.dw.w)[(ky * 3 + 0) * C4 + cg];
+        const uint32_t w1 = ((const uint32_t *)p.dw.w)[(ky * 3 + 1) * C4 + cg];
+        const uint32_t w2 = ((const uint32_t *)p.dw.w)[(ky * 3 + 2) * C4 + cg];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            wA[ky][k] = ((w0 >> (8 * k)) & 0xffu) | (((w1 >> (8 * k)) & 0xffu) << 8) | (((w2 >> (8 * k)) & 0xffu) << 16);
+            wB[ky][k] = wA[ky][k] << 8;
+        }
+    }
+    const float4 A = ((const float4 *)p.dw.A)[cg], Sc = ((const float4 *)p.dw.S)[cg];
+    const int4 Kc = magic4<MG>(((const int4 *)p.dw.Kc)[cg]);
+    int4 wz = make_int4(0, 0, 0, 0);
+    if constexpr (WZ) wz = ((const int4 *)p.wzp)[cg];
+    // first task of this lane in a step, and the carry-free increments of one pass (PPT pixel pairs further)
+    const int per_img = OHR * OWP;
+    int g0 = pp0 / per_img, rp0 = (pp0 % per_img) / OWP, xp0 = pp0 % OWP;
+    const int dx = PPT % OWP, drow = PPT / OWP, dr = drow % OHR, dg = drow / OHR;
+    __syncthreads(); // zero-point fill complete before any DMA lands
+
+    auto stage = [&](int st, int buf) {
+        const int band = st % NBANDS, ist = st / NBANDS;
+        const int yfirst = band * BH * S - 1;        // input row held by tile row 0
+        for (int g = 0; g < G; ++g) {
+            const long img = (long)ist * G + g;
+            if (img >= batch) break;
+            for (int r = wave; r < RB; r += NWAVE) {
+                const int y = yfirst + r;
+                uint8_t *dst = lds + buf * BUF + g * TILE + r * ROW + LP;
+                if (y >= 0 && y < H) {
+                    const int8_t *src = in + (img * H + y) * (long)ROWB;
+                    for (int o = 0; o < ROWB; o += 1024)
+                        if (o + lane * 16 < ROWB) dma16(src + o + lane * 16, dst + o);
+                } else if (NBANDS > 1) {             // band mode: this tile row is padding in this step only
+                    for (int o = lane * 16; o < ROWB; o += 1024) *(uint4 *)(dst + o) = make_uint4(p.dw.izp4, p.dw.izp4, p.dw.izp4, p.dw.izp4);
+                }
+            }
+        }
+    };
+
+    const int nsteps = ((batch + G - 1) / G) * NBANDS;
+    int cur = 0;
+    if (dq.step < nsteps) stage(dq.step, 0);
+    for (; dq.step < nsteps; dq.advance(tid), cur ^= 1) {
+        const int step = dq.step;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        dq.top(tid);
+        if (dq.nxt < nsteps) stage(dq.nxt, cur ^ 1);
+
+        const int band = step % NBANDS, ist = step / NBANDS;
+        const int gvalid = min(G, batch - ist * G);
+        const int oyb = band * BH;
+        const uint8_t *tile = lds + cur * BUF;
+        uint32_t *dst = (uint32_t *)out + (size_t)ist * G * OH * OW * C4;
+        int g = g0, rp = rp0, xp = xp0;
+        while (active && g < gvalid) {
+            const int oy0 = oyb + R * rp, ox0 = 2 * xp;
+            if (oy0 < OH) {
+                const uint8_t *base = tile + g * TILE + (R * rp * S) * ROW + LP + (ox0 * S - 1) * C + cg * 4;
+                int o0[R][4], o1[R][4], s0[R][4], s1[R][4];
+#pragma unroll
+                for (int j = 0; j < R; ++j) {
+                    o0[j][0] = o1[j][0] = Kc.x, o0[j][1] = o1[j][1] = Kc.y, o0[j][2] = o1[j][2] = Kc.z, o0[j][3] = o1[j][3] = Kc.w;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) s0[j][k] = s1[j][k] = 0;
+                }
+                constexpr int NIN = S == 1 ? R + 2 : 2 * R + 1; // input rows of the task
+                const uint8_t *rowp = base;
+#pragma unroll
+                for (int r = 0; r < NIN; ++r, rowp += ROW) {
+                    const uint32_t v0 = *(const uint32_t *)(rowp);
+                    const uint32_t v1 = *(const uint32_t *)(rowp + C);
+                    const uint32_t v2 = *(const uint32_t *)(rowp + 2 * C);
+                    const uint32_t v3 = *(const uint32_t *)(rowp + 3 * C);
+                    const uint32_t ab_lo = __builtin_amdgcn_perm(v1, v0, 0x05010400u), ab_hi = __builtin_amdgcn_perm(v1, v0, 0x07030602u);
+                    const uint32_t cd_lo = __builtin_amdgcn_perm(v3, v2, 0x05010400u), cd_hi = __builtin_amdgcn_perm(v3, v2, 0x07030602u);
+                    uint32_t win[4], winb[4];
+                    win[0] = __builtin_amdgcn_perm(cd_lo, ab_lo, 0x05040100u), win[1] = __builtin_amdgcn_perm(cd_lo, ab_lo, 0x07060302u);
+                    win[2] = __builtin_amdgcn_perm(cd_hi, ab_hi, 0x05040100u), win[3] = __builtin_amdgcn_perm(cd_hi, ab_hi, 0x07060302u);
+                    if constexpr (S == 2) {          // [v2, v3, v4 (byte k of the fifth pixel), 0]
+                        const uint32_t v4 = *(const uint32_t *)(rowp + 4 * C);
+                        winb[0] = __builtin_amdgcn_perm(v4, win[0], 0x0c040302u), winb[1] = __builtin_amdgcn_perm(v4, win[1], 0x0c050302u);
+                        winb[2] = __builtin_amdgcn_perm(v4, win[2], 0x0c060302u), winb[3] = __builtin_amdgcn_perm(v4, win[3], 0x0c070302u);
+                    }
+#pragma unroll
+                    for (int j = 0; j < R; ++j) {
+                        const int ky = r - S * j;    // filter row this input row plays for output row j
+                        if (ky >= 0 && ky <= 2) {
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                if constexpr (S == 1) {
+                                    o0[j][k] = sdot4(win[k], wA[ky][k], o0[j][k]);
+                                    o1[j][k] = sdot4(win[k], wB[ky][k], o1[j][k]);
+                                    if constexpr (WZ) s0[j][k] = sdot4(win[k], 0x00010101u, s0[j][k]), s1[j][k] = sdot4(win[k], 0x01010100u, s1[j][k]);
+                                } else {
+                                    o0[j][k] = sdot4(win[k], wA[ky][k], o0[j][k]);
+                                    o1[j][k] = sdot4(winb[k], wA[ky][k], o1[j][k]);
+                                    if constexpr (WZ) s0[j][k] = sdot4(win[k], 0x00010101u, s0[j][k]), s1[j][k] = sdot4(winb[k], 0x00010101u, s1[j][k]);
+                                }
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < R; ++j) {
+                    if (oy0 + j < OH) {
+                        if constexpr (WZ) {
+                            o0[j][0] -= wz.x * s0[j][0], o0[j][1] -= wz.y * s0[j][1], o0[j][2] -= wz.z * s0[j][2], o0[j][3] -= wz.w * s0[j][3];
+                            o1[j][0] -= wz.x * s1[j][0], o1[j][1] -= wz.y * s1[j][1], o1[j][2] -= wz.z * s1[j][2], o1[j][3] -= wz.w * s1[j][3];
+                        }
+                        uint32_t *dp = dst + ((size_t)(g * OH + oy0 + j) * OW + ox0) * C4 + cg;
+                        dp[0] = requant_pack4<MG, XR4>(o0[j][0], o0[j][1], o0[j][2], o0[j][3], A, Sc, p.dw.lo_f, p.dw.hi_f);
+                        if (ox0 + 1 < OW) dp[C4] = requant_pack4<MG, XR4>(o1[j][0], o1[j][1], o1[j][2], o1[j][3], A, Sc, p.dw.lo_f, p.dw.hi_f);
+                    }
+                }
+            }
+            // next task of this lane: PPT pixel pairs further (single carries by construction)
+            xp += dx, rp += dr, g += dg;
+            if (xp >= OWP) xp -= OWP, ++rp;
+            if (rp >= OHR) rp -= OHR, ++g;
+        }
+    }
+    dq.finish(tid);
+}
+
+// ------------------------------------------------------------------------
+// pw_rt -- Conv2D 1x1, stride 1, as an int8 MFMA product over the batch's pixel matrix: K % 16 == 0 input channels
+// (the host presents K = 8 / K = 4 as K = 16 on pixel pairs / quads with block-diagonal weights), N % 4 == 0 outputs.
+//
+//   weights : operand A of v_mfma_i32_16x16x64_i8 for every (16-channel tile, 64-deep k step), built by the host
+//             ([tile][k step][lane] x 16 bytes, zero beyond K and N), copied to LDS once per workgroup.
+//   pixels  : a wave takes 16 pixels at a time; lane (column, g) loads its 16 operand bytes of each k step straight
+//             from HBM in MFMA layout (the [pixel][K] matrix IS the batch), all k steps before the first MFMA.
+//   results : a lane ends a tile with 4 consecutive channels of its pixel = one packed dword, written to a per-wave
+//             LDS patch [16 pixels][N]; the patch is 16 N contiguous output bytes and leaves with 16-byte stores.
+//   WZ      : weight zero points (conv_2d.rs:57-63): acc -= wzp[n] * sum_k x[pixel][k], the row sum coming from one
+//             more MFMA tile of ones.
+// ------------------------------------------------------------------------
+template <bool WZ, int MG, uint32_t XR4>
+__global__ __launch_bounds__(256) void pw_rt(const int8_t *__restrict__ in, int8_t *__restrict__ out, PwRtArgs p, long long npix) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int K = p.K, N = p.N, KS = p.KS, NT = p.NT;
+    const int WBYTES = NT * KS * 1024;               // operand A image (+ the ones tile when WZ)
+    const int CONST_OFF = WBYTES + (WZ ? KS * 1024 : 0);
+    const int NP = NT * 16;                          // padded channel count of the constant tables
+    const int PATCH_OFF = CONST_OFF + NP * 16;       // A, S, Kc, wzp: four dwords per channel
+    const int PITCH = p.patch_pitch;                 // bytes per pixel row of a patch (N rounded up to 16)
+    for (int i = tid; i < CONST_OFF / 16; i += 256) ((uint4 *)lds)[i] = ((const uint4 *)p.wprep)[i];
+    for (int i = tid; i < NP; i += 256) {
+        const bool in_range = i < N;
+        ((float *)(lds + CONST_OFF))[i] = in_range ? p.A[i] : 0.0f;
+        ((float *)(lds + CONST_OFF + NP * 4))[i] = in_range ? p.S[i] : 0.0f;
+        ((int *)(lds + CONST_OFF + NP * 8))[i] = (in_range ? p.Kc[i] : 0) + (MG != 0 ? MF_MAGIC_I : 0);
+        ((int *)(lds + CONST_OFF + NP * 12))[i] = (WZ && in_range) ? p.wzp[i] : 0;
+    }
+    __syncthreads();
+    const int col = lane & 15, g = lane >> 4;
+    uint8_t *patch = lds + PATCH_OFF + wave * 16 * PITCH;
+    const long long nchunks = (npix + 15) / 16;
+    constexpr int KSMAX = 8;                         // K <= 512
+    for (long long chunk = (long long)blockIdx.x * 4 + wave; chunk < nchunks; chunk += (long long)gridDim.x * 4) {
+        long long pix = chunk * 16 + col;
+        pix = pix < npix ? pix : npix - 1;           // a ragged last chunk re-reads the last pixel
+        const int8_t *src = in + pix * K;
+        v4i B[KSMAX];
+#pragma unroll
+        for (int ks = 0; ks < KSMAX; ++ks) {
+            if (ks < KS) {
+                // the last k step may hang over K: those lanes' weights are zero, any readable bytes of the row will do
+                const int k0 = ks * 64 + g * 16;
+                B[ks] = *(const v4i *)(src + (k0 < K ? k0 : 0));
+            }
+        }
+        int rowsum = 0;
+        if constexpr (WZ) {
+            v4i acc = {0, 0, 0, 0};
+#pragma unroll
+            for (int ks = 0; ks < KSMAX; ++ks)
+                if (ks < KS) acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(*(const v4i *)(lds + WBYTES + ks * 1024 + lane * 16), B[ks], acc, 0, 0, 0);
+            rowsum = acc[0];                         // every row of the ones tile is sum_k x[pixel][k]
+        }
+        for (int nt = 0; nt < NT; ++nt) {
+            const int ch = nt * 16 + g * 4;
+            const int4 kc = *(const int4 *)(lds + CONST_OFF + NP * 8 + ch * 4);
+            v4i acc = {kc.x, kc.y, kc.z, kc.w};
+#pragma unroll
+            for (int ks = 0; ks < KSMAX; ++ks)
+                if (ks < KS) acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(*(const v4i *)(lds + (nt * KS + ks) * 1024 + lane * 16), B[ks], acc, 0, 0, 0);
+            if constexpr (WZ) {
+                const int4 wz = *(const int4 *)(lds + CONST_OFF + NP * 12 + ch * 4);
+                acc[0] -= wz.x * rowsum, acc[1] -= wz.y * rowsum, acc[2] -= wz.z * rowsum, acc[3] -= wz.w * rowsum;
+            }
+            const float4 a = *(const float4 *)(lds + CONST_OFF + ch * 4), s = *(const float4 *)(lds + CONST_OFF + NP * 4 + ch * 4);
+            const uint32_t d = requant_pack4<MG, XR4>(acc[0], acc[1], acc[2], acc[3], a, s, p.lo_f, p.hi_f);
+            if (ch < N) *(uint32_t *)(patch + col * PITCH + ch) = d;
+        }
+        __builtin_amdgcn_wave_barrier();
+        // patch rows are N bytes of consecutive pixels: 16 N contiguous output bytes (the last chunk may be short)
+        const long long first = chunk * 16;
+        const int valid = (int)((npix - first) < 16 ? (npix - first) : 16);
+        int8_t *o = out + first * N;
+        if (PITCH == N) {
+            for (int off = lane * 16; off < valid * N; off += 1024) *(uint4 *)(o + off) = *(const uint4 *)(patch + off);
+        } else {                                     // N not a multiple of 16: dword granularity, row by row
+            const int n4 = N >> 2;
+            for (int e = lane; e < valid * n4; e += 64) {
+                const int r = e / n4, c = e - r * n4;
+                *(uint32_t *)(o + (size_t)r * N + c * 4) = *(const uint32_t *)(patch + r * PITCH + c * 4);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ---- launchers ----
+bool dw_rt_plan(DwRtArgs &a, int H, int W, int C, int S, int OH, int OW) {
+    if (C % 4 != 0 || C / 4 > 512 || (S != 1 && S != 2) || (W * C) % 16 != 0) return false;
+    const int LP = ((C < 16 ? 16 : C) + 15) & ~15;
+    const int ROW = LP + W * C + LP;
+    constexpr int BUDGET = 36 * 1024;                // per staging buffer: two buffers, two workgroups per CU
+    auto rows_for = [&](int bh) { return (S == 1 ? bh + 2 : 2 * bh + 1) + 1; }; // + 1: the masked row of an odd last pair
+    const int OHE = (OH + 1) & ~1;
+    a.H = H, a.W = W, a.C = C, a.OH = OH, a.OW = OW, a.ROW = ROW, a.LP = LP;
+    if (rows_for(OHE) * ROW <= BUDGET) {
+        a.NBANDS = 1, a.BH = OHE, a.RB = rows_for(OHE), a.TILE = a.RB * ROW;
+        int g = BUDGET / a.TILE;
+        a.G = g < 1 ? 1 : (g > 16 ? 16 : g);
+    } else {
+        int bh = OHE;
+        while (bh > 2 && rows_for(bh) * ROW > BUDGET) bh -= 2;
+        if (rows_for(bh) * ROW > 64 * 1024) return false; // a single row pair does not fit: the row is too wide
+        a.BH = bh, a.NBANDS = (OH + bh - 1) / bh, a.RB = rows_for(bh), a.TILE = a.RB * ROW, a.G = 1;
+    }
+    a.BUF = a.G * a.TILE;
+    return 2 * a.BUF + 256 + 16 <= 160 * 1024;
+}
+template <int S, bool WZ, int MG, uint32_t XR4>
+static void launch_dw_rt_t(const int8_t *in, int8_t *out, const DwRtArgs &a, int batch, hipStream_t s) {
+    const int lds = 2 * a.BUF + 256 + 16;
+    // occupancy depends on the run-time LDS size: ask per launch (cheap) instead of caching per instance
+    (void)hipFuncSetAttribute((const void *)dw3x3_rt<S, WZ, MG, XR4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    int per_cu = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dw3x3_rt<S, WZ, MG, XR4>, 512, (size_t)lds) != hipSuccess || per_cu < 1) {
+        (void)hipGetLastError();
+        per_cu = 1;
+    }
+    const int nsteps = ((batch + a.G - 1) / a.G) * a.NBANDS;
+    const int grid = nsteps < 256 * per_cu ? nsteps : 256 * per_cu;
+    DwRtArgs b = a;
+    const double opix = (double)a.OH * a.OW;
+    b.dw.qcfg = dq_config(nsteps, grid, dq_est_us((double)batch * ((double)a.H * a.W * a.C + opix * a.C), (double)batch * opix * a.C));
+    hipLaunchKernelGGL((dw3x3_rt<S, WZ, MG, XR4>), dim3(grid), dim3(512), lds, s, in, out, b, batch);
+}
+void launch_dw_rt(const int8_t *in, int8_t *out, const DwRtArgs &a, int S, bool wz, int batch, hipStream_t s) {
+    const int mg = a.dw.magic;
+#define MF_RT_GO(SS, WZZ)                                                                          \
+    do {                                                                                           \
+        if (a.dw.xr) {                                                                             \
+            if (mg == 2) launch_dw_rt_t<SS, WZZ, 2, 0x80808080u>(in, out, a, batch, s);            \
+            else if (mg) launch_dw_rt_t<SS, WZZ, 1, 0x80808080u>(in, out, a, batch, s);            \
+            else launch_dw_rt_t<SS, WZZ, 0, 0x80808080u>(in, out, a, batch, s);                    \
+        } else {                                                                                   \
+            if (mg == 2) launch_dw_rt_t<SS, WZZ, 2, 0u>(in, out, a, batch, s);                     \
+            else if (mg) launch_dw_rt_t<SS, WZZ, 1, 0u>(in, out, a, batch, s);                     \
+            else launch_dw_rt_t<SS, WZZ, 0, 0u>(in, out, a, batch, s);                             \
+        }                                                                                          \
+    } while (0)
+    if (S == 1) { if (wz) MF_RT_GO(1, true); else MF_RT_GO(1, false); }
+    else { if (wz) MF_RT_GO(2, true); else MF_RT_GO(2, false); }
+#undef MF_RT_GO
+}
+
+int pw_rt_lds_bytes(int K, int N, bool wz) {
+    const int KS = (K + 63) / 64, NT = (N + 15) / 16;
+    return NT * KS * 1024 + (wz ? KS * 1024 : 0) + NT * 16 * 16 + 4 * 16 * ((N + 15) & ~15);
+}
+bool pw_rt_supported(int K, int N, bool wz) {
+    return K % 16 == 0 && K >= 16 && K <= 512 && N % 4 == 0 && N >= 4 && pw_rt_lds_bytes(K, N, wz) <= 96 * 1024;
+}
+template <bool WZ, int MG, uint32_t XR4>
+static void launch_pw_rt_t(const int8_t *in, int8_t *out, const PwRtArgs &a, long long npix, hipStream_t s) {
+    const int lds = pw_rt_lds_bytes(a.K, a.N, WZ);
+    (void)hipFuncSetAttribute((const void *)pw_rt<WZ, MG, XR4>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    int per_cu = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pw_rt<WZ, MG, XR4>, 256, (size_t)lds) != hipSuccess || per_cu < 1) {
+        (void)hipGetLastError();
+        per_cu = 1;
+    }
+    const long long nchunks = (npix + 15) / 16;
+    const long long want = (nchunks + 3) / 4;
+    const int cap = 256 * per_cu;                    // persistent: the weight image is copied to LDS once per workgroup
+    const int grid = (int)(want < cap ? want : cap);
+    hipLaunchKernelGGL((pw_rt<WZ, MG, XR4>), dim3(grid), dim3(256), lds, s, in, out, a, npix);
+}
+void launch_pw_rt(const int8_t *in, int8_t *out, const PwRtArgs &a, bool wz, long long npix, hipStream_t s) {
+    const int mg = a.magic;
+#define MF_RT_GO(WZZ)                                                                              \
+    do {                                                                                           \
+        if (a.xr) {                                                                                \
+            if (mg == 2) launch_pw_rt_t<WZZ, 2, 0x80808080u>(in, out, a, npix, s);                 \
+            else if (mg) launch_pw_rt_t<WZZ, 1, 0x80808080u>(in, out, a, npix, s);                 \
+            else launch_pw_rt_t<WZZ, 0, 0x80808080u>(in, out, a, npix, s);                         \
+        } else {                                                                                   \
+            if (mg == 2) launch_pw_rt_t<WZZ, 2, 0u>(in, out, a, npix, s);                          \
+            else if (mg) launch_pw_rt_t<WZZ, 1, 0u>(in, out, a, npix, s);                          \
+            else launch_pw_rt_t<WZZ, 0, 0u>(in, out, a, npix, s);                                  \
+        }                                                                                          \
+    } while (0)
+    if (wz) MF_RT_GO(true); else MF_RT_GO(false);
+#undef MF_RT_GO
+}
+
+} // namespace k
+} // namespace mf

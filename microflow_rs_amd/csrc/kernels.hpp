@@ -122,6 +122,32 @@ struct PwArgs {
     int magic, xr;
 };
 
+// run-time-geometry kernels (k_rt.hip): any H, W, C
+struct DwRtArgs {
+    DwFastArgs dw;      // weights [3][3][C], folded constants, clamp, epilogue mode, step queue
+    const int *wzp;     // [C] weight zero points (the WZ instance only)
+    int H, W, C, OH, OW;
+    int G;              // whole images per step (1 in band mode)
+    int BH, NBANDS;     // output rows per band (even) and bands per image (1 = whole images)
+    int RB;             // tile rows staged per image / band
+    int ROW, LP, TILE, BUF; // tile row pitch, side pad, bytes per staged image, bytes per staging buffer
+};
+struct PwRtArgs {
+    const void *wprep;  // [16-channel tile][64-deep k step][lane] x 16 bytes (+ a tile of ones per k step when wzp != 0)
+    const float *A;
+    const float *S;
+    const int *Kc;
+    const int *wzp;     // [N] (the WZ instance only)
+    float lo_f, hi_f;
+    int K, N, KS, NT;   // KS = ceil(K / 64), NT = ceil(N / 16)
+    int patch_pitch;    // N rounded up to 16
+    int magic, xr;
+};
+bool dw_rt_plan(DwRtArgs &a, int H, int W, int C, int S, int OH, int OW); // fills the geometry; false: not supported
+void launch_dw_rt(const int8_t *in, int8_t *out, const DwRtArgs &a, int S, bool wz, int batch, hipStream_t s);
+bool pw_rt_supported(int K, int N, bool wz);
+void launch_pw_rt(const int8_t *in, int8_t *out, const PwRtArgs &a, bool wz, long long npix, hipStream_t s);
+
 // fused DepthwiseConv2D 3x3 -> Conv2D 1x1: both argument blocks
 struct DwPwArgs {
     DwFastArgs dw;

@@ -89,7 +89,7 @@ struct OpImpl {
     bool accepts_f32 = false;  // op_set_input_quant succeeded: op_run_f32 may replace quantize + op_run
     bool finite_consts = true; // A / S all finite (the shape-specialised and fused epilogues assume it)
     std::string generic_name, fast_name;
-    enum Fast { NONE, DW_NHWC, DW_STEM, DW_C1, PW_MFMA, FC_ROWWAVE, FC_MFMA, POOL_C4, CONV1X1_ROW } fast = NONE;
+    enum Fast { NONE, DW_NHWC, DW_STEM, DW_C1, PW_MFMA, FC_ROWWAVE, FC_MFMA, POOL_C4, CONV1X1_ROW, DW_RT, PW_RT } fast = NONE;
     int *d_rowsum = nullptr; // FC_MFMA with wzp != 0: per-row input sums
     size_t rowsum_cap = 0;
     int8_t *d_ext = nullptr; // op_run_external on a u8 operator: input moved to the i8 domain
@@ -105,6 +105,12 @@ struct OpImpl {
     k::DwFastArgs dwf{};
     k::DwStemArgs stem{};
     k::PwArgs pw{};
+    // run-time-geometry kernels (k_rt.hip): shapes outside the tables of kernels.hpp
+    k::DwRtArgs dwrt{};
+    k::PwRtArgs pwrt{};
+    bool rt_wz = false;    // non-zero weight zero points
+    int pw_group = 1;      // pixels presented as one row of the 1x1 product (K = 8 -> 2, K = 4 -> 4)
+    DevBuf d_rtA, d_rtS, d_rtKc, d_rtwzp; // constants replicated per group member
 };
 
 namespace {
@@ -245,6 +251,33 @@ std::vector<int8_t> build_pw_rr_weights(const int8_t *w /*[N][K]*/, int K, int N
     return out;
 }
 
+// Operand A of v_mfma_i32_16x16x64_i8 for pw_rt (k_rt.hip): [16-row tile nt][k step ks][lane][16 bytes]; lane (r, g) holds
+// K-bytes 64 ks + 16 g .. + 15 of row 16 nt + r.  `group` pixels form one row of the product: row gi * N + n multiplies
+// only the K-bytes gj * K .. of its own pixel (block diagonal).  With `ones`, KS more KiB follow: a tile whose every row
+// is 1 on the real K-bytes (the row sum a weight zero point needs).
+std::vector<int8_t> build_pw_rt_weights(const int8_t *w /*[N][K]*/, int K, int N, int group, bool ones) {
+    const int Kg = K * group, Ng = N * group, KS = (Kg + 63) / 64, NT = (Ng + 15) / 16;
+    std::vector<int8_t> out(((size_t)NT * KS + (ones ? KS : 0)) * 1024, 0);
+    for (int nt = 0; nt < NT; ++nt)
+        for (int ks = 0; ks < KS; ++ks)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int row = 16 * nt + (lane & 15), g = lane >> 4;
+                if (row >= Ng) continue;
+                const int gi = row / N, n = row % N;
+                int8_t *dst = &out[(((size_t)nt * KS + ks) * 64 + lane) * 16];
+                for (int i = 0; i < 16; ++i) {
+                    const int kk = ks * 64 + g * 16 + i;
+                    if (kk < Kg && kk / K == gi) dst[i] = w[(size_t)n * K + kk % K];
+                }
+            }
+    if (ones)
+        for (int ks = 0; ks < KS; ++ks)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int i = 0; i < 16; ++i)
+                    if (ks * 64 + (lane >> 4) * 16 + i < Kg) out[(((size_t)NT * KS + ks) * 64 + lane) * 16 + i] = 1;
+    return out;
+}
+
 } // namespace
 
 // layer-wise DepthwiseConv2D 3x3: taps on the matrix pipe (dwpw_mm's depthwise phase, k_fused_mm.hip) unless
@@ -332,7 +365,10 @@ OpImpl *op_create(int device, const OpSpec &spec) {
         const bool zero_wzp = all_zero(wzp) && op->finite_consts;
         const bool same3x3 = s.KH == 3 && s.KW == 3 && s.pad == MF_PAD_SAME && s.sh == s.sw &&
                              s.OH == (s.H + s.sh - 1) / s.sh && s.OW == (s.W + s.sw - 1) / s.sw;
-        if (dw && zero_wzp && same3x3 && s.C == s.N && k::dw_fast_name(s.H, s.W, s.C, s.sh)) {
+        static const bool no_table = getenv("MF_NO_TABLE") != nullptr; // A-B: the run-time-geometry kernels on table shapes
+        if (no_table) {
+            // fall through to the run-time-geometry kernels below
+        } else if (dw && zero_wzp && same3x3 && s.C == s.N && k::dw_fast_name(s.H, s.W, s.C, s.sh)) {
             op->fast = OpImpl::DW_NHWC;
             op->fast_name = k::dw_fast_name(s.H, s.W, s.C, s.sh);
             k::DwFastArgs &f = op->dwf;
@@ -409,6 +445,46 @@ OpImpl *op_create(int device, const OpSpec &spec) {
                 const std::vector<int8_t> rr = build_pw_rr_weights(s.weights, s.C, s.N);
                 op->d_wrr.upload(rr.data(), rr.size());
                 f.wrr = op->d_wrr.p;
+            }
+        }
+        // shapes outside the tables: the run-time-geometry kernels (k_rt.hip), with or without weight zero points
+        static const bool no_rt = getenv("MF_NO_RT") != nullptr; // tests / A-B: shape-generic kernels instead
+        if (op->fast == OpImpl::NONE && !no_rt && op->finite_consts && dw && same3x3 && s.C == s.N &&
+            k::dw_rt_plan(op->dwrt, s.H, s.W, s.C, s.sh, s.OH, s.OW)) {
+            op->fast = OpImpl::DW_RT;
+            op->rt_wz = !all_zero(wzp);
+            op->fast_name = std::string("dw3x3_rt<") + std::to_string(s.sh) + (op->rt_wz ? ",wzp>" : ">");
+            k::DwFastArgs &f = op->dwrt.dw;
+            f.w = a.w, f.A = a.A, f.S = a.S, f.Kc = a.Kc, f.wmm = nullptr;
+            f.izp4 = 0x01010101u * (uint32_t)(uint8_t)(int8_t)s.izp;
+            f.lo_f = a.lo_f, f.hi_f = a.hi_f, f.magic = magic, f.xr = xr, f.queue = (int *)op->d_queue.p;
+            op->dwrt.wzp = a.wzp;
+        }
+        if (op->fast == OpImpl::NONE && !no_rt && op->finite_consts && !dw && s.KH == 1 && s.KW == 1 && s.sh == 1 && s.sw == 1 &&
+            s.OH == s.H && s.OW == s.W) {
+            const bool wz = !all_zero(wzp);
+            const int group = s.C % 16 == 0 ? 1 : (s.C == 8 ? 2 : (s.C == 4 ? 4 : 0));
+            if (group >= 1 && !(wz && group > 1) && k::pw_rt_supported(s.C * group, s.N * group, wz)) {
+                op->fast = OpImpl::PW_RT;
+                op->rt_wz = wz, op->pw_group = group;
+                op->fast_name = "pw_rt<" + std::to_string(s.C) + "," + std::to_string(s.N) + (wz ? ",wzp>" : ">");
+                const std::vector<int8_t> prep = build_pw_rt_weights(s.weights, s.C, s.N, group, wz);
+                op->d_wprep.upload(prep.data(), prep.size());
+                k::PwRtArgs &f = op->pwrt;
+                f.wprep = op->d_wprep.p;
+                f.K = s.C * group, f.N = s.N * group, f.KS = (f.K + 63) / 64, f.NT = (f.N + 15) / 16;
+                f.patch_pitch = (f.N + 15) & ~15;
+                f.lo_f = a.lo_f, f.hi_f = a.hi_f, f.magic = magic, f.xr = xr;
+                if (group == 1) {
+                    f.A = a.A, f.S = a.S, f.Kc = a.Kc, f.wzp = a.wzp;
+                } else { // the constants of row gi * N + n are channel n's
+                    std::vector<float> gA((size_t)f.N), gS((size_t)f.N);
+                    std::vector<int32_t> gK((size_t)f.N), gZ((size_t)f.N);
+                    for (int i = 0; i < f.N; ++i) gA[(size_t)i] = A[(size_t)(i % s.N)], gS[(size_t)i] = S[(size_t)(i % s.N)], gK[(size_t)i] = Kc[(size_t)(i % s.N)], gZ[(size_t)i] = wzp[(size_t)(i % s.N)];
+                    op->d_rtA.upload(gA.data(), gA.size() * 4), op->d_rtS.upload(gS.data(), gS.size() * 4);
+                    op->d_rtKc.upload(gK.data(), gK.size() * 4), op->d_rtwzp.upload(gZ.data(), gZ.size() * 4);
+                    f.A = op->d_rtA.as<float>(), f.S = op->d_rtS.as<float>(), f.Kc = op->d_rtKc.as<int>(), f.wzp = op->d_rtwzp.as<int>();
+                }
             }
         }
         if (op->fast == OpImpl::NONE && !dw && k::conv1x1_rowwave_supported(a)) // few outputs: one wavefront per pixel
@@ -559,6 +635,17 @@ void op_run(OpImpl *op, const int8_t *d_in, size_t batch, int8_t *d_out, void *s
         case OpImpl::PW_MFMA:
             done = k::launch_pw(sp.C, sp.N, d_in, d_out, op->pw, (long long)batch * sp.H * sp.W, s);
             break;
+        case OpImpl::DW_RT:
+            k::launch_dw_rt(d_in, d_out, op->dwrt, sp.sh, op->rt_wz, (int)batch, s);
+            done = true;
+            break;
+        case OpImpl::PW_RT: {
+            const long long npix = (long long)batch * sp.H * sp.W;
+            if (npix % op->pw_group) break; // an odd pixel count cannot be presented as pixel pairs: generic kernel
+            k::launch_pw_rt(d_in, d_out, op->pwrt, op->rt_wz, npix / op->pw_group, s);
+            done = true;
+            break;
+        }
         case OpImpl::FC_ROWWAVE:
             done = k::launch_fc_rowwave(d_in, d_out, op->fc, batch * sp.M, s);
             break;

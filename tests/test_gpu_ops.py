@@ -221,9 +221,12 @@ def test_conv_generic_vs_oracle(mf, O, case):
     c0, c1 = _rand_consts(rng, N, KH * KW * C, per_channel=pc)
     opts = mf.ops.Conv2DOptions(mf.FusedActivation(act), mf.TensorViewPadding(pad), (sh, sw))
     op = mf.ops.prepare_conv_2d((H, W, C), f, fzp, izp, oscale, ozp, opts, (c0, c1), (OH, OW))
-    assert op.kernel == "conv2d_generic"
+    # filters larger than 1x1 have no fast kernel; a 1x1 filter with weight zero points runs pw_rt (k_rt.hip)
+    assert op.kernel == ("conv2d_generic" if KH * KW > 1 else "pw_rt<16,16,wzp>"), op.kernel
     want = np.stack([O.conv_2d(x[i], f, fzp, izp, oscale, ozp, act, pad, (sh, sw), (OH, OW), c0, c1)
                      for i in range(batch)])
+    assert np.array_equal(op(x), want)
+    op.set_generic(True)
     assert np.array_equal(op(x), want)
 
 
