@@ -65,11 +65,13 @@ struct Taps {
 };
 } // namespace
 
-template <int G, int NTHR, int NREP, int MG, uint32_t XR4>
+template <int G, int NTHR, int MG, uint32_t XR4>
 __global__ __launch_bounds__(NTHR, 4) void stage_6x6x128(const int8_t *__restrict__ in, int8_t *__restrict__ out, StageArgs p,
                                                          int batch) {
     static_assert(G == 4 && NTHR == 512, "the column grid below is written for 4 images and 8 waves");
-    static_assert(NREP % 2 == 1, "the last pair must find region A free for its plain output");
+    // any number of pairs >= 2: the MID buffers alternate so that the LAST pair uses region B and finds region A free for
+    // its plain output
+    const int NREP = p.nrep, par = (NREP & 1) ^ 1;
     constexpr int NWAVE = 8;
     // 6x6x128 halo tile.  Depthwise column grid: 2 rows x 2 x x 4 images (y fastest).  Row pitch +32, image pitch +64
     // and the 16-byte group index XOR (x & 1) make every tap read conflict-free and the other three access patterns
@@ -194,7 +196,7 @@ __global__ __launch_bounds__(NTHR, 4) void stage_6x6x128(const int8_t *__restric
         MF_TR(0);
 
         for (int rep = 0; rep < NREP; ++rep) {
-            const int mid = (rep & 1) ? OFF_A : OFF_B; // this pair's MID buffer
+            const int mid = ((rep + par) & 1) ? OFF_A : OFF_B; // this pair's MID buffer
             const PwW wp = load_pw(rep);                // lands during the depthwise phase
             // ---------------- depthwise: tile -> MID ----------------
             {
@@ -304,13 +306,18 @@ __global__ __launch_bounds__(NTHR, 4) void stage_6x6x128(const int8_t *__restric
 
 // ---- launcher ----
 const char *stage_name(int H, int W, int C, int npairs) {
-    return (H == 6 && W == 6 && C == 128 && npairs == 5) ? "stage_6x6x128<4,512,5>" : nullptr;
+    static const char *names[17] = {nullptr, nullptr, "stage_6x6x128<4,512,2>", "stage_6x6x128<4,512,3>", "stage_6x6x128<4,512,4>",
+                                    "stage_6x6x128<4,512,5>", "stage_6x6x128<4,512,6>", "stage_6x6x128<4,512,7>", "stage_6x6x128<4,512,8>",
+                                    "stage_6x6x128<4,512,9>", "stage_6x6x128<4,512,10>", "stage_6x6x128<4,512,11>", "stage_6x6x128<4,512,12>",
+                                    "stage_6x6x128<4,512,13>", "stage_6x6x128<4,512,14>", "stage_6x6x128<4,512,15>", "stage_6x6x128<4,512,16>"};
+    return (H == 6 && W == 6 && C == 128 && npairs >= 2 && npairs <= 16) ? names[npairs] : nullptr; // (the run length is a kernel argument)
 }
 bool launch_stage(int H, int W, int C, int npairs, const int8_t *in, int8_t *out, const StageArgs &a_in, int batch, hipStream_t s) {
     if (!stage_name(H, W, C, npairs)) return false;
-    constexpr int G = 4, NTHR = 512, NREP = 5;
+    constexpr int G = 4, NTHR = 512;
     StageArgs a = a_in;
-    a.qcfg = dq_config((batch + G - 1) / G, 512, dq_est_us((double)batch * 2 * H * W * C, (double)batch * 2 * NREP * H * W * C));
+    a.nrep = npairs;
+    a.qcfg = dq_config((batch + G - 1) / G, 512, dq_est_us((double)batch * 2 * H * W * C, (double)batch * 2 * npairs * H * W * C));
     constexpr int lds = MF_STAGE_LDS_KB * 1024;
     const int nsteps = (batch + G - 1) / G;
     int per_cu = 0, grid = 0;
@@ -318,9 +325,9 @@ bool launch_stage(int H, int W, int C, int npairs, const int8_t *in, int8_t *out
 #define MF_STAGE_GO(MG, XR)                                                                                        \
     do {                                                                                                           \
         static LaunchState st_;                                                                                    \
-        per_cu = prepared(st_, stage_6x6x128<G, NTHR, NREP, MG, XR>, NTHR, lds);                                   \
+        per_cu = prepared(st_, stage_6x6x128<G, NTHR, MG, XR>, NTHR, lds);                                   \
         grid = nsteps < 256 * per_cu ? nsteps : 256 * per_cu;                                                      \
-        hipLaunchKernelGGL((stage_6x6x128<G, NTHR, NREP, MG, XR>), dim3(grid), dim3(NTHR), lds, s, in, out, a, batch); \
+        hipLaunchKernelGGL((stage_6x6x128<G, NTHR, MG, XR>), dim3(grid), dim3(NTHR), lds, s, in, out, a, batch); \
     } while (0)
     if (a.xr4) { // u8 element type: the stored byte is the value ^ 0x80 (XR4, see kernels.hpp)
         if (a.mode == 2) MF_STAGE_GO(2, 0x80808080u); else MF_STAGE_GO(1, 0x80808080u);

@@ -247,6 +247,7 @@ struct StageArgs {
     uint32_t xr4;            // 0 (i8) or 0x80808080 (u8): XOR of every stored dword
     int *queue;              // dynamic step queue (k_common.hpp DynSteps)
     int qcfg;                // set by the launcher (dq_config)
+    int nrep;                // number of pairs in the run (set by the launcher)
     int mode;                // epilogue mode of the whole run (k_common.hpp): 1, or 2 when every clamp is the type's range
 };
 

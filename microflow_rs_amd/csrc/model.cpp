@@ -255,9 +255,16 @@ void model_prepare(ModelImpl *m, int device, size_t max_batch) {
                 run.push_back(fused[a]);
                 a += 2;
             }
-            if (run.size() >= 2)
-                if (FusedImpl *f = fused_stage_create(run.data(), (int)run.size())) sg.v.push_back({f, (int)i, (int)a - 1});
-            if (!run.empty()) i = a - 1; // continue after the run
+            // the longest prefix of the run a stage kernel accepts (differing zero points, a run longer than the kernel's
+            // limit ...); what is left forms the next run
+            size_t used = 0;
+            for (size_t k = run.size(); k >= 2 && !used; --k)
+                if (FusedImpl *f = fused_stage_create(run.data(), (int)k)) {
+                    sg.v.push_back({f, (int)i, (int)(i + 2 * k) - 1});
+                    used = k;
+                }
+            if (used) i += 2 * used - 1;             // continue with the pair after the stage
+            else if (!run.empty()) i = a - 1;        // no stage for any prefix: continue after the run
         }
         // (5) DepthwiseConv2D with one input channel -> [Reshape] -> the FullyConnected + Softmax group -> one kernel
         for (size_t i = 0; i + 1 < n; ++i) {

@@ -463,7 +463,8 @@ OpImpl *op_create(int device, const OpSpec &spec) {
         if (op->fast == OpImpl::NONE && !no_rt && op->finite_consts && !dw && s.KH == 1 && s.KW == 1 && s.sh == 1 && s.sw == 1 &&
             s.OH == s.H && s.OW == s.W) {
             const bool wz = !all_zero(wzp);
-            const int group = s.C % 16 == 0 ? 1 : (s.C == 8 ? 2 : (s.C == 4 ? 4 : 0));
+            // K not a multiple of 16: `group` consecutive pixels form one row of the product (K = 8, 24, 40 ...: 2; K = 4, 12, 20 ...: 4)
+            const int group = s.C % 16 == 0 ? 1 : (s.C % 8 == 0 ? 2 : (s.C % 4 == 0 ? 4 : 0));
             if (group >= 1 && !(wz && group > 1) && k::pw_rt_supported(s.C * group, s.N * group, wz)) {
                 op->fast = OpImpl::PW_RT;
                 op->rt_wz = wz, op->pw_group = group;

@@ -117,3 +117,64 @@ def test_speech_like_one_launch_bit_exact(O, case):
         assert np.array_equal(got, layerwise), n
         k = min(n, 24)
         assert np.array_equal(got[:k], om.run_quantized_batch(xq[:k])), n
+
+
+# ---- person_detect's architecture at other sizes: the run-time-geometry kernels end to end ------------------------
+PD_LIKE = [
+    # side, width, pairs in the middle run, element type, weight zero points
+    (64, 1.0, 5, tw.INT8, False),     # 32x32x8 ... 4x4x128 x5 ... 2x2x256
+    (128, 1.0, 5, tw.INT8, False),    # 64x64x8 (row bands) ... 8x8x128 x5 ... 4x4x256
+    (96, 0.5, 5, tw.INT8, False),     # width 0.5: 4, 8, 16, 32, 64, 128 channels
+    (96, 0.75, 5, tw.INT8, False),    # width 0.75: 8, 12, 24, 48, 96, 192 channels
+    (96, 1.0, 6, tw.INT8, False),     # the shipped shapes with SIX 6x6x128 pairs: one stage kernel over all six
+    (96, 1.0, 2, tw.INT8, False),     # ... and with two
+    (64, 1.0, 3, tw.UINT8, False),
+    (80, 1.0, 4, tw.INT8, True),      # weight zero points everywhere (40x40x8 ... 5x5x128 ... 3x3x256)
+    (72, 0.5, 5, tw.UINT8, True),
+]
+
+
+def _pd_id(c):
+    return "%dx%d-w%s-n%d-%s-%s" % (c[0], c[0], c[1], c[2], "u8" if c[3] == tw.UINT8 else "i8", "wzp" if c[4] else "wz0")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", PD_LIKE, ids=_pd_id)
+def test_person_detect_like_models_run_on_fast_kernels(O, case):
+    """tools/tflite_writer.person_detect_like: person_detect's layer structure at input sizes / widths / run lengths the
+    table kernels were not compiled for.  Bit-exact against the oracle at EVERY layer, fused and layer-wise, and (weight
+    zero points == 0) no operator on a shape-generic `*_generic` kernel."""
+    mf = importlib.import_module("microflow_rs_amd")
+    side, width, nst, elem, wz = case
+    blob = tw.person_detect_like(np.random.default_rng(side * 7 + nst), side, width, elem, wz, nst)
+    m, om = mf.Model(blob), O.Model(blob)
+    rng = np.random.default_rng(side)
+    lo, hi = (0, 256) if m.dtype == np.uint8 else (-128, 128)
+    n = 6
+    xq = rng.integers(lo, hi, (n, m.input_elems)).astype(m.dtype)
+    xq[0], xq[1] = hi - 1, lo
+    want = om.run_quantized_batch(xq)
+    for fusion in (True, False):
+        m.set_fusion(fusion)
+        got = m.run_quantized(xq).reshape(n, -1)
+        if not np.array_equal(got, want):                  # localise the first differing layer
+            _, layers = om.run_quantized(xq[2], layers=True)
+            for i, lay in enumerate(layers):
+                g = np.asarray(m.run_until(xq[2:3], i)).reshape(-1)
+                assert np.array_equal(g, lay.reshape(-1)), (fusion, i, m.op(i)["name"], m.op(i)["kernel"])
+        assert np.array_equal(got, want), fusion
+    # every reference tensor, layer by layer
+    _, layers = om.run_quantized(xq[3], layers=True)
+    for i in (0, 1, 2, 3, 8, 13, 14, len(layers) - 5, len(layers) - 1):
+        assert np.array_equal(np.asarray(m.run_until(xq[3:4], i)).reshape(-1), layers[i].reshape(-1)), (i, m.op(i)["kernel"])
+    m.set_fusion(False)
+    kernels = [m.op(i)["kernel"] for i in range(m.num_ops)]
+    if not wz:
+        assert not [k for k in kernels if k.endswith("_generic")], kernels
+        assert any(k.startswith("dw3x3_rt") for k in kernels) or side == 96, kernels
+    else:
+        assert any(k.endswith(",wzp>") for k in kernels), kernels
+    m.set_fusion(True)
+    fused = [m.op(i)["kernel"] for i in range(m.num_ops)]
+    if side == 96 and width == 1.0 and not wz:
+        assert ("stage_6x6x128<4,512,%d>" % nst) in fused, fused

@@ -208,3 +208,48 @@ def speech_like(rng, elem=INT8, fc_wzp=0, per_channel=True, act="relu"):
                        out_shape=(1, 4), out_q=(float(np.float32(rng.uniform(0.3, 0.9))), int(rng.integers(lo + 60, hi - 60)))))
     layers.append(dict(op="softmax", out_shape=(1, 4), out_q=(1.0 / 256.0, lo)))
     return build_model((1, 1960), in_q, layers, elem)
+
+
+def person_detect_like(rng, side=96, width=1.0, elem=INT8, wzp_nonzero=False, n_stage=5, classes=2):
+    """The layer structure of person_detect.tflite (MobileNet-v1 0.25, grey input: a one-channel 3x3 stride-2 stem, then
+    depthwise 3x3 + 1x1 pairs with strides 1 2 1 2 1 2 [1 x n_stage] 2 1, AveragePool2D over what is left, a 1x1 head,
+    Reshape, Softmax) at another input size / channel width / run length, with random weights.  Activations keep the
+    shipped model's quantization (scale 6/255, zero point = the type's minimum, relu6), weights are per-channel."""
+    lo, hi = (0, 256) if elem == UINT8 else (-128, 128)
+    mid = (lo + hi) // 2
+    act_q = (0.0235294122, lo)
+    in_q = (0.00784313772, mid - 1)
+    ch = lambda c: max(4, int(round(c * width / 4.0)) * 4)  # noqa: E731
+    layers = []
+
+    def conv(op, in_shape, n, k, stride, act, in_scale, out_q):
+        _, h, w, c = in_shape
+        oh, ow = -(-h // stride), -(-w // stride)
+        fan = k * k * (1 if op == "depthwise_conv_2d" else c)
+        sc = (rng.uniform(0.6, 1.4, n) * 2.2 / (74.0 * np.sqrt(fan))).astype(np.float32)   # keeps the activations spread
+        zp = rng.integers(mid - 12, mid + 12, n) if wzp_nonzero else np.full(n, mid)
+        shape = (n, k, k, c) if op == "conv_2d" else (1, k, k, n)
+        d = dict(op=op, fscale=sc, fzp=zp, bias=rng.integers(-300, 300, n), bscale=(sc * np.float32(in_scale)).astype(np.float32),
+                 bzp=np.zeros(n, np.int64), padding="same", strides=(stride, stride), act=act, out_shape=(1, oh, ow, n), out_q=out_q)
+        d["filters" if op == "conv_2d" else "weights"] = rng.integers(lo, hi, shape)
+        layers.append(d)
+        return d["out_shape"]
+
+    shp = conv("depthwise_conv_2d", (1, side, side, 1), ch(8), 3, 2, "relu6", in_q[0], act_q)
+    plan = [(1, 16), (2, 32), (1, 32), (2, 64), (1, 64), (2, 128)] + [(1, 128)] * n_stage + [(2, 256), (1, 256)]
+    for stride, n in plan:
+        shp = conv("depthwise_conv_2d", shp, shp[3], 3, stride, "relu6", act_q[0], act_q)
+        shp = conv("conv_2d", shp, ch(n), 1, 1, "relu6", act_q[0], act_q)
+    layers.append(dict(op="average_pool_2d", filter=(shp[1], shp[2]), padding="valid", strides=(2, 2), act="none",
+                       out_shape=(1, 1, 1, shp[3]), out_q=(0.0186093301, lo)))
+    shp = (1, 1, 1, shp[3])
+    head_q = (0.0125187514, mid - 1)
+    sc = (rng.uniform(0.6, 1.4, classes) * 0.002).astype(np.float32)
+    zp = rng.integers(mid - 12, mid + 12, classes) if wzp_nonzero else np.full(classes, mid)
+    layers.append(dict(op="conv_2d", filters=rng.integers(lo, hi, (classes, 1, 1, shp[3])), fscale=sc, fzp=zp,
+                       bias=rng.integers(-300, 300, classes), bscale=(sc * np.float32(0.0186093301)).astype(np.float32),
+                       bzp=np.zeros(classes, np.int64), padding="same", strides=(1, 1), act="none",
+                       out_shape=(1, 1, 1, classes), out_q=head_q))
+    layers.append(dict(op="reshape", out_shape=(1, classes), out_q=head_q))
+    layers.append(dict(op="softmax", out_shape=(1, classes), out_q=(1.0 / 256.0, lo)))
+    return build_model((1, side, side, 1), in_q, layers, elem)
