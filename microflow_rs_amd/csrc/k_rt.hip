@@ -175,7 +175,7 @@ __global__ __launch_bounds__(512) void dw3x3_rt(const int8_t *__restrict__ in, i
 }
 
 // ------------------------------------------------------------------------
-// pw_rt -- Conv2D 1x1, stride 1, as an int8 MFMA product over the batch's pixel matrix: K % 16 == 0 input channels
+// pw_rt_lds -- Conv2D 1x1, stride 1, as an int8 MFMA product over the batch's pixel matrix: K % 16 == 0 input channels
 // (the host presents K = 8 / K = 4 as K = 16 on pixel pairs / quads with block-diagonal weights), N % 4 == 0 outputs.
 //
 //   weights : operand A of v_mfma_i32_16x16x64_i8 for every (16-channel tile, 64-deep k step), built by the host
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(512) void dw3x3_rt(const int8_t *__restrict__ in, i
 //             more MFMA tile of ones.
 // ------------------------------------------------------------------------
 template <bool WZ, int MG, uint32_t XR4>
-__global__ __launch_bounds__(256) void pw_rt(const int8_t *__restrict__ in, int8_t *__restrict__ out, PwRtArgs p, long long npix) {
+__global__ __launch_bounds__(256) void pw_rt_lds(const int8_t *__restrict__ in, int8_t *__restrict__ out, PwRtArgs p, long long npix) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -265,6 +265,87 @@ __global__ __launch_bounds__(256) void pw_rt(const int8_t *__restrict__ in, int8
     }
 }
 
+// ------------------------------------------------------------------------
+// pw_rt -- the same product with the weights in REGISTERS (weight zero points == 0): the form pw_mfma<K, N> has, with K
+// and N as arguments.
+//
+//   rows    : `group` consecutive pixels form one row of the product when K < 64 (block-diagonal weights built by the
+//             host), so that the 64-deep k step of the MFMA is filled and a row's output is >= 64 contiguous bytes.
+//   split   : the N' = N * group output channels are cut into blocks of TB <= 4 tiles; NSPLIT = 1, 2 or 4 waves share a
+//             16-row chunk, each holding ITS block's operand A for every k step in registers (KSC = 1, 2, 4 or 8 k steps
+//             is the template parameter) and reading the same operand B (L1 / L2 hits).
+//   rows of a tile are permuted on the host (row 4 gr + i of tile t = channel base + 4 TB gr + 4 t + i) so that a lane
+//             ends with 4 TB CONSECUTIVE output bytes of its row: one 4 .. 16-byte store, 64 .. 1024 contiguous bytes
+//             per wave-level store.
+//   U chunks are in flight per wave: all their loads are issued before the first MFMA.
+// ------------------------------------------------------------------------
+template <int KSC, int MG, uint32_t XR4>
+__global__ __launch_bounds__(256) void pw_rt(const int8_t *__restrict__ in, int8_t *__restrict__ out, PwRtArgs p, long long nrows) {
+    constexpr int U = KSC <= 2 ? 4 : 2;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int K = p.K, N = p.N, KS = p.KS, TB = p.TB, NSPLIT = p.NSPLIT;
+    const int col = lane & 15, g = lane >> 4;
+    const int blk = wave % NSPLIT, slot = wave / NSPLIT, SLOTS = 4 / NSPLIT;
+    v4i Aw[4][KSC];
+    float4 cA[4], cS[4];
+    int4 cK[4];
+    const int ch0 = blk * 16 * TB + g * 4 * TB;      // this lane's first channel
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+        for (int ks = 0; ks < KSC; ++ks) {
+            Aw[t][ks] = v4i{0, 0, 0, 0};
+            if (t < TB && ks < KS) Aw[t][ks] = ((const v4i *)p.wprep)[(((size_t)blk * TB + t) * KS + ks) * 64 + lane];
+        }
+        const int ch = ch0 + 4 * t;
+        const bool live = t < TB && ch < N;
+        cA[t] = live ? *(const float4 *)(p.A + ch) : make_float4(0.f, 0.f, 0.f, 0.f);
+        cS[t] = live ? *(const float4 *)(p.S + ch) : make_float4(0.f, 0.f, 0.f, 0.f);
+        cK[t] = magic4<MG>(live ? *(const int4 *)(p.Kc + ch) : make_int4(0, 0, 0, 0));
+    }
+    const long long nchunks = (nrows + 15) / 16;
+    for (long long cb = ((long long)blockIdx.x * SLOTS + slot) * U; cb < nchunks; cb += (long long)gridDim.x * SLOTS * U) {
+        v4i B[U][KSC];
+        long long row[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            row[u] = (cb + u) * 16 + col;
+            const long long r = row[u] < nrows ? row[u] : nrows - 1; // chunks past the end re-read the last row
+            const int8_t *src = in + r * K;
+#pragma unroll
+            for (int ks = 0; ks < KSC; ++ks) {
+                const int k0 = ks * 64 + g * 16;                     // a k step hanging over K meets zero weights
+                if (ks < KS) B[u][ks] = *(const v4i *)(src + (k0 < K ? k0 : 0));
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            uint32_t packed[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                if (t < TB) {
+                    v4i acc = {cK[t].x, cK[t].y, cK[t].z, cK[t].w};
+#pragma unroll
+                    for (int ks = 0; ks < KSC; ++ks)
+                        if (ks < KS) acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(Aw[t][ks], B[u][ks], acc, 0, 0, 0);
+                    packed[t] = requant_pack4<MG, XR4>(acc[0], acc[1], acc[2], acc[3], cA[t], cS[t], p.lo_f, p.hi_f);
+                }
+            }
+            if (row[u] < nrows) {
+                int8_t *o = out + row[u] * N + ch0;
+                if (TB == 4 && (N & 15) == 0 && ch0 + 16 <= N) { // (16-byte stores need rows that are whole 16-byte groups)
+                    *(uint4 *)o = make_uint4(packed[0], packed[1], packed[2], packed[3]);
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        if (t < TB && ch0 + 4 * t < N) *(uint32_t *)(o + 4 * t) = packed[t];
+                }
+            }
+        }
+    }
+}
+
 // ---- launchers ----
 bool dw_rt_plan(DwRtArgs &a, int H, int W, int C, int S, int OH, int OW) {
     if (C % 4 != 0 || C / 4 > 512 || (S != 1 && S != 2) || (W * C) % 16 != 0) return false;
@@ -333,9 +414,9 @@ bool pw_rt_supported(int K, int N, bool wz) {
 template <bool WZ, int MG, uint32_t XR4>
 static void launch_pw_rt_t(const int8_t *in, int8_t *out, const PwRtArgs &a, long long npix, hipStream_t s) {
     const int lds = pw_rt_lds_bytes(a.K, a.N, WZ);
-    (void)hipFuncSetAttribute((const void *)pw_rt<WZ, MG, XR4>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    (void)hipFuncSetAttribute((const void *)pw_rt_lds<WZ, MG, XR4>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     int per_cu = 1;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pw_rt<WZ, MG, XR4>, 256, (size_t)lds) != hipSuccess || per_cu < 1) {
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pw_rt_lds<WZ, MG, XR4>, 256, (size_t)lds) != hipSuccess || per_cu < 1) {
         (void)hipGetLastError();
         per_cu = 1;
     }
@@ -343,10 +424,41 @@ static void launch_pw_rt_t(const int8_t *in, int8_t *out, const PwRtArgs &a, lon
     const long long want = (nchunks + 3) / 4;
     const int cap = 256 * per_cu;                    // persistent: the weight image is copied to LDS once per workgroup
     const int grid = (int)(want < cap ? want : cap);
-    hipLaunchKernelGGL((pw_rt<WZ, MG, XR4>), dim3(grid), dim3(256), lds, s, in, out, a, npix);
+    hipLaunchKernelGGL((pw_rt_lds<WZ, MG, XR4>), dim3(grid), dim3(256), lds, s, in, out, a, npix);
+}
+template <int KSC, int MG, uint32_t XR4>
+static void launch_pw_rt_reg_t(const int8_t *in, int8_t *out, const PwRtArgs &a, long long nrows, hipStream_t s) {
+    static LaunchState st;
+    const int per_cu = prepared(st, pw_rt<KSC, MG, XR4>, 256, 0);
+    const int U = KSC <= 2 ? 4 : 2, SLOTS = 4 / a.NSPLIT;
+    const long long nchunks = (nrows + 15) / 16, want = (nchunks + (long long)SLOTS * U - 1) / ((long long)SLOTS * U);
+    // persistent: a workgroup fetches its operand A once; a few waves of workgroups per CU keep the loads deep
+    const long long cap = 256LL * per_cu * 2;
+    const int grid = (int)(want < cap ? (want < 1 ? 1 : want) : cap);
+    hipLaunchKernelGGL((pw_rt<KSC, MG, XR4>), dim3(grid), dim3(256), 0, s, in, out, a, nrows);
 }
 void launch_pw_rt(const int8_t *in, int8_t *out, const PwRtArgs &a, bool wz, long long npix, hipStream_t s) {
     const int mg = a.magic;
+    if (!wz && a.TB > 0) { // weights in registers
+#define MF_RT_GO(KSC)                                                                              \
+    do {                                                                                           \
+        if (a.xr) {                                                                                \
+            if (mg == 2) launch_pw_rt_reg_t<KSC, 2, 0x80808080u>(in, out, a, npix, s);             \
+            else if (mg) launch_pw_rt_reg_t<KSC, 1, 0x80808080u>(in, out, a, npix, s);             \
+            else launch_pw_rt_reg_t<KSC, 0, 0x80808080u>(in, out, a, npix, s);                     \
+        } else {                                                                                   \
+            if (mg == 2) launch_pw_rt_reg_t<KSC, 2, 0u>(in, out, a, npix, s);                      \
+            else if (mg) launch_pw_rt_reg_t<KSC, 1, 0u>(in, out, a, npix, s);                      \
+            else launch_pw_rt_reg_t<KSC, 0, 0u>(in, out, a, npix, s);                              \
+        }                                                                                          \
+    } while (0)
+        if (a.KS <= 1) MF_RT_GO(1);
+        else if (a.KS <= 2) MF_RT_GO(2);
+        else if (a.KS <= 4) MF_RT_GO(4);
+        else MF_RT_GO(8);
+#undef MF_RT_GO
+        return;
+    }
 #define MF_RT_GO(WZZ)                                                                              \
     do {                                                                                           \
         if (a.xr) {                                                                                \

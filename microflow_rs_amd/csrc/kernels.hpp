@@ -140,7 +140,8 @@ struct PwRtArgs {
     const int *wzp;     // [N] (the WZ instance only)
     float lo_f, hi_f;
     int K, N, KS, NT;   // KS = ceil(K / 64), NT = ceil(N / 16)
-    int patch_pitch;    // N rounded up to 16
+    int patch_pitch;    // N rounded up to 16 (pw_rt_lds)
+    int TB, NSPLIT;     // pw_rt (weights in registers): tiles per wave block (1..4; 0 = use pw_rt_lds) and waves per chunk (1, 2, 4)
     int magic, xr;
 };
 bool dw_rt_plan(DwRtArgs &a, int H, int W, int C, int S, int OH, int OW); // fills the geometry; false: not supported

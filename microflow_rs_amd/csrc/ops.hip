@@ -278,6 +278,28 @@ std::vector<int8_t> build_pw_rt_weights(const int8_t *w /*[N][K]*/, int K, int N
     return out;
 }
 
+// The same product for pw_rt with the weights in registers: [block][tile t][k step][lane][16 bytes], TB tiles per block, and
+// row 4 gr + i of tile t = channel 16 TB blk + 4 TB gr + 4 t + i (so that a lane ends with 4 TB consecutive output bytes).
+std::vector<int8_t> build_pw_rt_reg_weights(const int8_t *w /*[N][K]*/, int K, int N, int group, int TB, int NBLK) {
+    const int Kg = K * group, Ng = N * group, KS = (Kg + 63) / 64;
+    std::vector<int8_t> out((size_t)NBLK * TB * KS * 1024, 0);
+    for (int blk = 0; blk < NBLK; ++blk)
+        for (int t = 0; t < TB; ++t)
+            for (int ks = 0; ks < KS; ++ks)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int r = lane & 15, g = lane >> 4;
+                    const int row = 16 * TB * blk + 4 * TB * (r >> 2) + 4 * t + (r & 3);
+                    if (row >= Ng) continue;
+                    const int gi = row / N, n = row % N;
+                    int8_t *dst = &out[((((size_t)blk * TB + t) * KS + ks) * 64 + lane) * 16];
+                    for (int i = 0; i < 16; ++i) {
+                        const int kk = ks * 64 + g * 16 + i;
+                        if (kk < Kg && kk / K == gi) dst[i] = w[(size_t)n * K + kk % K];
+                    }
+                }
+    return out;
+}
+
 } // namespace
 
 // layer-wise DepthwiseConv2D 3x3: taps on the matrix pipe (dwpw_mm's depthwise phase, k_fused_mm.hip) unless
@@ -464,17 +486,29 @@ OpImpl *op_create(int device, const OpSpec &spec) {
             s.OH == s.H && s.OW == s.W) {
             const bool wz = !all_zero(wzp);
             // K not a multiple of 16: `group` consecutive pixels form one row of the product (K = 8, 24, 40 ...: 2; K = 4, 12, 20 ...: 4)
-            const int group = s.C % 16 == 0 ? 1 : (s.C % 8 == 0 ? 2 : (s.C % 4 == 0 ? 4 : 0));
-            if (group >= 1 && !(wz && group > 1) && k::pw_rt_supported(s.C * group, s.N * group, wz)) {
+            int group = s.C % 16 == 0 ? 1 : (s.C % 8 == 0 ? 2 : (s.C % 4 == 0 ? 4 : 0));
+            // weights in registers (zero weight zero points, N * group <= 256): more pixels per row while the 64-deep k
+            // step has room, so that the MFMA's k span is used and a row's output is a long contiguous run
+            if (s.N % 4 != 0) group = 0; // packed dword results: N in whole fours (a 2-output head runs conv1x1_rowwave)
+            bool reg = group >= 1 && !wz && s.N * group <= 256 && s.C * group <= 512;
+            if (reg)
+                while (s.C * group * 2 <= 64 && s.N * group * 2 <= 256) group *= 2;
+            if (group >= 1 && !(wz && group > 1) && (reg || k::pw_rt_supported(s.C * group, s.N * group, wz))) {
                 op->fast = OpImpl::PW_RT;
                 op->rt_wz = wz, op->pw_group = group;
                 op->fast_name = "pw_rt<" + std::to_string(s.C) + "," + std::to_string(s.N) + (wz ? ",wzp>" : ">");
-                const std::vector<int8_t> prep = build_pw_rt_weights(s.weights, s.C, s.N, group, wz);
+                const int NTg = (s.N * group + 15) / 16;
+                const int TB = reg ? (NTg < 4 ? NTg : 4) : 0;
+                const int NBLK = reg ? (NTg + TB - 1) / TB : 0;            // <= 4 because N * group <= 256
+                const int NSPLIT = NBLK <= 1 ? 1 : (NBLK == 2 ? 2 : 4);
+                const std::vector<int8_t> prep = reg ? build_pw_rt_reg_weights(s.weights, s.C, s.N, group, TB, NSPLIT)
+                                                     : build_pw_rt_weights(s.weights, s.C, s.N, group, wz);
                 op->d_wprep.upload(prep.data(), prep.size());
                 k::PwRtArgs &f = op->pwrt;
                 f.wprep = op->d_wprep.p;
                 f.K = s.C * group, f.N = s.N * group, f.KS = (f.K + 63) / 64, f.NT = (f.N + 15) / 16;
                 f.patch_pitch = (f.N + 15) & ~15;
+                f.TB = TB, f.NSPLIT = NSPLIT;
                 f.lo_f = a.lo_f, f.hi_f = a.hi_f, f.magic = magic, f.xr = xr;
                 if (group == 1) {
                     f.A = a.A, f.S = a.S, f.Kc = a.Kc, f.wzp = a.wzp;
@@ -641,9 +675,15 @@ void op_run(OpImpl *op, const int8_t *d_in, size_t batch, int8_t *d_out, void *s
             done = true;
             break;
         case OpImpl::PW_RT: {
-            const long long npix = (long long)batch * sp.H * sp.W;
-            if (npix % op->pw_group) break; // an odd pixel count cannot be presented as pixel pairs: generic kernel
-            k::launch_pw_rt(d_in, d_out, op->pwrt, op->rt_wz, npix / op->pw_group, s);
+            // `pw_group` pixels are one row of the product; the few pixels left over when the pixel count is not a
+            // multiple of it go through the shape-generic kernel as one short 1 x rem image
+            const long long npix = (long long)batch * sp.H * sp.W, full = npix / op->pw_group * op->pw_group;
+            if (full) k::launch_pw_rt(d_in, d_out, op->pwrt, op->rt_wz, full / op->pw_group, s);
+            if (npix > full) {
+                k::ConvArgs t = op->conv;
+                t.H = t.OH = 1, t.W = t.OW = (int)(npix - full);
+                k::launch_conv2d_generic(d_in + full * sp.C, d_out + full * sp.N, t, 1, s);
+            }
             done = true;
             break;
         }
