@@ -10,6 +10,10 @@
 // convolution live in LDS instead of registers.  Arithmetic contract and helpers: k_common.hpp.
 #include "k_common.hpp"
 
+#include <algorithm>
+#include <map>
+#include <mutex>
+
 namespace mf {
 namespace k {
 
@@ -28,15 +32,15 @@ namespace k {
 //   WZ      : non-zero weight zero points (depthwise_conv_2d.rs:57-63, :70-75): acc -= wzp[c] * sum of the window, the
 //             window sum being one more v_dot4 per filter row against the byte mask of the taps.
 // ------------------------------------------------------------------------
-template <int S, bool WZ, int MG, uint32_t XR4>
+template <int S, int R, bool WZ, int MG, uint32_t XR4>
 __global__ __launch_bounds__(512) void dw3x3_rt(const int8_t *__restrict__ in, int8_t *__restrict__ out, DwRtArgs p, int batch) {
-    constexpr int NTHR = 512, NWAVE = 8, R = 2;
+    constexpr int NTHR = 512, NWAVE = 8; // R = output rows per task (2, or 3 when the band height divides by 3)
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int C = p.C, C4 = C >> 2, ROW = p.ROW, LP = p.LP, TILE = p.TILE, BUF = p.BUF, G = p.G, RB = p.RB;
     const int H = p.H, OH = p.OH, OW = p.OW, ROWB = p.W * C, BH = p.BH, NBANDS = p.NBANDS;
-    const int OWP = (OW + 1) >> 1, OHR = BH >> 1;
+    const int OWP = (OW + 1) >> 1, OHR = BH / R;
 
     DynSteps dq;
     dq.init(lds + 2 * BUF + 256, p.dw.queue, tid, p.dw.qcfg);
@@ -66,6 +70,12 @@ __global__ __launch_bounds__(512) void dw3x3_rt(const int8_t *__restrict__ in, i
     const int per_img = OHR * OWP;
     int g0 = pp0 / per_img, rp0 = (pp0 % per_img) / OWP, xp0 = pp0 % OWP;
     const int dx = PPT % OWP, drow = PPT / OWP, dr = drow % OHR, dg = drow / OHR;
+    // strides of the walk in the staged tile (bytes) and in the output (dwords), and what a carry adds
+    const int t_x = 2 * S * C, t_row = R * S * ROW;
+    const int t_step = dg * TILE + dr * t_row + dx * t_x, t_cx = t_row - OWP * t_x, t_cr = TILE - OHR * t_row;
+    const int o_x = 2 * C4, o_row = R * OW * C4, o_img = OH * OW * C4;
+    const int o_step = dg * o_img + dr * o_row + dx * o_x, o_cx = o_row - OWP * o_x, o_cr = o_img - OHR * o_row;
+    const int tbase0 = LP - C + cg * 4;              // window start of pixel pair 0: one pixel left of the image
     __syncthreads(); // zero-point fill complete before any DMA lands
 
     auto stage = [&](int st, int buf) {
@@ -103,11 +113,15 @@ __global__ __launch_bounds__(512) void dw3x3_rt(const int8_t *__restrict__ in, i
         const int oyb = band * BH;
         const uint8_t *tile = lds + cur * BUF;
         uint32_t *dst = (uint32_t *)out + (size_t)ist * G * OH * OW * C4;
+        const int obase0 = oyb * OW * C4 + cg;       // (band mode: the band's first output row)
+        // task walk with incremental addresses: no multiplication per task (the strides are runtime values)
         int g = g0, rp = rp0, xp = xp0;
+        int toff = g0 * TILE + rp0 * t_row + xp0 * t_x;          // byte offset of the task's window in the staged tile
+        int ooff = (g0 * OH + R * rp0) * OW * C4 + xp0 * 2 * C4; // dword offset of its first output in the step's output
         while (active && g < gvalid) {
             const int oy0 = oyb + R * rp, ox0 = 2 * xp;
             if (oy0 < OH) {
-                const uint8_t *base = tile + g * TILE + (R * rp * S) * ROW + LP + (ox0 * S - 1) * C + cg * 4;
+                const uint8_t *base = tile + tbase0 + toff;
                 int o0[R][4], o1[R][4], s0[R][4], s1[R][4];
 #pragma unroll
                 for (int j = 0; j < R; ++j) {
@@ -140,12 +154,12 @@ __global__ __launch_bounds__(512) void dw3x3_rt(const int8_t *__restrict__ in, i
 #pragma unroll
                             for (int k = 0; k < 4; ++k) {
                                 if constexpr (S == 1) {
-                                    o0[j][k] = sdot4(win[k], wA[ky][k], o0[j][k]);
-                                    o1[j][k] = sdot4(win[k], wB[ky][k], o1[j][k]);
+                                    o0[j][k] = ky == 0 ? sdot4_first(win[k], wA[0][k], o0[j][k]) : sdot4(win[k], wA[ky][k], o0[j][k]);
+                                    o1[j][k] = ky == 0 ? sdot4_first(win[k], wB[0][k], o1[j][k]) : sdot4(win[k], wB[ky][k], o1[j][k]);
                                     if constexpr (WZ) s0[j][k] = sdot4(win[k], 0x00010101u, s0[j][k]), s1[j][k] = sdot4(win[k], 0x01010100u, s1[j][k]);
                                 } else {
-                                    o0[j][k] = sdot4(win[k], wA[ky][k], o0[j][k]);
-                                    o1[j][k] = sdot4(winb[k], wA[ky][k], o1[j][k]);
+                                    o0[j][k] = ky == 0 ? sdot4_first(win[k], wA[0][k], o0[j][k]) : sdot4(win[k], wA[ky][k], o0[j][k]);
+                                    o1[j][k] = ky == 0 ? sdot4_first(winb[k], wA[0][k], o1[j][k]) : sdot4(winb[k], wA[ky][k], o1[j][k]);
                                     if constexpr (WZ) s0[j][k] = sdot4(win[k], 0x00010101u, s0[j][k]), s1[j][k] = sdot4(winb[k], 0x00010101u, s1[j][k]);
                                 }
                             }
@@ -159,7 +173,7 @@ __global__ __launch_bounds__(512) void dw3x3_rt(const int8_t *__restrict__ in, i
                             o0[j][0] -= wz.x * s0[j][0], o0[j][1] -= wz.y * s0[j][1], o0[j][2] -= wz.z * s0[j][2], o0[j][3] -= wz.w * s0[j][3];
                             o1[j][0] -= wz.x * s1[j][0], o1[j][1] -= wz.y * s1[j][1], o1[j][2] -= wz.z * s1[j][2], o1[j][3] -= wz.w * s1[j][3];
                         }
-                        uint32_t *dp = dst + ((size_t)(g * OH + oy0 + j) * OW + ox0) * C4 + cg;
+                        uint32_t *dp = dst + obase0 + ooff + j * OW * C4;
                         dp[0] = requant_pack4<MG, XR4>(o0[j][0], o0[j][1], o0[j][2], o0[j][3], A, Sc, p.dw.lo_f, p.dw.hi_f);
                         if (ox0 + 1 < OW) dp[C4] = requant_pack4<MG, XR4>(o1[j][0], o1[j][1], o1[j][2], o1[j][3], A, Sc, p.dw.lo_f, p.dw.hi_f);
                     }
@@ -167,8 +181,9 @@ __global__ __launch_bounds__(512) void dw3x3_rt(const int8_t *__restrict__ in, i
             }
             // next task of this lane: PPT pixel pairs further (single carries by construction)
             xp += dx, rp += dr, g += dg;
-            if (xp >= OWP) xp -= OWP, ++rp;
-            if (rp >= OHR) rp -= OHR, ++g;
+            toff += t_step, ooff += o_step;
+            if (xp >= OWP) xp -= OWP, ++rp, toff += t_cx, ooff += o_cx;
+            if (rp >= OHR) rp -= OHR, ++g, toff += t_cr, ooff += o_cr;
         }
     }
     dq.finish(tid);
@@ -352,55 +367,85 @@ bool dw_rt_plan(DwRtArgs &a, int H, int W, int C, int S, int OH, int OW) {
     const int LP = ((C < 16 ? 16 : C) + 15) & ~15;
     const int ROW = LP + W * C + LP;
     constexpr int BUDGET = 36 * 1024;                // per staging buffer: two buffers, two workgroups per CU
-    auto rows_for = [&](int bh) { return (S == 1 ? bh + 2 : 2 * bh + 1) + 1; }; // + 1: the masked row of an odd last pair
-    const int OHE = (OH + 1) & ~1;
+    // output rows per task: 3 shares more input-row transposes (4.67 instead of 5 tap instructions per output byte at
+    // stride 1) when the rows divide by 3; else 2 with a masked last row
+    const int R = (OH % 3 == 0) ? 3 : 2;
+    a.R = R;
+    auto rows_for = [&](int bh) { return S == 1 ? bh + 2 : 2 * bh + 1; }; // tile rows behind bh output rows (masked rows included)
+    const int OHE = (OH + R - 1) / R * R;
     a.H = H, a.W = W, a.C = C, a.OH = OH, a.OW = OW, a.ROW = ROW, a.LP = LP;
     if (rows_for(OHE) * ROW <= BUDGET) {
         a.NBANDS = 1, a.BH = OHE, a.RB = rows_for(OHE), a.TILE = a.RB * ROW;
-        int g = BUDGET / a.TILE;
-        a.G = g < 1 ? 1 : (g > 16 ? 16 : g);
+        // images per step: as many as fit, but prefer a count whose tasks fill whole passes of the 512 threads
+        const int gmax = std::min(16, BUDGET / a.TILE), C4 = C / 4, pass = (512 / C4) * C4;
+        const int per_img = (OHE / R) * ((OW + 1) / 2) * C4;
+        int best = 1;
+        double best_eff = 0.0;
+        for (int g = 1; g <= gmax; ++g) {
+            const int tasks = g * per_img;
+            const double eff = (double)tasks / (double)(((tasks + pass - 1) / pass) * pass);
+            if (eff >= best_eff - 0.02) best = g, best_eff = std::max(best_eff, eff);
+        }
+        a.G = best;
     } else {
         int bh = OHE;
-        while (bh > 2 && rows_for(bh) * ROW > BUDGET) bh -= 2;
-        if (rows_for(bh) * ROW > 64 * 1024) return false; // a single row pair does not fit: the row is too wide
+        while (bh > R && rows_for(bh) * ROW > BUDGET) bh -= R;
+        if (rows_for(bh) * ROW > 64 * 1024) return false; // a single task row does not fit: the row is too wide
+        const int nb = (OH + bh - 1) / bh;                  // bands of (nearly) equal height
+        bh = ((OH + nb - 1) / nb + R - 1) / R * R;
         a.BH = bh, a.NBANDS = (OH + bh - 1) / bh, a.RB = rows_for(bh), a.TILE = a.RB * ROW, a.G = 1;
     }
     a.BUF = a.G * a.TILE;
     return 2 * a.BUF + 256 + 16 <= 160 * 1024;
 }
-template <int S, bool WZ, int MG, uint32_t XR4>
+template <int S, int R, bool WZ, int MG, uint32_t XR4>
 static void launch_dw_rt_t(const int8_t *in, int8_t *out, const DwRtArgs &a, int batch, hipStream_t s) {
     const int lds = 2 * a.BUF + 256 + 16;
-    // occupancy depends on the run-time LDS size: ask per launch (cheap) instead of caching per instance
-    (void)hipFuncSetAttribute((const void *)dw3x3_rt<S, WZ, MG, XR4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    // occupancy depends on the run-time LDS size: asked once per (instance, size, device)
     int per_cu = 1;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dw3x3_rt<S, WZ, MG, XR4>, 512, (size_t)lds) != hipSuccess || per_cu < 1) {
-        (void)hipGetLastError();
-        per_cu = 1;
+    {
+        static std::mutex mu;
+        static std::map<std::pair<int, int>, int> cache;
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        std::lock_guard<std::mutex> lock(mu);
+        auto it = cache.find({dev, lds});
+        if (it == cache.end()) {
+            (void)hipFuncSetAttribute((const void *)dw3x3_rt<S, R, WZ, MG, XR4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            int n = 1;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, dw3x3_rt<S, R, WZ, MG, XR4>, 512, (size_t)lds) != hipSuccess || n < 1) {
+                (void)hipGetLastError();
+                n = 1;
+            }
+            it = cache.emplace(std::make_pair(dev, lds), n).first;
+        }
+        per_cu = it->second;
     }
     const int nsteps = ((batch + a.G - 1) / a.G) * a.NBANDS;
     const int grid = nsteps < 256 * per_cu ? nsteps : 256 * per_cu;
     DwRtArgs b = a;
     const double opix = (double)a.OH * a.OW;
     b.dw.qcfg = dq_config(nsteps, grid, dq_est_us((double)batch * ((double)a.H * a.W * a.C + opix * a.C), (double)batch * opix * a.C));
-    hipLaunchKernelGGL((dw3x3_rt<S, WZ, MG, XR4>), dim3(grid), dim3(512), lds, s, in, out, b, batch);
+    hipLaunchKernelGGL((dw3x3_rt<S, R, WZ, MG, XR4>), dim3(grid), dim3(512), lds, s, in, out, b, batch);
 }
 void launch_dw_rt(const int8_t *in, int8_t *out, const DwRtArgs &a, int S, bool wz, int batch, hipStream_t s) {
     const int mg = a.dw.magic;
-#define MF_RT_GO(SS, WZZ)                                                                          \
+#define MF_RT_GO2(SS, RR, WZZ)                                                                     \
     do {                                                                                           \
         if (a.dw.xr) {                                                                             \
-            if (mg == 2) launch_dw_rt_t<SS, WZZ, 2, 0x80808080u>(in, out, a, batch, s);            \
-            else if (mg) launch_dw_rt_t<SS, WZZ, 1, 0x80808080u>(in, out, a, batch, s);            \
-            else launch_dw_rt_t<SS, WZZ, 0, 0x80808080u>(in, out, a, batch, s);                    \
+            if (mg == 2) launch_dw_rt_t<SS, RR, WZZ, 2, 0x80808080u>(in, out, a, batch, s);        \
+            else if (mg) launch_dw_rt_t<SS, RR, WZZ, 1, 0x80808080u>(in, out, a, batch, s);        \
+            else launch_dw_rt_t<SS, RR, WZZ, 0, 0x80808080u>(in, out, a, batch, s);                \
         } else {                                                                                   \
-            if (mg == 2) launch_dw_rt_t<SS, WZZ, 2, 0u>(in, out, a, batch, s);                     \
-            else if (mg) launch_dw_rt_t<SS, WZZ, 1, 0u>(in, out, a, batch, s);                     \
-            else launch_dw_rt_t<SS, WZZ, 0, 0u>(in, out, a, batch, s);                             \
+            if (mg == 2) launch_dw_rt_t<SS, RR, WZZ, 2, 0u>(in, out, a, batch, s);                 \
+            else if (mg) launch_dw_rt_t<SS, RR, WZZ, 1, 0u>(in, out, a, batch, s);                 \
+            else launch_dw_rt_t<SS, RR, WZZ, 0, 0u>(in, out, a, batch, s);                         \
         }                                                                                          \
     } while (0)
+#define MF_RT_GO(SS, WZZ) do { if (a.R == 3) MF_RT_GO2(SS, 3, WZZ); else MF_RT_GO2(SS, 2, WZZ); } while (0)
     if (S == 1) { if (wz) MF_RT_GO(1, true); else MF_RT_GO(1, false); }
     else { if (wz) MF_RT_GO(2, true); else MF_RT_GO(2, false); }
+#undef MF_RT_GO2
 #undef MF_RT_GO
 }
 

@@ -128,7 +128,8 @@ struct DwRtArgs {
     const int *wzp;     // [C] weight zero points (the WZ instance only)
     int H, W, C, OH, OW;
     int G;              // whole images per step (1 in band mode)
-    int BH, NBANDS;     // output rows per band (even) and bands per image (1 = whole images)
+    int R;              // output rows per task (2 or 3)
+    int BH, NBANDS;     // output rows per band (a multiple of R) and bands per image (1 = whole images)
     int RB;             // tile rows staged per image / band
     int ROW, LP, TILE, BUF; // tile row pitch, side pad, bytes per staged image, bytes per staging buffer
 };

@@ -388,9 +388,7 @@ OpImpl *op_create(int device, const OpSpec &spec) {
         const bool same3x3 = s.KH == 3 && s.KW == 3 && s.pad == MF_PAD_SAME && s.sh == s.sw &&
                              s.OH == (s.H + s.sh - 1) / s.sh && s.OW == (s.W + s.sw - 1) / s.sw;
         static const bool no_table = getenv("MF_NO_TABLE") != nullptr; // A-B: the run-time-geometry kernels on table shapes
-        if (no_table) {
-            // fall through to the run-time-geometry kernels below
-        } else if (dw && zero_wzp && same3x3 && s.C == s.N && k::dw_fast_name(s.H, s.W, s.C, s.sh)) {
+        if (!no_table && dw && zero_wzp && same3x3 && s.C == s.N && k::dw_fast_name(s.H, s.W, s.C, s.sh)) {
             op->fast = OpImpl::DW_NHWC;
             op->fast_name = k::dw_fast_name(s.H, s.W, s.C, s.sh);
             k::DwFastArgs &f = op->dwf;
@@ -405,7 +403,7 @@ OpImpl *op_create(int device, const OpSpec &spec) {
                 f.wmm = op->d_wprep.p;
                 if (dw_taps_on_matrix_pipe() && k::dw_mm_name(s.H, s.W, s.C, s.sh)) op->fast_name = k::dw_mm_name(s.H, s.W, s.C, s.sh);
             }
-        } else if (dw && zero_wzp && same3x3 && s.C == 1 && k::dw_stem_name(s.H, s.W, s.N, s.sh)) {
+        } else if (!no_table && dw && zero_wzp && same3x3 && s.C == 1 && k::dw_stem_name(s.H, s.W, s.N, s.sh)) {
             op->fast = OpImpl::DW_STEM;
             op->fast_name = k::dw_stem_name(s.H, s.W, s.N, s.sh);
             k::DwStemArgs &f = op->stem;
@@ -452,7 +450,7 @@ OpImpl *op_create(int device, const OpSpec &spec) {
                 op->fast = OpImpl::DW_C1;
                 op->fast_name = "dw_c1_lds";
             }
-        } else if (!dw && zero_wzp && s.KH == 1 && s.KW == 1 && s.sh == 1 && s.sw == 1 &&
+        } else if (!no_table && !dw && zero_wzp && s.KH == 1 && s.KW == 1 && s.sh == 1 && s.sw == 1 &&
                    s.OH == s.H && s.OW == s.W && k::pw_name(s.C, s.N) &&
                    (s.C != 8 || ((s.H * s.W) % 2 == 0))) {
             op->fast = OpImpl::PW_MFMA;
