@@ -361,6 +361,123 @@ __global__ __launch_bounds__(256) void pw_rt(const int8_t *__restrict__ in, int8
     }
 }
 
+// ------------------------------------------------------------------------
+// conv_rows_lds -- Conv2D with FEW input channels, any filter / stride / padding (a network's first convolution:
+// 3x3x3 -> 16 stride 2 and the like; src/ops/conv_2d.rs:28-108), and DepthwiseConv2D with ONE input channel and a
+// depth multiplier (src/ops/depthwise_conv_2d.rs:67: every output channel reads input channel 0).
+//
+// With few channels the taps of one filter row are KW * C CONSECUTIVE bytes of the NHWC image row, and the same holds
+// for the filter ([N][KH][KW][C]): a window row is KG = ceil(KW C / 4) dwords and every (filter row, dword group,
+// output channel) is one real 4-MAC v_dot4.
+//   step    : G whole images per workgroup step; the NEXT step's images are loaded into registers (dwords, 16 per thread)
+//             before this step's compute and written to the LDS tiles after it -- inside a halo of the input zero point,
+//             so that SAME padding needs no per-tap test.
+//   item    : one output pixel x 8 output channels per thread: the window row is read as KG + 1 aligned dwords and
+//             shifted with v_alignbyte; the packed weights ([ky][group][8 channels] dwords) are LDS broadcasts.
+//   WZ      : filter zero points (conv_2d.rs:57-63): acc -= fzp[n] * (sum of the window), one more v_dot4 per row group
+//             against the byte mask of the real taps.
+// ------------------------------------------------------------------------
+template <bool WZ, int MG, uint32_t XR4>
+__global__ __launch_bounds__(512) void conv_rows_lds(const int8_t *__restrict__ in, int8_t *__restrict__ out, ConvRowsArgs p, int batch) {
+    constexpr int NTHR = 512, MAXE = 16;
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const int tid = threadIdx.x;
+    const int KG = p.KG, KH = p.KH, TWP = p.TWP, TILE = p.TILE, G = p.G, NP = p.NP, NG8 = NP >> 3, N = p.N;
+    const int W_OFF = G * TILE;                          // [KH][KG][NP] weight dwords
+    const int M_OFF = W_OFF + KH * KG * NP * 4;          // [KG] byte masks of the real taps (WZ)
+    const int C_OFF = M_OFF + ((KG * 4 + 15) & ~15);     // A, S, Kc, fzp: [NP] each
+    for (int i = tid; i < G * TILE / 4; i += NTHR) ((uint32_t *)lds)[i] = p.izp4;
+    for (int i = tid; i < KH * KG * NP; i += NTHR) ((uint32_t *)(lds + W_OFF))[i] = p.wpack[i];
+    for (int i = tid; i < KG; i += NTHR) ((uint32_t *)(lds + M_OFF))[i] = p.mask[i];
+    for (int i = tid; i < NP; i += NTHR) {
+        const bool live = i < N;
+        ((float *)(lds + C_OFF))[i] = live ? p.A[i] : 0.0f;
+        ((float *)(lds + C_OFF + NP * 4))[i] = live ? p.S[i] : 0.0f;
+        ((int *)(lds + C_OFF + NP * 8))[i] = (live ? p.Kc[i] : 0) + (MG != 0 ? MF_MAGIC_I : 0);
+        ((int *)(lds + C_OFF + NP * 12))[i] = (WZ && live) ? p.wzp[i] : 0;
+    }
+    // staging map (the same for every step): dword e of this thread is image g, row y, dword x of the step
+    const int ROWD = p.ROWB >> 2, IMGD = p.H * ROWD, STEPD = G * IMGD;
+    int gofs[MAXE], lofs[MAXE];
+#pragma unroll
+    for (int e = 0; e < MAXE; ++e) {
+        const int idx = tid + NTHR * e;
+        const int g = idx / IMGD, r = idx - g * IMGD, y = r / ROWD, x = r - y * ROWD;
+        gofs[e] = idx < STEPD ? idx : -1;
+        lofs[e] = g * TILE + (y + p.shy) * TWP + p.XO + 4 * x;
+    }
+    const int nsteps = (batch + G - 1) / G;
+    uint32_t v[MAXE];
+    auto fetch = [&](int st) {
+        const uint32_t *src = (const uint32_t *)in + (size_t)st * STEPD;
+        const long lim = ((long)batch - (long)st * G) * IMGD; // dwords of the step that exist (a ragged last step)
+#pragma unroll
+        for (int e = 0; e < MAXE; ++e) v[e] = (gofs[e] >= 0 && gofs[e] < lim) ? src[gofs[e]] : p.izp4;
+    };
+    const float inv_ow = 1.0f / (float)p.OW, inv_opix = 1.0f / (float)(p.OH * p.OW);
+    const int OPIX = p.OH * p.OW;
+    int step = blockIdx.x;
+    if (step < nsteps) fetch(step);
+    for (; step < nsteps; step += gridDim.x) {
+        __syncthreads();                                 // the previous step's compute is done with the tiles
+#pragma unroll
+        for (int e = 0; e < MAXE; ++e)
+            if (gofs[e] >= 0) *(uint32_t *)(lds + lofs[e]) = v[e];
+        __syncthreads();
+        if (step + gridDim.x < nsteps) fetch(step + gridDim.x); // in flight during the compute below
+        const int gvalid = min(G, batch - step * G);
+        for (int po = tid; po < G * OPIX; po += NTHR) {
+            // pixel item -> (image, row, column); exact float divisions (indices < 2^22)
+            const int g = (int)(((float)po + 0.5f) * inv_opix);
+            const int o = po - g * OPIX;
+            const int oy = (int)(((float)o + 0.5f) * inv_ow), ox = o - oy * p.OW;
+            if (g >= gvalid) continue;
+            for (int cgp = 0; cgp < NG8; ++cgp) {        // 8 output channels at a time
+            int acc[8], wsum = 0;
+            const int4 k0 = *(const int4 *)(lds + C_OFF + NP * 8 + cgp * 32), k1 = *(const int4 *)(lds + C_OFF + NP * 8 + cgp * 32 + 16);
+            acc[0] = k0.x, acc[1] = k0.y, acc[2] = k0.z, acc[3] = k0.w, acc[4] = k1.x, acc[5] = k1.y, acc[6] = k1.z, acc[7] = k1.w;
+            const int base0 = g * TILE + (oy * p.sh) * TWP + ox * p.sw * p.C + p.X0;
+            for (int ky = 0; ky < KH; ++ky) {
+                const int base = base0 + ky * TWP;
+                const uint32_t *row = (const uint32_t *)(lds + (base & ~3));
+                const uint32_t sh = (uint32_t)(base & 3);
+                uint32_t lo = row[0];
+                for (int kg = 0; kg < KG; ++kg) {
+                    const uint32_t hi = row[kg + 1];
+                    const uint32_t val = __builtin_amdgcn_alignbyte(hi, lo, sh); // window bytes 4 kg .. 4 kg + 3 of this row
+                    lo = hi;
+                    const uint4 w0 = *(const uint4 *)(lds + W_OFF + ((ky * KG + kg) * NP + cgp * 8) * 4);
+                    const uint4 w1 = *(const uint4 *)(lds + W_OFF + ((ky * KG + kg) * NP + cgp * 8) * 4 + 16);
+                    acc[0] = sdot4(val, w0.x, acc[0]), acc[1] = sdot4(val, w0.y, acc[1]);
+                    acc[2] = sdot4(val, w0.z, acc[2]), acc[3] = sdot4(val, w0.w, acc[3]);
+                    acc[4] = sdot4(val, w1.x, acc[4]), acc[5] = sdot4(val, w1.y, acc[5]);
+                    acc[6] = sdot4(val, w1.z, acc[6]), acc[7] = sdot4(val, w1.w, acc[7]);
+                    if constexpr (WZ) wsum = sdot4(val, ((const uint32_t *)(lds + M_OFF))[kg], wsum);
+                }
+            }
+            if constexpr (WZ) {
+                const int4 z0 = *(const int4 *)(lds + C_OFF + NP * 12 + cgp * 32), z1 = *(const int4 *)(lds + C_OFF + NP * 12 + cgp * 32 + 16);
+                acc[0] -= z0.x * wsum, acc[1] -= z0.y * wsum, acc[2] -= z0.z * wsum, acc[3] -= z0.w * wsum;
+                acc[4] -= z1.x * wsum, acc[5] -= z1.y * wsum, acc[6] -= z1.z * wsum, acc[7] -= z1.w * wsum;
+            }
+            const float4 a0 = *(const float4 *)(lds + C_OFF + cgp * 32), a1 = *(const float4 *)(lds + C_OFF + cgp * 32 + 16);
+            const float4 s0 = *(const float4 *)(lds + C_OFF + NP * 4 + cgp * 32), s1 = *(const float4 *)(lds + C_OFF + NP * 4 + cgp * 32 + 16);
+            const uint32_t d0 = requant_pack4<MG, XR4>(acc[0], acc[1], acc[2], acc[3], a0, s0, p.lo_f, p.hi_f);
+            const uint32_t d1 = requant_pack4<MG, XR4>(acc[4], acc[5], acc[6], acc[7], a1, s1, p.lo_f, p.hi_f);
+            int8_t *dst = out + ((size_t)(step * G + g) * OPIX + o) * N + cgp * 8;
+            if ((N & 7) == 0) {
+                *(uint2 *)dst = make_uint2(d0, d1);
+            } else {                                     // N not a multiple of 8: byte stores of the channels that exist
+                const int nleft = N - cgp * 8;
+#pragma unroll
+                for (int c = 0; c < 8; ++c)
+                    if (c < nleft) dst[c] = (int8_t)(((c < 4 ? d0 : d1) >> (8 * (c & 3))) & 0xffu);
+            }
+            }
+        }
+    }
+}
+
 // ---- launchers ----
 bool dw_rt_plan(DwRtArgs &a, int H, int W, int C, int S, int OH, int OW) {
     if (C % 4 != 0 || C / 4 > 512 || (S != 1 && S != 2) || (W * C) % 16 != 0) return false;
@@ -514,6 +631,74 @@ void launch_pw_rt(const int8_t *in, int8_t *out, const PwRtArgs &a, bool wz, lon
             if (mg == 2) launch_pw_rt_t<WZZ, 2, 0u>(in, out, a, npix, s);                          \
             else if (mg) launch_pw_rt_t<WZZ, 1, 0u>(in, out, a, npix, s);                          \
             else launch_pw_rt_t<WZZ, 0, 0u>(in, out, a, npix, s);                                  \
+        }                                                                                          \
+    } while (0)
+    if (wz) MF_RT_GO(true); else MF_RT_GO(false);
+#undef MF_RT_GO
+}
+
+int conv_rows_lds_bytes(const ConvRowsArgs &a) {
+    return a.G * a.TILE + a.KH * a.KG * a.NP * 4 + ((a.KG * 4 + 15) & ~15) + a.NP * 16 + 64;
+}
+// fills the geometry of a; false: the shape is not for this kernel
+bool conv_rows_plan(ConvRowsArgs &a, int H, int W, int C, int N, int KH, int KW, int sh, int sw, int OH, int OW, bool pad_same) {
+    const int RWB = KW * C;
+    if (RWB > 64 || KH > 16 || N < 1 || N > 64 || (W * C) % 4 != 0 || C > 16) return false;
+    a.H = H, a.W = W, a.C = C, a.N = N, a.KH = KH, a.KW = KW, a.sh = sh, a.sw = sw, a.OH = OH, a.OW = OW;
+    a.ROWB = W * C, a.KG = (RWB + 3) / 4, a.NP = (N + 7) & ~7;
+    const int padl = pad_same ? (KW - 1) / 2 : 0, padt = pad_same ? (KH - 1) / 2 : 0;
+    a.shy = padt;
+    a.XO = (padl * C + 3) & ~3;                       // image column 0 at a dword boundary
+    a.X0 = a.XO - padl * C;                           // window of output column 0 starts here
+    const int need = a.X0 + ((OW - 1) * sw) * C + 4 * (a.KG + 1); // last window's last aligned dword
+    a.TWP = (std::max(need, a.XO + W * C) + 3 + 4) & ~3;
+    const int TH = std::max((OH - 1) * sh + KH, padt + H);
+    a.TILE = (TH * a.TWP + 4 + 15) & ~15;
+    const int img_dwords = H * (W * C / 4);
+    int g = std::min(8, (512 * 16) / std::max(img_dwords, 1));   // 16 prefetched dwords per thread
+    while (g > 1 && g * a.TILE > 64 * 1024) --g;
+    if (g < 1 || a.TILE > 64 * 1024) return false;
+    a.G = g;
+    return conv_rows_lds_bytes(a) <= 96 * 1024;
+}
+template <bool WZ, int MG, uint32_t XR4>
+static void launch_conv_rows_t(const int8_t *in, int8_t *out, const ConvRowsArgs &a, int batch, hipStream_t s) {
+    const int lds = conv_rows_lds_bytes(a);
+    int per_cu = 1;
+    {
+        static std::mutex mu;
+        static std::map<std::pair<int, int>, int> cache;
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        std::lock_guard<std::mutex> lock(mu);
+        auto it = cache.find({dev, lds});
+        if (it == cache.end()) {
+            (void)hipFuncSetAttribute((const void *)conv_rows_lds<WZ, MG, XR4>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+            int n = 1;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_rows_lds<WZ, MG, XR4>, 512, (size_t)lds) != hipSuccess || n < 1) {
+                (void)hipGetLastError();
+                n = 1;
+            }
+            it = cache.emplace(std::make_pair(dev, lds), n).first;
+        }
+        per_cu = it->second;
+    }
+    const int nsteps = (batch + a.G - 1) / a.G;
+    const int grid = nsteps < 256 * per_cu ? nsteps : 256 * per_cu;
+    hipLaunchKernelGGL((conv_rows_lds<WZ, MG, XR4>), dim3(grid), dim3(512), lds, s, in, out, a, batch);
+}
+void launch_conv_rows(const int8_t *in, int8_t *out, const ConvRowsArgs &a, bool wz, int batch, hipStream_t s) {
+    const int mg = a.magic;
+#define MF_RT_GO(WZZ)                                                                              \
+    do {                                                                                           \
+        if (a.xr) {                                                                                \
+            if (mg == 2) launch_conv_rows_t<WZZ, 2, 0x80808080u>(in, out, a, batch, s);            \
+            else if (mg) launch_conv_rows_t<WZZ, 1, 0x80808080u>(in, out, a, batch, s);            \
+            else launch_conv_rows_t<WZZ, 0, 0x80808080u>(in, out, a, batch, s);                    \
+        } else {                                                                                   \
+            if (mg == 2) launch_conv_rows_t<WZZ, 2, 0u>(in, out, a, batch, s);                     \
+            else if (mg) launch_conv_rows_t<WZZ, 1, 0u>(in, out, a, batch, s);                     \
+            else launch_conv_rows_t<WZZ, 0, 0u>(in, out, a, batch, s);                             \
         }                                                                                          \
     } while (0)
     if (wz) MF_RT_GO(true); else MF_RT_GO(false);

@@ -145,6 +145,25 @@ struct PwRtArgs {
     int TB, NSPLIT;     // pw_rt (weights in registers): tiles per wave block (1..4; 0 = use pw_rt_lds) and waves per chunk (1, 2, 4)
     int magic, xr;
 };
+// Conv2D with few input channels / DepthwiseConv2D with one input channel, any filter (k_rt.hip: conv_rows_lds)
+struct ConvRowsArgs {
+    int H, W, C, N, KH, KW, sh, sw, OH, OW;
+    int ROWB;            // W * C: image row bytes (a multiple of 4)
+    int KG, NP;          // dword groups per window row = ceil(KW C / 4); N rounded up to 8
+    int shy, XO, X0;     // halo rows above the image; tile byte of image column 0 / of output column 0's window
+    int TWP, TILE, G;    // tile row pitch, bytes per image tile, images per step
+    uint32_t izp4;
+    float lo_f, hi_f;
+    const uint32_t *wpack; // [KH][KG][NP] dwords: byte b = weight (n, ky, 4 kg + b) (zero beyond KW C and beyond N)
+    const uint32_t *mask;  // [KG] dwords: 1 in every byte that is a real tap
+    const float *A;
+    const float *S;
+    const int *Kc;
+    const int *wzp;
+    int magic, xr;
+};
+bool conv_rows_plan(ConvRowsArgs &a, int H, int W, int C, int N, int KH, int KW, int sh, int sw, int OH, int OW, bool pad_same);
+void launch_conv_rows(const int8_t *in, int8_t *out, const ConvRowsArgs &a, bool wz, int batch, hipStream_t s);
 bool dw_rt_plan(DwRtArgs &a, int H, int W, int C, int S, int OH, int OW); // fills the geometry; false: not supported
 void launch_dw_rt(const int8_t *in, int8_t *out, const DwRtArgs &a, int S, bool wz, int batch, hipStream_t s);
 bool pw_rt_supported(int K, int N, bool wz);

@@ -89,7 +89,7 @@ struct OpImpl {
     bool accepts_f32 = false;  // op_set_input_quant succeeded: op_run_f32 may replace quantize + op_run
     bool finite_consts = true; // A / S all finite (the shape-specialised and fused epilogues assume it)
     std::string generic_name, fast_name;
-    enum Fast { NONE, DW_NHWC, DW_STEM, DW_C1, PW_MFMA, FC_ROWWAVE, FC_MFMA, POOL_C4, CONV1X1_ROW, DW_RT, PW_RT } fast = NONE;
+    enum Fast { NONE, DW_NHWC, DW_STEM, DW_C1, PW_MFMA, FC_ROWWAVE, FC_MFMA, POOL_C4, CONV1X1_ROW, DW_RT, PW_RT, CONV_ROWS } fast = NONE;
     int *d_rowsum = nullptr; // FC_MFMA with wzp != 0: per-row input sums
     size_t rowsum_cap = 0;
     int8_t *d_ext = nullptr; // op_run_external on a u8 operator: input moved to the i8 domain
@@ -108,6 +108,8 @@ struct OpImpl {
     // run-time-geometry kernels (k_rt.hip): shapes outside the tables of kernels.hpp
     k::DwRtArgs dwrt{};
     k::PwRtArgs pwrt{};
+    k::ConvRowsArgs crows{};
+    DevBuf d_crw, d_crm;   // conv_rows_lds: packed weights, tap masks
     bool rt_wz = false;    // non-zero weight zero points
     int pw_group = 1;      // pixels presented as one row of the 1x1 product (K = 8 -> 2, K = 4 -> 4)
     DevBuf d_rtA, d_rtS, d_rtKc, d_rtwzp; // constants replicated per group member
@@ -520,6 +522,34 @@ OpImpl *op_create(int device, const OpSpec &spec) {
                 }
             }
         }
+        // few input channels (a first convolution; a one-channel depthwise with more than 8 outputs): window rows as dwords
+        // (a one-channel depthwise keeps dw_c1_lds only where the one-launch speech kernel builds on it, k_dwfc.hip;
+        // measured on the 96x96 stem: dw_c1_lds 1.22 ms, conv_rows_lds 0.70 ms; MF_DW_C1=lds forces the old kernel)
+        static const bool c1_lds = [] { const char *e = getenv("MF_DW_C1"); return e && e[0] == 'l'; }();
+        const bool rows_for_c1 = !c1_lds && !k::dwfc_supported(s.H, s.W, s.KH, s.KW, s.sh, s.sw, s.OH, s.OW, s.N, 4);
+        if ((op->fast == OpImpl::NONE || (op->fast == OpImpl::DW_C1 && rows_for_c1)) && !no_rt && op->finite_consts &&
+            (!dw || s.C == 1) && !(s.KH == 1 && s.KW == 1 && !dw && k::conv1x1_rowwave_supported(a)) &&
+            k::conv_rows_plan(op->crows, s.H, s.W, s.C, s.N, s.KH, s.KW, s.sh, s.sw, s.OH, s.OW, s.pad == MF_PAD_SAME)) {
+            k::ConvRowsArgs &f = op->crows;
+            std::vector<uint32_t> wp((size_t)s.KH * f.KG * f.NP, 0), mk((size_t)f.KG, 0);
+            const int RWB = s.KW * s.C;
+            for (int n = 0; n < s.N; ++n)
+                for (int ky = 0; ky < s.KH; ++ky)
+                    for (int b = 0; b < RWB; ++b) {
+                        // conv filters [N][KH][KW][C]: byte b of row ky = (kx, c) in memory order; depthwise [KH][KW][N], C == 1
+                        const int8_t wv = dw ? s.weights[((size_t)ky * s.KW + b) * s.N + n] : s.weights[((size_t)n * s.KH + ky) * RWB + b];
+                        wp[((size_t)ky * f.KG + b / 4) * f.NP + n] |= (uint32_t)(uint8_t)wv << (8 * (b & 3));
+                    }
+            for (int b = 0; b < RWB; ++b) mk[(size_t)(b / 4)] |= 1u << (8 * (b & 3));
+            op->d_crw.upload(wp.data(), wp.size() * 4), op->d_crm.upload(mk.data(), mk.size() * 4);
+            f.wpack = op->d_crw.as<uint32_t>(), f.mask = op->d_crm.as<uint32_t>();
+            f.A = a.A, f.S = a.S, f.Kc = a.Kc, f.wzp = a.wzp;
+            f.izp4 = 0x01010101u * (uint32_t)(uint8_t)(int8_t)s.izp;
+            f.lo_f = a.lo_f, f.hi_f = a.hi_f, f.magic = magic, f.xr = xr;
+            op->fast = OpImpl::CONV_ROWS;
+            op->rt_wz = !all_zero(wzp);
+            op->fast_name = std::string(dw ? "dw_rows_lds" : "conv_rows_lds") + (op->rt_wz ? "<wzp>" : "");
+        }
         if (op->fast == OpImpl::NONE && !dw && k::conv1x1_rowwave_supported(a)) // few outputs: one wavefront per pixel
             op->fast = OpImpl::CONV1X1_ROW, op->fast_name = "conv1x1_rowwave";
         if (getenv("MF_VERBOSE"))
@@ -667,6 +697,10 @@ void op_run(OpImpl *op, const int8_t *d_in, size_t batch, int8_t *d_out, void *s
             break;
         case OpImpl::PW_MFMA:
             done = k::launch_pw(sp.C, sp.N, d_in, d_out, op->pw, (long long)batch * sp.H * sp.W, s);
+            break;
+        case OpImpl::CONV_ROWS:
+            k::launch_conv_rows(d_in, d_out, op->crows, op->rt_wz, (int)batch, s);
+            done = true;
             break;
         case OpImpl::DW_RT:
             k::launch_dw_rt(d_in, d_out, op->dwrt, sp.sh, op->rt_wz, (int)batch, s);

@@ -221,8 +221,10 @@ def test_conv_generic_vs_oracle(mf, O, case):
     c0, c1 = _rand_consts(rng, N, KH * KW * C, per_channel=pc)
     opts = mf.ops.Conv2DOptions(mf.FusedActivation(act), mf.TensorViewPadding(pad), (sh, sw))
     op = mf.ops.prepare_conv_2d((H, W, C), f, fzp, izp, oscale, ozp, opts, (c0, c1), (OH, OW))
-    # filters larger than 1x1 have no fast kernel; a 1x1 filter with weight zero points runs pw_rt (k_rt.hip)
-    assert op.kernel == ("conv2d_generic" if KH * KW > 1 else "pw_rt<16,16,wzp>"), op.kernel
+    # few input channels with image rows in whole dwords: conv_rows_lds; a 1x1 filter with weight zero points: pw_rt
+    # (k_rt.hip); 3 channels x 7 columns = 21-byte rows: the shape-generic kernel
+    want_kernel = "pw_rt<16,16,wzp>" if KH * KW == 1 else ("conv_rows_lds<wzp>" if (W * C) % 4 == 0 else "conv2d_generic")
+    assert op.kernel == want_kernel, op.kernel
     want = np.stack([O.conv_2d(x[i], f, fzp, izp, oscale, ozp, act, pad, (sh, sw), (OH, OW), c0, c1)
                      for i in range(batch)])
     assert np.array_equal(op(x), want)

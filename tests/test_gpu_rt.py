@@ -142,3 +142,54 @@ def test_rt_kernels_on_a_large_batch_and_accumulator_extremes(mf, O):
     assert np.array_equal(got[idx], want)
     op.set_generic(True)
     assert np.array_equal(op(torch.as_tensor(x).cuda()).cpu().numpy(), got)
+
+
+ROWS = [
+    # kind, H, W, C, N, KH, KW, sh, sw, pad (0 SAME / 1 VALID), weight zero points, batch
+    ("conv", 96, 96, 3, 16, 3, 3, 2, 2, 0, False, 5),     # a colour MobileNet stem (rows of 288 bytes)
+    ("conv", 32, 32, 3, 16, 3, 3, 2, 2, 0, False, 9),
+    ("conv", 20, 16, 4, 8, 5, 5, 1, 1, 0, False, 7),      # 5x5 SAME
+    ("conv", 17, 12, 2, 24, 3, 3, 1, 2, 1, False, 6),     # VALID, stride (1, 2), N = 24
+    ("conv", 9, 8, 1, 5, 3, 3, 1, 1, 0, False, 11),       # N = 5: byte stores
+    ("conv", 12, 12, 4, 64, 3, 3, 2, 2, 0, False, 4),     # N = 64
+    ("conv", 10, 8, 3, 12, 1, 1, 1, 1, 0, False, 5),      # 1x1 with 3 input channels
+    ("conv", 9, 9, 4, 8, 3, 3, 2, 2, 0, True, 5),         # filter zero points
+    ("conv", 14, 16, 3, 10, 4, 2, 2, 1, 1, True, 5),      # even-sized filter, VALID, filter zero points
+    ("dw", 128, 128, 1, 8, 3, 3, 2, 2, 0, False, 3),      # the person_detect stem at 128 x 128
+    ("dw", 40, 40, 1, 16, 3, 3, 2, 2, 0, False, 5),       # depth multiplier 16 (dw_c1_lds stops at 8)
+    ("dw", 30, 28, 1, 12, 5, 3, 1, 1, 0, True, 4),        # weight zero points
+]
+
+
+@pytest.mark.parametrize("case", ROWS, ids=lambda c: "x".join(map(str, c)))
+@pytest.mark.parametrize("u8", [False, True], ids=["i8", "u8"])
+def test_conv_rows_vs_oracle(mf, O, case, u8, monkeypatch):
+    kind, H, W, C, N, KH, KW, sh, sw, pad, wz, batch = case
+    rng = np.random.default_rng(hash(case) % (2 ** 32) + int(u8))
+    dt = np.uint8 if u8 else np.int8
+    lo, hi = (0, 256) if u8 else (-128, 128)
+    if pad == 0:
+        OH, OW = -(-H // sh), -(-W // sw)
+    else:
+        OH, OW = (H - KH) // sh + 1, (W - KW) // sw + 1
+    x = rng.integers(lo, hi, (batch, H, W, C)).astype(dt)
+    x[0] = hi - 1
+    izp, oscale, ozp, act = int(rng.integers(lo, hi)), 0.0235294122, int(rng.integers(lo, lo + 100)), int(rng.choice([0, 1, 3]))
+    zp = (rng.integers(-25, 25, N) + (128 if u8 else 0)).astype(dt) if wz else np.full(N, 128 if u8 else 0, dt)
+    c0, c1 = _consts(rng, N, KH * KW * C)
+    if kind == "conv":
+        f = rng.integers(lo, hi, (N, KH, KW, C)).astype(dt)
+        opts = mf.ops.Conv2DOptions(mf.FusedActivation(act), mf.TensorViewPadding(pad), (sh, sw))
+        op = mf.ops.prepare_conv_2d((H, W, C), f, zp, izp, oscale, ozp, opts, (c0, c1), (OH, OW))
+        assert op.kernel == "conv_rows_lds" + ("<wzp>" if wz else ""), op.kernel
+        want = np.stack([O.conv_2d(x[i], f, zp, izp, oscale, ozp, act, pad, (sh, sw), (OH, OW), c0, c1) for i in range(batch)])
+    else:
+        w = rng.integers(lo, hi, (KH, KW, N)).astype(dt)
+        opts = mf.ops.DepthwiseConv2DOptions(mf.FusedActivation(act), mf.TensorViewPadding(pad), (sh, sw))
+        op = mf.ops.prepare_depthwise_conv_2d((H, W, C), w, zp, izp, oscale, ozp, opts, (c0, c1), (OH, OW))
+        assert op.kernel in ("dw_rows_lds" + ("<wzp>" if wz else ""), "dw_c1_lds"), op.kernel
+        want = np.stack([O.depthwise_conv_2d(x[i], w, zp, izp, oscale, ozp, act, pad, (sh, sw), (OH, OW), c0, c1) for i in range(batch)])
+    got = op(x)
+    assert np.array_equal(got, want), (op.kernel, np.argwhere(got != want)[:5])
+    op.set_generic(True)
+    assert np.array_equal(op(x), want)
