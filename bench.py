@@ -411,6 +411,11 @@ def main():
                                    "starts with it) -> dequantize kernel"}
             del xf, yf
 
+        generic_fb = rt_rec = None
+        if args.workload == "person_detect" and not args.no_extra:
+            generic_fb = generic_fallback_record(ctx, m, x, count, ev_med)
+            rt_rec = runtime_geometry_record(ctx, lw_kernels)
+
         result = {
             "metric": "inferences/sec (int8) for %s" % fname, "value": round(value, 1),
             "unit": "inferences/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -436,6 +441,8 @@ def main():
             "cpu_baseline_all_cores": cpu_mt,
             "host_fed": host_fed,
             "predict_f32": predict_f32,
+            "generic_fallback": generic_fb,
+            "runtime_geometry": rt_rec,
             "parity": {"bit_exact_vs_oracle": parity_ok, "what": PARITY_NOTE, "sampled_images": len(idx),
                        "structured_images": n_struct, "structured_distinct_outputs": n_distinct,
                        "structured_bit_exact": structured_ok,
@@ -656,6 +663,103 @@ def int8_gemm_crosscheck(torch, x, w_nk, iters=20):
     best = [v["TOPs"] for v in out["results"].values() if v.get("correct")]
     out["best_TOPs"] = max(best) if best else None
     return out
+
+
+def op_bytes_table(m, per_op, count):
+    """per launch: algorithmic bytes (unique in + out), GB/s -- for the layer-wise (one kernel per operator) sub-records"""
+    rows = []
+    for i in range(m.num_ops):
+        d = m.op(i)
+        if not d["kernel"] or d["kernel"].startswith("(fused") or per_op[i] <= 0:
+            continue
+        nbytes = (int(np.prod(d["in_shape"])) + d["out_elems"]) * count
+        rows.append({"op": i, "kind": d["name"], "kernel": d["kernel"], "ms": round(per_op[i], 4), "bytes": nbytes,
+                     "GBps": round(nbytes / (per_op[i] * 1e-3) / 1e9, 1)})
+    return rows
+
+
+def kind_agg(rows, kind):
+    ks = [k for k in rows if k["kind"] == kind]
+    ms, by = sum(k["ms"] for k in ks), sum(k["bytes"] for k in ks)
+    return {"kernels": len(ks), "ms": round(ms, 4), "GBps": round(by / (ms * 1e-3) / 1e9, 1) if ms > 0 else 0.0,
+            "frac": round(by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ms > 0 else 0.0}
+
+
+def runtime_geometry_record(ctx, table_layerwise):
+    """Shapes outside person_detect's tables (the reference compiles for any shape: src/ops/depthwise_conv_2d.rs:28-49):
+    (1) person_detect itself with the table kernels switched off (MF_NO_TABLE=1, a subprocess because routing is decided
+    when an operator is created) against the table kernels' layer-wise numbers of this run -- same shapes, like for like;
+    (2) generated person_detect-shaped models at other input sizes / widths (tools/tflite_writer.person_detect_like)."""
+    mf, _lib, torch, synth_i8, SEED = ctx["mf"], ctx["_lib"], ctx["torch"], ctx["synth_i8"], ctx["SEED"]
+    rec = {"note": "run-time-geometry kernels (k_rt.hip: dw3x3_rt, pw_rt, conv_rows_lds); GB/s = algorithmic bytes / median launch time"}
+    try:
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "time_kernels.py"), "20", "layerwise", "--json"],
+                             env=dict(os.environ, MF_NO_TABLE="1"), capture_output=True, text=True, timeout=300)
+        j = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+        tab = {k["op"]: k for k in table_layerwise}
+        rows = []
+        for k in j["kernels"]:
+            t = tab.get(k["op"])
+            if t and k["kernel"] != t["kernel"]:
+                rows.append({"op": k["op"], "kind": t["kind"], "kernel": k["kernel"], "ms": round(k["ms"], 4), "bytes": t["bytes"],
+                             "GBps": round(t["bytes"] / (k["ms"] * 1e-3) / 1e9, 1), "table_kernel": t["kernel"], "table_ms": t["ms"],
+                             "slowdown": round(k["ms"] / t["ms"], 3) if t["ms"] > 0 else None})
+        cmp_ = {"layerwise_ms": round(j["ms_per_step"], 4), "kernels": rows}
+        for kind in ("depthwise_conv_2d", "conv_2d"):
+            ks = [r for r in rows if r["kind"] == kind]
+            if ks:
+                ms, tms, by = sum(r["ms"] for r in ks), sum(r["table_ms"] for r in ks), sum(r["bytes"] for r in ks)
+                cmp_[kind] = {"kernels": len(ks), "ms": round(ms, 4), "GBps": round(by / (ms * 1e-3) / 1e9, 1), "table_ms": round(tms, 4),
+                              "table_GBps": round(by / (tms * 1e-3) / 1e9, 1), "slowdown": round(ms / tms, 3)}
+        rec["person_detect_without_tables"] = cmp_
+    except Exception as e:  # noqa: BLE001
+        rec["person_detect_without_tables"] = {"error": str(e)[:300]}
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import tflite_writer as tw
+    from oracle import oracle as O
+    L = _lib.lib()
+    models = {}
+    for side, width in ((128, 1.0), (64, 1.0), (96, 0.5)):
+        blob = tw.person_detect_like(np.random.default_rng(side), side, width)
+        m, om = mf.model(blob), O.Model(blob)
+        B = int(65536 * 96 * 96 / (side * side))
+        m.prepare(B, device=ctx["local_rank"])
+        _lib.check(L.mf_model_set_stream(m._h, torch.cuda.current_stream().cuda_stream))
+        x = synth_i8(SEED + 6, 0, B * m.input_elems)
+        y = torch.empty(B * m.output_elems, dtype=torch.int8, device="cuda")
+        fused_ms, _ = m.time_device(x, y, B, warmup=2, iters=10, per_op=False)
+        idx = [0, 1, B // 2, B - 1]
+        ok = bool(np.array_equal(y.reshape(B, -1)[idx].cpu().numpy(), om.run_quantized_batch(x.reshape(B, -1)[idx].cpu().numpy())))
+        m.set_fusion(False)
+        lw_ms, per = m.time_device(x, y, B, warmup=1, iters=10)
+        rows = op_bytes_table(m, per, B)
+        generic = [r["kernel"] for r in rows if r["kernel"].endswith("_generic")]
+        models["%dx%d_width%s" % (side, side, width)] = {
+            "batch": B, "value": round(B / (fused_ms * 1e-3), 1), "unit": "inferences/s", "ms_per_step": round(fused_ms, 4),
+            "layerwise_ms": round(lw_ms, 4), "depthwise": kind_agg(rows, "depthwise_conv_2d"), "conv_2d": kind_agg(rows, "conv_2d"),
+            "kernels_used": sorted({r["kernel"].split("<")[0] for r in rows}), "generic_kernels": generic,
+            "parity": {"bit_exact_vs_oracle": ok, "sampled_images": len(idx)}}
+        del m, x, y
+        torch.cuda.empty_cache()
+    rec["generated_models"] = models
+    return rec
+
+
+def generic_fallback_record(ctx, m, x, count, fast_ms):
+    """The cliff: person_detect on the byte-wise shape-generic kernels (mf_model_set_generic), on a slice of the batch."""
+    torch = ctx["torch"]
+    n = min(count, 2048)
+    y = torch.empty(n * m.output_elems, dtype=torch.int8, device="cuda")
+    m.set_generic(True)
+    try:
+        ms, _ = m.time_device(x[: n * m.input_elems], y, n, warmup=1, iters=3, per_op=False)
+    finally:
+        m.set_generic(False)
+    fast, _ = m.time_device(x[: n * m.input_elems], y, n, warmup=2, iters=10, per_op=False)
+    return {"batch": n, "ms_per_step": round(ms, 3), "value": round(n / (ms * 1e-3), 1), "unit": "inferences/s",
+            "fast_path_ms_same_batch": round(fast, 4), "slowdown": round(ms / fast, 1),
+            "note": "every operator on its `*_generic` kernel (one thread per output element, byte loads): what a shape with "
+                    "no fast kernel costs; the fused step of the full batch takes %.3f ms" % fast_ms}
 
 
 def cpu_baseline(om, x_dev_rows, seconds):
