@@ -415,6 +415,7 @@ def main():
         if args.workload == "person_detect" and not args.no_extra:
             generic_fb = generic_fallback_record(ctx, m, x, count, ev_med)
             rt_rec = runtime_geometry_record(ctx, lw_kernels)
+            rt_rec["general_conv"] = general_conv_record(ctx)
 
         result = {
             "metric": "inferences/sec (int8) for %s" % fname, "value": round(value, 1),
@@ -743,6 +744,41 @@ def runtime_geometry_record(ctx, table_layerwise):
         torch.cuda.empty_cache()
     rec["generated_models"] = models
     return rec
+
+
+def general_conv_record(ctx):
+    """Conv2D beyond 1x1 (src/ops/conv_2d.rs:28-108 is generic in filter size): a colour MobileNet stem (3x3x3 -> 16, stride 2,
+    batch 65536: conv_rows_lds), a ResNet-8-style 3x3 block (16 -> 16 on 32x32: conv_mm_rt, the MFMA product over
+    K = KH KW C) and a 64 -> 64 one on 8x8, each against the shape-generic kernel on a slice of its batch."""
+    mf, torch = ctx["mf"], ctx["torch"]
+    from oracle import oracle as O
+    rng = np.random.default_rng(3)
+    out = {}
+    for name, (H, W, C, N, K, S, B) in {"stem_96x96x3_to_16_s2": (96, 96, 3, 16, 3, 2, 65536), "block_32x32x16_to_16": (32, 32, 16, 16, 3, 1, 16384),
+                                        "block_8x8x64_to_64": (8, 8, 64, 64, 3, 1, 65536)}.items():
+        OH, OW = -(-H // S), -(-W // S)
+        f = rng.integers(-128, 128, (N, K, K, C)).astype(np.int8)
+        c0 = rng.uniform(-30, 30, N).astype(np.float32)
+        c1 = (rng.uniform(0.5, 1.5, N) * 40.0 / (5476.0 * np.sqrt(K * K * C))).astype(np.float32)
+        opts = mf.ops.Conv2DOptions(mf.FusedActivation(3), mf.TensorViewPadding.SAME, (S, S))
+        op = mf.ops.prepare_conv_2d((H, W, C), f, np.zeros(N, np.int8), -128, 0.0235294122, -128, opts, (c0, c1), (OH, OW))
+        x = torch.randint(-128, 128, (B, H, W, C), dtype=torch.int8, device="cuda")
+        y = op(x)
+        ms = median(event_times(torch, lambda: op(x), 12))
+        idx = [0, B // 2, B - 1]
+        want = np.stack([O.conv_2d(x[i].cpu().numpy(), f, np.zeros(N, np.int8), -128, 0.0235294122, -128, 3, 0, (S, S), (OH, OW), c0, c1) for i in idx])
+        ok = bool(np.array_equal(y[idx].cpu().numpy(), want))
+        kernel = op.kernel
+        nb = min(B, 512)
+        op.set_generic(True)
+        gms = median(event_times(torch, lambda: op(x[:nb]), 3)) * (B / nb)
+        nbytes, macs = B * (H * W * C + OH * OW * N), float(B) * OH * OW * N * K * K * C
+        out[name] = {"kernel": kernel, "batch": B, "ms": round(ms, 4), "GBps": round(nbytes / (ms * 1e-3) / 1e9, 1),
+                     "hbm_frac": round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "TMACps": round(macs / (ms * 1e-3) / 1e12, 2),
+                     "generic_ms_scaled": round(gms, 2), "speedup_vs_generic": round(gms / ms, 1), "bit_exact_vs_oracle": ok}
+        del x, y
+        torch.cuda.empty_cache()
+    return out
 
 
 def generic_fallback_record(ctx, m, x, count, fast_ms):

@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <map>
 #include <mutex>
+#include <vector>
 
 namespace mf {
 namespace k {
@@ -478,6 +479,123 @@ __global__ __launch_bounds__(512) void conv_rows_lds(const int8_t *__restrict__ 
     }
 }
 
+// ------------------------------------------------------------------------
+// conv_mm_rt -- Conv2D with any filter KH x KW, strides, SAME / VALID padding, C % 16 == 0 input channels, N % 4 == 0
+// outputs (src/ops/conv_2d.rs:28-108), as an int8 MFMA product over K = KH * KW * C.
+//
+// In NHWC the filter [N][KH][KW][C] IS the row-major [N][K] matrix, and the 16 operand bytes a lane supplies for k-bytes
+// 64 ks + 16 g .. of its pixel are 16 consecutive channels of ONE tap (C % 16 == 0) = 16 consecutive bytes of the staged
+// tile: address = (the pixel's window start) + (a per-(k step, lane group) offset from a small table).  No im2col.
+//   step    : G whole images or one band of output rows, staged by LDS-DMA into halo'd tiles as in dw3x3_rt (one staging
+//             buffer: the product is matrix-pipe work, several workgroups per CU cover each other's DMA waits).
+//   weights : operand A for every (block of <= 4 tiles, tile, k step) in LDS, rows permuted so that a lane ends with
+//             4 TB consecutive output channels (as pw_rt); read once per 16-pixel chunk and block.
+//   WZ      : filter zero points (conv_2d.rs:57-63): one more tile of ones gives the window sum.
+// ------------------------------------------------------------------------
+template <bool WZ, int MG, uint32_t XR4>
+__global__ __launch_bounds__(256) void conv_mm_rt(const int8_t *__restrict__ in, int8_t *__restrict__ out, ConvMmArgs p, int batch) {
+    constexpr int NTHR = 256, NWAVE = 4;
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int C = p.C, N = p.N, KS = p.KS, TB = p.TB, NBLK = p.NBLK, ROW = p.ROW, TILE = p.TILE, G = p.G, RB = p.RB;
+    const int H = p.H, OH = p.OH, OW = p.OW, ROWB = p.W * C, BH = p.BH, NBANDS = p.NBANDS;
+    const int T_OFF = 0, W_OFF = G * TILE + 256;
+    const int WBYTES = NBLK * TB * KS * 1024;
+    const int ONES_OFF = W_OFF + WBYTES;
+    const int O_OFF = ONES_OFF + (WZ ? KS * 1024 : 0);  // [KS][4] tap offsets
+    for (int i = tid; i < (G * TILE + 256) / 16; i += NTHR) ((uint4 *)lds)[i] = make_uint4(p.izp4, p.izp4, p.izp4, p.izp4);
+    for (int i = tid; i < (WBYTES + (WZ ? KS * 1024 : 0)) / 16; i += NTHR) ((uint4 *)(lds + W_OFF))[i] = ((const uint4 *)p.wprep)[i];
+    for (int i = tid; i < KS * 4; i += NTHR) ((int *)(lds + O_OFF))[i] = p.tap_off[i];
+    const int col = lane & 15, g = lane >> 4;
+    const float inv_ow = 1.0f / (float)OW, inv_bp = 1.0f / (float)(BH * OW);
+    const int nsteps = ((batch + G - 1) / G) * NBANDS;
+    __syncthreads();
+    for (int step = blockIdx.x; step < nsteps; step += gridDim.x) {
+        const int band = step % NBANDS, ist = step / NBANDS;
+        const int yfirst = band * BH * p.sh - p.padt;   // input row held by tile row 0
+        __syncthreads();                                 // the previous step's reads of the tile are done
+        for (int gi = 0; gi < G; ++gi) {
+            const long img = (long)ist * G + gi;
+            if (img >= batch) break;
+            for (int r = wave; r < RB; r += NWAVE) {
+                const int y = yfirst + r;
+                uint8_t *dst = lds + T_OFF + gi * TILE + r * ROW + p.LP;
+                if (y >= 0 && y < H) {
+                    const int8_t *src = in + (img * H + y) * (long)ROWB;
+                    for (int o = 0; o < ROWB; o += 1024)
+                        if (o + lane * 16 < ROWB) dma16(src + o + lane * 16, dst + o);
+                } else if (NBANDS > 1) {
+                    for (int o = lane * 16; o < ROWB; o += 1024) *(uint4 *)(dst + o) = make_uint4(p.izp4, p.izp4, p.izp4, p.izp4);
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const int gvalid = min(G, batch - ist * G);
+        const int rows_here = min(BH, OH - band * BH);
+        const int npix = gvalid * BH * OW;               // (rows past the image are masked below)
+        for (int chunk = wave; chunk * 16 < npix; chunk += NWAVE) {
+            const int pp = chunk * 16 + col;
+            const int pc = pp < npix ? pp : npix - 1;
+            const int gi = (int)(((float)pc + 0.5f) * inv_bp);
+            const int rr = pc - gi * BH * OW;
+            const int oyl = (int)(((float)rr + 0.5f) * inv_ow), ox = rr - oyl * OW;
+            const bool live = pp < npix && oyl < rows_here;
+            const uint8_t *win = lds + T_OFF + gi * TILE + (oyl * p.sh) * ROW + p.LP + (ox * p.sw - p.padl) * C;
+            int rowsum = 0;
+            if constexpr (WZ) {
+                v4i acc = {0, 0, 0, 0};
+                for (int ks = 0; ks < KS; ++ks) {
+                    const v4i b = *(const v4i *)(win + ((const int *)(lds + O_OFF))[ks * 4 + g]);
+                    acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(*(const v4i *)(lds + ONES_OFF + ks * 1024 + lane * 16), b, acc, 0, 0, 0);
+                }
+                rowsum = acc[0];
+            }
+            const size_t opix = ((size_t)(ist * G + gi) * OH + band * BH + oyl) * OW + ox;
+            for (int blk = 0; blk < NBLK; ++blk) {
+                const int ch0 = blk * 16 * TB + g * 4 * TB;
+                v4i acc[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int ch = ch0 + 4 * t;
+                    int4 kc = make_int4(0, 0, 0, 0);
+                    if (t < TB && ch < N) kc = *(const int4 *)(p.Kc + ch);
+                    kc = magic4<MG>(kc);
+                    acc[t] = v4i{kc.x, kc.y, kc.z, kc.w};
+                }
+                // two-deep software pipeline: the tap offset of step ks + 2 and the operand B of step ks + 1 are in flight
+                // while step ks multiplies
+                const int *tab = (const int *)(lds + O_OFF) + g;
+                int off1 = KS > 1 ? tab[4] : 0;
+                v4i b = *(const v4i *)(win + tab[0]);
+                for (int ks = 0; ks < KS; ++ks) {
+                    const int off2 = ks + 2 < KS ? tab[(ks + 2) * 4] : 0;
+                    const v4i bn = *(const v4i *)(win + off1);
+                    const uint8_t *wa = lds + W_OFF + ((size_t)(blk * TB) * KS + ks) * 1024 + lane * 16;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        if (t < TB) acc[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(*(const v4i *)(wa + (size_t)t * KS * 1024), b, acc[t], 0, 0, 0);
+                    b = bn, off1 = off2;
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int ch = ch0 + 4 * t;
+                    if (t < TB && ch < N) {
+                        if constexpr (WZ) {
+                            const int4 wz = *(const int4 *)(p.wzp + ch);
+                            acc[t][0] -= wz.x * rowsum, acc[t][1] -= wz.y * rowsum, acc[t][2] -= wz.z * rowsum, acc[t][3] -= wz.w * rowsum;
+                        }
+                        const uint32_t d = requant_pack4<MG, XR4>(acc[t][0], acc[t][1], acc[t][2], acc[t][3], *(const float4 *)(p.A + ch),
+                                                                  *(const float4 *)(p.S + ch), p.lo_f, p.hi_f);
+                        if (live) *(uint32_t *)(out + opix * N + ch) = d;
+                    }
+                }
+            }
+        }
+    }
+}
+
 // ---- launchers ----
 bool dw_rt_plan(DwRtArgs &a, int H, int W, int C, int S, int OH, int OW) {
     if (C % 4 != 0 || C / 4 > 512 || (S != 1 && S != 2) || (W * C) % 16 != 0) return false;
@@ -643,7 +761,7 @@ int conv_rows_lds_bytes(const ConvRowsArgs &a) {
 // fills the geometry of a; false: the shape is not for this kernel
 bool conv_rows_plan(ConvRowsArgs &a, int H, int W, int C, int N, int KH, int KW, int sh, int sw, int OH, int OW, bool pad_same) {
     const int RWB = KW * C;
-    if (RWB > 64 || KH > 16 || N < 1 || N > 64 || (W * C) % 4 != 0 || C > 16) return false;
+    if (RWB > 64 || KH > 16 || N < 1 || N > 64 || (W * C) % 4 != 0 || C >= 16) return false; // (16 and more channels: conv_mm_rt)
     a.H = H, a.W = W, a.C = C, a.N = N, a.KH = KH, a.KW = KW, a.sh = sh, a.sw = sw, a.OH = OH, a.OW = OW;
     a.ROWB = W * C, a.KG = (RWB + 3) / 4, a.NP = (N + 7) & ~7;
     const int padl = pad_same ? (KW - 1) / 2 : 0, padt = pad_same ? (KH - 1) / 2 : 0;
@@ -699,6 +817,94 @@ void launch_conv_rows(const int8_t *in, int8_t *out, const ConvRowsArgs &a, bool
             if (mg == 2) launch_conv_rows_t<WZZ, 2, 0u>(in, out, a, batch, s);                     \
             else if (mg) launch_conv_rows_t<WZZ, 1, 0u>(in, out, a, batch, s);                     \
             else launch_conv_rows_t<WZZ, 0, 0u>(in, out, a, batch, s);                             \
+        }                                                                                          \
+    } while (0)
+    if (wz) MF_RT_GO(true); else MF_RT_GO(false);
+#undef MF_RT_GO
+}
+
+int conv_mm_lds_bytes(const ConvMmArgs &a, bool wz) {
+    return a.G * a.TILE + 256 + a.NBLK * a.TB * a.KS * 1024 + (wz ? a.KS * 1024 : 0) + a.KS * 16 + 64;
+}
+// fills the geometry and the tap-offset table (host copy in `tap`); false: not for this kernel
+bool conv_mm_plan(ConvMmArgs &a, std::vector<int> &tap, int H, int W, int C, int N, int KH, int KW, int sh, int sw, int OH, int OW,
+                  bool pad_same, bool wz) {
+    if (C % 16 != 0 || N % 4 != 0 || KH > 7 || KW > 7 || (W * C) % 16 != 0) return false;
+    const int Ktot = KH * KW * C, KS = (Ktot + 63) / 64, NT = (N + 15) / 16;
+    const int TB = NT < 4 ? NT : 4, NBLK = (NT + TB - 1) / TB;
+    const int wbytes = NBLK * TB * KS * 1024 + (wz ? KS * 1024 : 0);
+    if (wbytes > 96 * 1024) return false;
+    const int padl = pad_same ? (KW - 1) / 2 : 0, padt = pad_same ? (KH - 1) / 2 : 0;
+    const int LP = (padl * C + 15) & ~15;
+    int over = ((OW - 1) * sw - padl + KW - W) * C;      // bytes read right of the image row
+    if (over < 0) over = 0;
+    const int RP = ((over + 15) & ~15) + 16;
+    const int ROW = LP + W * C + RP;
+    a.H = H, a.W = W, a.C = C, a.N = N, a.KH = KH, a.KW = KW, a.sh = sh, a.sw = sw, a.OH = OH, a.OW = OW;
+    a.padl = padl, a.padt = padt, a.LP = LP, a.ROW = ROW, a.KS = KS, a.TB = TB, a.NBLK = NBLK;
+    const int budget = 150 * 1024 - wbytes - 1024;
+    auto rows_for = [&](int bh) { return (bh - 1) * sh + KH; };
+    if (rows_for(OH) * ROW <= budget && rows_for(OH) * ROW <= 48 * 1024) {
+        a.NBANDS = 1, a.BH = OH, a.RB = rows_for(OH), a.TILE = a.RB * ROW;
+        int g = std::min(48 * 1024, budget) / a.TILE;
+        a.G = g < 1 ? 1 : (g > 16 ? 16 : g);
+    } else {
+        int bh = OH;
+        const int cap = std::min(budget, 48 * 1024);
+        while (bh > 1 && rows_for(bh) * ROW > cap) --bh;
+        if (rows_for(bh) * ROW > cap) return false;
+        const int nb = (OH + bh - 1) / bh;
+        bh = (OH + nb - 1) / nb;
+        a.BH = bh, a.NBANDS = (OH + bh - 1) / bh, a.RB = rows_for(bh), a.TILE = a.RB * ROW, a.G = 1;
+    }
+    tap.assign((size_t)KS * 4, 0);
+    for (int ks = 0; ks < KS; ++ks)
+        for (int g = 0; g < 4; ++g) {
+            const int kk0 = ks * 64 + g * 16;
+            if (kk0 >= Ktot) continue;                   // beyond K: zero weights, offset 0
+            const int t = kk0 / C, c0 = kk0 % C, ky = t / KW, kx = t % KW;
+            tap[(size_t)ks * 4 + g] = ky * ROW + kx * C + c0;
+        }
+    return conv_mm_lds_bytes(a, wz) <= 160 * 1024;
+}
+template <bool WZ, int MG, uint32_t XR4>
+static void launch_conv_mm_t(const int8_t *in, int8_t *out, const ConvMmArgs &a, int batch, hipStream_t s) {
+    const int lds = conv_mm_lds_bytes(a, WZ);
+    int per_cu = 1;
+    {
+        static std::mutex mu;
+        static std::map<std::pair<int, int>, int> cache;
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        std::lock_guard<std::mutex> lock(mu);
+        auto it = cache.find({dev, lds});
+        if (it == cache.end()) {
+            (void)hipFuncSetAttribute((const void *)conv_mm_rt<WZ, MG, XR4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            int n = 1;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_mm_rt<WZ, MG, XR4>, 256, (size_t)lds) != hipSuccess || n < 1) {
+                (void)hipGetLastError();
+                n = 1;
+            }
+            it = cache.emplace(std::make_pair(dev, lds), n).first;
+        }
+        per_cu = it->second;
+    }
+    const int nsteps = ((batch + a.G - 1) / a.G) * a.NBANDS;
+    const int grid = nsteps < 256 * per_cu ? nsteps : 256 * per_cu;
+    hipLaunchKernelGGL((conv_mm_rt<WZ, MG, XR4>), dim3(grid), dim3(256), lds, s, in, out, a, batch);
+}
+void launch_conv_mm(const int8_t *in, int8_t *out, const ConvMmArgs &a, bool wz, int batch, hipStream_t s) {
+    const int mg = a.magic;
+#define MF_RT_GO(WZZ)                                                                              \
+    do {                                                                                           \
+        if (a.xr) {                                                                                \
+            if (mg == 2) launch_conv_mm_t<WZZ, 2, 0x80808080u>(in, out, a, batch, s);              \
+            else if (mg) launch_conv_mm_t<WZZ, 1, 0x80808080u>(in, out, a, batch, s);              \
+            else launch_conv_mm_t<WZZ, 0, 0x80808080u>(in, out, a, batch, s);                      \
+        } else {                                                                                   \
+            if (mg == 2) launch_conv_mm_t<WZZ, 2, 0u>(in, out, a, batch, s);                       \
+            else if (mg) launch_conv_mm_t<WZZ, 1, 0u>(in, out, a, batch, s);                       \
+            else launch_conv_mm_t<WZZ, 0, 0u>(in, out, a, batch, s);                               \
         }                                                                                          \
     } while (0)
     if (wz) MF_RT_GO(true); else MF_RT_GO(false);

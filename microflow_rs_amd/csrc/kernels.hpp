@@ -4,6 +4,8 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <vector>
+
 namespace mf {
 namespace k {
 
@@ -164,6 +166,25 @@ struct ConvRowsArgs {
 };
 bool conv_rows_plan(ConvRowsArgs &a, int H, int W, int C, int N, int KH, int KW, int sh, int sw, int OH, int OW, bool pad_same);
 void launch_conv_rows(const int8_t *in, int8_t *out, const ConvRowsArgs &a, bool wz, int batch, hipStream_t s);
+// Conv2D with any filter, C % 16 == 0, as an MFMA product over K = KH KW C (k_rt.hip: conv_mm_rt)
+struct ConvMmArgs {
+    int H, W, C, N, KH, KW, sh, sw, OH, OW;
+    int padl, padt;      // SAME: (KW - 1) / 2, (KH - 1) / 2 (src/tensor.rs:193); VALID: 0
+    int LP, ROW, RB, TILE, G, BH, NBANDS; // tile geometry as DwRtArgs
+    int KS, TB, NBLK;    // 64-deep k steps over K = KH KW C; tiles per block (<= 4); blocks
+    uint32_t izp4;
+    float lo_f, hi_f;
+    const void *wprep;   // [block][tile][k step][lane] x 16 bytes (+ a tile of ones per k step when filter zero points != 0)
+    const int *tap_off;  // [KS][4]: byte offset, from a pixel's window start, of the 16 tile bytes lane group g supplies in k step ks
+    const float *A;
+    const float *S;
+    const int *Kc;
+    const int *wzp;
+    int magic, xr;
+};
+bool conv_mm_plan(ConvMmArgs &a, std::vector<int> &tap, int H, int W, int C, int N, int KH, int KW, int sh, int sw, int OH, int OW,
+                  bool pad_same, bool wz);
+void launch_conv_mm(const int8_t *in, int8_t *out, const ConvMmArgs &a, bool wz, int batch, hipStream_t s);
 bool dw_rt_plan(DwRtArgs &a, int H, int W, int C, int S, int OH, int OW); // fills the geometry; false: not supported
 void launch_dw_rt(const int8_t *in, int8_t *out, const DwRtArgs &a, int S, bool wz, int batch, hipStream_t s);
 bool pw_rt_supported(int K, int N, bool wz);

@@ -89,7 +89,7 @@ struct OpImpl {
     bool accepts_f32 = false;  // op_set_input_quant succeeded: op_run_f32 may replace quantize + op_run
     bool finite_consts = true; // A / S all finite (the shape-specialised and fused epilogues assume it)
     std::string generic_name, fast_name;
-    enum Fast { NONE, DW_NHWC, DW_STEM, DW_C1, PW_MFMA, FC_ROWWAVE, FC_MFMA, POOL_C4, CONV1X1_ROW, DW_RT, PW_RT, CONV_ROWS } fast = NONE;
+    enum Fast { NONE, DW_NHWC, DW_STEM, DW_C1, PW_MFMA, FC_ROWWAVE, FC_MFMA, POOL_C4, CONV1X1_ROW, DW_RT, PW_RT, CONV_ROWS, CONV_MM } fast = NONE;
     int *d_rowsum = nullptr; // FC_MFMA with wzp != 0: per-row input sums
     size_t rowsum_cap = 0;
     int8_t *d_ext = nullptr; // op_run_external on a u8 operator: input moved to the i8 domain
@@ -109,6 +109,8 @@ struct OpImpl {
     k::DwRtArgs dwrt{};
     k::PwRtArgs pwrt{};
     k::ConvRowsArgs crows{};
+    k::ConvMmArgs cmm{};
+    DevBuf d_tap;          // conv_mm_rt: tap offset table
     DevBuf d_crw, d_crm;   // conv_rows_lds: packed weights, tap masks
     bool rt_wz = false;    // non-zero weight zero points
     int pw_group = 1;      // pixels presented as one row of the 1x1 product (K = 8 -> 2, K = 4 -> 4)
@@ -550,6 +552,33 @@ OpImpl *op_create(int device, const OpSpec &spec) {
             op->rt_wz = !all_zero(wzp);
             op->fast_name = std::string(dw ? "dw_rows_lds" : "conv_rows_lds") + (op->rt_wz ? "<wzp>" : "");
         }
+        // any other Conv2D with C % 16 == 0: MFMA product over K = KH KW C with the image staged in LDS
+        if (op->fast == OpImpl::NONE && !no_rt && op->finite_consts && !dw && !(s.KH == 1 && s.KW == 1 && k::conv1x1_rowwave_supported(a))) {
+            const bool wz = !all_zero(wzp);
+            std::vector<int> tap;
+            if (k::conv_mm_plan(op->cmm, tap, s.H, s.W, s.C, s.N, s.KH, s.KW, s.sh, s.sw, s.OH, s.OW, s.pad == MF_PAD_SAME, wz)) {
+                k::ConvMmArgs &f = op->cmm;
+                const int Ktot = s.KH * s.KW * s.C;
+                std::vector<int8_t> prep = build_pw_rt_reg_weights(s.weights, Ktot, s.N, 1, f.TB, f.NBLK); // [N][KH][KW][C] IS [N][K]
+                if (wz) { // + a tile of ones over the real k-bytes
+                    const size_t base_sz = prep.size();
+                    prep.resize(base_sz + (size_t)f.KS * 1024, 0);
+                    for (int ks = 0; ks < f.KS; ++ks)
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int i = 0; i < 16; ++i)
+                                if (ks * 64 + (lane >> 4) * 16 + i < Ktot) prep[base_sz + ((size_t)ks * 64 + lane) * 16 + i] = 1;
+                }
+                op->d_wprep.upload(prep.data(), prep.size());
+                op->d_tap.upload(tap.data(), tap.size() * sizeof(int));
+                f.wprep = op->d_wprep.p, f.tap_off = op->d_tap.as<int>();
+                f.A = a.A, f.S = a.S, f.Kc = a.Kc, f.wzp = a.wzp;
+                f.izp4 = 0x01010101u * (uint32_t)(uint8_t)(int8_t)s.izp;
+                f.lo_f = a.lo_f, f.hi_f = a.hi_f, f.magic = magic, f.xr = xr;
+                op->fast = OpImpl::CONV_MM;
+                op->rt_wz = wz;
+                op->fast_name = std::string("conv_mm_rt") + (wz ? "<wzp>" : "");
+            }
+        }
         if (op->fast == OpImpl::NONE && !dw && k::conv1x1_rowwave_supported(a)) // few outputs: one wavefront per pixel
             op->fast = OpImpl::CONV1X1_ROW, op->fast_name = "conv1x1_rowwave";
         if (getenv("MF_VERBOSE"))
@@ -697,6 +726,10 @@ void op_run(OpImpl *op, const int8_t *d_in, size_t batch, int8_t *d_out, void *s
             break;
         case OpImpl::PW_MFMA:
             done = k::launch_pw(sp.C, sp.N, d_in, d_out, op->pw, (long long)batch * sp.H * sp.W, s);
+            break;
+        case OpImpl::CONV_MM:
+            k::launch_conv_mm(d_in, d_out, op->cmm, op->rt_wz, (int)batch, s);
+            done = true;
             break;
         case OpImpl::CONV_ROWS:
             k::launch_conv_rows(d_in, d_out, op->crows, op->rt_wz, (int)batch, s);

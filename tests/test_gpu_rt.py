@@ -193,3 +193,48 @@ def test_conv_rows_vs_oracle(mf, O, case, u8, monkeypatch):
     assert np.array_equal(got, want), (op.kernel, np.argwhere(got != want)[:5])
     op.set_generic(True)
     assert np.array_equal(op(x), want)
+
+
+CONV_MM = [
+    # H, W, C, N, KH, KW, sh, sw, pad, filter zero points, batch
+    (16, 16, 16, 16, 3, 3, 1, 1, 0, False, 5),       # ResNet-8-like blocks
+    (16, 16, 16, 32, 3, 3, 2, 2, 0, False, 5),
+    (8, 8, 32, 64, 3, 3, 2, 2, 0, False, 9),
+    (8, 8, 64, 64, 3, 3, 1, 1, 0, False, 9),         # K = 576: 9 k steps
+    (32, 32, 16, 16, 3, 3, 1, 1, 0, False, 3),
+    (12, 10, 16, 24, 5, 5, 1, 1, 0, False, 4),       # 5x5, N = 24
+    (9, 7, 32, 20, 3, 5, 2, 1, 1, False, 4),         # rectangular filter, VALID, N = 20
+    (10, 10, 48, 40, 3, 3, 1, 1, 0, False, 4),       # C = 48: taps straddle the 64-deep k steps
+    (64, 64, 16, 16, 3, 3, 1, 1, 0, False, 2),       # row bands
+    (6, 6, 128, 32, 3, 3, 1, 1, 0, False, 6),        # K = 1152: 18 k steps
+    (16, 16, 16, 16, 3, 3, 1, 1, 0, True, 5),        # filter zero points
+    (8, 8, 32, 72, 3, 3, 2, 2, 0, True, 6),          # ... and 5 tiles = two blocks
+    (7, 7, 16, 128, 2, 2, 1, 1, 1, False, 5),        # even filter, VALID, N = 128 (two blocks)
+]
+
+
+@pytest.mark.parametrize("case", CONV_MM, ids=lambda c: "x".join(map(str, c)))
+@pytest.mark.parametrize("u8", [False, True], ids=["i8", "u8"])
+def test_conv_mm_vs_oracle(mf, O, case, u8):
+    H, W, C, N, KH, KW, sh, sw, pad, wz, batch = case
+    rng = np.random.default_rng(hash(case) % (2 ** 32) + int(u8))
+    dt = np.uint8 if u8 else np.int8
+    lo, hi = (0, 256) if u8 else (-128, 128)
+    if pad == 0:
+        OH, OW = -(-H // sh), -(-W // sw)
+    else:
+        OH, OW = (H - KH) // sh + 1, (W - KW) // sw + 1
+    x = rng.integers(lo, hi, (batch, H, W, C)).astype(dt)
+    x[0] = hi - 1
+    f = rng.integers(lo, hi, (N, KH, KW, C)).astype(dt)
+    zp = (rng.integers(-25, 25, N) + (128 if u8 else 0)).astype(dt) if wz else np.full(N, 128 if u8 else 0, dt)
+    izp, oscale, ozp, act = int(rng.integers(lo, hi)), 0.0235294122, int(rng.integers(lo, lo + 100)), int(rng.choice([0, 1, 3]))
+    c0, c1 = _consts(rng, N, KH * KW * C)
+    opts = mf.ops.Conv2DOptions(mf.FusedActivation(act), mf.TensorViewPadding(pad), (sh, sw))
+    op = mf.ops.prepare_conv_2d((H, W, C), f, zp, izp, oscale, ozp, opts, (c0, c1), (OH, OW))
+    assert op.kernel == "conv_mm_rt" + ("<wzp>" if wz else ""), op.kernel
+    want = np.stack([O.conv_2d(x[i], f, zp, izp, oscale, ozp, act, pad, (sh, sw), (OH, OW), c0, c1) for i in range(batch)])
+    got = op(x)
+    assert np.array_equal(got, want), (op.kernel, np.argwhere(got != want)[:5])
+    op.set_generic(True)
+    assert np.array_equal(op(x), want)
