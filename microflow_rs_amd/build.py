@@ -48,7 +48,7 @@ def build_ubench(force=False):
     if (not force and os.path.exists(UBENCH_LIB)
             and os.path.getmtime(UBENCH_LIB) >= max(os.path.getmtime(d) for d in deps)):
         return UBENCH_LIB
-    subprocess.check_call([hipcc()] + [f for f in FLAGS if f != "-Wall"] + ["-Wno-unused-value", "-DMF_UBENCH_LIB", "-DITERS=256", "-shared", "-x", "hip",
+    subprocess.check_call([hipcc()] + [f for f in FLAGS if f != "-Wall"] + ["-Wno-unused-value", "-DMF_UBENCH_LIB", "-DITERS=1024", "-shared", "-x", "hip",
                                                     UBENCH_SRC, "-o", UBENCH_LIB])
     return UBENCH_LIB
 

@@ -38,10 +38,12 @@ except Exception as e:
     print("bench parse failed", e)
 PY
 fi
+# (--no-extra: the timed workload, its layer-wise table and the parity legs only -- the other sub-records of the default
+# line launch their own kernels hundreds of times and would top the stats)
 if [[ $STEPS == all || $STEPS == *prof* ]]; then
   rm -rf $OUT/prof
   (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/$OUT/prof" -- \
-      python "$OLDPWD/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-host-fed > "$OLDPWD/$OUT/prof_bench.json" 2> "$OLDPWD/$OUT/prof.err")
+      python "$OLDPWD/bench.py" --steps 20 --warmup 3 --no-cpu-baseline --no-host-fed --no-extra > "$OLDPWD/$OUT/prof_bench.json" 2> "$OLDPWD/$OUT/prof.err")
   echo "rocprof exit $?"
   find $OUT/prof -name "*kernel_stats*" | head
   f=$(find $OUT/prof -name "*kernel_stats.csv" | head -1)

@@ -12,7 +12,7 @@
 #include "../../microflow_rs_amd/csrc/k_common.hpp"
 
 #ifndef ITERS
-#define ITERS 4096 // (the library build uses 256: the whole measurement then costs bench.py ~15 ms of GPU time)
+#define ITERS 4096 // (the library build uses 1024: a variant costs bench.py ~17 ms of GPU time)
 #endif
 #define NG 8 // independent dword groups per iteration
 
