@@ -1,0 +1,336 @@
+// k_quad.hip -- TWO consecutive DepthwiseConv2D 3x3 + Conv2D 1x1 pairs in one launch ("quad"): person_detect ops 1..4
+// (48x48x8 stride 1 -> 16, then 48x48x16 stride 2 -> 24x24x32) and ops 5..8 (24x24x32 stride 1 -> 32, then stride 2 ->
+// 12x12x64).  (src/ops/depthwise_conv_2d.rs:28-105, src/ops/conv_2d.rs:28-108; four reference operators per launch, each
+// with the reference's own requantisation -- the three intermediate int8 tensors just never leave the CU.)
+//
+// Why.  The pair kernels alternate between two regimes: a stride-1 pair requantises as many bytes as it moves and is bounded
+// by the VALU (valu_frac 0.77-0.81, HBM at 0.6), the stride-2 pair that follows moves twice what it requantises and is
+// bounded by HBM (0.65-0.71 of peak, VALU at 0.45) -- and between the two the largest tensors of the network (36 864 and
+// 18 432 bytes per image) are written to HBM and read back.  Fused, the second pair's input never crosses HBM: ops 1..4
+// move 36 864 B per image instead of 110 592, ops 5..8 27 648 instead of 64 512, and the HBM-bound half disappears under
+// the VALU-bound one.
+//
+// How.  Both pairs are dwpw_rr pairs (k_fused_mm.hip: depthwise taps on the matrix pipe, the depthwise result requantised
+// in registers straight into the pointwise MFMA's B operand).  A step is one image:
+//     phase A : staged input tile -> pair A -> its 4..16 output bytes per lane are written into tile B, the halo'd,
+//               swizzled LDS tile pair B's tap loads expect (instead of to HBM)
+//     barrier ; the next image's DMA into tile A is issued here and lands during phase B (one staging buffer suffices)
+//     phase B : tile B -> pair B -> HBM
+//     barrier (top of the next step: the DMA has landed, everyone is done with tile B)
+// Column grids, row pads and swizzles are the table rows of the single pairs (kernels.hpp MF_DWRR_SHAPES); the workgroup
+// size is the one both unit grids divide over.  The dynamic step queue of k_common.hpp deals the images.
+#include "k_common.hpp"
+
+#include <algorithm>
+#include <type_traits>
+
+namespace mf {
+namespace k {
+
+template <int H_, int W_, int C_, int S_, int N_, int CG_, int CY_, int ORD_, int ROWPAD_, int TS_>
+struct RrGeom {
+    static constexpr int H = H_, W = W_, C = C_, S = S_, N = N_, CG = CG_, CY = CY_, ORD = ORD_, ROWPAD = ROWPAD_, TS = TS_;
+    static constexpr bool PAIR = C == 8;
+    static constexpr int OH = (H + S - 1) / S, OW = (W + S - 1) / S, OWC = PAIR ? OW / 2 : OW;
+    static constexpr int NQ = PAIR ? 1 : C / 16, CX = 16 / (CG * CY);
+    static constexpr int LP = C < 16 ? 16 : C;
+    static constexpr int ROWB = W * C, ROW = LP + ROWB + LP + ROWPAD, TILE = (H + 2) * ROW;
+    static constexpr int IMG = H * ROWB, ROWCH = ROWB / 16, OPIX = OH * OW;
+    static constexpr int NT = (PAIR ? 2 * N : N) / 16, LB = 4 * NT;
+    static_assert(C == 8 || C == 16 || C == 32, "register-resident pairs: C <= 32");
+    static_assert(CG * CY * CX == 16 && OH % CY == 0 && OWC % CX == 0, "column grid");
+    static_assert(ROWB % 16 == 0 && ROWCH <= 64 && ROW % 16 == 0, "staging geometry");
+    static_assert(!PAIR || (S == 1 && OW % 2 == 0), "pair columns");
+    static_assert(LB == 8 || LB == 16, "one 8- or 16-byte store per lane");
+};
+
+// geometry of the tile a pair writes into (void = HBM: never looked at)
+template <typename T> struct DstTile {
+    static constexpr int TILE = T::TILE, ROW = T::ROW, C = T::C;
+};
+template <> struct DstTile<void> {
+    static constexpr int TILE = 0, ROW = 0, C = 0;
+};
+
+// one pair of a quad: the per-lane constants (init) and the unit loop (run)
+template <typename Ge, int G, int NTHR, int MG, uint32_t XR4>
+struct RrPhase {
+    static constexpr int NWAVE = NTHR / 64;
+    static constexpr int UG = G / Ge::CG, UY = Ge::OH / Ge::CY, UX = Ge::OWC / Ge::CX;
+    static constexpr int PSY = cgcd(UY, NWAVE), PSX = cgcd(UX, NWAVE / PSY), PSG = cgcd(UG, NWAVE / PSY / PSX);
+    static_assert(G % Ge::CG == 0 && PSY * PSX * PSG == NWAVE, "the unit grid does not divide over the waves");
+    static constexpr int NUG = UG / PSG, NUY = UY / PSY, NUX = UX / PSX, NU = NUG * NUY * NUX;
+    static constexpr int T_UG = Ge::CG * Ge::TILE, T_UY = Ge::CY * Ge::S * Ge::ROW, T_UX = Ge::PAIR ? Ge::CX * 16 : Ge::CX * Ge::S * Ge::C;
+    static constexpr int NQ = Ge::NQ, NT = Ge::NT;
+
+    int tbase[NQ];
+    v4i Adw[NQ][3];
+    float4 dA[NQ], dS[NQ];
+    int4 dK[NQ];
+    long Apw[NT];
+    float4 cA[NT], cS[NT];
+    int4 cK[NT];
+    int dst_lane;   // this lane's first output byte: in the output tensor of a step (HBM) or in the next pair's LDS tile
+    int cg, wug;    // image column of this lane, image offset of this wave (ragged steps)
+    float dlo, dhi, plo, phi;
+
+    // NEXT = the geometry whose input tile this pair's output is written into (void: the output goes to HBM)
+    template <typename NEXT>
+    __device__ __forceinline__ void init(const DwPwArgs &p, int lane, int wave) {
+        const int col = lane & 15, g = lane >> 4;
+        int cy, cx;
+        {
+            constexpr int ORD = Ge::ORD, CGc = Ge::CG, CYc = Ge::CY, CXc = Ge::CX;
+            constexpr int D0 = (ORD == 0 || ORD == 1) ? CGc : (ORD == 2 || ORD == 3) ? CYc : CXc;
+            constexpr int D1 = (ORD == 2 || ORD == 4) ? CGc : (ORD == 0 || ORD == 5) ? CYc : CXc;
+            const int i0 = col % D0, i1 = (col / D0) % D1, i2 = col / (D0 * D1);
+            cg = (ORD == 0 || ORD == 1) ? i0 : (ORD == 2 || ORD == 4) ? i1 : i2;
+            cy = (ORD == 2 || ORD == 3) ? i0 : (ORD == 0 || ORD == 5) ? i1 : i2;
+            cx = (ORD == 4 || ORD == 5) ? i0 : (ORD == 1 || ORD == 3) ? i1 : i2;
+        }
+        const int wpy = wave % PSY, wpx = (wave / PSY) % PSX, wpg = wave / (PSY * PSX);
+        wug = wpg * Ge::CG;
+        const int wave_t = wpg * T_UG + wpy * T_UY + wpx * T_UX;
+        if constexpr (Ge::PAIR) {
+            tbase[0] = cg * Ge::TILE + cy * Ge::ROW + Ge::LP + (2 * cx - 2) * 8 + g * 16 + wave_t;
+        } else {
+            const int xl = cx * Ge::S + g - 1;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+                tbase[q] = cg * Ge::TILE + cy * Ge::S * Ge::ROW + Ge::LP + xl * Ge::C + 16 * (q ^ tile_swz<Ge::TS>(xl)) + wave_t;
+        }
+        const int opar = Ge::PAIR ? (g >> 1) : 0;
+        const int n0 = Ge::PAIR ? 8 * (g & 1) : (Ge::N / 4) * g;
+        const int ox = (Ge::PAIR ? 2 * cx + opar : cx) + wpx * (Ge::PAIR ? 2 : 1) * Ge::CX; // output pixel of unit (0, 0, 0)
+        const int oy = cy + wpy * Ge::CY;
+        if constexpr (std::is_void<NEXT>::value) {
+            dst_lane = ((cg + wug) * Ge::OPIX + oy * Ge::OW + ox) * Ge::N + n0;
+        } else {
+            static_assert(NEXT::H == Ge::OH && NEXT::W == Ge::OW && NEXT::C == Ge::N, "the next pair consumes this pair's output");
+            // the unit steps must not touch the x bits the next tile's swizzle looks at
+            static_assert(tile_swz<NEXT::TS>(((Ge::PAIR ? 2 : 1) * Ge::CX) * 255) == 0 || NEXT::TS == 0, "x step vs swizzle");
+            const int chunk = n0 >> 4, within = n0 & 15;
+            dst_lane = (cg + wug) * NEXT::TILE + (oy + 1) * NEXT::ROW + NEXT::LP + ox * NEXT::C +
+                       16 * (NEXT::NQ > 1 ? (chunk ^ tile_swz<NEXT::TS>(ox)) : chunk) + within;
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+#pragma unroll
+            for (int ty = 0; ty < 3; ++ty) Adw[q][ty] = ((const v4i *)p.dw.wmm)[(q * 3 + ty) * 64 + lane];
+            const int ch4 = Ge::PAIR ? (g & 1) : 4 * q + g;
+            dA[q] = ((const float4 *)p.dw.A)[ch4];
+            dS[q] = ((const float4 *)p.dw.S)[ch4];
+            dK[q] = magic4<MG>(((const int4 *)p.dw.Kc)[ch4]);
+        }
+#pragma unroll
+        for (int m = 0; m < NT; ++m) {
+            Apw[m] = ((const long *)p.pw.wrr)[m * 64 + lane];
+            cA[m] = *(const float4 *)(p.pw.A + n0 + 4 * m);
+            cS[m] = *(const float4 *)(p.pw.S + n0 + 4 * m);
+            cK[m] = magic4<MG>(*(const int4 *)(p.pw.Kc + n0 + 4 * m));
+        }
+        dlo = p.dw.lo_f, dhi = p.dw.hi_f, plo = p.pw.lo_f, phi = p.pw.hi_f;
+    }
+
+    // tb: this pair's staged input tile(s); dst: the step's output tensor in HBM, or the next pair's LDS tile
+    template <typename NEXT>
+    __device__ __forceinline__ void run(const uint8_t *tb, uint8_t *dst, int gvalid) const {
+        constexpr bool TO_LDS = !std::is_void<NEXT>::value;
+        // strides of one unit step at the destination
+        constexpr int XF = Ge::PAIR ? 2 : 1;
+        constexpr int D_UG = TO_LDS ? Ge::CG * DstTile<NEXT>::TILE : Ge::CG * Ge::OPIX * Ge::N;
+        constexpr int D_UY = TO_LDS ? Ge::CY * DstTile<NEXT>::ROW : Ge::CY * Ge::OW * Ge::N;
+        constexpr int D_UX = TO_LDS ? XF * Ge::CX * DstTile<NEXT>::C : XF * Ge::CX * Ge::N;
+        // units in flight: both pairs' operands are resident, so the two-channel-group pairs (C = 32) keep one
+        constexpr int UB = NQ > 1 ? 1 : (NU % 2 == 0 ? 2 : (NU % 3 == 0 ? 3 : 1));
+        auto coords = [](int iu, int &ug, int &uy, int &ux) constexpr {
+            ug = (iu / (NUY * NUX)) * PSG, uy = ((iu / NUX) % NUY) * PSY, ux = (iu % NUX) * PSX;
+        };
+        auto toff_of = [&](int iu) constexpr {
+            int ug = 0, uy = 0, ux = 0;
+            coords(iu, ug, uy, ux);
+            return ug * T_UG + uy * T_UY + ux * T_UX;
+        };
+        v4i bq[UB][NQ][3], bn[UB][NQ][3];
+#pragma unroll
+        for (int u = 0; u < UB; ++u)
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                for (int ty = 0; ty < 3; ++ty) bq[u][q][ty] = *(const v4i *)(tb + tbase[q] + toff_of(u) + ty * Ge::ROW);
+#pragma unroll
+        for (int t0 = 0; t0 < NU; t0 += UB) {
+            v4i acc[UB][NQ];
+#pragma unroll
+            for (int u = 0; u < UB; ++u)
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) acc[u][q] = v4i{dK[q].x, dK[q].y, dK[q].z, dK[q].w};
+#pragma unroll
+            for (int ty = 0; ty < 3; ++ty)
+#pragma unroll
+                for (int u = 0; u < UB; ++u)
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q)
+                        acc[u][q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Adw[q][ty], bq[u][q][ty], acc[u][q], 0, 0, 0);
+            if (t0 + UB < NU) {
+#pragma unroll
+                for (int u = 0; u < UB; ++u)
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                        for (int ty = 0; ty < 3; ++ty)
+                            bn[u][q][ty] = *(const v4i *)(tb + tbase[q] + toff_of(t0 + UB + u) + ty * Ge::ROW);
+            }
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                uint32_t d[2] = {0u, 0u};
+#pragma unroll
+                for (int q = 0; q < NQ; ++q)
+                    d[q] = requant_pack4<MG, XR4>(acc[u][q][0], acc[u][q][1], acc[u][q][2], acc[u][q][3], dA[q], dS[q], dlo, dhi);
+                const long bop = (long)(((unsigned long)d[1] << 32) | (unsigned long)d[0]);
+                uint32_t packed[NT];
+#pragma unroll
+                for (int m = 0; m < NT; ++m) {
+                    v4i pa = {cK[m].x, cK[m].y, cK[m].z, cK[m].w};
+                    pa = __builtin_amdgcn_mfma_i32_16x16x32_i8(Apw[m], bop, pa, 0, 0, 0);
+                    packed[m] = requant_pack4<MG, XR4>(pa[0], pa[1], pa[2], pa[3], cA[m], cS[m], plo, phi);
+                }
+                int ug = 0, uy = 0, ux = 0;
+                coords(t0 + u, ug, uy, ux);
+                const int doff = ug * D_UG + uy * D_UY + ux * D_UX;
+                if (cg + wug + ug * Ge::CG < gvalid) { // a ragged last step stages fewer than G images
+                    if constexpr (Ge::LB == 8) *(uint2 *)(dst + dst_lane + doff) = make_uint2(packed[0], packed[1]);
+                    else *(uint4 *)(dst + dst_lane + doff) = make_uint4(packed[0], packed[1], packed[2], packed[3]);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < UB; ++u)
+#pragma unroll
+                for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                    for (int ty = 0; ty < 3; ++ty) bq[u][q][ty] = bn[u][q][ty];
+        }
+    }
+};
+
+
+// the two quads of person_detect: pair geometries = the MF_DWRR_SHAPES rows of the single pairs
+struct Quad13 {
+    using A = RrGeom<48, 48, 8, 1, 16, 1, 4, 0, 32, 0x000>;
+    using B = RrGeom<48, 48, 16, 2, 32, 1, 2, 0, 32, 0x000>;
+    static constexpr int G = 1, NTHR = 768, WPE = 3;
+    static constexpr const char *name = "quad_rr<48,48,8,1,16|48,48,16,2,32>";
+};
+struct Quad57 {
+    using A = RrGeom<24, 24, 32, 1, 32, 1, 2, 0, 0, 0x002>;
+    using B = RrGeom<24, 24, 32, 2, 64, 1, 4, 0, 32, 0x002>;
+    static constexpr int G = 1, NTHR = 192, WPE = 2;
+    static constexpr const char *name = "quad_rr<24,24,32,1,32|24,24,32,2,64>";
+};
+
+template <typename Q> constexpr int quad_lds_bytes() {
+    return Q::G * Q::A::TILE + 512 + Q::G * Q::B::TILE + 512 + 16;
+}
+
+template <typename Q, int MG, uint32_t XR4>
+__global__ __launch_bounds__(Q::NTHR, Q::WPE) void quad_rr(const int8_t *__restrict__ in, int8_t *__restrict__ out, QuadArgs p, int batch) {
+    using GA = typename Q::A;
+    using GB = typename Q::B;
+    constexpr int G = Q::G, NTHR = Q::NTHR, NWAVE = NTHR / 64;
+    constexpr int BUF_A = G * GA::TILE, OFF_B = BUF_A + 512, BUF_B = G * GB::TILE, OFF_Q = OFF_B + BUF_B + 512;
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    DynSteps dq;
+    dq.init(lds + OFF_Q, p.a.dw.queue, tid, p.a.dw.qcfg);
+    // tile A's halo holds pair A's input zero point, tile B's pair B's (= the zero point of pair A's output tensor)
+    for (int i = tid; i < OFF_B / 16; i += NTHR) ((uint4 *)lds)[i] = make_uint4(p.a.dw.izp4, p.a.dw.izp4, p.a.dw.izp4, p.a.dw.izp4);
+    for (int i = tid; i < (BUF_B + 512) / 16; i += NTHR) ((uint4 *)(lds + OFF_B))[i] = make_uint4(p.b.dw.izp4, p.b.dw.izp4, p.b.dw.izp4, p.b.dw.izp4);
+    RrPhase<GA, G, NTHR, MG, XR4> pa;
+    RrPhase<GB, G, NTHR, MG, XR4> pb;
+    pa.template init<GB>(p.a, lane, wave);
+    pb.template init<void>(p.b, lane, wave);
+    __syncthreads(); // halo fills complete before any DMA lands
+
+    auto stage = [&](int st) {
+        constexpr int NROWS = G * GA::H;
+        const int src_lane = GA::NQ > 1 ? (lane ^ tile_swz<GA::TS>(lane / (GA::NQ > 1 ? GA::NQ : 1))) : lane;
+#pragma unroll
+        for (int k = 0; k < (NROWS + NWAVE - 1) / NWAVE; ++k) {
+            const int r = k * NWAVE + wave;
+            const int gi = r / GA::H, y = r % GA::H;
+            if (r < NROWS && st * G + gi < batch && lane < GA::ROWCH)
+                dma16(in + ((size_t)(st * G + gi) * GA::IMG + y * GA::ROWB + src_lane * 16), lds + gi * GA::TILE + (y + 1) * GA::ROW + GA::LP);
+        }
+    };
+    const int nsteps = (batch + G - 1) / G;
+    if (dq.step < nsteps) stage(dq.step);
+    for (; dq.step < nsteps; dq.advance(tid)) {
+        const int step = dq.step;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads(); // this step's image is in tile A; every wave is done reading tile B (the previous step's phase B)
+        dq.top(tid);
+        const int gvalid = min(G, batch - step * G);
+        pa.template run<GB>(lds, lds + OFF_B, gvalid);                    // pair A: tile A -> tile B
+        __syncthreads(); // tile B is complete; tile A is free
+        if (dq.nxt < nsteps) stage(dq.nxt);                               // lands during phase B
+        pb.template run<void>(lds + OFF_B, (uint8_t *)out + (size_t)step * G * GB::OPIX * GB::N, gvalid); // pair B: tile B -> HBM
+    }
+    dq.finish(tid);
+}
+
+template <typename Q, int MG, uint32_t XR4>
+static void launch_quad_t(const int8_t *in, int8_t *out, const QuadArgs &a, int batch, hipStream_t s) {
+    constexpr int lds = quad_lds_bytes<Q>();
+    static_assert(lds <= 163840, "quad tiles do not fit the LDS");
+    static LaunchState st;
+    const int per_cu = prepared(st, quad_rr<Q, MG, XR4>, Q::NTHR, lds);
+    const int nsteps = (batch + Q::G - 1) / Q::G;
+    const int grid = nsteps < 256 * per_cu ? nsteps : 256 * per_cu;
+    QuadArgs b = a;
+    using GA = typename Q::A;
+    using GB = typename Q::B;
+    const double hbm = (double)batch * (GA::H * GA::W * GA::C + GB::OPIX * GB::N);
+    const double rq = (double)batch * (GA::OPIX * (GA::C + GA::N) + GB::OPIX * (GB::C + GB::N));
+    b.a.dw.qcfg = dq_config(nsteps, grid, dq_est_us(hbm, rq));
+    hipLaunchKernelGGL((quad_rr<Q, MG, XR4>), dim3(grid), dim3(Q::NTHR), lds, s, in, out, b, batch);
+}
+template <typename Q> static bool quad_matches(int H, int W, int C, int S, int N, int H2, int W2, int C2, int S2, int N2) {
+    using GA = typename Q::A;
+    using GB = typename Q::B;
+    return H == GA::H && W == GA::W && C == GA::C && S == GA::S && N == GA::N && H2 == GB::H && W2 == GB::W && C2 == GB::C && S2 == GB::S &&
+           N2 == GB::N;
+}
+static int quad_mask() { // MF_QUADS: bit 0 = ops 1..4, bit 1 = ops 5..8 (tuning)
+    static const int m = [] { const char *e = getenv("MF_QUADS"); return e ? atoi(e) : 3; }();
+    return m;
+}
+const char *quad_name(int H, int W, int C, int S, int N, int H2, int W2, int C2, int S2, int N2) {
+    if ((quad_mask() & 1) && quad_matches<Quad13>(H, W, C, S, N, H2, W2, C2, S2, N2)) return Quad13::name;
+    if ((quad_mask() & 2) && quad_matches<Quad57>(H, W, C, S, N, H2, W2, C2, S2, N2)) return Quad57::name;
+    return nullptr;
+}
+bool launch_quad(int H, int W, int C, int S, int N, int H2, int W2, int C2, int S2, int N2, const int8_t *in, int8_t *out, const QuadArgs &a,
+                 int batch, hipStream_t s) {
+    if (!a.a.dw.wmm || !a.a.pw.wrr || !a.b.dw.wmm || !a.b.pw.wrr) return false;
+    const int mg = std::min(std::min(a.a.dw.magic, a.a.pw.magic), std::min(a.b.dw.magic, a.b.pw.magic));
+    if (mg == 0) return false; // (the quads exist for the bit-pattern epilogues only)
+#define MF_QUAD_GO(Q)                                                                              \
+    do {                                                                                           \
+        if (a.b.pw.xr) {                                                                           \
+            if (mg == 2) launch_quad_t<Q, 2, 0x80808080u>(in, out, a, batch, s);                   \
+            else launch_quad_t<Q, 1, 0x80808080u>(in, out, a, batch, s);                           \
+        } else {                                                                                   \
+            if (mg == 2) launch_quad_t<Q, 2, 0u>(in, out, a, batch, s);                            \
+            else launch_quad_t<Q, 1, 0u>(in, out, a, batch, s);                                    \
+        }                                                                                          \
+        return true;                                                                               \
+    } while (0)
+    if (quad_matches<Quad13>(H, W, C, S, N, H2, W2, C2, S2, N2)) MF_QUAD_GO(Quad13);
+    if (quad_matches<Quad57>(H, W, C, S, N, H2, W2, C2, S2, N2)) MF_QUAD_GO(Quad57);
+#undef MF_QUAD_GO
+    return false;
+}
+
+} // namespace k
+} // namespace mf

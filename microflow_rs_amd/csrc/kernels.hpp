@@ -196,6 +196,14 @@ struct DwPwArgs {
     PwArgs pw;
 };
 
+// two consecutive pairs in one launch (k_quad.hip)
+struct QuadArgs {
+    DwPwArgs a, b;
+};
+const char *quad_name(int H, int W, int C, int S, int N, int H2, int W2, int C2, int S2, int N2);
+bool launch_quad(int H, int W, int C, int S, int N, int H2, int W2, int C2, int S2, int N2, const int8_t *in, int8_t *out, const QuadArgs &a,
+                 int batch, hipStream_t s);
+
 // fused network tail: AveragePool2D (to 1x1) -> Conv2D 1x1 (N <= 8) -> [Reshape] -> Softmax
 struct TailArgs {
     int H, W, C, N;          // pool input; head outputs

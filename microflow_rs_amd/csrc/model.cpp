@@ -266,6 +266,16 @@ void model_prepare(ModelImpl *m, int device, size_t max_batch) {
             if (used) i += 2 * used - 1;             // continue with the pair after the stage
             else if (!run.empty()) i = a - 1;        // no stage for any prefix: continue after the run
         }
+        // (4b) two consecutive pair groups whose shapes have a quad kernel (k_quad.hip: a VALU-bound stride-1 pair with the
+        // HBM-bound stride-2 pair behind it; the tensor between them stays in LDS)
+        for (size_t i = 0; i + 3 < n; ++i) {
+            if (!fused[i] || fused_last[i] != (int)i + 1 || covered(i) || covered(i + 2)) continue;
+            if (!fused[i + 2] || fused_last[i + 2] != (int)i + 3) continue;
+            if (FusedImpl *f = fused_quad_create(fused[i], fused[i + 2])) {
+                sg.v.push_back({f, (int)i, (int)i + 3});
+                i += 3;
+            }
+        }
         // (5) DepthwiseConv2D with one input channel -> [Reshape] -> the FullyConnected + Softmax group -> one kernel
         for (size_t i = 0; i + 1 < n; ++i) {
             if (!ops[i] || fused[i] || covered(i) || m->pm.ops[i].kind != MF_OP_DEPTHWISE_CONV_2D) continue;

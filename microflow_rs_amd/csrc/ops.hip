@@ -864,7 +864,7 @@ void op_run_f32(OpImpl *op, const float *d_in, size_t batch, int8_t *d_out, void
 }
 
 struct FusedImpl {
-    enum Kind { DWPW, TAIL, FCSM, STAGE, DWFC, PAIRTAIL } kind;
+    enum Kind { DWPW, TAIL, FCSM, STAGE, DWFC, PAIRTAIL, QUAD } kind;
     OpImpl *a, *b, *c;
     k::DwPwArgs dwpw;
     k::TailArgs tail;
@@ -877,6 +877,9 @@ struct FusedImpl {
     k::DwFcArgs dwfc{};
     // PAIRTAIL: the last pair + the tail in one kernel (operand arrays in stage_w)
     k::PairTailArgs pairtail{};
+    // QUAD: two consecutive pairs in one kernel (k_quad.hip); a = the first pair's depthwise, b = the second pair's conv
+    k::QuadArgs quad{};
+    int quad_shape[10] = {0};
 };
 
 FusedImpl *fused_create(OpImpl *dw, OpImpl *pw) {
@@ -1104,6 +1107,26 @@ FusedImpl *fused_pair_tail_create(FusedImpl *pair, FusedImpl *tail) {
     return f.release();
 }
 
+// Two consecutive DepthwiseConv2D 3x3 + Conv2D 1x1 pair groups as one kernel (k_quad.hip), when a quad kernel exists for the two
+// shapes.  Second level like the stage: the pairs inside stay available for mf_model_run_until.
+FusedImpl *fused_quad_create(FusedImpl *p1, FusedImpl *p2) {
+    static const bool off = getenv("MF_NO_QUAD") != nullptr;
+    if (off || !p1 || !p2 || p1->kind != FusedImpl::DWPW || p2->kind != FusedImpl::DWPW) return nullptr;
+    const OpSpec &d1 = p1->a->s, &q1 = p1->b->s, &d2 = p2->a->s, &q2 = p2->b->s;
+    if (p1->a->device != p2->a->device || d1.u8 != d2.u8) return nullptr;
+    if (d2.H != q1.H || d2.W != q1.W || d2.C != q1.N) return nullptr; // the second pair consumes the first pair's output
+    const char *nm = k::quad_name(d1.H, d1.W, d1.C, d1.sh, q1.N, d2.H, d2.W, d2.C, d2.sh, q2.N);
+    if (!nm) return nullptr;
+    const k::DwPwArgs &a = p1->dwpw, &b = p2->dwpw;
+    if (!a.dw.wmm || !a.pw.wrr || !b.dw.wmm || !b.pw.wrr) return nullptr;
+    if (!a.dw.magic || !a.pw.magic || !b.dw.magic || !b.pw.magic) return nullptr; // bit-pattern epilogues
+    FusedImpl *f = new FusedImpl{FusedImpl::QUAD, p1->a, p2->b, nullptr, {}, {}, nm};
+    f->quad.a = a, f->quad.b = b;
+    const int shp[10] = {d1.H, d1.W, d1.C, d1.sh, q1.N, d2.H, d2.W, d2.C, d2.sh, q2.N};
+    for (int i = 0; i < 10; ++i) f->quad_shape[i] = shp[i];
+    return f;
+}
+
 void fused_destroy(FusedImpl *f) { delete f; }
 const char *fused_kernel_name(const FusedImpl *f) { return f->name.c_str(); }
 void fused_run(FusedImpl *f, const int8_t *d_in, size_t batch, int8_t *d_out, void *stream) {
@@ -1113,6 +1136,14 @@ void fused_run(FusedImpl *f, const int8_t *d_in, size_t batch, int8_t *d_out, vo
         const OpSpec &d = f->a->s;
         if (!k::launch_stage(d.H, d.W, d.C, f->stage_pairs, d_in, d_out, f->stage, (int)batch, (hipStream_t)stream))
             fail(MF_ERR_UNSUPPORTED, "stage kernel missing");
+        MF_HIP(hipGetLastError());
+        return;
+    }
+    if (f->kind == FusedImpl::QUAD) {
+        if (batch > 0x7fffffffull / 4) fail(MF_ERR_INVALID_ARG, "batch too large for one launch");
+        const int *q = f->quad_shape;
+        if (!k::launch_quad(q[0], q[1], q[2], q[3], q[4], q[5], q[6], q[7], q[8], q[9], d_in, d_out, f->quad, (int)batch, (hipStream_t)stream))
+            fail(MF_ERR_UNSUPPORTED, "quad kernel missing");
         MF_HIP(hipGetLastError());
         return;
     }

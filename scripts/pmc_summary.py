@@ -27,7 +27,7 @@ def load(d, counter):
 
 
 def short(name):
-    m = re.search(r"mf::k::([A-Za-z0-9_]+)(<[^>]*>)?", name)
+    m = re.search(r"mf::k::([A-Za-z0-9_]+)(<[^>]*>)?", name.replace("mf::k::Quad", "Quad"))
     if not m:
         return name[:40]
     # rocprofv3 prints bool template arguments as true/false, the library's names use 1/0; the
@@ -43,6 +43,9 @@ def short(name):
         args = "<" + ",".join(args.strip("<>").split(",")[: keep[base]]) + ">"
     if base == "dw_c1_lds":
         args = ""
+    if base == "quad_rr":  # quad_rr<mf::k::Quad13, MG, XR4>: the library's name carries the two pair shapes
+        which = "Quad13" if "Quad13" in name else "Quad57"
+        return {"Quad13": "quad_rr<48,48,8,1,16|48,48,16,2,32>", "Quad57": "quad_rr<24,24,32,1,32|24,24,32,2,64>"}[which]
     if base == "pair3_tail":
         args = "<3,3,256,2>"
     if base == "dwc1_fc_softmax":

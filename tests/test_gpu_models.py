@@ -200,8 +200,13 @@ def test_kernel_routing(models):
     # fused depthwise + 1x1 conv pairs: dwpw_rr / dwpw_mm (taps on the matrix pipe) or, with
     # MF_DWPW_IMPL=valu, r01's dwpw3x3; the five 6x6x128 pairs (ops 13..22) are ONE persistent kernel
     # (MF_NO_STAGE=1: not)
-    npairs = sum(n.startswith(("dwpw_rr", "dwpw_mm", "dwpw3x3")) for n in names)
+    # ops 1..4 and 5..8 are two "quads" (two pairs per launch, k_quad.hip; MF_NO_QUAD=1: four pair launches)
+    quads = sum(n.startswith("quad_rr") for n in names)
+    npairs = sum(n.startswith(("dwpw_rr", "dwpw_mm", "dwpw3x3")) for n in names) + 2 * quads
     pair_tail = not (os.environ.get("MF_NO_PAIRTAIL") or os.environ.get("MF_DWPW_IMPL") == "valu")
+    if not (os.environ.get("MF_NO_QUAD") or os.environ.get("MF_DWPW_IMPL")):
+        assert quads == 2 and names[1].startswith("quad_rr<48,48,8") and names[5].startswith("quad_rr<24,24,32"), names
+        assert all(n.startswith("(fused") for n in names[2:5] + names[6:9]), names
     if os.environ.get("MF_NO_STAGE"):
         assert npairs == (12 if pair_tail else 13), names
     else:
@@ -214,7 +219,7 @@ def test_kernel_routing(models):
         assert names[25].startswith("pair3_tail") and all(n.startswith("(fused") or n == "" for n in names[26:]), names
     assert names[28].startswith("(fused") and names[29] == "" and names[30].startswith("(fused")
     if not os.environ.get("MF_DWPW_IMPL"):
-        assert sum(n.startswith("dwpw_rr") for n in names) == 4
+        assert sum(n.startswith("dwpw_rr") for n in names) + 2 * quads == 4
     m.set_fusion(False)
     names = [m.op(i)["kernel"] for i in range(m.num_ops)]
     m.set_fusion(True)

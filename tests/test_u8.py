@@ -319,6 +319,7 @@ def test_u8_person_detect_uses_the_fast_kernels(mf, O):
     assert names[0].startswith("dw3x3_stem8"), names
     npairs = sum(k.startswith(("dwpw_rr", "dwpw_mm", "dwpw3x3")) for k in names)
     npairs += 5 * sum(k.startswith("stage_6x6x128") for k in names) + sum(k.startswith("pair3_tail") for k in names)
+    npairs += 2 * sum(k.startswith("quad_rr") for k in names)   # two pairs per quad launch (k_quad.hip)
     assert npairs == 13, names
     if not os.environ.get("MF_NO_PAIRTAIL") and os.environ.get("MF_DWPW_IMPL") != "valu":
         assert names[25].startswith("pair3_tail"), names
