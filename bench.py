@@ -285,7 +285,11 @@ def main():
                 # the binding roof is the one that gives the longer time floor: HBM for the algorithmic bytes, or the
                 # VALU for the bytes that go through the reference's f32 requantisation
                 bound = "valu" if rq / REQUANT_PEAK_GBS > nbytes / HBM_PEAK_GBS else "hbm"
-                rows.append({"op": i, "kind": kind if nops_in_group <= 3 else "stage(%d ops)" % nops_in_group,
+                if d["kernel"].startswith("quad_rr"):
+                    kind = "quad(2 pairs)"   # two depthwise+pointwise pairs in one launch (k_quad.hip)
+                elif nops_in_group > 3:
+                    kind = "stage(%d ops)" % nops_in_group
+                rows.append({"op": i, "kind": kind,
                              "kernel": d["kernel"], "ms": round(per_op[i], 4), "bound": bound,
                              "bytes": nbytes, "GBps": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4),
                              "hbm_frac": round(gbs / HBM_PEAK_GBS, 4),
@@ -434,6 +438,7 @@ def main():
                              "note": "HIP event pair per step on the launch stream, median; max over ranks"},
             "whole_step": whole_step,
             "fused_dwpw": agg(kernels, "depthwise_conv_2d+conv_2d"),
+            "fused_quad": agg(kernels, "quad(2 pairs)"),
             "depthwise": layerwise["depthwise"], "conv_2d": layerwise["conv_2d"],
             "event_ms_per_step": round(avg_ms, 4),
             "kernels": kernels,

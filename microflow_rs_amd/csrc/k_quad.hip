@@ -53,9 +53,11 @@ template <> struct DstTile<void> {
 };
 
 // one pair of a quad: the per-lane constants (init) and the unit loop (run)
-template <typename Ge, int G, int NTHR, int MG, uint32_t XR4>
+// NACT: the waves of the workgroup the unit grid is dealt over (waves >= NACT sit the phase out: a 3 x 3 unit grid does
+// not divide over 4 waves, and 4 waves per workgroup is what fills the four SIMDs evenly)
+template <typename Ge, int G, int NACT, int MG, uint32_t XR4>
 struct RrPhase {
-    static constexpr int NWAVE = NTHR / 64;
+    static constexpr int NWAVE = NACT;
     static constexpr int UG = G / Ge::CG, UY = Ge::OH / Ge::CY, UX = Ge::OWC / Ge::CX;
     static constexpr int PSY = cgcd(UY, NWAVE), PSX = cgcd(UX, NWAVE / PSY), PSG = cgcd(UG, NWAVE / PSY / PSX);
     static_assert(G % Ge::CG == 0 && PSY * PSX * PSG == NWAVE, "the unit grid does not divide over the waves");
@@ -218,14 +220,22 @@ struct RrPhase {
 struct Quad13 {
     using A = RrGeom<48, 48, 8, 1, 16, 1, 4, 0, 32, 0x000>;
     using B = RrGeom<48, 48, 16, 2, 32, 1, 2, 0, 32, 0x000>;
-    static constexpr int G = 1, NTHR = 768, WPE = 3;
+    static constexpr int G = 1, NTHR = 768, WPE = 3, ACT_A = 12, ACT_B = 12;
     static constexpr const char *name = "quad_rr<48,48,8,1,16|48,48,16,2,32>";
+};
+struct Quad13x : Quad13 { // (tuning alternative: two 6-wave workgroups per CU)
+    static constexpr int NTHR = 384, ACT_A = 6, ACT_B = 6;
 };
 struct Quad57 {
     using A = RrGeom<24, 24, 32, 1, 32, 1, 2, 0, 0, 0x002>;
     using B = RrGeom<24, 24, 32, 2, 64, 1, 4, 0, 32, 0x002>;
-    static constexpr int G = 1, NTHR = 192, WPE = 2;
+    // 4 waves = one per SIMD, two workgroups per CU (248 VGPRs); pair B's 3 x 3 unit grid runs on three of them.
+    // (3-wave workgroups load the SIMDs 2/2/1/1 and every barrier waits for the doubled-up ones: 0.85 ms vs 0.71)
+    static constexpr int G = 1, NTHR = 256, WPE = 2, ACT_A = 4, ACT_B = 3;
     static constexpr const char *name = "quad_rr<24,24,32,1,32|24,24,32,2,64>";
+};
+struct Quad57x : Quad57 { // (tuning alternative: the 3-wave workgroup)
+    static constexpr int NTHR = 192, ACT_A = 3, ACT_B = 3;
 };
 
 template <typename Q> constexpr int quad_lds_bytes() {
@@ -246,8 +256,8 @@ __global__ __launch_bounds__(Q::NTHR, Q::WPE) void quad_rr(const int8_t *__restr
     // tile A's halo holds pair A's input zero point, tile B's pair B's (= the zero point of pair A's output tensor)
     for (int i = tid; i < OFF_B / 16; i += NTHR) ((uint4 *)lds)[i] = make_uint4(p.a.dw.izp4, p.a.dw.izp4, p.a.dw.izp4, p.a.dw.izp4);
     for (int i = tid; i < (BUF_B + 512) / 16; i += NTHR) ((uint4 *)(lds + OFF_B))[i] = make_uint4(p.b.dw.izp4, p.b.dw.izp4, p.b.dw.izp4, p.b.dw.izp4);
-    RrPhase<GA, G, NTHR, MG, XR4> pa;
-    RrPhase<GB, G, NTHR, MG, XR4> pb;
+    RrPhase<GA, G, Q::ACT_A, MG, XR4> pa;
+    RrPhase<GB, G, Q::ACT_B, MG, XR4> pb;
     pa.template init<GB>(p.a, lane, wave);
     pb.template init<void>(p.b, lane, wave);
     __syncthreads(); // halo fills complete before any DMA lands
@@ -271,10 +281,11 @@ __global__ __launch_bounds__(Q::NTHR, Q::WPE) void quad_rr(const int8_t *__restr
         __syncthreads(); // this step's image is in tile A; every wave is done reading tile B (the previous step's phase B)
         dq.top(tid);
         const int gvalid = min(G, batch - step * G);
-        pa.template run<GB>(lds, lds + OFF_B, gvalid);                    // pair A: tile A -> tile B
+        if (Q::ACT_A == NWAVE || wave < Q::ACT_A) pa.template run<GB>(lds, lds + OFF_B, gvalid); // pair A: tile A -> tile B
         __syncthreads(); // tile B is complete; tile A is free
         if (dq.nxt < nsteps) stage(dq.nxt);                               // lands during phase B
-        pb.template run<void>(lds + OFF_B, (uint8_t *)out + (size_t)step * G * GB::OPIX * GB::N, gvalid); // pair B: tile B -> HBM
+        if (Q::ACT_B == NWAVE || wave < Q::ACT_B)
+            pb.template run<void>(lds + OFF_B, (uint8_t *)out + (size_t)step * G * GB::OPIX * GB::N, gvalid); // pair B: tile B -> HBM
     }
     dq.finish(tid);
 }
@@ -305,6 +316,10 @@ static int quad_mask() { // MF_QUADS: bit 0 = ops 1..4, bit 1 = ops 5..8 (tuning
     static const int m = [] { const char *e = getenv("MF_QUADS"); return e ? atoi(e) : 3; }();
     return m;
 }
+static int quad_alt() { // MF_QUAD_ALT: bit 0 = Quad13x, bit 1 = Quad57x (tuning)
+    static const int m = [] { const char *e = getenv("MF_QUAD_ALT"); return e ? atoi(e) : 0; }();
+    return m;
+}
 const char *quad_name(int H, int W, int C, int S, int N, int H2, int W2, int C2, int S2, int N2) {
     if ((quad_mask() & 1) && quad_matches<Quad13>(H, W, C, S, N, H2, W2, C2, S2, N2)) return Quad13::name;
     if ((quad_mask() & 2) && quad_matches<Quad57>(H, W, C, S, N, H2, W2, C2, S2, N2)) return Quad57::name;
@@ -326,8 +341,14 @@ bool launch_quad(int H, int W, int C, int S, int N, int H2, int W2, int C2, int 
         }                                                                                          \
         return true;                                                                               \
     } while (0)
-    if (quad_matches<Quad13>(H, W, C, S, N, H2, W2, C2, S2, N2)) MF_QUAD_GO(Quad13);
-    if (quad_matches<Quad57>(H, W, C, S, N, H2, W2, C2, S2, N2)) MF_QUAD_GO(Quad57);
+    if (quad_matches<Quad13>(H, W, C, S, N, H2, W2, C2, S2, N2)) {
+        if (quad_alt() & 1) MF_QUAD_GO(Quad13x);
+        MF_QUAD_GO(Quad13);
+    }
+    if (quad_matches<Quad57>(H, W, C, S, N, H2, W2, C2, S2, N2)) {
+        if (quad_alt() & 2) MF_QUAD_GO(Quad57x);
+        MF_QUAD_GO(Quad57);
+    }
 #undef MF_QUAD_GO
     return false;
 }

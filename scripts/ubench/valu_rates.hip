@@ -11,11 +11,14 @@
 
 template <int OP>
 __global__ __launch_bounds__(256) void bench(uint32_t *out, uint32_t seed) {
+    typedef float v2f __attribute__((ext_vector_type(2)));
     uint32_t a[NACC];
     float f[NACC];
+    v2f pk[NACC];
+    v2f pg = {1.0001f, 0.9999f};
     const uint32_t t = threadIdx.x + seed;
 #pragma unroll
-    for (int i = 0; i < NACC; ++i) { a[i] = t * (i + 3) + 1; f[i] = (float)(t + i) * 0.001f; }
+    for (int i = 0; i < NACC; ++i) { a[i] = t * (i + 3) + 1; f[i] = (float)(t + i) * 0.001f; pk[i] = v2f{f[i], f[i] + 1.0f}; }
     uint32_t w = t * 2654435761u | 1u;
     float g = 1.0001f, h = 0.49999997f;
     __shared__ uint32_t lds[4096];
@@ -66,13 +69,16 @@ __global__ __launch_bounds__(256) void bench(uint32_t *out, uint32_t seed) {
             if (OP == 41) asm volatile("v_min_f32 %0, %1, %2" : "=v"(f[i]) : "v"(f[i]), "v"(g));
             if (OP == 42) asm volatile("v_rndne_f32 %0, %1" : "=v"(f[i]) : "v"(f[i]));
             if (OP == 43) asm volatile("v_lshlrev_b32 %0, 3, %1" : "=v"(a[i]) : "v"(a[i]));
-            if (OP == 28) asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(*(double *)&f[i & ~1]) : "v"(*(double *)&f[i & ~1]), "v"(*(double *)&f[i & ~1]));
+            if (OP == 44) asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(pk[i]) : "v"(pk[i]), "v"(pg));
+            if (OP == 45) asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(pk[i]) : "v"(pk[i]), "v"(pg));
+            if (OP == 46) asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(pk[i]) : "v"(pk[i]), "v"(pg), "v"(pg));
+            if (OP == 47) asm volatile("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(pk[i]) : "v"(pk[i]), "v"(pg));
         }
         if (OP == 7) { h = -h; }
     }
     uint32_t r = 0;
 #pragma unroll
-    for (int i = 0; i < NACC; ++i) r ^= a[i] ^ __float_as_uint(f[i]);
+    for (int i = 0; i < NACC; ++i) r ^= a[i] ^ __float_as_uint(f[i]) ^ __float_as_uint(pk[i].x) ^ __float_as_uint(pk[i].y);
     if (r == 0x12345678u) out[0] = r;
 }
 
@@ -132,6 +138,10 @@ int main() {
     run<37>("v_add_f32_sdwa DWORD", 1, b);
     run<38>("v_mov_b32_sdwa byte insert", 1, b);
     run<39>("v_fmac_f32", 1, b);
+    run<44>("v_pk_add_f32 (2 results)", 1, b);
+    run<45>("v_pk_mul_f32 (2 results)", 1, b);
+    run<46>("v_pk_fma_f32 (2 results)", 1, b);
+    run<47>("v_pk_add_f32 op_sel_hi:[1,0]", 1, b);
     run<40>("v_cndmask_b32", 1, b);
     run<41>("v_min_f32", 1, b);
     run<42>("v_rndne_f32", 1, b);
