@@ -92,6 +92,29 @@ __device__ __forceinline__ int requant_any(int acc, float A, float S, float lo_f
     return (int)r;
 }
 
+// Output stores of the fast kernels.  NT = non-temporal: the written tensor is far larger than the L2 and is not read
+// again by this launch.  A plain copy gains 2 .. 12 % from it at these sizes (scripts/ubench/hbm_copy.hip); the layer-wise
+// kernels gain 2 .. 20 % where a wave's store instruction covers whole lines, and lose 3 .. 8 % where it does not (the
+// pointwise kernels with N = 2K, whose 128-byte lines are completed by two instructions), so each kernel picks
+// (profiles/r03/nt_store_ab.txt).  The fused kernels are bounded by the VALU and do not care: MF_NT_STORE (default 0).
+#ifndef MF_NT_STORE
+#define MF_NT_STORE 0
+#endif
+template <bool NT> __device__ __forceinline__ void st_out_t(void *p, uint4 v) {
+    if constexpr (NT) __builtin_nontemporal_store(v4i{(int)v.x, (int)v.y, (int)v.z, (int)v.w}, (v4i *)p);
+    else *(uint4 *)p = v;
+}
+template <bool NT> __device__ __forceinline__ void st_out_t(void *p, uint2 v) {
+    typedef int v2i_ __attribute__((ext_vector_type(2)));
+    if constexpr (NT) __builtin_nontemporal_store(v2i_{(int)v.x, (int)v.y}, (v2i_ *)p);
+    else *(uint2 *)p = v;
+}
+template <bool NT> __device__ __forceinline__ void st_out_t(void *p, uint32_t v) {
+    if constexpr (NT) __builtin_nontemporal_store(v, (uint32_t *)p);
+    else *(uint32_t *)p = v;
+}
+template <typename V> __device__ __forceinline__ void st_out(void *p, V v) { st_out_t<MF_NT_STORE != 0>(p, v); }
+
 // 4 ints in [-128,127] -> one dword of int8 (byte 0 = a)
 __device__ __forceinline__ uint32_t pack4(int a, int b, int c, int d) {
     const uint32_t lo = __builtin_amdgcn_perm((uint32_t)b, (uint32_t)a, 0x0c0c0400u);

@@ -124,6 +124,7 @@ __global__ __launch_bounds__(NTHR) void dw3x3_nhwc(const int8_t *__restrict__ in
                 const int g = pp / (OHR * OWP), rem = pp % (OHR * OWP);
                 const int oy0 = R * (rem / OWP), ox0 = 2 * (rem % OWP);
                 if (t < TASKS && g < gvalid) {
+                    constexpr bool NT = !(H == 12 && S == 1); // (k_common.hpp st_out_t; the 12x12x64 stride-1 layer loses 6 % with it)
                     int o0[R][4], o1[R][4];
                     const uint8_t *base = tile + g * TILE + (oy0 * S) * ROW + LP + (ox0 * S - 1) * C + cg * 4;
                     if constexpr (S == 2) dw_s2_task<R, ROW, C>(base, wA, Kc, o0, o1);
@@ -131,9 +132,9 @@ __global__ __launch_bounds__(NTHR) void dw3x3_nhwc(const int8_t *__restrict__ in
 #pragma unroll
                     for (int j = 0; j < R; ++j) {
                         uint32_t *dp = dst + ((size_t)(g * OH + oy0 + j) * OW + ox0) * C4 + cg;
-                        dp[0] = requant_pack4<MG, XR4>(o0[j][0], o0[j][1], o0[j][2], o0[j][3], A, Sc, p.lo_f, p.hi_f);
+                        st_out_t<NT>(dp, requant_pack4<MG, XR4>(o0[j][0], o0[j][1], o0[j][2], o0[j][3], A, Sc, p.lo_f, p.hi_f));
                         if (ox0 + 1 < OW)
-                            dp[C4] = requant_pack4<MG, XR4>(o1[j][0], o1[j][1], o1[j][2], o1[j][3], A, Sc, p.lo_f, p.hi_f);
+                            st_out_t<NT>(dp + C4, requant_pack4<MG, XR4>(o1[j][0], o1[j][1], o1[j][2], o1[j][3], A, Sc, p.lo_f, p.hi_f));
                     }
                 }
             }
@@ -289,7 +290,7 @@ __global__ __launch_bounds__(256) void dw3x3_stem8(const int8_t *__restrict__ in
                 v.y = pack4x<XR4>(qa[4], qa[5], qa[6], qa[7]);
                 v.z = pack4x<XR4>(qb[0], qb[1], qb[2], qb[3]);
                 v.w = pack4x<XR4>(qb[4], qb[5], qb[6], qb[7]);
-                dst[o] = v;
+                st_out(dst + o, v);
             }
         }
         if constexpr (F32IN) {
@@ -454,7 +455,7 @@ __global__ __launch_bounds__(256) void dw3x3_stem8_mm(const int8_t *__restrict__
             for (int k = 0; k < 3; ++k) {
                 uint32_t r0 = q[4 * k], r1 = q[4 * k + 1], r2 = q[4 * k + 2], r3 = q[4 * k + 3];
                 lane_group_transpose4(r0, r1, r2, r3);
-                dst[(size_t)it * 192 + (4 * k) * 16] = make_uint4(r0, r1, r2, r3); // tile 4k + g: + g * 16 is in dst
+                st_out(dst + (size_t)it * 192 + (4 * k) * 16, make_uint4(r0, r1, r2, r3)); // tile 4k + g: + g * 16 is in dst
             }
         }
         }

@@ -217,8 +217,7 @@ __global__ __launch_bounds__(NTHR) void dwpw3x3(const int8_t *__restrict__ in,
                 } else {
                     const int pix = chunk * CPIX + lpix;
                     if (pix < npix)
-                        *(uint4 *)(obase + (size_t)pix * N + blk * NB + pg * 16) =
-                            make_uint4(packed[0], packed[1], packed[2], packed[3]);
+                        st_out(obase + (size_t)pix * N + blk * NB + pg * 16, make_uint4(packed[0], packed[1], packed[2], packed[3]));
                 }
             }
             if constexpr (XPOSE) {
@@ -231,7 +230,7 @@ __global__ __launch_bounds__(NTHR) void dwpw3x3(const int8_t *__restrict__ in,
                     const int off = LO + (j * 64 + lane) * 16;
                     if (off < HI) {
                         const uint4 v = *(const uint4 *)(lds + PATCH_OFF + wave * CBYTES + off);
-                        if (cb + off < obytes) *(uint4 *)(obase + cb + off) = v;
+                        if (cb + off < obytes) st_out(obase + cb + off, v);
                     }
                 }
                 __builtin_amdgcn_wave_barrier();

@@ -285,10 +285,10 @@ __global__ __launch_bounds__(NTHR, WPE) void dwpw_mm(const int8_t *__restrict__ 
             const int npix = gvalid * OPIX;
             int8_t *ob = out + (size_t)step * G * OPIX * C;
             if constexpr (PAIR) { // MID is [pixel][8 bytes]: the output tensor itself (OPIX is even)
-                for (int i = tid; i < npix / 2; i += NTHR) *(uint4 *)(ob + i * 16) = *(const uint4 *)(mid + i * 16);
+                for (int i = tid; i < npix / 2; i += NTHR) st_out_t<true>(ob + i * 16, *(const uint4 *)(mid + i * 16));
             } else {              // planar [16-channel group][pixel][16 bytes] -> [pixel][C]
                 for (int e = tid; e < npix * NQ; e += NTHR)
-                    *(uint4 *)(ob + (size_t)e * 16) = *(const uint4 *)(mid + (e % NQ) * PLANE + (e / NQ) * 16);
+                    st_out_t<true>(ob + (size_t)e * 16, *(const uint4 *)(mid + (e % NQ) * PLANE + (e / NQ) * 16));
             }
             if constexpr (DBUF) cur ^= 1;
             continue;
@@ -340,8 +340,7 @@ __global__ __launch_bounds__(NTHR, WPE) void dwpw_mm(const int8_t *__restrict__ 
                 } else {
                     const int pix = chunk * CPIX + lpix;
                     if (pix < npix)
-                        *(uint4 *)(obase + (size_t)pix * N + blk * NB + pg * 16) =
-                            make_uint4(packed[0], packed[1], packed[2], packed[3]);
+                        st_out(obase + (size_t)pix * N + blk * NB + pg * 16, make_uint4(packed[0], packed[1], packed[2], packed[3]));
                 }
             }
             if constexpr (XPOSE) {
@@ -353,7 +352,7 @@ __global__ __launch_bounds__(NTHR, WPE) void dwpw_mm(const int8_t *__restrict__ 
                     const int off = LO + (j * 64 + lane) * 16;
                     if (off < HI) {
                         const uint4 v = *(const uint4 *)(lds + PATCH_OFF + wave * CBYTES + off);
-                        if (cb + off < obytes) *(uint4 *)(obase + cb + off) = v;
+                        if (cb + off < obytes) st_out(obase + cb + off, v);
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
@@ -585,8 +584,8 @@ __global__ __launch_bounds__(NTHR, WPE) void dwpw_rr(const int8_t *__restrict__ 
                 const int ooff = ug * O_UG + uy * O_UY + ux * O_UX;
                 if (cg + (ug + wpg) * CG < gvalid) // a ragged last step stages fewer than G images
                 {
-                    if constexpr (LB == 8) *(uint2 *)(ob + ooff) = make_uint2(packed[0], packed[1]);
-                    else *(uint4 *)(ob + ooff) = make_uint4(packed[0], packed[1], packed[2], packed[3]);
+                    if constexpr (LB == 8) st_out(ob + ooff, make_uint2(packed[0], packed[1]));
+                    else st_out(ob + ooff, make_uint4(packed[0], packed[1], packed[2], packed[3]));
                 }
             }
 #pragma unroll

@@ -28,6 +28,9 @@ namespace k {
 // N > 64 is split over the waves of the workgroup (NSPLIT = N/64), which all read the
 // same pixels (L1/L2 hits).  HBM-bound: MFMA work is ~1/8 of the memory time.
 // ------------------------------------------------------------------------
+#ifndef MF_PW_NT
+#define MF_PW_NT -1
+#endif
 #ifndef MF_PW_U_LO
 #define MF_PW_U_LO 2
 #define MF_PW_U_MID 4
@@ -52,6 +55,7 @@ __global__ __launch_bounds__(256) void pw_mfma(const int8_t *__restrict__ in,
     // narrow outputs (N < 64) go through a per-wave LDS patch so that every global store is
     // 16 bytes per lane and a wave writes whole contiguous KiB
     constexpr bool XPOSE = TB < 4;
+    constexpr bool NT = MF_PW_NT < 0 ? N <= K : MF_PW_NT != 0; // non-temporal stores (k_common.hpp st_out_t): not for N = 2K
     constexpr int CBYTES = CPIX * N;           // output bytes per chunk (XPOSE: 1 or 2 KiB)
     static_assert(N % 16 == 0 && (K == 8 || K % 16 == 0), "pw_mfma shape");
     static_assert(!XPOSE || (NSPLIT == 1 && CBYTES % 1024 == 0), "transposed store geometry");
@@ -147,8 +151,7 @@ __global__ __launch_bounds__(256) void pw_mfma(const int8_t *__restrict__ in,
                     } else {
                         const long long pix = chunk * CPIX + lpix;
                         if (pix < npix)
-                            *(uint4 *)(out + pix * N + blk * NB + g * 16) =
-                                make_uint4(packed[0], packed[1], packed[2], packed[3]);
+                            st_out_t<NT>(out + pix * N + blk * NB + g * 16, make_uint4(packed[0], packed[1], packed[2], packed[3]));
                     }
                 }
                 if constexpr (XPOSE) {
@@ -160,7 +163,7 @@ __global__ __launch_bounds__(256) void pw_mfma(const int8_t *__restrict__ in,
                     for (int j = 0; j < CBYTES / 1024; ++j) {
                         const int off = (j * 64 + lane) * 16;
                         const uint4 v = *(const uint4 *)(patch + wave * CBYTES + off);
-                        if (obase + off < obytes) *(uint4 *)(out + obase + off) = v;
+                        if (obase + off < obytes) st_out_t<NT>(out + obase + off, v);
                     }
                     __builtin_amdgcn_wave_barrier();
                 }

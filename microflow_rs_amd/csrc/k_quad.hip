@@ -201,8 +201,13 @@ struct RrPhase {
                 coords(t0 + u, ug, uy, ux);
                 const int doff = ug * D_UG + uy * D_UY + ux * D_UX;
                 if (cg + wug + ug * Ge::CG < gvalid) { // a ragged last step stages fewer than G images
-                    if constexpr (Ge::LB == 8) *(uint2 *)(dst + dst_lane + doff) = make_uint2(packed[0], packed[1]);
-                    else *(uint4 *)(dst + dst_lane + doff) = make_uint4(packed[0], packed[1], packed[2], packed[3]);
+                    if constexpr (TO_LDS) {
+                        if constexpr (Ge::LB == 8) *(uint2 *)(dst + dst_lane + doff) = make_uint2(packed[0], packed[1]);
+                        else *(uint4 *)(dst + dst_lane + doff) = make_uint4(packed[0], packed[1], packed[2], packed[3]);
+                    } else {
+                        if constexpr (Ge::LB == 8) st_out(dst + dst_lane + doff, make_uint2(packed[0], packed[1]));
+                        else st_out(dst + dst_lane + doff, make_uint4(packed[0], packed[1], packed[2], packed[3]));
+                    }
                 }
             }
 #pragma unroll

@@ -285,7 +285,7 @@ __global__ __launch_bounds__(NTHR, 4) void stage_6x6x128(const int8_t *__restric
             int8_t *dst = out + (size_t)step * G * PIX6 * 128;
             for (int i = tid * 16; i < nbytes; i += NTHR * 16) {
                 const int pix = i >> 7, slot = (i >> 4) & 7;
-                *(uint4 *)(dst + i) = *(const uint4 *)(lds + OFF_A + pix * 128 + 16 * (slot ^ (pix & 7)));
+                st_out(dst + i, *(const uint4 *)(lds + OFF_A + pix * 128 + 16 * (slot ^ (pix & 7))));
             }
         }
         MF_TR(17);
