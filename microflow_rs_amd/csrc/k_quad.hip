@@ -228,9 +228,8 @@ struct Quad13 {
     static constexpr int G = 1, NTHR = 768, WPE = 3, ACT_A = 12, ACT_B = 12;
     static constexpr const char *name = "quad_rr<48,48,8,1,16|48,48,16,2,32>";
 };
-struct Quad13x : Quad13 { // (tuning alternative: two 6-wave workgroups per CU)
-    static constexpr int NTHR = 384, ACT_A = 6, ACT_B = 6;
-};
+// (measured alternatives for ops 1..4: two 6-wave workgroups per CU -- 1.51 ms, the waves land 4/4/2/2 on the SIMDs; two
+// images per step = half the barriers per image -- 1.087 vs 1.086 ms: the barriers are not what bounds this kernel)
 struct Quad57 {
     using A = RrGeom<24, 24, 32, 1, 32, 1, 2, 0, 0, 0x002>;
     using B = RrGeom<24, 24, 32, 2, 64, 1, 4, 0, 32, 0x002>;
@@ -321,7 +320,7 @@ static int quad_mask() { // MF_QUADS: bit 0 = ops 1..4, bit 1 = ops 5..8 (tuning
     static const int m = [] { const char *e = getenv("MF_QUADS"); return e ? atoi(e) : 3; }();
     return m;
 }
-static int quad_alt() { // MF_QUAD_ALT: bit 0 = Quad13x, bit 1 = Quad57x (tuning)
+static int quad_alt() { // MF_QUAD_ALT: bit 1 = Quad57x (tuning)
     static const int m = [] { const char *e = getenv("MF_QUAD_ALT"); return e ? atoi(e) : 0; }();
     return m;
 }
@@ -347,7 +346,6 @@ bool launch_quad(int H, int W, int C, int S, int N, int H2, int W2, int C2, int 
         return true;                                                                               \
     } while (0)
     if (quad_matches<Quad13>(H, W, C, S, N, H2, W2, C2, S2, N2)) {
-        if (quad_alt() & 1) MF_QUAD_GO(Quad13x);
         MF_QUAD_GO(Quad13);
     }
     if (quad_matches<Quad57>(H, W, C, S, N, H2, W2, C2, S2, N2)) {
