@@ -191,6 +191,52 @@ def test_speech_batch_65536(mf, models, O):
     assert np.array_equal(y.cpu().numpy(), z.cpu().numpy())
 
 
+_NO_QUAD_SCRIPT = r"""
+import sys, numpy as np
+sys.path.insert(0, {root!r})
+import microflow_rs_amd as mf
+from tests.synth import synth_i8
+m = mf.model({root!r} + "/models/person_detect.tflite")
+x = synth_i8(3, 0, {n}, m.input_elems)
+m.prepare({n})
+names = [m.op(i)["kernel"] for i in range(m.num_ops)]
+assert not any(k.startswith("quad_rr") for k in names), names
+assert sum(k.startswith("dwpw_rr") for k in names) == 4, names
+np.save({out!r}, np.asarray(m.run_until(x, 8)))
+print("no-quad ok")
+"""
+
+
+def test_quads_equal_the_four_pair_launches(models, O, tmp_path):
+    """Ops 1..8 of person_detect run as two quad kernels (k_quad.hip: two depthwise + 1x1 pairs per launch, the tensor between
+    them in LDS).  The tensor after op 8 must be the one the four separate pair launches produce (MF_NO_QUAD=1, in a child
+    process: the switch is read once) on a batch that is not a multiple of anything, and the oracle's on its first images."""
+    import subprocess
+    import sys
+    m = models["person_detect"]
+    n = 1031
+    m.prepare(n)
+    names = [m.op(i)["kernel"] for i in range(m.num_ops)]
+    if not any(k.startswith("quad_rr") for k in names):
+        pytest.skip("quads switched off")
+    x = synth_i8(3, 0, n, m.input_elems)
+    got = np.asarray(m.run_until(x, 8)).reshape(n, -1)
+    om = O.Model(model_path("person_detect"))
+    for b in (0, 1, n - 1):
+        _, layers = om.run_quantized(x[b], layers=True)
+        assert np.array_equal(got[b], layers[8].reshape(-1)), b
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / "noquad.npy")
+    env = dict(os.environ, MF_NO_QUAD="1")
+    r = subprocess.run([sys.executable, "-c", _NO_QUAD_SCRIPT.format(root=root, n=n, out=out)], env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0 and "no-quad ok" in r.stdout, r.stdout + r.stderr
+    assert np.array_equal(got, np.load(out).reshape(n, -1))
+    # a single image and a batch smaller than the grid
+    for k in (1, 5):
+        assert np.array_equal(np.asarray(m.run_until(x[:k], 8)).reshape(k, -1), got[:k])
+
+
 def test_kernel_routing(models):
     """The fast HIP kernels are the ones that run for person_detect."""
     m = models["person_detect"]
