@@ -287,6 +287,8 @@ def main():
                 bound = "valu" if rq / REQUANT_PEAK_GBS > nbytes / HBM_PEAK_GBS else "hbm"
                 if d["kernel"].startswith("quad_rr"):
                     kind = "quad(2 pairs)"   # two depthwise+pointwise pairs in one launch (k_quad.hip)
+                elif d["kernel"].startswith("penta_rr"):
+                    kind = "penta(stem + 2 pairs)"   # ... with the network's first operator in front of them
                 elif nops_in_group > 3:
                     kind = "stage(%d ops)" % nops_in_group
                 rows.append({"op": i, "kind": kind,
@@ -439,6 +441,7 @@ def main():
             "whole_step": whole_step,
             "fused_dwpw": agg(kernels, "depthwise_conv_2d+conv_2d"),
             "fused_quad": agg(kernels, "quad(2 pairs)"),
+            "fused_penta": agg(kernels, "penta(stem + 2 pairs)"),
             "depthwise": layerwise["depthwise"], "conv_2d": layerwise["conv_2d"],
             "event_ms_per_step": round(avg_ms, 4),
             "kernels": kernels,

@@ -242,21 +242,33 @@ struct Quad57x : Quad57 { // (tuning alternative: the 3-wave workgroup)
     static constexpr int NTHR = 192, ACT_A = 3, ACT_B = 3;
 };
 
-template <typename Q> constexpr int quad_lds_bytes() {
-    return Q::G * Q::A::TILE + 512 + Q::G * Q::B::TILE + 512 + 16;
-}
 
-template <typename Q, int MG, uint32_t XR4>
+
+// STEM: the network's first operator in front of pair A (person_detect op 0: DepthwiseConv2D 3x3 stride 2 with one input channel
+// and 8 outputs, src/ops/depthwise_conv_2d.rs:28-105 with Cin = 1) as a third phase, dw3x3_stem8_mm's arithmetic (k_depthwise.hip):
+// the 96x96 image is DMA-staged into its own tile; a tile of the stem = 16 pixel pairs x (2 pixels x 8 channels) is ONE
+// v_mfma_i32_16x16x32_i8 whose K bytes are two aligned dwords of an image row; the lane's packed dword goes straight into tile A.
+// The stem's output tensor (18 432 B per image, the input of pair A) then never crosses HBM either.  Its per-lane operands are
+// re-read from device memory every step (L2 hits) instead of living in registers next to those of the two pairs.
+template <typename Q, bool STEM> constexpr int quad_stem_bytes() {
+    return STEM ? 16 + (2 * Q::A::H + 2) * (2 * Q::A::W) : 0;
+}
+template <typename Q, bool STEM, int MG, uint32_t XR4>
 __global__ __launch_bounds__(Q::NTHR, Q::WPE) void quad_rr(const int8_t *__restrict__ in, int8_t *__restrict__ out, QuadArgs p, int batch) {
     using GA = typename Q::A;
     using GB = typename Q::B;
     constexpr int G = Q::G, NTHR = Q::NTHR, NWAVE = NTHR / 64;
-    constexpr int BUF_A = G * GA::TILE, OFF_B = BUF_A + 512, BUF_B = G * GB::TILE, OFF_Q = OFF_B + BUF_B + 512;
+    constexpr int BUF_A = G * GA::TILE, OFF_B = BUF_A + 512, BUF_B = G * GB::TILE, OFF_S = OFF_B + BUF_B + 512;
+    constexpr int S_GUARD = 16, SW = 2 * GA::W, SH = 2 * GA::H, S_TILE = quad_stem_bytes<Q, STEM>(), OFF_Q = OFF_S + S_TILE;
+    static_assert(!STEM || (G == 1 && GA::C == 8 && GA::W == 48 && (GA::H / 2) % NWAVE == 0 && (SH * SW) % 1024 == 0 && S_TILE % 16 == 0),
+                  "stem phase: 8 channels, 24 pixel pairs per output row, whole row pairs per wave");
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     DynSteps dq;
     dq.init(lds + OFF_Q, p.a.dw.queue, tid, p.a.dw.qcfg);
+    if constexpr (STEM) // the stem tile's guard and padding rows hold the stem's input zero point
+        for (int i = tid; i < S_TILE / 16; i += NTHR) ((uint4 *)(lds + OFF_S))[i] = make_uint4(p.stem_izp4, p.stem_izp4, p.stem_izp4, p.stem_izp4);
     // tile A's halo holds pair A's input zero point, tile B's pair B's (= the zero point of pair A's output tensor)
     for (int i = tid; i < OFF_B / 16; i += NTHR) ((uint4 *)lds)[i] = make_uint4(p.a.dw.izp4, p.a.dw.izp4, p.a.dw.izp4, p.a.dw.izp4);
     for (int i = tid; i < (BUF_B + 512) / 16; i += NTHR) ((uint4 *)(lds + OFF_B))[i] = make_uint4(p.b.dw.izp4, p.b.dw.izp4, p.b.dw.izp4, p.b.dw.izp4);
@@ -267,6 +279,15 @@ __global__ __launch_bounds__(Q::NTHR, Q::WPE) void quad_rr(const int8_t *__restr
     __syncthreads(); // halo fills complete before any DMA lands
 
     auto stage = [&](int st) {
+        if constexpr (STEM) { // the 96 x 96 x 1 image, verbatim, in 1 KiB pieces behind the guard and the padding row
+            constexpr int NI = SH * SW / 1024;
+#pragma unroll
+            for (int k = 0; k < (NI + NWAVE - 1) / NWAVE; ++k) {
+                const int r = k * NWAVE + wave;
+                if (r < NI) dma16(in + ((size_t)st * (SH * SW) + r * 1024 + lane * 16), lds + OFF_S + S_GUARD + SW + r * 1024);
+            }
+            return;
+        }
         constexpr int NROWS = G * GA::H;
         const int src_lane = GA::NQ > 1 ? (lane ^ tile_swz<GA::TS>(lane / (GA::NQ > 1 ? GA::NQ : 1))) : lane;
 #pragma unroll
@@ -277,38 +298,84 @@ __global__ __launch_bounds__(Q::NTHR, Q::WPE) void quad_rr(const int8_t *__restr
                 dma16(in + ((size_t)(st * G + gi) * GA::IMG + y * GA::ROWB + src_lane * 16), lds + gi * GA::TILE + (y + 1) * GA::ROW + GA::LP);
         }
     };
+    // stem phase: three tile types per row pair (pairs 0..15 of row r0 | 16..23 of r0 and 0..7 of r0 + 1 | 8..23 of r0 + 1)
+    auto stem_phase = [&](const uint32_t *sc) {
+        constexpr int RPW = GA::H / 2 / NWAVE;        // output row pairs per wave
+        const int col = lane & 15, g = lane >> 4;
+        const long Aw = *(const long *)(sc + 2 * lane);
+        const int cq = (g & 1) * 4;                   // this lane's channels within its pixel
+        const float4 cA = *(const float4 *)(sc + 128 + cq), cS = *(const float4 *)(sc + 136 + cq);
+        const int4 ck = magic4<MG>(*(const int4 *)(sc + 144 + cq));
+        const v4i cK = {ck.x, ck.y, ck.z, ck.w};
+        const int oy1 = col >= 8 ? 1 : 0, j1 = col >= 8 ? col - 8 : 16 + col;
+        // operand: the aligned dwords at columns 4j - 4 and 4j of tile row 2 oy + ky (ky = g; tile row 0 = input row -1)
+        const int off0 = S_GUARD + g * SW + 4 * col - 4, off1 = S_GUARD + (2 * oy1 + g) * SW + 4 * j1 - 4, off2 = S_GUARD + (2 + g) * SW + 4 * (8 + col) - 4;
+        // result: pixel 2j + (g >> 1) of output row oy -> tile A row oy + 1, 8 bytes per pixel, this lane's 4 channels
+        const int px = (g >> 1) * 8 + cq;
+        const int dst0 = GA::ROW + GA::LP + 16 * col + px, dst1 = (1 + oy1) * GA::ROW + GA::LP + 16 * j1 + px, dst2 = 2 * GA::ROW + GA::LP + 16 * (8 + col) + px;
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+            const int rp = wave * RPW + i;
+            const uint8_t *t0 = lds + OFF_S + rp * (4 * SW);
+            uint8_t *d0 = lds + rp * (2 * GA::ROW);
+            long B[3];
+#pragma unroll
+            for (int n = 0; n < 3; ++n) {
+                const uint32_t *q = (const uint32_t *)(t0 + (n == 0 ? off0 : (n == 1 ? off1 : off2)));
+                uint32_t lo = q[0];
+                const uint32_t hi = q[1];
+                if (n == 0) lo = col == 0 ? p.stem_izp4 : lo;  // pair 0: column -1 is padding
+                if (n == 1) lo = col == 8 ? p.stem_izp4 : lo;
+                B[n] = (long)(((unsigned long)hi << 32) | (unsigned long)lo);
+            }
+#pragma unroll
+            for (int n = 0; n < 3; ++n) {
+                const v4i acc = __builtin_amdgcn_mfma_i32_16x16x32_i8(Aw, B[n], cK, 0, 0, 0);
+                *(uint32_t *)(d0 + (n == 0 ? dst0 : (n == 1 ? dst1 : dst2))) =
+                    requant_pack4<MG, XR4>(acc[0], acc[1], acc[2], acc[3], cA, cS, p.stem_lo, p.stem_hi);
+            }
+        }
+    };
     const int nsteps = (batch + G - 1) / G;
     if (dq.step < nsteps) stage(dq.step);
+    const uint32_t *sc = p.stem;
     for (; dq.step < nsteps; dq.advance(tid)) {
         const int step = dq.step;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads(); // this step's image is in tile A; every wave is done reading tile B (the previous step's phase B)
+        __syncthreads(); // this step's image is staged; every wave is done reading tile B (the previous step's phase B)
         dq.top(tid);
         const int gvalid = min(G, batch - step * G);
+        if constexpr (STEM) {
+            asm volatile("" : "+s"(sc));     // (the stem's operands are fetched here, every step, not hoisted into registers)
+            stem_phase(sc);                  // stem: image -> tile A
+            __syncthreads();                 // tile A is complete; the stem tile is free
+            if (dq.nxt < nsteps) stage(dq.nxt); // lands during phases A and B
+        }
         if (Q::ACT_A == NWAVE || wave < Q::ACT_A) pa.template run<GB>(lds, lds + OFF_B, gvalid); // pair A: tile A -> tile B
         __syncthreads(); // tile B is complete; tile A is free
-        if (dq.nxt < nsteps) stage(dq.nxt);                               // lands during phase B
+        if constexpr (!STEM)
+            if (dq.nxt < nsteps) stage(dq.nxt);                           // lands during phase B
         if (Q::ACT_B == NWAVE || wave < Q::ACT_B)
             pb.template run<void>(lds + OFF_B, (uint8_t *)out + (size_t)step * G * GB::OPIX * GB::N, gvalid); // pair B: tile B -> HBM
     }
     dq.finish(tid);
 }
 
-template <typename Q, int MG, uint32_t XR4>
+template <typename Q, bool STEM, int MG, uint32_t XR4>
 static void launch_quad_t(const int8_t *in, int8_t *out, const QuadArgs &a, int batch, hipStream_t s) {
-    constexpr int lds = quad_lds_bytes<Q>();
+    constexpr int lds = Q::G * Q::A::TILE + 512 + Q::G * Q::B::TILE + 512 + quad_stem_bytes<Q, STEM>() + 16;
     static_assert(lds <= 163840, "quad tiles do not fit the LDS");
     static LaunchState st;
-    const int per_cu = prepared(st, quad_rr<Q, MG, XR4>, Q::NTHR, lds);
+    const int per_cu = prepared(st, quad_rr<Q, STEM, MG, XR4>, Q::NTHR, lds);
     const int nsteps = (batch + Q::G - 1) / Q::G;
     const int grid = nsteps < 256 * per_cu ? nsteps : 256 * per_cu;
     QuadArgs b = a;
     using GA = typename Q::A;
     using GB = typename Q::B;
-    const double hbm = (double)batch * (GA::H * GA::W * GA::C + GB::OPIX * GB::N);
-    const double rq = (double)batch * (GA::OPIX * (GA::C + GA::N) + GB::OPIX * (GB::C + GB::N));
+    const double hbm = (double)batch * ((STEM ? 4 * GA::H * GA::W : GA::H * GA::W * GA::C) + GB::OPIX * GB::N);
+    const double rq = (double)batch * ((STEM ? GA::H * GA::W * GA::C : 0) + GA::OPIX * (GA::C + GA::N) + GB::OPIX * (GB::C + GB::N));
     b.a.dw.qcfg = dq_config(nsteps, grid, dq_est_us(hbm, rq));
-    hipLaunchKernelGGL((quad_rr<Q, MG, XR4>), dim3(grid), dim3(Q::NTHR), lds, s, in, out, b, batch);
+    hipLaunchKernelGGL((quad_rr<Q, STEM, MG, XR4>), dim3(grid), dim3(Q::NTHR), lds, s, in, out, b, batch);
 }
 template <typename Q> static bool quad_matches(int H, int W, int C, int S, int N, int H2, int W2, int C2, int S2, int N2) {
     using GA = typename Q::A;
@@ -316,8 +383,8 @@ template <typename Q> static bool quad_matches(int H, int W, int C, int S, int N
     return H == GA::H && W == GA::W && C == GA::C && S == GA::S && N == GA::N && H2 == GB::H && W2 == GB::W && C2 == GB::C && S2 == GB::S &&
            N2 == GB::N;
 }
-static int quad_mask() { // MF_QUADS: bit 0 = ops 1..4, bit 1 = ops 5..8 (tuning)
-    static const int m = [] { const char *e = getenv("MF_QUADS"); return e ? atoi(e) : 3; }();
+static int quad_mask() { // MF_QUADS: bit 0 = ops 1..4, bit 1 = ops 5..8, bit 2 = the stem in front of ops 1..4 (tuning)
+    static const int m = [] { const char *e = getenv("MF_QUADS"); return e ? atoi(e) : 7; }();
     return m;
 }
 static int quad_alt() { // MF_QUAD_ALT: bit 1 = Quad57x (tuning)
@@ -329,23 +396,31 @@ const char *quad_name(int H, int W, int C, int S, int N, int H2, int W2, int C2,
     if ((quad_mask() & 2) && quad_matches<Quad57>(H, W, C, S, N, H2, W2, C2, S2, N2)) return Quad57::name;
     return nullptr;
 }
+const char *quad_stem_name(int SH, int SW, int H, int W, int C, int S, int N, int H2, int W2, int C2, int S2, int N2) {
+    if ((quad_mask() & 4) && SH == 2 * Quad13::A::H && SW == 2 * Quad13::A::W && quad_matches<Quad13>(H, W, C, S, N, H2, W2, C2, S2, N2))
+        return "penta_rr<96,96,1,2,8|48,48,8,1,16|48,48,16,2,32>";
+    return nullptr;
+}
 bool launch_quad(int H, int W, int C, int S, int N, int H2, int W2, int C2, int S2, int N2, const int8_t *in, int8_t *out, const QuadArgs &a,
                  int batch, hipStream_t s) {
     if (!a.a.dw.wmm || !a.a.pw.wrr || !a.b.dw.wmm || !a.b.pw.wrr) return false;
-    const int mg = std::min(std::min(a.a.dw.magic, a.a.pw.magic), std::min(a.b.dw.magic, a.b.pw.magic));
+    int mg = std::min(std::min(a.a.dw.magic, a.a.pw.magic), std::min(a.b.dw.magic, a.b.pw.magic));
+    if (a.stem) mg = std::min(mg, a.stem_magic);
     if (mg == 0) return false; // (the quads exist for the bit-pattern epilogues only)
-#define MF_QUAD_GO(Q)                                                                              \
+#define MF_QUAD_GO2(Q, ST)                                                                         \
     do {                                                                                           \
         if (a.b.pw.xr) {                                                                           \
-            if (mg == 2) launch_quad_t<Q, 2, 0x80808080u>(in, out, a, batch, s);                   \
-            else launch_quad_t<Q, 1, 0x80808080u>(in, out, a, batch, s);                           \
+            if (mg == 2) launch_quad_t<Q, ST, 2, 0x80808080u>(in, out, a, batch, s);               \
+            else launch_quad_t<Q, ST, 1, 0x80808080u>(in, out, a, batch, s);                       \
         } else {                                                                                   \
-            if (mg == 2) launch_quad_t<Q, 2, 0u>(in, out, a, batch, s);                            \
-            else launch_quad_t<Q, 1, 0u>(in, out, a, batch, s);                                    \
+            if (mg == 2) launch_quad_t<Q, ST, 2, 0u>(in, out, a, batch, s);                        \
+            else launch_quad_t<Q, ST, 1, 0u>(in, out, a, batch, s);                                \
         }                                                                                          \
         return true;                                                                               \
     } while (0)
+#define MF_QUAD_GO(Q) MF_QUAD_GO2(Q, false)
     if (quad_matches<Quad13>(H, W, C, S, N, H2, W2, C2, S2, N2)) {
+        if (a.stem) MF_QUAD_GO2(Quad13, true);
         MF_QUAD_GO(Quad13);
     }
     if (quad_matches<Quad57>(H, W, C, S, N, H2, W2, C2, S2, N2)) {
@@ -353,6 +428,7 @@ bool launch_quad(int H, int W, int C, int S, int N, int H2, int W2, int C2, int 
         MF_QUAD_GO(Quad57);
     }
 #undef MF_QUAD_GO
+#undef MF_QUAD_GO2
     return false;
 }
 

@@ -199,8 +199,16 @@ struct DwPwArgs {
 // two consecutive pairs in one launch (k_quad.hip)
 struct QuadArgs {
     DwPwArgs a, b;
+    // the one-input-channel stem in front of pair a (k_quad.hip, STEM instance: person_detect ops 0..4 in one launch), or nullptr.
+    // Device dwords: [0, 128) operand A of v_mfma_i32_16x16x32_i8 per lane (DwStemArgs::wmm), [128, 136) A, [136, 144) S,
+    // [144, 152) Kc of the 8 output channels
+    const uint32_t *stem;
+    uint32_t stem_izp4;
+    float stem_lo, stem_hi;
+    int stem_magic;
 };
 const char *quad_name(int H, int W, int C, int S, int N, int H2, int W2, int C2, int S2, int N2);
+const char *quad_stem_name(int SH, int SW, int H, int W, int C, int S, int N, int H2, int W2, int C2, int S2, int N2); // with a.stem set
 bool launch_quad(int H, int W, int C, int S, int N, int H2, int W2, int C2, int S2, int N2, const int8_t *in, int8_t *out, const QuadArgs &a,
                  int batch, hipStream_t s);
 

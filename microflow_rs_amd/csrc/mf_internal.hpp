@@ -127,6 +127,7 @@ FusedImpl *fused_dwfc_create(OpImpl *dw, FusedImpl *fc_softmax);
 // the last depthwise + pointwise pair group (3x3x256) + the pool/head/softmax tail group as one kernel (second level)
 FusedImpl *fused_pair_tail_create(FusedImpl *pair, FusedImpl *tail);
 FusedImpl *fused_quad_create(FusedImpl *pair1, FusedImpl *pair2); // two consecutive pairs in one launch (k_quad.hip)
+FusedImpl *fused_quad_stem_create(OpImpl *stem, FusedImpl *quad); // the one-input-channel stem + a quad in one launch, or nullptr
 void fused_destroy(FusedImpl *f);
 void fused_run(FusedImpl *f, const int8_t *d_in, size_t batch, int8_t *d_out, void *stream);
 const char *fused_kernel_name(const FusedImpl *f);

@@ -130,10 +130,12 @@ static int fused_owner(const ModelImpl *m, int i) {
 }
 const char *model_op_kernel(const ModelImpl *m, int i) {
     if (!m->prepared || i < 0 || i >= (int)m->ops.size() || !m->ops[i]) return "";
-    if (const ModelImpl::Stage *st = stage_at(m, i, (int)m->ops.size() - 1)) return fused_kernel_name(st->f);
-    if (m->fusion && !m->generic)
+    if (m->fusion && !m->generic) { // the stage a run from operator 0 uses for op i: the covering one that starts first
+        const ModelImpl::Stage *best = nullptr;
         for (const ModelImpl::Stage &st : m->stages)
-            if (i > st.first && i <= st.last) return "(fused into the previous operator)";
+            if (i >= st.first && i <= st.last && (!best || st.first < best->first)) best = &st;
+        if (best) return best->first == i ? fused_kernel_name(best->f) : "(fused into the previous operator)";
+    }
     if (fused_at(m, i)) return fused_kernel_name(m->fused[(size_t)i]);
     if (fused_owner(m, i) >= 0) return "(fused into the previous operator)";
     return op_kernel_name(m->ops[i]);
@@ -273,6 +275,10 @@ void model_prepare(ModelImpl *m, int device, size_t max_batch) {
             if (!fused[i + 2] || fused_last[i + 2] != (int)i + 3) continue;
             if (FusedImpl *f = fused_quad_create(fused[i], fused[i + 2])) {
                 sg.v.push_back({f, (int)i, (int)i + 3});
+                // ... and with the stem in front of it: ops i - 1 .. i + 3 in one launch.  Both stay: a run that does not
+                // start at the stem (mf_model_run_until pieces, the f32 entry whose stem kernel quantises) uses the quad
+                if (i >= 1 && ops[i - 1] && !fused[i - 1] && !covered(i - 1))
+                    if (FusedImpl *g = fused_quad_stem_create(ops[i - 1], f)) sg.v.push_back({g, (int)i - 1, (int)i + 3});
                 i += 3;
             }
         }

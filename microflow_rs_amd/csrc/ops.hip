@@ -1127,6 +1127,35 @@ FusedImpl *fused_quad_create(FusedImpl *p1, FusedImpl *p2) {
     return f;
 }
 
+// The network's one-input-channel stem in front of a quad: five operators in one launch (k_quad.hip, STEM instance).  The quad
+// itself stays (mf_model_run_until, and the f32 entry point, whose boundary quantisation is fused into the stem kernel).
+FusedImpl *fused_quad_stem_create(OpImpl *stem, FusedImpl *quad) {
+    static const bool off = getenv("MF_NO_PENTA") != nullptr;
+    if (off || !stem || !quad || quad->kind != FusedImpl::QUAD || quad->quad.stem || stem->fast != OpImpl::DW_STEM) return nullptr;
+    const OpSpec &t = stem->s, &d1 = quad->a->s;
+    if (stem->device != quad->a->device || t.u8 != d1.u8 || stem->force_generic) return nullptr;
+    if (t.OH != d1.H || t.OW != d1.W || t.N != d1.C || t.sh != 2 || t.sw != 2 || t.C != 1) return nullptr; // pair A consumes the stem's output
+    const int *q = quad->quad_shape;
+    const char *nm = k::quad_stem_name(t.H, t.W, q[0], q[1], q[2], q[3], q[4], q[5], q[6], q[7], q[8], q[9]);
+    if (!nm || !stem->stem.magic) return nullptr;
+    std::unique_ptr<FusedImpl> f(new FusedImpl{FusedImpl::QUAD, stem, quad->b, nullptr, {}, {}, nm});
+    f->quad = quad->quad;
+    for (int i = 0; i < 10; ++i) f->quad_shape[i] = q[i];
+    const k::DwStemArgs &sa = stem->stem;
+    std::vector<uint32_t> tab(152);
+    for (int l = 0; l < 64; ++l) tab[(size_t)2 * l] = sa.wmm[l][0], tab[(size_t)2 * l + 1] = sa.wmm[l][1];
+    for (int c = 0; c < 8; ++c) {
+        memcpy(&tab[(size_t)128 + c], &sa.A[c], 4);
+        memcpy(&tab[(size_t)136 + c], &sa.S[c], 4);
+        memcpy(&tab[(size_t)144 + c], &sa.Kc[c], 4);
+    }
+    f->stage_w.emplace_back(new DevBuf);
+    f->stage_w.back()->upload(tab.data(), tab.size() * 4);
+    f->quad.stem = f->stage_w.back()->as<uint32_t>();
+    f->quad.stem_izp4 = sa.izp4, f->quad.stem_lo = sa.lo_f, f->quad.stem_hi = sa.hi_f, f->quad.stem_magic = sa.magic;
+    return f.release();
+}
+
 void fused_destroy(FusedImpl *f) { delete f; }
 const char *fused_kernel_name(const FusedImpl *f) { return f->name.c_str(); }
 void fused_run(FusedImpl *f, const int8_t *d_in, size_t batch, int8_t *d_out, void *stream) {

@@ -46,6 +46,8 @@ def short(name):
         args = ""
     if base == "quad_rr":  # quad_rr<mf::k::Quad13, MG, XR4>: the library's name carries the two pair shapes
         which = "Quad13" if "Quad13" in name else "Quad57"
+        if which == "Quad13" and re.search(r"Quad13,\s*(true|1)\b", name):  # the STEM instance: ops 0..4 in one launch
+            return "penta_rr<96,96,1,2,8|48,48,8,1,16|48,48,16,2,32>"
         return {"Quad13": "quad_rr<48,48,8,1,16|48,48,16,2,32>", "Quad57": "quad_rr<24,24,32,1,32|24,24,32,2,64>"}[which]
     if base == "pair3_tail":
         args = "<3,3,256,2>"

@@ -200,7 +200,7 @@ m = mf.model({root!r} + "/models/person_detect.tflite")
 x = synth_i8(3, 0, {n}, m.input_elems)
 m.prepare({n})
 names = [m.op(i)["kernel"] for i in range(m.num_ops)]
-assert not any(k.startswith("quad_rr") for k in names), names
+assert not any(k.startswith(("quad_rr", "penta_rr")) for k in names), names
 assert sum(k.startswith("dwpw_rr") for k in names) == 4, names
 np.save({out!r}, np.asarray(m.run_until(x, 8)))
 print("no-quad ok")
@@ -217,7 +217,7 @@ def test_quads_equal_the_four_pair_launches(models, O, tmp_path):
     n = 1031
     m.prepare(n)
     names = [m.op(i)["kernel"] for i in range(m.num_ops)]
-    if not any(k.startswith("quad_rr") for k in names):
+    if not any(k.startswith(("quad_rr", "penta_rr")) for k in names):
         pytest.skip("quads switched off")
     x = synth_i8(3, 0, n, m.input_elems)
     got = np.asarray(m.run_until(x, 8)).reshape(n, -1)
@@ -235,6 +235,10 @@ def test_quads_equal_the_four_pair_launches(models, O, tmp_path):
     # a single image and a batch smaller than the grid
     for k in (1, 5):
         assert np.array_equal(np.asarray(m.run_until(x[:k], 8)).reshape(k, -1), got[:k])
+    # pieces that end inside the five-operator launch fall back to the quad / the pairs / the stem alone
+    _, layers = om.run_quantized(x[2], layers=True)
+    for last in (0, 2, 4):
+        assert np.array_equal(np.asarray(m.run_until(x[2:3], last)).reshape(-1), layers[last].reshape(-1)), last
 
 
 def test_kernel_routing(models):
@@ -242,17 +246,21 @@ def test_kernel_routing(models):
     m = models["person_detect"]
     m.prepare(1)
     names = [m.op(i)["kernel"] for i in range(m.num_ops)]
-    assert names[0].startswith("dw3x3_stem8")
+    penta = names[0].startswith("penta_rr")   # the stem + ops 1..4 in one launch (k_quad.hip STEM; MF_NO_PENTA=1: not)
+    assert penta or names[0].startswith("dw3x3_stem8")
     # fused depthwise + 1x1 conv pairs: dwpw_rr / dwpw_mm (taps on the matrix pipe) or, with
     # MF_DWPW_IMPL=valu, r01's dwpw3x3; the five 6x6x128 pairs (ops 13..22) are ONE persistent kernel
     # (MF_NO_STAGE=1: not)
     # ops 1..4 and 5..8 are two "quads" (two pairs per launch, k_quad.hip; MF_NO_QUAD=1: four pair launches)
-    quads = sum(n.startswith("quad_rr") for n in names)
+    quads = sum(n.startswith(("quad_rr", "penta_rr")) for n in names)
     npairs = sum(n.startswith(("dwpw_rr", "dwpw_mm", "dwpw3x3")) for n in names) + 2 * quads
     pair_tail = not (os.environ.get("MF_NO_PAIRTAIL") or os.environ.get("MF_DWPW_IMPL") == "valu")
     if not (os.environ.get("MF_NO_QUAD") or os.environ.get("MF_DWPW_IMPL")):
-        assert quads == 2 and names[1].startswith("quad_rr<48,48,8") and names[5].startswith("quad_rr<24,24,32"), names
-        assert all(n.startswith("(fused") for n in names[2:5] + names[6:9]), names
+        assert quads == 2 and names[5].startswith("quad_rr<24,24,32"), names
+        assert names[0].startswith("penta_rr<96,96,1,2,8|48,48,8") if penta else names[1].startswith("quad_rr<48,48,8"), names
+        assert all(n.startswith("(fused") for n in names[2:5] + names[6:9]) and (not penta or names[1].startswith("(fused")), names
+        if not os.environ.get("MF_NO_PENTA"):
+            assert penta, names
     if os.environ.get("MF_NO_STAGE"):
         assert npairs == (12 if pair_tail else 13), names
     else:

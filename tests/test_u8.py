@@ -316,10 +316,10 @@ def test_u8_person_detect_uses_the_fast_kernels(mf, O):
     assert np.array_equal(m.run_quantized(xq).reshape(n, -1), want)
     names = [m.op(i)["kernel"] for i in range(m.num_ops)]
     # 13 pairs: pair kernels, five of them inside the stage kernel, the last inside pair3_tail (all with the u8 store)
-    assert names[0].startswith("dw3x3_stem8"), names
+    assert names[0].startswith(("dw3x3_stem8", "penta_rr")), names   # (penta_rr: the stem + ops 1..4 in one launch)
     npairs = sum(k.startswith(("dwpw_rr", "dwpw_mm", "dwpw3x3")) for k in names)
     npairs += 5 * sum(k.startswith("stage_6x6x128") for k in names) + sum(k.startswith("pair3_tail") for k in names)
-    npairs += 2 * sum(k.startswith("quad_rr") for k in names)   # two pairs per quad launch (k_quad.hip)
+    npairs += 2 * sum(k.startswith(("quad_rr", "penta_rr")) for k in names)   # two pairs per quad launch (k_quad.hip)
     assert npairs == 13, names
     if not os.environ.get("MF_NO_PAIRTAIL") and os.environ.get("MF_DWPW_IMPL") != "valu":
         assert names[25].startswith("pair3_tail"), names
