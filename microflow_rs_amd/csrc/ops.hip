@@ -124,7 +124,7 @@ namespace {
 // (acc = sum over ALL taps of (v' - izp)(w - wzp), the halo contributing 0).
 int64_t fold_conv_constants(OpImpl &op, const OpSpec &s, bool depthwise, std::vector<float> &A,
                             std::vector<float> &S, std::vector<int32_t> &Kc,
-                            std::vector<int32_t> &wzp) {
+                            std::vector<int32_t> &wzp, std::vector<int64_t> *acc_bound_per_channel = nullptr) {
     const int N = s.N;
     const int taps = s.KH * s.KW;
     int64_t max_wabs = 0;
@@ -152,6 +152,7 @@ int64_t fold_conv_constants(OpImpl &op, const OpSpec &s, bool depthwise, std::ve
             T = taps * s.C;
         }
         max_wabs = std::max(max_wabs, wabs);
+        if (acc_bound_per_channel) acc_bound_per_channel->push_back(wabs * std::max(127 - s.izp, s.izp + 128));
         // Kc = -izp * sum(w) + T * izp * wzp   (k2 and k3 of the reference with the halo == izp)
         Kc[c] = wrap_add(wrap_sub(0, wrap_mul(s.izp, wsum)), wrap_mul(wrap_mul(T, s.izp), wzp[c]));
     }
@@ -355,7 +356,8 @@ OpImpl *op_create(int device, const OpSpec &spec) {
         // the fast kernels may convert the accumulator to f32 by bit pattern when it provably
         // stays below 2^22 in magnitude (requant_t<true> in k_common.hpp)
         static const bool no_magic = getenv("MF_NO_MAGIC") != nullptr; // tests: force the convert form
-        const int64_t acc_bound = fold_conv_constants(*op, s, dw, A, S, Kc, wzp);
+        std::vector<int64_t> acc_bound_c; // per output channel: max |v - izp| * sum_taps |w - wzp|
+        const int64_t acc_bound = fold_conv_constants(*op, s, dw, A, S, Kc, wzp, &acc_bound_c);
         int magic = !no_magic && acc_bound < (1 << 22) ? 1 : 0;
         // mode 2 (k_common.hpp): the clamp is the element type's whole range (so a saturating pack can do it) and
         // |x| = |A + S * acc| stays below 2^15 for every input (so x + 128 fits the i16 the pack saturates from)
@@ -363,9 +365,13 @@ OpImpl *op_create(int device, const OpSpec &spec) {
         if (magic && !no_sat && lo == (s.u8 ? 0 : -128) && hi == (s.u8 ? 255 : 127) && all_finite(A) && all_finite(S)) {
             double xmax = 0.0;
             for (int c = 0; c < s.N; ++c)
-                xmax = std::max(xmax, std::fabs((double)A[(size_t)c]) + std::fabs((double)S[(size_t)c]) * (double)acc_bound);
+                xmax = std::max(xmax, std::fabs((double)A[(size_t)c]) + std::fabs((double)S[(size_t)c]) * (double)acc_bound_c[(size_t)c]);
             if (xmax < 30000.0) magic = 2;
         }
+        static const bool epi_dbg = getenv("MF_DEBUG_EPI") != nullptr; // which epilogue mode each operator gets, and why
+        if (epi_dbg)
+            fprintf(stderr, "[epi] %s %dx%dx%d -> %d: |acc| < %lld, clamp [%d, %d] -> mode %d\n", dw ? "depthwise" : "conv", s.H, s.W, s.C, s.N,
+                    (long long)acc_bound, lo, hi, magic);
         const size_t wbytes = dw ? (size_t)s.KH * s.KW * s.N : (size_t)s.N * s.KH * s.KW * s.C;
         op->d_w.upload(s.weights, wbytes);
         op->d_wzp.upload(wzp.data(), wzp.size() * 4);
