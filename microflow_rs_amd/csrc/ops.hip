@@ -499,8 +499,11 @@ OpImpl *op_create(int device, const OpSpec &spec) {
             // step has room, so that the MFMA's k span is used and a row's output is a long contiguous run
             if (s.N % 4 != 0) group = 0; // packed dword results: N in whole fours (a 2-output head runs conv1x1_rowwave)
             bool reg = group >= 1 && !wz && s.N * group <= 256 && s.C * group <= 512;
+            // (... but not past 64 output bytes per row: one wave then stores whole rows, 1 KiB contiguous per store
+            // instruction, instead of two waves storing half lines -- MF_PW_RT_NCAP: tuning)
+            static const int ncap = [] { const char *e = getenv("MF_PW_RT_NCAP"); return e ? atoi(e) : 64; }();
             if (reg)
-                while (s.C * group * 2 <= 64 && s.N * group * 2 <= 256) group *= 2;
+                while (s.C * group * 2 <= 64 && s.N * group * 2 <= std::max(ncap, s.N)) group *= 2;
             if (group >= 1 && !(wz && group > 1) && (reg || k::pw_rt_supported(s.C * group, s.N * group, wz))) {
                 op->fast = OpImpl::PW_RT;
                 op->rt_wz = wz, op->pw_group = group;
