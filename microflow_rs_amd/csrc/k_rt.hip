@@ -35,7 +35,8 @@ namespace k {
 // ------------------------------------------------------------------------
 template <int S, int R, bool WZ, int MG, uint32_t XR4>
 __global__ __launch_bounds__(512) void dw3x3_rt(const int8_t *__restrict__ in, int8_t *__restrict__ out, DwRtArgs p, int batch) {
-    constexpr int NTHR = 512, NWAVE = 8; // R = output rows per task (2, or 3 when the band height divides by 3)
+    // R = output rows per task (2, or 3 when the band height divides by 3); 256 or 512 threads (DwRtArgs::NTHR)
+    const int NTHR = (int)blockDim.x, NWAVE = NTHR >> 6;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -631,6 +632,14 @@ bool dw_rt_plan(DwRtArgs &a, int H, int W, int C, int S, int OH, int OW) {
         a.BH = bh, a.NBANDS = (OH + bh - 1) / bh, a.RB = rows_for(bh), a.TILE = a.RB * ROW, a.G = 1;
     }
     a.BUF = a.G * a.TILE;
+    // threads per workgroup: 256 for the large stride-2 layers (measured on person_detect's shapes with the tables off, 512 ->
+    // 256 threads: 48x48x16 s2 0.69 -> 0.56 ms, 24x24x32 s2 0.35 -> 0.32; the small tensors lose 15 - 20 %, stride 1 is indifferent)
+    {
+        static const int forced = [] { const char *e = getenv("MF_DW_RT_THREADS"); return e ? atoi(e) : 0; }();
+        a.NTHR = (S == 2 && H * W * C >= 16384 && C / 4 <= 256) ? 256 : 512;
+        if (forced == 256 && C / 4 <= 256) a.NTHR = 256;
+        if (forced == 512) a.NTHR = 512;
+    }
     return 2 * a.BUF + 256 + 16 <= 160 * 1024;
 }
 template <int S, int R, bool WZ, int MG, uint32_t XR4>
@@ -644,15 +653,15 @@ static void launch_dw_rt_t(const int8_t *in, int8_t *out, const DwRtArgs &a, int
         int dev = 0;
         (void)hipGetDevice(&dev);
         std::lock_guard<std::mutex> lock(mu);
-        auto it = cache.find({dev, lds});
+        auto it = cache.find({dev, lds * 2 + (a.NTHR == 256)});
         if (it == cache.end()) {
             (void)hipFuncSetAttribute((const void *)dw3x3_rt<S, R, WZ, MG, XR4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             int n = 1;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, dw3x3_rt<S, R, WZ, MG, XR4>, 512, (size_t)lds) != hipSuccess || n < 1) {
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, dw3x3_rt<S, R, WZ, MG, XR4>, a.NTHR, (size_t)lds) != hipSuccess || n < 1) {
                 (void)hipGetLastError();
                 n = 1;
             }
-            it = cache.emplace(std::make_pair(dev, lds), n).first;
+            it = cache.emplace(std::make_pair(dev, lds * 2 + (a.NTHR == 256)), n).first;
         }
         per_cu = it->second;
     }
@@ -661,7 +670,7 @@ static void launch_dw_rt_t(const int8_t *in, int8_t *out, const DwRtArgs &a, int
     DwRtArgs b = a;
     const double opix = (double)a.OH * a.OW;
     b.dw.qcfg = dq_config(nsteps, grid, dq_est_us((double)batch * ((double)a.H * a.W * a.C + opix * a.C), (double)batch * opix * a.C));
-    hipLaunchKernelGGL((dw3x3_rt<S, R, WZ, MG, XR4>), dim3(grid), dim3(512), lds, s, in, out, b, batch);
+    hipLaunchKernelGGL((dw3x3_rt<S, R, WZ, MG, XR4>), dim3(grid), dim3(a.NTHR), lds, s, in, out, b, batch);
 }
 void launch_dw_rt(const int8_t *in, int8_t *out, const DwRtArgs &a, int S, bool wz, int batch, hipStream_t s) {
     const int mg = a.dw.magic;

@@ -134,6 +134,7 @@ struct DwRtArgs {
     int BH, NBANDS;     // output rows per band (a multiple of R) and bands per image (1 = whole images)
     int RB;             // tile rows staged per image / band
     int ROW, LP, TILE, BUF; // tile row pitch, side pad, bytes per staged image, bytes per staging buffer
+    int NTHR;           // threads per workgroup (256 or 512)
 };
 struct PwRtArgs {
     const void *wprep;  // [16-channel tile][64-deep k step][lane] x 16 bytes (+ a tile of ones per k step when wzp != 0)
