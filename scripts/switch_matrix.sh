@@ -1,0 +1,7 @@
+#!/bin/bash
+# GPU box: the model-level parity tests under every A/B switch of the library (each switch is read once per process).
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+for sw in "" MF_NO_PENTA=1 MF_NO_QUAD=1 MF_QUADS=1 MF_QUADS=2 MF_NO_STAGE=1 MF_NO_PAIRTAIL=1 MF_DWPW_IMPL=valu MF_DW_IMPL=valu MF_NO_SAT_PACK=1 MF_NO_MAGIC=1 MF_NO_TABLE=1 MF_NO_RT=1 MF_NO_DWFC=1 MF_DQ_CFG=0; do
+  echo -n "[$sw] "
+  env $sw timeout 900 python -m pytest tests -q -m gpu 2>&1 | tail -1
+done

@@ -41,3 +41,8 @@ def O():
 
 def model_path(name):
     return os.path.join(MODELS, name + ".tflite")
+
+
+# scripts/switch_matrix.sh runs the parity tests under every A/B switch of the library (MF_NO_QUAD=1, MF_NO_TABLE=1, ...).
+# The assertions about WHICH kernel runs describe the default routing only and are skipped then; every parity assertion stays.
+ROUTING_SWITCHED = sorted(k for k in os.environ if k.startswith("MF_"))

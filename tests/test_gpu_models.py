@@ -8,7 +8,7 @@ import os
 import numpy as np
 import pytest
 
-from tests.conftest import GOLDEN, model_path
+from tests.conftest import GOLDEN, ROUTING_SWITCHED, model_path
 from tests.synth import SEED, layer_checksum, synth_i8
 
 pytestmark = pytest.mark.gpu
@@ -217,8 +217,8 @@ def test_quads_equal_the_four_pair_launches(models, O, tmp_path):
     n = 1031
     m.prepare(n)
     names = [m.op(i)["kernel"] for i in range(m.num_ops)]
-    if not any(k.startswith(("quad_rr", "penta_rr")) for k in names):
-        pytest.skip("quads switched off")
+    if ROUTING_SWITCHED or not any(k.startswith(("quad_rr", "penta_rr")) for k in names):
+        pytest.skip("quads switched off / non-default routing")
     x = synth_i8(3, 0, n, m.input_elems)
     got = np.asarray(m.run_until(x, 8)).reshape(n, -1)
     om = O.Model(model_path("person_detect"))
@@ -243,6 +243,8 @@ def test_quads_equal_the_four_pair_launches(models, O, tmp_path):
 
 def test_kernel_routing(models):
     """The fast HIP kernels are the ones that run for person_detect."""
+    if ROUTING_SWITCHED:
+        pytest.skip("default routing only (switches set: %s)" % ", ".join(ROUTING_SWITCHED))
     m = models["person_detect"]
     m.prepare(1)
     names = [m.op(i)["kernel"] for i in range(m.num_ops)]

@@ -5,6 +5,8 @@ The reference compiles for any shape (const generics); these are the kernels suc
 import numpy as np
 import pytest
 
+from tests.conftest import ROUTING_SWITCHED  # noqa: E402
+
 pytestmark = pytest.mark.gpu
 f32 = np.float32
 
@@ -70,7 +72,7 @@ def test_depthwise_rt_vs_oracle(mf, O, case, u8):
     c0, c1 = _consts(rng, C, 9)
     opts = mf.ops.DepthwiseConv2DOptions(mf.FusedActivation(act), mf.TensorViewPadding(0), (S, S))
     op = mf.ops.prepare_depthwise_conv_2d((H, W, C), w, wzp, izp, oscale, ozp, opts, (c0, c1), (OH, OW))
-    assert op.kernel == "dw3x3_rt<%d%s>" % (S, ",wzp" if wz else ""), op.kernel
+    assert ROUTING_SWITCHED or op.kernel == "dw3x3_rt<%d%s>" % (S, ",wzp" if wz else ""), op.kernel
     want = np.stack([O.depthwise_conv_2d(x[i], w, wzp, izp, oscale, ozp, act, 0, (S, S), (OH, OW), c0, c1)
                      for i in range(batch)])
     got = op(x)
@@ -113,7 +115,7 @@ def test_pointwise_rt_vs_oracle(mf, O, case, u8):
     c0, c1 = _consts(rng, N, K)
     opts = mf.ops.Conv2DOptions(mf.FusedActivation(act), mf.TensorViewPadding.SAME, (1, 1))
     op = mf.ops.prepare_conv_2d((H, W, K), f, fzp, izp, oscale, ozp, opts, (c0, c1), (H, W))
-    assert op.kernel == "pw_rt<%d,%d%s>" % (K, N, ",wzp" if wz else ""), op.kernel
+    assert ROUTING_SWITCHED or op.kernel == "pw_rt<%d,%d%s>" % (K, N, ",wzp" if wz else ""), op.kernel
     want = np.stack([O.conv_2d(x[i], f, fzp, izp, oscale, ozp, act, 0, (1, 1), (H, W), c0, c1) for i in range(batch)])
     got = op(x)
     assert np.array_equal(got, want), (op.kernel, np.argwhere(got != want)[:5])
@@ -135,7 +137,7 @@ def test_rt_kernels_on_a_large_batch_and_accumulator_extremes(mf, O):
     c0, c1 = _consts(rng, C, 9)
     opts = mf.ops.DepthwiseConv2DOptions(mf.FusedActivation(3), mf.TensorViewPadding(0), (S, S))
     op = mf.ops.prepare_depthwise_conv_2d((H, W, C), w, wzp, -128, 0.0235294122, -128, opts, (c0, c1), (H, W))
-    assert op.kernel == "dw3x3_rt<1>"
+    assert ROUTING_SWITCHED or op.kernel == "dw3x3_rt<1>"
     got = op(torch.as_tensor(x).cuda()).cpu().numpy()
     idx = [0, 1, 5, 6, 7, 511, 512, 2048, 4090, 4096, 4097, 4098]
     want = np.stack([O.depthwise_conv_2d(x[i], w, wzp, -128, 0.0235294122, -128, 3, 0, (S, S), (H, W), c0, c1) for i in idx])
@@ -181,13 +183,13 @@ def test_conv_rows_vs_oracle(mf, O, case, u8, monkeypatch):
         f = rng.integers(lo, hi, (N, KH, KW, C)).astype(dt)
         opts = mf.ops.Conv2DOptions(mf.FusedActivation(act), mf.TensorViewPadding(pad), (sh, sw))
         op = mf.ops.prepare_conv_2d((H, W, C), f, zp, izp, oscale, ozp, opts, (c0, c1), (OH, OW))
-        assert op.kernel == "conv_rows_lds" + ("<wzp>" if wz else ""), op.kernel
+        assert ROUTING_SWITCHED or op.kernel == "conv_rows_lds" + ("<wzp>" if wz else ""), op.kernel
         want = np.stack([O.conv_2d(x[i], f, zp, izp, oscale, ozp, act, pad, (sh, sw), (OH, OW), c0, c1) for i in range(batch)])
     else:
         w = rng.integers(lo, hi, (KH, KW, N)).astype(dt)
         opts = mf.ops.DepthwiseConv2DOptions(mf.FusedActivation(act), mf.TensorViewPadding(pad), (sh, sw))
         op = mf.ops.prepare_depthwise_conv_2d((H, W, C), w, zp, izp, oscale, ozp, opts, (c0, c1), (OH, OW))
-        assert op.kernel in ("dw_rows_lds" + ("<wzp>" if wz else ""), "dw_c1_lds"), op.kernel
+        assert ROUTING_SWITCHED or op.kernel in ("dw_rows_lds" + ("<wzp>" if wz else ""), "dw_c1_lds"), op.kernel
         want = np.stack([O.depthwise_conv_2d(x[i], w, zp, izp, oscale, ozp, act, pad, (sh, sw), (OH, OW), c0, c1) for i in range(batch)])
     got = op(x)
     assert np.array_equal(got, want), (op.kernel, np.argwhere(got != want)[:5])
@@ -232,7 +234,7 @@ def test_conv_mm_vs_oracle(mf, O, case, u8):
     c0, c1 = _consts(rng, N, KH * KW * C)
     opts = mf.ops.Conv2DOptions(mf.FusedActivation(act), mf.TensorViewPadding(pad), (sh, sw))
     op = mf.ops.prepare_conv_2d((H, W, C), f, zp, izp, oscale, ozp, opts, (c0, c1), (OH, OW))
-    assert op.kernel == "conv_mm_rt" + ("<wzp>" if wz else ""), op.kernel
+    assert ROUTING_SWITCHED or op.kernel == "conv_mm_rt" + ("<wzp>" if wz else ""), op.kernel
     want = np.stack([O.conv_2d(x[i], f, zp, izp, oscale, ozp, act, pad, (sh, sw), (OH, OW), c0, c1) for i in range(batch)])
     got = op(x)
     assert np.array_equal(got, want), (op.kernel, np.argwhere(got != want)[:5])
