@@ -18,7 +18,11 @@
 //     phase B : tile B -> pair B -> HBM
 //     barrier (top of the next step: the DMA has landed, everyone is done with tile B)
 // Column grids, row pads and swizzles are the table rows of the single pairs (kernels.hpp MF_DWRR_SHAPES); the workgroup
-// size is the one both unit grids divide over.  The dynamic step queue of k_common.hpp deals the images.
+// size is a multiple of four waves (waves go to the SIMDs round-robin per workgroup: anything else loads them unevenly and
+// every barrier waits for the doubled-up ones) over which pair A's unit grid divides; a pair whose grid does not divide runs
+// on fewer waves (ACT_B).  The dynamic step queue of k_common.hpp deals the images.
+// With STEM the network's first operator (one input channel -> 8, stride 2) is a third phase in front of pair A: ops 0..4 in
+// one launch (see quad_rr below).
 #include "k_common.hpp"
 
 #include <algorithm>
