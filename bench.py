@@ -337,6 +337,10 @@ def main():
                       "requant_bytes": step_rq, "requant_GBps": round(step_rq / (ev_med * 1e-3) / 1e9, 1),
                       "valu_frac": round(step_rq / (ev_med * 1e-3) / 1e9 / REQUANT_PEAK_GBS, 4),
                       "roof_floor_ms": round(floor_ms, 4), "frac_of_roof_floor": round(floor_ms / ev_med, 4),
+                      # fusing launches removes algorithmic bytes, so hbm_frac falls as the step gets faster; for comparison
+                      # with earlier rounds: the bytes of round 2's ten launches (pairs + stage + tail) over this step's time
+                      "hbm_frac_at_round2_bytes": (round(253442 * count / (ev_med * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                                                   if args.workload == "person_detect" else None),
                       "note": "all launches of the timed step: their algorithmic bytes / the step's median time vs 8 TB/s, their "
                               "requantised bytes / the same time vs the measured ceiling; roof_floor_ms = sum over launches of "
                               "max(bytes / 8 TB/s, requantised bytes / ceiling)"}
