@@ -343,24 +343,40 @@ __global__ __launch_bounds__(Q::NTHR, Q::WPE) void quad_rr(const int8_t *__restr
     const int nsteps = (batch + G - 1) / G;
     if (dq.step < nsteps) stage(dq.step);
     const uint32_t *sc = p.stem;
-    for (; dq.step < nsteps; dq.advance(tid)) {
-        const int step = dq.step;
+    if constexpr (STEM) {
+        // Two barriers per image: the stem phase of the NEXT image follows phase B of this one without a barrier between them
+        // (it reads the stem tile, landed by barrier Y, and writes tile A, free since barrier Y).
+        //     X : tile A complete (stem phase), tile B and the stem tile free  -> DMA of the next image, phase A
+        //     Y : tile B complete, tile A free, the next image landed          -> phase B, then the next image's stem phase
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads(); // this step's image is staged; every wave is done reading tile B (the previous step's phase B)
-        dq.top(tid);
-        const int gvalid = min(G, batch - step * G);
-        if constexpr (STEM) {
-            asm volatile("" : "+s"(sc));     // (the stem's operands are fetched here, every step, not hoisted into registers)
-            stem_phase(sc);                  // stem: image -> tile A
-            __syncthreads();                 // tile A is complete; the stem tile is free
-            if (dq.nxt < nsteps) stage(dq.nxt); // lands during phases A and B
+        __syncthreads();
+        if (dq.step < nsteps) stem_phase(sc);
+        for (; dq.step < nsteps; dq.advance(tid)) {
+            const int step = dq.step;
+            __syncthreads(); // X
+            dq.top(tid);
+            if (dq.nxt < nsteps) stage(dq.nxt);
+            if (Q::ACT_A == NWAVE || wave < Q::ACT_A) pa.template run<GB>(lds, lds + OFF_B, 1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads(); // Y
+            if (Q::ACT_B == NWAVE || wave < Q::ACT_B)
+                pb.template run<void>(lds + OFF_B, (uint8_t *)out + (size_t)step * GB::OPIX * GB::N, 1);
+            asm volatile("" : "+s"(sc)); // (the stem's operands are fetched here, every step, not hoisted into registers)
+            if (dq.nxt < nsteps) stem_phase(sc);
         }
-        if (Q::ACT_A == NWAVE || wave < Q::ACT_A) pa.template run<GB>(lds, lds + OFF_B, gvalid); // pair A: tile A -> tile B
-        __syncthreads(); // tile B is complete; tile A is free
-        if constexpr (!STEM)
-            if (dq.nxt < nsteps) stage(dq.nxt);                           // lands during phase B
-        if (Q::ACT_B == NWAVE || wave < Q::ACT_B)
-            pb.template run<void>(lds + OFF_B, (uint8_t *)out + (size_t)step * G * GB::OPIX * GB::N, gvalid); // pair B: tile B -> HBM
+    } else {
+        for (; dq.step < nsteps; dq.advance(tid)) {
+            const int step = dq.step;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads(); // this step's image is staged; every wave is done reading tile B (the previous step's phase B)
+            dq.top(tid);
+            const int gvalid = min(G, batch - step * G);
+            if (Q::ACT_A == NWAVE || wave < Q::ACT_A) pa.template run<GB>(lds, lds + OFF_B, gvalid); // pair A: tile A -> tile B
+            __syncthreads(); // tile B is complete; tile A is free
+            if (dq.nxt < nsteps) stage(dq.nxt);                               // lands during phase B
+            if (Q::ACT_B == NWAVE || wave < Q::ACT_B)
+                pb.template run<void>(lds + OFF_B, (uint8_t *)out + (size_t)step * G * GB::OPIX * GB::N, gvalid); // pair B: tile B -> HBM
+        }
     }
     dq.finish(tid);
 }
