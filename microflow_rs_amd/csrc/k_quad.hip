@@ -242,9 +242,6 @@ struct Quad57 {
     static constexpr int G = 1, NTHR = 256, WPE = 2, ACT_A = 4, ACT_B = 3;
     static constexpr const char *name = "quad_rr<24,24,32,1,32|24,24,32,2,64>";
 };
-struct Quad57x : Quad57 { // (tuning alternative: the 3-wave workgroup)
-    static constexpr int NTHR = 192, ACT_A = 3, ACT_B = 3;
-};
 
 
 
@@ -407,10 +404,6 @@ static int quad_mask() { // MF_QUADS: bit 0 = ops 1..4, bit 1 = ops 5..8, bit 2 
     static const int m = [] { const char *e = getenv("MF_QUADS"); return e ? atoi(e) : 7; }();
     return m;
 }
-static int quad_alt() { // MF_QUAD_ALT: bit 1 = Quad57x (tuning)
-    static const int m = [] { const char *e = getenv("MF_QUAD_ALT"); return e ? atoi(e) : 0; }();
-    return m;
-}
 const char *quad_name(int H, int W, int C, int S, int N, int H2, int W2, int C2, int S2, int N2) {
     if ((quad_mask() & 1) && quad_matches<Quad13>(H, W, C, S, N, H2, W2, C2, S2, N2)) return Quad13::name;
     if ((quad_mask() & 2) && quad_matches<Quad57>(H, W, C, S, N, H2, W2, C2, S2, N2)) return Quad57::name;
@@ -444,7 +437,6 @@ bool launch_quad(int H, int W, int C, int S, int N, int H2, int W2, int C2, int 
         MF_QUAD_GO(Quad13);
     }
     if (quad_matches<Quad57>(H, W, C, S, N, H2, W2, C2, S2, N2)) {
-        if (quad_alt() & 2) MF_QUAD_GO(Quad57x);
         MF_QUAD_GO(Quad57);
     }
 #undef MF_QUAD_GO
