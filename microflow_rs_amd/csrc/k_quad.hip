@@ -28,6 +28,13 @@
 #include <algorithm>
 #include <type_traits>
 
+// Wave priority 1 while a wave issues the MFMAs of its depthwise taps: the matrix pipe is fed ahead of the other waves'
+// requantisation VALU work, which fills the issue slots behind it (0: off).  Same box, back to back: ops 0..4 1.247 -> 1.226 ms,
+// ops 5..8 0.710 -> 0.700; priority on the pointwise MFMAs as well, or 2 / 3 instead of 1: no better.
+#ifndef MF_QUAD_PRIO
+#define MF_QUAD_PRIO 1
+#endif
+
 namespace mf {
 namespace k {
 
@@ -171,6 +178,9 @@ struct RrPhase {
             for (int u = 0; u < UB; ++u)
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) acc[u][q] = v4i{dK[q].x, dK[q].y, dK[q].z, dK[q].w};
+#if MF_QUAD_PRIO
+            __builtin_amdgcn_s_setprio(MF_QUAD_PRIO);
+#endif
 #pragma unroll
             for (int ty = 0; ty < 3; ++ty)
 #pragma unroll
@@ -178,6 +188,9 @@ struct RrPhase {
 #pragma unroll
                     for (int q = 0; q < NQ; ++q)
                         acc[u][q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Adw[q][ty], bq[u][q][ty], acc[u][q], 0, 0, 0);
+#if MF_QUAD_PRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
             if (t0 + UB < NU) {
 #pragma unroll
                 for (int u = 0; u < UB; ++u)
