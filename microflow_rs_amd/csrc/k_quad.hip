@@ -34,6 +34,12 @@
 #ifndef MF_QUAD_PRIO
 #define MF_QUAD_PRIO 1
 #endif
+#ifndef MF_Q13_X2A
+#define MF_Q13_X2A 0 // (tuning: RrPhase X2 of ops 1..4's two pairs and of ops 5..8's)
+#define MF_Q13_X2B 0
+#define MF_Q57_X2A 3
+#define MF_Q57_X2B 3
+#endif
 
 namespace mf {
 namespace k {
@@ -66,7 +72,10 @@ template <> struct DstTile<void> {
 // one pair of a quad: the per-lane constants (init) and the unit loop (run)
 // NACT: the waves of the workgroup the unit grid is dealt over (waves >= NACT sit the phase out: a 3 x 3 unit grid does
 // not divide over 4 waves, and 4 waves per workgroup is what fills the four SIMDs evenly)
-template <typename Ge, int G, int NACT, int MG, uint32_t XR4>
+// X2: requantise two dwords at a time with the interleaved packs of k_common.hpp (epi_pack4x2): bit 0 the two depthwise
+// dwords of a 32-channel pair, bit 1 the pointwise tiles in pairs.  Fewer hazard no-ops and two independent chains per wave:
+// ops 5..8 0.698 -> 0.654 ms; ops 0..4 (168 VGPRs with it: spills) 1.218 -> 1.260, so a quad chooses per pair.
+template <typename Ge, int G, int NACT, int MG, uint32_t XR4, int X2 = 0>
 struct RrPhase {
     static constexpr int NWAVE = NACT;
     static constexpr int UG = G / Ge::CG, UY = Ge::OH / Ge::CY, UX = Ge::OWC / Ge::CX;
@@ -203,16 +212,31 @@ struct RrPhase {
 #pragma unroll
             for (int u = 0; u < UB; ++u) {
                 uint32_t d[2] = {0u, 0u};
+                if constexpr (NQ == 2 && (X2 & 1) != 0) {
+                    requant_pack4x2<MG, XR4>(acc[u][0], dA[0], dS[0], acc[u][1], dA[1], dS[1], dlo, dhi, d[0], d[1]);
+                } else {
 #pragma unroll
-                for (int q = 0; q < NQ; ++q)
-                    d[q] = requant_pack4<MG, XR4>(acc[u][q][0], acc[u][q][1], acc[u][q][2], acc[u][q][3], dA[q], dS[q], dlo, dhi);
+                    for (int q = 0; q < NQ; ++q)
+                        d[q] = requant_pack4<MG, XR4>(acc[u][q][0], acc[u][q][1], acc[u][q][2], acc[u][q][3], dA[q], dS[q], dlo, dhi);
+                }
                 const long bop = (long)(((unsigned long)d[1] << 32) | (unsigned long)d[0]);
                 uint32_t packed[NT];
+                if constexpr ((X2 & 2) != 0) {
+                    static_assert((X2 & 2) == 0 || NT % 2 == 0, "pointwise tiles in pairs");
 #pragma unroll
-                for (int m = 0; m < NT; ++m) {
-                    v4i pa = {cK[m].x, cK[m].y, cK[m].z, cK[m].w};
-                    pa = __builtin_amdgcn_mfma_i32_16x16x32_i8(Apw[m], bop, pa, 0, 0, 0);
-                    packed[m] = requant_pack4<MG, XR4>(pa[0], pa[1], pa[2], pa[3], cA[m], cS[m], plo, phi);
+                    for (int m = 0; m < NT; m += 2) { // two tiles at a time
+                        v4i pa = {cK[m].x, cK[m].y, cK[m].z, cK[m].w}, pb2 = {cK[m + 1].x, cK[m + 1].y, cK[m + 1].z, cK[m + 1].w};
+                        pa = __builtin_amdgcn_mfma_i32_16x16x32_i8(Apw[m], bop, pa, 0, 0, 0);
+                        pb2 = __builtin_amdgcn_mfma_i32_16x16x32_i8(Apw[m + 1], bop, pb2, 0, 0, 0);
+                        requant_pack4x2<MG, XR4>(pa, cA[m], cS[m], pb2, cA[m + 1], cS[m + 1], plo, phi, packed[m], packed[m + 1]);
+                    }
+                } else {
+#pragma unroll
+                    for (int m = 0; m < NT; ++m) {
+                        v4i pa = {cK[m].x, cK[m].y, cK[m].z, cK[m].w};
+                        pa = __builtin_amdgcn_mfma_i32_16x16x32_i8(Apw[m], bop, pa, 0, 0, 0);
+                        packed[m] = requant_pack4<MG, XR4>(pa[0], pa[1], pa[2], pa[3], cA[m], cS[m], plo, phi);
+                    }
                 }
                 int ug = 0, uy = 0, ux = 0;
                 coords(t0 + u, ug, uy, ux);
@@ -242,7 +266,7 @@ struct RrPhase {
 struct Quad13 {
     using A = RrGeom<48, 48, 8, 1, 16, 1, 4, 0, 32, 0x000>;
     using B = RrGeom<48, 48, 16, 2, 32, 1, 2, 0, 32, 0x000>;
-    static constexpr int G = 1, NTHR = 768, WPE = 3, ACT_A = 12, ACT_B = 12;
+    static constexpr int G = 1, NTHR = 768, WPE = 3, ACT_A = 12, ACT_B = 12, X2A = MF_Q13_X2A, X2B = MF_Q13_X2B;
     static constexpr const char *name = "quad_rr<48,48,8,1,16|48,48,16,2,32>";
 };
 // (measured alternatives for ops 1..4: two 6-wave workgroups per CU -- 1.51 ms, the waves land 4/4/2/2 on the SIMDs; two
@@ -252,7 +276,7 @@ struct Quad57 {
     using B = RrGeom<24, 24, 32, 2, 64, 1, 4, 0, 32, 0x002>;
     // 4 waves = one per SIMD, two workgroups per CU (248 VGPRs); pair B's 3 x 3 unit grid runs on three of them.
     // (3-wave workgroups load the SIMDs 2/2/1/1 and every barrier waits for the doubled-up ones: 0.85 ms vs 0.71)
-    static constexpr int G = 1, NTHR = 256, WPE = 2, ACT_A = 4, ACT_B = 3;
+    static constexpr int G = 1, NTHR = 256, WPE = 2, ACT_A = 4, ACT_B = 3, X2A = MF_Q57_X2A, X2B = MF_Q57_X2B;
     static constexpr const char *name = "quad_rr<24,24,32,1,32|24,24,32,2,64>";
 };
 
@@ -286,8 +310,8 @@ __global__ __launch_bounds__(Q::NTHR, Q::WPE) void quad_rr(const int8_t *__restr
     // tile A's halo holds pair A's input zero point, tile B's pair B's (= the zero point of pair A's output tensor)
     for (int i = tid; i < OFF_B / 16; i += NTHR) ((uint4 *)lds)[i] = make_uint4(p.a.dw.izp4, p.a.dw.izp4, p.a.dw.izp4, p.a.dw.izp4);
     for (int i = tid; i < (BUF_B + 512) / 16; i += NTHR) ((uint4 *)(lds + OFF_B))[i] = make_uint4(p.b.dw.izp4, p.b.dw.izp4, p.b.dw.izp4, p.b.dw.izp4);
-    RrPhase<GA, G, Q::ACT_A, MG, XR4> pa;
-    RrPhase<GB, G, Q::ACT_B, MG, XR4> pb;
+    RrPhase<GA, G, Q::ACT_A, MG, XR4, Q::X2A> pa;
+    RrPhase<GB, G, Q::ACT_B, MG, XR4, Q::X2B> pb;
     pa.template init<GB>(p.a, lane, wave);
     pb.template init<void>(p.b, lane, wave);
     __syncthreads(); // halo fills complete before any DMA lands
