@@ -26,7 +26,14 @@ def test_bench_two_ranks_share_one_device(O):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]          # rank 0 prints ONE line, the other rank none
+    assert r.stdout.strip().splitlines()[-1] == lines[0]   # ... and it is the LAST thing on stdout
     rec = json.loads(lines[0])
+    from tests.test_bench_line import check_compact
+    rec.setdefault("cpu_baseline", None)
+    check_compact(rec, lines[0])                        # < 8 KB, the contract's keys, roofline block
+    assert len(lines[0]) < 4096
+    details = json.load(open(os.path.join(ROOT, rec["details"])))
+    assert details["value"] == rec["value"] and len(details["kernels"]) >= 1
     assert rec["n_gpus"] == world and rec["steps"] == 3 and rec["warmup"] == 1
     assert rec["config"]["per_gpu_batch"] == per_gpu and rec["config"]["global_batch"] == world * per_gpu
     assert rec["config"]["shards"] == [[0, per_gpu], [per_gpu, per_gpu]] and rec["config"]["backend"] == "gloo"
