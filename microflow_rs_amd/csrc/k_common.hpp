@@ -447,14 +447,20 @@ struct DynSteps {
         }
     }
     __device__ __forceinline__ void finish(int tid) {
-        if (MF_DYNQ && K != 0 && tid == 0 && atomicAdd(ctr + HEADS * PITCH, 1) == (int)gridDim.x - 1) {
+        if (MF_DYNQ && K != 0 && tid == 0) {
+            // this workgroup's last (speculative, unconsumed) draw must have landed before its arrival is counted: otherwise it
+            // could hit the counter after the last workgroup's reset and the next launch on this set would skip a chunk
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            if (__hip_atomic_fetch_add(ctr + HEADS * PITCH, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1) {
 #pragma unroll
-            for (int h = 0; h <= HEADS; ++h) ctr[h * PITCH] = 0;
+                for (int h = 0; h <= HEADS; ++h) ctr[h * PITCH] = 0;
+            }
         }
     }
 };
 // Queue configuration of a launch: `est_us` = the launch's expected duration (its bytes over the rates the kernels reach).
 unsigned long dq_next_launch(); // (k_generic.hip) one process-wide counter of queue launches, for MF_DQ_CFGS
+unsigned long dq_next_slot();   // (k_generic.hip) process-wide launch counter behind dq_slot below
 static inline int dq_config(int nsteps, int grid, double est_us) {
     // tuning: MF_DQ_CFG = K | heads << 8 for every launch (0x100 = static striding).  With MF_DQ_TUNE set it is re-read per
     // launch, and MF_DQ_CFGS = "c0,c1,..." gives the k-th queue launch of the process configuration c[k % n] (0 = automatic)
@@ -482,6 +488,10 @@ static inline int dq_config(int nsteps, int grid, double est_us) {
     static const bool verbose = getenv("MF_DQ_VERBOSE") != nullptr;
     if (verbose) fprintf(stderr, "[microflow_amd] step queue: %d steps on %d workgroups, est %.0f us -> cfg 0x%x\n", nsteps, grid, est_us, cfg);
     return cfg;
+}
+// the counter set of this launch: the operator's ring (kernels.hpp DYNQ_RING sets of DynSteps::INTS zeroed ints), next slot
+static inline int *dq_slot(int *ring) {
+    return ring ? ring + (size_t)(dq_next_slot() % (unsigned long)DYNQ_RING) * DynSteps::INTS : nullptr;
 }
 // expected duration of a depthwise / pair launch from its HBM bytes and requantised bytes (4.5 and 4.0 TB/s: what the kernels reach)
 static inline double dq_est_us(double hbm_bytes, double requant_bytes) {

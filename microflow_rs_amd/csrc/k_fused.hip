@@ -296,6 +296,7 @@ static void launch_dwpw_t(const int8_t *in, int8_t *out, const DwPwArgs &a, int 
     const int grid = nsteps < 256 * per_cu ? nsteps : 256 * per_cu;
     DwPwArgs b = a;
     b.dw.qcfg = dq_config(nsteps, grid, dq_est_us((double)batch * (H * W * C + OH * OW * N), (double)batch * OH * OW * (C + N)));
+    b.dw.queue = dq_slot(b.dw.queue);
     hipLaunchKernelGGL((dwpw3x3<H, W, C, S, N, G, NTHR, (DB != 0), MG, XR4>), dim3(grid), dim3(NTHR), lds, s, in, out, b, batch);
 }
 int dwpw_impl();

@@ -482,6 +482,10 @@ unsigned long dq_next_launch() {
     static std::atomic<unsigned long> n{0};
     return n.fetch_add(1);
 }
+unsigned long dq_next_slot() {
+    static std::atomic<unsigned long> n{0};
+    return n.fetch_add(1, std::memory_order_relaxed);
+}
 unsigned long long selftest_rounding(int mode, bool u8, float lo, float hi, hipStream_t s) {
     return run_selftest(s, [&](unsigned long long *d) {
         const dim3 g(256 * 16), b(256);

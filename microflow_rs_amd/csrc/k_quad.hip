@@ -429,6 +429,7 @@ static void launch_quad_t(const int8_t *in, int8_t *out, const QuadArgs &a, int 
     const double hbm = (double)batch * ((STEM ? 4 * GA::H * GA::W : GA::H * GA::W * GA::C) + GB::OPIX * GB::N);
     const double rq = (double)batch * ((STEM ? GA::H * GA::W * GA::C : 0) + GA::OPIX * (GA::C + GA::N) + GB::OPIX * (GB::C + GB::N));
     b.a.dw.qcfg = dq_config(nsteps, grid, dq_est_us(hbm, rq));
+    b.a.dw.queue = dq_slot(b.a.dw.queue);
     hipLaunchKernelGGL((quad_rr<Q, STEM, MG, XR4>), dim3(grid), dim3(Q::NTHR), lds, s, in, out, b, batch);
 }
 template <typename Q> static bool quad_matches(int H, int W, int C, int S, int N, int H2, int W2, int C2, int S2, int N2) {

@@ -670,6 +670,7 @@ static void launch_dw_rt_t(const int8_t *in, int8_t *out, const DwRtArgs &a, int
     DwRtArgs b = a;
     const double opix = (double)a.OH * a.OW;
     b.dw.qcfg = dq_config(nsteps, grid, dq_est_us((double)batch * ((double)a.H * a.W * a.C + opix * a.C), (double)batch * opix * a.C));
+    b.dw.queue = dq_slot(b.dw.queue);
     hipLaunchKernelGGL((dw3x3_rt<S, R, WZ, MG, XR4>), dim3(grid), dim3(a.NTHR), lds, s, in, out, b, batch);
 }
 void launch_dw_rt(const int8_t *in, int8_t *out, const DwRtArgs &a, int S, bool wz, int batch, hipStream_t s) {
@@ -703,12 +704,9 @@ bool pw_rt_supported(int K, int N, bool wz) {
 template <bool WZ, int MG, uint32_t XR4>
 static void launch_pw_rt_t(const int8_t *in, int8_t *out, const PwRtArgs &a, long long npix, hipStream_t s) {
     const int lds = pw_rt_lds_bytes(a.K, a.N, WZ);
-    (void)hipFuncSetAttribute((const void *)pw_rt_lds<WZ, MG, XR4>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-    int per_cu = 1;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pw_rt_lds<WZ, MG, XR4>, 256, (size_t)lds) != hipSuccess || per_cu < 1) {
-        (void)hipGetLastError();
-        per_cu = 1;
-    }
+    // occupancy per (device, LDS size in KiB): asked of the runtime once, not per launch (and never during a graph capture)
+    static LaunchState st[97];
+    const int per_cu = prepared(st[(lds + 1023) / 1024], pw_rt_lds<WZ, MG, XR4>, 256, lds);
     const long long nchunks = (npix + 15) / 16;
     const long long want = (nchunks + 3) / 4;
     const int cap = 256 * per_cu;                    // persistent: the weight image is copied to LDS once per workgroup

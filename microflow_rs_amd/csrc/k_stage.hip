@@ -318,6 +318,7 @@ bool launch_stage(int H, int W, int C, int npairs, const int8_t *in, int8_t *out
     StageArgs a = a_in;
     a.nrep = npairs;
     a.qcfg = dq_config((batch + G - 1) / G, 512, dq_est_us((double)batch * 2 * H * W * C, (double)batch * 2 * npairs * H * W * C));
+    a.queue = dq_slot(a.queue);
     constexpr int lds = MF_STAGE_LDS_KB * 1024;
     const int nsteps = (batch + G - 1) / G;
     int per_cu = 0, grid = 0;

@@ -71,6 +71,11 @@ struct SoftmaxArgs {
     int xr;
 };
 constexpr int DYNQ_INTS = 8 * 32 + 32; // = DynSteps::INTS (k_common.hpp): the counters of one dynamic step queue
+// An operator owns DYNQ_RING counter sets and every launch takes the next one (dq_slot, k_common.hpp): two launches of one
+// handle that are in flight together (two streams) then draw from different counters.  A launch leaves its set zeroed, so a
+// set is reusable as soon as the launch that used it has finished; a handle may therefore have up to DYNQ_RING launches
+// in flight (include/microflow_amd.h states the limit).
+constexpr int DYNQ_RING = 32;
 struct DwFastArgs {
     const int8_t *w;    // [3][3][C]
     const void *wmm;    // matrix-pipe form of w (k_fused_mm.hip): [C/16 or 1][3 filter rows][64 lanes] x 16 bytes

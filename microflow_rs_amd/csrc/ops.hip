@@ -379,7 +379,7 @@ OpImpl *op_create(int device, const OpSpec &spec) {
         op->d_S.upload(S.data(), S.size() * 4);
         op->d_Kc.upload(Kc.data(), Kc.size() * 4);
         {
-            const std::vector<int> zeros((size_t)k::DYNQ_INTS, 0);
+            const std::vector<int> zeros((size_t)k::DYNQ_INTS * k::DYNQ_RING, 0);
             op->d_queue.upload(zeros.data(), zeros.size() * sizeof(int));
         }
         k::ConvArgs &a = op->conv;

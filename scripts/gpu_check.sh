@@ -27,13 +27,15 @@ if [[ $STEPS == all || $STEPS == *bench* ]]; then
   python - <<'PY'
 import json
 try:
-    r = json.loads(open("gpurun_out/bench.json").read().strip().splitlines()[-1])
-    print("value", r["value"], r["unit"], "ms/step", r["ms_per_step"], "roofline", r["roofline"]); print("whole_step", r["whole_step"]); print("ceiling", r["requant_ceiling"]); print("fc4096", {k: v for k, v in r.get("fc4096", {}).items() if k in ("value", "crosscheck", "roofline")})
-    print("fused", r.get("fused_dwpw"))
+    line = open("gpurun_out/bench.json").read().strip().splitlines()[-1]
+    c = json.loads(line)
+    print("compact line: %d bytes; keys %s" % (len(line), sorted(c)))
+    r = json.load(open("gpurun_out/bench_details.json"))
+    print("value", r["value"], r["unit"], "ms/step", r["ms_per_step"], "roofline", c["roofline"]); print("whole_step", c["whole_step"]); print("ceiling", r["requant_ceiling"]); print("fc4096", c.get("fc4096"), c.get("fc4096_wzp")); print("speech", c.get("speech"))
     print("layerwise ms", r["layerwise"]["ms_per_step"], "depthwise", r["depthwise"], "conv", r["conv_2d"])
     for k in r["kernels"]:
-        print("%2d %-18s %-28s %8.4f ms %8.1f GB/s %.3f" % (k["op"], k["kind"], k["kernel"], k["ms"], k["GBps"], k["frac"]))
-    print("cpu", r["cpu_baseline"]); print("parity", r["parity"])
+        print("%2d %-18s %-28s %8.4f ms %8.1f GB/s hbm %.3f valu %.3f" % (k["op"], k["kind"], k["kernel"], k["ms"], k["GBps"], k["frac"], k["valu_frac"]))
+    print("cpu", c["cpu_baseline"]); print("parity", c["parity"])
 except Exception as e:
     print("bench parse failed", e)
 PY

@@ -45,4 +45,9 @@ def model_path(name):
 
 # scripts/switch_matrix.sh runs the parity tests under every A/B switch of the library (MF_NO_QUAD=1, MF_NO_TABLE=1, ...).
 # The assertions about WHICH kernel runs describe the default routing only and are skipped then; every parity assertion stays.
-ROUTING_SWITCHED = sorted(k for k in os.environ if k.startswith("MF_"))
+# Only the switches that change which kernel runs count: a stray debug variable (MF_VERBOSE, MF_DEBUG_EPI, MF_DQ_VERBOSE, ...)
+# must not switch the routing assertions off.
+_NOT_ROUTING = ("MF_VERBOSE", "MF_DEBUG", "MF_DQ_VERBOSE", "MF_STAGE_DIAG", "MF_TAIL3_DIAG")
+ROUTING_SWITCHED = sorted(k for k in os.environ if k.startswith("MF_") and not k.startswith(_NOT_ROUTING))
+if ROUTING_SWITCHED:
+    print("tests/conftest.py: kernel-routing assertions are SKIPPED because of %s" % ", ".join(ROUTING_SWITCHED), file=sys.stderr)
