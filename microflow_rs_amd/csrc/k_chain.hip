@@ -1,0 +1,612 @@
+// k_chain.hip -- RUN-TIME-GEOMETRY fused chains: 1 .. CHAIN_MAX consecutive DepthwiseConv2D 3x3 + Conv2D 1x1 pairs of ANY
+// height / width (C % 16 == 0, N % 16 == 0) in ONE launch, every tensor between the chain's input and output in LDS.
+//
+// (src/ops/depthwise_conv_2d.rs:28-105 + src/ops/conv_2d.rs:28-108.  The reference is generic over every dimension
+// (const generics, depthwise_conv_2d.rs:28-49, conv_2d.rs:28-49); the fused kernels of k_fused_mm.hip / k_quad.hip /
+// k_stage.hip are instantiated for person_detect's rows only.  This kernel is their run-time-geometry form: the same
+// arithmetic -- depthwise taps as three v_mfma_i32_16x16x64_i8 against block-diagonal weights, the reference's
+// requantisation of the intermediate tensor, the 1x1 convolution as an MFMA product over the pixel matrix, the reference's
+// requantisation again -- with every extent a kernel argument.  Each operator's result is the reference's int8 tensor; it
+// just never leaves the CU.)
+//
+//   step      : G whole images per workgroup (8 waves); the dynamic step queue of k_common.hpp deals the steps.
+//   staging   : the first pair's input rows by LDS-DMA into a halo'd tile (halo = that pair's input zero point, filled once);
+//               the next step's images are issued as soon as the first depthwise phase has read the tile.
+//   depthwise : unit = 16 MFMA columns (CG images x CY rows x CX columns, chosen by the host as divisors of the tensor)
+//               x one 16-channel group; a lane's operand is ONE ds_read_b128 per filter row; the 16-byte group index inside
+//               a pixel is XOR-swizzled with bits of the tile column (on the DMA source, on the tap reads and on the
+//               pointwise writes of the previous pair), which makes 16 consecutive columns conflict-free for every C.
+//               The unit list (channel group major) is cut into 8 contiguous ranges, one per wave; the walk is scalar.
+//               Result -> requantise -> planar MID [16-channel group][pixel][16 B].
+//   pointwise : item = 16 pixels x one block of TB <= 4 output tiles; B operand = KS ds_read_b128 of MID planes; operand A in
+//               registers (loaded once for a single pair, per phase for a chain: L2 hits); a lane ends with 4 TB consecutive
+//               output bytes of its pixel (row permutation of build_pw_rt_reg_weights) -> one store, to HBM or -- through a
+//               pixel -> tile-offset table built once per launch -- into the next pair's halo'd, swizzled tile.
+//   barriers  : depthwise | pointwise | next pair ...: two per pair.
+#include "k_common.hpp"
+
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+namespace mf {
+namespace k {
+
+namespace {
+struct CDwW {        // depthwise operands of one 16-channel group
+    v4i A[3];
+    float4 a, s;
+    int4 k;
+};
+// output tiles per wave block: 4 (a lane ends with 16 consecutive bytes) while one k step's operands fit the register budget of four
+// waves per SIMD, 2 beyond
+template <int KSC> constexpr int chain_tbm() { return KSC == 1 ? 4 : 2; }
+template <int KSC> struct CPwW { // pointwise operands of one block of output tiles
+    static constexpr int TBM = chain_tbm<KSC>();
+    v4i A[TBM][KSC];
+    float4 a[TBM], s[TBM];
+    int4 k[TBM];
+};
+} // namespace
+
+// W16: 16 waves per workgroup (plans whose LDS admits one workgroup per CU: four waves per SIMD all the same)
+template <int KSC, bool W16, int MG, uint32_t XR4>
+__global__ __launch_bounds__(W16 ? 1024 : 512, 4) void chain_rt(const int8_t *__restrict__ in, int8_t *__restrict__ out, ChainArgs p, int batch) {
+    constexpr int NTHR = W16 ? 1024 : 512, NWAVE = NTHR / 64, TBM = chain_tbm<KSC>();
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    typedef __attribute__((address_space(4))) const ChainPair c_pair;
+    c_pair *pairs = (c_pair *)(uintptr_t)p.pairs;
+    typedef __attribute__((address_space(1))) const v4i g_v4i;
+    auto ld16 = [](const void *base, uint32_t off) { return *(g_v4i *)((uintptr_t)base + off); };
+    auto ldf4 = [&](const void *base, uint32_t off) {
+        const v4i v = ld16(base, off);
+        return make_float4(__int_as_float(v[0]), __int_as_float(v[1]), __int_as_float(v[2]), __int_as_float(v[3]));
+    };
+    auto ldi4 = [&](const void *base, uint32_t off) {
+        const v4i v = ld16(base, off);
+        return magic4<MG>(make_int4(v[0], v[1], v[2], v[3]));
+    };
+    const int G = p.G, NP = p.npairs;
+    const int col = lane & 15, g = lane >> 4;
+
+    DynSteps dq;
+    dq.init(lds + p.q_off, p.queue, tid, p.qcfg);
+    // halo fills: every tile region holds the input zero point of the depthwise that reads it
+#pragma unroll
+    for (int f = 0; f < CHAIN_MAX; ++f) { // (constant indices: a run-time index into the argument struct would move it to scratch)
+        if (f < p.nfill) {
+            const uint32_t z = p.fill_izp4[f];
+            uint4 *dst = (uint4 *)(lds + p.fill_off[f]);
+            for (int i = tid; i < p.fill_bytes[f] / 16; i += NTHR) dst[i] = make_uint4(z, z, z, z);
+        }
+    }
+    // pixel -> next-tile offset tables of the pairs whose output stays in LDS: offset of the pixel's 16-byte group 0 (24 bits)
+    // | the group-index XOR of its tile column (8 bits)
+    for (int pi = 0; pi + 1 < NP; ++pi) {
+        c_pair &cp = pairs[pi];
+        if (cp.otab_off < 0) continue;
+        uint32_t *tab = (uint32_t *)(lds + cp.otab_off);
+        const int OW = cp.OW, OPIX = cp.plimit_img;
+        for (int pix = tid; pix < cp.P; pix += NTHR) {
+            const int img = pix / OPIX, r = pix - img * OPIX, y = r / OW, x = r - y * OW;
+            const uint32_t off = (uint32_t)(img * cp.dTILE + (y + 1) * cp.dROW + (x + 1) * cp.dC);
+            const uint32_t sw = (uint32_t)(((x + 1) >> cp.dswz_sh) & cp.dswz_mask);
+            tab[pix] = off | (sw << 24);
+        }
+    }
+
+    auto load_dw = [&](c_pair &cp, int q) {
+        CDwW w;
+#pragma unroll
+        for (int ty = 0; ty < 3; ++ty) w.A[ty] = ld16(cp.dw_wmm, (uint32_t)(((q * 3 + ty) * 64 + lane) * 16));
+        const uint32_t co = (uint32_t)((4 * q + g) * 16);
+        w.a = ldf4(cp.dwA, co), w.s = ldf4(cp.dwS, co), w.k = ldi4(cp.dwK, co);
+        return w;
+    };
+    auto load_pw = [&](c_pair &cp) {
+        CPwW<KSC> w;
+        const int TB = cp.TB, KS = cp.KS, blk = wave & (cp.NBLK - 1);
+#pragma unroll
+        for (int t = 0; t < TBM; ++t) {
+#pragma unroll
+            for (int ks = 0; ks < KSC; ++ks) {
+                w.A[t][ks] = v4i{0, 0, 0, 0};
+                if (t < TB && ks < KS) w.A[t][ks] = ld16(cp.pw_w, (uint32_t)((((blk * TB + t) * KS + ks) * 64 + lane) * 16));
+            }
+            const uint32_t co = (uint32_t)((blk * 16 * TB + g * 4 * TB + 4 * t) * 4);
+            if (t < TB) w.a[t] = ldf4(cp.pwA, co), w.s[t] = ldf4(cp.pwS, co), w.k[t] = ldi4(cp.pwK, co);
+            else w.a[t] = w.s[t] = make_float4(0.f, 0.f, 0.f, 0.f), w.k[t] = make_int4(0, 0, 0, 0);
+        }
+        return w;
+    };
+
+    // ---- staging of the chain's input (pair 0's tile) ----
+    auto stage = [&](int st, int buf) {
+        c_pair &cp = pairs[0];
+        const int H = cp.H, ROWB = cp.W * cp.C, ROWCH = ROWB >> 4, IMG = H * ROWB;
+        const int lgNQ = cp.lgNQ, nqm = cp.NQ - 1, sh = cp.swz_sh, mask = cp.swz_mask;
+        for (int gi = 0; gi < G; ++gi) {
+            const long img = (long)st * G + gi;
+            if (img >= batch) break;
+            for (int y = wave; y < H; y += NWAVE) {
+                const int8_t *src = in + img * IMG + (long)y * ROWB;
+                uint8_t *dst = lds + cp.tile_off + buf * p.dbuf_stride + gi * cp.TILE + (y + 1) * cp.ROW + cp.C;
+                for (int o = 0; o < ROWCH; o += 64) {
+                    const int i = o + lane; // 16-byte group i of the row lands at LDS group i; it must hold source group (x, c ^ swz(x))
+                    int sidx = i;
+                    if (mask != 0) {
+                        const int x = i >> lgNQ, c = i & nqm;
+                        sidx = (x << lgNQ) + (c ^ (((x + 1) >> sh) & mask));
+                    }
+                    if (i < ROWCH) dma16(src + sidx * 16, dst + o * 16);
+                }
+            }
+        }
+    };
+
+    // ---- depthwise phase of one pair: tile -> MID ----
+    // A wave's units are a contiguous range of the list (channel group q, column ux, j = (image group, row)): it is walked in
+    // segments of constant (q, ux) -- inside one, the lane's operand address is a per-segment VGPR plus a scalar offset from
+    // the host's table, and the unit loop is one branch-free block.
+    auto dw_phase = [&](c_pair &cp, CDwW &wd, int tile_base) { // wd: the operands of this wave's first channel group, already on their way
+        const int S = cp.S, C = cp.C, ROW = cp.ROW, sh = cp.swz_sh, mask = cp.swz_mask;
+        const int lgCX = cp.lgCX, lgCY = cp.lgCY, CXv = 1 << lgCX, CYv = 1 << lgCY;
+        const int gg = g < 2 ? g : 2; // tap column of this lane group (g == 3 meets zero weights: any readable bytes will do)
+        const int cx = col & (CXv - 1), cy = (col >> lgCX) & (CYv - 1), cg = col >> (lgCX + lgCY);
+        const int xin0 = cx * S + gg;
+        const int tb0 = tile_base + cg * cp.TILE + cy * S * ROW + xin0 * C;
+        const int mb0 = p.mid_off + (((cg * cp.OH + cy) * cp.OW + cx) << 4) + 4 * g;
+        const int UGY = cp.UG * cp.UY, UX = cp.UX;
+        const int T_UX = CXv * S * C, XSTEP = CXv * S, M_UX = CXv * 16, PLANE = cp.PLANE;
+        typedef int i32x2 __attribute__((ext_vector_type(2)));
+        typedef __attribute__((address_space(4))) const i32x2 c_int2;
+        c_int2 *rt = (c_int2 *)(uintptr_t)cp.rtab;
+        int q = cp.ustart[wave][0], ux = cp.ustart[wave][1], j = cp.ustart[wave][2];
+        int n = cp.ucount[wave];
+        const float lo = cp.dw_lo, hi = cp.dw_hi;
+        while (n > 0) {
+            const int seg = min(n, UGY - j);
+            const int xin = xin0 + ux * XSTEP;
+            const int a_seg = tb0 + ux * T_UX + ((q ^ ((xin >> sh) & mask)) << 4);
+            const int m_seg = mb0 + q * PLANE + ux * M_UX;
+            i32x2 e = rt[j];
+            v4i t0 = *(const v4i *)(lds + a_seg + e[0]), t1 = *(const v4i *)(lds + a_seg + e[0] + ROW), t2 = *(const v4i *)(lds + a_seg + e[0] + 2 * ROW);
+            for (int k = 0; k < seg; ++k) {
+                v4i acc = {wd.k.x, wd.k.y, wd.k.z, wd.k.w};
+                acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(wd.A[0], t0, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(wd.A[1], t1, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(wd.A[2], t2, acc, 0, 0, 0);
+                const int cur_m = e[1];
+                e = rt[j + (k + 1 < seg ? k + 1 : k)]; // the last unit of a segment prefetches itself (no branch)
+                t0 = *(const v4i *)(lds + a_seg + e[0]), t1 = *(const v4i *)(lds + a_seg + e[0] + ROW), t2 = *(const v4i *)(lds + a_seg + e[0] + 2 * ROW);
+                *(uint32_t *)(lds + m_seg + cur_m) = requant_pack4<MG, XR4>(acc[0], acc[1], acc[2], acc[3], wd.a, wd.s, lo, hi);
+            }
+            n -= seg, j = 0;
+            if (++ux == UX) {
+                ux = 0, ++q;
+                if (n > 0) wd = load_dw(cp, q); // (a wave's range crosses into the next channel group)
+            }
+        }
+    };
+
+    // ---- pointwise phase of one pair: MID -> the next pair's tile, or HBM ----
+    // The chunk loop is instantiated per (tiles per block, k steps, destination): with run-time bounds every MFMA sat in its own
+    // basic block behind a branch and the TB independent chains of a chunk could not be interleaved.
+    auto pw_items = [&](c_pair &cp, const CPwW<KSC> &wp, int step, int gvalid, auto tbc, auto ksc, auto dstc) {
+        constexpr int TB = decltype(tbc)::value, KS = decltype(ksc)::value;
+        constexpr bool TO_TILE = decltype(dstc)::value;
+        const int NBLK = cp.NBLK, N = cp.N;
+        const int lgB = NBLK == 1 ? 0 : (NBLK == 2 ? 1 : (NBLK == 4 ? 2 : 3));
+        const int blk = wave & (NBLK - 1), slot = wave >> lgB, SLOTS = NWAVE >> lgB;
+        const int P = cp.P, NCH = cp.NCH, PLANE = cp.PLANE, NQ = cp.NQ;
+        const float lo = cp.pw_lo, hi = cp.pw_hi;
+        int poff[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int pl = 4 * ks + g; // plane = 16-channel group; a k step hanging over K meets zero weights
+            poff[ks] = p.mid_off + (pl < NQ ? pl : NQ - 1) * PLANE;
+        }
+        const int ch0 = blk * 16 * TB + g * 4 * TB;
+        const int plim = gvalid * cp.plimit_img;
+        int8_t *obase = out + (size_t)step * G * cp.plimit_img * N;
+        const int voff0 = col * N + ch0;
+        const uint32_t *otab = (const uint32_t *)(lds + (TO_TILE ? cp.otab_off : 0));
+        const int chq = ch0 >> 4, chw = ch0 & 15, dst = cp.dst_off;
+        constexpr bool PF = KSC <= 2; // operand prefetch of the next chunk while the registers allow it
+        v4i B[KS], Bn[KS];
+        auto fetch = [&](int px, v4i (&d)[KS]) {
+            px = px < P ? px : P - 1;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) d[ks] = *(const v4i *)(lds + poff[ks] + px * 16);
+        };
+        fetch(16 * slot + col, B);
+        for (int c = slot; c < NCH; c += SLOTS) {
+            const int pix = 16 * c + col;
+            if constexpr (PF) fetch(pix + 16 * SLOTS, Bn); // the next chunk's operand (the last chunk re-reads pixel P - 1)
+            else if (c != slot) fetch(pix, B);
+            uint32_t tent = 0;
+            if constexpr (TO_TILE) tent = otab[pix < P ? pix : P - 1];
+            v4i acc[TB];
+#pragma unroll
+            for (int t = 0; t < TB; ++t) acc[t] = v4i{wp.k[t].x, wp.k[t].y, wp.k[t].z, wp.k[t].w};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int t = 0; t < TB; ++t) acc[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wp.A[t][ks], B[ks], acc[t], 0, 0, 0);
+            uint32_t packed[TB];
+            if constexpr (TB % 2 == 0) {
+#pragma unroll
+                for (int t = 0; t < TB; t += 2)
+                    requant_pack4x2<MG, XR4>(acc[t], wp.a[t], wp.s[t], acc[t + 1], wp.a[t + 1], wp.s[t + 1], lo, hi, packed[t], packed[t + 1]);
+            } else {
+#pragma unroll
+                for (int t = 0; t < TB; ++t) packed[t] = requant_pack4<MG, XR4>(acc[t][0], acc[t][1], acc[t][2], acc[t][3], wp.a[t], wp.s[t], lo, hi);
+            }
+            if constexpr (TO_TILE) {
+                if (pix < P) {
+                    uint8_t *d = lds + dst + (tent & 0xffffffu) + ((chq ^ (int)(tent >> 24)) << 4) + chw;
+                    if constexpr (TB == 4) *(uint4 *)d = make_uint4(packed[0], packed[1], packed[2], packed[3]);
+                    else if constexpr (TB == 2) *(uint2 *)d = make_uint2(packed[0], packed[1]);
+                    else *(uint32_t *)d = packed[0];
+                }
+            } else if (pix < plim) {
+                int8_t *o = obase + voff0 + c * 16 * N;
+                if constexpr (TB == 4) st_out(o, make_uint4(packed[0], packed[1], packed[2], packed[3]));
+                else if constexpr (TB == 2) st_out(o, make_uint2(packed[0], packed[1]));
+                else {
+#pragma unroll
+                    for (int t = 0; t < TB; ++t) st_out(o + 4 * t, packed[t]);
+                }
+            }
+            if constexpr (PF) {
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) B[ks] = Bn[ks];
+            }
+        }
+    };
+    auto pw_phase = [&](c_pair &cp, const CPwW<KSC> &wp, int step, int gvalid) {
+        using std::integral_constant;
+        const int TB = cp.TB, KS = cp.KS;
+        const bool to_tile = cp.dst_off >= 0;
+        bool done = false;
+        auto go = [&](auto tbc, auto ksc) {
+            if (done || TB != decltype(tbc)::value || KS != decltype(ksc)::value) return;
+            done = true;
+            if constexpr (decltype(tbc)::value != 3) {
+                if (to_tile) {
+                    pw_items(cp, wp, step, gvalid, tbc, ksc, integral_constant<bool, true>{});
+                    return;
+                }
+            }
+            pw_items(cp, wp, step, gvalid, tbc, ksc, integral_constant<bool, false>{});
+        };
+        auto go_tb = [&](auto ksc) {
+            go(integral_constant<int, 1>{}, ksc);
+            go(integral_constant<int, 2>{}, ksc);
+            if constexpr (TBM == 4) {
+                go(integral_constant<int, 3>{}, ksc);
+                go(integral_constant<int, 4>{}, ksc);
+            }
+        };
+        go_tb(integral_constant<int, 1>{});
+        if constexpr (KSC >= 2) go_tb(integral_constant<int, 2>{});
+        if constexpr (KSC >= 4) {
+            go_tb(integral_constant<int, 3>{});
+            go_tb(integral_constant<int, 4>{});
+        }
+    };
+
+    __syncthreads(); // halo fills and tables complete before any DMA lands
+    const int nsteps = (batch + G - 1) / G;
+    if (dq.step < nsteps) stage(dq.step, 0);
+    // a single pair keeps its operands in registers for the whole launch; a chain fetches them per phase (L2 hits): the
+    // pointwise operands before the depthwise phase in front of them, the next depthwise's (first channel group) before
+    // the pointwise phase in front of it -- so that both land under a phase of work
+    const bool persist = NP == 1;
+    CDwW wd = load_dw(pairs[0], pairs[0].ustart[wave][0]);
+    CPwW<KSC> wp;
+    if (persist) wp = load_pw(pairs[0]);
+    const bool dw_resident = persist && pairs[0].single_q != 0;
+    const bool dbuf = p.dbuf != 0;
+    int cur = 0;
+    for (; dq.step < nsteps; dq.advance(tid)) {
+        const int step = dq.step;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads(); // this step's images are in pair 0's tile; every wave has left the previous step's last phase
+        dq.top(tid);
+        asm volatile("" : "+s"(pairs));
+        if (dbuf && dq.nxt < nsteps) stage(dq.nxt, cur ^ 1); // double buffered: the next step's images have this whole step to land
+        const int gvalid = min(G, batch - step * G);
+        for (int pi = 0; pi < NP; ++pi) {
+            c_pair &cp = pairs[pi];
+            if (!persist) wp = load_pw(cp); // lands during the depthwise phase
+            dw_phase(cp, wd, cp.tile_off + (pi == 0 ? cur * p.dbuf_stride : 0));
+            __syncthreads(); // MID complete; the tile has been read
+            if (!dbuf && pi == p.stage_after && dq.nxt < nsteps) stage(dq.nxt, 0); // pair 0's tile region is free: the next step's images fly under the rest of this step
+            if (!dw_resident) {
+                c_pair &nx = pairs[pi + 1 < NP ? pi + 1 : 0];
+                wd = load_dw(nx, nx.ustart[wave][0]); // lands during the pointwise phase
+            }
+            pw_phase(cp, wp, step, gvalid);
+            if (pi + 1 < NP) __syncthreads(); // the next pair's tile is complete; MID is free
+        }
+        if (dbuf) cur ^= 1;
+    }
+    dq.finish(tid);
+}
+
+// ------------------------------------------------------------------------
+// host: plan + launch
+// ------------------------------------------------------------------------
+static int lg2_exact(int v) {
+    for (int i = 0; i < 31; ++i)
+        if ((1 << i) == v) return i;
+    return -1;
+}
+static int pow2_divisor(int v, int cap) { // largest power of two <= cap dividing v
+    int d = 1;
+    while (d * 2 <= cap && v % (d * 2) == 0) d *= 2;
+    return d;
+}
+
+bool chain_plan(const ChainGeom *g, int n, ChainPair *pairs, ChainArgs &a, int lds_budget) {
+    if (n < 1 || n > CHAIN_MAX) return false;
+    int maxCG = 1, KSC = 1;
+    for (int i = 0; i < n; ++i) {
+        const ChainGeom &s = g[i];
+        ChainPair &c = pairs[i];
+        if (s.C % 16 != 0 || s.C < 16 || s.C > 256 || s.N % 16 != 0 || s.N < 16 || s.N > 256) return false;
+        if (s.S != 1 && s.S != 2) return false;
+        if (s.OH != (s.H + s.S - 1) / s.S || s.OW != (s.W + s.S - 1) / s.S) return false;
+        if (i + 1 < n && (g[i + 1].H != s.OH || g[i + 1].W != s.OW || g[i + 1].C != s.N)) return false;
+        c.H = s.H, c.W = s.W, c.C = s.C, c.S = s.S, c.OH = s.OH, c.OW = s.OW, c.N = s.N;
+        c.NQ = s.C / 16, c.lgNQ = lg2_exact(c.NQ), c.KS = (s.C + 63) / 64;
+        KSC = std::max(KSC, c.KS <= 1 ? 1 : (c.KS == 2 ? 2 : 4));
+        // tile: one halo pixel on every side; the 16-byte group index inside a pixel is XOR-ed with bits of the tile column so
+        // that 16 consecutive columns hit 16 distinct 16-byte bank slots (NQ a power of two <= 16)
+        c.swz_sh = 0, c.swz_mask = 0;
+        if (c.lgNQ > 0) c.swz_sh = 4 - c.lgNQ, c.swz_mask = c.NQ - 1;
+        // depthwise columns: divisors only (no overhang, no per-lane predicate)
+        const int CX = pow2_divisor(s.OW, 16), CY = pow2_divisor(s.OH, 16 / CX), CG = 16 / (CX * CY);
+        c.lgCX = lg2_exact(CX), c.lgCY = lg2_exact(CY);
+        maxCG = std::max(maxCG, CG);
+        // Row and image pitch: when the 16 columns of a unit span rows (CY > 1) or images (CG > 1), the pitches decide which
+        // 16-byte bank slots the lanes of a ds_read_b128 service group hit.  Bank model (MI355X_MICROARCH.md, LDS): a wave's
+        // b128 read is served in four groups of 16 lanes, one cycle per group plus one per extra distinct address on a busy
+        // slot; the pads (multiples of 16 bytes) with the fewest modelled cycles over the channel groups win.
+        {
+            static const int grp[4][16] = {{0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27}, {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31},
+                                           {32, 33, 34, 35, 44, 45, 46, 47, 52, 53, 54, 55, 56, 57, 58, 59}, {36, 37, 38, 39, 40, 41, 42, 43, 48, 49, 50, 51, 60, 61, 62, 63}};
+            const int row0 = (s.W + 2) * s.C;
+            int best_cost = 1 << 30, best_rp = 0, best_ip = 0;
+            for (int rp = 0; rp < (CY > 1 ? 16 : 1); ++rp)
+                for (int ip = 0; ip < (CG > 1 ? 16 : 1); ++ip) {
+                    const int ROW = row0 + 16 * rp, TILE = (s.H + 2) * ROW + 16 * ip;
+                    int cost = 0;
+                    for (int q = 0; q < std::min(c.NQ, 4); ++q)
+                        for (int gi = 0; gi < 4; ++gi) {
+                            int addr[16], worst = 1;
+                            for (int l = 0; l < 16; ++l) {
+                                const int lane = grp[gi][l], col = lane & 15, g = lane >> 4, gg = g < 2 ? g : 2;
+                                const int cx = col & (CX - 1), cy = (col >> c.lgCX) & (CY - 1), cg = col >> (c.lgCX + c.lgCY);
+                                const int xin = cx * s.S + gg;
+                                addr[l] = cg * TILE + cy * s.S * ROW + xin * s.C + 16 * (q ^ ((xin >> c.swz_sh) & c.swz_mask));
+                            }
+                            for (int slot = 0; slot < 16; ++slot) {
+                                int distinct = 0;
+                                for (int l = 0; l < 16; ++l) {
+                                    if (((addr[l] >> 4) & 15) != slot) continue;
+                                    bool seen = false;
+                                    for (int m = 0; m < l; ++m) seen = seen || addr[m] == addr[l];
+                                    distinct += !seen;
+                                }
+                                worst = std::max(worst, distinct);
+                            }
+                            cost += worst;
+                        }
+                    cost = cost * 64 + rp + ip; // (ties: the smaller pads)
+                    if (cost < best_cost) best_cost = cost, best_rp = rp, best_ip = ip;
+                }
+            c.ROW = row0 + 16 * best_rp;
+            c.TILE = (s.H + 2) * c.ROW + 16 * best_ip;
+        }
+    }
+    // output tiles per wave block (the kernel's register budget: chain_tbm) and blocks: nt = TB * NBLK, NBLK a power of two <= 8
+    const int TBM = KSC == 1 ? 4 : 2;
+    for (int i = 0; i < n; ++i) {
+        ChainPair &c = pairs[i];
+        const int nt = c.N / 16;
+        c.NBLK = 0;
+        for (int nb = 1; nb <= 8; nb *= 2)
+            if (nt % nb == 0 && nt / nb <= TBM) {
+                c.NBLK = nb, c.TB = nt / nb;
+                break;
+            }
+        if (!c.NBLK) return false;
+        if (i + 1 < n && c.TB == 3) return false; // a 12-byte piece would straddle the next tile's 16-byte groups
+    }
+    // ---- LDS plan for G images per step ----
+    auto lds_for = [&](int G, bool fill, bool dbuf = false) {
+        int off = 0, nfill = 0;
+        for (int i = 0; i < n; ++i) {
+            ChainPair &c = pairs[i];
+            // pair i reads the tile pair i-1 wrote: the same region as pair i-1's OWN input if the geometry class (and zero point) agree
+            bool share = i > 0 && pairs[i - 1].H == c.H && pairs[i - 1].W == c.W && pairs[i - 1].C == c.C && g[i - 1].izp4 == g[i].izp4 &&
+                         pairs[i - 1].S == 1 && !(dbuf && i == 1); // (a double-buffered input tile is never a pointwise destination)
+            if (share) c.tile_off = pairs[i - 1].tile_off;
+            else {
+                c.tile_off = off;
+                const int copies = (dbuf && i == 0) ? 2 : 1, bytes = (G * c.TILE + 255) & ~255;
+                if (fill) a.fill_off[nfill] = off, a.fill_bytes[nfill] = copies * bytes, a.fill_izp4[nfill] = g[i].izp4;
+                if (fill && i == 0) a.dbuf = dbuf ? 1 : 0, a.dbuf_stride = dbuf ? bytes : 0;
+                ++nfill;
+                off += copies * bytes;
+            }
+        }
+        if (fill) a.nfill = nfill;
+        off += 512; // slack behind the last tile
+        int mid = 0;
+        for (int i = 0; i < n; ++i) {
+            ChainPair &c = pairs[i];
+            c.plimit_img = c.OH * c.OW;
+            c.P = G * c.plimit_img, c.NCH = (c.P + 15) / 16, c.PLANE = c.NCH * 256 + 16;
+            mid = std::max(mid, c.NQ * c.PLANE);
+        }
+        a.mid_off = off;
+        off += (mid + 255) & ~255;
+        for (int i = 0; i < n; ++i) {
+            ChainPair &c = pairs[i];
+            c.otab_off = -1, c.dst_off = -1;
+            c.dROW = c.dTILE = c.dC = c.dswz_sh = c.dswz_mask = 0;
+            if (i + 1 < n) {
+                const ChainPair &d = pairs[i + 1];
+                c.dst_off = d.tile_off, c.dROW = d.ROW, c.dTILE = d.TILE, c.dC = d.C, c.dswz_sh = d.swz_sh, c.dswz_mask = d.swz_mask;
+                c.otab_off = off;
+                off += (c.P * 4 + 15) & ~15;
+            }
+        }
+        a.q_off = off;
+        off += 16;
+        return off;
+    };
+    // ---- cost model (microseconds per image and CU): every phase costs its requantised bytes over the rate a workgroup gets
+    // (times the imbalance of its work list over the waves) but never less than a phase's latency (dependent chain + barrier);
+    // the chain's HBM bytes are the other roof.  Calibrated on the generated models (profiles/r04/chain_*).
+    auto estimate = [&](int G, int lds, int &nwave_out) {
+        const int wgs = lds > 80 * 1024 ? 1 : 2;
+        const int nwave = (wgs == 1 && KSC == 1) ? 16 : 8;
+        nwave_out = nwave;
+        const double waves_per_simd = wgs * nwave / 4.0;
+        const double r_cu = waves_per_simd >= 4.0 ? 14.0e3 : 8.0e3; // requantised bytes per microsecond and CU this kernel sustains
+        const double r_wg = r_cu / wgs, t_lat = 0.9, t_step = 0.6;
+        double step = t_step;
+        for (int i = 0; i < n; ++i) {
+            const ChainPair &c = pairs[i];
+            const int CG = 16 >> (c.lgCX + c.lgCY);
+            const int U = c.NQ * (G / CG) * (c.OH >> c.lgCY) * (c.OW >> c.lgCX);
+            const int items = ((G * c.OH * c.OW + 15) / 16) * c.NBLK;
+            const double imb_d = (double)((U + nwave - 1) / nwave * nwave) / U, imb_p = (double)((items + nwave - 1) / nwave * nwave) / items;
+            step += std::max(t_lat, (double)G * c.OH * c.OW * c.C * imb_d / r_wg) + std::max(t_lat, (double)G * c.OH * c.OW * c.N * imb_p / r_wg);
+            // a chain (n > 1) fetches the operands of every phase again in every step: ~4 KB per wave for a depthwise phase,
+            // (TB KS + TB) KB for a pointwise one, through the CU's vector L1 at ~100 KB per microsecond
+            if (n > 1) step += nwave * (4.0 + c.TB * c.KS + c.TB) / 100.0 * wgs;
+        }
+        const double compute = step / (G * wgs);
+        const double hbm = ((double)g[0].H * g[0].W * g[0].C + (double)g[n - 1].OH * g[n - 1].OW * g[n - 1].N) / 17.0e3;
+        return std::max(compute, hbm);
+    };
+    // images per step: a multiple of every pair's CG; the cheapest of the doublings that fit
+    int bestG = 0, best_nwave = 8;
+    double best = 1e30;
+    // double buffering of the input tile: where it does not cost a workgroup per CU
+    auto want_dbuf = [&](int G) {
+        const int l0 = lds_for(G, false, false), l1 = lds_for(G, false, true);
+        return l1 <= lds_budget && ((l0 <= 80 * 1024) == (l1 <= 80 * 1024));
+    };
+    for (int G = maxCG; G <= 128; G *= 2) {
+        const bool db = want_dbuf(G);
+        const int lds = lds_for(G, false, db);
+        if (lds > lds_budget) break;
+        int nw = 8;
+        const double e = estimate(G, lds, nw);
+        if (e < best * 0.97) best = e, bestG = G, best_nwave = nw; // (a larger step must pay for its LDS: 3 % at least)
+    }
+    if (!bestG) return false;
+    const int G = bestG, NW = best_nwave;
+    a.G = G, a.nwave = NW, a.est_us_per_image = best;
+    a.dbuf = 0, a.dbuf_stride = 0;
+    a.lds_bytes = lds_for(G, true, want_dbuf(G));
+    a.stage_after = 0;
+    for (int i = 0; i < n; ++i)
+        if (pairs[i].tile_off == pairs[0].tile_off) a.stage_after = i;
+    a.npairs = n, a.KSC = KSC;
+    a.hbm_bytes = (double)g[0].H * g[0].W * g[0].C + (double)g[n - 1].OH * g[n - 1].OW * g[n - 1].N;
+    a.requant_bytes = 0;
+    for (int i = 0; i < n; ++i) {
+        ChainPair &c = pairs[i];
+        a.requant_bytes += (double)c.OH * c.OW * (c.C + c.N);
+        const int CG = 16 >> (c.lgCX + c.lgCY);
+        c.UG = G / CG, c.UY = c.OH >> c.lgCY, c.UX = c.OW >> c.lgCX, c.NU = c.UG * c.UY * c.UX;
+        // the unit list (channel group, then column, image group, row) cut into one contiguous range per wave
+        const int U = c.NQ * c.NU;
+        c.single_q = 1;
+        for (int w = 0; w < 16; ++w) {
+            const int u0 = w < NW ? (int)((long)w * U / NW) : U, u1 = w < NW ? (int)((long)(w + 1) * U / NW) : U;
+            const int q = u0 < U ? u0 / c.NU : 0, r = u0 < U ? u0 % c.NU : 0;
+            c.ustart[w][0] = q, c.ustart[w][1] = r / (c.UG * c.UY), c.ustart[w][2] = r % (c.UG * c.UY), c.ustart[w][3] = 0;
+            c.ucount[w] = u1 - u0;
+            if (u1 > u0 && (u1 - 1) / c.NU != q) c.single_q = 0;
+        }
+        c.pad_ = 0;
+        c.rtab = nullptr;
+    }
+    return true;
+}
+
+void chain_rtab(const ChainPair &c, std::vector<int> &out) {
+    const int CG = 16 >> (c.lgCX + c.lgCY), CY = 1 << c.lgCY;
+    out.assign((size_t)c.UG * c.UY * 2, 0);
+    for (int ug = 0; ug < c.UG; ++ug)
+        for (int uy = 0; uy < c.UY; ++uy) {
+            out[(size_t)(ug * c.UY + uy) * 2] = ug * CG * c.TILE + uy * CY * c.S * c.ROW;
+            out[(size_t)(ug * c.UY + uy) * 2 + 1] = ug * CG * c.plimit_img * 16 + uy * CY * c.OW * 16;
+        }
+}
+
+double chain_unfused_us_per_image(const ChainGeom *g, int n) {
+    // one launch per operator on the run-time-geometry kernels: depthwise ~3.8 TB/s, 1x1 convolution ~4.6 TB/s of algorithmic bytes
+    // (bench.py runtime_geometry), small tensors less (a floor per launch is not modelled: batches are large)
+    double us = 0;
+    for (int i = 0; i < n; ++i) {
+        const double in = (double)g[i].H * g[i].W * g[i].C, mid = (double)g[i].OH * g[i].OW * g[i].C, out = (double)g[i].OH * g[i].OW * g[i].N;
+        us += (in + mid) / (3.8e6 / 256) + (mid + out) / (4.6e6 / 256);
+    }
+    return us;
+}
+
+template <int KSC, bool W16, int MG, uint32_t XR4>
+static void launch_chain_t(const int8_t *in, int8_t *out, const ChainArgs &a, int batch, hipStream_t s) {
+    // occupancy per (device, LDS size in KiB).  The dynamic-LDS limit of the function is raised to the maximum every time a
+    // slot is filled (a smaller later value would make a larger earlier plan unlaunchable).
+    static std::atomic<int> cache[LaunchState::MAX_DEV][161];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= LaunchState::MAX_DEV) dev = 0;
+    std::atomic<int> &slot = cache[dev][(a.lds_bytes + 1023) / 1024];
+    int per_cu = slot.load(std::memory_order_relaxed);
+    if (per_cu <= 0) {
+        (void)hipFuncSetAttribute((const void *)chain_rt<KSC, W16, MG, XR4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, chain_rt<KSC, W16, MG, XR4>, W16 ? 1024 : 512, (size_t)a.lds_bytes) != hipSuccess || per_cu < 1) {
+            (void)hipGetLastError();
+            per_cu = 1;
+        }
+        slot.store(per_cu, std::memory_order_relaxed);
+    }
+    const int nsteps = (batch + a.G - 1) / a.G;
+    const int grid = nsteps < 256 * per_cu ? nsteps : 256 * per_cu;
+    ChainArgs b = a;
+    b.qcfg = dq_config(nsteps, grid, dq_est_us((double)batch * a.hbm_bytes, (double)batch * a.requant_bytes));
+    b.queue = dq_slot(b.queue);
+    hipLaunchKernelGGL((chain_rt<KSC, W16, MG, XR4>), dim3(grid), dim3(W16 ? 1024 : 512), a.lds_bytes, s, in, out, b, batch);
+}
+void launch_chain(const int8_t *in, int8_t *out, const ChainArgs &a, int batch, hipStream_t s) {
+#define MF_CHAIN_GO(KSC, W)                                                              \
+    do {                                                                                 \
+        if (a.xr) {                                                                      \
+            if (a.magic == 2) launch_chain_t<KSC, W, 2, 0x80808080u>(in, out, a, batch, s); \
+            else launch_chain_t<KSC, W, 1, 0x80808080u>(in, out, a, batch, s);           \
+        } else {                                                                         \
+            if (a.magic == 2) launch_chain_t<KSC, W, 2, 0u>(in, out, a, batch, s);       \
+            else launch_chain_t<KSC, W, 1, 0u>(in, out, a, batch, s);                    \
+        }                                                                                \
+    } while (0)
+    if (a.KSC == 1 && a.nwave == 16) MF_CHAIN_GO(1, true);
+    else if (a.KSC == 1) MF_CHAIN_GO(1, false);
+    else if (a.KSC == 2) MF_CHAIN_GO(2, false);
+    else MF_CHAIN_GO(4, false);
+#undef MF_CHAIN_GO
+}
+
+} // namespace k
+} // namespace mf

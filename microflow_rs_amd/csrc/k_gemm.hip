@@ -146,7 +146,11 @@ __global__ __launch_bounds__(256) void fc_rowwave_softmax(const int8_t *__restri
 // ------------------------------------------------------------------------
 typedef int v16i __attribute__((ext_vector_type(16)));
 
-template <int BM, int BN, int WM, int WN, bool STAGGER>
+// RS: the weight zero point term x1 = wzp * sum_k x[m][k] (fully_connected.rs:60-64) is formed INSIDE the GEMM: the X fragments
+// a wave feeds the matrix pipe are the rows whose sums are needed, so wave (wm, wn) adds up ITS share of them (row block
+// mt == wn: the WN waves of a wave row hold the same X fragments) with v_dot4 against ones, issued between the MFMAs
+// (the VALU is idle there); the sums meet in LDS after the last k step.  No row-sum pre-pass, no extra launch.
+template <int BM, int BN, int WM, int WN, bool STAGGER, bool RS>
 __global__ __launch_bounds__(64 * WM * WN) void fc_mfma(const int8_t *__restrict__ X,
                                                         int8_t *__restrict__ Y, FcGemmArgs p) {
     constexpr int BK = 128;
@@ -154,6 +158,7 @@ __global__ __launch_bounds__(64 * WM * WN) void fc_mfma(const int8_t *__restrict
     constexpr int MT = BM / WM / 32, NT = BN / WN / 32;      // 32x32 MFMA tiles per wave
     constexpr int XT = BM * BK, WT = BN * BK, BUF = XT + WT; // one staging buffer (two allocated)
     constexpr int XP = XT / 1024 / NW, WP = WT / 1024 / NW;  // 1 KiB DMA pieces per wave
+    static_assert(!RS || MT == WN, "row sums: wave (wm, wn) owns row block mt == wn");
     static_assert(XT % (1024 * NW) == 0 && WT % (1024 * NW) == 0, "DMA pieces must divide over the waves");
     // swizzle key: with (row >> 1) & 7 the 16 lanes of every ds_read_b128 service group
     // ({0-3,12-15,20-27}, ...) hit 16 distinct 16-byte bank slots (row & 7 would be 2-way)
@@ -236,6 +241,7 @@ __global__ __launch_bounds__(64 * WM * WN) void fc_mfma(const int8_t *__restrict
     };
 
     const int nk = K / BK;
+    int rs = 0; // RS: this lane's share of sum_k x[row][k], row = row block wn of wave row wm, fragment row rho
     if constexpr (!STAGGER) {
         // lockstep loop: the DMAs of step t+1 fly during the MFMAs of step t; one vmcnt(0) +
         // barrier per step
@@ -250,13 +256,24 @@ __global__ __launch_bounds__(64 * WM * WN) void fc_mfma(const int8_t *__restrict
             for (int ks = 0; ks < BK / 32; ++ks) {
                 v4i a[NT], b[MT];
                 load_frags(lb, ks, a, b);
+                v4i bs = b[0];
+                if constexpr (RS) {
+#pragma unroll
+                    for (int mt = 1; mt < MT; ++mt)
+                        if (wn == mt) bs = b[mt];
+                }
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt)
+                    for (int mt = 0; mt < MT; ++mt) {
                         acc[nt][mt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[nt], b[mt], acc[nt][mt], 0, 0, 0);
+                        if constexpr (RS) {
+                            if (nt * MT + mt < 4) rs = sdot4((uint32_t)bs[nt * MT + mt], 0x01010101u, rs);
+                        }
+                    }
             }
         }
+        if constexpr (RS) __syncthreads(); // every wave is done with the staging buffers: the row sums go there
     } else {
         // Staggered wave rows.  Per tile kt every wave runs, in program order,
         //     L0: ds_read the fragments of k-substeps 0,1 of buffer cur
@@ -311,6 +328,12 @@ __global__ __launch_bounds__(64 * WM * WN) void fc_mfma(const int8_t *__restrict
                 __builtin_amdgcn_s_barrier();
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
+                v4i bs[2] = {b[0][0], b[1][0]};
+                if constexpr (RS) {
+#pragma unroll
+                    for (int mt = 1; mt < MT; ++mt)
+                        if (wn == mt) bs[0] = b[0][mt], bs[1] = b[1][mt];
+                }
                 __builtin_amdgcn_s_setprio(1);
                 int cnt = 0;
 #pragma unroll
@@ -320,6 +343,9 @@ __global__ __launch_bounds__(64 * WM * WN) void fc_mfma(const int8_t *__restrict
 #pragma unroll
                         for (int mt = 0; mt < MT; ++mt) {
                             acc[nt][mt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[u][nt], b[u][mt], acc[nt][mt], 0, 0, 0);
+                            if constexpr (RS) { // one v_dot4 behind each of the first eight MFMAs of the section
+                                if (cnt < 8) rs = sdot4((uint32_t)bs[cnt >> 2][cnt & 3], 0x01010101u, rs);
+                            }
                             ++cnt;
                             if (ph == 0 && cnt % GAP == 0 && piece < PIECES) {
                                 __builtin_amdgcn_sched_barrier(0);
@@ -337,6 +363,13 @@ __global__ __launch_bounds__(64 * WM * WN) void fc_mfma(const int8_t *__restrict
         if (wm == 0) __builtin_amdgcn_s_barrier(); // row 0 absorbs row 1's extra barrier
     }
 
+    // RS: lanes rho and rho + 32 hold the two halves of every k step's 32 bytes; the finished sums meet in LDS (the
+    // staging buffers are dead: every wave has passed its last fragment read)
+    if constexpr (RS) {
+        rs += __shfl_xor(rs, 32, 64);
+        if (half == 0) ((int *)lds)[wm * (BM / WM) + wn * 32 + rho] = rs;
+        __syncthreads();
+    }
     // epilogue: lane (m column = lane & 31, half) holds n = tile + 16*half + r, r = 0..15
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
@@ -354,7 +387,9 @@ __global__ __launch_bounds__(64 * WM * WN) void fc_mfma(const int8_t *__restrict
         for (int mt = 0; mt < MT; ++mt) {
             const int m = tm * BM + wm * (BM / WM) + mt * 32 + rho;
             if (m >= p.M) continue; // ragged last row tile
-            const int corr = p.rowsum ? p.wzp * p.rowsum[m] : 0; // x1 = wzp * row-sum of the input
+            int corr = 0; // x1 = wzp * row-sum of the input
+            if constexpr (RS) corr = p.wzp * ((const int *)lds)[wm * (BM / WM) + mt * 32 + rho];
+            else if (p.rowsum) corr = p.wzp * p.rowsum[m];
             uint32_t d[4];
 #pragma unroll
             for (int r = 0; r < 16; r += 4) {
@@ -410,22 +445,31 @@ bool fc_mfma_supported(size_t rows, int N, int K) {
 void launch_fc_rowsum(const int8_t *in, int *rowsum, size_t rows, int K, hipStream_t s) {
     hipLaunchKernelGGL(fc_rowsum, dim3(grid_for(rows, 4)), dim3(256), 0, s, in, rowsum, rows, K);
 }
-template <int BM, int BN, int WM, int WN, bool STAGGER>
+template <int BM, int BN, int WM, int WN, bool STAGGER, bool RS>
 static void launch_fc_mfma_t(const int8_t *in, int8_t *out, const FcGemmArgs &a, hipStream_t s) {
     constexpr int lds = 2 * (BM + BN) * 128;
     static LaunchState st;
-    (void)prepared(st, fc_mfma<BM, BN, WM, WN, STAGGER>, 64 * WM * WN, lds);
+    (void)prepared(st, fc_mfma<BM, BN, WM, WN, STAGGER, RS>, 64 * WM * WN, lds);
     const int grid = ((a.M + BM - 1) / BM) * (a.N / BN);
-    hipLaunchKernelGGL((fc_mfma<BM, BN, WM, WN, STAGGER>), dim3(grid), dim3(64 * WM * WN), lds, s, in, out, a);
+    hipLaunchKernelGGL((fc_mfma<BM, BN, WM, WN, STAGGER, RS>), dim3(grid), dim3(64 * WM * WN), lds, s, in, out, a);
+}
+// MF_FC_ROWSUM_PREPASS=1: the separate fc_rowsum launch of rounds 1-3 instead of the in-GEMM row sums (A/B switch)
+bool fc_mfma_rowsum_prepass() {
+    static const bool on = getenv("MF_FC_ROWSUM_PREPASS") != nullptr;
+    return on;
 }
 void launch_fc_mfma(const int8_t *in, int8_t *out, const FcGemmArgs &a, hipStream_t s) {
     static const int force = [] { const char *e = getenv("MF_FC_TILE"); return e ? atoi(e) : 0; }();
     // 256 x 256 tiles halve the L2 -> LDS traffic per MAC; they need >= 256 tiles to fill the chip
     const bool big = a.N % 256 == 0 && (size_t)((a.M + 255) / 256) * (a.N / 256) >= 192;
-    if ((big && force != 128) || (force == 256 && a.N % 256 == 0))
-        launch_fc_mfma_t<256, 256, 2, 4, true>(in, out, a, s);
-    else
-        launch_fc_mfma_t<128, 128, 2, 2, false>(in, out, a, s);
+    const bool rs = a.wzp != 0 && !a.rowsum; // the weight zero point term from in-kernel row sums
+    if ((big && force != 128) || (force == 256 && a.N % 256 == 0)) {
+        if (rs) launch_fc_mfma_t<256, 256, 2, 4, true, true>(in, out, a, s);
+        else launch_fc_mfma_t<256, 256, 2, 4, true, false>(in, out, a, s);
+    } else {
+        if (rs) launch_fc_mfma_t<128, 128, 2, 2, false, true>(in, out, a, s);
+        else launch_fc_mfma_t<128, 128, 2, 2, false, false>(in, out, a, s);
+    }
 }
 bool launch_fc_rowwave_softmax(const int8_t *in, int8_t *out, const FcArgs &a, const SoftmaxArgs &sm, size_t rows,
                                hipStream_t s) {

@@ -56,7 +56,7 @@ struct FcGemmArgs {
     const int8_t *w;    // [N][K]
     const float *A;     // [N]
     const int *Kc;      // [N]
-    const int *rowsum;  // [rows] sum_k x[row][k], or nullptr when wzp == 0
+    const int *rowsum;  // [rows] sum_k x[row][k] from the fc_rowsum pre-pass, or nullptr: wzp == 0, or the GEMM forms the sums itself
     int wzp;
     float S;
     float lo_f, hi_f;
@@ -201,6 +201,63 @@ struct DwPwArgs {
     DwFastArgs dw;
     PwArgs pw;
 };
+
+// ---- run-time-geometry fused chains (k_chain.hip) ----
+// A chain = 1 .. CHAIN_MAX consecutive DepthwiseConv2D 3x3 (SAME, stride 1 or 2) + Conv2D 1x1 pairs of ANY height / width with
+// C % 16 == 0 input and N % 16 == 0 output channels, run in ONE launch on G whole images per workgroup step; every tensor between
+// the chain's first input and last output stays in LDS.  Geometry, work split and LDS plan are made by the host (chain_plan) and
+// handed over in a device table the kernel reads with scalar loads.
+constexpr int CHAIN_MAX = 16;
+struct ChainGeom {           // one pair, as the model states it
+    int H, W, C, S, OH, OW, N;
+    uint32_t izp4;           // input zero point of the depthwise, in every byte
+};
+struct ChainPair {           // one pair, planned (device table entry)
+    int H, W, C, S, OH, OW, N;
+    int NQ, lgNQ, KS, TB, NBLK;    // 16-channel groups (lg = -1: not a power of two); 64-deep k steps; output tiles per wave block; blocks
+    int ROW, TILE, tile_off;       // input tile: row pitch, image pitch, LDS offset
+    int swz_sh, swz_mask;          // 16-byte group index of tile column x (halo column = 0) is XOR-ed with (x >> sh) & mask
+    int lgCX, lgCY;                // depthwise unit = CG images x CY rows x CX columns (CG CY CX = 16)
+    int UG, UY, UX, NU;            // units per channel group along images / rows / columns, and their product
+    int P, NCH, PLANE, plimit_img; // output pixels per step, 16-pixel chunks, MID plane pitch, output pixels per image
+    int dst_off, dROW, dTILE, dC, dswz_sh, dswz_mask, otab_off; // next pair's tile (dst_off < 0: the chain's output, HBM)
+    float dw_lo, dw_hi, pw_lo, pw_hi;
+    int ustart[16][4];             // first depthwise unit of wave w: (q, ux, j = ug * UY + uy, -)
+    int ucount[16];
+    int single_q;                  // every wave's unit range lies inside one channel group
+    int pad_;
+    const int *rtab;               // [UG * UY] x {tile offset, MID offset} of unit (ug, uy) relative to unit (0, 0) (chain_rtab)
+    const void *dw_wmm;            // DwFastArgs::wmm
+    const float *dwA, *dwS;
+    const int *dwK;
+    const void *pw_w;              // build_pw_rt_reg_weights(K, N, group 1, TB, NBLK)
+    const float *pwA, *pwS;
+    const int *pwK;
+};
+struct ChainArgs {
+    const ChainPair *pairs;
+    int npairs, G;
+    int lds_bytes, mid_off, q_off;
+    int dbuf, dbuf_stride;         // pair 0's input tile is double buffered (the next step's images are staged a whole step ahead)
+    int stage_after;               // the next step's images are DMA-staged after the depthwise phase of this pair (the last reader of pair 0's tile region)
+    int nfill;
+    int fill_off[CHAIN_MAX], fill_bytes[CHAIN_MAX];
+    uint32_t fill_izp4[CHAIN_MAX];
+    int *queue;
+    int qcfg;
+    int KSC;                       // template selector: 1, 2 or 4 k steps (max over the pairs)
+    int nwave;                     // waves per workgroup: 8, or 16 when the LDS plan admits one workgroup per CU only (KSC == 1)
+    double est_us_per_image;       // the planner's cost estimate (per CU), for choosing between chainings
+    int magic, xr;                 // epilogue mode of the whole chain (min over its operators), element type
+    double hbm_bytes, requant_bytes; // per image (the step queue's duration estimate)
+};
+// plans `n` pairs as one chain: fills `pairs` (everything but the operand pointers and clamps) and the LDS part of `a`.
+// false: no plan (a channel count, the LDS budget, ...).  `lds_budget`: bytes a workgroup may use.
+bool chain_plan(const ChainGeom *g, int n, ChainPair *pairs, ChainArgs &a, int lds_budget);
+// estimated microseconds per image and CU of the same pairs run one operator at a time (the run-time-geometry kernels of k_rt.hip)
+double chain_unfused_us_per_image(const ChainGeom *g, int n);
+void chain_rtab(const ChainPair &c, std::vector<int> &out); // the unit offset table ChainPair::rtab points to
+void launch_chain(const int8_t *in, int8_t *out, const ChainArgs &a, int batch, hipStream_t s);
 
 // two consecutive pairs in one launch (k_quad.hip)
 struct QuadArgs {
@@ -429,6 +486,7 @@ bool launch_fc_rowwave_softmax(const int8_t *in, int8_t *out, const FcArgs &a, c
 bool fc_mfma_supported(size_t rows, int N, int K);
 void launch_fc_rowsum(const int8_t *in, int *rowsum, size_t rows, int K, hipStream_t s);
 void launch_fc_mfma(const int8_t *in, int8_t *out, const FcGemmArgs &a, hipStream_t s);
+bool fc_mfma_rowsum_prepass(); // MF_FC_ROWSUM_PREPASS: rounds 1-3's separate row-sum launch (A/B switch)
 void launch_softmax(const int8_t *in, int8_t *out, const SoftmaxArgs &a, size_t batch, hipStream_t s);
 // number of float bit patterns (of all 2^32) whose quantised byte differs between quant_div's fast form and the true
 // division, for these parameters; synchronises the stream

@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <cstring>
 #include <string>
+#include <memory>
 #include <vector>
 
 #include "mf_internal.hpp"
@@ -281,6 +282,32 @@ void model_prepare(ModelImpl *m, int device, size_t max_batch) {
                     if (FusedImpl *g = fused_quad_stem_create(ops[i - 1], f)) sg.v.push_back({g, (int)i - 1, (int)i + 3});
                 i += 3;
             }
+        }
+        // (4c) runs of consecutive run-time-geometry pairs (single-pair chain groups, k_chain.hip): the planner's cost model
+        // decides how the run is cut into chain launches (ops.hip: fused_chain_partition); a pair that is cheapest as two
+        // separate launches loses its group
+        for (size_t i = 0; i + 1 < n; ++i) {
+            if (!fused_is_chain_single(fused[i]) || fused_last[i] != (int)i + 1 || covered(i)) continue;
+            std::vector<FusedImpl *> run;
+            size_t a = i;
+            while (a + 1 < n && fused_is_chain_single(fused[a]) && fused_last[a] == (int)a + 1 && !covered(a)) {
+                run.push_back(fused[a]);
+                a += 2;
+            }
+            const int rn = (int)run.size();
+            std::vector<int> seg((size_t)rn, 0);
+            std::unique_ptr<bool[]> unf(new bool[(size_t)rn]);
+            fused_chain_partition(run.data(), rn, seg.data(), unf.get());
+            for (int k = 0; k < rn; ++k) {
+                const size_t at = i + 2 * (size_t)k;
+                if (seg[(size_t)k] >= 2) {
+                    if (FusedImpl *f = fused_chain_create(run.data() + k, seg[(size_t)k])) sg.v.push_back({f, (int)at, (int)(at + 2 * (size_t)seg[(size_t)k]) - 1});
+                } else if (seg[(size_t)k] == 1 && unf[(size_t)k]) {
+                    fused_destroy(fused[at]);
+                    fused[at] = nullptr, fused_last[at] = -1;
+                }
+            }
+            i = a - 1;
         }
         // (5) DepthwiseConv2D with one input channel -> [Reshape] -> the FullyConnected + Softmax group -> one kernel
         for (size_t i = 0; i + 1 < n; ++i) {

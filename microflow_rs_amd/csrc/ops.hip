@@ -113,6 +113,7 @@ struct OpImpl {
     DevBuf d_tap;          // conv_mm_rt: tap offset table
     DevBuf d_crw, d_crm;   // conv_rows_lds: packed weights, tap masks
     bool rt_wz = false;    // non-zero weight zero points
+    int magic_mode = 0;    // conv-like operators: epilogue mode the host proved usable (k_common.hpp: 0, 1 or 2)
     int pw_group = 1;      // pixels presented as one row of the 1x1 product (K = 8 -> 2, K = 4 -> 4)
     DevBuf d_rtA, d_rtS, d_rtKc, d_rtwzp; // constants replicated per group member
 };
@@ -372,6 +373,7 @@ OpImpl *op_create(int device, const OpSpec &spec) {
         if (epi_dbg)
             fprintf(stderr, "[epi] %s %dx%dx%d -> %d: |acc| < %lld, clamp [%d, %d] -> mode %d\n", dw ? "depthwise" : "conv", s.H, s.W, s.C, s.N,
                     (long long)acc_bound, lo, hi, magic);
+        op->magic_mode = magic;
         const size_t wbytes = dw ? (size_t)s.KH * s.KW * s.N : (size_t)s.N * s.KH * s.KW * s.C;
         op->d_w.upload(s.weights, wbytes);
         op->d_wzp.upload(wzp.data(), wzp.size() * 4);
@@ -489,6 +491,11 @@ OpImpl *op_create(int device, const OpSpec &spec) {
             f.izp4 = 0x01010101u * (uint32_t)(uint8_t)(int8_t)s.izp;
             f.lo_f = a.lo_f, f.hi_f = a.hi_f, f.magic = magic, f.xr = xr, f.queue = (int *)op->d_queue.p;
             op->dwrt.wzp = a.wzp;
+            if (!op->rt_wz && s.C % 16 == 0) { // matrix-pipe form of the taps: what the fused chain kernel (k_chain.hip) multiplies
+                const std::vector<int8_t> prep = build_dw_mm_weights(s.weights, s.C);
+                op->d_wprep.upload(prep.data(), prep.size());
+                f.wmm = op->d_wprep.p;
+            }
         }
         if (op->fast == OpImpl::NONE && !no_rt && op->finite_consts && !dw && s.KH == 1 && s.KW == 1 && s.sh == 1 && s.sw == 1 &&
             s.OH == s.H && s.OW == s.W) {
@@ -772,7 +779,7 @@ void op_run(OpImpl *op, const int8_t *d_in, size_t batch, int8_t *d_out, void *s
             g.lo_f = op->fc.lo_f, g.hi_f = op->fc.hi_f, g.M = (int)rows, g.N = sp.N, g.K = sp.K;
             g.xr4 = 0x01010101u * (uint32_t)op->fc.xr;
             g.rowsum = nullptr;
-            if (op->fc.wzp != 0) {
+            if (op->fc.wzp != 0 && k::fc_mfma_rowsum_prepass()) {
                 if (op->rowsum_cap < rows) {
                     MF_HIP(hipStreamSynchronize(s));
                     if (op->d_rowsum) (void)hipFree(op->d_rowsum);
@@ -873,7 +880,7 @@ void op_run_f32(OpImpl *op, const float *d_in, size_t batch, int8_t *d_out, void
 }
 
 struct FusedImpl {
-    enum Kind { DWPW, TAIL, FCSM, STAGE, DWFC, PAIRTAIL, QUAD } kind;
+    enum Kind { DWPW, TAIL, FCSM, STAGE, DWFC, PAIRTAIL, QUAD, CHAIN } kind;
     OpImpl *a, *b, *c;
     k::DwPwArgs dwpw;
     k::TailArgs tail;
@@ -889,9 +896,147 @@ struct FusedImpl {
     // QUAD: two consecutive pairs in one kernel (k_quad.hip); a = the first pair's depthwise, b = the second pair's conv
     k::QuadArgs quad{};
     int quad_shape[10] = {0};
+    // CHAIN: 1 .. CHAIN_MAX consecutive pairs of any geometry in one launch (k_chain.hip); table and weights in stage_w
+    k::ChainArgs chain{};
+    std::vector<std::pair<OpImpl *, OpImpl *>> chain_members;
 };
 
+// ---- run-time-geometry chains (k_chain.hip) ----
+static bool chain_enabled() {
+    static const bool off = getenv("MF_NO_CHAIN") != nullptr;
+    return !off;
+}
+// a DepthwiseConv2D 3x3 + Conv2D 1x1 pair the chain kernel can run: any H / W, C % 16 == 0, N % 16 == 0
+static bool chain_pair_ok(const OpImpl *dw, const OpImpl *pw) {
+    if (!dw || !pw || dw->device != pw->device || dw->force_generic || pw->force_generic) return false;
+    const OpSpec &d = dw->s, &q = pw->s;
+    if (d.kind != MF_OP_DEPTHWISE_CONV_2D || q.kind != MF_OP_CONV_2D || d.u8 != q.u8) return false;
+    if (dw->fast != OpImpl::DW_RT && dw->fast != OpImpl::DW_NHWC) return false;
+    const k::DwFastArgs &f = dw->fast == OpImpl::DW_NHWC ? dw->dwf : dw->dwrt.dw;
+    if (!f.wmm || (dw->fast == OpImpl::DW_RT && dw->rt_wz)) return false;
+    if (d.KH != 3 || d.KW != 3 || d.pad != MF_PAD_SAME || d.sh != d.sw || (d.sh != 1 && d.sh != 2) || d.C != d.N || d.C % 16 != 0) return false;
+    if (q.KH != 1 || q.KW != 1 || q.sh != 1 || q.sw != 1 || q.OH != q.H || q.OW != q.W || q.N % 16 != 0) return false;
+    if (q.H != d.OH || q.W != d.OW || q.C != d.N) return false;
+    if (pw->fast != OpImpl::PW_RT && pw->fast != OpImpl::PW_MFMA) return false;
+    if (pw->fast == OpImpl::PW_RT && pw->rt_wz) return false;
+    if (!dw->finite_consts || !pw->finite_consts || dw->magic_mode < 1 || pw->magic_mode < 1) return false;
+    return true;
+}
+static FusedImpl *chain_create(const std::pair<OpImpl *, OpImpl *> *mem, int n) {
+    if (!chain_enabled() || n < 1 || n > k::CHAIN_MAX) return nullptr;
+    std::vector<k::ChainGeom> geo((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        if (!chain_pair_ok(mem[i].first, mem[i].second)) return nullptr;
+        if (mem[i].first->device != mem[0].first->device || mem[i].first->s.u8 != mem[0].first->s.u8) return nullptr;
+        const OpSpec &d = mem[i].first->s, &q = mem[i].second->s;
+        const k::DwFastArgs &f = mem[i].first->fast == OpImpl::DW_NHWC ? mem[i].first->dwf : mem[i].first->dwrt.dw;
+        geo[(size_t)i] = k::ChainGeom{d.H, d.W, d.C, d.sh, d.OH, d.OW, q.N, f.izp4};
+    }
+    std::vector<k::ChainPair> tab((size_t)n);
+    std::unique_ptr<FusedImpl> c(new FusedImpl{FusedImpl::CHAIN, mem[0].first, mem[n - 1].second, nullptr, {}, {}, ""});
+    if (!k::chain_plan(geo.data(), n, tab.data(), c->chain, 150 * 1024)) return nullptr;
+    int magic = 2;
+    std::string name = "chain_rt<";
+    for (int i = 0; i < n; ++i) {
+        OpImpl *dw = mem[i].first, *pw = mem[i].second;
+        const k::DwFastArgs &f = dw->fast == OpImpl::DW_NHWC ? dw->dwf : dw->dwrt.dw;
+        k::ChainPair &t = tab[(size_t)i];
+        t.dw_wmm = f.wmm, t.dwA = f.A, t.dwS = f.S, t.dwK = f.Kc, t.dw_lo = f.lo_f, t.dw_hi = f.hi_f;
+        const OpSpec &q = pw->s;
+        std::vector<int8_t> host((size_t)q.N * q.C);
+        MF_HIP(hipMemcpy(host.data(), pw->conv.w, host.size(), hipMemcpyDeviceToHost)); // [N][1][1][C], i8 domain, as uploaded
+        const std::vector<int8_t> prep = build_pw_rt_reg_weights(host.data(), q.C, q.N, 1, t.TB, t.NBLK);
+        c->stage_w.emplace_back(new DevBuf);
+        c->stage_w.back()->upload(prep.data(), prep.size());
+        t.pw_w = c->stage_w.back()->p;
+        t.pwA = pw->conv.A, t.pwS = pw->conv.S, t.pwK = pw->conv.Kc, t.pw_lo = pw->conv.lo_f, t.pw_hi = pw->conv.hi_f;
+        {
+            std::vector<int> rt;
+            k::chain_rtab(t, rt);
+            c->stage_w.emplace_back(new DevBuf);
+            c->stage_w.back()->upload(rt.data(), rt.size() * sizeof(int));
+            t.rtab = c->stage_w.back()->as<int>();
+        }
+        magic = std::min(magic, std::min(dw->magic_mode, pw->magic_mode));
+        name += (i ? "|" : "") + std::to_string(dw->s.H) + "x" + std::to_string(dw->s.W) + "x" + std::to_string(dw->s.C) +
+                (dw->s.sh == 2 ? "s2" : "") + "-" + std::to_string(q.N);
+        c->chain_members.push_back(mem[i]);
+    }
+    name += ";G" + std::to_string(c->chain.G) + ">";
+    c->name = name;
+    c->stage_w.emplace_back(new DevBuf);
+    c->stage_w.back()->upload(tab.data(), tab.size() * sizeof(k::ChainPair));
+    c->chain.pairs = (const k::ChainPair *)c->stage_w.back()->p;
+    c->chain.magic = magic, c->chain.xr = mem[0].first->s.u8 ? 0x80 : 0;
+    c->chain.queue = (int *)mem[0].first->d_queue.p;
+    return c.release();
+}
+// second level: `n` consecutive single-pair chain groups as ONE chain (nullptr: no plan fits)
+FusedImpl *fused_chain_create(FusedImpl *const *groups, int n) {
+    std::vector<std::pair<OpImpl *, OpImpl *>> mem;
+    for (int i = 0; i < n; ++i) {
+        if (!groups[i] || groups[i]->kind != FusedImpl::CHAIN || groups[i]->chain_members.size() != 1) return nullptr;
+        mem.push_back(groups[i]->chain_members[0]);
+    }
+    return chain_create(mem.data(), n);
+}
+bool fused_is_chain_single(const FusedImpl *f) { return f && f->kind == FusedImpl::CHAIN && f->chain_members.size() == 1; }
+// How to run `n` consecutive single-pair chain groups: seg_len[i] = number of pairs of the chain that starts at pair i (0: pair i is
+// inside a chain that started earlier); unfused[i] = pair i is cheapest as two separate operator launches.  Dynamic programme over the
+// planner's cost estimates (k_chain.hip: chain_plan / chain_unfused_us_per_image).
+void fused_chain_partition(FusedImpl *const *groups, int n, int *seg_len, bool *unfused) {
+    std::vector<k::ChainGeom> geo((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        const std::pair<OpImpl *, OpImpl *> &m = groups[i]->chain_members[0];
+        const OpSpec &d = m.first->s;
+        const k::DwFastArgs &f = m.first->fast == OpImpl::DW_NHWC ? m.first->dwf : m.first->dwrt.dw;
+        geo[(size_t)i] = k::ChainGeom{d.H, d.W, d.C, d.sh, d.OH, d.OW, m.second->s.N, f.izp4};
+    }
+    static const bool force_fuse = getenv("MF_CHAIN_FORCE") != nullptr; // tests: never prefer the unfused operators
+    const double INF = 1e30;
+    std::vector<double> best((size_t)n + 1, INF);
+    std::vector<int> choice((size_t)n + 1, 1);
+    std::vector<char> choice_unf((size_t)n + 1, 0);
+    best[(size_t)n] = 0;
+    std::vector<k::ChainPair> tab((size_t)k::CHAIN_MAX);
+    for (int i = n - 1; i >= 0; --i) {
+        for (int len = 1; len <= n - i && len <= k::CHAIN_MAX; ++len) {
+            k::ChainArgs a{};
+            bool ok = true;
+            for (int j = i; j < i + len && ok; ++j) ok = groups[j]->chain_members[0].first->s.u8 == groups[i]->chain_members[0].first->s.u8;
+            if (!ok || !k::chain_plan(geo.data() + i, len, tab.data(), a, 150 * 1024)) {
+                if (len == 1) { // (cannot happen for a group that exists; keep the programme total)
+                    if (best[(size_t)i + 1] < best[(size_t)i]) best[(size_t)i] = best[(size_t)i + 1], choice[(size_t)i] = 1, choice_unf[(size_t)i] = 1;
+                }
+                continue;
+            }
+            double c = a.est_us_per_image;
+            char unf = 0;
+            if (len == 1 && !force_fuse) {
+                const double u = k::chain_unfused_us_per_image(geo.data() + i, 1);
+                if (u < c) c = u, unf = 1;
+            }
+            if (c + best[(size_t)i + len] < best[(size_t)i]) best[(size_t)i] = c + best[(size_t)i + len], choice[(size_t)i] = len, choice_unf[(size_t)i] = unf;
+        }
+    }
+    for (int i = 0; i < n; ++i) seg_len[i] = 0, unfused[i] = false;
+    for (int i = 0; i < n; i += choice[(size_t)i]) seg_len[i] = choice[(size_t)i], unfused[i] = choice_unf[(size_t)i] != 0;
+    static const bool verbose = getenv("MF_CHAIN_VERBOSE") != nullptr;
+    if (verbose) {
+        fprintf(stderr, "[microflow_amd] chain partition of %d pairs:", n);
+        for (int i = 0; i < n; ++i)
+            if (seg_len[i]) fprintf(stderr, " [%d..%d%s]", i, i + seg_len[i] - 1, unfused[i] ? " unfused" : "");
+        fprintf(stderr, " est %.3f us/image/CU\n", best[0]);
+    }
+}
+
 FusedImpl *fused_create(OpImpl *dw, OpImpl *pw) {
+    static const bool chain_all = getenv("MF_CHAIN_ALL") != nullptr; // tests / A-B: the chain kernel on table shapes too
+    if (dw && pw && (chain_all || dw->fast != OpImpl::DW_NHWC || pw->fast != OpImpl::PW_MFMA ||
+                     !k::dwpw_name(dw->s.H, dw->s.W, dw->s.C, dw->s.sh, pw->s.N))) {
+        const std::pair<OpImpl *, OpImpl *> one(dw, pw);
+        if (FusedImpl *c = chain_create(&one, 1)) return c;
+    }
     if (!dw || !pw || dw->fast != OpImpl::DW_NHWC || pw->fast != OpImpl::PW_MFMA) return nullptr;
     const OpSpec &d = dw->s, &q = pw->s;
     // the pointwise conv must consume exactly the depthwise output tensor
@@ -1174,6 +1319,12 @@ void fused_run(FusedImpl *f, const int8_t *d_in, size_t batch, int8_t *d_out, vo
         const OpSpec &d = f->a->s;
         if (!k::launch_stage(d.H, d.W, d.C, f->stage_pairs, d_in, d_out, f->stage, (int)batch, (hipStream_t)stream))
             fail(MF_ERR_UNSUPPORTED, "stage kernel missing");
+        MF_HIP(hipGetLastError());
+        return;
+    }
+    if (f->kind == FusedImpl::CHAIN) {
+        if (batch > 0x7fffffffull / 4) fail(MF_ERR_INVALID_ARG, "batch too large for one launch");
+        k::launch_chain(d_in, d_out, f->chain, (int)batch, (hipStream_t)stream);
         MF_HIP(hipGetLastError());
         return;
     }
