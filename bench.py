@@ -823,6 +823,8 @@ def runtime_geometry_record(ctx, table_layerwise):
         x = synth_i8(SEED + 6, 0, B * m.input_elems)
         y = torch.empty(B * m.output_elems, dtype=torch.int8, device="cuda")
         fused_ms, _ = m.time_device(x, y, B, warmup=2, iters=10, per_op=False)
+        fused_kernels = sorted({m.op(i)["kernel"].split("<")[0] for i in range(m.num_ops) if m.op(i)["kernel"] and not m.op(i)["kernel"].startswith("(fused")})
+        chains = [m.op(i)["kernel"] for i in range(m.num_ops) if m.op(i)["kernel"].startswith("chain_rt<")]
         idx = [0, 1, B // 2, B - 1]
         ok = bool(np.array_equal(y.reshape(B, -1)[idx].cpu().numpy(), om.run_quantized_batch(x.reshape(B, -1)[idx].cpu().numpy())))
         m.set_fusion(False)
@@ -832,7 +834,8 @@ def runtime_geometry_record(ctx, table_layerwise):
         models["%dx%d_width%s" % (side, side, width)] = {
             "batch": B, "value": round(B / (fused_ms * 1e-3), 1), "unit": "inferences/s", "ms_per_step": round(fused_ms, 4),
             "layerwise_ms": round(lw_ms, 4), "depthwise": kind_agg(rows, "depthwise_conv_2d"), "conv_2d": kind_agg(rows, "conv_2d"),
-            "kernels_used": sorted({r["kernel"].split("<")[0] for r in rows}), "generic_kernels": generic,
+            "kernels_used": fused_kernels, "chains": chains, "layerwise_kernels": sorted({r["kernel"].split("<")[0] for r in rows}),
+            "speedup_vs_layerwise": round(lw_ms / fused_ms, 3), "generic_kernels": generic,
             "parity": {"bit_exact_vs_oracle": ok, "sampled_images": len(idx)}}
         del m, x, y
         torch.cuda.empty_cache()

@@ -29,6 +29,17 @@
 #include <cstring>
 #include <vector>
 
+// tuning switches (scripts/variants.py)
+#ifndef MF_CHAIN_TBM1
+#define MF_CHAIN_TBM1 4   // output tiles per wave block with one k step (K <= 64): 4 or 2
+#endif
+#ifndef MF_CHAIN_RES
+#define MF_CHAIN_RES 0    // 1: a separate reload-free depthwise loop for launches whose operands are resident (measured: the second copy of the loop costs registers -- spills with one k step -- and 12 % of the generated models' chain time; profiles/r04/chain_ab.txt)
+#endif
+#ifndef MF_CHAIN_WPE
+#define MF_CHAIN_WPE 4    // waves per SIMD the register allocation leaves room for (K <= 128)
+#endif
+
 namespace mf {
 namespace k {
 
@@ -40,7 +51,7 @@ struct CDwW {        // depthwise operands of one 16-channel group
 };
 // output tiles per wave block: 4 (a lane ends with 16 consecutive bytes) while one k step's operands fit the register budget of four
 // waves per SIMD, 2 beyond
-template <int KSC> constexpr int chain_tbm() { return KSC == 1 ? 4 : 2; }
+template <int KSC> constexpr int chain_tbm() { return KSC == 1 ? MF_CHAIN_TBM1 : 2; }
 template <int KSC> struct CPwW { // pointwise operands of one block of output tiles
     static constexpr int TBM = chain_tbm<KSC>();
     v4i A[TBM][KSC];
@@ -51,7 +62,7 @@ template <int KSC> struct CPwW { // pointwise operands of one block of output ti
 
 // W16: 16 waves per workgroup (plans whose LDS admits one workgroup per CU: four waves per SIMD all the same)
 template <int KSC, bool W16, int MG, uint32_t XR4>
-__global__ __launch_bounds__(W16 ? 1024 : 512, 4) void chain_rt(const int8_t *__restrict__ in, int8_t *__restrict__ out, ChainArgs p, int batch) {
+__global__ __launch_bounds__(W16 ? 1024 : 512, KSC == 4 ? 2 : (W16 ? 4 : MF_CHAIN_WPE)) void chain_rt(const int8_t *__restrict__ in, int8_t *__restrict__ out, ChainArgs p, int batch) {
     constexpr int NTHR = W16 ? 1024 : 512, NWAVE = NTHR / 64, TBM = chain_tbm<KSC>();
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -150,7 +161,10 @@ __global__ __launch_bounds__(W16 ? 1024 : 512, 4) void chain_rt(const int8_t *__
     // A wave's units are a contiguous range of the list (channel group q, column ux, j = (image group, row)): it is walked in
     // segments of constant (q, ux) -- inside one, the lane's operand address is a per-segment VGPR plus a scalar offset from
     // the host's table, and the unit loop is one branch-free block.
-    auto dw_phase = [&](c_pair &cp, CDwW &wd, int tile_base) { // wd: the operands of this wave's first channel group, already on their way
+    // RES (compile time): the wave's operands stay what they are for the whole launch -- no reload code in the loop, hence no
+    // vmcnt wait there (a wait for an operand reload would also wait for the step-ahead staging DMAs: both count on vmcnt)
+    auto dw_phase = [&](c_pair &cp, CDwW &wd, int tile_base, auto resc) { // wd: the operands of this wave's first channel group, already on their way
+        constexpr bool RES = decltype(resc)::value;
         const int S = cp.S, C = cp.C, ROW = cp.ROW, sh = cp.swz_sh, mask = cp.swz_mask;
         const int lgCX = cp.lgCX, lgCY = cp.lgCY, CXv = 1 << lgCX, CYv = 1 << lgCY;
         const int gg = g < 2 ? g : 2; // tap column of this lane group (g == 3 meets zero weights: any readable bytes will do)
@@ -171,22 +185,27 @@ __global__ __launch_bounds__(W16 ? 1024 : 512, 4) void chain_rt(const int8_t *__
             const int xin = xin0 + ux * XSTEP;
             const int a_seg = tb0 + ux * T_UX + ((q ^ ((xin >> sh) & mask)) << 4);
             const int m_seg = mb0 + q * PLANE + ux * M_UX;
-            i32x2 e = rt[j];
-            v4i t0 = *(const v4i *)(lds + a_seg + e[0]), t1 = *(const v4i *)(lds + a_seg + e[0] + ROW), t2 = *(const v4i *)(lds + a_seg + e[0] + 2 * ROW);
+            // unit offsets come from the host's table by scalar loads issued two units ahead (the wait that covers a unit's tap
+            // loads then finds the entry of the unit after next already there)
+            i32x2 e0 = rt[j], e1 = rt[j + (seg > 1 ? 1 : 0)];
+            v4i t0 = *(const v4i *)(lds + a_seg + e0[0]), t1 = *(const v4i *)(lds + a_seg + e0[0] + ROW), t2 = *(const v4i *)(lds + a_seg + e0[0] + 2 * ROW);
             for (int k = 0; k < seg; ++k) {
+                const i32x2 e2 = rt[j + (k + 2 < seg ? k + 2 : seg - 1)];
                 v4i acc = {wd.k.x, wd.k.y, wd.k.z, wd.k.w};
                 acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(wd.A[0], t0, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(wd.A[1], t1, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(wd.A[2], t2, acc, 0, 0, 0);
-                const int cur_m = e[1];
-                e = rt[j + (k + 1 < seg ? k + 1 : k)]; // the last unit of a segment prefetches itself (no branch)
-                t0 = *(const v4i *)(lds + a_seg + e[0]), t1 = *(const v4i *)(lds + a_seg + e[0] + ROW), t2 = *(const v4i *)(lds + a_seg + e[0] + 2 * ROW);
-                *(uint32_t *)(lds + m_seg + cur_m) = requant_pack4<MG, XR4>(acc[0], acc[1], acc[2], acc[3], wd.a, wd.s, lo, hi);
+                // the next unit's taps (the last unit of a segment prefetches itself: no branch)
+                t0 = *(const v4i *)(lds + a_seg + e1[0]), t1 = *(const v4i *)(lds + a_seg + e1[0] + ROW), t2 = *(const v4i *)(lds + a_seg + e1[0] + 2 * ROW);
+                *(uint32_t *)(lds + m_seg + e0[1]) = requant_pack4<MG, XR4>(acc[0], acc[1], acc[2], acc[3], wd.a, wd.s, lo, hi);
+                e0 = e1, e1 = e2;
             }
             n -= seg, j = 0;
             if (++ux == UX) {
                 ux = 0, ++q;
-                if (n > 0) wd = load_dw(cp, q); // (a wave's range crosses into the next channel group)
+                if constexpr (!RES) {
+                    if (n > 0) wd = load_dw(cp, q); // (a wave's range crosses into the next channel group)
+                }
             }
         }
     };
@@ -236,7 +255,7 @@ __global__ __launch_bounds__(W16 ? 1024 : 512, 4) void chain_rt(const int8_t *__
 #pragma unroll
                 for (int t = 0; t < TB; ++t) acc[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wp.A[t][ks], B[ks], acc[t], 0, 0, 0);
             uint32_t packed[TB];
-            if constexpr (TB % 2 == 0) {
+            if constexpr (TB == 2) { // (with four tiles the interleaved packs cost more registers than four waves per SIMD leave)
 #pragma unroll
                 for (int t = 0; t < TB; t += 2)
                     requant_pack4x2<MG, XR4>(acc[t], wp.a[t], wp.s[t], acc[t + 1], wp.a[t + 1], wp.s[t + 1], lo, hi, packed[t], packed[t + 1]);
@@ -322,7 +341,8 @@ __global__ __launch_bounds__(W16 ? 1024 : 512, 4) void chain_rt(const int8_t *__
         for (int pi = 0; pi < NP; ++pi) {
             c_pair &cp = pairs[pi];
             if (!persist) wp = load_pw(cp); // lands during the depthwise phase
-            dw_phase(cp, wd, cp.tile_off + (pi == 0 ? cur * p.dbuf_stride : 0));
+            if (MF_CHAIN_RES && dw_resident) dw_phase(cp, wd, cp.tile_off + cur * p.dbuf_stride, std::integral_constant<bool, true>{});
+            else dw_phase(cp, wd, cp.tile_off + (pi == 0 ? cur * p.dbuf_stride : 0), std::integral_constant<bool, false>{});
             __syncthreads(); // MID complete; the tile has been read
             if (!dbuf && pi == p.stage_after && dq.nxt < nsteps) stage(dq.nxt, 0); // pair 0's tile region is free: the next step's images fly under the rest of this step
             if (!dw_resident) {
@@ -414,7 +434,7 @@ bool chain_plan(const ChainGeom *g, int n, ChainPair *pairs, ChainArgs &a, int l
         }
     }
     // output tiles per wave block (the kernel's register budget: chain_tbm) and blocks: nt = TB * NBLK, NBLK a power of two <= 8
-    const int TBM = KSC == 1 ? 4 : 2;
+    const int TBM = KSC == 1 ? MF_CHAIN_TBM1 : 2;
     for (int i = 0; i < n; ++i) {
         ChainPair &c = pairs[i];
         const int nt = c.N / 16;
@@ -434,7 +454,8 @@ bool chain_plan(const ChainGeom *g, int n, ChainPair *pairs, ChainArgs &a, int l
             ChainPair &c = pairs[i];
             // pair i reads the tile pair i-1 wrote: the same region as pair i-1's OWN input if the geometry class (and zero point) agree
             bool share = i > 0 && pairs[i - 1].H == c.H && pairs[i - 1].W == c.W && pairs[i - 1].C == c.C && g[i - 1].izp4 == g[i].izp4 &&
-                         pairs[i - 1].S == 1 && !(dbuf && i == 1); // (a double-buffered input tile is never a pointwise destination)
+                         pairs[i - 1].S == 1 && pairs[i - 1].ROW == c.ROW && pairs[i - 1].TILE == c.TILE && // (the pitches are per pair: bank model)
+                         !(dbuf && i == 1); // (a double-buffered input tile is never a pointwise destination)
             if (share) c.tile_off = pairs[i - 1].tile_off;
             else {
                 c.tile_off = off;
@@ -474,13 +495,15 @@ bool chain_plan(const ChainGeom *g, int n, ChainPair *pairs, ChainArgs &a, int l
     // ---- cost model (microseconds per image and CU): every phase costs its requantised bytes over the rate a workgroup gets
     // (times the imbalance of its work list over the waves) but never less than a phase's latency (dependent chain + barrier);
     // the chain's HBM bytes are the other roof.  Calibrated on the generated models (profiles/r04/chain_*).
+    static const double opcost = [] { const char *e = getenv("MF_CHAIN_OPCOST"); return e ? atof(e) : 1.0; }(); // (tuning: weight of the operand-reload term)
     auto estimate = [&](int G, int lds, int &nwave_out) {
-        const int wgs = lds > 80 * 1024 ? 1 : 2;
+        const int wgs = (KSC == 4 || lds > 80 * 1024) ? 1 : 2; // (four k steps: 2 waves per SIMD and one workgroup per CU)
         const int nwave = (wgs == 1 && KSC == 1) ? 16 : 8;
         nwave_out = nwave;
         const double waves_per_simd = wgs * nwave / 4.0;
         const double r_cu = waves_per_simd >= 4.0 ? 14.0e3 : 8.0e3; // requantised bytes per microsecond and CU this kernel sustains
-        const double r_wg = r_cu / wgs, t_lat = 0.9, t_step = 0.6;
+        const double r_wg = r_cu / wgs, t_lat = 0.9, t_step = 1.8; // (t_step: what a step costs beyond its phases -- queue draw, top barrier, the
+                                                                 // first operand wait behind the staging DMAs; measured 1.5 - 2.5 us on the generated models)
         double step = t_step;
         for (int i = 0; i < n; ++i) {
             const ChainPair &c = pairs[i];
@@ -491,7 +514,9 @@ bool chain_plan(const ChainGeom *g, int n, ChainPair *pairs, ChainArgs &a, int l
             step += std::max(t_lat, (double)G * c.OH * c.OW * c.C * imb_d / r_wg) + std::max(t_lat, (double)G * c.OH * c.OW * c.N * imb_p / r_wg);
             // a chain (n > 1) fetches the operands of every phase again in every step: ~4 KB per wave for a depthwise phase,
             // (TB KS + TB) KB for a pointwise one, through the CU's vector L1 at ~100 KB per microsecond
-            if (n > 1) step += nwave * (4.0 + c.TB * c.KS + c.TB) / 100.0 * wgs;
+            // Measured (profiles/r04/chain_opcost.txt): at G >= 4 the fetches mostly hide under the phases (six 4x4x128 pairs in one
+            // launch: 1.12 ms against 1.50 as six launches), at G = 1 - 2 they do not (64x64x16 s2 + 32x32x32: 1.77 against 1.31).
+            if (n > 1) step += opcost * (G >= 4 ? 0.3 : 1.5) * nwave * (4.0 + c.TB * c.KS + c.TB) / 100.0 * wgs;
         }
         const double compute = step / (G * wgs);
         const double hbm = ((double)g[0].H * g[0].W * g[0].C + (double)g[n - 1].OH * g[n - 1].OW * g[n - 1].N) / 17.0e3;

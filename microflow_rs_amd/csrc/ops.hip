@@ -491,7 +491,7 @@ OpImpl *op_create(int device, const OpSpec &spec) {
             f.izp4 = 0x01010101u * (uint32_t)(uint8_t)(int8_t)s.izp;
             f.lo_f = a.lo_f, f.hi_f = a.hi_f, f.magic = magic, f.xr = xr, f.queue = (int *)op->d_queue.p;
             op->dwrt.wzp = a.wzp;
-            if (!op->rt_wz && s.C % 16 == 0) { // matrix-pipe form of the taps: what the fused chain kernel (k_chain.hip) multiplies
+            if (!op->rt_wz && (s.C % 16 == 0 || s.C == 8)) { // matrix-pipe form of the taps: what the fused chain kernel (k_chain.hip) multiplies
                 const std::vector<int8_t> prep = build_dw_mm_weights(s.weights, s.C);
                 op->d_wprep.upload(prep.data(), prep.size());
                 f.wmm = op->d_wprep.p;
@@ -914,13 +914,24 @@ static bool chain_pair_ok(const OpImpl *dw, const OpImpl *pw) {
     if (dw->fast != OpImpl::DW_RT && dw->fast != OpImpl::DW_NHWC) return false;
     const k::DwFastArgs &f = dw->fast == OpImpl::DW_NHWC ? dw->dwf : dw->dwrt.dw;
     if (!f.wmm || (dw->fast == OpImpl::DW_RT && dw->rt_wz)) return false;
-    if (d.KH != 3 || d.KW != 3 || d.pad != MF_PAD_SAME || d.sh != d.sw || (d.sh != 1 && d.sh != 2) || d.C != d.N || d.C % 16 != 0) return false;
-    if (q.KH != 1 || q.KW != 1 || q.sh != 1 || q.sw != 1 || q.OH != q.H || q.OW != q.W || q.N % 16 != 0) return false;
+    if (d.KH != 3 || d.KW != 3 || d.pad != MF_PAD_SAME || d.sh != d.sw || (d.sh != 1 && d.sh != 2) || d.C != d.N) return false;
+    if (d.C % 16 != 0 && !(d.C == 8 && d.sh == 1 && d.W % 2 == 0)) return false; // (C == 8: pixel pairs, see chain_geom)
+    if (q.KH != 1 || q.KW != 1 || q.sh != 1 || q.sw != 1 || q.OH != q.H || q.OW != q.W || (d.C == 8 ? 2 * q.N : q.N) % 16 != 0) return false;
     if (q.H != d.OH || q.W != d.OW || q.C != d.N) return false;
     if (pw->fast != OpImpl::PW_RT && pw->fast != OpImpl::PW_MFMA) return false;
     if (pw->fast == OpImpl::PW_RT && pw->rt_wz) return false;
     if (!dw->finite_consts || !pw->finite_consts || dw->magic_mode < 1 || pw->magic_mode < 1) return false;
     return true;
+}
+// The geometry the planner sees.  C == 8, stride 1 (the first pair of a MobileNet-v1-shaped network): two adjacent pixels form one
+// 16-channel "superpixel" -- the depthwise taps are build_dw_mm_weights' pair form (MFMA rows = (pixel parity, channel), filter-row
+// blocks = neighbouring superpixels), the 1x1 convolution is block diagonal over the two pixels -- so the pair IS a 16-channel pair
+// of half the width with twice the outputs.  Such a pair only ever runs alone (its output tensor is not in the next pair's units).
+static k::ChainGeom chain_geom(const OpImpl *dw, const OpImpl *pw) {
+    const OpSpec &d = dw->s;
+    const k::DwFastArgs &f = dw->fast == OpImpl::DW_NHWC ? dw->dwf : dw->dwrt.dw;
+    if (d.C == 8) return k::ChainGeom{d.H, d.W / 2, 16, 1, d.OH, d.OW / 2, 2 * pw->s.N, f.izp4};
+    return k::ChainGeom{d.H, d.W, d.C, d.sh, d.OH, d.OW, pw->s.N, f.izp4};
 }
 static FusedImpl *chain_create(const std::pair<OpImpl *, OpImpl *> *mem, int n) {
     if (!chain_enabled() || n < 1 || n > k::CHAIN_MAX) return nullptr;
@@ -928,9 +939,8 @@ static FusedImpl *chain_create(const std::pair<OpImpl *, OpImpl *> *mem, int n) 
     for (int i = 0; i < n; ++i) {
         if (!chain_pair_ok(mem[i].first, mem[i].second)) return nullptr;
         if (mem[i].first->device != mem[0].first->device || mem[i].first->s.u8 != mem[0].first->s.u8) return nullptr;
-        const OpSpec &d = mem[i].first->s, &q = mem[i].second->s;
-        const k::DwFastArgs &f = mem[i].first->fast == OpImpl::DW_NHWC ? mem[i].first->dwf : mem[i].first->dwrt.dw;
-        geo[(size_t)i] = k::ChainGeom{d.H, d.W, d.C, d.sh, d.OH, d.OW, q.N, f.izp4};
+        if (mem[i].first->s.C == 8 && n != 1) return nullptr;
+        geo[(size_t)i] = chain_geom(mem[i].first, mem[i].second);
     }
     std::vector<k::ChainPair> tab((size_t)n);
     std::unique_ptr<FusedImpl> c(new FusedImpl{FusedImpl::CHAIN, mem[0].first, mem[n - 1].second, nullptr, {}, {}, ""});
@@ -943,13 +953,26 @@ static FusedImpl *chain_create(const std::pair<OpImpl *, OpImpl *> *mem, int n) 
         k::ChainPair &t = tab[(size_t)i];
         t.dw_wmm = f.wmm, t.dwA = f.A, t.dwS = f.S, t.dwK = f.Kc, t.dw_lo = f.lo_f, t.dw_hi = f.hi_f;
         const OpSpec &q = pw->s;
+        const int group = dw->s.C == 8 ? 2 : 1; // pixels per MFMA column / product row
         std::vector<int8_t> host((size_t)q.N * q.C);
         MF_HIP(hipMemcpy(host.data(), pw->conv.w, host.size(), hipMemcpyDeviceToHost)); // [N][1][1][C], i8 domain, as uploaded
-        const std::vector<int8_t> prep = build_pw_rt_reg_weights(host.data(), q.C, q.N, 1, t.TB, t.NBLK);
+        const std::vector<int8_t> prep = build_pw_rt_reg_weights(host.data(), q.C, q.N, group, t.TB, t.NBLK);
         c->stage_w.emplace_back(new DevBuf);
         c->stage_w.back()->upload(prep.data(), prep.size());
         t.pw_w = c->stage_w.back()->p;
         t.pwA = pw->conv.A, t.pwS = pw->conv.S, t.pwK = pw->conv.Kc, t.pw_lo = pw->conv.lo_f, t.pw_hi = pw->conv.hi_f;
+        if (group == 2) { // the constants of MFMA row (pixel parity, channel) are the channel's: both halves hold the same arrays
+            auto twice = [&](const void *d_src, int count) {
+                std::vector<int32_t> h((size_t)2 * count);
+                MF_HIP(hipMemcpy(h.data(), d_src, (size_t)count * 4, hipMemcpyDeviceToHost));
+                for (int e = 0; e < count; ++e) h[(size_t)count + e] = h[(size_t)e];
+                c->stage_w.emplace_back(new DevBuf);
+                c->stage_w.back()->upload(h.data(), h.size() * 4);
+                return c->stage_w.back()->p;
+            };
+            t.dwA = (const float *)twice(f.A, 8), t.dwS = (const float *)twice(f.S, 8), t.dwK = (const int *)twice(f.Kc, 8);
+            t.pwA = (const float *)twice(pw->conv.A, q.N), t.pwS = (const float *)twice(pw->conv.S, q.N), t.pwK = (const int *)twice(pw->conv.Kc, q.N);
+        }
         {
             std::vector<int> rt;
             k::chain_rtab(t, rt);
@@ -988,9 +1011,7 @@ void fused_chain_partition(FusedImpl *const *groups, int n, int *seg_len, bool *
     std::vector<k::ChainGeom> geo((size_t)n);
     for (int i = 0; i < n; ++i) {
         const std::pair<OpImpl *, OpImpl *> &m = groups[i]->chain_members[0];
-        const OpSpec &d = m.first->s;
-        const k::DwFastArgs &f = m.first->fast == OpImpl::DW_NHWC ? m.first->dwf : m.first->dwrt.dw;
-        geo[(size_t)i] = k::ChainGeom{d.H, d.W, d.C, d.sh, d.OH, d.OW, m.second->s.N, f.izp4};
+        geo[(size_t)i] = chain_geom(m.first, m.second);
     }
     static const bool force_fuse = getenv("MF_CHAIN_FORCE") != nullptr; // tests: never prefer the unfused operators
     const double INF = 1e30;
@@ -1003,7 +1024,8 @@ void fused_chain_partition(FusedImpl *const *groups, int n, int *seg_len, bool *
         for (int len = 1; len <= n - i && len <= k::CHAIN_MAX; ++len) {
             k::ChainArgs a{};
             bool ok = true;
-            for (int j = i; j < i + len && ok; ++j) ok = groups[j]->chain_members[0].first->s.u8 == groups[i]->chain_members[0].first->s.u8;
+            for (int j = i; j < i + len && ok; ++j)
+                ok = groups[j]->chain_members[0].first->s.u8 == groups[i]->chain_members[0].first->s.u8 && (len == 1 || groups[j]->chain_members[0].first->s.C != 8);
             if (!ok || !k::chain_plan(geo.data() + i, len, tab.data(), a, 150 * 1024)) {
                 if (len == 1) { // (cannot happen for a group that exists; keep the programme total)
                     if (best[(size_t)i + 1] < best[(size_t)i]) best[(size_t)i] = best[(size_t)i + 1], choice[(size_t)i] = 1, choice_unf[(size_t)i] = 1;
