@@ -111,6 +111,29 @@ def self_launch(args):
     raise SystemExit(subprocess.call(cmd, env=env))
 
 
+def requant_peak(mode):
+    """the measured requantisation ceiling (GB/s) of the epilogue form a launch runs (k_common.hpp modes 0 / 1 / 2)"""
+    forms = (REQUANT_CEILING or {}).get("forms", {})
+    name = {2: "mode2_saturating_pack", 1: "mode1_med3", 0: "round2_form"}.get(mode, "mode2_saturating_pack")
+    return forms.get(name, {}).get("GBps", REQUANT_PEAK_GBS)
+
+
+def sq_counters(kernel):
+    """Independent of the microbenchmark: per-kernel figures from the committed rocprofv3 SQ counter passes of this same
+    command (profiles/sq_latest.json = scripts/sq_derived.py --json).  valu_busy = VALU wave-instructions per SIMD clock / 0.5
+    (a wave64 instruction occupies a SIMD-32 for at least two clocks, so 0.5 per clock is the issue ceiling)."""
+    try:
+        sq = json.load(open(os.path.join(ROOT, "profiles", "sq_latest.json")))
+        k = sq["kernels"].get(kernel)
+        if k:
+            return {"valu_busy": k["valu_busy"], "valu_inst_per_clk_per_simd": k["valu_inst_per_clk_per_simd"],
+                    "lds_bank_conflict_ratio": k["lds_bank_conflict_ratio"], "shader_clock_GHz": k.get("shader_clock_GHz"),
+                    "source": "profiles/sq_latest.json"}
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
+
+
 def pmc_traffic(kernel, count):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/pmc_traffic_latest.json =
     scripts/pmc_summary.py over separate --pmc FETCH_SIZE / WRITE_SIZE passes of this same command)."""
@@ -282,9 +305,13 @@ def main():
                 rq = sum(descs[j]["out_elems"] for j in range(i, last + 1) if descs[j]["name"] not in ("reshape",)) * count
                 rq_gbs = rq / (per_op[i] * 1e-3) / 1e9 if per_op[i] > 0 else 0.0
                 nops_in_group = sum(1 for j in range(i, last + 1) if descs[j]["name"] != "reshape")
+                # the launch's own requantisation form (a fused launch runs the weakest form any of its operators needs) and
+                # that form's measured ceiling
+                mode = m.op_epilogue_mode(i)
+                peak = requant_peak(mode)
                 # the binding roof is the one that gives the longer time floor: HBM for the algorithmic bytes, or the
                 # VALU for the bytes that go through the reference's f32 requantisation
-                bound = "valu" if rq / REQUANT_PEAK_GBS > nbytes / HBM_PEAK_GBS else "hbm"
+                bound = "valu" if rq / peak > nbytes / HBM_PEAK_GBS else "hbm"
                 if d["kernel"].startswith("quad_rr"):
                     kind = "quad(2 pairs)"   # two depthwise+pointwise pairs in one launch (k_quad.hip)
                 elif d["kernel"].startswith("penta_rr"):
@@ -296,8 +323,9 @@ def main():
                              "bytes": nbytes, "GBps": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4),
                              "hbm_frac": round(gbs / HBM_PEAK_GBS, 4),
                              "requant_bytes": rq, "requant_GBps": round(rq_gbs, 1),
-                             "requant_frac": round(rq_gbs / REQUANT_PEAK_GBS, 4),
-                             "valu_frac": round(rq_gbs / REQUANT_PEAK_GBS, 4)})
+                             "epilogue_mode": mode, "requant_peak_GBps": peak,
+                             "requant_frac": round(rq_gbs / peak, 4),
+                             "valu_frac": round(rq_gbs / peak, 4), "sq": sq_counters(d["kernel"])})
             return avg_ms, rows
 
         def agg(rows, kind):
@@ -319,23 +347,26 @@ def main():
         roofline = {"bound": dom["bound"], "kernel": dom["kernel"], "op": dom["op"], "kind": dom["kind"], "ms": dom["ms"],
                     "achieved": dom["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["frac"],
                     "hbm_frac": dom["hbm_frac"], "valu_frac": dom["valu_frac"],
-                    "requant_GBps": dom["requant_GBps"], "requant_peak_GBps": REQUANT_PEAK_GBS,
+                    "requant_GBps": dom["requant_GBps"], "requant_peak_GBps": dom["requant_peak_GBps"], "epilogue_mode": dom["epilogue_mode"],
+                    "valu_busy": (dom["sq"] or {}).get("valu_busy"),
                     "algorithmic_bytes": dom["bytes"], "requant_bytes": dom["requant_bytes"],
                     "traffic": traffic, "traffic_source": traffic_src,
                     "method": "HIP events on the launch stream, median of %d launches" % iters,
                     "note": "the longest launch of the step.  achieved / peak / frac: algorithmic bytes per launch / its "
                             "duration vs the 8 TB/s HBM peak; valu_frac: every int8 byte the launch requantises (on chip or "
-                            "not) / its duration vs the requantisation ceiling measured in this run (`requant_ceiling`); "
+                            "not) / its duration vs the ceiling, measured in this run, of the requantisation form the launch runs "
+                            "(`epilogue_mode`, `requant_ceiling`); valu_busy: VALU wave-instructions per SIMD clock / 0.5 from the "
+                            "committed SQ counter pass -- independent of that microbenchmark; "
                             "`bound` = the roof with the longer time floor"}
         step_bytes = sum(k["bytes"] for k in kernels)
         step_rq = sum(k["requant_bytes"] for k in kernels)
-        floor_ms = sum(max(k["bytes"] / HBM_PEAK_GBS, k["requant_bytes"] / REQUANT_PEAK_GBS) for k in kernels) / 1e6
+        floor_ms = sum(max(k["bytes"] / HBM_PEAK_GBS, k["requant_bytes"] / k["requant_peak_GBps"]) for k in kernels) / 1e6
         whole_step = {"ms": round(ev_med, 4), "launches": len(kernels),
                       "algorithmic_bytes": step_bytes, "GBps": round(step_bytes / (ev_med * 1e-3) / 1e9, 1),
                       "frac": round(step_bytes / (ev_med * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                       "hbm_frac": round(step_bytes / (ev_med * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                       "requant_bytes": step_rq, "requant_GBps": round(step_rq / (ev_med * 1e-3) / 1e9, 1),
-                      "valu_frac": round(step_rq / (ev_med * 1e-3) / 1e9 / REQUANT_PEAK_GBS, 4),
+                      "valu_frac": round(sum(k["requant_bytes"] / k["requant_peak_GBps"] for k in kernels) / 1e6 / ev_med, 4),
                       "roof_floor_ms": round(floor_ms, 4), "frac_of_roof_floor": round(floor_ms / ev_med, 4),
                       # fusing launches removes algorithmic bytes, so hbm_frac falls as the step gets faster; for comparison
                       # with earlier rounds: the bytes of round 2's ten launches (pairs + stage + tail) over this step's time

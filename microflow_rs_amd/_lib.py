@@ -88,6 +88,7 @@ SIGNATURES = {
     "mf_model_get_info": (C.c_int, [_vp, C.POINTER(ModelInfo)]),
     "mf_model_get_op": (C.c_int, [_vp, C.c_int, C.POINTER(OpDesc)]),
     "mf_model_get_op_constants": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp]),
+    "mf_model_get_op_epilogue_mode": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_int)]),
     "mf_model_prepare": (C.c_int, [_vp, C.c_int, C.c_size_t]),
     "mf_model_set_stream": (C.c_int, [_vp, _vp]),
     "mf_model_sync": (C.c_int, [_vp]),

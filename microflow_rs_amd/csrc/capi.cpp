@@ -393,6 +393,13 @@ int mf_model_get_op(const mf_model *model, int index, mf_op_desc *d) {
     })
 }
 
+int mf_model_get_op_epilogue_mode(const mf_model *model, int index, int *mode) {
+    MF_TRY({
+        MF_NEED(model && model->impl && mode);
+        *mode = mf::model_op_epilogue_mode(model->impl, index);
+    })
+}
+
 int mf_model_get_op_constants(const mf_model *model, int index, float *c0, float *c1, int32_t *c2,
                               int32_t *c3) {
     MF_TRY({

@@ -493,9 +493,13 @@ __global__ __launch_bounds__(512) void conv_rows_lds(const int8_t *__restrict__ 
 //             4 TB consecutive output channels (as pw_rt); read once per 16-pixel chunk and block.
 //   WZ      : filter zero points (conv_2d.rs:57-63): one more tile of ones gives the window sum.
 // ------------------------------------------------------------------------
-template <bool WZ, int MG, uint32_t XR4>
-__global__ __launch_bounds__(256) void conv_mm_rt(const int8_t *__restrict__ in, int8_t *__restrict__ out, ConvMmArgs p, int batch) {
-    constexpr int NTHR = 256, NWAVE = 4;
+//   NTHR    : 256, several workgroups per CU -- or, when the weight image leaves room for ONE workgroup per CU only, 1024: the
+//             16 waves share that one copy of the weights and a step of up to 32 images (round 3 ran such shapes with four
+//             waves per CU, each step a DMA wait and two barriers for 4 - 7 images: 85 - 139 TMAC/s, 0.04 VALU instructions
+//             per clock and SIMD).
+template <bool WZ, int MG, uint32_t XR4, int NTHR>
+__global__ __launch_bounds__(NTHR) void conv_mm_rt(const int8_t *__restrict__ in, int8_t *__restrict__ out, ConvMmArgs p, int batch) {
+    constexpr int NWAVE = NTHR / 64;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -851,10 +855,21 @@ bool conv_mm_plan(ConvMmArgs &a, std::vector<int> &tap, int H, int W, int C, int
     a.padl = padl, a.padt = padt, a.LP = LP, a.ROW = ROW, a.KS = KS, a.TB = TB, a.NBLK = NBLK;
     const int budget = 150 * 1024 - wbytes - 1024;
     auto rows_for = [&](int bh) { return (bh - 1) * sh + KH; };
+    a.NTHR = 256;
     if (rows_for(OH) * ROW <= budget && rows_for(OH) * ROW <= 48 * 1024) {
         a.NBANDS = 1, a.BH = OH, a.RB = rows_for(OH), a.TILE = a.RB * ROW;
         int g = std::min(48 * 1024, budget) / a.TILE;
         a.G = g < 1 ? 1 : (g > 16 ? 16 : g);
+        // Does a second workgroup fit beside this one?  If not, one 16-wave workgroup with a step as large as the LDS allows
+        // (whole chunks per wave: 16 waves x 16 pixels).
+        static const bool small_wg = getenv("MF_CONV_MM_256") != nullptr; // A/B: round 3's four-wave workgroups
+        if (!small_wg && 2 * (a.G * a.TILE + wbytes + 1024) > 160 * 1024) {
+            int gg = budget / a.TILE;
+            gg = gg > 32 ? 32 : gg;
+            const int opix = OH * OW;
+            while (gg > 1 && (gg * opix) % 256 != 0 && ((gg - 1) * opix + 255) / 256 == (gg * opix + 255) / 256) --gg; // no smaller step with as many rounds
+            if (gg >= 1) a.G = gg, a.NTHR = 1024;
+        }
     } else {
         int bh = OH;
         const int cap = std::min(budget, 48 * 1024);
@@ -874,8 +889,8 @@ bool conv_mm_plan(ConvMmArgs &a, std::vector<int> &tap, int H, int W, int C, int
         }
     return conv_mm_lds_bytes(a, wz) <= 160 * 1024;
 }
-template <bool WZ, int MG, uint32_t XR4>
-static void launch_conv_mm_t(const int8_t *in, int8_t *out, const ConvMmArgs &a, int batch, hipStream_t s) {
+template <bool WZ, int MG, uint32_t XR4, int NTHR>
+static void launch_conv_mm_n(const int8_t *in, int8_t *out, const ConvMmArgs &a, int batch, hipStream_t s) {
     const int lds = conv_mm_lds_bytes(a, WZ);
     int per_cu = 1;
     {
@@ -886,9 +901,9 @@ static void launch_conv_mm_t(const int8_t *in, int8_t *out, const ConvMmArgs &a,
         std::lock_guard<std::mutex> lock(mu);
         auto it = cache.find({dev, lds});
         if (it == cache.end()) {
-            (void)hipFuncSetAttribute((const void *)conv_mm_rt<WZ, MG, XR4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void *)conv_mm_rt<WZ, MG, XR4, NTHR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             int n = 1;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_mm_rt<WZ, MG, XR4>, 256, (size_t)lds) != hipSuccess || n < 1) {
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_mm_rt<WZ, MG, XR4, NTHR>, NTHR, (size_t)lds) != hipSuccess || n < 1) {
                 (void)hipGetLastError();
                 n = 1;
             }
@@ -898,7 +913,12 @@ static void launch_conv_mm_t(const int8_t *in, int8_t *out, const ConvMmArgs &a,
     }
     const int nsteps = ((batch + a.G - 1) / a.G) * a.NBANDS;
     const int grid = nsteps < 256 * per_cu ? nsteps : 256 * per_cu;
-    hipLaunchKernelGGL((conv_mm_rt<WZ, MG, XR4>), dim3(grid), dim3(256), lds, s, in, out, a, batch);
+    hipLaunchKernelGGL((conv_mm_rt<WZ, MG, XR4, NTHR>), dim3(grid), dim3(NTHR), lds, s, in, out, a, batch);
+}
+template <bool WZ, int MG, uint32_t XR4>
+static void launch_conv_mm_t(const int8_t *in, int8_t *out, const ConvMmArgs &a, int batch, hipStream_t s) {
+    if (a.NTHR == 1024) launch_conv_mm_n<WZ, MG, XR4, 1024>(in, out, a, batch, s);
+    else launch_conv_mm_n<WZ, MG, XR4, 256>(in, out, a, batch, s);
 }
 void launch_conv_mm(const int8_t *in, int8_t *out, const ConvMmArgs &a, bool wz, int batch, hipStream_t s) {
     const int mg = a.magic;

@@ -178,6 +178,7 @@ struct ConvMmArgs {
     int padl, padt;      // SAME: (KW - 1) / 2, (KH - 1) / 2 (src/tensor.rs:193); VALID: 0
     int LP, ROW, RB, TILE, G, BH, NBANDS; // tile geometry as DwRtArgs
     int KS, TB, NBLK;    // 64-deep k steps over K = KH KW C; tiles per block (<= 4); blocks
+    int NTHR;            // threads per workgroup: 256, or 1024 when the weights leave room for one workgroup per CU only
     uint32_t izp4;
     float lo_f, hi_f;
     const void *wprep;   // [block][tile][k step][lane] x 16 bytes (+ a tile of ones per k step when filter zero points != 0)

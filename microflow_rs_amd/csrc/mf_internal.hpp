@@ -106,6 +106,7 @@ void op_run_external(OpImpl *op, const int8_t *d_in, size_t batch, int8_t *d_out
 size_t op_in_elems(const OpImpl *op);
 size_t op_out_elems(const OpImpl *op);
 const char *op_kernel_name(const OpImpl *op);
+int op_epilogue_mode(const OpImpl *op); // k_common.hpp epilogue mode (0, 1, 2) the operator's constants admit; -1: no requantising epilogue of that kind
 void op_set_generic(OpImpl *op, bool generic);
 // fuse the model-boundary quantize (f32 -> T) into this operator if it has an f32-input kernel
 bool op_set_input_quant(OpImpl *op, float scale, int zp, bool u8);
@@ -157,6 +158,7 @@ ModelImpl *model_create(const uint8_t *buf, size_t len);
 void model_destroy(ModelImpl *m);
 const ParsedModel &model_parsed(const ModelImpl *m);
 const char *model_op_kernel(const ModelImpl *m, int i);
+int model_op_epilogue_mode(const ModelImpl *m, int i); // of the launch that starts at operator i: the minimum over its operators
 void model_prepare(ModelImpl *m, int device, size_t max_batch);
 void model_set_stream(ModelImpl *m, void *stream);
 void model_sync(ModelImpl *m);

@@ -707,6 +707,9 @@ const char *op_kernel_name(const OpImpl *op) {
                                                              : op->generic_name.c_str();
 }
 void op_set_generic(OpImpl *op, bool g) { op->force_generic = g; }
+int op_epilogue_mode(const OpImpl *op) { // -1: not a convolution-like operator
+    return (op->s.kind == MF_OP_CONV_2D || op->s.kind == MF_OP_DEPTHWISE_CONV_2D) ? op->magic_mode : -1;
+}
 
 void op_run(OpImpl *op, const int8_t *d_in, size_t batch, int8_t *d_out, void *stream) {
     if (!batch) return;

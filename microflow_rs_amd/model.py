@@ -55,6 +55,12 @@ class Model:
                     out_scale=np.float32(d.out_scale), in_zp=d.in_zero_point, out_zp=d.out_zero_point,
                     out_elems=d.out_elems, kernel=(d.kernel or b"").decode())
 
+    def op_epilogue_mode(self, i):
+        """requantisation form (k_common.hpp: 0, 1, 2) of the launch that starts at operator i of a prepared model; -1: none"""
+        mode = C.c_int(-1)
+        _lib.check(_lib.lib().mf_model_get_op_epilogue_mode(self._h, int(i), C.byref(mode)))
+        return mode.value
+
     @property
     def ops(self):
         return [self.op(i) for i in range(self.num_ops)]

@@ -51,7 +51,7 @@ if [[ $STEPS == all || $STEPS == *prof* ]]; then
   f=$(find $OUT/prof -name "*kernel_stats.csv" | head -1)
   [ -n "$f" ] && head -40 "$f"
 fi
-if [[ $STEPS == *pmc* ]]; then
+if [[ $STEPS == *pmc* && $STEPS != sqpmc ]]; then
   # HBM traffic counters, one --pmc pass per counter (FETCH_SIZE needs 3 of the 4 TCC slots,
   # WRITE_SIZE 2), with --kernel-trace only (MI355X_MICROARCH.md, HBM section)
   for c in FETCH_SIZE WRITE_SIZE; do
@@ -63,6 +63,12 @@ if [[ $STEPS == *pmc* ]]; then
   done
   f=$(find $OUT/pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1)
   [ -n "$f" ] && head -3 "$f"
+  python scripts/pmc_summary.py $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/bench_details.json > $OUT/pmc_traffic.json
+  python - <<'PY'
+import json
+for k in json.load(open("gpurun_out/pmc_traffic.json"))["kernels"]:
+    if "traffic_over_algorithmic" in k: print("%-60s traffic %12d  x%.3f of algorithmic" % (k["kernel"][:60], k["traffic_bytes"], k["traffic_over_algorithmic"]))
+PY
 fi
 if [[ $STEPS == *sqpmc* ]]; then
   # SQ counters (8 slots per pass) for the issue/stall breakdown of every kernel
@@ -91,6 +97,9 @@ with open("gpurun_out/sq_summary.csv", "w") as o:
         o.write('"' + k + '",' + ",".join("%.0f" % (sum(acc[k][n]) / max(len(acc[k][n]), 1)) for n in names) + "\n")
 print(open("gpurun_out/sq_summary.csv").read())
 PY
+  f=$(find $OUT/prof -name "*kernel_stats.csv" | head -1)
+  python scripts/pmc_summary.py --sq $OUT/pmc_sq $OUT/pmc_sq2 $f > $OUT/sq_latest.json
+  head -c 600 $OUT/sq_latest.json
 fi
 if [[ $STEPS == *fcprof* ]]; then
   # kernel stats of the 4096^3 FullyConnected workload alone (BASELINE config 5)

@@ -60,12 +60,54 @@ def short(name):
     return base + args
 
 
+def sq_main(dirs, stats_csv):
+    """python scripts/pmc_summary.py --sq gpurun_out/pmc_sq gpurun_out/pmc_sq2 [kernel_stats.csv] > profiles/sq_latest.json
+    Per kernel (library names), median over launches: VALU wave-instructions per SIMD clock (/ 0.5 = valu_busy: a wave64
+    instruction occupies a SIMD-32 for at least two clocks), LDS bank-conflict ratio, share of wave cycles parked, effective shader
+    clock (cycles per XCD / average duration from the kernel-trace stats of the same command)."""
+    acc = defaultdict(lambda: defaultdict(list))
+    for d in dirs:
+        for f in sorted(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)):
+            for r in csv.DictReader(open(f)):
+                if "mf::k::" in r["Kernel_Name"]:
+                    acc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    dur = {}
+    if stats_csv:
+        for r in csv.DictReader(open(stats_csv)):
+            if "mf::k::" in r["Name"]:
+                dur[short(r["Name"])] = float(r["AverageNs"])
+    med = lambda v: sorted(v)[len(v) // 2] if v else 0.0  # noqa: E731
+    out = {"note": "rocprofv3 --pmc SQ passes of bench.py (scripts/gpu_check.sh STEPS=sqpmc), median over launches; valu_busy = "
+                   "SQ_INSTS_VALU / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs) / 0.5", "kernels": {}}
+    for k in sorted(acc):
+        c = {n: med(v) for n, v in acc[k].items()}
+        cyc = c.get("GRBM_GUI_ACTIVE", 0.0) / 8.0
+        if cyc <= 0:
+            continue
+        v = c.get("SQ_INSTS_VALU", 0.0) / cyc / 1024.0
+        e = {"valu_inst_per_clk_per_simd": round(v, 4), "valu_busy": round(v / 0.5, 4),
+             "lds_bank_conflict_ratio": round(c.get("SQ_LDS_BANK_CONFLICT", 0.0) / c["SQ_LDS_IDX_ACTIVE"], 4) if c.get("SQ_LDS_IDX_ACTIVE") else 0.0,
+             "wait_any_frac": round(c.get("SQ_WAIT_ANY", 0.0) / c["SQ_WAVE_CYCLES"], 4) if c.get("SQ_WAVE_CYCLES") else None,
+             "cycles_per_xcd": round(cyc)}
+        if k in dur and dur[k] > 0:
+            e["shader_clock_GHz"] = round(cyc / dur[k], 3)
+        out["kernels"][k] = e
+    print(json.dumps(out, indent=1))
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--sq":
+        rest = sys.argv[2:]
+        return sq_main([a for a in rest if not a.endswith(".csv")], next((a for a in rest if a.endswith(".csv")), None))
     fetch = load(sys.argv[1], "FETCH_SIZE")
     write = load(sys.argv[2], "WRITE_SIZE")
     bench = None
     if len(sys.argv) > 3:
-        bench = json.loads(open(sys.argv[3]).read().strip().splitlines()[-1])
+        text = open(sys.argv[3]).read().strip()
+        try:
+            bench = json.loads(text)                      # bench_details.json (the full record)
+        except ValueError:
+            bench = json.loads(text.splitlines()[-1])     # a one-line record
     alg = {}
     if bench:
         for k in bench["kernels"] + bench.get("layerwise", {}).get("kernels", []):
