@@ -58,13 +58,29 @@ def measure_requant_ceiling():
         lib = ctypes.CDLL(os.path.join(ROOT, "scripts", "ubench", "libepi_rate.so"))
         lib.mf_ubench_requant_ns.restype = ctypes.c_double
         lib.mf_ubench_requant_ns.argtypes = [ctypes.c_int]
+        # a ceiling is the BEST rate the chip sustains: three repetitions per form, the fastest counts (a repetition that meets
+        # a power-management transient would otherwise understate it)
         for name, v in (("mode2_saturating_pack", 5), ("mode1_med3", 4), ("round2_form", 1)):
-            ns = lib.mf_ubench_requant_ns(v)  # 1 warm-up + 5 timed launches of ~0.7 ms each
-            if ns > 0:
-                rec["forms"][name] = {"ns_per_256B_wave_group_per_simd": round(ns, 2), "GBps": round(1024 * 256 / ns, 1)}
+            reps = [lib.mf_ubench_requant_ns(v) for _ in range(3)]  # each: 1 warm-up + 5 timed launches of ~2.6 ms
+            reps = [r for r in reps if r > 0]
+            if reps:
+                ns = min(reps)
+                rec["forms"][name] = {"ns_per_256B_wave_group_per_simd": round(ns, 2), "GBps": round(1024 * 256 / ns, 1),
+                                      "repetitions_ns": [round(r, 2) for r in reps]}
         if "mode2_saturating_pack" in rec["forms"]:
-            REQUANT_PEAK_GBS = rec["forms"]["mode2_saturating_pack"]["GBps"]
-            rec["used"] = "mode2_saturating_pack"
+            got = rec["forms"]["mode2_saturating_pack"]["GBps"]
+            # Observed once in round 4 (profiles/r04/f_slow_ubench_box.txt): a box whose pure-VALU microbenchmark ran at
+            # 0.73 of every other box's rate while the kernels ran at 0.97 of theirs -- the "ceiling" then sits BELOW what the
+            # kernels reach.  A measurement under 0.85 of the reference figure is reported but not used: the fractions are then priced
+            # against the reference literals (profiles/r03/epi_rate.txt: 6 590 / 6 310 / 5 970 GB/s), and the record says so.
+            if got >= 0.85 * REQUANT_PEAK_GBS:
+                REQUANT_PEAK_GBS = got
+                rec["used"] = "mode2_saturating_pack (measured in this run)"
+            else:
+                rec["used"] = "reference literals: the in-run measurement (%.0f GB/s) is below 0.85 of the reference %.0f GB/s" % (got, REQUANT_PEAK_GBS)
+                rec["suspect"] = True
+                rec["forms_measured"] = rec["forms"]
+                rec["forms"] = {"mode2_saturating_pack": {"GBps": 6590.0}, "mode1_med3": {"GBps": 6310.0}, "round2_form": {"GBps": 5970.0}}
     except OSError as e:
         rec["error"] = "libepi_rate.so not loadable (%s): literal fallback" % e
     rec["GBps"] = REQUANT_PEAK_GBS
@@ -125,9 +141,12 @@ def sq_counters(kernel):
     try:
         sq = json.load(open(os.path.join(ROOT, "profiles", "sq_latest.json")))
         k = sq["kernels"].get(kernel)
+        if not k:  # (rocprofv3 prints template arguments the library's names drop or replace: one kernel of that base name -> that one)
+            same = [v for n, v in sq["kernels"].items() if n.split("<")[0] == kernel.split("<")[0]]
+            k = same[0] if len(same) == 1 else None
         if k:
             return {"valu_busy": k["valu_busy"], "valu_inst_per_clk_per_simd": k["valu_inst_per_clk_per_simd"],
-                    "lds_bank_conflict_ratio": k["lds_bank_conflict_ratio"], "shader_clock_GHz": k.get("shader_clock_GHz"),
+                    "lds_bank_conflict_ratio": k["lds_bank_conflict_ratio"], "wait_any_frac": k.get("wait_any_frac"),
                     "source": "profiles/sq_latest.json"}
     except (OSError, ValueError, KeyError):
         pass

@@ -138,22 +138,26 @@ __global__ __launch_bounds__(W16 ? 1024 : 512, KSC == 4 ? 2 : (W16 ? 4 : MF_CHAI
         c_pair &cp = pairs[0];
         const int H = cp.H, ROWB = cp.W * cp.C, ROWCH = ROWB >> 4, IMG = H * ROWB;
         const int lgNQ = cp.lgNQ, nqm = cp.NQ - 1, sh = cp.swz_sh, mask = cp.swz_mask;
-        for (int gi = 0; gi < G; ++gi) {
-            const long img = (long)st * G + gi;
-            if (img >= batch) break;
-            for (int y = wave; y < H; y += NWAVE) {
-                const int8_t *src = in + img * IMG + (long)y * ROWB;
-                uint8_t *dst = lds + cp.tile_off + buf * p.dbuf_stride + gi * cp.TILE + (y + 1) * cp.ROW + cp.C;
-                for (int o = 0; o < ROWCH; o += 64) {
-                    const int i = o + lane; // 16-byte group i of the row lands at LDS group i; it must hold source group (x, c ^ swz(x))
-                    int sidx = i;
-                    if (mask != 0) {
-                        const int x = i >> lgNQ, c = i & nqm;
-                        sidx = (x << lgNQ) + (c ^ (((x + 1) >> sh) & mask));
-                    }
-                    if (i < ROWCH) dma16(src + sidx * 16, dst + o * 16);
+        // rows of the step's G images are one contiguous run of the input (image after image): wave w takes rows w, w + NWAVE, ...
+        const int nrows = (int)min((long)G, (long)batch - (long)st * G) * H;
+        const int8_t *src0 = in + (long)st * G * IMG;
+        uint8_t *tile0 = lds + cp.tile_off + buf * p.dbuf_stride + cp.C;
+        int gi = 0, y = wave;
+        while (y >= H) y -= H, ++gi;
+        for (int r = wave; r < nrows; r += NWAVE) {
+            const int8_t *src = src0 + (long)r * ROWB;
+            uint8_t *dst = tile0 + gi * cp.TILE + (y + 1) * cp.ROW;
+            for (int o = 0; o < ROWCH; o += 64) {
+                const int i = o + lane; // 16-byte group i of the row lands at LDS group i; it must hold source group (x, c ^ swz(x))
+                int sidx = i;
+                if (mask != 0) {
+                    const int x = i >> lgNQ, c = i & nqm;
+                    sidx = (x << lgNQ) + (c ^ (((x + 1) >> sh) & mask));
                 }
+                if (i < ROWCH) dma16(src + sidx * 16, dst + o * 16);
             }
+            y += NWAVE;
+            while (y >= H) y -= H, ++gi;
         }
     };
 

@@ -89,8 +89,8 @@ def sq_main(dirs, stats_csv):
              "lds_bank_conflict_ratio": round(c.get("SQ_LDS_BANK_CONFLICT", 0.0) / c["SQ_LDS_IDX_ACTIVE"], 4) if c.get("SQ_LDS_IDX_ACTIVE") else 0.0,
              "wait_any_frac": round(c.get("SQ_WAIT_ANY", 0.0) / c["SQ_WAVE_CYCLES"], 4) if c.get("SQ_WAVE_CYCLES") else None,
              "cycles_per_xcd": round(cyc)}
-        if k in dur and dur[k] > 0:
-            e["shader_clock_GHz"] = round(cyc / dur[k], 3)
+        if k in dur and dur[k] > 0:  # (profiled cycles over the UNprofiled duration of the same command: indicative only)
+            e["cycles_per_xcd_over_trace_duration_GHz"] = round(cyc / dur[k], 3)
         out["kernels"][k] = e
     print(json.dumps(out, indent=1))
 
