@@ -263,9 +263,15 @@ struct RrPhase {
 
 
 // the two quads of person_detect: pair geometries = the MF_DWRR_SHAPES rows of the single pairs
+#ifndef MF_Q13B_ROWPAD
+#define MF_Q13B_ROWPAD 32 // (tuning: row pitch padding of tile B in ops 1..4 -- pair A's 8-byte stores into it vs pair B's tap reads)
+#endif
+#ifndef MF_Q13A_ROWPAD
+#define MF_Q13A_ROWPAD 32
+#endif
 struct Quad13 {
-    using A = RrGeom<48, 48, 8, 1, 16, 1, 4, 0, 32, 0x000>;
-    using B = RrGeom<48, 48, 16, 2, 32, 1, 2, 0, 32, 0x000>;
+    using A = RrGeom<48, 48, 8, 1, 16, 1, 4, 0, MF_Q13A_ROWPAD, 0x000>;
+    using B = RrGeom<48, 48, 16, 2, 32, 1, 2, 0, MF_Q13B_ROWPAD, 0x000>;
     static constexpr int G = 1, NTHR = 768, WPE = 3, ACT_A = 12, ACT_B = 12, X2A = MF_Q13_X2A, X2B = MF_Q13_X2B;
     static constexpr const char *name = "quad_rr<48,48,8,1,16|48,48,16,2,32>";
 };
