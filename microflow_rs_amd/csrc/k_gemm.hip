@@ -453,10 +453,13 @@ static void launch_fc_mfma_t(const int8_t *in, int8_t *out, const FcGemmArgs &a,
     const int grid = ((a.M + BM - 1) / BM) * (a.N / BN);
     hipLaunchKernelGGL((fc_mfma<BM, BN, WM, WN, STAGGER, RS>), dim3(grid), dim3(64 * WM * WN), lds, s, in, out, a);
 }
-// MF_FC_ROWSUM_PREPASS=1: the separate fc_rowsum launch of rounds 1-3 instead of the in-GEMM row sums (A/B switch)
+// The weight zero point term needs sum_k x[m][k].  Default: the separate fc_rowsum launch in front of the GEMM.  MF_FC_ROWSUM_FOLD=1:
+// the RS instance forms the sums inside the GEMM (no extra launch, no row-sum buffer) -- measured 3-4 % SLOWER than the pre-pass
+// (profiles/r04/fc_rowsum_ab.txt: 75.0-75.7 us against 71.8-73.1 us per 4096^3 step; weight zero point 0: 67.8), so it is the switch,
+// not the default.
 bool fc_mfma_rowsum_prepass() {
-    static const bool on = getenv("MF_FC_ROWSUM_PREPASS") != nullptr;
-    return on;
+    static const bool fold = getenv("MF_FC_ROWSUM_FOLD") != nullptr;
+    return !fold;
 }
 void launch_fc_mfma(const int8_t *in, int8_t *out, const FcGemmArgs &a, hipStream_t s) {
     static const int force = [] { const char *e = getenv("MF_FC_TILE"); return e ? atoi(e) : 0; }();

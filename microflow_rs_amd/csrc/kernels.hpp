@@ -487,7 +487,7 @@ bool launch_fc_rowwave_softmax(const int8_t *in, int8_t *out, const FcArgs &a, c
 bool fc_mfma_supported(size_t rows, int N, int K);
 void launch_fc_rowsum(const int8_t *in, int *rowsum, size_t rows, int K, hipStream_t s);
 void launch_fc_mfma(const int8_t *in, int8_t *out, const FcGemmArgs &a, hipStream_t s);
-bool fc_mfma_rowsum_prepass(); // MF_FC_ROWSUM_PREPASS: rounds 1-3's separate row-sum launch (A/B switch)
+bool fc_mfma_rowsum_prepass(); // true (default): fc_rowsum runs in front of the GEMM; MF_FC_ROWSUM_FOLD=1: the GEMM forms the sums itself
 void launch_softmax(const int8_t *in, int8_t *out, const SoftmaxArgs &a, size_t batch, hipStream_t s);
 // number of float bit patterns (of all 2^32) whose quantised byte differs between quant_div's fast form and the true
 // division, for these parameters; synchronises the stream

@@ -23,6 +23,7 @@ fi
 if [[ $STEPS == all || $STEPS == *bench* ]]; then
   timeout 600 python bench.py ${BENCH_ARGS} > $OUT/bench.json 2> $OUT/bench.err
   echo "bench exit $?"
+  cp $OUT/bench_details.json $OUT/bench_details_default.json   # (the profiling passes below run bench.py again and overwrite it)
   tail -5 $OUT/bench.err
   python - <<'PY'
 import json
@@ -30,7 +31,7 @@ try:
     line = open("gpurun_out/bench.json").read().strip().splitlines()[-1]
     c = json.loads(line)
     print("compact line: %d bytes; keys %s" % (len(line), sorted(c)))
-    r = json.load(open("gpurun_out/bench_details.json"))
+    r = json.load(open("gpurun_out/bench_details_default.json"))
     print("value", r["value"], r["unit"], "ms/step", r["ms_per_step"], "roofline", c["roofline"]); print("whole_step", c["whole_step"]); print("ceiling", r["requant_ceiling"]); print("fc4096", c.get("fc4096"), c.get("fc4096_wzp")); print("speech", c.get("speech"))
     print("layerwise ms", r["layerwise"]["ms_per_step"], "depthwise", r["depthwise"], "conv", r["conv_2d"])
     for k in r["kernels"]:

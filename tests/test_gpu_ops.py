@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from tests.conftest import ROUTING_SWITCHED
+from tests.conftest import ROOT, ROUTING_SWITCHED
 
 pytestmark = pytest.mark.gpu
 
@@ -648,3 +648,36 @@ def test_fc_mfma_equals_generic_kernel_on_every_row(mf, O, M, K, N):
     ref = O.fully_connected(x[rows], w, wzp, 0.05, 3, 0, c0, c1, c2, c3)
     assert np.array_equal(got.cpu().numpy().reshape(M, N)[rows], ref)
     del guard
+
+
+def test_fc_mfma_row_sums_inside_the_gemm():
+    """MF_FC_ROWSUM_FOLD=1: the weight-zero-point term from row sums formed inside the GEMM (fc_mfma<..., RS>, both tile sizes,
+    ragged M) instead of the fc_rowsum pre-pass -- the whole output against the shape-generic kernel.  A child process: the switch
+    is read once per process."""
+    import subprocess
+    import sys as _sys
+    code = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+import microflow_rs_amd as mf
+f32 = np.float32
+for M, K, N in ((4096, 2048, 4096), (1000, 640, 768), (193, 256, 384)):
+    rng = np.random.default_rng(M + K)
+    x = rng.integers(-128, 128, (M, K)).astype(np.int8)
+    w = rng.integers(-128, 128, (N, K)).astype(np.int8)
+    c0 = rng.uniform(-3, 3, N).astype(f32)
+    c1 = f32(127.0 / (74 * 74 * 3 * np.sqrt(K)))
+    wzp, izp = 7, -128
+    c2 = (izp * w.astype(np.int64).sum(axis=1)).astype(np.int32)
+    op = mf.ops.prepare_fully_connected(M, w, wzp, 0.05, 3, mf.ops.FullyConnectedOptions(), (c0, c1, c2, int(K * izp * wzp)))
+    assert op.kernel == "fc_mfma", op.kernel
+    xd = torch.as_tensor(x).cuda()
+    got = op(xd).clone()
+    op.set_generic(True)
+    want = op(xd)
+    assert torch.equal(got, want), (M, K, N, int((got != want).sum()))
+print("FOLD_OK")
+''' % ROOT
+    env = dict(os.environ, MF_FC_ROWSUM_FOLD="1")
+    r = subprocess.run([_sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0 and "FOLD_OK" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
