@@ -101,13 +101,15 @@ __device__ __forceinline__ int requant_any(int acc, float A, float S, float lo_f
 #define MF_NT_STORE 0
 #endif
 template <bool NT> __device__ __forceinline__ void st_out_t(void *p, uint4 v) {
+    // (a native vector store in both forms: assigning HIP's struct-based uint4 through a pointer was seen split into four dword
+    // stores when the value came straight out of an LDS load -- the stage kernel's output copy, round 4)
     if constexpr (NT) __builtin_nontemporal_store(v4i{(int)v.x, (int)v.y, (int)v.z, (int)v.w}, (v4i *)p);
-    else *(uint4 *)p = v;
+    else *(v4i *)p = v4i{(int)v.x, (int)v.y, (int)v.z, (int)v.w};
 }
 template <bool NT> __device__ __forceinline__ void st_out_t(void *p, uint2 v) {
     typedef int v2i_ __attribute__((ext_vector_type(2)));
     if constexpr (NT) __builtin_nontemporal_store(v2i_{(int)v.x, (int)v.y}, (v2i_ *)p);
-    else *(uint2 *)p = v;
+    else *(v2i_ *)p = v2i_{(int)v.x, (int)v.y};
 }
 template <bool NT> __device__ __forceinline__ void st_out_t(void *p, uint32_t v) {
     if constexpr (NT) __builtin_nontemporal_store(v, (uint32_t *)p);

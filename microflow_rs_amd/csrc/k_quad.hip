@@ -346,10 +346,18 @@ __global__ __launch_bounds__(Q::NTHR, Q::WPE) void quad_rr(const int8_t *__restr
     auto stem_phase = [&](const uint32_t *sc) {
         constexpr int RPW = GA::H / 2 / NWAVE;        // output row pairs per wave
         const int col = lane & 15, g = lane >> 4;
-        const long Aw = *(const long *)(sc + 2 * lane);
+        // (the pointer is laundered every step, so the compiler no longer knows it is global: say so, or these become flat loads
+        // that count on lgkmcnt as well and make every LDS wait of the phase wait for them)
+        typedef __attribute__((address_space(1))) const uint32_t g_u32;
+        g_u32 *gsc = (g_u32 *)(uintptr_t)sc;
+        typedef long i64x1 __attribute__((ext_vector_type(1)));
+        const long Aw = (*(__attribute__((address_space(1))) const i64x1 *)(gsc + 2 * lane))[0];
         const int cq = (g & 1) * 4;                   // this lane's channels within its pixel
-        const float4 cA = *(const float4 *)(sc + 128 + cq), cS = *(const float4 *)(sc + 136 + cq);
-        const int4 ck = magic4<MG>(*(const int4 *)(sc + 144 + cq));
+        const v4i cA_ = *(__attribute__((address_space(1))) const v4i *)(gsc + 128 + cq), cS_ = *(__attribute__((address_space(1))) const v4i *)(gsc + 136 + cq);
+        const v4i ck_ = *(__attribute__((address_space(1))) const v4i *)(gsc + 144 + cq);
+        const float4 cA = make_float4(__int_as_float(cA_[0]), __int_as_float(cA_[1]), __int_as_float(cA_[2]), __int_as_float(cA_[3]));
+        const float4 cS = make_float4(__int_as_float(cS_[0]), __int_as_float(cS_[1]), __int_as_float(cS_[2]), __int_as_float(cS_[3]));
+        const int4 ck = magic4<MG>(make_int4(ck_[0], ck_[1], ck_[2], ck_[3]));
         const v4i cK = {ck.x, ck.y, ck.z, ck.w};
         const int oy1 = col >= 8 ? 1 : 0, j1 = col >= 8 ? col - 8 : 16 + col;
         // operand: the aligned dwords at columns 4j - 4 and 4j of tile row 2 oy + ky (ky = g; tile row 0 = input row -1)

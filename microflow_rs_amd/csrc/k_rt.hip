@@ -414,7 +414,13 @@ __global__ __launch_bounds__(512) void conv_rows_lds(const int8_t *__restrict__ 
         const uint32_t *src = (const uint32_t *)in + (size_t)st * STEPD;
         const long lim = ((long)batch - (long)st * G) * IMGD; // dwords of the step that exist (a ragged last step)
 #pragma unroll
-        for (int e = 0; e < MAXE; ++e) v[e] = (gofs[e] >= 0 && gofs[e] < lim) ? src[gofs[e]] : p.izp4;
+        for (int e = 0; e < MAXE; ++e) {
+            // (select the VALUE, not the address: `cond ? src[i] : p.izp4` made the compiler choose between a global and a
+            // kernel-argument address, i.e. a flat load that also counts on lgkmcnt)
+            const bool ok = gofs[e] >= 0 && gofs[e] < lim;
+            const uint32_t got = src[ok ? gofs[e] : 0];
+            v[e] = ok ? got : p.izp4;
+        }
     };
     const float inv_ow = 1.0f / (float)p.OW, inv_opix = 1.0f / (float)(p.OH * p.OW);
     const int OPIX = p.OH * p.OW;
@@ -468,7 +474,7 @@ __global__ __launch_bounds__(512) void conv_rows_lds(const int8_t *__restrict__ 
             const uint32_t d1 = requant_pack4<MG, XR4>(acc[4], acc[5], acc[6], acc[7], a1, s1, p.lo_f, p.hi_f);
             int8_t *dst = out + ((size_t)(step * G + g) * OPIX + o) * N + cgp * 8;
             if ((N & 7) == 0) {
-                *(uint2 *)dst = make_uint2(d0, d1);
+                st_out_t<false>(dst, make_uint2(d0, d1));
             } else {                                     // N not a multiple of 8: byte stores of the channels that exist
                 const int nleft = N - cgp * 8;
 #pragma unroll
