@@ -20,6 +20,10 @@ HEADERS = ["mf_internal.hpp", "kernels.hpp", "k_common.hpp", "k_dwtask.hpp", "k_
 # removes one v_accvgpr_read per accumulator element from every fused epilogue.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-fno-fast-math", "-Wall", "-Wno-unused-result", "-mllvm", "-amdgpu-mfma-vgpr-form=1"]
+# (-mllvm -amdgpu-atomic-optimizer-strategy=None was tried in round 4 together with a step-queue draw whose result is first
+# touched at the END of the step: hipcc otherwise broadcasts a returning atomic with v_readfirstlane right behind it, i.e. the
+# drawing wave waits for the round trip at the top of the step.  Same-box A/B, profiles/r04/dq_ab.txt: no gain -- the round
+# trip is short enough -- and the flag cost the five-operator launch 2 %.  Not kept.)
 FLAGS += os.environ.get("MF_EXTRA_HIPCC_FLAGS", "").split()  # kernel-tuning experiments (-DMF_...=n)
 
 

@@ -33,15 +33,23 @@
 #ifndef MF_CHAIN_TBM1
 #define MF_CHAIN_TBM1 4   // output tiles per wave block with one k step (K <= 64): 4 or 2
 #endif
-#ifndef MF_CHAIN_RES
-#define MF_CHAIN_RES 0    // 1: a separate reload-free depthwise loop for launches whose operands are resident (measured: the second copy of the loop costs registers -- spills with one k step -- and 12 % of the generated models' chain time; profiles/r04/chain_ab.txt)
-#endif
 #ifndef MF_CHAIN_WPE
 #define MF_CHAIN_WPE 4    // waves per SIMD the register allocation leaves room for (K <= 128)
 #endif
 
+#ifndef MF_CHAIN_DIAG
+#define MF_CHAIN_DIAG 0   // 1: shader-clock stamps of workgroup 0 / wave 0 at the phase boundaries of its 3rd step (never shipped)
+#endif
+
 namespace mf {
 namespace k {
+
+#if MF_CHAIN_DIAG
+__device__ long long g_chain_trace[64];
+#define MF_CTR(k) do { if (blockIdx.x == 0 && wave == 0 && lane == 0 && trace_step == 2 && (k) < 64) g_chain_trace[k] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define MF_CTR(k) do { } while (0)
+#endif
 
 namespace {
 struct CDwW {        // depthwise operands of one 16-channel group
@@ -60,10 +68,19 @@ template <int KSC> struct CPwW { // pointwise operands of one block of output ti
 };
 } // namespace
 
-// W16: 16 waves per workgroup (plans whose LDS admits one workgroup per CU: four waves per SIMD all the same)
-template <int KSC, bool W16, int MG, uint32_t XR4>
-__global__ __launch_bounds__(W16 ? 1024 : 512, KSC == 4 ? 2 : (W16 ? 4 : MF_CHAIN_WPE)) void chain_rt(const int8_t *__restrict__ in, int8_t *__restrict__ out, ChainArgs p, int batch) {
-    constexpr int NTHR = W16 ? 1024 : 512, NWAVE = NTHR / 64, TBM = chain_tbm<KSC>();
+// NW: waves per workgroup.  8 by default (two workgroups per CU = four waves per SIMD); 16 where the LDS plan admits one workgroup per CU
+// only (K <= 64).
+// SOLO: the chain is ONE pair (the common case).  The pair record is then loop-invariant: its fields are read once and kept in
+// scalar registers (for a chain the record pointer is laundered every step so that the per-phase operand addresses are formed
+// where they are used -- and every phase entry pays a few dependent scalar-load latencies: stamps of round 4, MF_CHAIN_DIAG,
+// showed 2 000 - 3 000 cycles between a step's top barrier and its first tap load).
+// RES (with SOLO): every wave's depthwise units lie inside ONE channel group, so its operands are loaded once per launch and the
+// depthwise loop carries no reload code -- hence no vmcnt wait inside a step.  That matters beyond the load itself: the step queue's
+// returning atomic (issued at a step's top, consumed at its end) would otherwise be waited for by the first such wait, 1 - 3 us
+// under load, by the one wave that drew -- and the phase barrier makes everyone wait for that wave (stamps: MF_CHAIN_DIAG).
+template <int KSC, int NW, bool SOLO, bool RES, int MG, uint32_t XR4>
+__global__ __launch_bounds__(NW * 64, KSC == 4 ? 2 : (NW == 8 ? MF_CHAIN_WPE : 4)) void chain_rt(const int8_t *__restrict__ in, int8_t *__restrict__ out, ChainArgs p, int batch) {
+    constexpr int NTHR = NW * 64, NWAVE = NW, TBM = chain_tbm<KSC>();
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -79,7 +96,7 @@ __global__ __launch_bounds__(W16 ? 1024 : 512, KSC == 4 ? 2 : (W16 ? 4 : MF_CHAI
         const v4i v = ld16(base, off);
         return magic4<MG>(make_int4(v[0], v[1], v[2], v[3]));
     };
-    const int G = p.G, NP = p.npairs;
+    const int G = p.G, NP = SOLO ? 1 : p.npairs;
     const int col = lane & 15, g = lane >> 4;
 
     DynSteps dq;
@@ -168,7 +185,7 @@ __global__ __launch_bounds__(W16 ? 1024 : 512, KSC == 4 ? 2 : (W16 ? 4 : MF_CHAI
     // RES (compile time): the wave's operands stay what they are for the whole launch -- no reload code in the loop, hence no
     // vmcnt wait there (a wait for an operand reload would also wait for the step-ahead staging DMAs: both count on vmcnt)
     auto dw_phase = [&](c_pair &cp, CDwW &wd, int tile_base, auto resc) { // wd: the operands of this wave's first channel group, already on their way
-        constexpr bool RES = decltype(resc)::value;
+        constexpr bool RESD = decltype(resc)::value;
         const int S = cp.S, C = cp.C, ROW = cp.ROW, sh = cp.swz_sh, mask = cp.swz_mask;
         const int lgCX = cp.lgCX, lgCY = cp.lgCY, CXv = 1 << lgCX, CYv = 1 << lgCY;
         const int gg = g < 2 ? g : 2; // tap column of this lane group (g == 3 meets zero weights: any readable bytes will do)
@@ -207,7 +224,7 @@ __global__ __launch_bounds__(W16 ? 1024 : 512, KSC == 4 ? 2 : (W16 ? 4 : MF_CHAI
             n -= seg, j = 0;
             if (++ux == UX) {
                 ux = 0, ++q;
-                if constexpr (!RES) {
+                if constexpr (!RESD) {
                     if (n > 0) wd = load_dw(cp, q); // (a wave's range crosses into the next channel group)
                 }
             }
@@ -331,32 +348,46 @@ __global__ __launch_bounds__(W16 ? 1024 : 512, KSC == 4 ? 2 : (W16 ? 4 : MF_CHAI
     CDwW wd = load_dw(pairs[0], pairs[0].ustart[wave][0]);
     CPwW<KSC> wp;
     if (persist) wp = load_pw(pairs[0]);
-    const bool dw_resident = persist && pairs[0].single_q != 0;
+    const bool dw_resident = RES; // (the launcher picks the RES instance when the plan says single_q)
     const bool dbuf = p.dbuf != 0;
     int cur = 0;
+#if MF_CHAIN_DIAG
+    int trace_step = 0;
+#endif
     for (; dq.step < nsteps; dq.advance(tid)) {
         const int step = dq.step;
+        MF_CTR(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        MF_CTR(1);
         __syncthreads(); // this step's images are in pair 0's tile; every wave has left the previous step's last phase
+        MF_CTR(2);
         dq.top(tid);
-        asm volatile("" : "+s"(pairs));
+        if constexpr (!SOLO) asm volatile("" : "+s"(pairs));
+        MF_CTR(60);
         if (dbuf && dq.nxt < nsteps) stage(dq.nxt, cur ^ 1); // double buffered: the next step's images have this whole step to land
+        MF_CTR(61);
         const int gvalid = min(G, batch - step * G);
         for (int pi = 0; pi < NP; ++pi) {
             c_pair &cp = pairs[pi];
             if (!persist) wp = load_pw(cp); // lands during the depthwise phase
-            if (MF_CHAIN_RES && dw_resident) dw_phase(cp, wd, cp.tile_off + cur * p.dbuf_stride, std::integral_constant<bool, true>{});
-            else dw_phase(cp, wd, cp.tile_off + (pi == 0 ? cur * p.dbuf_stride : 0), std::integral_constant<bool, false>{});
+            MF_CTR(3 + 4 * pi);
+            dw_phase(cp, wd, cp.tile_off + (pi == 0 ? cur * p.dbuf_stride : 0), std::integral_constant<bool, RES>{});
+            MF_CTR(4 + 4 * pi);
             __syncthreads(); // MID complete; the tile has been read
+            MF_CTR(5 + 4 * pi);
             if (!dbuf && pi == p.stage_after && dq.nxt < nsteps) stage(dq.nxt, 0); // pair 0's tile region is free: the next step's images fly under the rest of this step
             if (!dw_resident) {
                 c_pair &nx = pairs[pi + 1 < NP ? pi + 1 : 0];
                 wd = load_dw(nx, nx.ustart[wave][0]); // lands during the pointwise phase
             }
             pw_phase(cp, wp, step, gvalid);
+            MF_CTR(6 + 4 * pi);
             if (pi + 1 < NP) __syncthreads(); // the next pair's tile is complete; MID is free
         }
         if (dbuf) cur ^= 1;
+#if MF_CHAIN_DIAG
+        ++trace_step;
+#endif
     }
     dq.finish(tid);
 }
@@ -501,7 +532,10 @@ bool chain_plan(const ChainGeom *g, int n, ChainPair *pairs, ChainArgs &a, int l
     // the chain's HBM bytes are the other roof.  Calibrated on the generated models (profiles/r04/chain_*).
     static const double opcost = [] { const char *e = getenv("MF_CHAIN_OPCOST"); return e ? atof(e) : 1.0; }(); // (tuning: weight of the operand-reload term)
     auto estimate = [&](int G, int lds, int &nwave_out) {
-        const int wgs = (KSC == 4 || lds > 80 * 1024) ? 1 : 2; // (four k steps: 2 waves per SIMD and one workgroup per CU)
+        // workgroups per CU the LDS admits (at most two: 8 waves each = four waves per SIMD); with four k steps the registers allow
+        // two waves per SIMD, i.e. one workgroup.  (Four-wave workgroups, four per CU, for small tensors were measured in round 4:
+        // 8x8x128 -> 128 0.27 ms against 0.22 with two eight-wave workgroups; not kept.)
+        const int wgs = (KSC == 4 || lds > 80 * 1024) ? 1 : 2;
         const int nwave = (wgs == 1 && KSC == 1) ? 16 : 8;
         nwave_out = nwave;
         const double waves_per_simd = wgs * nwave / 4.0;
@@ -532,7 +566,8 @@ bool chain_plan(const ChainGeom *g, int n, ChainPair *pairs, ChainArgs &a, int l
     // double buffering of the input tile: where it does not cost a workgroup per CU
     auto want_dbuf = [&](int G) {
         const int l0 = lds_for(G, false, false), l1 = lds_for(G, false, true);
-        return l1 <= lds_budget && ((l0 <= 80 * 1024) == (l1 <= 80 * 1024));
+        auto cls = [](int l) { return l > 80 * 1024 ? 1 : 2; }; // workgroups per CU
+        return l1 <= lds_budget && cls(l0) == cls(l1);
     };
     for (int G = maxCG; G <= 128; G *= 2) {
         const bool db = want_dbuf(G);
@@ -551,6 +586,7 @@ bool chain_plan(const ChainGeom *g, int n, ChainPair *pairs, ChainArgs &a, int l
     for (int i = 0; i < n; ++i)
         if (pairs[i].tile_off == pairs[0].tile_off) a.stage_after = i;
     a.npairs = n, a.KSC = KSC;
+    a.resident = 0; // set below: a single pair whose every wave stays inside one channel group
     a.hbm_bytes = (double)g[0].H * g[0].W * g[0].C + (double)g[n - 1].OH * g[n - 1].OW * g[n - 1].N;
     a.requant_bytes = 0;
     for (int i = 0; i < n; ++i) {
@@ -571,6 +607,8 @@ bool chain_plan(const ChainGeom *g, int n, ChainPair *pairs, ChainArgs &a, int l
         c.pad_ = 0;
         c.rtab = nullptr;
     }
+    static const bool no_res = getenv("MF_CHAIN_NO_RES") != nullptr; // A/B
+    a.resident = (n == 1 && pairs[0].single_q && !no_res) ? 1 : 0;
     return true;
 }
 
@@ -595,7 +633,7 @@ double chain_unfused_us_per_image(const ChainGeom *g, int n) {
     return us;
 }
 
-template <int KSC, bool W16, int MG, uint32_t XR4>
+template <int KSC, int NW, bool SOLO, bool RES, int MG, uint32_t XR4>
 static void launch_chain_t(const int8_t *in, int8_t *out, const ChainArgs &a, int batch, hipStream_t s) {
     // occupancy per (device, LDS size in KiB).  The dynamic-LDS limit of the function is raised to the maximum every time a
     // slot is filled (a smaller later value would make a larger earlier plan unlaunchable).
@@ -605,8 +643,8 @@ static void launch_chain_t(const int8_t *in, int8_t *out, const ChainArgs &a, in
     std::atomic<int> &slot = cache[dev][(a.lds_bytes + 1023) / 1024];
     int per_cu = slot.load(std::memory_order_relaxed);
     if (per_cu <= 0) {
-        (void)hipFuncSetAttribute((const void *)chain_rt<KSC, W16, MG, XR4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, chain_rt<KSC, W16, MG, XR4>, W16 ? 1024 : 512, (size_t)a.lds_bytes) != hipSuccess || per_cu < 1) {
+        (void)hipFuncSetAttribute((const void *)chain_rt<KSC, NW, SOLO, RES, MG, XR4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, chain_rt<KSC, NW, SOLO, RES, MG, XR4>, NW * 64, (size_t)a.lds_bytes) != hipSuccess || per_cu < 1) {
             (void)hipGetLastError();
             per_cu = 1;
         }
@@ -617,24 +655,42 @@ static void launch_chain_t(const int8_t *in, int8_t *out, const ChainArgs &a, in
     ChainArgs b = a;
     b.qcfg = dq_config(nsteps, grid, dq_est_us((double)batch * a.hbm_bytes, (double)batch * a.requant_bytes));
     b.queue = dq_slot(b.queue);
-    hipLaunchKernelGGL((chain_rt<KSC, W16, MG, XR4>), dim3(grid), dim3(W16 ? 1024 : 512), a.lds_bytes, s, in, out, b, batch);
+    hipLaunchKernelGGL((chain_rt<KSC, NW, SOLO, RES, MG, XR4>), dim3(grid), dim3(NW * 64), a.lds_bytes, s, in, out, b, batch);
+#if MF_CHAIN_DIAG
+    {
+        (void)hipStreamSynchronize(s);
+        long long h[64];
+        (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_chain_trace), sizeof(h));
+        fprintf(stderr, "[chain trace] %d pairs G %d lds %d nwave %d grid %d per_cu %d dbuf %d | cycles since the step's top:", a.npairs, a.G, a.lds_bytes, a.nwave, grid, per_cu, a.dbuf);
+        for (int i = 1; i < 3 + 4 * a.npairs && i < 60; ++i) fprintf(stderr, " %d:%lld", i, h[i] - h[0]);
+        fprintf(stderr, " | after queue top %lld, after staging issue %lld", h[60] - h[0], h[61] - h[0]);
+        fprintf(stderr, "\n");
+    }
+#endif
 }
 void launch_chain(const int8_t *in, int8_t *out, const ChainArgs &a, int batch, hipStream_t s) {
-#define MF_CHAIN_GO(KSC, W)                                                              \
+#define MF_CHAIN_GO2(KSC, W, SO, RE)                                                         \
     do {                                                                                 \
         if (a.xr) {                                                                      \
-            if (a.magic == 2) launch_chain_t<KSC, W, 2, 0x80808080u>(in, out, a, batch, s); \
-            else launch_chain_t<KSC, W, 1, 0x80808080u>(in, out, a, batch, s);           \
+            if (a.magic == 2) launch_chain_t<KSC, W, SO, RE, 2, 0x80808080u>(in, out, a, batch, s); \
+            else launch_chain_t<KSC, W, SO, RE, 1, 0x80808080u>(in, out, a, batch, s);   \
         } else {                                                                         \
-            if (a.magic == 2) launch_chain_t<KSC, W, 2, 0u>(in, out, a, batch, s);       \
-            else launch_chain_t<KSC, W, 1, 0u>(in, out, a, batch, s);                    \
+            if (a.magic == 2) launch_chain_t<KSC, W, SO, RE, 2, 0u>(in, out, a, batch, s); \
+            else launch_chain_t<KSC, W, SO, RE, 1, 0u>(in, out, a, batch, s);            \
         }                                                                                \
     } while (0)
-    if (a.KSC == 1 && a.nwave == 16) MF_CHAIN_GO(1, true);
-    else if (a.KSC == 1) MF_CHAIN_GO(1, false);
-    else if (a.KSC == 2) MF_CHAIN_GO(2, false);
-    else MF_CHAIN_GO(4, false);
+#define MF_CHAIN_GO(KSC, W)                                                              \
+    do {                                                                                 \
+        if (a.npairs == 1 && a.resident) MF_CHAIN_GO2(KSC, W, true, true);               \
+        else if (a.npairs == 1) MF_CHAIN_GO2(KSC, W, true, false);                       \
+        else MF_CHAIN_GO2(KSC, W, false, false);                                         \
+    } while (0)
+    if (a.KSC == 1 && a.nwave == 16) MF_CHAIN_GO(1, 16);
+    else if (a.KSC == 1) MF_CHAIN_GO(1, 8);
+    else if (a.KSC == 2) MF_CHAIN_GO(2, 8);
+    else MF_CHAIN_GO(4, 8);
 #undef MF_CHAIN_GO
+#undef MF_CHAIN_GO2
 }
 
 } // namespace k

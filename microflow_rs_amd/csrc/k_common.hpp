@@ -426,14 +426,27 @@ struct DynSteps {
         pool_next = 0, pool_left = 0, sel = 0, write_at = -1;
         if (MF_DYNQ && K != 0 && tid == 0) slot[0] = draw();
     }
-    __device__ __forceinline__ int draw() { return 2 * (int)gridDim.x + K * (nheads * atomicAdd(ctr + head * PITCH, 1) + head); }
+    __device__ __forceinline__ int draw() { return index_of(atomicAdd(ctr + head * PITCH, 1)); }
+    // first step of the d-th chunk drawn from this workgroup's head
+    __device__ __forceinline__ int index_of(int d) const { return 2 * (int)gridDim.x + K * (nheads * d + head); }
     // right after the barrier at the top of an iteration
     __device__ __forceinline__ void top(int tid) {
         if (MF_DYNQ && K != 0) {
             if (pool_left == 0) { // start the chunk drawn earlier, draw the one after it (due K iterations from now)
                 nn = __builtin_amdgcn_readfirstlane(slot[sel]);
                 pool_next = nn + 1, pool_left = K - 1, sel ^= 1, write_at = it + K - 1;
-                if (tid == 0) fetched = draw();
+                // The RAW result of the atomic is kept and nothing is computed from it here (the index arithmetic happens in
+                // advance()).  Note that hipcc's atomic optimizer still broadcasts the result with a v_readfirstlane right behind
+                // the atomic, so the drawing wave waits for the round trip here; switching the optimizer off and deferring the
+                // wait to the end of the step was measured (round 4, profiles/r04/dq_ab.txt): no gain.
+#if defined(MF_DQ_EAGER) && MF_DQ_EAGER
+                if (tid == 0) { // (A/B: round 3's eager use of the result -- the wave waits for the atomic right here)
+                    fetched = atomicAdd(ctr + head * PITCH, 1);
+                    asm volatile("" : "+v"(fetched));
+                }
+#else
+                if (tid == 0) fetched = atomicAdd(ctr + head * PITCH, 1);
+#endif
             } else {
                 nn = pool_next++, --pool_left;
             }
@@ -442,7 +455,7 @@ struct DynSteps {
     // end of an iteration (before the next iteration's barrier)
     __device__ __forceinline__ void advance(int tid) {
         if (MF_DYNQ && K != 0) {
-            if (it == write_at && tid == 0) slot[sel] = fetched;
+            if (it == write_at && tid == 0) slot[sel] = index_of(fetched); // (the wait for the atomic's return is here)
             step = nxt, nxt = nn, ++it;
         } else {
             step = nxt, nxt += gridDim.x;

@@ -247,6 +247,7 @@ struct ChainArgs {
     int *queue;
     int qcfg;
     int KSC;                       // template selector: 1, 2 or 4 k steps (max over the pairs)
+    int resident;                  // single pair whose waves each stay inside one channel group: the reload-free kernel instance
     int nwave;                     // waves per workgroup: 8, or 16 when the LDS plan admits one workgroup per CU only (KSC == 1)
     double est_us_per_image;       // the planner's cost estimate (per CU), for choosing between chainings
     int magic, xr;                 // epilogue mode of the whole chain (min over its operators), element type
