@@ -33,6 +33,9 @@
 #ifndef MF_CHAIN_TBM1
 #define MF_CHAIN_TBM1 4   // output tiles per wave block with one k step (K <= 64): 4 or 2
 #endif
+#ifndef MF_CHAIN_RAW_BARRIER
+#define MF_CHAIN_RAW_BARRIER 1 // 0: __syncthreads() between the phases of a step (A/B)
+#endif
 #ifndef MF_CHAIN_WPE
 #define MF_CHAIN_WPE 4    // waves per SIMD the register allocation leaves room for (K <= 128)
 #endif
@@ -125,6 +128,19 @@ __global__ __launch_bounds__(NW * 64, KSC == 4 ? 2 : (NW == 8 ? MF_CHAIN_WPE : 4
         }
     }
 
+    // A workgroup barrier between two phases of a step: every wave's LDS writes of the phase are complete (lgkmcnt) and visible
+    // behind it.  NOT __syncthreads(): its fence makes hipcc wait vmcnt(0) whenever an LDS-DMA is in flight (a DMA is a pending LDS
+    // write on the VM counter: cdna_hip_programming.md, "Pipelining across barriers"), which would drain the next step's staging DMAs
+    // -- and this step's HBM stores -- at every phase boundary instead of at the next step's top.
+    auto phase_barrier = [&]() {
+#if MF_CHAIN_RAW_BARRIER
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+#else
+        __syncthreads();
+#endif
+    };
     auto load_dw = [&](c_pair &cp, int q) {
         CDwW w;
 #pragma unroll
@@ -373,7 +389,7 @@ __global__ __launch_bounds__(NW * 64, KSC == 4 ? 2 : (NW == 8 ? MF_CHAIN_WPE : 4
             MF_CTR(3 + 4 * pi);
             dw_phase(cp, wd, cp.tile_off + (pi == 0 ? cur * p.dbuf_stride : 0), std::integral_constant<bool, RES>{});
             MF_CTR(4 + 4 * pi);
-            __syncthreads(); // MID complete; the tile has been read
+            phase_barrier(); // MID complete; the tile has been read
             MF_CTR(5 + 4 * pi);
             if (!dbuf && pi == p.stage_after && dq.nxt < nsteps) stage(dq.nxt, 0); // pair 0's tile region is free: the next step's images fly under the rest of this step
             if (!dw_resident) {
@@ -382,7 +398,7 @@ __global__ __launch_bounds__(NW * 64, KSC == 4 ? 2 : (NW == 8 ? MF_CHAIN_WPE : 4
             }
             pw_phase(cp, wp, step, gvalid);
             MF_CTR(6 + 4 * pi);
-            if (pi + 1 < NP) __syncthreads(); // the next pair's tile is complete; MID is free
+            if (pi + 1 < NP) phase_barrier(); // the next pair's tile is complete; MID is free
         }
         if (dbuf) cur ^= 1;
 #if MF_CHAIN_DIAG
