@@ -772,6 +772,97 @@ void launch_pw_rt(const int8_t *in, int8_t *out, const PwRtArgs &a, bool wz, lon
 #undef MF_RT_GO
 }
 
+// ------------------------------------------------------------------------
+// dw3x3_stem_rt -- DepthwiseConv2D 3x3 stride 2 SAME with ONE input channel and DM = 4 or 8 outputs at any H x W (W % 16 == 0):
+// a MobileNet stem at any input resolution and width (src/ops/depthwise_conv_2d.rs:28-105 with Cin = 1: every output channel reads
+// input channel 0).  The run-time-geometry form of dw3x3_stem8_mm (k_depthwise.hip): the 9 taps are ONE MFMA per 256 output bytes.
+//   column  : one 16-byte group of the NHWC output = 16 / DM adjacent pixels x DM channels (group j of output row oy); its windows
+//             span input columns XS j - 1 .. XS j + XS - 1 of rows 2 oy - 1 .. 2 oy + 1, XS = 32 / DM
+//   K bytes : lane group g = filter row; the lane supplies the aligned bytes at columns XS j - 4 .. of tile row 2 oy + g (8 bytes
+//             and v_mfma_i32_16x16x32_i8 for DM = 8, 16 bytes and 16x16x64 for DM = 4); pixel p of the group uses bytes
+//             3 + 2 p .. 5 + 2 p, where the host put the weights in operand A (group 3: zeros)
+//   rows    : (pixel of the group, channel): a lane ends with 4 consecutive channels = one packed dword; four tiles are
+//             transposed across the lane groups, so that a lane stores 16 bytes and 16 lanes 256 contiguous ones
+//   step    : G whole images, copied verbatim by LDS-DMA between izp rows (row pitch W: column -1 is patched with a select,
+//             no other padding exists for even W), double buffered, dynamic step queue
+// ------------------------------------------------------------------------
+template <int DM, int MG, uint32_t XR4>
+__global__ __launch_bounds__(256) void dw3x3_stem_rt(const int8_t *__restrict__ in, int8_t *__restrict__ out, DwStemRtArgs p, int batch) {
+    constexpr int GUARD = 16, XS = 32 / DM;
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int col = lane & 15, g = lane >> 4;
+    const int W = p.W, G = p.G, TILE = p.TILE, BUF = G * TILE, IMG = p.H * W, QR = p.QR, QTOT = p.QTOT, NQUAD = p.NQUAD;
+    for (int i = tid; i < (2 * BUF + 64) / 16; i += 256) ((uint4 *)lds)[i] = make_uint4(p.izp4, p.izp4, p.izp4, p.izp4);
+    const long Aw8 = (long)(((unsigned long)p.wmm[lane][1] << 32) | (unsigned long)p.wmm[lane][0]);
+    const v4i Aw16 = {(int)p.wmm[lane][0], (int)p.wmm[lane][1], (int)p.wmm[lane][2], (int)p.wmm[lane][3]};
+    const int cq = DM == 8 ? (g & 1) * 4 : 0; // this lane's channels within its pixel
+    const float4 cA = make_float4(p.A[cq], p.A[cq + 1], p.A[cq + 2], p.A[cq + 3]);
+    const float4 cS = make_float4(p.S[cq], p.S[cq + 1], p.S[cq + 2], p.S[cq + 3]);
+    const v4i cK = {p.Kc[cq] + (MG ? MF_MAGIC_I : 0), p.Kc[cq + 1] + (MG ? MF_MAGIC_I : 0), p.Kc[cq + 2] + (MG ? MF_MAGIC_I : 0),
+                    p.Kc[cq + 3] + (MG ? MF_MAGIC_I : 0)};
+    DynSteps dq;
+    dq.init(lds + 2 * BUF + 64, p.queue, tid, p.qcfg);
+    __syncthreads();
+
+    const int NI = (IMG + 1023) >> 10; // 1 KiB DMA instructions per image (the last one partly masked)
+    auto stage = [&](int st, int buf) {
+        for (int gg = 0; gg < G; ++gg) {
+            if (st * G + gg >= batch) break;
+            const int8_t *src = in + (size_t)(st * G + gg) * IMG;
+            uint8_t *dst = lds + buf * BUF + gg * TILE + GUARD + W;
+            for (int c = wave; c < NI; c += 4)
+                if (c * 1024 + lane * 16 < IMG) dma16(src + c * 1024 + lane * 16, dst + c * 1024);
+        }
+    };
+    const int nsteps = (batch + G - 1) / G;
+    int cur = 0;
+    if (dq.step < nsteps) stage(dq.step, 0);
+    const int lane_row = GUARD + g * W - 4; // + XS q + oy W = tile row 2 oy + g, column XS j - 4
+    for (; dq.step < nsteps; dq.advance(tid), cur ^= 1) {
+        const int step = dq.step;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        dq.top(tid);
+        if (dq.nxt < nsteps) stage(dq.nxt, cur ^ 1);
+        const int gv = min(G, batch - step * G);
+        for (int gg = 0; gg < gv; ++gg) {
+            const uint8_t *tile = lds + cur * BUF + gg * TILE + lane_row;
+            uint4 *dst = (uint4 *)out + (size_t)(step * G + gg) * QTOT;
+#pragma unroll 1
+            for (int k = (wave + gg) & 3; k < NQUAD; k += 4) {
+                uint32_t r[4];
+#pragma unroll
+                for (int n = 0; n < 4; n += 2) {
+                    v4i acc[2];
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) {
+                        const int q = min((4 * k + n + m) * 16 + col, QTOT - 1); // (a ragged last quad re-reads the last group)
+                        const int oy = (int)(((float)q + 0.5f) * p.inv_qr);
+                        const bool first = q == oy * QR;                   // j == 0: column -1 is padding
+                        const uint32_t *src = (const uint32_t *)(tile + XS * q + oy * W);
+                        uint32_t d0 = src[0];
+                        d0 = first ? p.izp4 : d0;
+                        if constexpr (DM == 8) {
+                            const long B = (long)(((unsigned long)src[1] << 32) | (unsigned long)d0);
+                            acc[m] = __builtin_amdgcn_mfma_i32_16x16x32_i8(Aw8, B, cK, 0, 0, 0);
+                        } else {
+                            const v4i B = {(int)d0, (int)src[1], (int)src[2], (int)src[3]};
+                            acc[m] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Aw16, B, cK, 0, 0, 0);
+                        }
+                    }
+                    requant_pack4x2<MG, XR4>(acc[0], cA, cS, acc[1], cA, cS, p.lo_f, p.hi_f, r[n], r[n + 1]);
+                }
+                lane_group_transpose4(r[0], r[1], r[2], r[3]); // lane (col, g): the 16 bytes of group col of tile 4 k + g
+                const int qs = (4 * k + g) * 16 + col;
+                if (qs < QTOT) st_out(dst + qs, make_uint4(r[0], r[1], r[2], r[3]));
+            }
+        }
+    }
+    dq.finish(tid);
+}
+
 int conv_rows_lds_bytes(const ConvRowsArgs &a) {
     return a.G * a.TILE + a.KH * a.KG * a.NP * 4 + ((a.KG * 4 + 15) & ~15) + a.NP * 16 + 64;
 }
@@ -821,6 +912,49 @@ static void launch_conv_rows_t(const int8_t *in, int8_t *out, const ConvRowsArgs
     const int nsteps = (batch + a.G - 1) / a.G;
     const int grid = nsteps < 256 * per_cu ? nsteps : 256 * per_cu;
     hipLaunchKernelGGL((conv_rows_lds<WZ, MG, XR4>), dim3(grid), dim3(512), lds, s, in, out, a, batch);
+}
+bool dw_stem_rt_plan(DwStemRtArgs &a, int H, int W, int DM, int OH, int OW) {
+    if ((DM != 4 && DM != 8) || W % 16 != 0 || W < 16 || H < 2 || OH != (H + 1) / 2 || OW != W / 2) return false;
+    a.H = H, a.W = W, a.OH = OH, a.OW = OW, a.DM = DM;
+    a.QR = OW * DM / 16, a.QTOT = OH * a.QR, a.NQUAD = (a.QTOT + 63) / 64;
+    if (a.QTOT + 64 >= (1 << 22)) return false;       // (the float index arithmetic)
+    a.inv_qr = 1.0f / (float)a.QR;
+    a.TILE = (16 + (H + 3) * W + 15) & ~15;            // guard, izp row, H rows, izp rows (lane group 3 reads row 2 oy + 3 against zero weights)
+    if (2 * a.TILE + 80 > 150 * 1024) return false;
+    int g = 1;
+    while (g < 8 && 2 * (2 * g) * a.TILE <= 40 * 1024) g *= 2;
+    a.G = g;
+    return true;
+}
+template <int DM, int MG, uint32_t XR4>
+static void launch_dw_stem_rt_t(const int8_t *in, int8_t *out, const DwStemRtArgs &a_in, int batch, hipStream_t s) {
+    DwStemRtArgs a = a_in;
+    const int lds = 2 * a.G * a.TILE + 64 + 16;
+    static LaunchState st[161];
+    const int per_cu = prepared(st[(lds + 1023) / 1024], dw3x3_stem_rt<DM, MG, XR4>, 256, lds);
+    const int nsteps = (batch + a.G - 1) / a.G;
+    const int grid = nsteps < 256 * per_cu ? nsteps : 256 * per_cu;
+    const double out_bytes = (double)batch * a.OH * a.OW * a.DM;
+    a.qcfg = dq_config(nsteps, grid, dq_est_us((double)batch * a.H * a.W + out_bytes, out_bytes));
+    a.queue = dq_slot(a.queue);
+    hipLaunchKernelGGL((dw3x3_stem_rt<DM, MG, XR4>), dim3(grid), dim3(256), lds, s, in, out, a, batch);
+}
+void launch_dw_stem_rt(const int8_t *in, int8_t *out, const DwStemRtArgs &a, int batch, hipStream_t s) {
+    const int mg = a.magic;
+#define MF_RT_GO(DMM)                                                                              \
+    do {                                                                                           \
+        if (a.xr) {                                                                                \
+            if (mg == 2) launch_dw_stem_rt_t<DMM, 2, 0x80808080u>(in, out, a, batch, s);           \
+            else if (mg) launch_dw_stem_rt_t<DMM, 1, 0x80808080u>(in, out, a, batch, s);           \
+            else launch_dw_stem_rt_t<DMM, 0, 0x80808080u>(in, out, a, batch, s);                   \
+        } else {                                                                                   \
+            if (mg == 2) launch_dw_stem_rt_t<DMM, 2, 0u>(in, out, a, batch, s);                    \
+            else if (mg) launch_dw_stem_rt_t<DMM, 1, 0u>(in, out, a, batch, s);                    \
+            else launch_dw_stem_rt_t<DMM, 0, 0u>(in, out, a, batch, s);                            \
+        }                                                                                          \
+    } while (0)
+    if (a.DM == 8) MF_RT_GO(8); else MF_RT_GO(4);
+#undef MF_RT_GO
 }
 void launch_conv_rows(const int8_t *in, int8_t *out, const ConvRowsArgs &a, bool wz, int batch, hipStream_t s) {
     const int mg = a.magic;

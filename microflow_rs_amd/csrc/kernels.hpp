@@ -170,6 +170,24 @@ struct ConvRowsArgs {
     const int *wzp;
     int magic, xr;
 };
+// DepthwiseConv2D 3x3 stride 2 SAME with ONE input channel and 4 or 8 outputs, any H x W with W % 16 == 0 (a MobileNet stem at any
+// resolution / width 0.5; k_rt.hip: dw3x3_stem_rt)
+struct DwStemRtArgs {
+    uint32_t wmm[64][4]; // the taps as operand A: lane -> 8 K-bytes (DM = 8, v_mfma_i32_16x16x32_i8) or 16 (DM = 4, 16x16x64)
+    float A[8], S[8];
+    int Kc[8];
+    int H, W, OH, OW, DM;
+    int G, TILE;         // images per step; bytes of one image tile [guard 16][izp row][H rows][izp rows]
+    int QR, QTOT, NQUAD; // 16-byte output groups per output row / per image; groups of 4 x 16 of them per image
+    float inv_qr;
+    uint32_t izp4;
+    float lo_f, hi_f;
+    int magic, xr;
+    int *queue;
+    int qcfg;
+};
+bool dw_stem_rt_plan(DwStemRtArgs &a, int H, int W, int DM, int OH, int OW);
+void launch_dw_stem_rt(const int8_t *in, int8_t *out, const DwStemRtArgs &a, int batch, hipStream_t s);
 bool conv_rows_plan(ConvRowsArgs &a, int H, int W, int C, int N, int KH, int KW, int sh, int sw, int OH, int OW, bool pad_same);
 void launch_conv_rows(const int8_t *in, int8_t *out, const ConvRowsArgs &a, bool wz, int batch, hipStream_t s);
 // Conv2D with any filter, C % 16 == 0, as an MFMA product over K = KH KW C (k_rt.hip: conv_mm_rt)

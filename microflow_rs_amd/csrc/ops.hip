@@ -89,7 +89,7 @@ struct OpImpl {
     bool accepts_f32 = false;  // op_set_input_quant succeeded: op_run_f32 may replace quantize + op_run
     bool finite_consts = true; // A / S all finite (the shape-specialised and fused epilogues assume it)
     std::string generic_name, fast_name;
-    enum Fast { NONE, DW_NHWC, DW_STEM, DW_C1, PW_MFMA, FC_ROWWAVE, FC_MFMA, POOL_C4, CONV1X1_ROW, DW_RT, PW_RT, CONV_ROWS, CONV_MM } fast = NONE;
+    enum Fast { NONE, DW_NHWC, DW_STEM, DW_STEM_RT, DW_C1, PW_MFMA, FC_ROWWAVE, FC_MFMA, POOL_C4, CONV1X1_ROW, DW_RT, PW_RT, CONV_ROWS, CONV_MM } fast = NONE;
     int *d_rowsum = nullptr; // FC_MFMA with wzp != 0: per-row input sums
     size_t rowsum_cap = 0;
     int8_t *d_ext = nullptr; // op_run_external on a u8 operator: input moved to the i8 domain
@@ -104,6 +104,7 @@ struct OpImpl {
     k::SoftmaxArgs sm{};
     k::DwFastArgs dwf{};
     k::DwStemArgs stem{};
+    k::DwStemRtArgs stemrt{};
     k::PwArgs pw{};
     // run-time-geometry kernels (k_rt.hip): shapes outside the tables of kernels.hpp
     k::DwRtArgs dwrt{};
@@ -441,6 +442,27 @@ OpImpl *op_create(int device, const OpSpec &spec) {
             for (int c = 0; c < 8; ++c) f.A[c] = A[c], f.S[c] = S[c], f.Kc[c] = Kc[c];
             f.izp4 = 0x01010101u * (uint32_t)(uint8_t)(int8_t)s.izp;
             f.lo_f = a.lo_f, f.hi_f = a.hi_f, f.magic = magic, f.xr = xr;
+        } else if (!getenv("MF_NO_RT") && !getenv("MF_NO_STEM_RT") && dw && zero_wzp && same3x3 && s.C == 1 && s.sh == 2 &&
+                   k::dw_stem_rt_plan(op->stemrt, s.H, s.W, s.N, s.OH, s.OW)) {
+            // a one-channel 3x3 stride-2 stem at any resolution: the taps as one MFMA per 256 output bytes (k_rt.hip)
+            op->fast = OpImpl::DW_STEM_RT;
+            op->fast_name = "dw3x3_stem_rt<" + std::to_string(s.N) + ">";
+            k::DwStemRtArgs &f = op->stemrt;
+            f.queue = (int *)op->d_queue.p;
+            // operand A: accumulator row r = (p, c) = pixel p of a 16-byte output group, channel c; lane group g = filter row; the
+            // lane's K-bytes are input columns XS j - 4 .. of that row, of which pixel p uses bytes 3 + 2 p .. 5 + 2 p
+            const int KB = s.N == 8 ? 8 : 16;
+            for (int lane = 0; lane < 64; ++lane) {
+                const int r = lane & 15, g = lane >> 4, pp = r / s.N, c = r % s.N;
+                uint8_t b[16] = {0};
+                if (g < 3)
+                    for (int kx = 0; kx < 3; ++kx) b[3 + 2 * pp + kx] = (uint8_t)s.weights[((size_t)g * 3 + kx) * s.N + c];
+                for (int d = 0; d < 4; ++d)
+                    f.wmm[lane][d] = d * 4 < KB ? ((uint32_t)b[4 * d] | (uint32_t)b[4 * d + 1] << 8 | (uint32_t)b[4 * d + 2] << 16 | (uint32_t)b[4 * d + 3] << 24) : 0u;
+            }
+            for (int c = 0; c < 8; ++c) f.A[c] = A[(size_t)(c % s.N)], f.S[c] = S[(size_t)(c % s.N)], f.Kc[c] = Kc[(size_t)(c % s.N)];
+            f.izp4 = 0x01010101u * (uint32_t)(uint8_t)(int8_t)s.izp;
+            f.lo_f = a.lo_f, f.hi_f = a.hi_f, f.magic = magic, f.xr = xr;
         } else if (dw && zero_wzp && s.C == 1 && s.N <= 8) {
             // one input channel, few output channels, any filter: LDS-staged direct kernel
             k::DwC1Args &f = op->dwc1;
@@ -730,6 +752,10 @@ void op_run(OpImpl *op, const int8_t *d_in, size_t batch, int8_t *d_out, void *s
             break;
         case OpImpl::DW_STEM:
             done = k::launch_dw_stem(sp.H, sp.W, sp.N, sp.sh, d_in, d_out, op->stem, (int)batch, s);
+            break;
+        case OpImpl::DW_STEM_RT:
+            k::launch_dw_stem_rt(d_in, d_out, op->stemrt, (int)batch, s);
+            done = true;
             break;
         case OpImpl::CONV1X1_ROW:
             k::launch_conv1x1_rowwave(d_in, d_out, op->conv, batch, s);

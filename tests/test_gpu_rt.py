@@ -188,6 +188,7 @@ def test_conv_rows_vs_oracle(mf, O, case, u8, monkeypatch):
     else:
         w = rng.integers(lo, hi, (KH, KW, N)).astype(dt)
         opts = mf.ops.DepthwiseConv2DOptions(mf.FusedActivation(act), mf.TensorViewPadding(pad), (sh, sw))
+        monkeypatch.setenv("MF_NO_STEM_RT", "1")    # (3x3 stride-2 stems with 4 / 8 outputs have their own kernel: test_stem_rt_vs_oracle)
         op = mf.ops.prepare_depthwise_conv_2d((H, W, C), w, zp, izp, oscale, ozp, opts, (c0, c1), (OH, OW))
         assert ROUTING_SWITCHED or op.kernel in ("dw_rows_lds" + ("<wzp>" if wz else ""), "dw_c1_lds"), op.kernel
         want = np.stack([O.depthwise_conv_2d(x[i], w, zp, izp, oscale, ozp, act, pad, (sh, sw), (OH, OW), c0, c1) for i in range(batch)])
@@ -195,6 +196,70 @@ def test_conv_rows_vs_oracle(mf, O, case, u8, monkeypatch):
     assert np.array_equal(got, want), (op.kernel, np.argwhere(got != want)[:5])
     op.set_generic(True)
     assert np.array_equal(op(x), want)
+
+
+STEM_RT = [
+    # H, W, outputs, activation, batch
+    (128, 128, 8, 3, 3),      # the person_detect stem at 128 x 128 (one image per step)
+    (64, 64, 8, 3, 11),       # 4 images per step, a ragged last step
+    (96, 96, 4, 3, 5),        # width 0.5: four pixels per 16-byte group, v_mfma_i32_16x16x64_i8
+    (48, 48, 8, 1, 3),
+    (80, 80, 8, 3, 4),        # 50 tiles per image: a ragged last quad
+    (112, 112, 8, 0, 2),
+    (160, 160, 8, 3, 2),
+    (33, 48, 4, 3, 7),        # odd height: the bottom row of windows reads the izp row
+    (17, 16, 8, 1, 9),        # 16 wide: four 16-byte groups per output row, odd height
+    (2, 16, 4, 3, 70),        # the smallest image
+    (30, 240, 8, 3, 3),       # wide rows
+]
+
+
+@pytest.mark.parametrize("case", STEM_RT, ids=lambda c: "x".join(map(str, c)))
+@pytest.mark.parametrize("u8", [False, True], ids=["i8", "u8"])
+def test_stem_rt_vs_oracle(mf, O, case, u8):
+    """dw3x3_stem_rt (k_rt.hip): DepthwiseConv2D 3x3 stride 2 SAME, one input channel -> 4 / 8 outputs at any resolution
+    (src/ops/depthwise_conv_2d.rs:28-105 with every output channel reading input channel 0)."""
+    H, W, N, act, batch = case
+    rng = np.random.default_rng(hash(case) % (2 ** 32) + int(u8))
+    dt = np.uint8 if u8 else np.int8
+    lo, hi = (0, 256) if u8 else (-128, 128)
+    OH, OW = (H + 1) // 2, W // 2
+    x = rng.integers(lo, hi, (batch, H, W, 1)).astype(dt)
+    x[0] = hi - 1
+    x[-1, ::2] = lo
+    w = rng.integers(lo, hi, (3, 3, N)).astype(dt)
+    wzp = np.full(N, 128 if u8 else 0, dt)
+    izp, oscale, ozp = int(rng.integers(lo, hi)), 0.0235294122, int(rng.integers(lo, lo + 100))
+    c0, c1 = _consts(rng, N, 9)
+    opts = mf.ops.DepthwiseConv2DOptions(mf.FusedActivation(act), mf.TensorViewPadding(0), (2, 2))
+    op = mf.ops.prepare_depthwise_conv_2d((H, W, 1), w, wzp, izp, oscale, ozp, opts, (c0, c1), (OH, OW))
+    assert ROUTING_SWITCHED or op.kernel == "dw3x3_stem_rt<%d>" % N, op.kernel
+    want = np.stack([O.depthwise_conv_2d(x[i], w, wzp, izp, oscale, ozp, act, 0, (2, 2), (OH, OW), c0, c1) for i in range(batch)])
+    got = op(x)
+    assert np.array_equal(got, want), (op.kernel, np.argwhere(got != want)[:5])
+    op.set_generic(True)
+    assert np.array_equal(op(x), want)
+
+
+def test_stem_rt_on_a_large_batch(mf, O):
+    """Many steps per workgroup (the step queue, both staging buffers): 4099 images of 64 x 64 equal the shape-generic kernel's."""
+    import torch
+    rng = np.random.default_rng(77)
+    B = 4099
+    x = rng.integers(-128, 128, (B, 64, 64, 1)).astype(np.int8)
+    w = rng.integers(-128, 128, (3, 3, 8)).astype(np.int8)
+    wzp = np.zeros(8, np.int8)
+    c0, c1 = _consts(rng, 8, 9)
+    opts = mf.ops.DepthwiseConv2DOptions(mf.FusedActivation(3), mf.TensorViewPadding(0), (2, 2))
+    op = mf.ops.prepare_depthwise_conv_2d((64, 64, 1), w, wzp, -128, 0.0235294122, -128, opts, (c0, c1), (32, 32))
+    assert ROUTING_SWITCHED or op.kernel == "dw3x3_stem_rt<8>", op.kernel
+    xd = torch.as_tensor(x).cuda()
+    got = op(xd).cpu().numpy()
+    idx = [0, 1, 2047, 4096, 4098]
+    want = np.stack([O.depthwise_conv_2d(x[i], w, wzp, -128, 0.0235294122, -128, 3, 0, (2, 2), (32, 32), c0, c1) for i in idx])
+    assert np.array_equal(got[idx], want)
+    op.set_generic(True)
+    assert np.array_equal(op(xd).cpu().numpy(), got)
 
 
 CONV_MM = [
