@@ -226,6 +226,25 @@ std::vector<int8_t> build_dw_mm_weights(const int8_t *w /*[3][3][C]*/, int C) {
     return out;
 }
 
+// The same operand for FEWER than 16 channels (chain_rt, k_chain.hip): P = 16 / C horizontally adjacent pixels are one 16-channel
+// "superpixel", stride S in superpixels.  Row r = (output pixel p = r / C of superpixel X, channel r % C); block g = input superpixel
+// S X - 1 + g, whose byte (pp, c') is input pixel P (S X - 1 + g) + pp: non-zero for c' == channel and the tap column
+// tx = P (g - 1) + pp - S p + 1 in 0..2 (output pixel P X + p reads input pixels S (P X + p) + tx - 1).
+std::vector<int8_t> build_dw_mm_weights_sp(const int8_t *w /*[3][3][C]*/, int C, int S) {
+    const int P = 16 / C;
+    std::vector<int8_t> out((size_t)3 * 64 * 16, 0);
+    for (int ty = 0; ty < 3; ++ty)
+        for (int lane = 0; lane < 64; ++lane) {
+            const int r = lane & 15, g = lane >> 4, p = r / C, c = r % C;
+            int8_t *dst = &out[((size_t)ty * 64 + lane) * 16];
+            for (int pp = 0; pp < P; ++pp) {
+                const int tx = P * (g - 1) + pp - S * p + 1;
+                if (g < 3 && tx >= 0 && tx <= 2) dst[pp * C + c] = w[(ty * 3 + tx) * C + c];
+            }
+        }
+    return out;
+}
+
 // Pointwise weights [N][K] as operands A of v_mfma_i32_16x16x32_i8 for dwpw_rr (k_fused_mm.hip), whose B operand
 // is the depthwise result as it sits in registers: [16-row tile m][lane][8 bytes].  Lane (r = lane & 15,
 // g = lane >> 4) holds K-bytes 8g .. 8g+7 of MFMA row r.
@@ -936,30 +955,40 @@ static bool chain_enabled() {
     return !off;
 }
 // a DepthwiseConv2D 3x3 + Conv2D 1x1 pair the chain kernel can run: any H / W, C % 16 == 0, N % 16 == 0
+static int chain_superpixel(int C) {
+    static const bool no_sp = getenv("MF_CHAIN_NO_SP") != nullptr; // A/B: only C == 8 stride 1 (round 4's first form) below 16 channels
+    if (C % 16 == 0) return 1;
+    if (C == 8 || (!no_sp && (C == 4 || C == 2))) return 16 / C;
+    return 0;
+}
 static bool chain_pair_ok(const OpImpl *dw, const OpImpl *pw) {
     if (!dw || !pw || dw->device != pw->device || dw->force_generic || pw->force_generic) return false;
     const OpSpec &d = dw->s, &q = pw->s;
     if (d.kind != MF_OP_DEPTHWISE_CONV_2D || q.kind != MF_OP_CONV_2D || d.u8 != q.u8) return false;
     if (dw->fast != OpImpl::DW_RT && dw->fast != OpImpl::DW_NHWC) return false;
     const k::DwFastArgs &f = dw->fast == OpImpl::DW_NHWC ? dw->dwf : dw->dwrt.dw;
-    if (!f.wmm || (dw->fast == OpImpl::DW_RT && dw->rt_wz)) return false;
+    const int P = chain_superpixel(d.C);  // pixels per 16-channel "superpixel" (1: C % 16 == 0; 0: no such form)
+    if ((P == 1 && !f.wmm) || (dw->fast == OpImpl::DW_RT && dw->rt_wz)) return false;
     if (d.KH != 3 || d.KW != 3 || d.pad != MF_PAD_SAME || d.sh != d.sw || (d.sh != 1 && d.sh != 2) || d.C != d.N) return false;
-    if (d.C % 16 != 0 && !(d.C == 8 && d.sh == 1 && d.W % 2 == 0)) return false; // (C == 8: pixel pairs, see chain_geom)
-    if (q.KH != 1 || q.KW != 1 || q.sh != 1 || q.sw != 1 || q.OH != q.H || q.OW != q.W || (d.C == 8 ? 2 * q.N : q.N) % 16 != 0) return false;
+    if (P == 0 || d.W % (P * d.sh) != 0) return false; // (C < 16: whole superpixels in and out, see chain_geom)
+    if (P > 1 && d.sh == 2 && getenv("MF_CHAIN_NO_SP")) return false;
+    if (q.KH != 1 || q.KW != 1 || q.sh != 1 || q.sw != 1 || q.OH != q.H || q.OW != q.W || (P * q.N) % 16 != 0) return false;
     if (q.H != d.OH || q.W != d.OW || q.C != d.N) return false;
     if (pw->fast != OpImpl::PW_RT && pw->fast != OpImpl::PW_MFMA) return false;
     if (pw->fast == OpImpl::PW_RT && pw->rt_wz) return false;
     if (!dw->finite_consts || !pw->finite_consts || dw->magic_mode < 1 || pw->magic_mode < 1) return false;
     return true;
 }
-// The geometry the planner sees.  C == 8, stride 1 (the first pair of a MobileNet-v1-shaped network): two adjacent pixels form one
-// 16-channel "superpixel" -- the depthwise taps are build_dw_mm_weights' pair form (MFMA rows = (pixel parity, channel), filter-row
-// blocks = neighbouring superpixels), the 1x1 convolution is block diagonal over the two pixels -- so the pair IS a 16-channel pair
-// of half the width with twice the outputs.  Such a pair only ever runs alone (its output tensor is not in the next pair's units).
+// The geometry the planner sees.  C < 16 (the first pairs of a MobileNet-v1-shaped network: C = 8, or 4 and 8 at width 0.5): P = 16 / C
+// adjacent pixels form one 16-channel "superpixel" -- the depthwise taps are build_dw_mm_weights_sp (MFMA rows = (pixel of the
+// superpixel, channel), filter-row blocks = neighbouring superpixels, either stride), the 1x1 convolution is block diagonal over the P
+// pixels -- so the pair IS a 16-channel pair of 1/P the width with P times the outputs.  Such a pair only ever runs alone (its output
+// tensor is not in the next pair's units).
 static k::ChainGeom chain_geom(const OpImpl *dw, const OpImpl *pw) {
     const OpSpec &d = dw->s;
     const k::DwFastArgs &f = dw->fast == OpImpl::DW_NHWC ? dw->dwf : dw->dwrt.dw;
-    if (d.C == 8) return k::ChainGeom{d.H, d.W / 2, 16, 1, d.OH, d.OW / 2, 2 * pw->s.N, f.izp4};
+    const int P = chain_superpixel(d.C);
+    if (P > 1) return k::ChainGeom{d.H, d.W / P, 16, d.sh, d.OH, d.OW / P, P * pw->s.N, f.izp4};
     return k::ChainGeom{d.H, d.W, d.C, d.sh, d.OH, d.OW, pw->s.N, f.izp4};
 }
 static FusedImpl *chain_create(const std::pair<OpImpl *, OpImpl *> *mem, int n) {
@@ -968,7 +997,7 @@ static FusedImpl *chain_create(const std::pair<OpImpl *, OpImpl *> *mem, int n) 
     for (int i = 0; i < n; ++i) {
         if (!chain_pair_ok(mem[i].first, mem[i].second)) return nullptr;
         if (mem[i].first->device != mem[0].first->device || mem[i].first->s.u8 != mem[0].first->s.u8) return nullptr;
-        if (mem[i].first->s.C == 8 && n != 1) return nullptr;
+        if (mem[i].first->s.C < 16 && n != 1) return nullptr;
         geo[(size_t)i] = chain_geom(mem[i].first, mem[i].second);
     }
     std::vector<k::ChainPair> tab((size_t)n);
@@ -982,7 +1011,7 @@ static FusedImpl *chain_create(const std::pair<OpImpl *, OpImpl *> *mem, int n) 
         k::ChainPair &t = tab[(size_t)i];
         t.dw_wmm = f.wmm, t.dwA = f.A, t.dwS = f.S, t.dwK = f.Kc, t.dw_lo = f.lo_f, t.dw_hi = f.hi_f;
         const OpSpec &q = pw->s;
-        const int group = dw->s.C == 8 ? 2 : 1; // pixels per MFMA column / product row
+        const int group = chain_superpixel(dw->s.C); // pixels per MFMA column / product row
         std::vector<int8_t> host((size_t)q.N * q.C);
         MF_HIP(hipMemcpy(host.data(), pw->conv.w, host.size(), hipMemcpyDeviceToHost)); // [N][1][1][C], i8 domain, as uploaded
         const std::vector<int8_t> prep = build_pw_rt_reg_weights(host.data(), q.C, q.N, group, t.TB, t.NBLK);
@@ -990,17 +1019,26 @@ static FusedImpl *chain_create(const std::pair<OpImpl *, OpImpl *> *mem, int n) 
         c->stage_w.back()->upload(prep.data(), prep.size());
         t.pw_w = c->stage_w.back()->p;
         t.pwA = pw->conv.A, t.pwS = pw->conv.S, t.pwK = pw->conv.Kc, t.pw_lo = pw->conv.lo_f, t.pw_hi = pw->conv.hi_f;
-        if (group == 2) { // the constants of MFMA row (pixel parity, channel) are the channel's: both halves hold the same arrays
-            auto twice = [&](const void *d_src, int count) {
-                std::vector<int32_t> h((size_t)2 * count);
+        if (group > 1) {
+            // the taps in superpixel form (from the depthwise weights as uploaded: [3][3][C], i8 domain)
+            std::vector<int8_t> hw((size_t)9 * dw->s.C);
+            MF_HIP(hipMemcpy(hw.data(), dw->conv.w, hw.size(), hipMemcpyDeviceToHost));
+            const std::vector<int8_t> sp = build_dw_mm_weights_sp(hw.data(), dw->s.C, dw->s.sh);
+            c->stage_w.emplace_back(new DevBuf);
+            c->stage_w.back()->upload(sp.data(), sp.size());
+            t.dw_wmm = c->stage_w.back()->p;
+            // the constants of MFMA row (pixel of the superpixel, channel) are the channel's: `group` copies of the arrays
+            auto copies = [&](const void *d_src, int count) {
+                std::vector<int32_t> h((size_t)group * count);
                 MF_HIP(hipMemcpy(h.data(), d_src, (size_t)count * 4, hipMemcpyDeviceToHost));
-                for (int e = 0; e < count; ++e) h[(size_t)count + e] = h[(size_t)e];
+                for (int e = count; e < group * count; ++e) h[(size_t)e] = h[(size_t)(e % count)];
                 c->stage_w.emplace_back(new DevBuf);
                 c->stage_w.back()->upload(h.data(), h.size() * 4);
                 return c->stage_w.back()->p;
             };
-            t.dwA = (const float *)twice(f.A, 8), t.dwS = (const float *)twice(f.S, 8), t.dwK = (const int *)twice(f.Kc, 8);
-            t.pwA = (const float *)twice(pw->conv.A, q.N), t.pwS = (const float *)twice(pw->conv.S, q.N), t.pwK = (const int *)twice(pw->conv.Kc, q.N);
+            const int C = dw->s.C;
+            t.dwA = (const float *)copies(f.A, C), t.dwS = (const float *)copies(f.S, C), t.dwK = (const int *)copies(f.Kc, C);
+            t.pwA = (const float *)copies(pw->conv.A, q.N), t.pwS = (const float *)copies(pw->conv.S, q.N), t.pwK = (const int *)copies(pw->conv.Kc, q.N);
         }
         {
             std::vector<int> rt;
@@ -1054,7 +1092,7 @@ void fused_chain_partition(FusedImpl *const *groups, int n, int *seg_len, bool *
             k::ChainArgs a{};
             bool ok = true;
             for (int j = i; j < i + len && ok; ++j)
-                ok = groups[j]->chain_members[0].first->s.u8 == groups[i]->chain_members[0].first->s.u8 && (len == 1 || groups[j]->chain_members[0].first->s.C != 8);
+                ok = groups[j]->chain_members[0].first->s.u8 == groups[i]->chain_members[0].first->s.u8 && (len == 1 || groups[j]->chain_members[0].first->s.C >= 16);
             if (!ok || !k::chain_plan(geo.data() + i, len, tab.data(), a, 150 * 1024)) {
                 if (len == 1) { // (cannot happen for a group that exists; keep the programme total)
                     if (best[(size_t)i + 1] < best[(size_t)i]) best[(size_t)i] = best[(size_t)i + 1], choice[(size_t)i] = 1, choice_unf[(size_t)i] = 1;

@@ -25,6 +25,9 @@ CASES = [
     (80, 1.0, tw.INT8, 77),     # 40x40, 20x20, 10x10, 5x5, 3x3: odd sizes (few divisors: small column grids, many images per step)
     (64, 1.0, tw.UINT8, 140),
     (112, 1.0, tw.INT8, 33),
+    (128, 0.5, tw.INT8, 41),    # C = 4 and C = 8 stride 2 as superpixel pairs at 64x64
+    (64, 0.5, tw.UINT8, 90),
+    (96, 0.25, tw.INT8, 100),   # C = 2 (eight pixels per superpixel), C = 4 stride 2
 ]
 
 
