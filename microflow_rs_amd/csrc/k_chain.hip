@@ -36,6 +36,13 @@
 #ifndef MF_CHAIN_RAW_BARRIER
 #define MF_CHAIN_RAW_BARRIER 1 // 0: __syncthreads() between the phases of a step (A/B)
 #endif
+#ifndef MF_CHAIN_KEEP
+#define MF_CHAIN_KEEP 1 // 0: the single pair's record may be re-materialised by scalar loads inside the step loop (A/B)
+#endif
+#ifndef MF_CHAIN_KO
+#define MF_CHAIN_KO 0   // knock-out timing experiments (WRONG results, never shipped): 1 no depthwise requantisation, 2 no pointwise
+                          // requantisation, 4 no HBM stores, 8 no staging after the first step, 16 no phase barriers, 32 no top-of-step drain
+#endif
 #ifndef MF_CHAIN_WPE
 #define MF_CHAIN_WPE 4    // waves per SIMD the register allocation leaves room for (K <= 128)
 #endif
@@ -48,8 +55,8 @@ namespace mf {
 namespace k {
 
 #if MF_CHAIN_DIAG
-__device__ long long g_chain_trace[64];
-#define MF_CTR(k) do { if (blockIdx.x == 0 && wave == 0 && lane == 0 && trace_step == 2 && (k) < 64) g_chain_trace[k] = (long long)__builtin_readcyclecounter(); } while (0)
+__device__ long long g_chain_trace[128]; // [0..63] wave 0 (the wave that draws from the step queue), [64..127] wave 3
+#define MF_CTR(k) do { if (blockIdx.x == 0 && (wave == 0 || wave == 3) && lane == 0 && (k) < 62) { if (trace_step == 2) g_chain_trace[(k) + (wave ? 64 : 0)] = (long long)__builtin_readcyclecounter(); if (trace_step == 3 && (k) == 0) g_chain_trace[62 + (wave ? 64 : 0)] = (long long)__builtin_readcyclecounter(); } } while (0)
 #else
 #define MF_CTR(k) do { } while (0)
 #endif
@@ -133,7 +140,9 @@ __global__ __launch_bounds__(NW * 64, KSC == 4 ? 2 : (NW == 8 ? MF_CHAIN_WPE : 4
     // write on the VM counter: cdna_hip_programming.md, "Pipelining across barriers"), which would drain the next step's staging DMAs
     // -- and this step's HBM stores -- at every phase boundary instead of at the next step's top.
     auto phase_barrier = [&]() {
-#if MF_CHAIN_RAW_BARRIER
+#if MF_CHAIN_KO & 16
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#elif MF_CHAIN_RAW_BARRIER
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -141,7 +150,44 @@ __global__ __launch_bounds__(NW * 64, KSC == 4 ? 2 : (NW == 8 ? MF_CHAIN_WPE : 4
         __syncthreads();
 #endif
     };
-    auto load_dw = [&](c_pair &cp, int q) {
+    // A pair's record as the phases use it: plain registers.  SOLO: fetched ONCE before the step loop and laundered, so that the
+    // register allocator keeps (or lane-spills) the values instead of re-materialising them -- it otherwise re-issued ~50 scalar
+    // loads of the record per step, behind ~15 dependent lgkmcnt(0) waits (which also wait for the wave's LDS traffic), in front
+    // of every phase.  A chain fetches the record of the pair it enters (one batch of loads, one wait).
+    struct PR {
+        int H, W, C, S, OH, OW, N, NQ, lgNQ, KS, TB, NBLK, ROW, TILE, tile_off, swz_sh, swz_mask, lgCX, lgCY, UG, UY, UX, P, NCH, PLANE,
+            plimit_img, dst_off, dROW, dTILE, dC, dswz_sh, dswz_mask, otab_off;
+        float dw_lo, dw_hi, pw_lo, pw_hi;
+        int us0, us1, us2, ucnt;
+        const int *rtab;
+        const void *dw_wmm, *pw_w;
+        const float *dwA, *dwS, *pwA, *pwS;
+        const int *dwK, *pwK;
+    };
+    auto fetch_pair = [&](int pi) {
+        c_pair &c = pairs[pi];
+        PR r;
+        r.H = c.H, r.W = c.W, r.C = c.C, r.S = c.S, r.OH = c.OH, r.OW = c.OW, r.N = c.N, r.NQ = c.NQ, r.lgNQ = c.lgNQ, r.KS = c.KS, r.TB = c.TB;
+        r.NBLK = c.NBLK, r.ROW = c.ROW, r.TILE = c.TILE, r.tile_off = c.tile_off, r.swz_sh = c.swz_sh, r.swz_mask = c.swz_mask;
+        r.lgCX = c.lgCX, r.lgCY = c.lgCY, r.UG = c.UG, r.UY = c.UY, r.UX = c.UX, r.P = c.P, r.NCH = c.NCH, r.PLANE = c.PLANE;
+        r.plimit_img = c.plimit_img, r.dst_off = c.dst_off, r.dROW = c.dROW, r.dTILE = c.dTILE, r.dC = c.dC, r.dswz_sh = c.dswz_sh;
+        r.dswz_mask = c.dswz_mask, r.otab_off = c.otab_off;
+        r.dw_lo = c.dw_lo, r.dw_hi = c.dw_hi, r.pw_lo = c.pw_lo, r.pw_hi = c.pw_hi;
+        r.us0 = c.ustart[wave][0], r.us1 = c.ustart[wave][1], r.us2 = c.ustart[wave][2], r.ucnt = c.ucount[wave];
+        r.rtab = c.rtab, r.dw_wmm = c.dw_wmm, r.pw_w = c.pw_w, r.dwA = c.dwA, r.dwS = c.dwS, r.pwA = c.pwA, r.pwS = c.pwS, r.dwK = c.dwK, r.pwK = c.pwK;
+        if constexpr (SOLO && MF_CHAIN_KEEP) {
+#define MF_KEEP(x) asm volatile("" : "+s"(x))
+            MF_KEEP(r.H); MF_KEEP(r.W); MF_KEEP(r.C); MF_KEEP(r.S); MF_KEEP(r.OH); MF_KEEP(r.OW); MF_KEEP(r.N); MF_KEEP(r.NQ); MF_KEEP(r.lgNQ);
+            MF_KEEP(r.KS); MF_KEEP(r.TB); MF_KEEP(r.NBLK); MF_KEEP(r.ROW); MF_KEEP(r.TILE); MF_KEEP(r.tile_off); MF_KEEP(r.swz_sh);
+            MF_KEEP(r.swz_mask); MF_KEEP(r.lgCX); MF_KEEP(r.lgCY); MF_KEEP(r.UG); MF_KEEP(r.UY); MF_KEEP(r.UX); MF_KEEP(r.P); MF_KEEP(r.NCH);
+            MF_KEEP(r.PLANE); MF_KEEP(r.plimit_img); MF_KEEP(r.dst_off); MF_KEEP(r.otab_off);
+            MF_KEEP(r.dw_lo); MF_KEEP(r.dw_hi); MF_KEEP(r.pw_lo); MF_KEEP(r.pw_hi);
+            MF_KEEP(r.us0); MF_KEEP(r.us1); MF_KEEP(r.us2); MF_KEEP(r.ucnt); MF_KEEP(r.rtab);
+#undef MF_KEEP
+        }
+        return r;
+    };
+    auto load_dw = [&](const PR &cp, int q) {
         CDwW w;
 #pragma unroll
         for (int ty = 0; ty < 3; ++ty) w.A[ty] = ld16(cp.dw_wmm, (uint32_t)(((q * 3 + ty) * 64 + lane) * 16));
@@ -149,7 +195,7 @@ __global__ __launch_bounds__(NW * 64, KSC == 4 ? 2 : (NW == 8 ? MF_CHAIN_WPE : 4
         w.a = ldf4(cp.dwA, co), w.s = ldf4(cp.dwS, co), w.k = ldi4(cp.dwK, co);
         return w;
     };
-    auto load_pw = [&](c_pair &cp) {
+    auto load_pw = [&](const PR &cp) {
         CPwW<KSC> w;
         const int TB = cp.TB, KS = cp.KS, blk = wave & (cp.NBLK - 1);
 #pragma unroll
@@ -167,8 +213,7 @@ __global__ __launch_bounds__(NW * 64, KSC == 4 ? 2 : (NW == 8 ? MF_CHAIN_WPE : 4
     };
 
     // ---- staging of the chain's input (pair 0's tile) ----
-    auto stage = [&](int st, int buf) {
-        c_pair &cp = pairs[0];
+    auto stage = [&](const PR &cp, int st, int buf) {
         const int H = cp.H, ROWB = cp.W * cp.C, ROWCH = ROWB >> 4, IMG = H * ROWB;
         const int lgNQ = cp.lgNQ, nqm = cp.NQ - 1, sh = cp.swz_sh, mask = cp.swz_mask;
         // rows of the step's G images are one contiguous run of the input (image after image): wave w takes rows w, w + NWAVE, ...
@@ -200,7 +245,7 @@ __global__ __launch_bounds__(NW * 64, KSC == 4 ? 2 : (NW == 8 ? MF_CHAIN_WPE : 4
     // the host's table, and the unit loop is one branch-free block.
     // RES (compile time): the wave's operands stay what they are for the whole launch -- no reload code in the loop, hence no
     // vmcnt wait there (a wait for an operand reload would also wait for the step-ahead staging DMAs: both count on vmcnt)
-    auto dw_phase = [&](c_pair &cp, CDwW &wd, int tile_base, auto resc) { // wd: the operands of this wave's first channel group, already on their way
+    auto dw_phase = [&](const PR &cp, CDwW &wd, int tile_base, auto resc) { // wd: the operands of this wave's first channel group, already on their way
         constexpr bool RESD = decltype(resc)::value;
         const int S = cp.S, C = cp.C, ROW = cp.ROW, sh = cp.swz_sh, mask = cp.swz_mask;
         const int lgCX = cp.lgCX, lgCY = cp.lgCY, CXv = 1 << lgCX, CYv = 1 << lgCY;
@@ -214,8 +259,8 @@ __global__ __launch_bounds__(NW * 64, KSC == 4 ? 2 : (NW == 8 ? MF_CHAIN_WPE : 4
         typedef int i32x2 __attribute__((ext_vector_type(2)));
         typedef __attribute__((address_space(4))) const i32x2 c_int2;
         c_int2 *rt = (c_int2 *)(uintptr_t)cp.rtab;
-        int q = cp.ustart[wave][0], ux = cp.ustart[wave][1], j = cp.ustart[wave][2];
-        int n = cp.ucount[wave];
+        int q = cp.us0, ux = cp.us1, j = cp.us2;
+        int n = cp.ucnt;
         const float lo = cp.dw_lo, hi = cp.dw_hi;
         while (n > 0) {
             const int seg = min(n, UGY - j);
@@ -234,7 +279,11 @@ __global__ __launch_bounds__(NW * 64, KSC == 4 ? 2 : (NW == 8 ? MF_CHAIN_WPE : 4
                 acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(wd.A[2], t2, acc, 0, 0, 0);
                 // the next unit's taps (the last unit of a segment prefetches itself: no branch)
                 t0 = *(const v4i *)(lds + a_seg + e1[0]), t1 = *(const v4i *)(lds + a_seg + e1[0] + ROW), t2 = *(const v4i *)(lds + a_seg + e1[0] + 2 * ROW);
+#if MF_CHAIN_KO & 1
+                *(uint32_t *)(lds + m_seg + e0[1]) = (uint32_t)(acc[0] ^ acc[1] ^ acc[2] ^ acc[3]);
+#else
                 *(uint32_t *)(lds + m_seg + e0[1]) = requant_pack4<MG, XR4>(acc[0], acc[1], acc[2], acc[3], wd.a, wd.s, lo, hi);
+#endif
                 e0 = e1, e1 = e2;
             }
             n -= seg, j = 0;
@@ -250,7 +299,7 @@ __global__ __launch_bounds__(NW * 64, KSC == 4 ? 2 : (NW == 8 ? MF_CHAIN_WPE : 4
     // ---- pointwise phase of one pair: MID -> the next pair's tile, or HBM ----
     // The chunk loop is instantiated per (tiles per block, k steps, destination): with run-time bounds every MFMA sat in its own
     // basic block behind a branch and the TB independent chains of a chunk could not be interleaved.
-    auto pw_items = [&](c_pair &cp, const CPwW<KSC> &wp, int step, int gvalid, auto tbc, auto ksc, auto dstc) {
+    auto pw_items = [&](const PR &cp, const CPwW<KSC> &wp, int step, int gvalid, auto tbc, auto ksc, auto dstc) {
         constexpr int TB = decltype(tbc)::value, KS = decltype(ksc)::value;
         constexpr bool TO_TILE = decltype(dstc)::value;
         const int NBLK = cp.NBLK, N = cp.N;
@@ -292,13 +341,21 @@ __global__ __launch_bounds__(NW * 64, KSC == 4 ? 2 : (NW == 8 ? MF_CHAIN_WPE : 4
 #pragma unroll
                 for (int t = 0; t < TB; ++t) acc[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wp.A[t][ks], B[ks], acc[t], 0, 0, 0);
             uint32_t packed[TB];
-            if constexpr (TB == 2) { // (with four tiles the interleaved packs cost more registers than four waves per SIMD leave)
+#if MF_CHAIN_KO & 2
+#pragma unroll
+            for (int t = 0; t < TB; ++t) packed[t] = (uint32_t)(acc[t][0] ^ acc[t][1] ^ acc[t][2] ^ acc[t][3]);
+            if constexpr (false) {
+#else
+            if constexpr (TB == 2) {
+#endif // (with four tiles the interleaved packs cost more registers than four waves per SIMD leave)
 #pragma unroll
                 for (int t = 0; t < TB; t += 2)
                     requant_pack4x2<MG, XR4>(acc[t], wp.a[t], wp.s[t], acc[t + 1], wp.a[t + 1], wp.s[t + 1], lo, hi, packed[t], packed[t + 1]);
             } else {
+#if !(MF_CHAIN_KO & 2)
 #pragma unroll
                 for (int t = 0; t < TB; ++t) packed[t] = requant_pack4<MG, XR4>(acc[t][0], acc[t][1], acc[t][2], acc[t][3], wp.a[t], wp.s[t], lo, hi);
+#endif
             }
             if constexpr (TO_TILE) {
                 if (pix < P) {
@@ -307,7 +364,7 @@ __global__ __launch_bounds__(NW * 64, KSC == 4 ? 2 : (NW == 8 ? MF_CHAIN_WPE : 4
                     else if constexpr (TB == 2) *(uint2 *)d = make_uint2(packed[0], packed[1]);
                     else *(uint32_t *)d = packed[0];
                 }
-            } else if (pix < plim) {
+            } else if (pix < plim && (!(MF_CHAIN_KO & 4) || packed[0] == 0x12345678u)) {
                 int8_t *o = obase + voff0 + c * 16 * N;
                 if constexpr (TB == 4) st_out(o, make_uint4(packed[0], packed[1], packed[2], packed[3]));
                 else if constexpr (TB == 2) st_out(o, make_uint2(packed[0], packed[1]));
@@ -322,7 +379,7 @@ __global__ __launch_bounds__(NW * 64, KSC == 4 ? 2 : (NW == 8 ? MF_CHAIN_WPE : 4
             }
         }
     };
-    auto pw_phase = [&](c_pair &cp, const CPwW<KSC> &wp, int step, int gvalid) {
+    auto pw_phase = [&](const PR &cp, const CPwW<KSC> &wp, int step, int gvalid) {
         using std::integral_constant;
         const int TB = cp.TB, KS = cp.KS;
         const bool to_tile = cp.dst_off >= 0;
@@ -356,14 +413,15 @@ __global__ __launch_bounds__(NW * 64, KSC == 4 ? 2 : (NW == 8 ? MF_CHAIN_WPE : 4
 
     __syncthreads(); // halo fills and tables complete before any DMA lands
     const int nsteps = (batch + G - 1) / G;
-    if (dq.step < nsteps) stage(dq.step, 0);
+    PR cp = fetch_pair(0);
+    if (dq.step < nsteps) stage(cp, dq.step, 0);
     // a single pair keeps its operands in registers for the whole launch; a chain fetches them per phase (L2 hits): the
     // pointwise operands before the depthwise phase in front of them, the next depthwise's (first channel group) before
     // the pointwise phase in front of it -- so that both land under a phase of work
     const bool persist = NP == 1;
-    CDwW wd = load_dw(pairs[0], pairs[0].ustart[wave][0]);
+    CDwW wd = load_dw(cp, cp.us0);
     CPwW<KSC> wp;
-    if (persist) wp = load_pw(pairs[0]);
+    if (persist) wp = load_pw(cp);
     const bool dw_resident = RES; // (the launcher picks the RES instance when the plan says single_q)
     const bool dbuf = p.dbuf != 0;
     int cur = 0;
@@ -373,28 +431,36 @@ __global__ __launch_bounds__(NW * 64, KSC == 4 ? 2 : (NW == 8 ? MF_CHAIN_WPE : 4
     for (; dq.step < nsteps; dq.advance(tid)) {
         const int step = dq.step;
         MF_CTR(0);
+#if !(MF_CHAIN_KO & 32)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
         MF_CTR(1);
         __syncthreads(); // this step's images are in pair 0's tile; every wave has left the previous step's last phase
         MF_CTR(2);
         dq.top(tid);
         if constexpr (!SOLO) asm volatile("" : "+s"(pairs));
         MF_CTR(60);
-        if (dbuf && dq.nxt < nsteps) stage(dq.nxt, cur ^ 1); // double buffered: the next step's images have this whole step to land
+        if constexpr (!SOLO) cp = fetch_pair(0);
+        if (dbuf && dq.nxt < nsteps && !(MF_CHAIN_KO & 8)) stage(cp, dq.nxt, cur ^ 1); // double buffered: the next step's images have this whole step to land
         MF_CTR(61);
         const int gvalid = min(G, batch - step * G);
+        PR cp0 = cp; // (a chain stages pair 0's tile while it is inside a later pair)
         for (int pi = 0; pi < NP; ++pi) {
-            c_pair &cp = pairs[pi];
+            if constexpr (!SOLO) {
+                if (pi > 0) cp = fetch_pair(pi);
+            }
             if (!persist) wp = load_pw(cp); // lands during the depthwise phase
             MF_CTR(3 + 4 * pi);
             dw_phase(cp, wd, cp.tile_off + (pi == 0 ? cur * p.dbuf_stride : 0), std::integral_constant<bool, RES>{});
             MF_CTR(4 + 4 * pi);
             phase_barrier(); // MID complete; the tile has been read
             MF_CTR(5 + 4 * pi);
-            if (!dbuf && pi == p.stage_after && dq.nxt < nsteps) stage(dq.nxt, 0); // pair 0's tile region is free: the next step's images fly under the rest of this step
+            if (!dbuf && pi == p.stage_after && dq.nxt < nsteps && !(MF_CHAIN_KO & 8)) stage(cp0, dq.nxt, 0); // pair 0's tile region is free: the next step's images fly under the rest of this step
             if (!dw_resident) {
                 c_pair &nx = pairs[pi + 1 < NP ? pi + 1 : 0];
-                wd = load_dw(nx, nx.ustart[wave][0]); // lands during the pointwise phase
+                PR nr;
+                nr.dw_wmm = nx.dw_wmm, nr.dwA = nx.dwA, nr.dwS = nx.dwS, nr.dwK = nx.dwK;
+                wd = load_dw(nr, nx.ustart[wave][0]); // lands during the pointwise phase
             }
             pw_phase(cp, wp, step, gvalid);
             MF_CTR(6 + 4 * pi);
@@ -670,17 +736,29 @@ static void launch_chain_t(const int8_t *in, int8_t *out, const ChainArgs &a, in
     const int grid = nsteps < 256 * per_cu ? nsteps : 256 * per_cu;
     ChainArgs b = a;
     b.qcfg = dq_config(nsteps, grid, dq_est_us((double)batch * a.hbm_bytes, (double)batch * a.requant_bytes));
+    // Short steps, few of them per workgroup: static striding.  The queue's returning atomic is waited for where it is issued (hipcc
+    // broadcasts its result at once), ~600 - 1 200 cycles of the drawing wave at the top of a step, and the phase barrier makes that
+    // everyone's; the balance it buys only pays over many or long steps (profiles/r04/chain_dq_ab.txt: 8x8x128 -> 128 0.213 -> 0.192 ms,
+    // 3x3x128 0.084 -> 0.064 static; 64x64x8 -> 16 0.854 -> 0.906, five 4x4x128 pairs 1.015 -> 1.07 the other way).
+    {
+        static const bool forced = getenv("MF_DQ_CFG") != nullptr || getenv("MF_DQ_TUNE") != nullptr || getenv("MF_CHAIN_DQ_AUTO") != nullptr;
+        const double t_step_us = a.est_us_per_image * a.G * per_cu;
+        if (!forced && t_step_us < 8.0 && nsteps <= 48 * grid) b.qcfg = 0x100;
+    }
     b.queue = dq_slot(b.queue);
     hipLaunchKernelGGL((chain_rt<KSC, NW, SOLO, RES, MG, XR4>), dim3(grid), dim3(NW * 64), a.lds_bytes, s, in, out, b, batch);
 #if MF_CHAIN_DIAG
     {
         (void)hipStreamSynchronize(s);
-        long long h[64];
+        long long h[128];
         (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_chain_trace), sizeof(h));
-        fprintf(stderr, "[chain trace] %d pairs G %d lds %d nwave %d grid %d per_cu %d dbuf %d | cycles since the step's top:", a.npairs, a.G, a.lds_bytes, a.nwave, grid, per_cu, a.dbuf);
-        for (int i = 1; i < 3 + 4 * a.npairs && i < 60; ++i) fprintf(stderr, " %d:%lld", i, h[i] - h[0]);
-        fprintf(stderr, " | after queue top %lld, after staging issue %lld", h[60] - h[0], h[61] - h[0]);
-        fprintf(stderr, "\n");
+        fprintf(stderr, "[chain trace] %d pairs G %d lds %d nwave %d grid %d per_cu %d dbuf %d qcfg 0x%x\n", a.npairs, a.G, a.lds_bytes, a.nwave, grid, per_cu, a.dbuf, b.qcfg);
+        for (int w = 0; w < 2; ++w) {
+            const long long *t = h + 64 * w;
+            fprintf(stderr, "   wave %d: cycles since the step's top:", w ? 3 : 0);
+            for (int i = 1; i < 3 + 4 * a.npairs && i < 60; ++i) fprintf(stderr, " %d:%lld", i, t[i] - t[0]);
+            fprintf(stderr, " | after queue top %lld, after staging issue %lld, next step's top %lld\n", t[60] - t[0], t[61] - t[0], t[62] - t[0]);
+        }
     }
 #endif
 }

@@ -1054,6 +1054,7 @@ static FusedImpl *chain_create(const std::pair<OpImpl *, OpImpl *> *mem, int n) 
     }
     name += ";G" + std::to_string(c->chain.G) + ">";
     c->name = name;
+    if (getenv("MF_CHAIN_VERBOSE")) fprintf(stderr, "[microflow_amd] %s est %.4f us/image/CU lds %d nwave %d dbuf %d\n", name.c_str(), c->chain.est_us_per_image, c->chain.lds_bytes, c->chain.nwave, c->chain.dbuf);
     c->stage_w.emplace_back(new DevBuf);
     c->stage_w.back()->upload(tab.data(), tab.size() * sizeof(k::ChainPair));
     c->chain.pairs = (const k::ChainPair *)c->stage_w.back()->p;
