@@ -36,6 +36,9 @@
 #ifndef MF_CHAIN_RAW_BARRIER
 #define MF_CHAIN_RAW_BARRIER 1 // 0: __syncthreads() between the phases of a step (A/B)
 #endif
+#ifndef MF_CHAIN_STAGE_FAST
+#define MF_CHAIN_STAGE_FAST 1 // 0: every step's staging DMAs by the generic walk (A/B)
+#endif
 #ifndef MF_CHAIN_KEEP
 #define MF_CHAIN_KEEP 1 // 0: the single pair's record may be re-materialised by scalar loads inside the step loop (A/B)
 #endif
@@ -239,6 +242,44 @@ __global__ __launch_bounds__(NW * 64, KSC == 4 ? 2 : (NW == 8 ? MF_CHAIN_WPE : 4
         }
     };
 
+    // The same DMAs from per-wave descriptors made once per launch: a full step of a wave is `nd` instructions whose lane source
+    // offsets (relative to the step's first byte) and LDS destinations never change.  The generic walk above costs ~40 scalar and
+    // vector instructions per DMA -- ~1 100 cycles per wave and step for two DMAs on an 8x8x128 tensor (stamps), an eighth of the step.
+    constexpr int KD = 4;
+    int sd_src[KD], sd_dst[KD], nd = 0;
+    auto stage_plan = [&](const PR &cp) {
+        const int H = cp.H, ROWB = cp.W * cp.C, ROWCH = ROWB >> 4;
+        const int lgNQ = cp.lgNQ, nqm = cp.NQ - 1, sh = cp.swz_sh, mask = cp.swz_mask;
+#pragma unroll
+        for (int t = 0; t < KD; ++t) sd_src[t] = -1, sd_dst[t] = 0;
+        int gi = 0, y = wave;
+        while (y >= H) y -= H, ++gi;
+        for (int r = wave; r < G * H; r += NWAVE) {
+            for (int o = 0; o < ROWCH; o += 64) {
+                const int i = o + lane;
+                int sidx = i;
+                if (mask != 0) {
+                    const int x = i >> lgNQ, c = i & nqm;
+                    sidx = (x << lgNQ) + (c ^ (((x + 1) >> sh) & mask));
+                }
+                const int so = i < ROWCH ? r * ROWB + sidx * 16 : -1, dd = cp.C + gi * cp.TILE + (y + 1) * cp.ROW + o * 16;
+#pragma unroll
+                for (int t = 0; t < KD; ++t)
+                    if (t == nd) sd_src[t] = so, sd_dst[t] = dd;
+                ++nd;
+            }
+            y += NWAVE;
+            while (y >= H) y -= H, ++gi;
+        }
+    };
+    auto stage_fast = [&](const PR &cp, int st, int buf) {
+        const int8_t *src0 = in + (long)st * G * (cp.H * cp.W * cp.C);
+        uint8_t *tile0 = lds + cp.tile_off + buf * p.dbuf_stride;
+#pragma unroll
+        for (int t = 0; t < KD; ++t)
+            if (t < nd && sd_src[t] >= 0) dma16(src0 + sd_src[t], tile0 + __builtin_amdgcn_readfirstlane(sd_dst[t]));
+    };
+
     // ---- depthwise phase of one pair: tile -> MID ----
     // A wave's units are a contiguous range of the list (channel group q, column ux, j = (image group, row)): it is walked in
     // segments of constant (q, ux) -- inside one, the lane's operand address is a per-segment VGPR plus a scalar offset from
@@ -414,7 +455,20 @@ __global__ __launch_bounds__(NW * 64, KSC == 4 ? 2 : (NW == 8 ? MF_CHAIN_WPE : 4
     __syncthreads(); // halo fills and tables complete before any DMA lands
     const int nsteps = (batch + G - 1) / G;
     PR cp = fetch_pair(0);
-    if (dq.step < nsteps) stage(cp, dq.step, 0);
+    // (with one k step the kernel sits on the 128-register limit of four waves per SIMD: four more registers are spills there --
+    // 32x32x32 s2 -> 64 0.40 -> 0.54 ms with the descriptors; profiles/r04/chain_ab.txt)
+    constexpr bool FASTST = SOLO && KSC >= 2 && MF_CHAIN_STAGE_FAST;
+    if constexpr (FASTST) stage_plan(cp);
+    auto stage_any = [&](const PR &c0, int st, int buf) {
+        if constexpr (FASTST) {
+            if (nd <= KD && (st + 1) * G <= batch) { // (a full step; the ragged last one and large tensors take the generic walk)
+                stage_fast(c0, st, buf);
+                return;
+            }
+        }
+        stage(c0, st, buf);
+    };
+    if (dq.step < nsteps) stage_any(cp, dq.step, 0);
     // a single pair keeps its operands in registers for the whole launch; a chain fetches them per phase (L2 hits): the
     // pointwise operands before the depthwise phase in front of them, the next depthwise's (first channel group) before
     // the pointwise phase in front of it -- so that both land under a phase of work
@@ -441,7 +495,7 @@ __global__ __launch_bounds__(NW * 64, KSC == 4 ? 2 : (NW == 8 ? MF_CHAIN_WPE : 4
         if constexpr (!SOLO) asm volatile("" : "+s"(pairs));
         MF_CTR(60);
         if constexpr (!SOLO) cp = fetch_pair(0);
-        if (dbuf && dq.nxt < nsteps && !(MF_CHAIN_KO & 8)) stage(cp, dq.nxt, cur ^ 1); // double buffered: the next step's images have this whole step to land
+        if (dbuf && dq.nxt < nsteps && !(MF_CHAIN_KO & 8)) stage_any(cp, dq.nxt, cur ^ 1); // double buffered: the next step's images have this whole step to land
         MF_CTR(61);
         const int gvalid = min(G, batch - step * G);
         PR cp0 = cp; // (a chain stages pair 0's tile while it is inside a later pair)
@@ -455,7 +509,7 @@ __global__ __launch_bounds__(NW * 64, KSC == 4 ? 2 : (NW == 8 ? MF_CHAIN_WPE : 4
             MF_CTR(4 + 4 * pi);
             phase_barrier(); // MID complete; the tile has been read
             MF_CTR(5 + 4 * pi);
-            if (!dbuf && pi == p.stage_after && dq.nxt < nsteps && !(MF_CHAIN_KO & 8)) stage(cp0, dq.nxt, 0); // pair 0's tile region is free: the next step's images fly under the rest of this step
+            if (!dbuf && pi == p.stage_after && dq.nxt < nsteps && !(MF_CHAIN_KO & 8)) stage_any(cp0, dq.nxt, 0); // pair 0's tile region is free: the next step's images fly under the rest of this step
             if (!dw_resident) {
                 c_pair &nx = pairs[pi + 1 < NP ? pi + 1 : 0];
                 PR nr;
