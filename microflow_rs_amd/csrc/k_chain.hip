@@ -790,14 +790,12 @@ static void launch_chain_t(const int8_t *in, int8_t *out, const ChainArgs &a, in
     const int grid = nsteps < 256 * per_cu ? nsteps : 256 * per_cu;
     ChainArgs b = a;
     b.qcfg = dq_config(nsteps, grid, dq_est_us((double)batch * a.hbm_bytes, (double)batch * a.requant_bytes));
-    // Short steps, few of them per workgroup: static striding.  The queue's returning atomic is waited for where it is issued (hipcc
-    // broadcasts its result at once), ~600 - 1 200 cycles of the drawing wave at the top of a step, and the phase barrier makes that
-    // everyone's; the balance it buys only pays over many or long steps (profiles/r04/chain_dq_ab.txt: 8x8x128 -> 128 0.213 -> 0.192 ms,
-    // 3x3x128 0.084 -> 0.064 static; 64x64x8 -> 16 0.854 -> 0.906, five 4x4x128 pairs 1.015 -> 1.07 the other way).
+    // A handful of short steps per workgroup: static striding (the queue's first draw and its arrival count are a fixed cost per
+    // launch, and there is nothing to balance over 8 - 16 steps; profiles/r04/chain_dq_ab.txt: 3x3x128 0.073 -> 0.066 ms, 6x6x64 s2 0.074 -> 0.072).
     {
         static const bool forced = getenv("MF_DQ_CFG") != nullptr || getenv("MF_DQ_TUNE") != nullptr || getenv("MF_CHAIN_DQ_AUTO") != nullptr;
         const double t_step_us = a.est_us_per_image * a.G * per_cu;
-        if (!forced && t_step_us < 8.0 && nsteps <= 48 * grid) b.qcfg = 0x100;
+        if (!forced && t_step_us < 8.0 && nsteps <= 20 * grid) b.qcfg = 0x100;
     }
     b.queue = dq_slot(b.queue);
     hipLaunchKernelGGL((chain_rt<KSC, NW, SOLO, RES, MG, XR4>), dim3(grid), dim3(NW * 64), a.lds_bytes, s, in, out, b, batch);

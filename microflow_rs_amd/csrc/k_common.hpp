@@ -412,6 +412,7 @@ struct DynSteps {
     int *ctr;  // device: ctr[h * PITCH] = draws from head h; ctr[HEADS * PITCH] = workgroups finished
     int step, nxt, nn, it, fetched;
     int K, nheads, head;                  // steps per draw; counters in use (1 or 8) and this workgroup's
+    int S0;                               // the first S0 steps of every workgroup are static (blockIdx.x + i gridDim.x), drawn ones follow
     int pool_next, pool_left, sel, write_at;
     // cfg = K | nheads << 8 (dq_config below).  A draw is a chunk of K consecutive steps and has K iterations to return.
     // One device-wide counter sustains ~90 draws per microsecond (MI355X_MICROARCH.md) while the kernels with one-image
@@ -422,17 +423,21 @@ struct DynSteps {
     // Call before the kernel's first __syncthreads().
     __device__ __forceinline__ void init(uint8_t *lds_slot, int *counters, int tid, int cfg) {
         slot = (int *)lds_slot, ctr = counters, step = blockIdx.x, nxt = blockIdx.x + gridDim.x, nn = 0, it = 0, fetched = 0;
-        K = cfg & 0xff, nheads = cfg >> 8, head = nheads > 1 ? blockIdx.x % nheads : 0; // K == 0: static striding
+        K = cfg & 0xff, nheads = (cfg >> 8) & 0xff, head = nheads > 1 ? blockIdx.x % nheads : 0; // K == 0: static striding
+        S0 = cfg >> 16;
+        if (S0 < 2) S0 = 2;
         pool_next = 0, pool_left = 0, sel = 0, write_at = -1;
         if (MF_DYNQ && K != 0 && tid == 0) slot[0] = draw();
     }
     __device__ __forceinline__ int draw() { return index_of(atomicAdd(ctr + head * PITCH, 1)); }
     // first step of the d-th chunk drawn from this workgroup's head
-    __device__ __forceinline__ int index_of(int d) const { return 2 * (int)gridDim.x + K * (nheads * d + head); }
+    __device__ __forceinline__ int index_of(int d) const { return S0 * (int)gridDim.x + K * (nheads * d + head); }
     // right after the barrier at the top of an iteration
     __device__ __forceinline__ void top(int tid) {
         if (MF_DYNQ && K != 0) {
-            if (pool_left == 0) { // start the chunk drawn earlier, draw the one after it (due K iterations from now)
+            if (it + 2 < S0) {    // still inside the static prefix: the step after next is a stride away
+                nn = nxt + (int)gridDim.x;
+            } else if (pool_left == 0) { // start the chunk drawn earlier, draw the one after it (due K iterations from now)
                 nn = __builtin_amdgcn_readfirstlane(slot[sel]);
                 pool_next = nn + 1, pool_left = K - 1, sel ^= 1, write_at = it + K - 1;
                 // The RAW result of the atomic is kept and nothing is computed from it here (the index arithmetic happens in
@@ -465,8 +470,12 @@ struct DynSteps {
         if (MF_DYNQ && K != 0 && tid == 0) {
             // this workgroup's last (speculative, unconsumed) draw must have landed before its arrival is counted: otherwise it
             // could hit the counter after the last workgroup's reset and the next launch on this set would skip a chunk
+            // (A returning atomic that has returned has been performed, and the arrival below is issued after the wait: that is all
+            // the order the reset needs.  The arrival itself stays RELAXED: an agent-scope acquire/release here writes back and
+            // invalidates the XCD's L2 once per workgroup -- 512 times per launch, under the workgroups that are still running;
+            // round 4 measured 0.208 vs 0.183 ms on a 0.2 ms launch, profiles/r04/chain_dq_ab.txt.)
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            if (__hip_atomic_fetch_add(ctr + HEADS * PITCH, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1) {
+            if (__hip_atomic_fetch_add(ctr + HEADS * PITCH, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1) {
 #pragma unroll
                 for (int h = 0; h <= HEADS; ++h) ctr[h * PITCH] = 0;
             }
@@ -499,7 +508,14 @@ static inline int dq_config(int nsteps, int grid, double est_us) {
     const double t_step = est_us * grid / (nsteps > 0 ? nsteps : 1);   // one workgroup's step, us
     const int K = t_step >= 8.0 ? 1 : (t_step >= 4.0 ? 2 : 4);
     const double draws_per_us = nsteps / (K * (est_us > 1.0 ? est_us : 1.0));
-    const int cfg = K | (draws_per_us > 60.0 ? 8 : 1) << 8;
+    // Static prefix: a draw's returning atomic is waited for where it is issued (hipcc broadcasts the result at once), 600 - 1 200
+    // cycles of one wave at the top of a step that the next barrier makes the whole workgroup's.  What the queue is for -- workgroups
+    // of one CU drifting apart, the tail -- needs only the last part of a launch to be dealt dynamically: the first
+    // MF_DQ_STATIC (default 0.6) of every workgroup's share is a stride walk.
+    static const double sfrac = [] { const char *e = getenv("MF_DQ_STATIC"); return e ? atof(e) : 0.6; }();
+    int S0 = (int)(sfrac * (double)nsteps / (grid > 0 ? grid : 1));
+    S0 = S0 < 2 ? 2 : (S0 > 32767 ? 32767 : S0);
+    const int cfg = K | (draws_per_us > 60.0 ? 8 : 1) << 8 | S0 << 16;
     static const bool verbose = getenv("MF_DQ_VERBOSE") != nullptr;
     if (verbose) fprintf(stderr, "[microflow_amd] step queue: %d steps on %d workgroups, est %.0f us -> cfg 0x%x\n", nsteps, grid, est_us, cfg);
     return cfg;
