@@ -31,7 +31,9 @@
 
 // tuning switches (scripts/variants.py)
 #ifndef MF_CHAIN_TBM1
-#define MF_CHAIN_TBM1 4   // output tiles per wave block with one k step (K <= 64): 4 or 2
+#define MF_CHAIN_TBM1 2   // output tiles per wave block with one k step (K <= 64): 2, or 4 (a lane then ends with 16 consecutive bytes, but the
+                          // kernel sits on the 128-register limit and spills: its reloads are vector-memory loads whose wait also waits for the
+                          // staging DMAs; round 4, profiles/r04/chain_ab.txt: 32x32x32 s2 -> 64 0.395 -> 0.336 ms, 64x64x16 s2 -> 32 0.757 -> 0.667 with 2)
 #endif
 #ifndef MF_CHAIN_RAW_BARRIER
 #define MF_CHAIN_RAW_BARRIER 1 // 0: __syncthreads() between the phases of a step (A/B)
@@ -457,11 +459,15 @@ __global__ __launch_bounds__(NW * 64, KSC == 4 ? 2 : (NW == 8 ? MF_CHAIN_WPE : 4
     PR cp = fetch_pair(0);
     // (with one k step the kernel sits on the 128-register limit of four waves per SIMD: four more registers are spills there --
     // 32x32x32 s2 -> 64 0.40 -> 0.54 ms with the descriptors; profiles/r04/chain_ab.txt)
-    constexpr bool FASTST = SOLO && KSC >= 2 && MF_CHAIN_STAGE_FAST;
-    if constexpr (FASTST) stage_plan(cp);
+    constexpr bool FASTST = SOLO && (RES || KSC == 1) && (KSC >= 2 || MF_CHAIN_TBM1 <= 2) && MF_CHAIN_STAGE_FAST;
+    // (the descriptors are a prologue: not for a launch of a few steps per workgroup -- 3x3x128 0.063 -> 0.067 ms with them)
+    const bool fast_stage = FASTST && ((batch + G - 1) / G) > 24 * (int)gridDim.x;
+    if constexpr (FASTST) {
+        if (fast_stage) stage_plan(cp);
+    }
     auto stage_any = [&](const PR &c0, int st, int buf) {
         if constexpr (FASTST) {
-            if (nd <= KD && (st + 1) * G <= batch) { // (a full step; the ragged last one and large tensors take the generic walk)
+            if (fast_stage && nd <= KD && (st + 1) * G <= batch) { // (a full step; the ragged last one and large tensors take the generic walk)
                 stage_fast(c0, st, buf);
                 return;
             }

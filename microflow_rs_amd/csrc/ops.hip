@@ -1075,6 +1075,46 @@ bool fused_is_chain_single(const FusedImpl *f) { return f && f->kind == FusedImp
 // How to run `n` consecutive single-pair chain groups: seg_len[i] = number of pairs of the chain that starts at pair i (0: pair i is
 // inside a chain that started earlier); unfused[i] = pair i is cheapest as two separate operator launches.  Dynamic programme over the
 // planner's cost estimates (k_chain.hip: chain_plan / chain_unfused_us_per_image).
+void fused_run(FusedImpl *f, const int8_t *d_in, size_t batch, int8_t *d_out, void *stream);
+namespace {
+// The partition by MEASUREMENT (the default when a device is there, i.e. always: operators are created on one): every plannable
+// candidate "pairs i .. i + len - 1 as one chain_rt launch", and every pair as its two separate operators, is run on scratch tensors
+// at a batch that fills the chip for dozens of steps, and the dynamic programme takes the times.  The cost model's errors were
+// 0.7 - 1.5x on single pairs and 1.0 - 1.3x on chains (profiles/r04/chain_calib.txt) -- larger than the differences it decides
+// between -- and every kernel change moved them.  ~0.1 - 0.3 s per model at creation; MF_CHAIN_AUTOTUNE=0 goes back to the estimates.
+struct ChainTimer {
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    DevBuf a, b, c;
+    size_t cap = 0;
+    bool ok = false;
+    explicit ChainTimer(size_t bytes) {
+        if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return;
+        for (DevBuf *d : {&a, &b, &c}) {
+            if (hipMalloc(&d->p, bytes) != hipSuccess) { (void)hipGetLastError(); return; }
+            (void)hipMemset(d->p, 0, bytes);
+        }
+        cap = bytes, ok = hipDeviceSynchronize() == hipSuccess;
+    }
+    ~ChainTimer() {
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+    }
+    template <typename F> double us(F &&launch) { // best of three after a warm-up; < 0: failed
+        launch();
+        double best = -1;
+        for (int r = 0; r < 3; ++r) {
+            if (hipEventRecord(e0, nullptr) != hipSuccess) return -1;
+            launch();
+            if (hipEventRecord(e1, nullptr) != hipSuccess || hipEventSynchronize(e1) != hipSuccess) return -1;
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, e0, e1) != hipSuccess) return -1;
+            best = best < 0 || ms * 1e3 < best ? ms * 1e3 : best;
+        }
+        return best;
+    }
+};
+} // namespace
+
 void fused_chain_partition(FusedImpl *const *groups, int n, int *seg_len, bool *unfused) {
     std::vector<k::ChainGeom> geo((size_t)n);
     for (int i = 0; i < n; ++i) {
@@ -1088,8 +1128,62 @@ void fused_chain_partition(FusedImpl *const *groups, int n, int *seg_len, bool *
     std::vector<char> choice_unf((size_t)n + 1, 0);
     best[(size_t)n] = 0;
     std::vector<k::ChainPair> tab((size_t)k::CHAIN_MAX);
+    static const bool autotune = [] { const char *e = getenv("MF_CHAIN_AUTOTUNE"); return !(e && e[0] == '0'); }();
+    static const bool verbose_t = getenv("MF_CHAIN_VERBOSE") != nullptr;
+    // measured[i][len]: microseconds per image of the candidate (< 0: not measured); measured_unf[i]: of the pair's two operators
+    std::vector<std::vector<double>> measured((size_t)n, std::vector<double>((size_t)k::CHAIN_MAX + 1, -1.0));
+    std::vector<double> measured_unf((size_t)n, -1.0);
+    if (autotune && n >= 1) {
+        const size_t CAP = (size_t)192 << 20;
+        ChainTimer tm(CAP);
+        auto tensor_bytes = [&](int i, int len) { // the largest tensor any operator of pairs i .. i + len - 1 touches, per image
+            size_t m = 0;
+            for (int j = i; j < i + len; ++j) {
+                const OpSpec &d = groups[j]->chain_members[0].first->s, &q = groups[j]->chain_members[0].second->s;
+                m = std::max(m, std::max((size_t)d.H * d.W * d.C, std::max((size_t)d.OH * d.OW * d.N, (size_t)q.OH * q.OW * q.N)));
+            }
+            return m;
+        };
+        for (int i = 0; i < n && tm.ok; ++i) {
+            for (int len = 1; len <= n - i && len <= k::CHAIN_MAX; ++len) {
+                bool ok = true;
+                for (int j = i; j < i + len && ok; ++j)
+                    ok = groups[j]->chain_members[0].first->s.u8 == groups[i]->chain_members[0].first->s.u8 && (len == 1 || groups[j]->chain_members[0].first->s.C >= 16);
+                if (!ok) break;
+                size_t B = CAP / std::max<size_t>(tensor_bytes(i, len), 1);
+                B = std::min<size_t>(B, 65536) & ~(size_t)63;
+                if (B < 256) continue;
+                FusedImpl *f = len == 1 ? groups[i] : fused_chain_create(groups + i, len);
+                if (!f) continue; // (no plan: longer candidates from i may still exist -- a later pair can be smaller)
+                const double t = tm.us([&] { fused_run(f, (const int8_t *)tm.a.p, B, (int8_t *)tm.b.p, nullptr); });
+                if (len > 1) fused_destroy(f);
+                if (t > 0) measured[(size_t)i][(size_t)len] = t / (double)B;
+                if (len == 1) {
+                    OpImpl *dw = groups[i]->chain_members[0].first, *pw = groups[i]->chain_members[0].second;
+                    const double u = tm.us([&] {
+                        op_run(dw, (const int8_t *)tm.a.p, B, (int8_t *)tm.c.p, nullptr);
+                        op_run(pw, (const int8_t *)tm.c.p, B, (int8_t *)tm.b.p, nullptr);
+                    });
+                    if (u > 0) measured_unf[(size_t)i] = u / (double)B;
+                }
+                if (verbose_t)
+                    fprintf(stderr, "[microflow_amd] chain autotune: pairs %d..%d batch %zu: %.4f us/image%s\n", i, i + len - 1, B, measured[(size_t)i][(size_t)len],
+                            len == 1 ? (" (unfused " + std::to_string(measured_unf[(size_t)i]) + ")").c_str() : "");
+            }
+        }
+        (void)hipDeviceSynchronize();
+        (void)hipGetLastError();
+    }
     for (int i = n - 1; i >= 0; --i) {
         for (int len = 1; len <= n - i && len <= k::CHAIN_MAX; ++len) {
+            if (autotune && measured[(size_t)i][1] > 0) { // measured costs (a candidate that was not measured does not exist)
+                double c = measured[(size_t)i][(size_t)len];
+                if (c <= 0) continue;
+                char unf = 0;
+                if (len == 1 && !force_fuse && measured_unf[(size_t)i] > 0 && measured_unf[(size_t)i] < c) c = measured_unf[(size_t)i], unf = 1;
+                if (c + best[(size_t)i + len] < best[(size_t)i]) best[(size_t)i] = c + best[(size_t)i + len], choice[(size_t)i] = len, choice_unf[(size_t)i] = unf;
+                continue;
+            }
             k::ChainArgs a{};
             bool ok = true;
             for (int j = i; j < i + len && ok; ++j)
@@ -1116,7 +1210,7 @@ void fused_chain_partition(FusedImpl *const *groups, int n, int *seg_len, bool *
         fprintf(stderr, "[microflow_amd] chain partition of %d pairs:", n);
         for (int i = 0; i < n; ++i)
             if (seg_len[i]) fprintf(stderr, " [%d..%d%s]", i, i + seg_len[i] - 1, unfused[i] ? " unfused" : "");
-        fprintf(stderr, " est %.3f us/image/CU\n", best[0]);
+        fprintf(stderr, " %s %.4f us/image%s\n", autotune ? "measured" : "est", best[0], autotune ? "" : "/CU");
     }
 }
 
