@@ -840,7 +840,19 @@ void launch_chain(const int8_t *in, int8_t *out, const ChainArgs &a, int batch, 
     if (a.KSC == 1 && a.nwave == 16) MF_CHAIN_GO(1, 16);
     else if (a.KSC == 1) MF_CHAIN_GO(1, 8);
     else if (a.KSC == 2) MF_CHAIN_GO(2, 8);
-    else MF_CHAIN_GO(4, 8);
+    else if (a.magic == 0) {
+        // 256-deep products whose accumulators may leave (-2^22, 2^22) (full-range weights): the v_cvt form of the epilogue.  Only
+        // here: below 256 input channels |acc| <= K * 127 * 255 < 2^22 always holds.
+        if (a.xr) {
+            if (a.npairs == 1 && a.resident) launch_chain_t<4, 8, true, true, 0, 0x80808080u>(in, out, a, batch, s);
+            else if (a.npairs == 1) launch_chain_t<4, 8, true, false, 0, 0x80808080u>(in, out, a, batch, s);
+            else launch_chain_t<4, 8, false, false, 0, 0x80808080u>(in, out, a, batch, s);
+        } else {
+            if (a.npairs == 1 && a.resident) launch_chain_t<4, 8, true, true, 0, 0u>(in, out, a, batch, s);
+            else if (a.npairs == 1) launch_chain_t<4, 8, true, false, 0, 0u>(in, out, a, batch, s);
+            else launch_chain_t<4, 8, false, false, 0, 0u>(in, out, a, batch, s);
+        }
+    } else MF_CHAIN_GO(4, 8);
 #undef MF_CHAIN_GO
 #undef MF_CHAIN_GO2
 }

@@ -976,7 +976,8 @@ static bool chain_pair_ok(const OpImpl *dw, const OpImpl *pw) {
     if (q.H != d.OH || q.W != d.OW || q.C != d.N) return false;
     if (pw->fast != OpImpl::PW_RT && pw->fast != OpImpl::PW_MFMA) return false;
     if (pw->fast == OpImpl::PW_RT && pw->rt_wz) return false;
-    if (!dw->finite_consts || !pw->finite_consts || dw->magic_mode < 1 || pw->magic_mode < 1) return false;
+    if (!dw->finite_consts || !pw->finite_consts) return false;
+    if ((dw->magic_mode < 1 || pw->magic_mode < 1) && q.C < 256) return false; // (the v_cvt epilogue exists for four k steps only: launch_chain)
     return true;
 }
 // The geometry the planner sees.  C < 16 (the first pairs of a MobileNet-v1-shaped network: C = 8, or 4 and 8 at width 0.5): P = 16 / C
@@ -995,14 +996,23 @@ static FusedImpl *chain_create(const std::pair<OpImpl *, OpImpl *> *mem, int n) 
     if (!chain_enabled() || n < 1 || n > k::CHAIN_MAX) return nullptr;
     std::vector<k::ChainGeom> geo((size_t)n);
     for (int i = 0; i < n; ++i) {
-        if (!chain_pair_ok(mem[i].first, mem[i].second)) return nullptr;
+        if (!chain_pair_ok(mem[i].first, mem[i].second)) {
+            if (n == 1 && getenv("MF_CHAIN_VERBOSE"))
+                fprintf(stderr, "[microflow_amd] not a chain pair: %dx%dx%d s%d (kernels %s, %s; epilogue modes %d, %d)\n", mem[i].first->s.H, mem[i].first->s.W,
+                        mem[i].first->s.C, mem[i].first->s.sh, mem[i].first->fast_name.c_str(), mem[i].second->fast_name.c_str(), mem[i].first->magic_mode, mem[i].second->magic_mode);
+            return nullptr;
+        }
         if (mem[i].first->device != mem[0].first->device || mem[i].first->s.u8 != mem[0].first->s.u8) return nullptr;
         if (mem[i].first->s.C < 16 && n != 1) return nullptr;
         geo[(size_t)i] = chain_geom(mem[i].first, mem[i].second);
     }
     std::vector<k::ChainPair> tab((size_t)n);
     std::unique_ptr<FusedImpl> c(new FusedImpl{FusedImpl::CHAIN, mem[0].first, mem[n - 1].second, nullptr, {}, {}, ""});
-    if (!k::chain_plan(geo.data(), n, tab.data(), c->chain, 150 * 1024)) return nullptr;
+    if (!k::chain_plan(geo.data(), n, tab.data(), c->chain, 150 * 1024)) {
+        if (n == 1 && getenv("MF_CHAIN_VERBOSE"))
+            fprintf(stderr, "[microflow_amd] no chain plan for %dx%dx%d s%d -> %d\n", geo[0].H, geo[0].W, geo[0].C, geo[0].S, geo[0].N);
+        return nullptr;
+    }
     int magic = 2;
     std::string name = "chain_rt<";
     for (int i = 0; i < n; ++i) {
@@ -1058,6 +1068,7 @@ static FusedImpl *chain_create(const std::pair<OpImpl *, OpImpl *> *mem, int n) 
     c->stage_w.emplace_back(new DevBuf);
     c->stage_w.back()->upload(tab.data(), tab.size() * sizeof(k::ChainPair));
     c->chain.pairs = (const k::ChainPair *)c->stage_w.back()->p;
+    if (magic == 0 && c->chain.KSC != 4) return nullptr;
     c->chain.magic = magic, c->chain.xr = mem[0].first->s.u8 ? 0x80 : 0;
     c->chain.queue = (int *)mem[0].first->d_queue.p;
     return c.release();
@@ -1099,10 +1110,10 @@ struct ChainTimer {
         if (e0) (void)hipEventDestroy(e0);
         if (e1) (void)hipEventDestroy(e1);
     }
-    template <typename F> double us(F &&launch) { // best of three after a warm-up; < 0: failed
+    template <typename F> double us(F &&launch) { // best of five after a warm-up; < 0: failed
         launch();
         double best = -1;
-        for (int r = 0; r < 3; ++r) {
+        for (int r = 0; r < 5; ++r) {
             if (hipEventRecord(e0, nullptr) != hipSuccess) return -1;
             launch();
             if (hipEventRecord(e1, nullptr) != hipSuccess || hipEventSynchronize(e1) != hipSuccess) return -1;
@@ -1179,6 +1190,7 @@ void fused_chain_partition(FusedImpl *const *groups, int n, int *seg_len, bool *
             if (autotune && measured[(size_t)i][1] > 0) { // measured costs (a candidate that was not measured does not exist)
                 double c = measured[(size_t)i][(size_t)len];
                 if (c <= 0) continue;
+                if (len > 1) c *= 1.05; // (a chain has to win clearly: isolated timings of this size repeat to 2 - 3 %)
                 char unf = 0;
                 if (len == 1 && !force_fuse && measured_unf[(size_t)i] > 0 && measured_unf[(size_t)i] < c) c = measured_unf[(size_t)i], unf = 1;
                 if (c + best[(size_t)i + len] < best[(size_t)i]) best[(size_t)i] = c + best[(size_t)i + len], choice[(size_t)i] = len, choice_unf[(size_t)i] = unf;
