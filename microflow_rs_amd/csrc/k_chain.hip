@@ -46,7 +46,8 @@
 #endif
 #ifndef MF_CHAIN_KO
 #define MF_CHAIN_KO 0   // knock-out timing experiments (WRONG results, never shipped): 1 no depthwise requantisation, 2 no pointwise
-                          // requantisation, 4 no HBM stores, 8 no staging after the first step, 16 no phase barriers, 32 no top-of-step drain
+                          // requantisation, 4 no HBM stores, 8 no staging after the first step, 16 no phase barriers, 32 no top-of-step drain,
+                          // 64 a chain's per-phase operand loads only in the first step, 128 its pair records only in the first step
 #endif
 #ifndef MF_CHAIN_WPE
 #define MF_CHAIN_WPE 4    // waves per SIMD the register allocation leaves room for (K <= 128)
@@ -485,6 +486,7 @@ __global__ __launch_bounds__(NW * 64, KSC == 4 ? 2 : (NW == 8 ? MF_CHAIN_WPE : 4
     const bool dw_resident = RES; // (the launcher picks the RES instance when the plan says single_q)
     const bool dbuf = p.dbuf != 0;
     int cur = 0;
+    int trace_ko = 0; // (steps done: the knock-out switches 64 / 128 act from the second step on)
 #if MF_CHAIN_DIAG
     int trace_step = 0;
 #endif
@@ -507,16 +509,16 @@ __global__ __launch_bounds__(NW * 64, KSC == 4 ? 2 : (NW == 8 ? MF_CHAIN_WPE : 4
         PR cp0 = cp; // (a chain stages pair 0's tile while it is inside a later pair)
         for (int pi = 0; pi < NP; ++pi) {
             if constexpr (!SOLO) {
-                if (pi > 0) cp = fetch_pair(pi);
+                if (pi > 0 && !((MF_CHAIN_KO & 128) && trace_ko > 0)) cp = fetch_pair(pi);
             }
-            if (!persist) wp = load_pw(cp); // lands during the depthwise phase
+            if (!persist && !((MF_CHAIN_KO & 64) && trace_ko > 0)) wp = load_pw(cp); // lands during the depthwise phase
             MF_CTR(3 + 4 * pi);
             dw_phase(cp, wd, cp.tile_off + (pi == 0 ? cur * p.dbuf_stride : 0), std::integral_constant<bool, RES>{});
             MF_CTR(4 + 4 * pi);
             phase_barrier(); // MID complete; the tile has been read
             MF_CTR(5 + 4 * pi);
             if (!dbuf && pi == p.stage_after && dq.nxt < nsteps && !(MF_CHAIN_KO & 8)) stage_any(cp0, dq.nxt, 0); // pair 0's tile region is free: the next step's images fly under the rest of this step
-            if (!dw_resident) {
+            if (!dw_resident && !((MF_CHAIN_KO & 64) && trace_ko > 0)) {
                 c_pair &nx = pairs[pi + 1 < NP ? pi + 1 : 0];
                 PR nr;
                 nr.dw_wmm = nx.dw_wmm, nr.dwA = nx.dwA, nr.dwS = nx.dwS, nr.dwK = nx.dwK;
@@ -527,6 +529,7 @@ __global__ __launch_bounds__(NW * 64, KSC == 4 ? 2 : (NW == 8 ? MF_CHAIN_WPE : 4
             if (pi + 1 < NP) phase_barrier(); // the next pair's tile is complete; MID is free
         }
         if (dbuf) cur ^= 1;
+        ++trace_ko;
 #if MF_CHAIN_DIAG
         ++trace_step;
 #endif
