@@ -723,6 +723,16 @@ bool chain_plan(const ChainGeom *g, int n, ChainPair *pairs, ChainArgs &a, int l
         if (e < best * 0.97) best = e, bestG = G, best_nwave = nw; // (a larger step must pay for its LDS: 3 % at least)
     }
     if (!bestG) return false;
+    {   // experiment: MF_CHAIN_G_SHIFT = +1 / -1 doubles / halves the chosen G where the LDS allows (single pairs only)
+        static const int gshift = [] { const char *e = getenv("MF_CHAIN_G_SHIFT"); return e ? atoi(e) : 0; }();
+        if (gshift != 0 && n == 1) {
+            const int G2 = gshift > 0 ? bestG * 2 : bestG / 2;
+            if (G2 >= maxCG && G2 <= 128 && lds_for(G2, false, want_dbuf(G2)) <= lds_budget) {
+                int nw = 8;
+                best = estimate(G2, lds_for(G2, false, want_dbuf(G2)), nw), bestG = G2, best_nwave = nw;
+            }
+        }
+    }
     const int G = bestG, NW = best_nwave;
     a.G = G, a.nwave = NW, a.est_us_per_image = best;
     a.dbuf = 0, a.dbuf_stride = 0;

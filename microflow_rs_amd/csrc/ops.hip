@@ -1145,7 +1145,7 @@ void fused_chain_partition(FusedImpl *const *groups, int n, int *seg_len, bool *
     std::vector<std::vector<double>> measured((size_t)n, std::vector<double>((size_t)k::CHAIN_MAX + 1, -1.0));
     std::vector<double> measured_unf((size_t)n, -1.0);
     if (autotune && n >= 1) {
-        const size_t CAP = (size_t)192 << 20;
+        const size_t CAP = (size_t)512 << 20; // bytes of the largest tensor of a candidate: dozens of steps per workgroup also for 2 KB images
         ChainTimer tm(CAP);
         auto tensor_bytes = [&](int i, int len) { // the largest tensor any operator of pairs i .. i + len - 1 touches, per image
             size_t m = 0;
@@ -1162,7 +1162,7 @@ void fused_chain_partition(FusedImpl *const *groups, int n, int *seg_len, bool *
                     ok = groups[j]->chain_members[0].first->s.u8 == groups[i]->chain_members[0].first->s.u8 && (len == 1 || groups[j]->chain_members[0].first->s.C >= 16);
                 if (!ok) break;
                 size_t B = CAP / std::max<size_t>(tensor_bytes(i, len), 1);
-                B = std::min<size_t>(B, 65536) & ~(size_t)63;
+                B = std::min<size_t>(B, 262144) & ~(size_t)63;
                 if (B < 256) continue;
                 FusedImpl *f = len == 1 ? groups[i] : fused_chain_create(groups + i, len);
                 if (!f) continue; // (no plan: longer candidates from i may still exist -- a later pair can be smaller)
