@@ -551,7 +551,7 @@ static int pow2_divisor(int v, int cap) { // largest power of two <= cap dividin
     return d;
 }
 
-bool chain_plan(const ChainGeom *g, int n, ChainPair *pairs, ChainArgs &a, int lds_budget) {
+bool chain_plan(const ChainGeom *g, int n, ChainPair *pairs, ChainArgs &a, int lds_budget, int force_G, int force_dbuf) {
     if (n < 1 || n > CHAIN_MAX) return false;
     int maxCG = 1, KSC = 1;
     for (int i = 0; i < n; ++i) {
@@ -711,10 +711,18 @@ bool chain_plan(const ChainGeom *g, int n, ChainPair *pairs, ChainArgs &a, int l
     // double buffering of the input tile: where it does not cost a workgroup per CU
     auto want_dbuf = [&](int G) {
         const int l0 = lds_for(G, false, false), l1 = lds_for(G, false, true);
+        if (force_dbuf >= 0) return force_dbuf != 0 && l1 <= lds_budget;
         auto cls = [](int l) { return l > 80 * 1024 ? 1 : 2; }; // workgroups per CU
         return l1 <= lds_budget && cls(l0) == cls(l1);
     };
-    for (int G = maxCG; G <= 128; G *= 2) {
+    if (force_G > 0) { // the caller's choice (the measured search of fused_chain_partition): any multiple of the column grids' images
+        if (force_G % maxCG != 0 || force_G > 128) return false;
+        const int lds = lds_for(force_G, false, want_dbuf(force_G));
+        if (lds > lds_budget) return false;
+        int nw = 8;
+        best = estimate(force_G, lds, nw), bestG = force_G, best_nwave = nw;
+    }
+    for (int G = maxCG; G <= 128 && force_G <= 0; G *= 2) {
         const bool db = want_dbuf(G);
         const int lds = lds_for(G, false, db);
         if (lds > lds_budget) break;
@@ -723,19 +731,10 @@ bool chain_plan(const ChainGeom *g, int n, ChainPair *pairs, ChainArgs &a, int l
         if (e < best * 0.97) best = e, bestG = G, best_nwave = nw; // (a larger step must pay for its LDS: 3 % at least)
     }
     if (!bestG) return false;
-    {   // experiment: MF_CHAIN_G_SHIFT = +1 / -1 doubles / halves the chosen G where the LDS allows (single pairs only)
-        static const int gshift = [] { const char *e = getenv("MF_CHAIN_G_SHIFT"); return e ? atoi(e) : 0; }();
-        if (gshift != 0 && n == 1) {
-            const int G2 = gshift > 0 ? bestG * 2 : bestG / 2;
-            if (G2 >= maxCG && G2 <= 128 && lds_for(G2, false, want_dbuf(G2)) <= lds_budget) {
-                int nw = 8;
-                best = estimate(G2, lds_for(G2, false, want_dbuf(G2)), nw), bestG = G2, best_nwave = nw;
-            }
-        }
-    }
     const int G = bestG, NW = best_nwave;
     a.G = G, a.nwave = NW, a.est_us_per_image = best;
     a.dbuf = 0, a.dbuf_stride = 0;
+    a.max_cg = maxCG;
     a.lds_bytes = lds_for(G, true, want_dbuf(G));
     a.stage_after = 0;
     for (int i = 0; i < n; ++i)

@@ -265,6 +265,7 @@ struct ChainArgs {
     int *queue;
     int qcfg;
     int KSC;                       // template selector: 1, 2 or 4 k steps (max over the pairs)
+    int max_cg;                    // images per depthwise column grid (G is a multiple of it)
     int resident;                  // single pair whose waves each stay inside one channel group: the reload-free kernel instance
     int nwave;                     // waves per workgroup: 8, or 16 when the LDS plan admits one workgroup per CU only (KSC == 1)
     double est_us_per_image;       // the planner's cost estimate (per CU), for choosing between chainings
@@ -273,7 +274,7 @@ struct ChainArgs {
 };
 // plans `n` pairs as one chain: fills `pairs` (everything but the operand pointers and clamps) and the LDS part of `a`.
 // false: no plan (a channel count, the LDS budget, ...).  `lds_budget`: bytes a workgroup may use.
-bool chain_plan(const ChainGeom *g, int n, ChainPair *pairs, ChainArgs &a, int lds_budget);
+bool chain_plan(const ChainGeom *g, int n, ChainPair *pairs, ChainArgs &a, int lds_budget, int force_G = 0, int force_dbuf = -1); // force_*: the caller's G / double buffering
 // estimated microseconds per image and CU of the same pairs run one operator at a time (the run-time-geometry kernels of k_rt.hip)
 double chain_unfused_us_per_image(const ChainGeom *g, int n);
 void chain_rtab(const ChainPair &c, std::vector<int> &out); // the unit offset table ChainPair::rtab points to

@@ -992,7 +992,7 @@ static k::ChainGeom chain_geom(const OpImpl *dw, const OpImpl *pw) {
     if (P > 1) return k::ChainGeom{d.H, d.W / P, 16, d.sh, d.OH, d.OW / P, P * pw->s.N, f.izp4};
     return k::ChainGeom{d.H, d.W, d.C, d.sh, d.OH, d.OW, pw->s.N, f.izp4};
 }
-static FusedImpl *chain_create(const std::pair<OpImpl *, OpImpl *> *mem, int n) {
+static FusedImpl *chain_create(const std::pair<OpImpl *, OpImpl *> *mem, int n, int force_G = 0, int force_dbuf = -1) {
     if (!chain_enabled() || n < 1 || n > k::CHAIN_MAX) return nullptr;
     std::vector<k::ChainGeom> geo((size_t)n);
     for (int i = 0; i < n; ++i) {
@@ -1008,8 +1008,8 @@ static FusedImpl *chain_create(const std::pair<OpImpl *, OpImpl *> *mem, int n) 
     }
     std::vector<k::ChainPair> tab((size_t)n);
     std::unique_ptr<FusedImpl> c(new FusedImpl{FusedImpl::CHAIN, mem[0].first, mem[n - 1].second, nullptr, {}, {}, ""});
-    if (!k::chain_plan(geo.data(), n, tab.data(), c->chain, 150 * 1024)) {
-        if (n == 1 && getenv("MF_CHAIN_VERBOSE"))
+    if (!k::chain_plan(geo.data(), n, tab.data(), c->chain, 150 * 1024, force_G, force_dbuf)) {
+        if (n == 1 && force_G == 0 && getenv("MF_CHAIN_VERBOSE"))
             fprintf(stderr, "[microflow_amd] no chain plan for %dx%dx%d s%d -> %d\n", geo[0].H, geo[0].W, geo[0].C, geo[0].S, geo[0].N);
         return nullptr;
     }
@@ -1141,6 +1141,7 @@ void fused_chain_partition(FusedImpl *const *groups, int n, int *seg_len, bool *
     std::vector<k::ChainPair> tab((size_t)k::CHAIN_MAX);
     static const bool autotune = [] { const char *e = getenv("MF_CHAIN_AUTOTUNE"); return !(e && e[0] == '0'); }();
     static const bool verbose_t = getenv("MF_CHAIN_VERBOSE") != nullptr;
+    static const bool tune_g = [] { const char *e = getenv("MF_CHAIN_TUNE_G"); return !(e && e[0] == '0'); }();
     // measured[i][len]: microseconds per image of the candidate (< 0: not measured); measured_unf[i]: of the pair's two operators
     std::vector<std::vector<double>> measured((size_t)n, std::vector<double>((size_t)k::CHAIN_MAX + 1, -1.0));
     std::vector<double> measured_unf((size_t)n, -1.0);
@@ -1169,6 +1170,31 @@ void fused_chain_partition(FusedImpl *const *groups, int n, int *seg_len, bool *
                 const double t = tm.us([&] { fused_run(f, (const int8_t *)tm.a.p, B, (int8_t *)tm.b.p, nullptr); });
                 if (len > 1) fused_destroy(f);
                 if (t > 0) measured[(size_t)i][(size_t)len] = t / (double)B;
+                if (len == 1 && tune_g && t > 0) {
+                    // the single pair's images per step and double buffering, measured: every multiple of the column grids' images up to
+                    // 4x / down to 1/4 of the planner's choice, with and without the second input buffer.  The winner's plan replaces
+                    // the group's in place.
+                    const int G0 = groups[i]->chain.G, cg = std::max(1, groups[i]->chain.max_cg), db0 = groups[i]->chain.dbuf;
+                    double best_t = t;
+                    std::unique_ptr<FusedImpl> best_f;
+                    const int cands[8] = {G0 / 4, G0 / 2, 3 * G0 / 4, G0, 3 * G0 / 2, 2 * G0, 3 * G0, 4 * G0};
+                    for (int ci = 0; ci < 8; ++ci) {
+                        const int G = cands[ci];
+                        if (G < cg || G > 128 || G % cg != 0 || (ci > 0 && G == cands[ci - 1])) continue;
+                        for (int db = 0; db < 2; ++db) {
+                            if (G == G0 && db == db0) continue;
+                            std::unique_ptr<FusedImpl> cand(chain_create(&groups[i]->chain_members[0], 1, G, db));
+                            if (!cand || cand->chain.dbuf != db) continue;
+                            const double tc = tm.us([&] { fused_run(cand.get(), (const int8_t *)tm.a.p, B, (int8_t *)tm.b.p, nullptr); });
+                            if (verbose_t) fprintf(stderr, "[microflow_amd] chain autotune: pair %d G %d dbuf %d: %.4f us/image (planner's G %d dbuf %d: %.4f)\n", i, G, db, tc / (double)B, G0, db0, t / (double)B);
+                            if (tc > 0 && tc < (best_f ? best_t : t * 0.96)) best_t = tc, best_f = std::move(cand); // (a clear win over the planner's: 4 %)
+                        }
+                    }
+                    if (best_f) {
+                        std::swap(*groups[i], *best_f);
+                        measured[(size_t)i][1] = best_t / (double)B;
+                    }
+                }
                 if (len == 1) {
                     OpImpl *dw = groups[i]->chain_members[0].first, *pw = groups[i]->chain_members[0].second;
                     const double u = tm.us([&] {
