@@ -34,6 +34,10 @@
 #ifndef MF_STAGE_DIAG
 #define MF_STAGE_DIAG 0 // 2: cycle stamps of block 0 / wave 0 at the phase boundaries of its 2nd step (never shipped)
 #endif
+#ifndef MF_STAGE_KO
+#define MF_STAGE_KO 0 // knock-out timing experiments (WRONG results, never shipped): 1 no requantisation, 2 no copy-out to HBM, 4 no staging after the
+                      // first step, 8 no barriers inside a step, 16 operand loads only in the first step
+#endif
 #ifndef MF_STAGE_LDS_KB
 #define MF_STAGE_LDS_KB 70 // (tuning: 100 forces one workgroup per CU)
 #endif
@@ -176,6 +180,10 @@ __global__ __launch_bounds__(NTHR, 4) void stage_6x6x128(const int8_t *__restric
     const int nsteps = (batch + G - 1) / G;
     if (dq.step < nsteps) stage(dq.step);
     DwW wd = load_dw(0);
+    int ko_steps = 0; // (steps done: the knock-out switches 4 / 16 act from the second step on)
+#if MF_STAGE_KO & 16
+    PwW wpk = load_pw(0);
+#endif
 
 #if MF_STAGE_DIAG == 2
     int trace_step = 0;
@@ -197,7 +205,12 @@ __global__ __launch_bounds__(NTHR, 4) void stage_6x6x128(const int8_t *__restric
 
         for (int rep = 0; rep < NREP; ++rep) {
             const int mid = ((rep + par) & 1) ? OFF_A : OFF_B; // this pair's MID buffer
+#if MF_STAGE_KO & 16
+            if (ko_steps == 0 || rep == 0) wpk = load_pw(ko_steps == 0 ? rep : 0);
+            const PwW wp = wpk;
+#else
             const PwW wp = load_pw(rep);                // lands during the depthwise phase
+#endif
             // ---------------- depthwise: tile -> MID ----------------
             {
                 const float lo = pairs[rep].dw_lo, hi = pairs[rep].dw_hi;
@@ -225,20 +238,28 @@ __global__ __launch_bounds__(NTHR, 4) void stage_6x6x128(const int8_t *__restric
                     const float r3 = epi_value<MG>(acc[3], wd.a.w, wd.s.w, lo, hi);
                     __builtin_amdgcn_sched_barrier(0);
                     if (more) nxt = __builtin_amdgcn_mfma_i32_16x16x64_i8(wd.A[2], t2.b[2], nxt, 0, 0, 0);
+#if MF_STAGE_KO & 1
+                    *(uint32_t *)(lds + mb + moff(u)) = (uint32_t)(acc[0] ^ acc[1] ^ acc[2] ^ acc[3]);
+#else
                     *(uint32_t *)(lds + mb + moff(u)) = epi_pack4<MG, XR4>(r0, r1, r2, r3);
+#endif
                     __builtin_amdgcn_sched_barrier(0);
                     acc = nxt, t2 = t3;
                 }
             }
             MF_TR(1 + 3 * rep);
+#if MF_STAGE_KO & 8
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
             __syncthreads(); // MID complete (every channel group); every wave is done reading the tile
+#endif
             MF_TR(2 + 3 * rep);
             const bool last = rep == NREP - 1;
             if (last) {
                 const int next = dq.nxt;
-                if (next < nsteps) stage(next); // the tile is dead: the next step's images fly under the last pointwise phase
+                if (next < nsteps && !((MF_STAGE_KO & 4) && ko_steps > 0)) stage(next); // the tile is dead: the next step's images fly under the last pointwise phase
             }
-            wd = load_dw(last ? 0 : rep + 1); // the next depthwise's operands land during the pointwise phase
+            if (!((MF_STAGE_KO & 16) && ko_steps > 0)) wd = load_dw(last ? 0 : rep + 1); // the next depthwise's operands land during the pointwise phase
             // ---------------- pointwise: MID -> tile (last pair: -> plain output in region A) ----------------
             {
                 const float lo = pairs[rep].pw_lo, hi = pairs[rep].pw_hi;
@@ -265,7 +286,11 @@ __global__ __launch_bounds__(NTHR, 4) void stage_6x6x128(const int8_t *__restric
                     if (more) nxt = __builtin_amdgcn_mfma_i32_16x16x64_i8(wp.A[1], c1, nxt, 0, 0, 0);
                     const float r2 = epi_value<MG>(acc[2], wp.a.z, wp.s.z, lo, hi);
                     const float r3 = epi_value<MG>(acc[3], wp.a.w, wp.s.w, lo, hi);
+#if MF_STAGE_KO & 1
+                    const uint32_t d = (uint32_t)(acc[0] ^ acc[1] ^ acc[2] ^ acc[3]);
+#else
                     const uint32_t d = epi_pack4<MG, XR4>(r0, r1, r2, r3);
+#endif
                     if (last) *(uint32_t *)(lds + oplain + c * 2048) = d;
                     else *(uint32_t *)(lds + o6[c]) = d;
                     __builtin_amdgcn_sched_barrier(0);
@@ -278,17 +303,23 @@ __global__ __launch_bounds__(NTHR, 4) void stage_6x6x128(const int8_t *__restric
         }
 
         // ---------------- the last pair's output leaves the chip ----------------
+#if MF_STAGE_KO & 8
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
         __syncthreads(); // every channel group of the output is in region A
+#endif
         MF_TR(16);
         {
             const int nbytes = gvalid * PIX6 * 128;
             int8_t *dst = out + (size_t)step * G * PIX6 * 128;
             for (int i = tid * 16; i < nbytes; i += NTHR * 16) {
                 const int pix = i >> 7, slot = (i >> 4) & 7;
-                st_out(dst + i, *(const uint4 *)(lds + OFF_A + pix * 128 + 16 * (slot ^ (pix & 7))));
+                const uint4 vv = *(const uint4 *)(lds + OFF_A + pix * 128 + 16 * (slot ^ (pix & 7)));
+                if (!(MF_STAGE_KO & 2) || vv.x == 0x12345678u) st_out(dst + i, vv);
             }
         }
         MF_TR(17);
+        ++ko_steps;
 #if MF_STAGE_DIAG == 2
         ++trace_step;
 #endif
