@@ -22,6 +22,9 @@
 //              in registers (the element values -- i8 or u8 -- exactly as the reference's pool input).
 //   tail     : pool epilogue, the lane's share of the head dot products (4 channels x N), lane-group and wave
 //              reduction through LDS, 16 threads finish head epilogue + table softmax for their image.
+// Round 4: the tensor is H x W = 3x3, 2x2 or 4x4 (a 96-, 64- or 128-pixel input; compile-time), the epilogue form MG 0 (v_cvt: 256-deep
+// products whose accumulators may leave (-2^22, 2^22)) or 1; 4x4 keeps ONE staged image set (135 KB of LDS) and refills it behind the
+// depthwise phase's barrier.
 // HBM traffic: 2304 B in, N bytes out per inference.  Image pitch 2320 B: the 16 lanes of a b128 service group hit
 // 16 distinct 16-byte bank slots (2320 / 4 = 4 mod 64 words).
 #include "k_common.hpp"
@@ -40,17 +43,18 @@ __device__ long long g_tail3_trace[32];
 #define MF_TR(k) do { } while (0)
 #endif
 
-template <int N, int NTHR, uint32_t XR4>
+template <int H, int W, int N, int NTHR, bool DBUF, int MG, uint32_t XR4>
 __global__ __launch_bounds__(NTHR) void pair3_tail(const int8_t *__restrict__ in, int8_t *__restrict__ out, PairTailArgs p,
                                                    size_t batch) {
-    constexpr int IMGS = 16, PIX = 9, C = 256, IMG = PIX * C;
+    constexpr int IMGS = 16, PIX = H * W, C = 256, IMG = PIX * C;
+    constexpr int NPIECE = (IMG + 1023) / 1024;            // 1 KiB DMA pieces per image (the last one may be short)
     constexpr int XP = IMG + 16;                           // image pitch in LDS (X3 and MID)
     constexpr int NW = NTHR / 64;
     static_assert(NW == 16 && C / 16 == NW, "one channel group and one output tile per wave");
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     constexpr int SET = 16 * XP;                           // one set of 16 staged images
-    uint8_t *x3 = lds;                                     // [2 sets][16][XP] + one all-zero-point image slot
-    uint8_t *zslot = lds + 2 * SET;
+    uint8_t *x3 = lds;                                     // [1 or 2 sets][16][XP] + one all-zero-point image slot
+    uint8_t *zslot = lds + (DBUF ? 2 : 1) * SET;
     uint8_t *mid = zslot + XP;                             // [16][XP]
     int *part = (int *)(mid + 16 * XP);                    // [2][16 images][4]: head sums + value sum, added up by LDS atomics
     float *expt = (float *)(part + 2 * 16 * 4);            // softmax's 256-entry table
@@ -87,11 +91,11 @@ __global__ __launch_bounds__(NTHR) void pair3_tail(const int8_t *__restrict__ in
 #pragma unroll
     for (int n = 0; n < N; ++n) hw[n] = *(const uint32_t *)(p.tail.w + (size_t)n * C + ch);
     // lane part of the depthwise operand address for output column x: input column x + g - 1, or the zero-point slot
-    int laneoff[3];
+    int laneoff[W];
 #pragma unroll
-    for (int x = 0; x < 3; ++x) {
+    for (int x = 0; x < W; ++x) {
         const int cx = x + g - 1;
-        laneoff[x] = (cx >= 0 && cx <= 2) ? col * XP + cx * C : -1; // (-1: the zero-point slot, see below)
+        laneoff[x] = (cx >= 0 && cx <= W - 1) ? col * XP + cx * C : -1; // (-1: the zero-point slot, see below)
     }
 
     const size_t nblk = (batch + IMGS - 1) / IMGS;
@@ -99,11 +103,11 @@ __global__ __launch_bounds__(NTHR) void pair3_tail(const int8_t *__restrict__ in
     // step, 3 per wave.  A ragged last step re-reads the last image.
     auto stage = [&](size_t blk, int set) {
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const int j = wave + NW * k, img = j / 3, piece = j - img * 3;
+        for (int k = 0; k < NPIECE; ++k) {
+            const int j = wave + NW * k, img = j / NPIECE, piece = j - img * NPIECE;
             size_t image = blk * IMGS + img;
             image = image < batch ? image : batch - 1;
-            if (piece < 2 || lane < 16)
+            if (piece * 1024 + lane * 16 < IMG)
                 dma16(in + image * IMG + piece * 1024 + lane * 16, x3 + set * SET + img * XP + piece * 1024);
         }
     };
@@ -114,27 +118,32 @@ __global__ __launch_bounds__(NTHR) void pair3_tail(const int8_t *__restrict__ in
     int cur = 0;
     for (size_t blk = blockIdx.x; blk < nblk; blk += gridDim.x, cur ^= 1) {
         // the other image set was last read before the previous step's barriers: refill it, a whole step ahead
-        if (blk + gridDim.x < nblk) stage(blk + gridDim.x, cur ^ 1);
-        const uint8_t *xs = x3 + cur * SET;
+        if constexpr (DBUF) {
+            if (blk + gridDim.x < nblk) stage(blk + gridDim.x, cur ^ 1);
+        }
+        const uint8_t *xs = x3 + (DBUF ? cur : 0) * SET;
         MF_TR(0);
         // ---- depthwise 3x3: channel group `wave`, all 9 pixels ----
 #pragma unroll
         for (int px = 0; px < PIX; ++px) {
-            const int y = px / 3, x = px % 3;
+            const int y = px / W, x = px % W;
             v4i acc = dK;
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky) {
                 const int iy = y + ky - 1;
                 // a row outside the tensor: the zero-point slot too (compile-time choice)
-                const uint8_t *src = (laneoff[x] >= 0 && iy >= 0 && iy <= 2) ? xs + laneoff[x] + iy * (3 * C) : zslot;
+                const uint8_t *src = (laneoff[x] >= 0 && iy >= 0 && iy <= H - 1) ? xs + laneoff[x] + iy * (W * C) : zslot;
                 const v4i B = *(const v4i *)(src + 16 * wave);
                 acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(Adw[ky], B, acc, 0, 0, 0);
             }
             *(uint32_t *)(mid + col * XP + px * C + ch) =
-                requant_pack4<true, XR4>(acc[0], acc[1], acc[2], acc[3], dA, dS, p.dw_lo, p.dw_hi);
+                requant_pack4<MG, XR4>(acc[0], acc[1], acc[2], acc[3], dA, dS, p.dw_lo, p.dw_hi);
         }
         MF_TR(1);
         __syncthreads(); // MID complete
+        if constexpr (!DBUF) { // one image set: it has been read, refill it under the rest of the step
+            if (blk + gridDim.x < nblk) stage(blk + gridDim.x, 0);
+        }
         MF_TR(2);
         MF_TR(3);
         // ---- pointwise 256 -> 256: output tile `wave`; AveragePool2D = the sum over the 9 pixels ----
@@ -147,10 +156,10 @@ __global__ __launch_bounds__(NTHR) void pair3_tail(const int8_t *__restrict__ in
                 const v4i B = *(const v4i *)(mid + col * XP + px * C + 64 * ks + 16 * g);
                 acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(Apw[ks], B, acc, 0, 0, 0);
             }
-            pool[0] += (int)requant_clamped<true>(acc[0], pA.x, pS.x, p.pw_lo, p.pw_hi);
-            pool[1] += (int)requant_clamped<true>(acc[1], pA.y, pS.y, p.pw_lo, p.pw_hi);
-            pool[2] += (int)requant_clamped<true>(acc[2], pA.z, pS.z, p.pw_lo, p.pw_hi);
-            pool[3] += (int)requant_clamped<true>(acc[3], pA.w, pS.w, p.pw_lo, p.pw_hi);
+            pool[0] += (int)requant_clamped<MG>(acc[0], pA.x, pS.x, p.pw_lo, p.pw_hi);
+            pool[1] += (int)requant_clamped<MG>(acc[1], pA.y, pS.y, p.pw_lo, p.pw_hi);
+            pool[2] += (int)requant_clamped<MG>(acc[2], pA.z, pS.z, p.pw_lo, p.pw_hi);
+            pool[3] += (int)requant_clamped<MG>(acc[3], pA.w, pS.w, p.pw_lo, p.pw_hi);
         }
         MF_TR(4);
         // ---- pool epilogue (average_pool_2d.rs:52-57) and this lane's share of the head dot products ----
@@ -210,25 +219,37 @@ __global__ __launch_bounds__(NTHR) void pair3_tail(const int8_t *__restrict__ in
 }
 
 bool pair_tail_supported(int H, int W, int C, int N_pw, int N_head, int ntaps) {
-    return H == 3 && W == 3 && C == 256 && N_pw == 256 && N_head == 2 && ntaps == 9;
+    return H == W && (H == 2 || H == 3 || H == 4) && C == 256 && N_pw == 256 && N_head == 2 && ntaps == H * W;
 }
-const char *pair_tail_name() { return "pair3_tail<3,3,256,2>"; }
-void launch_pair_tail(const int8_t *in, int8_t *out, const PairTailArgs &a, size_t batch, hipStream_t s) {
-    constexpr int NTHR = 1024, XP = 9 * 256 + 16;
-    constexpr int lds = (2 * 16 + 1 + 16) * XP + 2 * 16 * 4 * 4 + 256 * 4 + 2 * 4 * 4;
+const char *pair_tail_name(int H) { return H == 3 ? "pair3_tail<3,3,256,2>" : (H == 2 ? "pair3_tail<2,2,256,2>" : "pair3_tail<4,4,256,2>"); }
+template <int H, bool DBUF, int MG, uint32_t XR4>
+static int launch_pair_tail_t(const int8_t *in, int8_t *out, const PairTailArgs &a, size_t batch, hipStream_t s) {
+    constexpr int NTHR = 1024, XP = H * H * 256 + 16;
+    constexpr int lds = ((DBUF ? 2 : 1) * 16 + 1 + 16) * XP + 2 * 16 * 4 * 4 + 256 * 4 + 2 * 4 * 4;
     const size_t nblk = (batch + 15) / 16;
+    static LaunchState st;
+    const int per_cu = prepared(st, pair3_tail<H, H, 2, NTHR, DBUF, MG, XR4>, NTHR, lds);
+    const size_t cap = (size_t)256 * per_cu;
+    hipLaunchKernelGGL((pair3_tail<H, H, 2, NTHR, DBUF, MG, XR4>), dim3((unsigned)(nblk < cap ? nblk : cap)), dim3(NTHR), lds, s, in, out, a, batch);
+    return per_cu;
+}
+void launch_pair_tail(const int8_t *in, int8_t *out, const PairTailArgs &a, size_t batch, hipStream_t s) {
     int per_cu = 1;
-    if (a.tail.xr) {
-        static LaunchState st;
-        per_cu = prepared(st, pair3_tail<2, NTHR, 0x80808080u>, NTHR, lds);
-        const size_t cap = (size_t)256 * per_cu;
-        hipLaunchKernelGGL((pair3_tail<2, NTHR, 0x80808080u>), dim3((unsigned)(nblk < cap ? nblk : cap)), dim3(NTHR), lds, s, in, out, a, batch);
-    } else {
-        static LaunchState st;
-        per_cu = prepared(st, pair3_tail<2, NTHR, 0u>, NTHR, lds);
-        const size_t cap = (size_t)256 * per_cu;
-        hipLaunchKernelGGL((pair3_tail<2, NTHR, 0u>), dim3((unsigned)(nblk < cap ? nblk : cap)), dim3(NTHR), lds, s, in, out, a, batch);
-    }
+#define MF_PT_GO(HH, DB)                                                                          \
+    do {                                                                                          \
+        if (a.tail.xr) {                                                                          \
+            if (a.magic) per_cu = launch_pair_tail_t<HH, DB, 1, 0x80808080u>(in, out, a, batch, s); \
+            else per_cu = launch_pair_tail_t<HH, DB, 0, 0x80808080u>(in, out, a, batch, s);       \
+        } else {                                                                                  \
+            if (a.magic) per_cu = launch_pair_tail_t<HH, DB, 1, 0u>(in, out, a, batch, s);        \
+            else per_cu = launch_pair_tail_t<HH, DB, 0, 0u>(in, out, a, batch, s);                \
+        }                                                                                         \
+    } while (0)
+    if (a.H == 3) MF_PT_GO(3, true);
+    else if (a.H == 2) MF_PT_GO(2, true);
+    else MF_PT_GO(4, false);
+#undef MF_PT_GO
+    (void)per_cu;
 #if MF_TAIL3_DIAG
     {
         static int calls = 0;

@@ -302,6 +302,14 @@ void model_prepare(ModelImpl *m, int device, size_t max_batch) {
                 i += 3;
             }
         }
+        // (4b') the last pair group directly followed by the tail group -> one kernel (ops.hip: fused_pair_tail_create).  Before the
+        // chain partition below, so that a run-time-geometry pair taken here is not also a candidate there
+        for (size_t i = 0; i + 2 < n; ++i) {
+            if (!fused[i] || fused_last[i] != (int)i + 1 || covered(i)) continue;
+            const size_t j = i + 2;
+            if (fused[j] && !covered(j))
+                if (FusedImpl *f = fused_pair_tail_create(fused[i], fused[j])) sg.v.push_back({f, (int)i, fused_last[j]});
+        }
         // (4c) runs of consecutive run-time-geometry pairs (single-pair chain groups, k_chain.hip): the planner's cost model
         // decides how the run is cut into chain launches (ops.hip: fused_chain_partition); a pair that is cheapest as two
         // separate launches loses its group
@@ -335,13 +343,6 @@ void model_prepare(ModelImpl *m, int device, size_t max_batch) {
             while (j < n && m->pm.ops[j].kind == MF_OP_RESHAPE) ++j;
             if (j < n && fused[j] && !covered(j))
                 if (FusedImpl *f = fused_dwfc_create(ops[i], fused[j])) sg.v.push_back({f, (int)i, fused_last[j]});
-        }
-        // (6) the last pair group directly followed by the tail group -> one kernel (ops.hip: fused_pair_tail_create)
-        for (size_t i = 0; i + 2 < n; ++i) {
-            if (!fused[i] || fused_last[i] != (int)i + 1 || covered(i)) continue;
-            const size_t j = i + 2;
-            if (fused[j] && !covered(j))
-                if (FusedImpl *f = fused_pair_tail_create(fused[i], fused[j])) sg.v.push_back({f, (int)i, fused_last[j]});
         }
         // commit (nothing below throws)
         m->stages.swap(sg.v);

@@ -1452,15 +1452,25 @@ FusedImpl *fused_dwfc_create(OpImpl *dw, FusedImpl *fcsm) {
 // stage; nullptr when the shapes are not the compiled instance.
 FusedImpl *fused_pair_tail_create(FusedImpl *pair, FusedImpl *tail) {
     static const bool off = getenv("MF_NO_PAIRTAIL") != nullptr;
-    if (off || !pair || !tail || pair->kind != FusedImpl::DWPW || tail->kind != FusedImpl::TAIL) return nullptr;
-    const OpSpec &d = pair->a->s, &q = pair->b->s;
+    if (off || !pair || !tail || tail->kind != FusedImpl::TAIL) return nullptr;
+    // the pair: a table group (dwpw_mm) or a single-pair run-time-geometry chain group
+    OpImpl *dw = nullptr, *pw = nullptr;
+    if (pair->kind == FusedImpl::DWPW) dw = pair->a, pw = pair->b;
+    else if (pair->kind == FusedImpl::CHAIN && pair->chain_members.size() == 1) dw = pair->chain_members[0].first, pw = pair->chain_members[0].second;
+    if (!dw || !pw || (dw->fast != OpImpl::DW_NHWC && dw->fast != OpImpl::DW_RT) || (dw->fast == OpImpl::DW_RT && dw->rt_wz)) return nullptr;
+    if ((pw->fast != OpImpl::PW_MFMA && pw->fast != OpImpl::PW_RT) || (pw->fast == OpImpl::PW_RT && pw->rt_wz)) return nullptr;
+    const OpSpec &d = dw->s, &q = pw->s;
     const k::TailArgs &t = tail->tail;
-    if (!k::pair_tail_supported(d.H, d.W, d.C, q.N, t.N, t.ntaps) || d.sh != 1 || d.sw != 1 || d.u8 != pair->b->s.u8) return nullptr;
+    if (!k::pair_tail_supported(d.H, d.W, d.C, q.N, t.N, t.ntaps) || d.sh != 1 || d.sw != 1 || d.u8 != q.u8) return nullptr;
+    if (d.KH != 3 || d.KW != 3 || d.pad != MF_PAD_SAME || d.C != d.N || q.KH != 1 || q.KW != 1 || q.C != d.N) return nullptr;
     if ((d.u8 ? 0x80 : 0) != t.xr) return nullptr;
-    if (t.H != d.OH || t.W != d.OW || t.C != q.N || pair->a->device != tail->a->device) return nullptr;
-    if (!pair->dwpw.dw.magic || !pair->dwpw.pw.magic || !pair->dwpw.dw.wmm) return nullptr; // bit-pattern epilogues
-    std::unique_ptr<FusedImpl> f(new FusedImpl{FusedImpl::PAIRTAIL, pair->a, tail->b, tail->c, {}, {}, k::pair_tail_name()});
+    if (t.H != d.OH || t.W != d.OW || t.C != q.N || dw->device != tail->a->device) return nullptr;
+    const k::DwFastArgs &df = dw->fast == OpImpl::DW_NHWC ? dw->dwf : dw->dwrt.dw;
+    if (!df.wmm || !dw->finite_consts || !pw->finite_consts) return nullptr;
+    const int magic = (dw->magic_mode >= 1 && pw->magic_mode >= 1) ? 1 : 0; // bit-pattern epilogues, or the v_cvt form for both
+    std::unique_ptr<FusedImpl> f(new FusedImpl{FusedImpl::PAIRTAIL, dw, tail->b, tail->c, {}, {}, k::pair_tail_name(d.H)});
     auto with_magic = [&](const int *d_kc, int n) { // Kc + the bit-pattern offset of requant_t<true> (k_common.hpp)
+        if (!magic) return d_kc;
         std::vector<int32_t> h((size_t)n);
         MF_HIP(hipMemcpy(h.data(), d_kc, h.size() * 4, hipMemcpyDeviceToHost));
         for (int32_t &v : h) v = wrap_add(v, 0x4B400000);
@@ -1469,16 +1479,17 @@ FusedImpl *fused_pair_tail_create(FusedImpl *pair, FusedImpl *tail) {
         return (const int *)f->stage_w.back()->p;
     };
     k::PairTailArgs &a = f->pairtail;
-    a.dw_wmm = pair->dwpw.dw.wmm, a.dwA = pair->dwpw.dw.A, a.dwS = pair->dwpw.dw.S, a.dwK = with_magic(pair->dwpw.dw.Kc, d.N);
-    a.dw_lo = pair->dwpw.dw.lo_f, a.dw_hi = pair->dwpw.dw.hi_f, a.izp4 = pair->dwpw.dw.izp4;
+    a.H = d.H, a.magic = magic;
+    a.dw_wmm = df.wmm, a.dwA = df.A, a.dwS = df.S, a.dwK = with_magic(df.Kc, d.N);
+    a.dw_lo = df.lo_f, a.dw_hi = df.hi_f, a.izp4 = df.izp4;
     std::vector<int8_t> host((size_t)q.N * q.C);
-    MF_HIP(hipMemcpy(host.data(), pair->b->conv.w, host.size(), hipMemcpyDeviceToHost)); // [N][1][1][C] as uploaded
+    MF_HIP(hipMemcpy(host.data(), pw->conv.w, host.size(), hipMemcpyDeviceToHost)); // [N][1][1][C] as uploaded
     const std::vector<int8_t> prep = build_pw_plain_weights(host.data(), q.C, q.N);
     f->stage_w.emplace_back(new DevBuf);
     f->stage_w.back()->upload(prep.data(), prep.size());
     a.pw_w = f->stage_w.back()->p;
-    a.pwA = pair->dwpw.pw.A, a.pwS = pair->dwpw.pw.S, a.pwK = with_magic(pair->dwpw.pw.Kc, q.N);
-    a.pw_lo = pair->dwpw.pw.lo_f, a.pw_hi = pair->dwpw.pw.hi_f;
+    a.pwA = pw->conv.A, a.pwS = pw->conv.S, a.pwK = with_magic(pw->conv.Kc, q.N);
+    a.pw_lo = pw->conv.lo_f, a.pw_hi = pw->conv.hi_f;
     a.tail = t;
     return f.release();
 }

@@ -28,15 +28,17 @@ CASES = [
     (128, 0.5, tw.INT8, 41),    # C = 4 and C = 8 stride 2 as superpixel pairs at 64x64
     (64, 0.5, tw.UINT8, 90),
     (96, 0.25, tw.INT8, 100),   # C = 2 (eight pixels per superpixel), C = 4 stride 2
+    (64, 1.0, tw.INT8, 90, 40),     # small weights: the bit-pattern epilogues in the 256-deep layers (pair3_tail<2,2>, mode 1)
+    (128, 1.0, tw.UINT8, 35, 40),   # ... pair3_tail<4,4>, u8
 ]
 
 
-@pytest.mark.parametrize("case", CASES, ids=lambda c: "%dx%d-w%s-%s-b%d" % (c[0], c[0], c[1], "u8" if c[2] == tw.UINT8 else "i8", c[3]))
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "%dx%d-w%s-%s-b%d%s" % (c[0], c[0], c[1], "u8" if c[2] == tw.UINT8 else "i8", c[3], "-wmax%d" % c[4] if len(c) > 4 else ""))
 def test_generated_models_through_chains(O, case):
     import torch
     import microflow_rs_amd as mf
-    side, width, elem, batch = case
-    blob = tw.person_detect_like(np.random.default_rng(side + int(width * 100)), side, width, elem)
+    side, width, elem, batch = case[:4]
+    blob = tw.person_detect_like(np.random.default_rng(side + int(width * 100)), side, width, elem, wmax=case[4] if len(case) > 4 else None)
     m, om = mf.Model(blob), O.Model(blob)
     m.prepare(batch)
     rng = np.random.default_rng(side)
@@ -62,6 +64,8 @@ def test_generated_models_through_chains(O, case):
         assert torch.equal(a, b), (last, fused_names[last], m.op(last)["name"])
     if not ROUTING_SWITCHED and side != 96:
         assert any(k.startswith("chain_rt<") for k in fused_names), fused_names
+    if not ROUTING_SWITCHED and width == 1.0 and side in (64, 128):  # the last pair + the tail in one launch, 2x2 / 4x4
+        assert "pair3_tail<%d,%d,256,2>" % (side // 32, side // 32) in fused_names, fused_names
         if False:   # (whether pairs are chained is the planner's cost decision)
             assert any(k.startswith("chain_rt<") and "|" in k for k in fused_names), fused_names
 

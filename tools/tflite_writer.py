@@ -210,11 +210,13 @@ def speech_like(rng, elem=INT8, fc_wzp=0, per_channel=True, act="relu"):
     return build_model((1, 1960), in_q, layers, elem)
 
 
-def person_detect_like(rng, side=96, width=1.0, elem=INT8, wzp_nonzero=False, n_stage=5, classes=2):
+def person_detect_like(rng, side=96, width=1.0, elem=INT8, wzp_nonzero=False, n_stage=5, classes=2, wmax=None):
     """The layer structure of person_detect.tflite (MobileNet-v1 0.25, grey input: a one-channel 3x3 stride-2 stem, then
     depthwise 3x3 + 1x1 pairs with strides 1 2 1 2 1 2 [1 x n_stage] 2 1, AveragePool2D over what is left, a 1x1 head,
     Reshape, Softmax) at another input size / channel width / run length, with random weights.  Activations keep the
-    shipped model's quantization (scale 6/255, zero point = the type's minimum, relu6), weights are per-channel."""
+    shipped model's quantization (scale 6/255, zero point = the type's minimum, relu6), weights are per-channel.
+    `wmax`: weights within +-wmax of the type's middle (trained networks have small weights; None = the full range, the worst
+    case for the accumulator bounds that decide the epilogue form)."""
     lo, hi = (0, 256) if elem == UINT8 else (-128, 128)
     mid = (lo + hi) // 2
     act_q = (0.0235294122, lo)
@@ -231,7 +233,7 @@ def person_detect_like(rng, side=96, width=1.0, elem=INT8, wzp_nonzero=False, n_
         shape = (n, k, k, c) if op == "conv_2d" else (1, k, k, n)
         d = dict(op=op, fscale=sc, fzp=zp, bias=rng.integers(-300, 300, n), bscale=(sc * np.float32(in_scale)).astype(np.float32),
                  bzp=np.zeros(n, np.int64), padding="same", strides=(stride, stride), act=act, out_shape=(1, oh, ow, n), out_q=out_q)
-        d["filters" if op == "conv_2d" else "weights"] = rng.integers(lo, hi, shape)
+        d["filters" if op == "conv_2d" else "weights"] = rng.integers(lo, hi, shape) if wmax is None else rng.integers(mid - wmax, mid + wmax + 1, shape)
         layers.append(d)
         return d["out_shape"]
 
