@@ -22,7 +22,7 @@
 //              in registers (the element values -- i8 or u8 -- exactly as the reference's pool input).
 //   tail     : pool epilogue, the lane's share of the head dot products (4 channels x N), lane-group and wave
 //              reduction through LDS, 16 threads finish head epilogue + table softmax for their image.
-// Round 4: the tensor is H x W = 3x3, 2x2 or 4x4 (a 96-, 64- or 128-pixel input; compile-time), the epilogue form MG 0 (v_cvt: 256-deep
+// Round 4: C = 256 or 128 channels (16 or 8 waves); the tensor is H x W = 3x3, 2x2 or 4x4 (a 96-, 64- or 128-pixel input; compile-time), the epilogue form MG 0 (v_cvt: 256-deep
 // products whose accumulators may leave (-2^22, 2^22)) or 1; 4x4 keeps ONE staged image set (135 KB of LDS) and refills it behind the
 // depthwise phase's barrier.
 // HBM traffic: 2304 B in, N bytes out per inference.  Image pitch 2320 B: the 16 lanes of a b128 service group hit
@@ -43,14 +43,14 @@ __device__ long long g_tail3_trace[32];
 #define MF_TR(k) do { } while (0)
 #endif
 
-template <int H, int W, int N, int NTHR, bool DBUF, int MG, uint32_t XR4>
+template <int H, int W, int C, int N, int NTHR, bool DBUF, int MG, uint32_t XR4>
 __global__ __launch_bounds__(NTHR) void pair3_tail(const int8_t *__restrict__ in, int8_t *__restrict__ out, PairTailArgs p,
                                                    size_t batch) {
-    constexpr int IMGS = 16, PIX = H * W, C = 256, IMG = PIX * C;
+    constexpr int IMGS = 16, PIX = H * W, IMG = PIX * C, KS = C / 64;
     constexpr int NPIECE = (IMG + 1023) / 1024;            // 1 KiB DMA pieces per image (the last one may be short)
     constexpr int XP = IMG + 16;                           // image pitch in LDS (X3 and MID)
     constexpr int NW = NTHR / 64;
-    static_assert(NW == 16 && C / 16 == NW, "one channel group and one output tile per wave");
+    static_assert((C == 128 || C == 256) && C / 16 == NW, "one channel group and one output tile per wave");
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     constexpr int SET = 16 * XP;                           // one set of 16 staged images
     uint8_t *x3 = lds;                                     // [1 or 2 sets][16][XP] + one all-zero-point image slot
@@ -75,11 +75,11 @@ __global__ __launch_bounds__(NTHR) void pair3_tail(const int8_t *__restrict__ in
         hci[4 * tid + 2] = __float_as_int(p.tail.A[tid]), hci[4 * tid + 3] = __float_as_int(p.tail.S[tid]);
     }
     // operands and constants of this wave's channel group / output tile (channels 16 wave + 4 g .. + 3 for this lane)
-    v4i Adw[3], Apw[4];
+    v4i Adw[3], Apw[KS];
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky) Adw[ky] = ((const v4i *)p.dw_wmm)[(wave * 3 + ky) * 64 + lane];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) Apw[ks] = ((const v4i *)p.pw_w)[(wave * 4 + ks) * 64 + lane];
+    for (int ks = 0; ks < KS; ++ks) Apw[ks] = ((const v4i *)p.pw_w)[(wave * KS + ks) * 64 + lane];
     const int ch = 16 * wave + 4 * g;
     const float4 dA = *(const float4 *)(p.dwA + ch), dS = *(const float4 *)(p.dwS + ch);
     const int4 dK4 = *(const int4 *)(p.dwK + ch);
@@ -103,11 +103,11 @@ __global__ __launch_bounds__(NTHR) void pair3_tail(const int8_t *__restrict__ in
     // step, 3 per wave.  A ragged last step re-reads the last image.
     auto stage = [&](size_t blk, int set) {
 #pragma unroll
-        for (int k = 0; k < NPIECE; ++k) {
+        for (int k = 0; k < (IMGS * NPIECE + NW - 1) / NW; ++k) { // 16 x NPIECE pieces per step, dealt over the NW waves
             const int j = wave + NW * k, img = j / NPIECE, piece = j - img * NPIECE;
             size_t image = blk * IMGS + img;
             image = image < batch ? image : batch - 1;
-            if (piece * 1024 + lane * 16 < IMG)
+            if (j < IMGS * NPIECE && piece * 1024 + lane * 16 < IMG)
                 dma16(in + image * IMG + piece * 1024 + lane * 16, x3 + set * SET + img * XP + piece * 1024);
         }
     };
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(NTHR) void pair3_tail(const int8_t *__restrict__ in
         for (int px = 0; px < PIX; ++px) {
             v4i acc = pK;
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
+            for (int ks = 0; ks < KS; ++ks) {
                 const v4i B = *(const v4i *)(mid + col * XP + px * C + 64 * ks + 16 * g);
                 acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(Apw[ks], B, acc, 0, 0, 0);
             }
@@ -219,35 +219,45 @@ __global__ __launch_bounds__(NTHR) void pair3_tail(const int8_t *__restrict__ in
 }
 
 bool pair_tail_supported(int H, int W, int C, int N_pw, int N_head, int ntaps) {
-    return H == W && (H == 2 || H == 3 || H == 4) && C == 256 && N_pw == 256 && N_head == 2 && ntaps == H * W;
+    return H == W && (H == 2 || H == 3 || H == 4) && (C == 256 || C == 128) && N_pw == C && N_head == 2 && ntaps == H * W;
 }
-const char *pair_tail_name(int H) { return H == 3 ? "pair3_tail<3,3,256,2>" : (H == 2 ? "pair3_tail<2,2,256,2>" : "pair3_tail<4,4,256,2>"); }
-template <int H, bool DBUF, int MG, uint32_t XR4>
+const char *pair_tail_name(int H, int C) {
+    static const char *names[2][3] = {{"pair3_tail<2,2,128,2>", "pair3_tail<3,3,128,2>", "pair3_tail<4,4,128,2>"},
+                                      {"pair3_tail<2,2,256,2>", "pair3_tail<3,3,256,2>", "pair3_tail<4,4,256,2>"}};
+    return names[C == 256][H - 2];
+}
+template <int H, int C, bool DBUF, int MG, uint32_t XR4>
 static int launch_pair_tail_t(const int8_t *in, int8_t *out, const PairTailArgs &a, size_t batch, hipStream_t s) {
-    constexpr int NTHR = 1024, XP = H * H * 256 + 16;
+    constexpr int NTHR = C * 4, XP = H * H * C + 16; // one wave per 16 channels
     constexpr int lds = ((DBUF ? 2 : 1) * 16 + 1 + 16) * XP + 2 * 16 * 4 * 4 + 256 * 4 + 2 * 4 * 4;
     const size_t nblk = (batch + 15) / 16;
     static LaunchState st;
-    const int per_cu = prepared(st, pair3_tail<H, H, 2, NTHR, DBUF, MG, XR4>, NTHR, lds);
+    const int per_cu = prepared(st, pair3_tail<H, H, C, 2, NTHR, DBUF, MG, XR4>, NTHR, lds);
     const size_t cap = (size_t)256 * per_cu;
-    hipLaunchKernelGGL((pair3_tail<H, H, 2, NTHR, DBUF, MG, XR4>), dim3((unsigned)(nblk < cap ? nblk : cap)), dim3(NTHR), lds, s, in, out, a, batch);
+    hipLaunchKernelGGL((pair3_tail<H, H, C, 2, NTHR, DBUF, MG, XR4>), dim3((unsigned)(nblk < cap ? nblk : cap)), dim3(NTHR), lds, s, in, out, a, batch);
     return per_cu;
 }
 void launch_pair_tail(const int8_t *in, int8_t *out, const PairTailArgs &a, size_t batch, hipStream_t s) {
     int per_cu = 1;
-#define MF_PT_GO(HH, DB)                                                                          \
-    do {                                                                                          \
-        if (a.tail.xr) {                                                                          \
-            if (a.magic) per_cu = launch_pair_tail_t<HH, DB, 1, 0x80808080u>(in, out, a, batch, s); \
-            else per_cu = launch_pair_tail_t<HH, DB, 0, 0x80808080u>(in, out, a, batch, s);       \
-        } else {                                                                                  \
-            if (a.magic) per_cu = launch_pair_tail_t<HH, DB, 1, 0u>(in, out, a, batch, s);        \
-            else per_cu = launch_pair_tail_t<HH, DB, 0, 0u>(in, out, a, batch, s);                \
-        }                                                                                         \
+#define MF_PT_GO(HH, CC, DB)                                                                          \
+    do {                                                                                              \
+        if (a.tail.xr) {                                                                              \
+            if (a.magic) per_cu = launch_pair_tail_t<HH, CC, DB, 1, 0x80808080u>(in, out, a, batch, s); \
+            else per_cu = launch_pair_tail_t<HH, CC, DB, 0, 0x80808080u>(in, out, a, batch, s);       \
+        } else {                                                                                      \
+            if (a.magic) per_cu = launch_pair_tail_t<HH, CC, DB, 1, 0u>(in, out, a, batch, s);        \
+            else per_cu = launch_pair_tail_t<HH, CC, DB, 0, 0u>(in, out, a, batch, s);                \
+        }                                                                                             \
     } while (0)
-    if (a.H == 3) MF_PT_GO(3, true);
-    else if (a.H == 2) MF_PT_GO(2, true);
-    else MF_PT_GO(4, false);
+    if (a.C == 256) {
+        if (a.H == 3) MF_PT_GO(3, 256, true);
+        else if (a.H == 2) MF_PT_GO(2, 256, true);
+        else MF_PT_GO(4, 256, false);
+    } else {
+        if (a.H == 3) MF_PT_GO(3, 128, true);
+        else if (a.H == 2) MF_PT_GO(2, 128, true);
+        else MF_PT_GO(4, 128, true);
+    }
 #undef MF_PT_GO
     (void)per_cu;
 #if MF_TAIL3_DIAG

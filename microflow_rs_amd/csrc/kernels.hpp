@@ -361,7 +361,7 @@ struct PairTailArgs {
     const int *dwK;          // folded constants (+ 0x4B400000, the bit-pattern int->float offset, added on the host when magic != 0)
     float dw_lo, dw_hi;
     uint32_t izp4;
-    int H;                   // the tensor is H x H x 256 (2, 3 or 4)
+    int H, C;                // the tensor is H x H x C (H = 2, 3 or 4; C = 256 or 128)
     int magic;               // 1: bit-pattern epilogue (|acc| < 2^22 for both convolutions), 0: v_cvt
     const void *pw_w;        // pointwise weights [N/16][K/64][64 lanes] x 16 bytes (row r of tile tt = channel 16 tt + r)
     const float *pwA, *pwS;
@@ -370,7 +370,7 @@ struct PairTailArgs {
     TailArgs tail;
 };
 bool pair_tail_supported(int H, int W, int C, int N_pw, int N_head, int ntaps);
-const char *pair_tail_name(int H);
+const char *pair_tail_name(int H, int C);
 void launch_pair_tail(const int8_t *in, int8_t *out, const PairTailArgs &a, size_t batch, hipStream_t s);
 
 // a run of identical depthwise + pointwise pairs on a small tensor as one persistent kernel (k_stage.hip)

@@ -1468,7 +1468,7 @@ FusedImpl *fused_pair_tail_create(FusedImpl *pair, FusedImpl *tail) {
     const k::DwFastArgs &df = dw->fast == OpImpl::DW_NHWC ? dw->dwf : dw->dwrt.dw;
     if (!df.wmm || !dw->finite_consts || !pw->finite_consts) return nullptr;
     const int magic = (dw->magic_mode >= 1 && pw->magic_mode >= 1) ? 1 : 0; // bit-pattern epilogues, or the v_cvt form for both
-    std::unique_ptr<FusedImpl> f(new FusedImpl{FusedImpl::PAIRTAIL, dw, tail->b, tail->c, {}, {}, k::pair_tail_name(d.H)});
+    std::unique_ptr<FusedImpl> f(new FusedImpl{FusedImpl::PAIRTAIL, dw, tail->b, tail->c, {}, {}, k::pair_tail_name(d.H, d.C)});
     auto with_magic = [&](const int *d_kc, int n) { // Kc + the bit-pattern offset of requant_t<true> (k_common.hpp)
         if (!magic) return d_kc;
         std::vector<int32_t> h((size_t)n);
@@ -1479,7 +1479,7 @@ FusedImpl *fused_pair_tail_create(FusedImpl *pair, FusedImpl *tail) {
         return (const int *)f->stage_w.back()->p;
     };
     k::PairTailArgs &a = f->pairtail;
-    a.H = d.H, a.magic = magic;
+    a.H = d.H, a.C = d.C, a.magic = magic;
     a.dw_wmm = df.wmm, a.dwA = df.A, a.dwS = df.S, a.dwK = with_magic(df.Kc, d.N);
     a.dw_lo = df.lo_f, a.dw_hi = df.hi_f, a.izp4 = df.izp4;
     std::vector<int8_t> host((size_t)q.N * q.C);

@@ -64,8 +64,8 @@ def test_generated_models_through_chains(O, case):
         assert torch.equal(a, b), (last, fused_names[last], m.op(last)["name"])
     if not ROUTING_SWITCHED and side != 96:
         assert any(k.startswith("chain_rt<") for k in fused_names), fused_names
-    if not ROUTING_SWITCHED and width == 1.0 and side in (64, 128):  # the last pair + the tail in one launch, 2x2 / 4x4
-        assert "pair3_tail<%d,%d,256,2>" % (side // 32, side // 32) in fused_names, fused_names
+    if not ROUTING_SWITCHED and width in (1.0, 0.5) and side in (64, 96, 128):  # the last pair + the tail in one launch, 2x2 / 3x3 / 4x4
+        assert "pair3_tail<%d,%d,%d,2>" % (side // 32, side // 32, int(256 * width)) in fused_names, fused_names
         if False:   # (whether pairs are chained is the planner's cost decision)
             assert any(k.startswith("chain_rt<") and "|" in k for k in fused_names), fused_names
 
