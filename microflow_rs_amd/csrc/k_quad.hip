@@ -41,6 +41,11 @@
 #define MF_Q57_X2B 3
 #endif
 
+#ifndef MF_QUAD_KO
+#define MF_QUAD_KO 0 // knock-out timing experiments (WRONG results, never shipped): 1 no depthwise requantisation, 2 no pointwise requantisation,
+                     // 4 no HBM stores, 8 no staging after the first step, 16 no barriers inside a step
+#endif
+
 namespace mf {
 namespace k {
 
@@ -212,7 +217,10 @@ struct RrPhase {
 #pragma unroll
             for (int u = 0; u < UB; ++u) {
                 uint32_t d[2] = {0u, 0u};
-                if constexpr (NQ == 2 && (X2 & 1) != 0) {
+                if constexpr ((MF_QUAD_KO & 1) != 0) {
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) d[q] = (uint32_t)(acc[u][q][0] ^ acc[u][q][1] ^ acc[u][q][2] ^ acc[u][q][3]);
+                } else if constexpr (NQ == 2 && (X2 & 1) != 0) {
                     requant_pack4x2<MG, XR4>(acc[u][0], dA[0], dS[0], acc[u][1], dA[1], dS[1], dlo, dhi, d[0], d[1]);
                 } else {
 #pragma unroll
@@ -221,7 +229,14 @@ struct RrPhase {
                 }
                 const long bop = (long)(((unsigned long)d[1] << 32) | (unsigned long)d[0]);
                 uint32_t packed[NT];
-                if constexpr ((X2 & 2) != 0) {
+                if constexpr ((MF_QUAD_KO & 2) != 0) {
+#pragma unroll
+                    for (int m = 0; m < NT; ++m) {
+                        v4i pa = {cK[m].x, cK[m].y, cK[m].z, cK[m].w};
+                        pa = __builtin_amdgcn_mfma_i32_16x16x32_i8(Apw[m], bop, pa, 0, 0, 0);
+                        packed[m] = (uint32_t)(pa[0] ^ pa[1] ^ pa[2] ^ pa[3]);
+                    }
+                } else if constexpr ((X2 & 2) != 0) {
                     static_assert((X2 & 2) == 0 || NT % 2 == 0, "pointwise tiles in pairs");
 #pragma unroll
                     for (int m = 0; m < NT; m += 2) { // two tiles at a time
@@ -245,7 +260,7 @@ struct RrPhase {
                     if constexpr (TO_LDS) {
                         if constexpr (Ge::LB == 8) *(uint2 *)(dst + dst_lane + doff) = make_uint2(packed[0], packed[1]);
                         else *(uint4 *)(dst + dst_lane + doff) = make_uint4(packed[0], packed[1], packed[2], packed[3]);
-                    } else {
+                    } else if (!(MF_QUAD_KO & 4) || packed[0] == 0x12345678u) {
                         if constexpr (Ge::LB == 8) st_out(dst + dst_lane + doff, make_uint2(packed[0], packed[1]));
                         else st_out(dst + dst_lane + doff, make_uint4(packed[0], packed[1], packed[2], packed[3]));
                     }
@@ -390,6 +405,7 @@ __global__ __launch_bounds__(Q::NTHR, Q::WPE) void quad_rr(const int8_t *__restr
     };
     const int nsteps = (batch + G - 1) / G;
     if (dq.step < nsteps) stage(dq.step);
+    int ko_steps = 0; // (steps done: knock-out switch 8 acts from the second step on)
     const uint32_t *sc = p.stem;
     if constexpr (STEM) {
         // Two barriers per image: the stem phase of the NEXT image follows phase B of this one without a barrier between them
@@ -401,16 +417,17 @@ __global__ __launch_bounds__(Q::NTHR, Q::WPE) void quad_rr(const int8_t *__restr
         if (dq.step < nsteps) stem_phase(sc);
         for (; dq.step < nsteps; dq.advance(tid)) {
             const int step = dq.step;
-            __syncthreads(); // X
+            if (!(MF_QUAD_KO & 16)) __syncthreads(); // X
             dq.top(tid);
-            if (dq.nxt < nsteps) stage(dq.nxt);
+            if (dq.nxt < nsteps && !((MF_QUAD_KO & 8) && ko_steps > 0)) stage(dq.nxt);
             if (Q::ACT_A == NWAVE || wave < Q::ACT_A) pa.template run<GB>(lds, lds + OFF_B, 1);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads(); // Y
+            if (!(MF_QUAD_KO & 16)) __syncthreads(); // Y
             if (Q::ACT_B == NWAVE || wave < Q::ACT_B)
                 pb.template run<void>(lds + OFF_B, (uint8_t *)out + (size_t)step * GB::OPIX * GB::N, 1);
             asm volatile("" : "+s"(sc)); // (the stem's operands are fetched here, every step, not hoisted into registers)
             if (dq.nxt < nsteps) stem_phase(sc);
+            ++ko_steps;
         }
     } else {
         for (; dq.step < nsteps; dq.advance(tid)) {
@@ -420,10 +437,11 @@ __global__ __launch_bounds__(Q::NTHR, Q::WPE) void quad_rr(const int8_t *__restr
             dq.top(tid);
             const int gvalid = min(G, batch - step * G);
             if (Q::ACT_A == NWAVE || wave < Q::ACT_A) pa.template run<GB>(lds, lds + OFF_B, gvalid); // pair A: tile A -> tile B
-            __syncthreads(); // tile B is complete; tile A is free
-            if (dq.nxt < nsteps) stage(dq.nxt);                               // lands during phase B
+            if (!(MF_QUAD_KO & 16)) __syncthreads(); // tile B is complete; tile A is free
+            if (dq.nxt < nsteps && !((MF_QUAD_KO & 8) && ko_steps > 0)) stage(dq.nxt); // lands during phase B
             if (Q::ACT_B == NWAVE || wave < Q::ACT_B)
                 pb.template run<void>(lds + OFF_B, (uint8_t *)out + (size_t)step * G * GB::OPIX * GB::N, gvalid); // pair B: tile B -> HBM
+            ++ko_steps;
         }
     }
     dq.finish(tid);
