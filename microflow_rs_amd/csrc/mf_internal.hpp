@@ -127,9 +127,9 @@ FusedImpl *fused_stage_create(FusedImpl *const *pairs, int npairs);
 FusedImpl *fused_dwfc_create(OpImpl *dw, FusedImpl *fc_softmax);
 // the last depthwise + pointwise pair group (3x3x256) + the pool/head/softmax tail group as one kernel (second level)
 FusedImpl *fused_pair_tail_create(FusedImpl *pair, FusedImpl *tail);
-FusedImpl *fused_chain_create(FusedImpl *const *single_pair_chains, int n); // consecutive run-time-geometry pairs as one launch (k_chain.hip)
+FusedImpl *fused_chain_create(FusedImpl *const *single_pair_chains, int n, int force_G = 0); // consecutive run-time-geometry pairs as one launch (k_chain.hip); force_G: images per step (0: the planner's)
 bool fused_is_chain_single(const FusedImpl *f);
-void fused_chain_partition(FusedImpl *const *single_pair_chains, int n, int *seg_len, bool *unfused);
+void fused_chain_partition(FusedImpl *const *single_pair_chains, int n, int *seg_len, bool *unfused, int *seg_G = nullptr); // seg_G[i]: measured images per step of the chain starting at i (0: the planner's)
 FusedImpl *fused_quad_create(FusedImpl *pair1, FusedImpl *pair2); // two consecutive pairs in one launch (k_quad.hip)
 FusedImpl *fused_quad_stem_create(OpImpl *stem, FusedImpl *quad); // the one-input-channel stem + a quad in one launch, or nullptr
 void fused_destroy(FusedImpl *f);

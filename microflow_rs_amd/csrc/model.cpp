@@ -324,11 +324,12 @@ void model_prepare(ModelImpl *m, int device, size_t max_batch) {
             const int rn = (int)run.size();
             std::vector<int> seg((size_t)rn, 0);
             std::unique_ptr<bool[]> unf(new bool[(size_t)rn]);
-            fused_chain_partition(run.data(), rn, seg.data(), unf.get());
+            std::vector<int> segG((size_t)rn, 0);
+            fused_chain_partition(run.data(), rn, seg.data(), unf.get(), segG.data());
             for (int k = 0; k < rn; ++k) {
                 const size_t at = i + 2 * (size_t)k;
                 if (seg[(size_t)k] >= 2) {
-                    if (FusedImpl *f = fused_chain_create(run.data() + k, seg[(size_t)k])) sg.v.push_back({f, (int)at, (int)(at + 2 * (size_t)seg[(size_t)k]) - 1});
+                    if (FusedImpl *f = fused_chain_create(run.data() + k, seg[(size_t)k], segG[(size_t)k])) sg.v.push_back({f, (int)at, (int)(at + 2 * (size_t)seg[(size_t)k]) - 1});
                 } else if (seg[(size_t)k] == 1 && unf[(size_t)k]) {
                     fused_destroy(fused[at]);
                     fused[at] = nullptr, fused_last[at] = -1;

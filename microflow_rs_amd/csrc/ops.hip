@@ -1074,13 +1074,13 @@ static FusedImpl *chain_create(const std::pair<OpImpl *, OpImpl *> *mem, int n, 
     return c.release();
 }
 // second level: `n` consecutive single-pair chain groups as ONE chain (nullptr: no plan fits)
-FusedImpl *fused_chain_create(FusedImpl *const *groups, int n) {
+FusedImpl *fused_chain_create(FusedImpl *const *groups, int n, int force_G) {
     std::vector<std::pair<OpImpl *, OpImpl *>> mem;
     for (int i = 0; i < n; ++i) {
         if (!groups[i] || groups[i]->kind != FusedImpl::CHAIN || groups[i]->chain_members.size() != 1) return nullptr;
         mem.push_back(groups[i]->chain_members[0]);
     }
-    return chain_create(mem.data(), n);
+    return chain_create(mem.data(), n, force_G);
 }
 bool fused_is_chain_single(const FusedImpl *f) { return f && f->kind == FusedImpl::CHAIN && f->chain_members.size() == 1; }
 // How to run `n` consecutive single-pair chain groups: seg_len[i] = number of pairs of the chain that starts at pair i (0: pair i is
@@ -1126,7 +1126,7 @@ struct ChainTimer {
 };
 } // namespace
 
-void fused_chain_partition(FusedImpl *const *groups, int n, int *seg_len, bool *unfused) {
+void fused_chain_partition(FusedImpl *const *groups, int n, int *seg_len, bool *unfused, int *seg_G) {
     std::vector<k::ChainGeom> geo((size_t)n);
     for (int i = 0; i < n; ++i) {
         const std::pair<OpImpl *, OpImpl *> &m = groups[i]->chain_members[0];
@@ -1243,6 +1243,43 @@ void fused_chain_partition(FusedImpl *const *groups, int n, int *seg_len, bool *
     }
     for (int i = 0; i < n; ++i) seg_len[i] = 0, unfused[i] = false;
     for (int i = 0; i < n; i += choice[(size_t)i]) seg_len[i] = choice[(size_t)i], unfused[i] = choice_unf[(size_t)i] != 0;
+    // the images per step of the chosen multi-pair chains, measured like the single pairs' (1/2 ... 2x the planner's)
+    if (seg_G) {
+        for (int i = 0; i < n; ++i) seg_G[i] = 0;
+        if (autotune && tune_g) {
+            const size_t CAP = (size_t)512 << 20;
+            std::unique_ptr<ChainTimer> tm;
+            for (int i = 0; i < n; ++i) {
+                const int len = seg_len[i];
+                if (len < 2) continue;
+                if (!tm) tm.reset(new ChainTimer(CAP));
+                if (!tm->ok) break;
+                size_t mx = 1;
+                for (int j = i; j < i + len; ++j) {
+                    const OpSpec &d = groups[j]->chain_members[0].first->s, &q = groups[j]->chain_members[0].second->s;
+                    mx = std::max(mx, std::max((size_t)d.H * d.W * d.C, std::max((size_t)d.OH * d.OW * d.N, (size_t)q.OH * q.OW * q.N)));
+                }
+                const size_t B = std::min<size_t>(CAP / mx, 262144) & ~(size_t)63;
+                std::unique_ptr<FusedImpl> base(fused_chain_create(groups + i, len, 0));
+                if (!base || B < 256) continue;
+                const double t0 = tm->us([&] { fused_run(base.get(), (const int8_t *)tm->a.p, B, (int8_t *)tm->b.p, nullptr); });
+                const int G0 = base->chain.G, cg = std::max(1, base->chain.max_cg);
+                double best_t = t0;
+                const int cands[4] = {G0 / 2, 3 * G0 / 4, 3 * G0 / 2, 2 * G0};
+                for (int ci = 0; ci < 4 && t0 > 0; ++ci) {
+                    const int G = cands[ci];
+                    if (G < cg || G > 128 || G % cg != 0 || G == G0) continue;
+                    std::unique_ptr<FusedImpl> cand(fused_chain_create(groups + i, len, G));
+                    if (!cand) continue;
+                    const double tc = tm->us([&] { fused_run(cand.get(), (const int8_t *)tm->a.p, B, (int8_t *)tm->b.p, nullptr); });
+                    if (verbose_t) fprintf(stderr, "[microflow_amd] chain autotune: chain %d..%d G %d: %.4f us/image (planner's G %d: %.4f)\n", i, i + len - 1, G, tc / (double)B, G0, t0 / (double)B);
+                    if (tc > 0 && tc < (seg_G[i] ? best_t : t0 * 0.96)) best_t = tc, seg_G[i] = G;
+                }
+            }
+            (void)hipDeviceSynchronize();
+            (void)hipGetLastError();
+        }
+    }
     static const bool verbose = getenv("MF_CHAIN_VERBOSE") != nullptr;
     if (verbose) {
         fprintf(stderr, "[microflow_amd] chain partition of %d pairs:", n);
