@@ -563,6 +563,39 @@ int mf_selftest_requant(int device, int mode, int is_u8, float A, float S, int l
         *mismatches = mf::dev_selftest_epilogue(device, mode, is_u8 != 0, true, A, S, lo, hi);
     })
 }
+int mf_fma_epilogue_search(float A, float S, int is_u8, long long acc_min, long long acc_max, float *S_out, float *C_out,
+                           int *pivot_out, int *found) {
+    MF_TRY({
+        MF_NEED(S_out && C_out && pivot_out && found);
+        mf::FmaForm f;
+        *found = mf::fma_form_search(A, S, is_u8 ? 0 : 128, is_u8 ? 0 : -128, is_u8 ? 255 : 127, acc_min, acc_max, false, false, f) ? 1 : 0;
+        *S_out = f.S, *C_out = f.C, *pivot_out = f.d;
+    })
+}
+int mf_fma_epilogue_check_host(float A, float S, int is_u8, long long acc_min, long long acc_max, float S_fma, float C_fma,
+                               int pivot, uint64_t *mismatches) {
+    MF_TRY({
+        MF_NEED(mismatches && acc_min <= acc_max && acc_min > -(1ll << 22) && acc_max < (1ll << 22));
+        MF_NEED(acc_min + pivot >= -(1ll << 22) && acc_max + pivot < (1ll << 22));
+        mf::FmaForm f;
+        f.S = S_fma, f.C = C_fma, f.d = pivot;
+        *mismatches = mf::fma_form_mismatches(A, S, is_u8 ? 0 : 128, is_u8 ? 0 : -128, is_u8 ? 255 : 127, acc_min, acc_max, f);
+    })
+}
+int mf_selftest_fma_epilogue(int device, float A, float S, int is_u8, long long acc_min, long long acc_max, float S_fma,
+                             float C_fma, int pivot, uint64_t *mismatches) {
+    MF_TRY({
+        MF_NEED(mismatches && acc_min <= acc_max && acc_min > -(1ll << 22) && acc_max < (1ll << 22));
+        MF_NEED(acc_min + pivot >= -(1ll << 22) && acc_max + pivot < (1ll << 22));
+        *mismatches = mf::dev_selftest_fma_epilogue(device, A, S, is_u8 != 0, acc_min, acc_max, S_fma, C_fma, pivot);
+    })
+}
+int mf_selftest_cvt_pk(int device, uint64_t *mismatches) {
+    MF_TRY({
+        MF_NEED(mismatches);
+        *mismatches = mf::dev_selftest_cvt_pk(device);
+    })
+}
 int mf_checksum_i8(int device, const int8_t *d_input, size_t n, uint64_t *checksum, void *stream) {
     MF_TRY({
         MF_NEED(checksum && (n == 0 || d_input));

@@ -1,0 +1,184 @@
+// epi_fma.cpp -- host search for the single-fma requantisation ("epilogue mode 3", k_common.hpp).
+//
+// The reference ends every conv-like operator in   y = sat_T(roundf(fl(A + fl(S * f32(acc)))))   (src/ops/conv_2d.rs:93-98,
+// depthwise_conv_2d.rs:90-95; A = fl(f32(ozp) + c0[c]), S = c1[c]).  As a function of the integer accumulator that is a
+// monotone staircase with at most 255 steps.  ANY other monotone map with the same step positions over the accumulators the
+// operator can produce is bit-identical to it, and the cheapest one the VALU offers is
+//
+//     x = v_fma_f32(S', F, C')                 F = the accumulator's own bit pattern read as f32 = 1.5 * 2^23 + acc + d
+//     y = v_cvt_pk_u8_f32(x)                   truncate toward zero, saturate to [0, 255]  (u8 domain: i8 results are y ^ 0x80)
+//
+// two instructions per byte instead of six.  Per channel the host looks for (S', C', d) -- S' within a few ulps of S, an integer
+// pivot d folded into the accumulator's start value, C' an f32 -- whose staircase has exactly the reference's steps:
+//   1. the reference's steps T_k (first accumulator whose output is >= k) inside the reachable accumulator range [-B, B] are found
+//      by bisection on the exact two-rounding form (monotone: every f32 operation in it is);
+//   2. in real arithmetic x = s * acc + e reproduces them iff  e in [max_k (k - s T_k), min_k (k - s (T_k - 1)))  -- the width w(s)
+//      of that interval is evaluated for the f32 neighbours of S and the widest few are kept;
+//   3. e = C' + s * (1.5 * 2^23 + d) must hit the interval with C' an f32 of magnitude ~ s * 2^23 (ulp 2^-4 .. 2^-11, far coarser
+//      than w): the pivot d supplies the fraction -- s * d mod ulp(C') is equidistributed, so one d in ulp / w works;
+//   4. every candidate is then checked EXACTLY (std::fmaf = the device's v_fma_f32: one rounding) at the 2 x 255 accumulators that
+//      decide the steps: T_k must give >= k, T_k - 1 must give < k.  With monotonicity of both maps that is equality on the
+//      whole range, not a sample.
+// What the host proves here the device re-checks exhaustively, accumulator by accumulator, with the real instructions
+// (k_generic.hip: verify_fma_form) before an operator is allowed to use the form; a channel without a solution keeps its operator
+// (and every fused launch the operator is part of) on the two-rounding forms.
+#include <algorithm>
+#include <cfenv>
+#include <cmath>
+#include <cstring>
+#include <limits>
+
+#include "mf_internal.hpp"
+
+namespace mf {
+
+namespace {
+constexpr int64_t M0 = 12582912; // 1.5 * 2^23: the f32 whose bit pattern is 0x4B400000
+inline float next_up(float x, int n) { // n ulps away (n may be negative); x > 0 finite normal
+    int32_t b;
+    std::memcpy(&b, &x, 4);
+    b += n;
+    float r;
+    std::memcpy(&r, &b, 4);
+    return r;
+}
+} // namespace
+
+// the reference's tail for one accumulator, in the u8 domain (off = 128 for i8, 0 for u8): clamp(roundf(A + S acc), lo, hi) + off
+int ref_form_eval(float A, float S, int off, int lo, int hi, int64_t acc) {
+    volatile float p = S * (float)acc; // |acc| <= 2^24: exact conversion
+    volatile float x = A + p;
+    float r = h_roundf(x);
+    if (std::isnan(r)) r = 0.0f; // Rust: NaN as T == 0
+    int y = r >= (float)hi ? hi : (r <= (float)lo ? lo : (int)r);
+    return y + off;
+}
+
+// the device's form, instruction by instruction
+int fma_form_eval(const FmaForm &f, int64_t acc) {
+    const float F = (float)(M0 + acc + (int64_t)f.d); // an integer in [2^23, 2^24): exact, and what the bit pattern 0x4B400000 + acc + d reads as
+    float x;
+    if (f.rz) { // the kernel runs with FP_ROUND = toward zero (s_setreg MODE)
+        const int old = fegetround();
+        fesetround(FE_TOWARDZERO);
+        volatile float vs = f.S, vF = F, vC = f.C;
+        volatile float r = std::fmaf(vs, vF, vC);
+        fesetround(old);
+        x = r;
+    } else {
+        x = std::fmaf(f.S, F, f.C); // v_fma_f32: one rounding
+    }
+    // v_cvt_pk_u8_f32: truncation toward zero, saturation to [0, 255], NaN -> 0
+    int y = !(x > 0.0f) ? 0 : (x >= 255.0f ? 255 : (int)x);
+    return f.neg ? 255 - y : y; // neg: the form computes 255 - y with a negative slope; the XOR that returns to the stored domain is 0xff ^ ...
+}
+
+namespace {
+// spacing of the f32 values just below the positive integer k (k <= 256): ulp(pred(k))
+inline double grid_below(int k) {
+    int m = 0;
+    while ((1 << (m + 1)) < k) ++m; // 2^m < k <= 2^(m+1)   (k = 1: m = 0 -> handled below)
+    if (k <= 1) return std::ldexp(1.0, -24);
+    return std::ldexp(1.0, m - 23);
+}
+} // namespace
+
+bool fma_form_search(float A, float S, int off, int lo, int hi, int64_t amin, int64_t amax, bool neg, bool rz, FmaForm &out,
+                     FmaSearchStats *st) {
+    if (st) *st = FmaSearchStats{};
+    if (!std::isfinite(A) || !std::isfinite(S) || !(S > 0.0f) || std::fpclassify(S) != FP_NORMAL) return false;
+    if (amin > amax || amin <= -(1 << 22) || amax >= (1 << 22) - 1 || lo > hi) return false;
+    auto Y = [&](int64_t a) { return ref_form_eval(A, S, off, lo, hi, a); };
+    // --- 1. the steps of the reference inside [amin, amax] ---
+    struct Con { int64_t a; int k; };
+    std::vector<Con> lower, upper; // lower: y(a) >= k;  upper: y(a) < k
+    const int y0 = Y(amin), yN = Y(amax);
+    if (y0 < 0 || yN > 255 || y0 > yN) return false;
+    if (y0 >= 1) lower.push_back({amin, y0});
+    if (yN <= 254) upper.push_back({amax, yN + 1});
+    for (int k = y0 + 1; k <= yN; ++k) {
+        int64_t l = amin, h = amax; // Y(l) < k <= Y(h)
+        while (h - l > 1) {
+            const int64_t m = l + (h - l) / 2;
+            if (Y(m) >= k) h = m;
+            else l = m;
+        }
+        lower.push_back({h, k});
+        upper.push_back({h - 1, k});
+    }
+    if (st) st->steps = yN - y0;
+    // --- 2. the EXACT window of e.  With v = s acc + e (real numbers; every product and sum below is exact in double):
+    //   plain form:   x = RN(v),            y = trunc(x):         y >= k  <=>  v >= k - g(k)/2   (RN; the tie goes to the even k)   or  v >= k (RZ)
+    //   negated form: x' = RN(256 - v),     y = 255 - trunc(x'):  y >= k  <=>  x' < 256 - k  <=>  256 - v < (256 - k) - g(256 - k)/2   <=>  v > k + g(256 - k)/2   (RZ: v > k)
+    // g(j) = the spacing of the floats just below j.
+    double th[257];
+    for (int k = 1; k <= 256; ++k) th[k] = rz ? (double)k : (neg ? (double)k + 0.5 * grid_below(256 - k + (k == 256 ? 1 : 0)) : (double)k - 0.5 * grid_below(k));
+    const double INF = std::numeric_limits<double>::infinity();
+    auto window = [&](float s, double &elo, double &ehi) {
+        elo = -INF, ehi = INF;
+        for (const Con &c : lower) elo = std::max(elo, th[c.k] - (double)s * (double)c.a);
+        for (const Con &c : upper) ehi = std::min(ehi, th[c.k] - (double)s * (double)c.a);
+        if (elo == -INF) elo = ehi - 0.5; // a constant output: any e on the right side
+        if (ehi == INF) ehi = elo + 0.5;
+    };
+    struct Cand { float s; double elo, ehi; };
+    std::vector<Cand> cands;
+    constexpr int J = 64;
+    for (int j = -J; j <= J; ++j) {
+        const float s = next_up(S, j);
+        if (!(s > 0.0f) || std::fpclassify(s) != FP_NORMAL) continue;
+        double elo, ehi;
+        window(s, elo, ehi);
+        if (ehi > elo) cands.push_back({s, elo, ehi});
+    }
+    if (st) st->s_candidates = (int)cands.size();
+    if (cands.empty()) return false;
+    std::sort(cands.begin(), cands.end(), [](const Cand &a, const Cand &b) { return (a.ehi - a.elo) > (b.ehi - b.elo); });
+    if (st) st->best_width = cands[0].ehi - cands[0].elo;
+    // --- 3 + 4. pivot and offset, exact check ---
+    const int64_t dlo = -(1 << 22) - amin, dhi = (1 << 22) - 1 - amax; // 2^23 <= M0 + acc + d < 2^24 for every acc in [amin, amax]
+    auto exact_ok = [&](const FmaForm &f) {
+        for (const Con &c : lower)
+            if (fma_form_eval(f, c.a) < c.k) return false;
+        for (const Con &c : upper)
+            if (fma_form_eval(f, c.a) >= c.k) return false;
+        return true;
+    };
+    for (size_t ci = 0; ci < cands.size(); ++ci) {
+        const Cand &c = cands[ci];
+        const double w = c.ehi - c.elo, emid = 0.5 * (c.elo + c.ehi);
+        const double s = (double)c.s;
+        // pivots in the order 0, 1, -1, 2, -2, ...: the first hit has the smallest |d|
+        const int64_t budget = std::min<int64_t>(2 * std::max(dhi, -dlo) + 1, 2000000);
+        int exact_tries = 0;
+        for (int64_t i = 0; i < budget; ++i) {
+            const int64_t d = (i & 1) ? (i + 1) / 2 : -(i / 2);
+            if (d > dhi || d < dlo) continue;
+            // plain:   x = s F + C,            e = C + s (M0 + d)
+            // negated: x' = -s F + C = 256 - v, e = 256 - C + s (M0 + d)
+            const double sN = s * (double)(M0 + d);   // 24 x 25 bits: exact in double
+            const double t = neg ? 256.0 - emid + sN : emid - sN;
+            const float C = (float)t;
+            if (!(std::fabs((double)C - t) < 0.499 * w)) continue;
+            const FmaForm f{neg ? -c.s : c.s, C, (int32_t)d, neg, rz};
+            ++exact_tries;
+            if (exact_ok(f)) {
+                out = f;
+                if (st) st->pivots_tried = i + 1, st->exact_checks += exact_tries, st->s_rank = (int)ci;
+                return true;
+            }
+            if (exact_tries > 64) break; // (the window is exact: a candidate inside it that fails means the model of the rounding is wrong)
+        }
+        if (st) st->exact_checks += exact_tries;
+    }
+    return false;
+}
+
+// every accumulator of [amin, amax]: the host-side twin of the device verifier (tests)
+uint64_t fma_form_mismatches(float A, float S, int off, int lo, int hi, int64_t amin, int64_t amax, const FmaForm &f) {
+    uint64_t bad = 0;
+    for (int64_t a = amin; a <= amax; ++a) bad += ref_form_eval(A, S, off, lo, hi, a) != fma_form_eval(f, a);
+    return bad;
+}
+
+} // namespace mf

@@ -64,8 +64,13 @@ constexpr int MF_MAGIC_I = 0x4B400000;
 //   1  bit-pattern int -> f32 (above)
 //   2  = 1, and the clamp [lo, hi] is exactly the element type's range and |x| < 2^15 for every input, so that the
 //      clamp is done by a saturating pack (v_sat_pk_u8_i16) instead of v_med3_f32 (requant_pack4 below)
+//   3  the single-fma form: the host found, per channel, (S', C', d) whose staircase  acc -> v_cvt_pk_u8_f32(v_fma_f32(S', F, C'))
+//      equals the reference's on every accumulator the operator can produce (epi_fma.cpp: search; k_generic.hip
+//      verify_fma_form: exhaustive check on the device).  The kernels then receive C' in place of A, S' in place of S and
+//      Kc + d in place of Kc; the clamp is the element type's whole range (the conversion saturates).  Two instructions per byte.
 template <int MG>
 __device__ __forceinline__ int requant_t(int acc, float A, float S, float lo_f, float hi_f) {
+    static_assert(MG != 3, "the single-fma form exists for the packed epilogues only (requant_pack4)");
     if constexpr (MG == 0) {
         return requant(acc, A, S, lo_f, hi_f);
     } else {
@@ -128,12 +133,11 @@ __device__ __forceinline__ uint32_t pack4(int a, int b, int c, int d) {
 // The epilogue of the fast kernels: four accumulators -> one packed dword.
 //
 // x = fl(A + fl(S * f32(acc))) is the reference's value (two roundings, conv_2d.rs:93-98); what follows it in the
-// reference is roundf (half away from zero), the activation clamp and `as T`.  Three exact forms of that tail:
+// reference is roundf (half away from zero), the activation clamp and `as T`.  The exact forms of that tail (round 2's
+// x + copysign(pred(0.5), x); v_med3; truncating v_cvt form -- 10 issue units per byte -- lives on in requant() for the
+// shape-generic kernels only):
 //
-// MF_EPI == 0 (round 2): r = x + copysign(pred(0.5), x); v_med3_f32; v_cvt_i32_f32 (truncating) with an SDWA byte
-//   destination.  v_bfi, v_med3 and v_cvt issue at half rate on gfx950: 10 issue units per byte.
-//
-// MF_EPI == 1, "sticky bit": roundf(x) == RNE_int(x | 1) for every finite x with |x| < 2^22, where `x | 1` sets the
+// Modes 0 / 1, "sticky bit": roundf(x) == RNE_int(x | 1) for every finite x with |x| < 2^22, where `x | 1` sets the
 //   lowest mantissa bit.  Proof sketch: a tie k + 1/2 has an even mantissa (its ulp is < 1/2), so the OR moves it one
 //   ulp AWAY from zero and round-to-nearest then goes away from zero, as roundf does; a non-tie x with an even
 //   mantissa moves by one ulp towards the next float of the same sign, and the nearest tie (even mantissa, at least
@@ -148,19 +152,15 @@ __device__ __forceinline__ uint32_t pack4(int a, int b, int c, int d) {
 //   16 bits of two sums are written into the halves of one dword, and v_sat_pk_u8_i16 saturates both to [0, 255] =
 //   the clamp; XOR 0x80 per byte returns to the stored i8 domain.  No v_med3: 6.25 issue units per byte.
 // ------------------------------------------------------------------------
-#ifndef MF_EPI
-#define MF_EPI 1
-#endif
-#ifndef MF_SDWA_PACK
-#define MF_SDWA_PACK 1 // 0: v_cvt + v_perm packing (A/B switch, MF_EPI == 0 only)
-#endif
 template <int MG> __device__ __forceinline__ float requant_x(int acc, float A, float S) {
+    static_assert(MG != 3, "mode 3 has no two-rounding value: epi_value");
     float f;
     if constexpr (MG != 0) f = __fsub_rn(__int_as_float(acc), 12582912.0f);
     else f = (float)acc;
     return __fadd_rn(A, __fmul_rn(S, f));
 }
-// round 2's pre-conversion value: x + copysign(pred(0.5), x), clamped (truncation by the conversion follows)
+// x + copysign(pred(0.5), x), clamped: the value whose truncation is the reference's result (for epilogues that go on with
+// the integer instead of packing it: the pooled sum of k_tail3.hip)
 template <int MG> __device__ __forceinline__ float requant_clamped(int acc, float A, float S, float lo_f, float hi_f) {
     const float x = requant_x<MG>(acc, A, S);
     const float r = __fadd_rn(x, __builtin_copysignf(0x1.fffffep-2f, x));
@@ -168,32 +168,9 @@ template <int MG> __device__ __forceinline__ float requant_clamped(int acc, floa
 }
 // gfx950 has a destination-forwarding hazard on partial (dst_sel) writes: an instruction that reads a VGPR in the
 // issue slot right after an SDWA byte write of it may see the old value (observed: an MFMA fed such a dword).  hipcc
-// pads this for its own instructions but cannot see into inline asm, so the four conversions are ONE asm block with
-// an independent instruction (s_nop) after each: nothing the compiler schedules next to it can break the rule.
-__device__ __forceinline__ uint32_t cvt_pack4(float r0, float r1, float r2, float r3) {
-    uint32_t d;
-    asm("v_cvt_i32_f32_sdwa %0, %1 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:DWORD\n\ts_nop 0\n\t"
-        "v_cvt_i32_f32_sdwa %0, %2 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD\n\ts_nop 0\n\t"
-        "v_cvt_i32_f32_sdwa %0, %3 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD\n\ts_nop 0\n\t"
-        "v_cvt_i32_f32_sdwa %0, %4 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:DWORD\n\ts_nop 0"
-        : "=&v"(d) : "v"(r0), "v"(r1), "v"(r2), "v"(r3));
-    return d;
-}
-// Two dwords at once: the two chains alternate, so each write's successor is the other chain's (independent)
-// conversion and only the very last write needs the s_nop -- 1 idle slot per 8 bytes instead of 4 per 4.
-__device__ __forceinline__ void cvt_pack4x2(float a0, float a1, float a2, float a3, float b0, float b1, float b2, float b3,
-                                            uint32_t &da, uint32_t &db) {
-    asm("v_cvt_i32_f32_sdwa %0, %2 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:DWORD\n\t"
-        "v_cvt_i32_f32_sdwa %1, %6 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:DWORD\n\t"
-        "v_cvt_i32_f32_sdwa %0, %3 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD\n\t"
-        "v_cvt_i32_f32_sdwa %1, %7 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD\n\t"
-        "v_cvt_i32_f32_sdwa %0, %4 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD\n\t"
-        "v_cvt_i32_f32_sdwa %1, %8 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD\n\t"
-        "v_cvt_i32_f32_sdwa %0, %5 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:DWORD\n\t"
-        "v_cvt_i32_f32_sdwa %1, %9 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:DWORD\n\ts_nop 0"
-        : "=&v"(da), "=&v"(db) : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(b0), "v"(b1), "v"(b2), "v"(b3));
-}
-
+// pads this for its own instructions but cannot see into inline asm, so the packs below are ONE asm block each in which
+// every partial write is followed by an independent instruction (the OR of a later value, the other chain of a two-dword
+// pack, or s_nop): nothing the compiler schedules next to them can break the rule.
 // ---- sticky-bit forms ----
 // RNE_int of four values (|v| < 2^22, lowest mantissa bit set) into the four bytes of a dword: the low byte of
 // v + 1.5 * 2^23.  Every SDWA write is followed by an independent instruction (the OR of a later value / s_nop).
@@ -288,62 +265,51 @@ __device__ __forceinline__ void sat_pack4x2(float a0, float a1, float a2, float 
 // The value an epilogue hands to its pack (epi_pack4 / epi_pack4x2): kernels that interleave the epilogue with MFMAs
 // by hand (k_stage.hip, k_tail3.hip) call the two halves themselves.
 template <int MG> __device__ __forceinline__ float epi_value(int acc, float A, float S, float lo_f, float hi_f) {
-#if MF_EPI == 0
-    return requant_clamped<MG>(acc, A, S, lo_f, hi_f);
-#else
-    if constexpr (MG == 2) return requant_x<MG>(acc, A, S); // clamp = the saturating pack
+    if constexpr (MG == 3) return __fmaf_rn(S, __int_as_float(acc), A); // S = S', A = C', acc carries the pivot: ONE rounding
+    else if constexpr (MG == 2) return requant_x<MG>(acc, A, S); // clamp = the saturating pack
     else return __builtin_amdgcn_fmed3f(requant_x<MG>(acc, A, S), lo_f, hi_f);
-#endif
+}
+// MG == 3: truncation toward zero + saturation to [0, 255] + byte insert in one instruction per value (VOP3, whole-dword
+// write: no SDWA hazard, free for the compiler to schedule)
+__device__ __forceinline__ uint32_t cvtpk_pack4(float r0, float r1, float r2, float r3) {
+    uint32_t d = __builtin_amdgcn_cvt_pk_u8_f32(r0, 0u, 0u);
+    d = __builtin_amdgcn_cvt_pk_u8_f32(r1, 1u, d);
+    d = __builtin_amdgcn_cvt_pk_u8_f32(r2, 2u, d);
+    return __builtin_amdgcn_cvt_pk_u8_f32(r3, 3u, d);
 }
 template <int MG, uint32_t XR4> __device__ __forceinline__ uint32_t epi_pack4(float r0, float r1, float r2, float r3) {
-#if MF_EPI == 0
-    return cvt_pack4(r0, r1, r2, r3) ^ XR4;
-#else
-    if constexpr (MG == 2) return sat_pack4(r0, r1, r2, r3, XR4 ? 12582912.0f : 12583040.0f) ^ 0x80808080u;
+    if constexpr (MG == 3) return cvtpk_pack4(r0, r1, r2, r3) ^ 0x80808080u; // u8 domain -> the stored i8 domain, either element type
+    else if constexpr (MG == 2) return sat_pack4(r0, r1, r2, r3, XR4 ? 12582912.0f : 12583040.0f) ^ 0x80808080u;
     else return rne_pack4(r0, r1, r2, r3) ^ XR4;
-#endif
 }
 template <int MG, uint32_t XR4>
 __device__ __forceinline__ void epi_pack4x2(float a0, float a1, float a2, float a3, float b0, float b1, float b2, float b3,
                                             uint32_t &da, uint32_t &db) {
-#if MF_EPI == 0
-    cvt_pack4x2(a0, a1, a2, a3, b0, b1, b2, b3, da, db);
-    da ^= XR4, db ^= XR4;
-#else
-    if constexpr (MG == 2) {
+    if constexpr (MG == 3) {
+        da = cvtpk_pack4(a0, a1, a2, a3) ^ 0x80808080u, db = cvtpk_pack4(b0, b1, b2, b3) ^ 0x80808080u;
+    } else if constexpr (MG == 2) {
         sat_pack4x2(a0, a1, a2, a3, b0, b1, b2, b3, XR4 ? 12582912.0f : 12583040.0f, da, db);
         da ^= 0x80808080u, db ^= 0x80808080u;
     } else {
         rne_pack4x2(a0, a1, a2, a3, b0, b1, b2, b3, da, db);
         da ^= XR4, db ^= XR4;
     }
-#endif
 }
 template <int MG, uint32_t XR4>
 __device__ __forceinline__ uint32_t requant_pack4(int a0, int a1, int a2, int a3, const float4 &A, const float4 &S,
                                                   float lo_f, float hi_f) {
-#if MF_EPI == 0 && !MF_SDWA_PACK
-    return pack4(requant_t<MG>(a0, A.x, S.x, lo_f, hi_f), requant_t<MG>(a1, A.y, S.y, lo_f, hi_f),
-                 requant_t<MG>(a2, A.z, S.z, lo_f, hi_f), requant_t<MG>(a3, A.w, S.w, lo_f, hi_f)) ^ XR4;
-#else
     return epi_pack4<MG, XR4>(epi_value<MG>(a0, A.x, S.x, lo_f, hi_f), epi_value<MG>(a1, A.y, S.y, lo_f, hi_f),
                               epi_value<MG>(a2, A.z, S.z, lo_f, hi_f), epi_value<MG>(a3, A.w, S.w, lo_f, hi_f));
-#endif
 }
 
 // requant_pack4 of two accumulator quads (two dwords) with the alternating chains of the x2 packs
 template <int MG, uint32_t XR4>
 __device__ __forceinline__ void requant_pack4x2(const v4i &a, const float4 &aA, const float4 &aS, const v4i &b, const float4 &bA,
                                                 const float4 &bS, float lo_f, float hi_f, uint32_t &da, uint32_t &db) {
-#if MF_EPI == 0 && !MF_SDWA_PACK
-    da = requant_pack4<MG, XR4>(a[0], a[1], a[2], a[3], aA, aS, lo_f, hi_f);
-    db = requant_pack4<MG, XR4>(b[0], b[1], b[2], b[3], bA, bS, lo_f, hi_f);
-#else
     epi_pack4x2<MG, XR4>(epi_value<MG>(a[0], aA.x, aS.x, lo_f, hi_f), epi_value<MG>(a[1], aA.y, aS.y, lo_f, hi_f),
                          epi_value<MG>(a[2], aA.z, aS.z, lo_f, hi_f), epi_value<MG>(a[3], aA.w, aS.w, lo_f, hi_f),
                          epi_value<MG>(b[0], bA.x, bS.x, lo_f, hi_f), epi_value<MG>(b[1], bA.y, bS.y, lo_f, hi_f),
                          epi_value<MG>(b[2], bA.z, bS.z, lo_f, hi_f), epi_value<MG>(b[3], bA.w, bS.w, lo_f, hi_f), da, db);
-#endif
 }
 
 // pack4 for either element type: XR4 = 0x80808080 moves u8-domain epilogue results (0..255) back
@@ -602,7 +568,7 @@ static inline int grid_for(size_t total, int per_block = 256, int cap = 256 * 8)
 }
 
 // ---- fast-path dispatch tables ------------------------------------------------
-// the six instances of a fast kernel: epilogue mode MG in {0, 1, 2} (requant_t above)  x  {i8, u8} element type
+// the instances of a fast kernel: epilogue mode MG in {0, 1, 2} (requant_t above)  x  {i8, u8} element type ...
 #define MF_DISPATCH4(magic, xr, FN, ARGS, ...)                         \
     do {                                                               \
         const int mg_ = (magic);                                       \
@@ -615,6 +581,13 @@ static inline int grid_for(size_t total, int per_block = 256, int cap = 256 * 8)
             else if (mg_) FN<__VA_ARGS__, 1, 0u> ARGS;                 \
             else FN<__VA_ARGS__, 0, 0u> ARGS;                          \
         }                                                              \
+    } while (0);
+// ... plus mode 3 (the single-fma form; its code does not depend on the element type: one instance, XR4 = 0) for the kernels
+// of the fused step and their layer-wise counterparts
+#define MF_DISPATCH5(magic, xr, FN, ARGS, ...)                         \
+    do {                                                               \
+        if ((magic) == 3) FN<__VA_ARGS__, 3, 0u> ARGS;                 \
+        else MF_DISPATCH4(magic, xr, FN, ARGS, __VA_ARGS__)            \
     } while (0);
 
 } // namespace k

@@ -649,6 +649,7 @@ bool launch_dw_stem(int H, int W, int DM, int S, const int8_t *in, int8_t *out, 
     if (a.xr) { if (a.magic) MF_STEM(true, 0x80808080u, F); else MF_STEM(false, 0x80808080u, F); } \
     else { if (a.magic) MF_STEM(true, 0u, F); else MF_STEM(false, 0u, F); }
         static const bool valu = [] { const char *e = getenv("MF_STEM_IMPL"); return e && e[0] == 'v'; }();
+        if (a.magic == 3 && valu) return false; // (the single-fma epilogue exists in the matrix-pipe form only; the caller does not ask for it then)
         if (!valu) { // taps on the matrix pipe
             static LaunchState stm, stmf;
             const int pcu = f32_input ? prepared(stmf, dw3x3_stem8_mm<96, 96, G, false, 0u, true>, 256, lds)
@@ -656,6 +657,7 @@ bool launch_dw_stem(int H, int W, int DM, int S, const int8_t *in, int8_t *out, 
             const int gridm = nsteps < 256 * pcu ? nsteps : 256 * pcu;
 #define MF_STEMM(MG, XR, F) hipLaunchKernelGGL((dw3x3_stem8_mm<96, 96, G, MG, XR, F>), dim3(gridm), dim3(256), lds, s, in, out, a, batch)
 #define MF_STEMM2(F)                                                                               \
+    if (a.magic == 3) MF_STEMM(3, 0u, F); else                                                     \
     if (a.xr) { if (a.magic == 2) MF_STEMM(2, 0x80808080u, F); else if (a.magic) MF_STEMM(1, 0x80808080u, F); else MF_STEMM(0, 0x80808080u, F); } \
     else { if (a.magic == 2) MF_STEMM(2, 0u, F); else if (a.magic) MF_STEMM(1, 0u, F); else MF_STEMM(0, 0u, F); }
             if (f32_input) { MF_STEMM2(true) } else { MF_STEMM2(false) }

@@ -37,9 +37,6 @@
 // plane) is conflict-free without a swizzle.  The pointwise phase is dwpw3x3's.
 #include "k_common.hpp"
 
-#ifndef MF_RR_PERM_PACK
-#define MF_RR_PERM_PACK 0 // 1: v_cvt + v_perm packing of the intermediate (A/B switch)
-#endif
 
 namespace mf {
 namespace k {
@@ -559,17 +556,10 @@ __global__ __launch_bounds__(NTHR, WPE) void dwpw_rr(const int8_t *__restrict__ 
                 uint32_t d[2] = {0u, 0u};
 #pragma unroll
                 for (int q = 0; q < NQ; ++q)
-#if MF_RR_PERM_PACK
-                    d[q] = pack4x<XR4>(requant_t<MG>(acc[u][q][0], dA[q].x, dS[q].x, p.dw.lo_f, p.dw.hi_f),
-                                       requant_t<MG>(acc[u][q][1], dA[q].y, dS[q].y, p.dw.lo_f, p.dw.hi_f),
-                                       requant_t<MG>(acc[u][q][2], dA[q].z, dS[q].z, p.dw.lo_f, p.dw.hi_f),
-                                       requant_t<MG>(acc[u][q][3], dA[q].w, dS[q].w, p.dw.lo_f, p.dw.hi_f));
-#else
                     // this dword is an MFMA operand a few instructions later: the SDWA byte writes must not be the
-                    // instruction right before their reader (k_common.hpp: cvt_pack4 ends with an independent slot)
+                    // instruction right before their reader (k_common.hpp: the packs end with an independent slot)
                     d[q] = requant_pack4<MG, XR4>(acc[u][q][0], acc[u][q][1], acc[u][q][2], acc[u][q][3], dA[q], dS[q],
                                                   p.dw.lo_f, p.dw.hi_f);
-#endif
                 // K-bytes 8g .. 8g+7 of the pointwise contraction (bytes 4..7 meet zero weights when C < 32)
                 const long bop = (long)(((unsigned long)d[1] << 32) | (unsigned long)d[0]);
                 uint32_t packed[NT];
@@ -658,7 +648,7 @@ bool launch_dw_mm(int H, int W, int C, int S, const int8_t *in, int8_t *out, con
 #define MF_DWMM(h, w, c, st, n, g, t, d, cg, cy, ord, rp, ts, wpe)                                                  \
     if constexpr (dw_mm_layerwise(h, st)) {                                                                        \
         if (H == h && W == w && C == c && S == st) {                                                               \
-            MF_DISPATCH4(dw.magic, dw.xr, launch_dw_mm_t, (in, out, a, batch, s), h, w, c, st, n, g, t, d, cg, cy, ord, rp, ts, wpe) \
+            MF_DISPATCH5(dw.magic, dw.xr, launch_dw_mm_t, (in, out, a, batch, s), h, w, c, st, n, g, t, d, cg, cy, ord, rp, ts, wpe) \
             return true;                                                                                           \
         }                                                                                                          \
     }
@@ -682,7 +672,7 @@ bool launch_dwpw_mm(int H, int W, int C, int S, int N, const int8_t *in, int8_t 
         (void)idx;
 #define MF_DWMM(h, w, c, st, n, g, t, d, cg, cy, ord, rp, ts, wpe)                                                        \
     if (idx++ == alt && H == h && W == w && C == c && S == st && N == n) {                                           \
-        MF_DISPATCH4(a.dw.magic < a.pw.magic ? a.dw.magic : a.pw.magic, a.pw.xr, launch_dwpw_mm_t, (in, out, a, batch, s), h, w, c, st, n, g, t, d, \
+        MF_DISPATCH5(a.dw.magic < a.pw.magic ? a.dw.magic : a.pw.magic, a.pw.xr, launch_dwpw_mm_t, (in, out, a, batch, s), h, w, c, st, n, g, t, d, \
                      cg, cy, ord, rp, ts, wpe)                                                                            \
         return true;                                                                                                 \
     }
@@ -691,7 +681,7 @@ bool launch_dwpw_mm(int H, int W, int C, int S, int N, const int8_t *in, int8_t 
     }
 #define MF_DWMM(h, w, c, st, n, g, t, d, cg, cy, ord, rp, ts, wpe)                                                        \
     if (H == h && W == w && C == c && S == st && N == n) {                                                           \
-        MF_DISPATCH4(a.dw.magic < a.pw.magic ? a.dw.magic : a.pw.magic, a.pw.xr, launch_dwpw_mm_t, (in, out, a, batch, s), h, w, c, st, n, g, t, d, \
+        MF_DISPATCH5(a.dw.magic < a.pw.magic ? a.dw.magic : a.pw.magic, a.pw.xr, launch_dwpw_mm_t, (in, out, a, batch, s), h, w, c, st, n, g, t, d, \
                      cg, cy, ord, rp, ts, wpe)                                                                            \
         return true;                                                                                                 \
     }
@@ -733,7 +723,7 @@ bool launch_dwpw_rr(int H, int W, int C, int S, int N, const int8_t *in, int8_t 
         (void)idx;
 #define MF_DWRR(h, w, c, st, n, g, t, d, cg, cy, ord, rp, ts, wpe)                                                   \
     if (idx++ == alt && H == h && W == w && C == c && S == st && N == n) {                                           \
-        MF_DISPATCH4(a.dw.magic < a.pw.magic ? a.dw.magic : a.pw.magic, a.pw.xr, launch_dwpw_rr_t, (in, out, a, batch, s), h, w, c, st, n, g, t, d, \
+        MF_DISPATCH5(a.dw.magic < a.pw.magic ? a.dw.magic : a.pw.magic, a.pw.xr, launch_dwpw_rr_t, (in, out, a, batch, s), h, w, c, st, n, g, t, d, \
                      cg, cy, ord, rp, ts, wpe)                                                                       \
         return true;                                                                                                 \
     }
@@ -742,7 +732,7 @@ bool launch_dwpw_rr(int H, int W, int C, int S, int N, const int8_t *in, int8_t 
     }
 #define MF_DWRR(h, w, c, st, n, g, t, d, cg, cy, ord, rp, ts, wpe)                                                   \
     if (H == h && W == w && C == c && S == st && N == n) {                                                           \
-        MF_DISPATCH4(a.dw.magic < a.pw.magic ? a.dw.magic : a.pw.magic, a.pw.xr, launch_dwpw_rr_t, (in, out, a, batch, s), h, w, c, st, n, g, t, d, \
+        MF_DISPATCH5(a.dw.magic < a.pw.magic ? a.dw.magic : a.pw.magic, a.pw.xr, launch_dwpw_rr_t, (in, out, a, batch, s), h, w, c, st, n, g, t, d, \
                      cg, cy, ord, rp, ts, wpe)                                                                       \
         return true;                                                                                                 \
     }

@@ -461,6 +461,62 @@ __global__ __launch_bounds__(256) void selftest_requant_kernel(float A, float S,
     }
     if (cnt) atomicAdd(bad, (unsigned long long)cnt);
 }
+// ---- the gate of epilogue mode 3 (k_common.hpp; host search: epi_fma.cpp) ----
+// For every channel c of an operator and EVERY accumulator the channel can produce, acc in [amin[c], amax[c]]: the byte the kernels'
+// own requant_pack4<3> stores (v_fma_f32 on the accumulator's bit pattern with the pivot folded in, v_cvt_pk_u8_f32, XOR) against the
+// reference's two-rounding tail (requant_any: v_cvt_f32_i32, v_mul, v_add, roundf, clamp, truncating convert).  bad[c] counts the
+// mismatches; the operator may use the form only if all of them are zero.  blockIdx.y = channel.
+__global__ __launch_bounds__(256) void verify_fma_form_kernel(const float *A, const float *S, const float *C3, const float *S3, const int *piv,
+                                                             const int *amin, const int *amax, float lo, float hi, uint32_t xr,
+                                                             unsigned long long *bad) {
+    const int c = blockIdx.y;
+    const float a_ = A[c], s_ = S[c], c3 = C3[c], s3 = S3[c];
+    const int d = piv[c];
+    const long long a0 = amin[c], a1 = amax[c];
+    const float4 c4 = make_float4(c3, c3, c3, c3), s4 = make_float4(s3, s3, s3, s3);
+    unsigned cnt = 0;
+    for (long long base = a0 + 4ll * ((long long)blockIdx.x * 256 + threadIdx.x); base <= a1; base += 4ll * gridDim.x * 256) {
+        int bits[4];
+        uint32_t want = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const long long a = base + k <= a1 ? base + k : a1; // (the tail repeats the last accumulator)
+            bits[k] = MF_MAGIC_I + (int)a + d;
+            want |= (((uint32_t)requant_any((int)a, a_, s_, lo, hi) & 0xffu) ^ xr) << (8 * k);
+        }
+        const uint32_t got = requant_pack4<3, 0u>(bits[0], bits[1], bits[2], bits[3], c4, s4, lo, hi);
+        const uint32_t df = got ^ want;
+        cnt += (df & 0xffu ? 1 : 0) + (df & 0xff00u ? 1 : 0) + (df & 0xff0000u ? 1 : 0) + (df & 0xff000000u ? 1 : 0);
+    }
+    if (cnt) atomicAdd(bad + c, (unsigned long long)cnt);
+}
+// all pointers are DEVICE arrays of n entries (bad: zeroed by the caller); returns false when the launch failed
+bool verify_fma_form(const float *A, const float *S, const float *C3, const float *S3, const int *piv, const int *amin, const int *amax, int n,
+                     float lo, float hi, bool u8, unsigned long long *bad, hipStream_t s) {
+    hipLaunchKernelGGL(verify_fma_form_kernel, dim3(64, n), dim3(256), 0, s, A, S, C3, S3, piv, amin, amax, lo, hi, u8 ? 0x80u : 0u, bad);
+    return hipGetLastError() == hipSuccess;
+}
+// v_cvt_pk_u8_f32 itself, over all 2^32 bit patterns, against what epi_fma.cpp assumes of it: truncation toward zero,
+// saturation to [0, 255], NaN -> 0, the other three bytes of the destination untouched
+__global__ __launch_bounds__(256) void selftest_cvt_pk_kernel(unsigned long long *bad) {
+    const unsigned long long stride = (unsigned long long)gridDim.x * 256;
+    unsigned cnt = 0;
+    for (unsigned long long b = (unsigned long long)blockIdx.x * 256 + threadIdx.x; b < (1ull << 32); b += stride) {
+        const float x = __uint_as_float((uint32_t)b);
+        const uint32_t want = !(x > 0.0f) ? 0u : (x >= 255.0f ? 255u : (uint32_t)(int)x);
+        const uint32_t sel = (uint32_t)b & 3u, keep = 0xA5C3F17Eu;
+        uint32_t got;
+        switch (sel) { // (the byte selector is an immediate in the kernels)
+        case 0: got = __builtin_amdgcn_cvt_pk_u8_f32(x, 0u, keep); break;
+        case 1: got = __builtin_amdgcn_cvt_pk_u8_f32(x, 1u, keep); break;
+        case 2: got = __builtin_amdgcn_cvt_pk_u8_f32(x, 2u, keep); break;
+        default: got = __builtin_amdgcn_cvt_pk_u8_f32(x, 3u, keep); break;
+        }
+        const uint32_t exp = (keep & ~(0xffu << (8 * sel))) | (want << (8 * sel));
+        cnt += got != exp;
+    }
+    if (cnt) atomicAdd(bad, (unsigned long long)cnt);
+}
 template <typename Launch> static unsigned long long run_selftest(hipStream_t s, Launch launch) {
     unsigned long long *d = nullptr, h = ~0ull;
     if (hipMalloc((void **)&d, sizeof(h)) != hipSuccess) {
@@ -499,6 +555,9 @@ unsigned long long selftest_rounding(int mode, bool u8, float lo, float hi, hipS
             else hipLaunchKernelGGL((selftest_rounding_kernel<1, 0u>), g, b, 0, s, lo, hi, d);
         }
     });
+}
+unsigned long long selftest_cvt_pk(hipStream_t s) {
+    return run_selftest(s, [&](unsigned long long *d) { hipLaunchKernelGGL(selftest_cvt_pk_kernel, dim3(256 * 16), dim3(256), 0, s, d); });
 }
 unsigned long long selftest_requant(int mode, bool u8, float A, float S, float lo, float hi, hipStream_t s) {
     return run_selftest(s, [&](unsigned long long *d) {

@@ -206,7 +206,7 @@ bool launch_pw(int K, int N, const int8_t *in, int8_t *out, const PwArgs &a, lon
         long long grid = (nchunks + SLOTS * U - 1) / (SLOTS * U);                               \
         if (grid > pw_grid_cap(k, n)) grid = pw_grid_cap(k, n);                                 \
         if (grid < 1) grid = 1;                                                                 \
-        MF_DISPATCH4(a.magic, a.xr, launch_pw_t, (in, out, a, npix, (int)grid, s), k, n)                  \
+        MF_DISPATCH5(a.magic, a.xr, launch_pw_t, (in, out, a, npix, (int)grid, s), k, n)                  \
         return true;                                                                            \
     }
     MF_PW_SHAPES(MF_PW)

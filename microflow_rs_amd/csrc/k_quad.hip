@@ -492,7 +492,9 @@ bool launch_quad(int H, int W, int C, int S, int N, int H2, int W2, int C2, int 
     if (mg == 0) return false; // (the quads exist for the bit-pattern epilogues only)
 #define MF_QUAD_GO2(Q, ST)                                                                         \
     do {                                                                                           \
-        if (a.b.pw.xr) {                                                                           \
+        if (mg == 3) {                                                                             \
+            launch_quad_t<Q, ST, 3, 0u>(in, out, a, batch, s);                                     \
+        } else if (a.b.pw.xr) {                                                                           \
             if (mg == 2) launch_quad_t<Q, ST, 2, 0x80808080u>(in, out, a, batch, s);               \
             else launch_quad_t<Q, ST, 1, 0x80808080u>(in, out, a, batch, s);                       \
         } else {                                                                                   \

@@ -361,7 +361,9 @@ bool launch_stage(int H, int W, int C, int npairs, const int8_t *in, int8_t *out
         grid = nsteps < 256 * per_cu ? nsteps : 256 * per_cu;                                                      \
         hipLaunchKernelGGL((stage_6x6x128<G, NTHR, MG, XR>), dim3(grid), dim3(NTHR), lds, s, in, out, a, batch); \
     } while (0)
-    if (a.xr4) { // u8 element type: the stored byte is the value ^ 0x80 (XR4, see kernels.hpp)
+    if (a.mode == 3) { // the single-fma form for every operator of the run (its code does not depend on the element type)
+        MF_STAGE_GO(3, 0u);
+    } else if (a.xr4) { // u8 element type: the stored byte is the value ^ 0x80 (XR4, see kernels.hpp)
         if (a.mode == 2) MF_STAGE_GO(2, 0x80808080u); else MF_STAGE_GO(1, 0x80808080u);
     } else {
         if (a.mode == 2) MF_STAGE_GO(2, 0u); else MF_STAGE_GO(1, 0u);

@@ -89,6 +89,11 @@ struct DwFastArgs {
     int xr;             // 0 (i8) or 0x80 (u8): see ConvArgs
     int *queue;         // dynamic step queue of the persistent kernels (k_common.hpp DynSteps): DYNQ_INTS zeroed device ints
     int qcfg;           // its configuration for this launch (set by the launcher: dq_config)
+    // the single-fma form of this operator's epilogue (mode 3, k_common.hpp): C', S', Kc + pivot -- or nullptr when the host
+    // search (epi_fma.cpp) or the device check failed for a channel.  use_fma() switches a COPY of the block to it.
+    const float *A3, *S3;
+    const int *Kc3;
+    bool use_fma() { return A3 ? (A = A3, S = S3, Kc = Kc3, magic = 3, true) : false; }
 };
 // depthwise with ONE input channel and up to 8 output channels, any filter / stride (speech op 1)
 struct DwC1Args {
@@ -110,6 +115,14 @@ struct DwStemArgs {
     uint32_t izp4;
     float lo_f, hi_f;
     int magic, xr;
+    float A3[8], S3[8]; // the single-fma form (mode 3), valid when fma_ok
+    int Kc3[8];
+    int fma_ok;
+    bool use_fma() {
+        if (!fma_ok) return false;
+        for (int c = 0; c < 8; ++c) A[c] = A3[c], S[c] = S3[c], Kc[c] = Kc3[c];
+        return magic = 3, true;
+    }
     // f32-input variant (boundary quantisation fused into the staging): q = sat(roundf(x / in_scale + in_zp_f))
     float in_scale, in_zp_f, in_sat_lo, in_sat_hi;
     uint32_t in_xr4;
@@ -127,6 +140,9 @@ struct PwArgs {
     const int *Kc;
     float lo_f, hi_f;
     int magic, xr;
+    const float *A3, *S3; // the single-fma form (see DwFastArgs)
+    const int *Kc3;
+    bool use_fma() { return A3 ? (A = A3, S = S3, Kc = Kc3, magic = 3, true) : false; }
 };
 
 // run-time-geometry kernels (k_rt.hip): any H, W, C
@@ -414,31 +430,7 @@ struct StageArgs {
 // (G=4, 512 thr) -16 %, 24x24x32 s2 -> 512 thr -4 %; the rest already at their best.
 #define MF_DW_ALT_SHAPES(X)
 
-// fused depthwise 3x3 + pointwise pairs: H, W, C, stride, N (pointwise outputs), images per
-// step, threads per workgroup, double-buffered staging (1) or single (0)
-#define MF_DWPW_SHAPES(X)           \
-    X(48, 48, 8, 1, 16, 1, 512, 1)  \
-    X(48, 48, 16, 2, 32, 1, 768, 1) \
-    X(24, 24, 32, 1, 32, 1, 512, 1) \
-    X(24, 24, 32, 2, 64, 2, 256, 0) \
-    X(12, 12, 64, 1, 64, 4, 512, 0) \
-    X(12, 12, 64, 2, 128, 2, 256, 0) \
-    X(6, 6, 128, 1, 128, 8, 512, 0) \
-    X(6, 6, 128, 2, 256, 8, 512, 0) \
-    X(3, 3, 256, 1, 256, 8, 256, 0)
-
-// Tuning candidates: MF_DWPW_ALT=<i> makes the i-th entry (0-based) override the table above for
-// its shape; `scripts/tune_dwpw.sh` runs bench.py once per entry.  Empty in the product build --
-// add (H, W, C, S, N, G, NTHR, DB) rows here to A/B them.  Last sweep (r01, 15 candidates over
-// the four stride-1 pairs): only 12x12x64 moved, (G=2, 512 thr, DB) -> (G=4, 512 thr, SB) -11 %;
-// a second sweep over the stride-2 pairs and the two largest: 12x12x64 s2 -> (G=2, 256 thr) -8 %,
-// 6x6x128 s2 -> (G=8, 512 thr) -9 %, everything else already at its best.  After the rows-per-task
-// change a third sweep (thread counts matched to the new task counts): 48x48x16 s2 -> 768 thr -6 %.
-// Thread counts that are not multiples of 256 (384, 576) always lose 20-35 %: a workgroup's waves
-// are dealt round-robin to the 4 SIMDs, so 6 or 9 waves leave one SIMD with 50 % more work.
-#define MF_DWPW_ALT_SHAPES(X)
-
-// The same pairs with the depthwise taps on the matrix pipe (dwpw_mm, k_fused_mm.hip): H, W, C, stride, N,
+// Fused DepthwiseConv2D 3x3 + Conv2D 1x1 pairs with the depthwise taps on the matrix pipe (dwpw_mm, k_fused_mm.hip): H, W, C, stride, N,
 // images per step, threads, double-buffered staging, then the column grid of a depthwise unit -- CG images x
 // CY rows x (16 / CG / CY) x-positions, ORD = which of them varies fastest over the 16 MFMA columns
 // (0 gyx, 1 gxy, 2 ygx, 3 yxg, 4 xgy, 5 xyg) -- the row pitch padding (bytes) and the tile swizzle TS
@@ -518,6 +510,10 @@ unsigned long long verify_quant_div(float scale, float rcp, float zp_f, float sa
 // pattern taken as the pre-rounding value x, (b) over every accumulator in (-2^22, 2^22) at one (A, S); ~0 = could not run
 unsigned long long selftest_rounding(int mode, bool u8, float lo, float hi, hipStream_t s);
 unsigned long long selftest_requant(int mode, bool u8, float A, float S, float lo, float hi, hipStream_t s);
+unsigned long long selftest_cvt_pk(hipStream_t s); // v_cvt_pk_u8_f32 over all 2^32 inputs against the model epi_fma.cpp uses
+// exhaustive device check of the single-fma epilogue of one operator (k_generic.hip); device arrays of n channels
+bool verify_fma_form(const float *A, const float *S, const float *C3, const float *S3, const int *piv, const int *amin, const int *amax, int n,
+                     float lo, float hi, bool u8, unsigned long long *bad, hipStream_t s);
 void launch_quantize(const float *in, int8_t *out, size_t n, float scale, float zp_f, bool u8, hipStream_t s);
 void launch_xor80(const int8_t *in, int8_t *out, size_t n, hipStream_t s);
 void launch_dequantize(const int8_t *in, float *out, size_t n, float scale, float zp_f, bool raw_u8, hipStream_t s);

@@ -42,6 +42,28 @@ void h_preprocess_conv(float iscale, int n, const int32_t *bias, const float *bs
                        float *c0, float *c1);
 void h_preprocess_pool(float iscale, int izp, float oscale, int ozp, float *c0, float *c1);
 
+// ---- single-fma requantisation: host search (epi_fma.cpp) -------------------
+// y_u8(acc) = v_cvt_pk_u8_f32(v_fma_f32(S, bits_as_f32(0x4B400000 + acc + d), C))  -- k_common.hpp, epilogue mode 3
+struct FmaForm {
+    float S = 0, C = 0;
+    int32_t d = 0;
+    bool neg = false; // the negated variant: S < 0, the form yields 255 - y
+    bool rz = false;  // evaluated with FP_ROUND = toward zero
+};
+struct FmaSearchStats {
+    int steps = 0;            // steps of the reference staircase inside the reachable accumulator range
+    int s_candidates = 0;     // f32 neighbours of S with a non-empty real-arithmetic window
+    int s_rank = -1;          // which of them (by window width) gave the solution
+    double best_width = 0;    // widest window
+    long long pivots_tried = 0, exact_checks = 0;
+};
+// off: 128 (i8: the form works in the u8 domain, results are XOR-ed back) or 0 (u8); [lo, hi]: the clamp in T's domain;
+// [amin, amax]: the accumulators this channel can produce (inside (-2^22, 2^22)).  false: no (S', C', d) reproduces the reference on it.
+bool fma_form_search(float A, float S, int off, int lo, int hi, int64_t amin, int64_t amax, bool neg, bool rz, FmaForm &out, FmaSearchStats *stats = nullptr);
+int ref_form_eval(float A, float S, int off, int lo, int hi, int64_t acc); // the reference's tail, u8 domain
+int fma_form_eval(const FmaForm &f, int64_t acc);                          // the device's instructions, emulated exactly
+uint64_t fma_form_mismatches(float A, float S, int off, int lo, int hi, int64_t amin, int64_t amax, const FmaForm &f); // exhaustive, host
+
 // ---- parsed model (tflite.cpp) -------------------------------------------
 struct ParsedOp {
     int kind = 0;
@@ -106,7 +128,8 @@ void op_run_external(OpImpl *op, const int8_t *d_in, size_t batch, int8_t *d_out
 size_t op_in_elems(const OpImpl *op);
 size_t op_out_elems(const OpImpl *op);
 const char *op_kernel_name(const OpImpl *op);
-int op_epilogue_mode(const OpImpl *op); // k_common.hpp epilogue mode (0, 1, 2) the operator's constants admit; -1: no requantising epilogue of that kind
+int op_epilogue_mode(const OpImpl *op); // k_common.hpp epilogue mode (0 .. 3) of the operator's own launch; -1: no requantising epilogue of that kind
+bool op_has_fma_epilogue(const OpImpl *op); // the single-fma form (mode 3) was found for every channel and confirmed on the device
 void op_set_generic(OpImpl *op, bool generic);
 // fuse the model-boundary quantize (f32 -> T) into this operator if it has an f32-input kernel
 bool op_set_input_quant(OpImpl *op, float scale, int zp, bool u8);
@@ -135,6 +158,7 @@ FusedImpl *fused_quad_stem_create(OpImpl *stem, FusedImpl *quad); // the one-inp
 void fused_destroy(FusedImpl *f);
 void fused_run(FusedImpl *f, const int8_t *d_in, size_t batch, int8_t *d_out, void *stream);
 const char *fused_kernel_name(const FusedImpl *f);
+int fused_epilogue_mode(const FusedImpl *f); // epilogue mode of the launch (one for all its requantising operators); -1: none
 
 // zp is a value of T; with u8 the int8 buffer is in the internal domain (byte ^ 0x80)
 void dev_quantize(int device, const float *d_in, size_t n, float scale, int zp, bool u8, int8_t *d_out,
@@ -149,6 +173,9 @@ uint64_t dev_checksum_i8(int device, const int8_t *d_in, size_t n, void *stream)
 // exhaustive check of the 3-instruction boundary-quantisation division (k_common.hpp: quant_div): mismatching bytes
 uint64_t dev_verify_quant_div(int device, float scale, float rcp, int zp, bool u8);
 uint64_t dev_selftest_epilogue(int device, int mode, bool u8, bool have_as, float A, float S, int lo, int hi);
+// one channel of the single-fma epilogue on the device, every accumulator of [amin, amax] (k_generic.hip verify_fma_form): mismatches
+uint64_t dev_selftest_fma_epilogue(int device, float A, float S, bool u8, int64_t amin, int64_t amax, float S3, float C3, int pivot);
+uint64_t dev_selftest_cvt_pk(int device);
 int dev_count();
 void dev_require(int device); // throws MF_ERR_NO_DEVICE
 

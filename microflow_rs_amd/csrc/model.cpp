@@ -144,21 +144,14 @@ const char *model_op_kernel(const ModelImpl *m, int i) {
 
 int model_op_epilogue_mode(const ModelImpl *m, int i) {
     if (!m->prepared || i < 0 || i >= (int)m->ops.size() || !m->ops[i]) return -1;
-    int last = i;
     if (m->fusion && !m->generic) {
         const ModelImpl::Stage *best = nullptr;
         for (const ModelImpl::Stage &st : m->stages)
             if (i >= st.first && i <= st.last && (!best || st.first < best->first)) best = &st;
-        if (best && best->first == i) last = best->last;
-        else if (!best && fused_at(m, i)) last = m->fused_last[(size_t)i];
+        if (best && best->first == i) return fused_epilogue_mode(best->f);
+        if (!best && fused_at(m, i)) return fused_epilogue_mode(m->fused[(size_t)i]);
     }
-    int mode = -1;
-    for (int j = i; j <= last && j < (int)m->ops.size(); ++j) {
-        if (!m->ops[j]) continue;
-        const int e = op_epilogue_mode(m->ops[j]);
-        if (e >= 0) mode = mode < 0 ? e : (e < mode ? e : mode);
-    }
-    return mode;
+    return op_epilogue_mode(m->ops[i]);
 }
 
 static void ensure_capacity(ModelImpl *m, size_t batch) {

@@ -115,6 +115,13 @@ struct OpImpl {
     DevBuf d_crw, d_crm;   // conv_rows_lds: packed weights, tap masks
     bool rt_wz = false;    // non-zero weight zero points
     int magic_mode = 0;    // conv-like operators: epilogue mode the host proved usable (k_common.hpp: 0, 1 or 2)
+    // ... and mode 3, the single-fma form: found per channel by the host search (epi_fma.cpp) AND confirmed on the device over every
+    // reachable accumulator (k_generic.hip verify_fma_form).  The arrays hold C', S', Kc + pivot; the two-rounding constants stay
+    // beside them (a fused launch uses mode 3 only if every operator in it has it).
+    bool fma_ok = false;
+    DevBuf d_A3, d_S3, d_Kc3;
+    std::vector<float> h_A3, h_S3;
+    std::vector<int32_t> h_Kc3;
     int pw_group = 1;      // pixels presented as one row of the 1x1 product (K = 8 -> 2, K = 4 -> 4)
     DevBuf d_rtA, d_rtS, d_rtKc, d_rtwzp; // constants replicated per group member
 };
@@ -126,7 +133,8 @@ namespace {
 // (acc = sum over ALL taps of (v' - izp)(w - wzp), the halo contributing 0).
 int64_t fold_conv_constants(OpImpl &op, const OpSpec &s, bool depthwise, std::vector<float> &A,
                             std::vector<float> &S, std::vector<int32_t> &Kc,
-                            std::vector<int32_t> &wzp, std::vector<int64_t> *acc_bound_per_channel = nullptr) {
+                            std::vector<int32_t> &wzp, std::vector<int64_t> *acc_bound_per_channel = nullptr,
+                            std::vector<std::pair<int64_t, int64_t>> *acc_range_per_channel = nullptr) {
     const int N = s.N;
     const int taps = s.KH * s.KW;
     int64_t max_wabs = 0;
@@ -139,20 +147,25 @@ int64_t fold_conv_constants(OpImpl &op, const OpSpec &s, bool depthwise, std::ve
         int32_t wsum = 0;
         int32_t T;
         int64_t wabs = 0;
+        // the exact interval of acc = sum_taps (v - izp)(w - wzp) over int8 v (a halo tap contributes 0, which lies inside every
+        // tap's own interval): what the single-fma epilogue has to reproduce the reference on (epi_fma.cpp)
+        const int64_t vlo = -128 - s.izp, vhi = 127 - s.izp;
+        int64_t amin = 0, amax = 0;
+        auto tap = [&](int w) {
+            wsum = wrap_add(wsum, w);
+            const int64_t dw_ = (int64_t)w - wzp[c];
+            wabs += dw_ < 0 ? -dw_ : dw_;
+            amin += std::min(std::min(vlo * dw_, vhi * dw_), (int64_t)0), amax += std::max(std::max(vlo * dw_, vhi * dw_), (int64_t)0);
+        };
         if (depthwise) { // weights [KH][KW][N]
-            for (int t = 0; t < taps; ++t) {
-                wsum = wrap_add(wsum, s.weights[(size_t)t * N + c]);
-                wabs += std::abs((int)s.weights[(size_t)t * N + c] - wzp[c]);
-            }
+            for (int t = 0; t < taps; ++t) tap(s.weights[(size_t)t * N + c]);
             T = taps;
         } else { // filters [N][KH][KW][C]
             const int8_t *f = s.weights + (size_t)c * taps * s.C;
-            for (int t = 0; t < taps * s.C; ++t) {
-                wsum = wrap_add(wsum, f[t]);
-                wabs += std::abs((int)f[t] - wzp[c]);
-            }
+            for (int t = 0; t < taps * s.C; ++t) tap(f[t]);
             T = taps * s.C;
         }
+        if (acc_range_per_channel) acc_range_per_channel->push_back({amin, amax});
         max_wabs = std::max(max_wabs, wabs);
         if (acc_bound_per_channel) acc_bound_per_channel->push_back(wabs * std::max(127 - s.izp, s.izp + 128));
         // Kc = -izp * sum(w) + T * izp * wzp   (k2 and k3 of the reference with the halo == izp)
@@ -328,12 +341,9 @@ std::vector<int8_t> build_pw_rt_reg_weights(const int8_t *w /*[N][K]*/, int K, i
 
 } // namespace
 
-// layer-wise DepthwiseConv2D 3x3: taps on the matrix pipe (dwpw_mm's depthwise phase, k_fused_mm.hip) unless
-// MF_DW_IMPL=valu asks for the v_dot4 kernels (dw3x3_nhwc)
-static bool dw_taps_on_matrix_pipe() {
-    static const bool valu = [] { const char *e = getenv("MF_DW_IMPL"); return e && e[0] == 'v'; }();
-    return !valu;
-}
+// layer-wise DepthwiseConv2D 3x3: taps on the matrix pipe (dwpw_mm's depthwise phase, k_fused_mm.hip) where that form is the
+// faster one (the three large early layers), the v_dot4 kernel dw3x3_nhwc elsewhere: k::launch_dw_mm decides per shape
+static bool dw_taps_on_matrix_pipe() { return true; }
 
 OpImpl *op_create(int device, const OpSpec &spec) {
     dev_require(device);
@@ -378,7 +388,8 @@ OpImpl *op_create(int device, const OpSpec &spec) {
         // stays below 2^22 in magnitude (requant_t<true> in k_common.hpp)
         static const bool no_magic = getenv("MF_NO_MAGIC") != nullptr; // tests: force the convert form
         std::vector<int64_t> acc_bound_c; // per output channel: max |v - izp| * sum_taps |w - wzp|
-        const int64_t acc_bound = fold_conv_constants(*op, s, dw, A, S, Kc, wzp, &acc_bound_c);
+        std::vector<std::pair<int64_t, int64_t>> acc_range_c; // per output channel: the exact interval of acc over all inputs
+        const int64_t acc_bound = fold_conv_constants(*op, s, dw, A, S, Kc, wzp, &acc_bound_c, &acc_range_c);
         int magic = !no_magic && acc_bound < (1 << 22) ? 1 : 0;
         // mode 2 (k_common.hpp): the clamp is the element type's whole range (so a saturating pack can do it) and
         // |x| = |A + S * acc| stays below 2^15 for every input (so x + 128 fits the i16 the pack saturates from)
@@ -403,6 +414,43 @@ OpImpl *op_create(int device, const OpSpec &spec) {
         {
             const std::vector<int> zeros((size_t)k::DYNQ_INTS * k::DYNQ_RING, 0);
             op->d_queue.upload(zeros.data(), zeros.size() * sizeof(int));
+        }
+        // Epilogue mode 3: y = v_cvt_pk_u8_f32(v_fma_f32(S', bits(acc + pivot), C')).  Conditions: bit-pattern accumulators (mode >= 1),
+        // the clamp is the element type's whole range (the conversion's saturation IS the clamp), finite constants; then a solution
+        // for EVERY channel (host, exact: epi_fma.cpp) that the device confirms on every reachable accumulator.
+        static const bool no_fma = getenv("MF_NO_FMA_EPI") != nullptr; // tests / A-B: keep the two-rounding forms
+        if (magic >= 1 && !no_fma && lo == (s.u8 ? 0 : -128) && hi == (s.u8 ? 255 : 127) && all_finite(A) && all_finite(S)) {
+            std::vector<float> A3((size_t)s.N), S3((size_t)s.N);
+            std::vector<int32_t> K3((size_t)s.N), piv((size_t)s.N), amn((size_t)s.N), amx((size_t)s.N);
+            bool ok = true;
+            int fail_c = -1;
+            for (int c = 0; c < s.N && ok; ++c) {
+                FmaForm f;
+                const auto &r = acc_range_c[(size_t)c];
+                ok = fma_form_search(A[(size_t)c], S[(size_t)c], s.u8 ? 0 : 128, lo, hi, r.first, r.second, false, false, f);
+                if (!ok) fail_c = c;
+                A3[(size_t)c] = f.C, S3[(size_t)c] = f.S, piv[(size_t)c] = f.d, K3[(size_t)c] = wrap_add(Kc[(size_t)c], f.d);
+                amn[(size_t)c] = (int32_t)r.first, amx[(size_t)c] = (int32_t)r.second;
+            }
+            unsigned long long nbad = 0;
+            if (ok) {
+                op->d_A3.upload(A3.data(), A3.size() * 4), op->d_S3.upload(S3.data(), S3.size() * 4), op->d_Kc3.upload(K3.data(), K3.size() * 4);
+                DevBuf d_piv, d_amn, d_amx, d_bad;
+                const std::vector<unsigned long long> zero((size_t)s.N, 0ull);
+                d_piv.upload(piv.data(), piv.size() * 4), d_amn.upload(amn.data(), amn.size() * 4), d_amx.upload(amx.data(), amx.size() * 4);
+                d_bad.upload(zero.data(), zero.size() * 8);
+                std::vector<unsigned long long> bad((size_t)s.N, ~0ull);
+                if (k::verify_fma_form(op->d_A.as<float>(), op->d_S.as<float>(), op->d_A3.as<float>(), op->d_S3.as<float>(), d_piv.as<int>(),
+                                       d_amn.as<int>(), d_amx.as<int>(), s.N, (float)lo, (float)hi, s.u8, (unsigned long long *)d_bad.p, nullptr))
+                    MF_HIP(hipMemcpy(bad.data(), d_bad.p, bad.size() * 8, hipMemcpyDeviceToHost));
+                for (int c = 0; c < s.N; ++c)
+                    if (bad[(size_t)c]) nbad += bad[(size_t)c], fail_c = c;
+                ok = nbad == 0;
+                if (!ok) // the host's exact arithmetic and the device disagree: that is a bug in one of them, say so -- and do not use the form
+                    fprintf(stderr, "[microflow_amd] single-fma epilogue REJECTED by the device check (%llu accumulators differ, channel %d)\n", nbad, fail_c);
+            }
+            if (ok) op->fma_ok = true, op->h_A3 = A3, op->h_S3 = S3, op->h_Kc3 = K3;
+            if (epi_dbg) fprintf(stderr, "[epi] single-fma form: %s%s\n", ok ? "all channels" : "no: channel ", ok ? "" : std::to_string(fail_c).c_str());
         }
         k::ConvArgs &a = op->conv;
         a.H = s.H, a.W = s.W, a.C = s.C, a.N = s.N, a.KH = s.KH, a.KW = s.KW, a.sh = s.sh, a.sw = s.sw;
@@ -638,6 +686,14 @@ OpImpl *op_create(int device, const OpSpec &spec) {
         }
         if (op->fast == OpImpl::NONE && !dw && k::conv1x1_rowwave_supported(a)) // few outputs: one wavefront per pixel
             op->fast = OpImpl::CONV1X1_ROW, op->fast_name = "conv1x1_rowwave";
+        if (op->fma_ok) { // the single-fma constants beside the two-rounding ones, in the blocks of the kernels that have the form
+            op->dwf.A3 = op->pw.A3 = op->d_A3.as<float>(), op->dwf.S3 = op->pw.S3 = op->d_S3.as<float>();
+            op->dwf.Kc3 = op->pw.Kc3 = op->d_Kc3.as<int>();
+            if (op->fast == OpImpl::DW_STEM) {
+                for (int c = 0; c < 8; ++c) op->stem.A3[c] = op->h_A3[(size_t)c], op->stem.S3[c] = op->h_S3[(size_t)c], op->stem.Kc3[c] = op->h_Kc3[(size_t)c];
+                op->stem.fma_ok = 1;
+            }
+        }
         if (getenv("MF_VERBOSE"))
             fprintf(stderr, "[microflow_amd] %s %dx%dx%d -> %d: kernel %s, worst-case |acc| %lld%s\n",
                     dw ? "depthwise_conv_2d" : "conv_2d", s.H, s.W, s.C, s.N,
@@ -748,9 +804,19 @@ const char *op_kernel_name(const OpImpl *op) {
                                                              : op->generic_name.c_str();
 }
 void op_set_generic(OpImpl *op, bool g) { op->force_generic = g; }
-int op_epilogue_mode(const OpImpl *op) { // -1: not a convolution-like operator
-    return (op->s.kind == MF_OP_CONV_2D || op->s.kind == MF_OP_DEPTHWISE_CONV_2D) ? op->magic_mode : -1;
+// the layer-wise kernels that have the single-fma epilogue (k_common.hpp mode 3): the matrix-pipe depthwise, the MFMA pointwise, the stem
+static bool op_runs_fma(const OpImpl *op) {
+    if (!op->fma_ok) return false;
+    const OpSpec &sp = op->s;
+    static const bool stem_valu = [] { const char *e = getenv("MF_STEM_IMPL"); return e && e[0] == 'v'; }();
+    return (op->fast == OpImpl::DW_NHWC && dw_taps_on_matrix_pipe() && op->dwf.wmm && k::dw_mm_name(sp.H, sp.W, sp.C, sp.sh)) ||
+           op->fast == OpImpl::PW_MFMA || (op->fast == OpImpl::DW_STEM && !stem_valu);
 }
+int op_epilogue_mode(const OpImpl *op) { // of the operator's own (layer-wise) launch; -1: not a convolution-like operator
+    if (op->s.kind != MF_OP_CONV_2D && op->s.kind != MF_OP_DEPTHWISE_CONV_2D) return -1;
+    return op_runs_fma(op) ? 3 : op->magic_mode;
+}
+bool op_has_fma_epilogue(const OpImpl *op) { return op->fma_ok; }
 
 void op_run(OpImpl *op, const int8_t *d_in, size_t batch, int8_t *d_out, void *stream) {
     if (!batch) return;
@@ -765,13 +831,19 @@ void op_run(OpImpl *op, const int8_t *d_in, size_t batch, int8_t *d_out, void *s
     if (fast) {
         if (batch > 0x7fffffffull / 4) fail(MF_ERR_INVALID_ARG, "batch too large for one launch");
         switch (op->fast) {
-        case OpImpl::DW_NHWC:
-            done = (dw_taps_on_matrix_pipe() && k::launch_dw_mm(sp.H, sp.W, sp.C, sp.sh, d_in, d_out, op->dwf, (int)batch, s)) ||
+        case OpImpl::DW_NHWC: {
+            k::DwFastArgs f3 = op->dwf;
+            const bool fma = op_runs_fma(op) && f3.use_fma();
+            done = (dw_taps_on_matrix_pipe() && k::launch_dw_mm(sp.H, sp.W, sp.C, sp.sh, d_in, d_out, fma ? f3 : op->dwf, (int)batch, s)) ||
                    k::launch_dw_fast(sp.H, sp.W, sp.C, sp.sh, d_in, d_out, op->dwf, (int)batch, s);
             break;
-        case OpImpl::DW_STEM:
-            done = k::launch_dw_stem(sp.H, sp.W, sp.N, sp.sh, d_in, d_out, op->stem, (int)batch, s);
+        }
+        case OpImpl::DW_STEM: {
+            k::DwStemArgs f3 = op->stem;
+            const bool fma = op_runs_fma(op) && f3.use_fma();
+            done = k::launch_dw_stem(sp.H, sp.W, sp.N, sp.sh, d_in, d_out, fma ? f3 : op->stem, (int)batch, s);
             break;
+        }
         case OpImpl::DW_STEM_RT:
             k::launch_dw_stem_rt(d_in, d_out, op->stemrt, (int)batch, s);
             done = true;
@@ -788,9 +860,12 @@ void op_run(OpImpl *op, const int8_t *d_in, size_t batch, int8_t *d_out, void *s
             k::launch_dw_c1(d_in, d_out, op->dwc1, batch, s);
             done = true;
             break;
-        case OpImpl::PW_MFMA:
-            done = k::launch_pw(sp.C, sp.N, d_in, d_out, op->pw, (long long)batch * sp.H * sp.W, s);
+        case OpImpl::PW_MFMA: {
+            k::PwArgs f3 = op->pw;
+            const bool fma = op_runs_fma(op) && f3.use_fma();
+            done = k::launch_pw(sp.C, sp.N, d_in, d_out, fma ? f3 : op->pw, (long long)batch * sp.H * sp.W, s);
             break;
+        }
         case OpImpl::CONV_MM:
             k::launch_conv_mm(d_in, d_out, op->cmm, op->rt_wz, (int)batch, s);
             done = true;
@@ -921,7 +996,9 @@ void op_run_f32(OpImpl *op, const float *d_in, size_t batch, int8_t *d_out, void
     if (!d_in || !d_out) fail(MF_ERR_INVALID_ARG, "op_run_f32: null device pointer");
     if (batch > 0x7fffffffull / 4) fail(MF_ERR_INVALID_ARG, "batch too large for one launch");
     const OpSpec &sp = op->s;
-    if (!k::launch_dw_stem(sp.H, sp.W, sp.N, sp.sh, (const int8_t *)d_in, d_out, op->stem, (int)batch,
+    k::DwStemArgs f3 = op->stem;
+    const bool fma = op_runs_fma(op) && f3.use_fma();
+    if (!k::launch_dw_stem(sp.H, sp.W, sp.N, sp.sh, (const int8_t *)d_in, d_out, fma ? f3 : op->stem, (int)batch,
                            (hipStream_t)stream, true))
         fail(MF_ERR_UNSUPPORTED, "f32 stem kernel missing");
     MF_HIP(hipGetLastError());
@@ -944,10 +1021,21 @@ struct FusedImpl {
     // QUAD: two consecutive pairs in one kernel (k_quad.hip); a = the first pair's depthwise, b = the second pair's conv
     k::QuadArgs quad{};
     int quad_shape[10] = {0};
+    OpImpl *quad_ops[4] = {nullptr, nullptr, nullptr, nullptr}; // the two pairs' operators (the stem variant rebuilds the blocks from them)
     // CHAIN: 1 .. CHAIN_MAX consecutive pairs of any geometry in one launch (k_chain.hip); table and weights in stage_w
     k::ChainArgs chain{};
     std::vector<std::pair<OpImpl *, OpImpl *>> chain_members;
+    int epi_mode = -1; // epilogue mode (k_common.hpp) of the launch's requantising operators; -1: not recorded (the operators' minimum)
 };
+// the pair's argument blocks as the operators hold them (two-rounding constants), and switched to the single-fma form when
+// both operators have it
+static k::DwPwArgs pair_args(const OpImpl *dw, const OpImpl *pw, bool fma) {
+    k::DwPwArgs a;
+    a.dw = dw->dwf, a.pw = pw->pw;
+    if (fma && dw->fma_ok && pw->fma_ok) a.dw.use_fma(), a.pw.use_fma();
+    return a;
+}
+static int pair_mode(const k::DwPwArgs &a) { return std::min(a.dw.magic, a.pw.magic); }
 
 // ---- run-time-geometry chains (k_chain.hip) ----
 static bool chain_enabled() {
@@ -1070,6 +1158,7 @@ static FusedImpl *chain_create(const std::pair<OpImpl *, OpImpl *> *mem, int n, 
     c->chain.pairs = (const k::ChainPair *)c->stage_w.back()->p;
     if (magic == 0 && c->chain.KSC != 4) return nullptr;
     c->chain.magic = magic, c->chain.xr = mem[0].first->s.u8 ? 0x80 : 0;
+    c->epi_mode = magic;
     c->chain.queue = (int *)mem[0].first->d_queue.p;
     return c.release();
 }
@@ -1303,8 +1392,8 @@ FusedImpl *fused_create(OpImpl *dw, OpImpl *pw) {
     const char *nm = k::dwpw_name(d.H, d.W, d.C, d.sh, q.N);
     if (!nm) return nullptr;
     FusedImpl *f = new FusedImpl{FusedImpl::DWPW, dw, pw, nullptr, {}, {}, nm};
-    f->dwpw.dw = dw->dwf;
-    f->dwpw.pw = pw->pw;
+    f->dwpw = pair_args(dw, pw, true);
+    f->epi_mode = pair_mode(f->dwpw);
     return f;
 }
 
@@ -1382,11 +1471,16 @@ FusedImpl *fused_stage_create(FusedImpl *const *pairs, int npairs) {
         if (d.u8 != d0.u8 || q.u8 != d0.u8 || !f->dwpw.dw.magic || !f->dwpw.pw.magic || !f->dwpw.dw.wmm) return nullptr; // bit-pattern epilogues
         if (f->dwpw.dw.izp4 != pairs[0]->dwpw.dw.izp4 || f->a->device != pairs[0]->a->device) return nullptr;
     }
+    bool all_fma = true; // the single-fma form needs it of every operator of the run
+    for (int i = 0; i < npairs; ++i) all_fma = all_fma && pairs[i]->a->fma_ok && pairs[i]->b->fma_ok;
     std::unique_ptr<FusedImpl> s(new FusedImpl{FusedImpl::STAGE, pairs[0]->a, pairs[npairs - 1]->b, nullptr, {}, {}, nm});
     s->stage_pairs = npairs;
     std::vector<k::StagePair> table((size_t)npairs);
     for (int i = 0; i < npairs; ++i) {
-        const FusedImpl *f = pairs[i];
+        const FusedImpl *fp = pairs[i];
+        FusedImpl tmp{FusedImpl::DWPW, fp->a, fp->b, nullptr, {}, {}, ""};
+        tmp.dwpw = pair_args(fp->a, fp->b, all_fma);
+        const FusedImpl *f = &tmp;
         k::StagePair &sp = table[(size_t)i];
         // Kc + the bit-pattern offset of requant_t<true> (k_common.hpp), as separate arrays for this kernel
         auto with_magic = [&](const int *d_kc, int n) {
@@ -1415,9 +1509,10 @@ FusedImpl *fused_stage_create(FusedImpl *const *pairs, int npairs) {
     s->stage.izp4 = pairs[0]->dwpw.dw.izp4;
     s->stage.xr4 = d0.u8 ? 0x80808080u : 0u;
     s->stage.queue = pairs[0]->dwpw.dw.queue;
-    s->stage.mode = 2; // the saturating-pack epilogue needs it of every operator of the run
-    for (int i = 0; i < npairs; ++i)
-        if (pairs[i]->dwpw.dw.magic != 2 || pairs[i]->dwpw.pw.magic != 2) s->stage.mode = 1;
+    s->stage.mode = all_fma ? 3 : 2; // the saturating-pack epilogue needs it of every operator of the run
+    for (int i = 0; i < npairs && !all_fma; ++i)
+        if (pairs[i]->a->magic_mode != 2 || pairs[i]->b->magic_mode != 2) s->stage.mode = 1;
+    s->epi_mode = s->stage.mode;
     return s.release();
 }
 
@@ -1480,6 +1575,7 @@ FusedImpl *fused_dwfc_create(OpImpl *dw, FusedImpl *fcsm) {
     f->dwfc.dwA = c1.A, f->dwfc.dwS = c1.S, f->dwfc.dwKc = c1.Kc, f->dwfc.dw_lo = c1.lo_f, f->dwfc.dw_hi = c1.hi_f;
     f->dwfc.izp4 = 0x01010101u * (uint32_t)(uint8_t)(int8_t)c1.izp;
     f->dwfc.magic = c1.magic, f->dwfc.xr = c1.xr;
+    f->epi_mode = c1.magic;
     f->dwfc.fc = fc->fc, f->dwfc.sm = sm->sm;
     return f.release();
 }
@@ -1517,6 +1613,7 @@ FusedImpl *fused_pair_tail_create(FusedImpl *pair, FusedImpl *tail) {
     };
     k::PairTailArgs &a = f->pairtail;
     a.H = d.H, a.C = d.C, a.magic = magic;
+    f->epi_mode = magic;
     a.dw_wmm = df.wmm, a.dwA = df.A, a.dwS = df.S, a.dwK = with_magic(df.Kc, d.N);
     a.dw_lo = df.lo_f, a.dw_hi = df.hi_f, a.izp4 = df.izp4;
     std::vector<int8_t> host((size_t)q.N * q.C);
@@ -1541,11 +1638,15 @@ FusedImpl *fused_quad_create(FusedImpl *p1, FusedImpl *p2) {
     if (d2.H != q1.H || d2.W != q1.W || d2.C != q1.N) return nullptr; // the second pair consumes the first pair's output
     const char *nm = k::quad_name(d1.H, d1.W, d1.C, d1.sh, q1.N, d2.H, d2.W, d2.C, d2.sh, q2.N);
     if (!nm) return nullptr;
-    const k::DwPwArgs &a = p1->dwpw, &b = p2->dwpw;
+    // (the single-fma form needs it of all four operators)
+    const bool fma = p1->a->fma_ok && p1->b->fma_ok && p2->a->fma_ok && p2->b->fma_ok;
+    const k::DwPwArgs a = pair_args(p1->a, p1->b, fma), b = pair_args(p2->a, p2->b, fma);
     if (!a.dw.wmm || !a.pw.wrr || !b.dw.wmm || !b.pw.wrr) return nullptr;
     if (!a.dw.magic || !a.pw.magic || !b.dw.magic || !b.pw.magic) return nullptr; // bit-pattern epilogues
     FusedImpl *f = new FusedImpl{FusedImpl::QUAD, p1->a, p2->b, nullptr, {}, {}, nm};
     f->quad.a = a, f->quad.b = b;
+    f->epi_mode = std::min(pair_mode(a), pair_mode(b));
+    f->quad_ops[0] = p1->a, f->quad_ops[1] = p1->b, f->quad_ops[2] = p2->a, f->quad_ops[3] = p2->b;
     const int shp[10] = {d1.H, d1.W, d1.C, d1.sh, q1.N, d2.H, d2.W, d2.C, d2.sh, q2.N};
     for (int i = 0; i < 10; ++i) f->quad_shape[i] = shp[i];
     return f;
@@ -1565,7 +1666,12 @@ FusedImpl *fused_quad_stem_create(OpImpl *stem, FusedImpl *quad) {
     std::unique_ptr<FusedImpl> f(new FusedImpl{FusedImpl::QUAD, stem, quad->b, nullptr, {}, {}, nm});
     f->quad = quad->quad;
     for (int i = 0; i < 10; ++i) f->quad_shape[i] = q[i];
-    const k::DwStemArgs &sa = stem->stem;
+    // five operators, one epilogue mode: the single-fma form if all five have it, else everyone's two-rounding constants
+    OpImpl *const *qo = quad->quad_ops;
+    const bool fma = stem->fma_ok && qo[0]->fma_ok && qo[1]->fma_ok && qo[2]->fma_ok && qo[3]->fma_ok;
+    f->quad.a = pair_args(qo[0], qo[1], fma), f->quad.b = pair_args(qo[2], qo[3], fma);
+    k::DwStemArgs sa = stem->stem;
+    if (fma) sa.use_fma();
     std::vector<uint32_t> tab(152);
     for (int l = 0; l < 64; ++l) tab[(size_t)2 * l] = sa.wmm[l][0], tab[(size_t)2 * l + 1] = sa.wmm[l][1];
     for (int c = 0; c < 8; ++c) {
@@ -1577,11 +1683,19 @@ FusedImpl *fused_quad_stem_create(OpImpl *stem, FusedImpl *quad) {
     f->stage_w.back()->upload(tab.data(), tab.size() * 4);
     f->quad.stem = f->stage_w.back()->as<uint32_t>();
     f->quad.stem_izp4 = sa.izp4, f->quad.stem_lo = sa.lo_f, f->quad.stem_hi = sa.hi_f, f->quad.stem_magic = sa.magic;
+    f->epi_mode = std::min(std::min(pair_mode(f->quad.a), pair_mode(f->quad.b)), sa.magic);
     return f.release();
 }
 
 void fused_destroy(FusedImpl *f) { delete f; }
 const char *fused_kernel_name(const FusedImpl *f) { return f->name.c_str(); }
+int fused_epilogue_mode(const FusedImpl *f) {
+    if (f->epi_mode >= 0) return f->epi_mode;
+    int mode = -1; // not recorded by the builder: the minimum over the group's conv-like operators
+    for (const OpImpl *o : {f->a, f->b, f->c})
+        if (o && (o->s.kind == MF_OP_CONV_2D || o->s.kind == MF_OP_DEPTHWISE_CONV_2D)) mode = mode < 0 ? o->magic_mode : std::min(mode, o->magic_mode);
+    return mode;
+}
 void fused_run(FusedImpl *f, const int8_t *d_in, size_t batch, int8_t *d_out, void *stream) {
     if (!batch) return;
     if (f->kind == FusedImpl::STAGE) {
@@ -1683,6 +1797,28 @@ uint64_t dev_selftest_epilogue(int device, int mode, bool u8, bool have_as, floa
                                          : k::selftest_rounding(mode, u8, (float)lo, (float)hi, nullptr);
     if (r == ~0ull) fail(MF_ERR_HIP, "selftest kernel could not run");
     return r;
+}
+uint64_t dev_selftest_fma_epilogue(int device, float A, float S, bool u8, int64_t amin, int64_t amax, float S3, float C3, int pivot) {
+    dev_require(device);
+    MF_HIP(hipSetDevice(device));
+    DevBuf dA, dS, dC3, dS3, dpiv, dmn, dmx, dbad;
+    const int32_t mn = (int32_t)amin, mx = (int32_t)amax;
+    const unsigned long long zero = 0;
+    dA.upload(&A, 4), dS.upload(&S, 4), dC3.upload(&C3, 4), dS3.upload(&S3, 4), dpiv.upload(&pivot, 4), dmn.upload(&mn, 4), dmx.upload(&mx, 4);
+    dbad.upload(&zero, 8);
+    unsigned long long bad = ~0ull;
+    if (!k::verify_fma_form(dA.as<float>(), dS.as<float>(), dC3.as<float>(), dS3.as<float>(), dpiv.as<int>(), dmn.as<int>(), dmx.as<int>(), 1,
+                            u8 ? 0.0f : -128.0f, u8 ? 255.0f : 127.0f, u8, (unsigned long long *)dbad.p, nullptr))
+        fail(MF_ERR_HIP, "selftest kernel could not run");
+    MF_HIP(hipMemcpy(&bad, dbad.p, 8, hipMemcpyDeviceToHost));
+    return (uint64_t)bad;
+}
+uint64_t dev_selftest_cvt_pk(int device) {
+    dev_require(device);
+    MF_HIP(hipSetDevice(device));
+    const unsigned long long r = k::selftest_cvt_pk(nullptr);
+    if (r == ~0ull) fail(MF_ERR_HIP, "selftest kernel could not run");
+    return (uint64_t)r;
 }
 uint64_t dev_verify_quant_div(int device, float scale, float rcp, int zp, bool u8) {
     dev_require(device);

@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void bench(uint32_t *out, int seed, float A, f
             if (V == 0) { // requant + v_cvt + 3 v_perm (r01)
                 d = pack4((int)rq(acc[g][0], A, S, lo, hi), (int)rq(acc[g][1], A, S, lo, hi), (int)rq(acc[g][2], A, S, lo, hi),
                           (int)rq(acc[g][3], A, S, lo, hi));
-            } else if (V == 1) { // SDWA cvt into byte k, dependent chain, s_nop between
+            } else if (V == 1) { // SDWA cvt into byte k, dependent chain, s_nop between (round 2's form, retired from the library in round 5)
                 const float r0 = rq(acc[g][0], A, S, lo, hi), r1 = rq(acc[g][1], A, S, lo, hi), r2 = rq(acc[g][2], A, S, lo, hi),
                             r3 = rq(acc[g][3], A, S, lo, hi);
                 asm("v_cvt_i32_f32_sdwa %0, %1 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:DWORD\n\ts_nop 0\n\t"
@@ -47,6 +47,15 @@ __global__ __launch_bounds__(256) void bench(uint32_t *out, int seed, float A, f
                     "v_cvt_i32_f32_sdwa %0, %3 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD\n\ts_nop 0\n\t"
                     "v_cvt_i32_f32_sdwa %0, %4 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:DWORD\n\ts_nop 0"
                     : "=&v"(d) : "v"(r0), "v"(r1), "v"(r2), "v"(r3));
+            } else if (V == 8) { // epilogue mode 3: v_fma_f32 + v_cvt_pk_u8_f32 per byte (the library's requant_pack4<3>)
+                d = mf::k::requant_pack4<3, 0u>(acc[g][0], acc[g][1], acc[g][2], acc[g][3], make_float4(A, A, A, A), make_float4(S, S, S, S), lo, hi);
+            } else if (V == 9) { // mode 3, two dwords per call
+                if (g & 1) {
+                    uint32_t da, db;
+                    const mf::k::v4i a0 = {acc[g - 1][0], acc[g - 1][1], acc[g - 1][2], acc[g - 1][3]}, a1 = {acc[g][0], acc[g][1], acc[g][2], acc[g][3]};
+                    mf::k::requant_pack4x2<3, 0u>(a0, make_float4(A, A, A, A), make_float4(S, S, S, S), a1, make_float4(A, A, A, A), make_float4(S, S, S, S), lo, hi, da, db);
+                    d = da + db;
+                }
             } else if (V == 2) { // requant only (no conversion, no packing): lower bound of the float part
                 d = __float_as_uint(rq(acc[g][0], A, S, lo, hi)) ^ __float_as_uint(rq(acc[g][1], A, S, lo, hi)) ^
                     __float_as_uint(rq(acc[g][2], A, S, lo, hi)) ^ __float_as_uint(rq(acc[g][3], A, S, lo, hi));
@@ -106,7 +115,7 @@ template <int V> static double run(uint32_t *d, const char *name, double base_ex
     return ns_per_group_simd;
 }
 
-// ns per packed dword (4 output bytes) per SIMD of variant v (4: epilogue mode 1, 5: mode 2, 1: round 2's form), loop
+// ns per packed dword (4 output bytes) per SIMD of variant v (4: epilogue mode 1, 5: mode 2, 8: mode 3, 1: round 2's form), loop
 // overhead included (one v_add per value); < 0 on failure.  The chip-wide rate is 1024 SIMDs * 4 bytes / that.
 extern "C" double mf_ubench_requant_ns(int variant) {
     uint32_t *d = nullptr;
@@ -119,6 +128,8 @@ extern "C" double mf_ubench_requant_ns(int variant) {
     case 5: ns = run<5>(d, "", 0); break;
     case 6: ns = run<6>(d, "", 0); break;
     case 7: ns = run<7>(d, "", 0); break;
+    case 8: ns = run<8>(d, "", 0); break;
+    case 9: ns = run<9>(d, "", 0); break;
     default: break;
     }
     g_quiet = false;
@@ -138,6 +149,8 @@ int main() {
     run<5>(d, "mode 2: sticky RNE + sat pack", 0);
     run<6>(d, "mode 1, two dwords per block", 0);
     run<7>(d, "mode 2, two dwords per block", 0);
+    run<8>(d, "mode 3: fma + cvt_pk_u8", 0);
+    run<9>(d, "mode 3, two dwords per call", 0);
     return 0;
 }
 #endif

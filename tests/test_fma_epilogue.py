@@ -1,0 +1,250 @@
+"""Epilogue mode 3 -- the single-fma requantisation (csrc/epi_fma.cpp, k_common.hpp).
+
+The reference's tail  y = sat(roundf(fl(A + fl(S * f32(acc)))))  (src/ops/conv_2d.rs:93-98) is a staircase in acc; the library
+replaces it by  v_cvt_pk_u8_f32(v_fma_f32(S', bits(acc + pivot), C'))  only where the two staircases are IDENTICAL on every
+accumulator the channel can produce.  CPU tests: what the host search returns is checked here against an independent numpy
+restatement of both forms (no code shared with the product).  GPU tests: the device's own instructions against the
+two-rounding form, a negative control, and the models end to end.
+"""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from tests.conftest import ROOT, ROUTING_SWITCHED, model_path
+
+f32 = np.float32
+M0 = 12582912  # 1.5 * 2^23 = the f32 whose bit pattern is 0x4B400000
+
+
+def _lib():
+    from microflow_rs_amd import _lib
+    return _lib
+
+
+def search(A, S, amin, amax, u8=False):
+    L = _lib().lib()
+    s, c, d, found = C.c_float(), C.c_float(), C.c_int(), C.c_int()
+    _lib().check(L.mf_fma_epilogue_search(C.c_float(A), C.c_float(S), int(u8), int(amin), int(amax), C.byref(s), C.byref(c),
+                                          C.byref(d), C.byref(found)))
+    return (f32(s.value), f32(c.value), d.value) if found.value else None
+
+
+def ref_numpy(A, S, acc, off):
+    """the reference's tail on an array of accumulators, in the u8 domain (individually rounded f32 operations; roundf = half away)"""
+    x = f32(A) + f32(S) * acc.astype(np.float32)           # two roundings (numpy never fuses)
+    r = np.sign(x) * np.floor(np.abs(x).astype(np.float64) + 0.5)
+    lo, hi = (-128, 127) if off else (0, 255)               # i8 (then + 128) or u8
+    return np.clip(r, lo, hi).astype(np.int64) + off
+
+
+def fma_numpy(s3, c3, d, acc):
+    """v_fma_f32 on the bit pattern + v_cvt_pk_u8_f32, emulated: the product and sum are exact in x87 long double
+    (24 x 24 bit product, addend within 2^40 of its last bit), ONE rounding to f32, truncation, saturation"""
+    assert np.finfo(np.longdouble).nmant >= 63
+    F = (acc + (M0 + d)).astype(np.float32)
+    assert np.all(F.astype(np.int64) == acc + M0 + d)      # the bit pattern reads as exactly this value
+    x = (np.longdouble(s3) * F.astype(np.longdouble) + np.longdouble(c3)).astype(np.float32)
+    return np.clip(np.trunc(x.astype(np.float64)), 0, 255).astype(np.int64)
+
+
+def full_range(A, S):
+    """accumulators covering every output value plus a saturated margin on both sides"""
+    lo = int(np.floor((-129.0 - float(A)) / float(S))) - 3
+    hi = int(np.ceil((128.0 - float(A)) / float(S))) + 3
+    lim = (1 << 22) - 2
+    return max(lo, -lim), min(hi, lim)
+
+
+def person_detect_channels(O, ops=(0, 1, 2, 4, 6, 8, 12, 13, 14, 20, 24, 26), per_op=6):
+    om = O.Model(model_path("person_detect"))
+    out = []
+    for i in ops:
+        c0, c1 = om.op_constants(i)[:2]
+        ozp = om.ops[i]["out_zp"]
+        n = len(c0)
+        for c in sorted(set(int(round(t)) for t in np.linspace(0, n - 1, per_op))):
+            out.append((i, c, f32(f32(ozp) + f32(c0[c])), f32(c1[c if c < len(c1) else 0])))
+    return out
+
+
+def test_search_results_hold_on_every_accumulator(O):
+    """Whatever the search returns reproduces the reference on the WHOLE range it was asked for -- checked with numpy, not
+    with the library's own evaluator -- and it finds a solution for most real channels even on the full output range
+    (the library restricts the range to the accumulators the weights can produce, which only makes it easier)."""
+    chans = person_detect_channels(O)
+    found = 0
+    for op, c, A, S in chans:
+        amin, amax = full_range(A, S)
+        r = search(A, S, amin, amax)
+        if r is None:
+            continue
+        found += 1
+        s3, c3, d = r
+        acc = np.arange(amin, amax + 1, dtype=np.int64)
+        want = ref_numpy(A, S, acc, 128)
+        got = fma_numpy(s3, c3, d, acc)
+        assert np.array_equal(want, got), (op, c, float(A), float(S), np.flatnonzero(want != got)[:4])
+        assert abs(int(np.float32(s3).view(np.int32)) - int(np.float32(S).view(np.int32))) <= 64  # S' is S moved by ulps
+    assert found >= 0.85 * len(chans), (found, len(chans))
+
+
+def test_search_synthetic_constants():
+    """ties on purpose (A and S dyadic), steep and shallow staircases, outputs that saturate on one side only.  "No solution"
+    is a legitimate answer -- the operator then keeps the two-rounding form: dyadic constants produce exact ties, which the
+    reference rounds away from zero on both sides of 0 and no single line does; other constants can have two near-ties the
+    reference's roundings resolve in opposite directions -- but whatever IS returned must hold on the whole range."""
+    found = 0
+    cases = [(-127.5, 0.5), (-128.0, 0.25), (0.5, 1.0), (-3.25, 0.001953125), (-127.31, 0.0021), (-100.0, 0.31964308), (5.0, 0.007),
+             (-64.03125, 0.015625), (-200.0, 0.004), (90.0, 0.02), (-131.7, 0.0123), (-150.2, 0.0031), (-128.9, 0.05), (-180.0, 0.0077)]
+    for A, S in cases:
+        amin, amax = full_range(f32(A), f32(S))
+        r = search(A, S, amin, amax)
+        if r is None:
+            continue
+        found += 1
+        s3, c3, d = r
+        acc = np.arange(amin, amax + 1, dtype=np.int64)
+        assert np.array_equal(ref_numpy(f32(A), f32(S), acc, 128), fma_numpy(s3, c3, d, acc)), (A, S)
+        bad = C.c_uint64(1)
+        _lib().check(_lib().lib().mf_fma_epilogue_check_host(C.c_float(A), C.c_float(S), 0, amin, amax, C.c_float(s3), C.c_float(c3), d,
+                                                             C.byref(bad)))
+        assert bad.value == 0, (A, S)
+    assert found >= 6, found
+
+
+def test_search_u8_and_degenerate_inputs():
+    amin, amax = -60000, 70000
+    r = search(3.25, 0.0031, amin, amax, u8=True)      # u8: the reference's own domain, no +128
+    assert r is not None
+    acc = np.arange(amin, amax + 1, dtype=np.int64)
+    assert np.array_equal(ref_numpy(f32(3.25), f32(0.0031), acc, 0), fma_numpy(*r, acc))
+    assert search(1.0, 0.0, -100, 100) is None              # S must be positive and normal
+    assert search(1.0, -0.01, -100, 100) is None
+    assert search(float("nan"), 0.01, -100, 100) is None
+    assert search(1.0, float("inf"), -100, 100) is None
+    assert search(1.0, 0.01, -(1 << 22), 100) is None       # outside the bit-pattern accumulators
+    # a narrow reachable range: few steps, a solution with a small pivot
+    assert search(-20.0, 0.02, -50, 50) is not None
+
+
+def test_a_perturbed_constant_is_not_accepted_by_the_host_check(O):
+    """negative control of the host-side exhaustive check: nudging C' by a few f32 steps must move a step somewhere"""
+    L = _lib().lib()
+    bad = C.c_uint64(0)
+    caught = tried = 0
+    for op, c, A, S in person_detect_channels(O, ops=(2, 6, 12), per_op=4):
+        amin, amax = full_range(A, S)
+        r = search(A, S, amin, amax)
+        if r is None:
+            continue
+        s3, c3, d = r
+        for k in (-64, 64):
+            c_bad = f32(np.int32(np.float32(c3).view(np.int32) + k).view(np.float32))
+            _lib().check(L.mf_fma_epilogue_check_host(C.c_float(A), C.c_float(S), 0, amin, amax, C.c_float(s3), C.c_float(c_bad), d,
+                                                      C.byref(bad)))
+            tried += 1
+            caught += bad.value > 0
+    assert tried >= 8 and caught == tried, (caught, tried)
+
+
+# ------------------------------------------------------------------------------------------------------- GPU
+@pytest.mark.gpu
+def test_cvt_pk_u8_f32_is_what_the_search_assumes():
+    bad = C.c_uint64(1)
+    _lib().check(_lib().lib().mf_selftest_cvt_pk(0, C.byref(bad)))
+    assert bad.value == 0  # all 2^32 inputs: truncation toward zero, saturation to [0, 255], NaN -> 0, the other bytes kept
+
+
+@pytest.mark.gpu
+def test_device_confirms_the_host_and_catches_a_wrong_constant(O):
+    """the gate the library itself uses at mf_*_create: the kernels' own requant_pack4<3> on every accumulator of the range"""
+    L = _lib().lib()
+    bad = C.c_uint64(1)
+    n = 0
+    for op, c, A, S in person_detect_channels(O, per_op=3):
+        amin, amax = full_range(A, S)
+        r = search(A, S, amin, amax)
+        if r is None:
+            continue
+        s3, c3, d = r
+        _lib().check(L.mf_selftest_fma_epilogue(0, C.c_float(A), C.c_float(S), 0, amin, amax, C.c_float(s3), C.c_float(c3), d, C.byref(bad)))
+        assert bad.value == 0, (op, c, float(A), float(S), bad.value)
+        c_bad = f32(np.int32(np.float32(c3).view(np.int32) + 48).view(np.float32))
+        _lib().check(L.mf_selftest_fma_epilogue(0, C.c_float(A), C.c_float(S), 0, amin, amax, C.c_float(s3), C.c_float(c_bad), d, C.byref(bad)))
+        assert bad.value > 0, (op, c)                         # negative control: a perturbed C' is caught
+        # and the host's evaluator agrees with the device on how many accumulators the wrong constant moves
+        hb = C.c_uint64(0)
+        _lib().check(L.mf_fma_epilogue_check_host(C.c_float(A), C.c_float(S), 0, amin, amax, C.c_float(s3), C.c_float(c_bad), d, C.byref(hb)))
+        assert hb.value == bad.value, (op, c, hb.value, bad.value)
+        n += 1
+    assert n >= 20
+    r = search(3.25, 0.0031, -60000, 70000, u8=True)
+    _lib().check(L.mf_selftest_fma_epilogue(0, C.c_float(3.25), C.c_float(0.0031), 1, -60000, 70000, C.c_float(r[0]), C.c_float(r[1]), r[2], C.byref(bad)))
+    assert bad.value == 0
+
+
+@pytest.mark.gpu
+def test_person_detect_launch_modes_and_parity(O):
+    """which launches of the fused step take the single-fma form, and that the step stays bit-exact at every layer"""
+    import microflow_rs_amd as mf
+    from tests.synth import synth_i8
+    m = mf.Model(model_path("person_detect"))
+    m.prepare(64)
+    modes = {i: m.op_epilogue_mode(i) for i in range(m.num_ops)}
+    if not ROUTING_SWITCHED:
+        assert m.op(0)["kernel"].startswith("penta_rr") and modes[0] == 3      # ops 0..4: every channel of all five operators
+        assert m.op(5)["kernel"].startswith("quad_rr") and modes[5] == 3       # ops 5..8
+        assert modes[11] == 3                                                  # ops 11..12
+        assert modes[9] == 2                                                   # op 10 has a channel whose steps are not a line's
+    om = O.Model(model_path("person_detect"))
+    x = synth_i8(3, 0, 64, om.in_elems)
+    x[0] = -128
+    x[1] = 127
+    got = m.run_quantized(x)
+    want = om.run_quantized_batch(x)
+    assert np.array_equal(np.asarray(got).reshape(want.shape), want)
+    for last in (0, 2, 4, 6, 8, 10, 12, 22, 24, 26):
+        lay = m.run_until(x[:8], last)
+        for b in range(8):
+            _, outs = om.run_quantized(x[b], layers=True)
+            assert np.array_equal(np.asarray(lay[b]).reshape(-1), outs[last].reshape(-1)), (last, b)
+    m.set_fusion(False)                                     # layer-wise: dw3x3_mm / pw_mfma / the stem in mode 3 where they have it
+    got = m.run_quantized(x)
+    assert np.array_equal(np.asarray(got).reshape(want.shape), want)
+
+
+_CHILD = r"""
+import sys, numpy as np
+sys.path.insert(0, {root!r})
+import microflow_rs_amd as mf
+from tests.synth import synth_i8
+for name, cfg, n in (("person_detect", 3, 4099), ("speech", 2, 257)):
+    m = mf.Model({root!r} + "/models/" + name + ".tflite")
+    m.prepare(n)
+    x = synth_i8(cfg, 0, n, m.input_elems)
+    y = np.asarray(m.run_quantized(x))
+    from microflow_rs_amd.synth import layer_checksum
+    print(name, m.op_epilogue_mode(0), int(layer_checksum(y.view(np.int8) if y.dtype != np.int8 else y)))
+"""
+
+
+@pytest.mark.gpu
+def test_switching_the_form_off_changes_no_byte():
+    """MF_NO_FMA_EPI=1 (every operator on the two-rounding forms) in a child process: the same outputs, different modes"""
+    outs = []
+    for env_extra in ({}, {"MF_NO_FMA_EPI": "1"}):
+        env = dict(os.environ)
+        env.pop("MF_NO_FMA_EPI", None)
+        env.update(env_extra)
+        r = subprocess.run([sys.executable, "-c", _CHILD.format(root=ROOT)], env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append([l.split() for l in r.stdout.strip().splitlines()])
+    a, b = outs
+    assert [l[0] for l in a] == [l[0] for l in b] == ["person_detect", "speech"]
+    assert [l[2] for l in a] == [l[2] for l in b]          # checksums
+    if not ROUTING_SWITCHED:
+        assert a[0][1] == "3" and b[0][1] in ("1", "2")
