@@ -568,7 +568,7 @@ int mf_fma_epilogue_search(float A, float S, int is_u8, long long acc_min, long 
     MF_TRY({
         MF_NEED(S_out && C_out && pivot_out && found);
         mf::FmaForm f;
-        *found = mf::fma_form_search(A, S, is_u8 ? 0 : 128, is_u8 ? 0 : -128, is_u8 ? 255 : 127, acc_min, acc_max, false, false, f) ? 1 : 0;
+        *found = mf::fma_form_search(A, S, is_u8 ? 0 : 128, is_u8 ? 0 : -128, is_u8 ? 255 : 127, acc_min, acc_max, f) ? 1 : 0;
         *S_out = f.S, *C_out = f.C, *pivot_out = f.d;
     })
 }

@@ -6,24 +6,27 @@
 // operator can produce is bit-identical to it, and the cheapest one the VALU offers is
 //
 //     x = v_fma_f32(S', F, C')                 F = the accumulator's own bit pattern read as f32 = 1.5 * 2^23 + acc + d
-//     y = v_cvt_pk_u8_f32(x)                   truncate toward zero, saturate to [0, 255]  (u8 domain: i8 results are y ^ 0x80)
+//     y = v_cvt_pk_u8_f32(x)                   saturate to [0, 255]  (u8 domain: i8 results are y ^ 0x80)
 //
-// two instructions per byte instead of six.  Per channel the host looks for (S', C', d) -- S' within a few ulps of S, an integer
-// pivot d folded into the accumulator's start value, C' an f32 -- whose staircase has exactly the reference's steps:
-//   1. the reference's steps T_k (first accumulator whose output is >= k) inside the reachable accumulator range [-B, B] are found
-//      by bisection on the exact two-rounding form (monotone: every f32 operation in it is);
-//   2. in real arithmetic x = s * acc + e reproduces them iff  e in [max_k (k - s T_k), min_k (k - s (T_k - 1)))  -- the width w(s)
-//      of that interval is evaluated for the f32 neighbours of S and the widest few are kept;
+// both executed with the f32 rounding mode TOWARD ZERO (the kernel sets MODE.FP_ROUND on entry, k_common.hpp epi_enter; both
+// instructions follow it -- measured over all 2^32 inputs, scripts/ubench/cvt_pk_probe.hip): x = RZ(S' F + C') and y = trunc(x),
+// together y = floor(S' F + C') of the EXACT real value, clamped.  Two instructions per byte instead of six.  Per channel the host
+// looks for (S', C', d) -- S' within a few ulps of S, an integer pivot d folded into the accumulator's start value, C' an f32 --
+// whose staircase has exactly the reference's steps:
+//   1. the reference's steps T_k (first accumulator whose output is >= k) inside the reachable accumulator range [amin, amax] are
+//      found by bisection on the exact two-rounding form (monotone: every f32 operation in it is);
+//   2. floor(s * acc + e) reproduces them iff  e in [max_k (k - s T_k), min_k (k - s (T_k - 1)))  -- the width w(s) of that
+//      interval is evaluated, exactly, for the f32 neighbours of S and the candidates are tried widest first;
 //   3. e = C' + s * (1.5 * 2^23 + d) must hit the interval with C' an f32 of magnitude ~ s * 2^23 (ulp 2^-4 .. 2^-11, far coarser
 //      than w): the pivot d supplies the fraction -- s * d mod ulp(C') is equidistributed, so one d in ulp / w works;
-//   4. every candidate is then checked EXACTLY (std::fmaf = the device's v_fma_f32: one rounding) at the 2 x 255 accumulators that
-//      decide the steps: T_k must give >= k, T_k - 1 must give < k.  With monotonicity of both maps that is equality on the
-//      whole range, not a sample.
+//   4. every candidate is then checked with the instructions emulated at the 2 x 255 accumulators that decide the steps: T_k must
+//      give >= k, T_k - 1 must give < k.  With monotonicity of both maps that is equality on the whole range, not a sample.
 // What the host proves here the device re-checks exhaustively, accumulator by accumulator, with the real instructions
 // (k_generic.hip: verify_fma_form) before an operator is allowed to use the form; a channel without a solution keeps its operator
-// (and every fused launch the operator is part of) on the two-rounding forms.
+// (and every fused launch the operator is part of) on the two-rounding forms.  A channel has no solution when two near-ties of the
+// reference were resolved in opposite directions by ITS roundings (fl(S acc) at the grid of S acc, fl(A + .) at the grid of the
+// sum): then no line passes all 2 x 255 gaps.
 #include <algorithm>
-#include <cfenv>
 #include <cmath>
 #include <cstring>
 #include <limits>
@@ -54,37 +57,19 @@ int ref_form_eval(float A, float S, int off, int lo, int hi, int64_t acc) {
     return y + off;
 }
 
-// the device's form, instruction by instruction
+// the device's form: trunc(RZ_f32(S F + C)) = floor of the exact value for positive values (every integer below 2^24 is an f32, so
+// rounding toward zero to f32 never crosses one), 0 for negative ones and NaN, 255 from 255 on.  S F is exact in double (24 x 24
+// bits) and so is the sum: both terms are multiples of ulp(S) * 1 or ulp(C) -- at least 2^-60 for any S that gives a staircase --
+// and the sum is below 2^9 wherever its value matters (a sum outside [0, 256) saturates whatever its low bits are).
 int fma_form_eval(const FmaForm &f, int64_t acc) {
-    const float F = (float)(M0 + acc + (int64_t)f.d); // an integer in [2^23, 2^24): exact, and what the bit pattern 0x4B400000 + acc + d reads as
-    float x;
-    if (f.rz) { // the kernel runs with FP_ROUND = toward zero (s_setreg MODE)
-        const int old = fegetround();
-        fesetround(FE_TOWARDZERO);
-        volatile float vs = f.S, vF = F, vC = f.C;
-        volatile float r = std::fmaf(vs, vF, vC);
-        fesetround(old);
-        x = r;
-    } else {
-        x = std::fmaf(f.S, F, f.C); // v_fma_f32: one rounding
-    }
-    // v_cvt_pk_u8_f32: truncation toward zero, saturation to [0, 255], NaN -> 0
-    int y = !(x > 0.0f) ? 0 : (x >= 255.0f ? 255 : (int)x);
-    return f.neg ? 255 - y : y; // neg: the form computes 255 - y with a negative slope; the XOR that returns to the stored domain is 0xff ^ ...
+    const double F = (double)(M0 + acc + (int64_t)f.d); // an integer in [2^23, 2^24): what the bit pattern 0x4B400000 + acc + d reads as
+    const double v = std::fma((double)f.S, F, (double)f.C);
+    if (!(v >= 1.0)) return 0;
+    if (v >= 255.0) return 255;
+    return (int)std::floor(v);
 }
 
-namespace {
-// spacing of the f32 values just below the positive integer k (k <= 256): ulp(pred(k))
-inline double grid_below(int k) {
-    int m = 0;
-    while ((1 << (m + 1)) < k) ++m; // 2^m < k <= 2^(m+1)   (k = 1: m = 0 -> handled below)
-    if (k <= 1) return std::ldexp(1.0, -24);
-    return std::ldexp(1.0, m - 23);
-}
-} // namespace
-
-bool fma_form_search(float A, float S, int off, int lo, int hi, int64_t amin, int64_t amax, bool neg, bool rz, FmaForm &out,
-                     FmaSearchStats *st) {
+bool fma_form_search(float A, float S, int off, int lo, int hi, int64_t amin, int64_t amax, FmaForm &out, FmaSearchStats *st) {
     if (st) *st = FmaSearchStats{};
     if (!std::isfinite(A) || !std::isfinite(S) || !(S > 0.0f) || std::fpclassify(S) != FP_NORMAL) return false;
     if (amin > amax || amin <= -(1 << 22) || amax >= (1 << 22) - 1 || lo > hi) return false;
@@ -107,12 +92,10 @@ bool fma_form_search(float A, float S, int off, int lo, int hi, int64_t amin, in
         upper.push_back({h - 1, k});
     }
     if (st) st->steps = yN - y0;
-    // --- 2. the EXACT window of e.  With v = s acc + e (real numbers; every product and sum below is exact in double):
-    //   plain form:   x = RN(v),            y = trunc(x):         y >= k  <=>  v >= k - g(k)/2   (RN; the tie goes to the even k)   or  v >= k (RZ)
-    //   negated form: x' = RN(256 - v),     y = 255 - trunc(x'):  y >= k  <=>  x' < 256 - k  <=>  256 - v < (256 - k) - g(256 - k)/2   <=>  v > k + g(256 - k)/2   (RZ: v > k)
-    // g(j) = the spacing of the floats just below j.
+    // --- 2. the EXACT window of e: with v = s acc + e (real numbers; every product and sum below is exact in double) the form gives
+    // y >= k  <=>  floor(v) >= k  <=>  v >= k, for k = 1 .. 255 -- one comparison per step, no grid or tie effects.
     double th[257];
-    for (int k = 1; k <= 256; ++k) th[k] = rz ? (double)k : (neg ? (double)k + 0.5 * grid_below(256 - k + (k == 256 ? 1 : 0)) : (double)k - 0.5 * grid_below(k));
+    for (int k = 0; k <= 256; ++k) th[k] = (double)k;
     const double INF = std::numeric_limits<double>::infinity();
     auto window = [&](float s, double &elo, double &ehi) {
         elo = -INF, ehi = INF;
@@ -123,14 +106,14 @@ bool fma_form_search(float A, float S, int off, int lo, int hi, int64_t amin, in
     };
     struct Cand { float s; double elo, ehi; };
     std::vector<Cand> cands;
-    constexpr int J = 64;
-    for (int j = -J; j <= J; ++j) {
-        const float s = next_up(S, j);
-        if (!(s > 0.0f) || std::fpclassify(s) != FP_NORMAL) continue;
-        double elo, ehi;
-        window(s, elo, ehi);
-        if (ehi > elo) cands.push_back({s, elo, ehi});
-    }
+    for (int J = 8; J <= 64 && cands.empty(); J *= 8) // S itself and its neighbours; further out only when those have no window
+        for (int j = -J; j <= J; ++j) {
+            const float s = next_up(S, j);
+            if (!(s > 0.0f) || std::fpclassify(s) != FP_NORMAL) continue;
+            double elo, ehi;
+            window(s, elo, ehi);
+            if (ehi > elo) cands.push_back({s, elo, ehi});
+        }
     if (st) st->s_candidates = (int)cands.size();
     if (cands.empty()) return false;
     std::sort(cands.begin(), cands.end(), [](const Cand &a, const Cand &b) { return (a.ehi - a.elo) > (b.ehi - b.elo); });
@@ -154,13 +137,10 @@ bool fma_form_search(float A, float S, int off, int lo, int hi, int64_t amin, in
         for (int64_t i = 0; i < budget; ++i) {
             const int64_t d = (i & 1) ? (i + 1) / 2 : -(i / 2);
             if (d > dhi || d < dlo) continue;
-            // plain:   x = s F + C,            e = C + s (M0 + d)
-            // negated: x' = -s F + C = 256 - v, e = 256 - C + s (M0 + d)
-            const double sN = s * (double)(M0 + d);   // 24 x 25 bits: exact in double
-            const double t = neg ? 256.0 - emid + sN : emid - sN;
+            const double t = emid - s * (double)(M0 + d); // x = s F + C, e = C + s (M0 + d); the product is 24 x 25 bits: exact in double
             const float C = (float)t;
             if (!(std::fabs((double)C - t) < 0.499 * w)) continue;
-            const FmaForm f{neg ? -c.s : c.s, C, (int32_t)d, neg, rz};
+            const FmaForm f{c.s, C, (int32_t)d};
             ++exact_tries;
             if (exact_ok(f)) {
                 out = f;

@@ -65,9 +65,10 @@ constexpr int MF_MAGIC_I = 0x4B400000;
 //   2  = 1, and the clamp [lo, hi] is exactly the element type's range and |x| < 2^15 for every input, so that the
 //      clamp is done by a saturating pack (v_sat_pk_u8_i16) instead of v_med3_f32 (requant_pack4 below)
 //   3  the single-fma form: the host found, per channel, (S', C', d) whose staircase  acc -> v_cvt_pk_u8_f32(v_fma_f32(S', F, C'))
-//      equals the reference's on every accumulator the operator can produce (epi_fma.cpp: search; k_generic.hip
-//      verify_fma_form: exhaustive check on the device).  The kernels then receive C' in place of A, S' in place of S and
-//      Kc + d in place of Kc; the clamp is the element type's whole range (the conversion saturates).  Two instructions per byte.
+//      -- both instructions executed with MODE.FP_ROUND = toward zero, which the kernel sets on entry (epi_enter) -- equals the
+//      reference's on every accumulator the operator can produce (epi_fma.cpp: search; k_generic.hip verify_fma_form: exhaustive
+//      check on the device).  The kernels then receive C' in place of A, S' in place of S and Kc + d in place of Kc; the clamp is
+//      the element type's whole range (the conversion saturates).  Two instructions per byte.
 template <int MG>
 __device__ __forceinline__ int requant_t(int acc, float A, float S, float lo_f, float hi_f) {
     static_assert(MG != 3, "the single-fma form exists for the packed epilogues only (requant_pack4)");
@@ -80,6 +81,15 @@ __device__ __forceinline__ int requant_t(int acc, float A, float S, float lo_f, 
         r = __builtin_amdgcn_fmed3f(r, lo_f, hi_f);
         return (int)r;
     }
+}
+// Mode 3 kernels run with the f32 rounding mode TOWARD ZERO for their whole life (MODE is per-wave state, initialised from the
+// kernel descriptor at every wave launch, so nothing has to be restored).  Both v_fma_f32 and v_cvt_pk_u8_f32 follow it (measured
+// over all 2^32 inputs: scripts/ubench/cvt_pk_probe.hip, mf_selftest_cvt_pk), which makes the form y = floor(S' F + C') of the
+// EXACT real value -- the step for output k sits exactly where S' F + C' reaches k, with no grid or tie effects of its own.  (In
+// the default mode the conversion rounds half to even and the steps of odd and even k shift against each other by an f32
+// spacing: fewer channels have a solution.)  Such a kernel must contain no other f32 arithmetic that needs round-to-nearest.
+template <int MG> __device__ __forceinline__ void epi_enter() {
+    if constexpr (MG == 3) __builtin_amdgcn_s_setreg(0x801 /* hwreg(HW_REG_MODE, 0, 2): FP_ROUND, single precision */, 3u /* toward zero */);
 }
 template <int MG> __device__ __forceinline__ int4 magic4(int4 k) {
     if constexpr (MG != 0) k.x += MF_MAGIC_I, k.y += MF_MAGIC_I, k.z += MF_MAGIC_I, k.w += MF_MAGIC_I;
@@ -269,8 +279,8 @@ template <int MG> __device__ __forceinline__ float epi_value(int acc, float A, f
     else if constexpr (MG == 2) return requant_x<MG>(acc, A, S); // clamp = the saturating pack
     else return __builtin_amdgcn_fmed3f(requant_x<MG>(acc, A, S), lo_f, hi_f);
 }
-// MG == 3: truncation toward zero + saturation to [0, 255] + byte insert in one instruction per value (VOP3, whole-dword
-// write: no SDWA hazard, free for the compiler to schedule)
+// MG == 3: conversion in the current rounding mode (toward zero: truncation) + saturation to [0, 255] + byte insert in one
+// instruction per value (VOP3, whole-dword write: no SDWA hazard, free for the compiler to schedule)
 __device__ __forceinline__ uint32_t cvtpk_pack4(float r0, float r1, float r2, float r3) {
     uint32_t d = __builtin_amdgcn_cvt_pk_u8_f32(r0, 0u, 0u);
     d = __builtin_amdgcn_cvt_pk_u8_f32(r1, 1u, d);

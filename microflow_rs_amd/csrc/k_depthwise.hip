@@ -317,6 +317,8 @@ __global__ __launch_bounds__(256) void dw3x3_stem8(const int8_t *__restrict__ in
 template <int H, int W, int G, int MG, uint32_t XR4, bool F32IN>
 __global__ __launch_bounds__(256) void dw3x3_stem8_mm(const int8_t *__restrict__ in, int8_t *__restrict__ out, DwStemArgs p,
                                                       int batch) {
+    static_assert(!(F32IN && MG == 3), "the boundary quantisation of the f32 entry needs round-to-nearest: no single-fma epilogue there");
+    epi_enter<MG>();
     constexpr int S = 2;
     constexpr int OH = (H + S - 1) / S, OW = (W + S - 1) / S;
     constexpr int GUARD = 16;
@@ -657,10 +659,12 @@ bool launch_dw_stem(int H, int W, int DM, int S, const int8_t *in, int8_t *out, 
             const int gridm = nsteps < 256 * pcu ? nsteps : 256 * pcu;
 #define MF_STEMM(MG, XR, F) hipLaunchKernelGGL((dw3x3_stem8_mm<96, 96, G, MG, XR, F>), dim3(gridm), dim3(256), lds, s, in, out, a, batch)
 #define MF_STEMM2(F)                                                                               \
-    if (a.magic == 3) MF_STEMM(3, 0u, F); else                                                     \
     if (a.xr) { if (a.magic == 2) MF_STEMM(2, 0x80808080u, F); else if (a.magic) MF_STEMM(1, 0x80808080u, F); else MF_STEMM(0, 0x80808080u, F); } \
     else { if (a.magic == 2) MF_STEMM(2, 0u, F); else if (a.magic) MF_STEMM(1, 0u, F); else MF_STEMM(0, 0u, F); }
-            if (f32_input) { MF_STEMM2(true) } else { MF_STEMM2(false) }
+            if (a.magic == 3) { // (the caller asks for the single-fma form only with int8 input: ops.hip)
+                if (f32_input) return false;
+                MF_STEMM(3, 0u, false);
+            } else if (f32_input) { MF_STEMM2(true) } else { MF_STEMM2(false) }
 #undef MF_STEMM2
 #undef MF_STEMM
             return true;

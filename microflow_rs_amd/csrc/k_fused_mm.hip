@@ -59,6 +59,7 @@ template <int H, int W, int C, int S, int N, int G, int NTHR, bool DBUF, int CG,
           int WPE, int MG, uint32_t XR4, bool DWONLY>
 __global__ __launch_bounds__(NTHR, WPE) void dwpw_mm(const int8_t *__restrict__ in, int8_t *__restrict__ out, DwPwArgs p,
                                                 int batch) {
+    epi_enter<MG>();
     // ---- depthwise geometry ----
     constexpr bool PAIR = C == 8;                 // MFMA column = two adjacent output pixels
     constexpr int OH = (H + S - 1) / S, OW = (W + S - 1) / S;
@@ -390,6 +391,7 @@ template <int H, int W, int C, int S, int N, int G, int NTHR, int DB, int CG, in
           int WPE, int MG, uint32_t XR4>
 __global__ __launch_bounds__(NTHR, WPE) void dwpw_rr(const int8_t *__restrict__ in, int8_t *__restrict__ out, DwPwArgs p,
                                                      int batch) {
+    epi_enter<MG>();
     constexpr bool PAIR = C == 8;
     // DB: 0 one staging buffer, 1 two.  (A dedicated loader wave -- the only wave that waits for the DMAs, so that the
     // compute waves' `s_waitcnt vmcnt(0)` never waits for their own output stores -- was measured: no gain.)

@@ -463,31 +463,46 @@ __global__ __launch_bounds__(256) void selftest_requant_kernel(float A, float S,
 }
 // ---- the gate of epilogue mode 3 (k_common.hpp; host search: epi_fma.cpp) ----
 // For every channel c of an operator and EVERY accumulator the channel can produce, acc in [amin[c], amax[c]]: the byte the kernels'
-// own requant_pack4<3> stores (v_fma_f32 on the accumulator's bit pattern with the pivot folded in, v_cvt_pk_u8_f32, XOR) against the
-// reference's two-rounding tail (requant_any: v_cvt_f32_i32, v_mul, v_add, roundf, clamp, truncating convert).  bad[c] counts the
-// mismatches; the operator may use the form only if all of them are zero.  blockIdx.y = channel.
+// own requant_pack4<3> stores (v_fma_f32 on the accumulator's bit pattern with the pivot folded in, v_cvt_pk_u8_f32, XOR; executed
+// in round-toward-zero as in the kernels) against the reference's two-rounding tail (requant_any: v_cvt_f32_i32, v_mul, v_add,
+// roundf, clamp, truncating convert; executed in the default round-to-nearest).  bad[c] counts the mismatches; the operator may use
+// the form only if all of them are zero.  blockIdx.y = channel.
+// The two halves of an iteration run in different rounding modes.  The compiler does not model MODE, so each half is fenced by
+// data: its inputs come out of a volatile asm placed after the mode switch, its results go into one placed before the next.
+__device__ __forceinline__ void fp_round_mode(uint32_t m) {
+    if (m) asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3\n\ts_nop 3" ::: "memory");
+    else asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0\n\ts_nop 3" ::: "memory");
+}
 __global__ __launch_bounds__(256) void verify_fma_form_kernel(const float *A, const float *S, const float *C3, const float *S3, const int *piv,
                                                              const int *amin, const int *amax, float lo, float hi, uint32_t xr,
                                                              unsigned long long *bad) {
     const int c = blockIdx.y;
-    const float a_ = A[c], s_ = S[c], c3 = C3[c], s3 = S3[c];
+    float a_ = A[c], s_ = S[c], c3 = C3[c], s3 = S3[c];
     const int d = piv[c];
     const long long a0 = amin[c], a1 = amax[c];
-    const float4 c4 = make_float4(c3, c3, c3, c3), s4 = make_float4(s3, s3, s3, s3);
     unsigned cnt = 0;
     for (long long base = a0 + 4ll * ((long long)blockIdx.x * 256 + threadIdx.x); base <= a1; base += 4ll * gridDim.x * 256) {
-        int bits[4];
+        int av[4], bits[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) av[k] = (int)(base + k <= a1 ? base + k : a1); // (the tail repeats the last accumulator)
+        // reference half: round to nearest
+        fp_round_mode(0);
+        asm volatile("" : "+v"(av[0]), "+v"(av[1]), "+v"(av[2]), "+v"(av[3]), "+v"(a_), "+v"(s_));
         uint32_t want = 0;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const long long a = base + k <= a1 ? base + k : a1; // (the tail repeats the last accumulator)
-            bits[k] = MF_MAGIC_I + (int)a + d;
-            want |= (((uint32_t)requant_any((int)a, a_, s_, lo, hi) & 0xffu) ^ xr) << (8 * k);
-        }
-        const uint32_t got = requant_pack4<3, 0u>(bits[0], bits[1], bits[2], bits[3], c4, s4, lo, hi);
+        for (int k = 0; k < 4; ++k) want |= (((uint32_t)requant_any(av[k], a_, s_, lo, hi) & 0xffu) ^ xr) << (8 * k);
+        asm volatile("" : "+v"(want));
+        // the form's half: toward zero
+        fp_round_mode(3);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) bits[k] = MF_MAGIC_I + av[k] + d;
+        asm volatile("" : "+v"(bits[0]), "+v"(bits[1]), "+v"(bits[2]), "+v"(bits[3]), "+v"(c3), "+v"(s3));
+        uint32_t got = requant_pack4<3, 0u>(bits[0], bits[1], bits[2], bits[3], make_float4(c3, c3, c3, c3), make_float4(s3, s3, s3, s3), lo, hi);
+        asm volatile("" : "+v"(got));
         const uint32_t df = got ^ want;
         cnt += (df & 0xffu ? 1 : 0) + (df & 0xff00u ? 1 : 0) + (df & 0xff0000u ? 1 : 0) + (df & 0xff000000u ? 1 : 0);
     }
+    fp_round_mode(0);
     if (cnt) atomicAdd(bad + c, (unsigned long long)cnt);
 }
 // all pointers are DEVICE arrays of n entries (bad: zeroed by the caller); returns false when the launch failed
@@ -496,14 +511,27 @@ bool verify_fma_form(const float *A, const float *S, const float *C3, const floa
     hipLaunchKernelGGL(verify_fma_form_kernel, dim3(64, n), dim3(256), 0, s, A, S, C3, S3, piv, amin, amax, lo, hi, u8 ? 0x80u : 0u, bad);
     return hipGetLastError() == hipSuccess;
 }
-// v_cvt_pk_u8_f32 itself, over all 2^32 bit patterns, against what epi_fma.cpp assumes of it: truncation toward zero,
-// saturation to [0, 255], NaN -> 0, the other three bytes of the destination untouched
-__global__ __launch_bounds__(256) void selftest_cvt_pk_kernel(unsigned long long *bad) {
+// v_cvt_pk_u8_f32 itself, over all 2^32 bit patterns, against what epi_fma.cpp assumes of it (in integer arithmetic, so that the
+// model does not depend on the mode it is checked in): RZ = 1, the kernels' mode: truncation toward zero; RZ = 0, the default mode:
+// round half to even; either way saturation to [0, 255], NaN -> 0, the other three bytes of the destination untouched
+__device__ __forceinline__ uint32_t cvt_pk_model(float x, bool trunc_) {
+    if (!(x > 0.0f)) return 0u; // (comparisons are exact in every mode)
+    if (x >= 256.0f) return 255u;
+    const uint32_t b = __float_as_uint(x), e = b >> 23, man = (b & 0x7fffffu) | 0x800000u;
+    if (e < 126) return 0u;     // x < 0.5
+    const int sh = 150 - (int)e; // x = man 2^-sh, sh in 16 .. 24
+    const uint32_t ip = man >> sh, frac = man & ((1u << sh) - 1u), half = 1u << (sh - 1);
+    uint32_t r = ip;
+    if (!trunc_) r += (frac > half || (frac == half && (ip & 1u))) ? 1u : 0u;
+    return r > 255u ? 255u : r;
+}
+template <int RZ> __global__ __launch_bounds__(256) void selftest_cvt_pk_kernel(unsigned long long *bad) {
+    if (RZ) __builtin_amdgcn_s_setreg(0x801, 3u);
     const unsigned long long stride = (unsigned long long)gridDim.x * 256;
     unsigned cnt = 0;
     for (unsigned long long b = (unsigned long long)blockIdx.x * 256 + threadIdx.x; b < (1ull << 32); b += stride) {
         const float x = __uint_as_float((uint32_t)b);
-        const uint32_t want = !(x > 0.0f) ? 0u : (x >= 255.0f ? 255u : (uint32_t)(int)x);
+        const uint32_t want = cvt_pk_model(x, RZ != 0);
         const uint32_t sel = (uint32_t)b & 3u, keep = 0xA5C3F17Eu;
         uint32_t got;
         switch (sel) { // (the byte selector is an immediate in the kernels)
@@ -556,8 +584,11 @@ unsigned long long selftest_rounding(int mode, bool u8, float lo, float hi, hipS
         }
     });
 }
-unsigned long long selftest_cvt_pk(hipStream_t s) {
-    return run_selftest(s, [&](unsigned long long *d) { hipLaunchKernelGGL(selftest_cvt_pk_kernel, dim3(256 * 16), dim3(256), 0, s, d); });
+unsigned long long selftest_cvt_pk(hipStream_t s) { // both modes in one count
+    return run_selftest(s, [&](unsigned long long *d) {
+        hipLaunchKernelGGL(selftest_cvt_pk_kernel<1>, dim3(256 * 16), dim3(256), 0, s, d);
+        hipLaunchKernelGGL(selftest_cvt_pk_kernel<0>, dim3(256 * 16), dim3(256), 0, s, d);
+    });
 }
 unsigned long long selftest_requant(int mode, bool u8, float A, float S, float lo, float hi, hipStream_t s) {
     return run_selftest(s, [&](unsigned long long *d) {

@@ -42,6 +42,7 @@ template <int K, int N, int MG, uint32_t XR4>
 __global__ __launch_bounds__(256) void pw_mfma(const int8_t *__restrict__ in,
                                                int8_t *__restrict__ out, PwArgs p,
                                                long long npix) {
+    epi_enter<MG>();
     constexpr int NB = N < 64 ? N : 64;        // channels per wave block
     constexpr int TB = NB / 16;                // 16-channel MFMA tiles per block
     constexpr int NSPLIT = N / NB;             // waves sharing one pixel chunk

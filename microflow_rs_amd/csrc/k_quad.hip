@@ -316,6 +316,7 @@ template <typename Q, bool STEM, int MG, uint32_t XR4>
 __global__ __launch_bounds__(Q::NTHR, Q::WPE) void quad_rr(const int8_t *__restrict__ in, int8_t *__restrict__ out, QuadArgs p, int batch) {
     using GA = typename Q::A;
     using GB = typename Q::B;
+    epi_enter<MG>();
     constexpr int G = Q::G, NTHR = Q::NTHR, NWAVE = NTHR / 64;
     constexpr int BUF_A = G * GA::TILE, OFF_B = BUF_A + 512, BUF_B = G * GB::TILE, OFF_S = OFF_B + BUF_B + 512;
     constexpr int S_GUARD = 16, SW = 2 * GA::W, SH = 2 * GA::H, S_TILE = quad_stem_bytes<Q, STEM>(), OFF_Q = OFF_S + S_TILE;

@@ -73,6 +73,7 @@ template <int G, int NTHR, int MG, uint32_t XR4>
 __global__ __launch_bounds__(NTHR, 4) void stage_6x6x128(const int8_t *__restrict__ in, int8_t *__restrict__ out, StageArgs p,
                                                          int batch) {
     static_assert(G == 4 && NTHR == 512, "the column grid below is written for 4 images and 8 waves");
+    epi_enter<MG>();
     // any number of pairs >= 2: the MID buffers alternate so that the LAST pair uses region B and finds region A free for
     // its plain output
     const int NREP = p.nrep, par = (NREP & 1) ^ 1;

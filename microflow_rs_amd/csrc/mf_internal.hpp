@@ -47,8 +47,6 @@ void h_preprocess_pool(float iscale, int izp, float oscale, int ozp, float *c0, 
 struct FmaForm {
     float S = 0, C = 0;
     int32_t d = 0;
-    bool neg = false; // the negated variant: S < 0, the form yields 255 - y
-    bool rz = false;  // evaluated with FP_ROUND = toward zero
 };
 struct FmaSearchStats {
     int steps = 0;            // steps of the reference staircase inside the reachable accumulator range
@@ -59,7 +57,7 @@ struct FmaSearchStats {
 };
 // off: 128 (i8: the form works in the u8 domain, results are XOR-ed back) or 0 (u8); [lo, hi]: the clamp in T's domain;
 // [amin, amax]: the accumulators this channel can produce (inside (-2^22, 2^22)).  false: no (S', C', d) reproduces the reference on it.
-bool fma_form_search(float A, float S, int off, int lo, int hi, int64_t amin, int64_t amax, bool neg, bool rz, FmaForm &out, FmaSearchStats *stats = nullptr);
+bool fma_form_search(float A, float S, int off, int lo, int hi, int64_t amin, int64_t amax, FmaForm &out, FmaSearchStats *stats = nullptr);
 int ref_form_eval(float A, float S, int off, int lo, int hi, int64_t acc); // the reference's tail, u8 domain
 int fma_form_eval(const FmaForm &f, int64_t acc);                          // the device's instructions, emulated exactly
 uint64_t fma_form_mismatches(float A, float S, int off, int lo, int hi, int64_t amin, int64_t amax, const FmaForm &f); // exhaustive, host

@@ -427,7 +427,7 @@ OpImpl *op_create(int device, const OpSpec &spec) {
             for (int c = 0; c < s.N && ok; ++c) {
                 FmaForm f;
                 const auto &r = acc_range_c[(size_t)c];
-                ok = fma_form_search(A[(size_t)c], S[(size_t)c], s.u8 ? 0 : 128, lo, hi, r.first, r.second, false, false, f);
+                ok = fma_form_search(A[(size_t)c], S[(size_t)c], s.u8 ? 0 : 128, lo, hi, r.first, r.second, f);
                 if (!ok) fail_c = c;
                 A3[(size_t)c] = f.C, S3[(size_t)c] = f.S, piv[(size_t)c] = f.d, K3[(size_t)c] = wrap_add(Kc[(size_t)c], f.d);
                 amn[(size_t)c] = (int32_t)r.first, amx[(size_t)c] = (int32_t)r.second;
@@ -996,9 +996,9 @@ void op_run_f32(OpImpl *op, const float *d_in, size_t batch, int8_t *d_out, void
     if (!d_in || !d_out) fail(MF_ERR_INVALID_ARG, "op_run_f32: null device pointer");
     if (batch > 0x7fffffffull / 4) fail(MF_ERR_INVALID_ARG, "batch too large for one launch");
     const OpSpec &sp = op->s;
-    k::DwStemArgs f3 = op->stem;
-    const bool fma = op_runs_fma(op) && f3.use_fma();
-    if (!k::launch_dw_stem(sp.H, sp.W, sp.N, sp.sh, (const int8_t *)d_in, d_out, fma ? f3 : op->stem, (int)batch,
+    // (never the single-fma epilogue here: that form runs its kernel in round-toward-zero, and this kernel's boundary quantisation
+    // needs round-to-nearest)
+    if (!k::launch_dw_stem(sp.H, sp.W, sp.N, sp.sh, (const int8_t *)d_in, d_out, op->stem, (int)batch,
                            (hipStream_t)stream, true))
         fail(MF_ERR_UNSUPPORTED, "f32 stem kernel missing");
     MF_HIP(hipGetLastError());

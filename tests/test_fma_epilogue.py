@@ -42,13 +42,24 @@ def ref_numpy(A, S, acc, off):
 
 
 def fma_numpy(s3, c3, d, acc):
-    """v_fma_f32 on the bit pattern + v_cvt_pk_u8_f32, emulated: the product and sum are exact in x87 long double
-    (24 x 24 bit product, addend within 2^40 of its last bit), ONE rounding to f32, truncation, saturation"""
-    assert np.finfo(np.longdouble).nmant >= 63
-    F = (acc + (M0 + d)).astype(np.float32)
-    assert np.all(F.astype(np.int64) == acc + M0 + d)      # the bit pattern reads as exactly this value
-    x = (np.longdouble(s3) * F.astype(np.longdouble) + np.longdouble(c3)).astype(np.float32)
-    return np.clip(np.trunc(x.astype(np.float64)), 0, 255).astype(np.int64)
+    """v_fma_f32 on the bit pattern + v_cvt_pk_u8_f32, both in round-toward-zero, emulated with exact integer arithmetic:
+    S' = ms 2^es, C' = mc 2^ec, F an integer  ->  S' F + C' = (ms F 2^(es - e0) + mc 2^(ec - e0)) 2^e0 with e0 = min(es, ec);
+    rounding that toward zero to f32 and truncating is the floor of the exact value wherever it is positive (integers below
+    2^24 are f32 values, so the first rounding never crosses one); then saturation to [0, 255]"""
+    def split(x):
+        m, e = np.frexp(np.float64(x))                     # x = m 2^e, |m| in [0.5, 1)
+        return int(m * (1 << 24)), int(e) - 24             # 24-bit integer mantissa (exact: x is an f32)
+    ms, es = split(s3)
+    mc, ec = split(c3)
+    e0 = min(es, ec)
+    assert es - e0 <= 40 and ec - e0 <= 40                 # python integers below, no overflow anyway
+    F = acc.astype(object) + (M0 + d)
+    num = F * (ms << (es - e0)) + (mc << (ec - e0))        # exact, as python ints
+    if e0 >= 0:
+        v = num * (1 << e0)
+    else:
+        v = np.array([int(n) >> (-e0) for n in num], dtype=object)   # floor division by 2^-e0 (python >> floors)
+    return np.clip(np.array(v, dtype=object), 0, 255).astype(np.int64)
 
 
 def full_range(A, S):
@@ -156,7 +167,9 @@ def test_a_perturbed_constant_is_not_accepted_by_the_host_check(O):
 def test_cvt_pk_u8_f32_is_what_the_search_assumes():
     bad = C.c_uint64(1)
     _lib().check(_lib().lib().mf_selftest_cvt_pk(0, C.byref(bad)))
-    assert bad.value == 0  # all 2^32 inputs: truncation toward zero, saturation to [0, 255], NaN -> 0, the other bytes kept
+    # all 2^32 inputs, in both rounding modes: truncation when MODE.FP_ROUND = toward zero (the mode-3 kernels), round half to even in
+    # the default mode; saturation to [0, 255], NaN -> 0, the other bytes of the destination kept
+    assert bad.value == 0
 
 
 @pytest.mark.gpu
