@@ -868,7 +868,7 @@ def runtime_geometry_record(ctx, table_layerwise):
     models = {}
     for side, width in ((128, 1.0), (64, 1.0), (96, 0.5)):
         blob = tw.person_detect_like(np.random.default_rng(side), side, width)
-        m, om = mf.model(blob), O.Model(blob)
+        m, om = mf.Model(blob, autotune=True), O.Model(blob)  # (opt-in: the chain candidates are timed at creation, mf_model_set_autotune)
         B = int(65536 * 96 * 96 / (side * side))
         m.prepare(B, device=ctx["local_rank"])
         _lib.check(L.mf_model_set_stream(m._h, torch.cuda.current_stream().cuda_stream))

@@ -51,6 +51,7 @@ _vp = C.c_void_p
 SIGNATURES = {
     "mf_last_error": (C.c_char_p, []),
     "mf_abi_version": (C.c_int, []),
+    "mf_build_info": (C.c_char_p, []),
     "mf_device_count": (C.c_int, []),
     "mf_preprocess_fully_connected": (C.c_int, [C.c_float, C.c_int8, C.c_int, _vp, C.c_int, C.c_int,
                                                 C.c_float, C.c_int8, _vp, C.c_float, C.c_int32,
@@ -101,6 +102,7 @@ SIGNATURES = {
     "mf_models_predict_quantized": (C.c_int, [C.POINTER(_vp), C.c_int, _vp, C.c_size_t, _vp]),
     "mf_model_set_generic": (C.c_int, [_vp, C.c_int]),
     "mf_model_set_fusion": (C.c_int, [_vp, C.c_int]),
+    "mf_model_set_autotune": (C.c_int, [_vp, C.c_int]),
     "mf_model_set_graph": (C.c_int, [_vp, C.c_int]),
     "mf_model_graph_launches": (C.c_ulonglong, [_vp]),
     "mf_synth_i8": (C.c_int, [C.c_int, C.c_uint64, C.c_uint64, C.c_size_t, _vp, _vp]),
@@ -160,8 +162,14 @@ def lib():
         fn = getattr(L, name)  # AttributeError here = ABI / header drift: fail loudly
         fn.restype = res
         fn.argtypes = args
-    if L.mf_abi_version() != 2:
+    if L.mf_abi_version() != 3:
         raise ImportError("libmicroflow_amd.so ABI version mismatch")
+    import re
+    info = (L.mf_build_info() or b"").decode()
+    if re.search(r"-DMF_\w*(KO|DIAG)\w*=(?!0(\s|$))", info) and not os.environ.get("MF_ALLOW_DIAG_BUILD"):
+        raise ImportError("libmicroflow_amd.so was built with knock-out / diagnostic switches (%s): its kernels are wrong on "
+                          "purpose.  Rebuild without MF_EXTRA_HIPCC_FLAGS (python microflow_rs_amd/build.py --force), or set "
+                          "MF_ALLOW_DIAG_BUILD=1 for a profiling script." % info)
     _lib = L
     return L
 

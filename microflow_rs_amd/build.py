@@ -24,7 +24,13 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
 # touched at the END of the step: hipcc otherwise broadcasts a returning atomic with v_readfirstlane right behind it, i.e. the
 # drawing wave waits for the round trip at the top of the step.  Same-box A/B, profiles/r04/dq_ab.txt: no gain -- the round
 # trip is short enough -- and the flag cost the five-operator launch 2 %.  Not kept.)
-FLAGS += os.environ.get("MF_EXTRA_HIPCC_FLAGS", "").split()  # kernel-tuning experiments (-DMF_...=n)
+EXTRA = os.environ.get("MF_EXTRA_HIPCC_FLAGS", "").split()  # kernel-tuning experiments (-DMF_...=n)
+FLAGS += EXTRA
+# Knock-out / diagnostic switches (-DMF_*_KO=n, -DMF_*_DIAG=n with n != 0) make kernels that are WRONG on purpose (profiling only).
+# Such a build says so loudly here, carries the flags inside the library (mf_build_info) and is refused by _lib.py unless
+# MF_ALLOW_DIAG_BUILD=1 is set, so that it cannot pass for the product.
+import re  # noqa: E402
+NONSHIPPING = [f for f in EXTRA if re.match(r"-DMF_\w*(KO|DIAG)\w*=(?!0$)", f)]
 
 
 # measurement tool, not product: the requantisation-rate microbenchmark bench.py runs beside its timed region
@@ -58,6 +64,9 @@ def build_ubench(force=False):
 
 
 def build(force=False, verbose=False):
+    if NONSHIPPING:
+        sys.stderr.write("\n*** microflow_rs_amd/build.py: NON-SHIPPING BUILD -- %s make kernels that are wrong on purpose. "
+                         "Rebuild without MF_EXTRA_HIPCC_FLAGS before running tests or benchmarks. ***\n\n" % " ".join(NONSHIPPING))
     build_ubench(force)
     if not force and not stale():
         return LIB
@@ -70,6 +79,8 @@ def build(force=False, verbose=False):
         obj = os.path.join(objdir, src + ".o")
         objs.append(obj)
         cmd = [cc] + FLAGS + ["-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
+        if src == "capi.cpp":
+            cmd.insert(1, '-DMF_BUILD_EXTRA="%s"' % " ".join(EXTRA).replace('"', ""))
         if verbose:
             print(" ".join(cmd))
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

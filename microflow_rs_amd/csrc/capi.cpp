@@ -44,6 +44,10 @@ extern "C" {
 
 const char *mf_last_error(void) { return mf::g_last_error.c_str(); }
 int mf_abi_version(void) { return MF_ABI_VERSION; }
+#ifndef MF_BUILD_EXTRA
+#define MF_BUILD_EXTRA ""
+#endif
+const char *mf_build_info(void) { return MF_BUILD_EXTRA; }
 int mf_device_count(void) { return mf::dev_count(); }
 
 // ---- 1. constant preparation ------------------------------------------------
@@ -439,6 +443,12 @@ int mf_model_set_generic(mf_model *model, int generic) {
     })
 }
 
+int mf_model_set_autotune(mf_model *model, int enabled) {
+    MF_TRY({
+        MF_NEED(model && model->impl);
+        mf::model_set_autotune(model->impl, enabled != 0);
+    })
+}
 int mf_model_set_fusion(mf_model *model, int enabled) {
     MF_TRY({
         MF_NEED(model && model->impl);

@@ -43,7 +43,7 @@
 
 #ifndef MF_QUAD_KO
 #define MF_QUAD_KO 0 // knock-out timing experiments (WRONG results, never shipped): 1 no depthwise requantisation, 2 no pointwise requantisation,
-                     // 4 no HBM stores, 8 no staging after the first step, 16 no barriers inside a step
+                     // 4 no HBM stores, 8 no staging after the first step, 16 no barriers inside a step, 32 one of the three tap-row LDS loads only
 #endif
 
 namespace mf {
@@ -184,7 +184,7 @@ struct RrPhase {
 #pragma unroll
             for (int q = 0; q < NQ; ++q)
 #pragma unroll
-                for (int ty = 0; ty < 3; ++ty) bq[u][q][ty] = *(const v4i *)(tb + tbase[q] + toff_of(u) + ty * Ge::ROW);
+                for (int ty = 0; ty < 3; ++ty) bq[u][q][ty] = ((MF_QUAD_KO & 32) && ty > 0) ? bq[u][q][0] : *(const v4i *)(tb + tbase[q] + toff_of(u) + ty * Ge::ROW);
 #pragma unroll
         for (int t0 = 0; t0 < NU; t0 += UB) {
             v4i acc[UB][NQ];
@@ -212,7 +212,7 @@ struct RrPhase {
                     for (int q = 0; q < NQ; ++q)
 #pragma unroll
                         for (int ty = 0; ty < 3; ++ty)
-                            bn[u][q][ty] = *(const v4i *)(tb + tbase[q] + toff_of(t0 + UB + u) + ty * Ge::ROW);
+                            bn[u][q][ty] = ((MF_QUAD_KO & 32) && ty > 0) ? bn[u][q][0] : *(const v4i *)(tb + tbase[q] + toff_of(t0 + UB + u) + ty * Ge::ROW);
             }
 #pragma unroll
             for (int u = 0; u < UB; ++u) {

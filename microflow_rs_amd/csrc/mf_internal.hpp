@@ -150,7 +150,7 @@ FusedImpl *fused_dwfc_create(OpImpl *dw, FusedImpl *fc_softmax);
 FusedImpl *fused_pair_tail_create(FusedImpl *pair, FusedImpl *tail);
 FusedImpl *fused_chain_create(FusedImpl *const *single_pair_chains, int n, int force_G = 0); // consecutive run-time-geometry pairs as one launch (k_chain.hip); force_G: images per step (0: the planner's)
 bool fused_is_chain_single(const FusedImpl *f);
-void fused_chain_partition(FusedImpl *const *single_pair_chains, int n, int *seg_len, bool *unfused, int *seg_G = nullptr); // seg_G[i]: measured images per step of the chain starting at i (0: the planner's)
+void fused_chain_partition(FusedImpl *const *single_pair_chains, int n, int *seg_len, bool *unfused, int *seg_G, bool autotune); // seg_G[i]: measured images per step of the chain starting at i (0: the planner's); autotune: time the candidates on the device instead of using the cost model
 FusedImpl *fused_quad_create(FusedImpl *pair1, FusedImpl *pair2); // two consecutive pairs in one launch (k_quad.hip)
 FusedImpl *fused_quad_stem_create(OpImpl *stem, FusedImpl *quad); // the one-input-channel stem + a quad in one launch, or nullptr
 void fused_destroy(FusedImpl *f);
@@ -189,6 +189,8 @@ void model_set_stream(ModelImpl *m, void *stream);
 void model_sync(ModelImpl *m);
 void model_set_generic(ModelImpl *m, bool generic);
 void model_set_fusion(ModelImpl *m, bool enabled);
+// before model_prepare: measure the run-time-geometry chain candidates at creation (ops.hip fused_chain_partition) instead of planning from the cost model
+void model_set_autotune(ModelImpl *m, bool enabled);
 // replay the device-resident launch sequence as a hipGraph (captured on the 2nd identical call)
 void model_set_graph(ModelImpl *m, bool enabled);
 uint64_t model_graph_launches(const ModelImpl *m);

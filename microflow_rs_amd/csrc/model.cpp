@@ -48,6 +48,7 @@ struct ModelImpl {
     };
     std::vector<Stage> stages;
     bool fusion = true;
+    bool autotune = false; // model_set_autotune: time the run-time-geometry chain candidates at creation
     size_t cap_batch = 0;
     int8_t *act[2] = {nullptr, nullptr};
     int8_t *in_q = nullptr;   // quantized input staging (host-fed or f32 path)
@@ -318,7 +319,7 @@ void model_prepare(ModelImpl *m, int device, size_t max_batch) {
             std::vector<int> seg((size_t)rn, 0);
             std::unique_ptr<bool[]> unf(new bool[(size_t)rn]);
             std::vector<int> segG((size_t)rn, 0);
-            fused_chain_partition(run.data(), rn, seg.data(), unf.get(), segG.data());
+            fused_chain_partition(run.data(), rn, seg.data(), unf.get(), segG.data(), m->autotune);
             for (int k = 0; k < rn; ++k) {
                 const size_t at = i + 2 * (size_t)k;
                 if (seg[(size_t)k] >= 2) {
@@ -356,6 +357,11 @@ void model_sync(ModelImpl *m) {
     if (!m->prepared) return;
     MF_HIP(hipSetDevice(m->device));
     MF_HIP(hipStreamSynchronize(m->stream));
+}
+
+void model_set_autotune(ModelImpl *m, bool enabled) {
+    if (m->prepared) fail(MF_ERR_INVALID_ARG, "mf_model_set_autotune: call it before mf_model_prepare");
+    m->autotune = enabled;
 }
 
 void model_set_fusion(ModelImpl *m, bool enabled) {

@@ -94,6 +94,22 @@ struct OpImpl {
     size_t rowsum_cap = 0;
     int8_t *d_ext = nullptr; // op_run_external on a u8 operator: input moved to the i8 domain
     size_t ext_cap = 0;
+    // d_rowsum and d_ext are ONE scratch each per operator, while a handle may be launched on several streams: every use waits (on
+    // the device) for the previous use's last reader and records the event again behind its own, so concurrent launches of these
+    // two paths are serialised instead of racing; growing a buffer waits for the event on the host before the free.
+    hipEvent_t scratch_ev = nullptr;
+    bool scratch_used = false;
+    void scratch_acquire(hipStream_t s, bool growing) {
+        if (!scratch_ev) MF_HIP(hipEventCreateWithFlags(&scratch_ev, hipEventDisableTiming));
+        if (scratch_used) {
+            if (growing) MF_HIP(hipEventSynchronize(scratch_ev));
+            else MF_HIP(hipStreamWaitEvent(s, scratch_ev, 0));
+        }
+    }
+    void scratch_release(hipStream_t s) {
+        MF_HIP(hipEventRecord(scratch_ev, s));
+        scratch_used = true;
+    }
 
     DevBuf d_w, d_wzp, d_A, d_S, d_Kc, d_wprep, d_wrr, d_table;
     DevBuf d_queue; // zeroed counters: the dynamic step queue of the persistent kernels launched for this operator (k_common.hpp)
@@ -792,6 +808,10 @@ OpImpl *op_create(int device, const OpSpec &spec) {
 void op_destroy(OpImpl *op) {
     if (!op) return;
     (void)hipSetDevice(op->device);
+    if (op->scratch_ev) {
+        (void)hipEventSynchronize(op->scratch_ev);
+        (void)hipEventDestroy(op->scratch_ev);
+    }
     if (op->d_rowsum) (void)hipFree(op->d_rowsum);
     if (op->d_ext) (void)hipFree(op->d_ext);
     delete op;
@@ -902,11 +922,12 @@ void op_run(OpImpl *op, const int8_t *d_in, size_t batch, int8_t *d_out, void *s
             g.lo_f = op->fc.lo_f, g.hi_f = op->fc.hi_f, g.M = (int)rows, g.N = sp.N, g.K = sp.K;
             g.xr4 = 0x01010101u * (uint32_t)op->fc.xr;
             g.rowsum = nullptr;
-            if (op->fc.wzp != 0 && k::fc_mfma_rowsum_prepass()) {
+            const bool prepass = op->fc.wzp != 0 && k::fc_mfma_rowsum_prepass();
+            if (prepass) {
+                op->scratch_acquire(s, op->rowsum_cap < rows);
                 if (op->rowsum_cap < rows) {
-                    MF_HIP(hipStreamSynchronize(s));
                     if (op->d_rowsum) (void)hipFree(op->d_rowsum);
-                    op->d_rowsum = nullptr;
+                    op->d_rowsum = nullptr, op->rowsum_cap = 0;
                     MF_HIP(hipMalloc((void **)&op->d_rowsum, rows * sizeof(int)));
                     op->rowsum_cap = rows;
                 }
@@ -914,6 +935,7 @@ void op_run(OpImpl *op, const int8_t *d_in, size_t batch, int8_t *d_out, void *s
                 g.rowsum = op->d_rowsum;
             }
             k::launch_fc_mfma(d_in, d_out, g, s);
+            if (prepass) op->scratch_release(s);
             done = true;
             break;
         }
@@ -941,15 +963,18 @@ void op_run_external(OpImpl *op, const int8_t *d_in, size_t batch, int8_t *d_out
     if (!d_in || !d_out) fail(MF_ERR_INVALID_ARG, "op_run: null device pointer");
     hipStream_t s = (hipStream_t)stream;
     const size_t n_in = batch * op->in_elems;
+    // (two scratch buffers may be in play -- d_ext here, d_rowsum inside op_run for an FC with a weight zero point -- behind one
+    // event: op_run's own acquire then waits for nothing new, its release is superseded by the one below)
+    op->scratch_acquire(s, op->ext_cap < n_in);
     if (op->ext_cap < n_in) {
-        MF_HIP(hipStreamSynchronize(s));
         if (op->d_ext) (void)hipFree(op->d_ext);
-        op->d_ext = nullptr;
+        op->d_ext = nullptr, op->ext_cap = 0;
         MF_HIP(hipMalloc((void **)&op->d_ext, n_in + 256));
         op->ext_cap = n_in;
     }
     k::launch_xor80(d_in, op->d_ext, n_in, s);
     op_run(op, op->d_ext, batch, d_out, stream);
+    op->scratch_release(s); // op_run's kernels were the last readers of d_ext
     k::launch_xor80(d_out, d_out, batch * op->out_elems, s);
     MF_HIP(hipGetLastError());
 }
@@ -1184,38 +1209,49 @@ namespace {
 // between -- and every kernel change moved them.  ~0.1 - 0.3 s per model at creation; MF_CHAIN_AUTOTUNE=0 goes back to the estimates.
 struct ChainTimer {
     hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipStream_t st = nullptr; // a private NON-BLOCKING stream: the timing neither waits for nor stalls the caller's other streams
     DevBuf a, b, c;
     size_t cap = 0;
     bool ok = false;
     explicit ChainTimer(size_t bytes) {
+        if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); st = nullptr; return; }
         if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return;
         for (DevBuf *d : {&a, &b, &c}) {
             if (hipMalloc(&d->p, bytes) != hipSuccess) { (void)hipGetLastError(); return; }
-            (void)hipMemset(d->p, 0, bytes);
+            (void)hipMemsetAsync(d->p, 0, bytes, st);
         }
-        cap = bytes, ok = hipDeviceSynchronize() == hipSuccess;
+        cap = bytes, ok = hipStreamSynchronize(st) == hipSuccess;
     }
     ~ChainTimer() {
+        if (st) (void)hipStreamSynchronize(st);
         if (e0) (void)hipEventDestroy(e0);
         if (e1) (void)hipEventDestroy(e1);
+        if (st) (void)hipStreamDestroy(st);
     }
-    template <typename F> double us(F &&launch) { // best of five after a warm-up; < 0: failed
-        launch();
-        double best = -1;
-        for (int r = 0; r < 5; ++r) {
-            if (hipEventRecord(e0, nullptr) != hipSuccess) return -1;
+    template <typename F> double us(F &&launch) { // best of five after a warm-up; < 0: failed (a throwing launch counts as failed)
+        try {
             launch();
-            if (hipEventRecord(e1, nullptr) != hipSuccess || hipEventSynchronize(e1) != hipSuccess) return -1;
-            float ms = 0;
-            if (hipEventElapsedTime(&ms, e0, e1) != hipSuccess) return -1;
-            best = best < 0 || ms * 1e3 < best ? ms * 1e3 : best;
+            double best = -1;
+            for (int r = 0; r < 5; ++r) {
+                if (hipEventRecord(e0, st) != hipSuccess) return -1;
+                launch();
+                if (hipEventRecord(e1, st) != hipSuccess || hipEventSynchronize(e1) != hipSuccess) return -1;
+                float ms = 0;
+                if (hipEventElapsedTime(&ms, e0, e1) != hipSuccess) return -1;
+                best = best < 0 || ms * 1e3 < best ? ms * 1e3 : best;
+            }
+            return best;
+        } catch (const Error &) {
+            (void)hipGetLastError();
+            failed = true;
+            return -1;
         }
-        return best;
     }
+    bool failed = false; // a launch threw: the caller drops every measurement and plans from the estimates
 };
 } // namespace
 
-void fused_chain_partition(FusedImpl *const *groups, int n, int *seg_len, bool *unfused, int *seg_G) {
+void fused_chain_partition(FusedImpl *const *groups, int n, int *seg_len, bool *unfused, int *seg_G, bool autotune_opt) {
     std::vector<k::ChainGeom> geo((size_t)n);
     for (int i = 0; i < n; ++i) {
         const std::pair<OpImpl *, OpImpl *> &m = groups[i]->chain_members[0];
@@ -1228,15 +1264,17 @@ void fused_chain_partition(FusedImpl *const *groups, int n, int *seg_len, bool *
     std::vector<char> choice_unf((size_t)n + 1, 0);
     best[(size_t)n] = 0;
     std::vector<k::ChainPair> tab((size_t)k::CHAIN_MAX);
-    static const bool autotune = [] { const char *e = getenv("MF_CHAIN_AUTOTUNE"); return !(e && e[0] == '0'); }();
+    // measuring is the CALLER's choice (mf_model_set_autotune; off by default: model creation is then deterministic, allocates no
+    // scratch and launches nothing); MF_CHAIN_AUTOTUNE=1 / =0 overrides it for scripts
+    static const int env_tune = [] { const char *e = getenv("MF_CHAIN_AUTOTUNE"); return !e ? -1 : (e[0] == '0' ? 0 : 1); }();
+    bool autotune = env_tune < 0 ? autotune_opt : env_tune != 0;
     static const bool verbose_t = getenv("MF_CHAIN_VERBOSE") != nullptr;
     static const bool tune_g = [] { const char *e = getenv("MF_CHAIN_TUNE_G"); return !(e && e[0] == '0'); }();
     // measured[i][len]: microseconds per image of the candidate (< 0: not measured); measured_unf[i]: of the pair's two operators
     std::vector<std::vector<double>> measured((size_t)n, std::vector<double>((size_t)k::CHAIN_MAX + 1, -1.0));
     std::vector<double> measured_unf((size_t)n, -1.0);
     if (autotune && n >= 1) {
-        const size_t CAP = (size_t)512 << 20; // bytes of the largest tensor of a candidate: dozens of steps per workgroup also for 2 KB images
-        ChainTimer tm(CAP);
+        const size_t CAP = (size_t)512 << 20; // upper limit of a scratch tensor: dozens of steps per workgroup also for 2 KB images
         auto tensor_bytes = [&](int i, int len) { // the largest tensor any operator of pairs i .. i + len - 1 touches, per image
             size_t m = 0;
             for (int j = i; j < i + len; ++j) {
@@ -1245,19 +1283,23 @@ void fused_chain_partition(FusedImpl *const *groups, int n, int *seg_len, bool *
             }
             return m;
         };
+        auto batch_of = [&](size_t tb) { return std::min<size_t>(CAP / std::max<size_t>(tb, 1), 262144) & ~(size_t)63; };
+        size_t need = 0; // the scratch the largest candidate needs (not a fixed 512 MB)
+        for (int i = 0; i < n; ++i)
+            for (int len = 1; len <= n - i && len <= k::CHAIN_MAX; ++len) need = std::max(need, batch_of(tensor_bytes(i, len)) * tensor_bytes(i, len));
+        ChainTimer tm(need + 256);
         for (int i = 0; i < n && tm.ok; ++i) {
             for (int len = 1; len <= n - i && len <= k::CHAIN_MAX; ++len) {
                 bool ok = true;
                 for (int j = i; j < i + len && ok; ++j)
                     ok = groups[j]->chain_members[0].first->s.u8 == groups[i]->chain_members[0].first->s.u8 && (len == 1 || groups[j]->chain_members[0].first->s.C >= 16);
                 if (!ok) break;
-                size_t B = CAP / std::max<size_t>(tensor_bytes(i, len), 1);
-                B = std::min<size_t>(B, 262144) & ~(size_t)63;
+                const size_t B = batch_of(tensor_bytes(i, len));
                 if (B < 256) continue;
-                FusedImpl *f = len == 1 ? groups[i] : fused_chain_create(groups + i, len);
+                std::unique_ptr<FusedImpl> owned(len == 1 ? nullptr : fused_chain_create(groups + i, len)); // (freed on every path)
+                FusedImpl *f = len == 1 ? groups[i] : owned.get();
                 if (!f) continue; // (no plan: longer candidates from i may still exist -- a later pair can be smaller)
-                const double t = tm.us([&] { fused_run(f, (const int8_t *)tm.a.p, B, (int8_t *)tm.b.p, nullptr); });
-                if (len > 1) fused_destroy(f);
+                const double t = tm.us([&] { fused_run(f, (const int8_t *)tm.a.p, B, (int8_t *)tm.b.p, tm.st); });
                 if (t > 0) measured[(size_t)i][(size_t)len] = t / (double)B;
                 if (len == 1 && tune_g && t > 0) {
                     // the single pair's images per step and double buffering, measured: every multiple of the column grids' images up to
@@ -1274,7 +1316,7 @@ void fused_chain_partition(FusedImpl *const *groups, int n, int *seg_len, bool *
                             if (G == G0 && db == db0) continue;
                             std::unique_ptr<FusedImpl> cand(chain_create(&groups[i]->chain_members[0], 1, G, db));
                             if (!cand || cand->chain.dbuf != db) continue;
-                            const double tc = tm.us([&] { fused_run(cand.get(), (const int8_t *)tm.a.p, B, (int8_t *)tm.b.p, nullptr); });
+                            const double tc = tm.us([&] { fused_run(cand.get(), (const int8_t *)tm.a.p, B, (int8_t *)tm.b.p, tm.st); });
                             if (verbose_t) fprintf(stderr, "[microflow_amd] chain autotune: pair %d G %d dbuf %d: %.4f us/image (planner's G %d dbuf %d: %.4f)\n", i, G, db, tc / (double)B, G0, db0, t / (double)B);
                             if (tc > 0 && tc < (best_f ? best_t : t * 0.96)) best_t = tc, best_f = std::move(cand); // (a clear win over the planner's: 4 %)
                         }
@@ -1287,8 +1329,8 @@ void fused_chain_partition(FusedImpl *const *groups, int n, int *seg_len, bool *
                 if (len == 1) {
                     OpImpl *dw = groups[i]->chain_members[0].first, *pw = groups[i]->chain_members[0].second;
                     const double u = tm.us([&] {
-                        op_run(dw, (const int8_t *)tm.a.p, B, (int8_t *)tm.c.p, nullptr);
-                        op_run(pw, (const int8_t *)tm.c.p, B, (int8_t *)tm.b.p, nullptr);
+                        op_run(dw, (const int8_t *)tm.a.p, B, (int8_t *)tm.c.p, tm.st);
+                        op_run(pw, (const int8_t *)tm.c.p, B, (int8_t *)tm.b.p, tm.st);
                     });
                     if (u > 0) measured_unf[(size_t)i] = u / (double)B;
                 }
@@ -1297,12 +1339,21 @@ void fused_chain_partition(FusedImpl *const *groups, int n, int *seg_len, bool *
                             len == 1 ? (" (unfused " + std::to_string(measured_unf[(size_t)i]) + ")").c_str() : "");
             }
         }
-        (void)hipDeviceSynchronize();
+        if (tm.st) (void)hipStreamSynchronize(tm.st);
         (void)hipGetLastError();
+        // The measurements are used only as a whole: every pair must have its own time (measured us/image of the chip and estimated
+        // us/image per CU are different units and must never meet in one sum); a launch that threw, a pair too large for the scratch
+        // or a failed timer send the whole run back to the estimates.
+        bool complete = tm.ok && !tm.failed;
+        for (int i = 0; i < n && complete; ++i) complete = measured[(size_t)i][1] > 0;
+        if (!complete) {
+            if (verbose_t || getenv("MF_VERBOSE")) fprintf(stderr, "[microflow_amd] chain autotune incomplete: planning %d pairs from the cost model\n", n);
+            autotune = false;
+        }
     }
     for (int i = n - 1; i >= 0; --i) {
         for (int len = 1; len <= n - i && len <= k::CHAIN_MAX; ++len) {
-            if (autotune && measured[(size_t)i][1] > 0) { // measured costs (a candidate that was not measured does not exist)
+            if (autotune) { // measured costs (a candidate that was not measured does not exist)
                 double c = measured[(size_t)i][(size_t)len];
                 if (c <= 0) continue;
                 if (len > 1) c *= 1.05; // (a chain has to win clearly: isolated timings of this size repeat to 2 - 3 %)
@@ -1341,8 +1392,20 @@ void fused_chain_partition(FusedImpl *const *groups, int n, int *seg_len, bool *
             for (int i = 0; i < n; ++i) {
                 const int len = seg_len[i];
                 if (len < 2) continue;
-                if (!tm) tm.reset(new ChainTimer(CAP));
-                if (!tm->ok) break;
+                if (!tm) {
+                    size_t need2 = 0;
+                    for (int i2 = 0; i2 < n; ++i2) {
+                        if (seg_len[i2] < 2) continue;
+                        size_t mx2 = 1;
+                        for (int j = i2; j < i2 + seg_len[i2]; ++j) {
+                            const OpSpec &d = groups[j]->chain_members[0].first->s, &q = groups[j]->chain_members[0].second->s;
+                            mx2 = std::max(mx2, std::max((size_t)d.H * d.W * d.C, std::max((size_t)d.OH * d.OW * d.N, (size_t)q.OH * q.OW * q.N)));
+                        }
+                        need2 = std::max(need2, (std::min<size_t>(CAP / mx2, 262144) & ~(size_t)63) * mx2);
+                    }
+                    tm.reset(new ChainTimer(need2 + 256));
+                }
+                if (!tm->ok || tm->failed) break;
                 size_t mx = 1;
                 for (int j = i; j < i + len; ++j) {
                     const OpSpec &d = groups[j]->chain_members[0].first->s, &q = groups[j]->chain_members[0].second->s;
@@ -1351,7 +1414,7 @@ void fused_chain_partition(FusedImpl *const *groups, int n, int *seg_len, bool *
                 const size_t B = std::min<size_t>(CAP / mx, 262144) & ~(size_t)63;
                 std::unique_ptr<FusedImpl> base(fused_chain_create(groups + i, len, 0));
                 if (!base || B < 256) continue;
-                const double t0 = tm->us([&] { fused_run(base.get(), (const int8_t *)tm->a.p, B, (int8_t *)tm->b.p, nullptr); });
+                const double t0 = tm->us([&] { fused_run(base.get(), (const int8_t *)tm->a.p, B, (int8_t *)tm->b.p, tm->st); });
                 const int G0 = base->chain.G, cg = std::max(1, base->chain.max_cg);
                 double best_t = t0;
                 const int cands[4] = {G0 / 2, 3 * G0 / 4, 3 * G0 / 2, 2 * G0};
@@ -1360,16 +1423,16 @@ void fused_chain_partition(FusedImpl *const *groups, int n, int *seg_len, bool *
                     if (G < cg || G > 128 || G % cg != 0 || G == G0) continue;
                     std::unique_ptr<FusedImpl> cand(fused_chain_create(groups + i, len, G));
                     if (!cand) continue;
-                    const double tc = tm->us([&] { fused_run(cand.get(), (const int8_t *)tm->a.p, B, (int8_t *)tm->b.p, nullptr); });
+                    const double tc = tm->us([&] { fused_run(cand.get(), (const int8_t *)tm->a.p, B, (int8_t *)tm->b.p, tm->st); });
                     if (verbose_t) fprintf(stderr, "[microflow_amd] chain autotune: chain %d..%d G %d: %.4f us/image (planner's G %d: %.4f)\n", i, i + len - 1, G, tc / (double)B, G0, t0 / (double)B);
                     if (tc > 0 && tc < (seg_G[i] ? best_t : t0 * 0.96)) best_t = tc, seg_G[i] = G;
                 }
             }
-            (void)hipDeviceSynchronize();
+            if (tm && tm->st) (void)hipStreamSynchronize(tm->st);
             (void)hipGetLastError();
         }
     }
-    static const bool verbose = getenv("MF_CHAIN_VERBOSE") != nullptr;
+    static const bool verbose = getenv("MF_CHAIN_VERBOSE") != nullptr || getenv("MF_VERBOSE") != nullptr; // the plan, so that a run can be reproduced
     if (verbose) {
         fprintf(stderr, "[microflow_amd] chain partition of %d pairs:", n);
         for (int i = 0; i < n; ++i)

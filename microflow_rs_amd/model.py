@@ -16,7 +16,7 @@ OP_NAMES = {1: "average_pool_2d", 3: "conv_2d", 4: "depthwise_conv_2d", 9: "full
 
 
 class Model:
-    def __init__(self, path_or_bytes, device=None, max_batch=0):
+    def __init__(self, path_or_bytes, device=None, max_batch=0, autotune=False):
         if isinstance(path_or_bytes, (bytes, bytearray, memoryview)):
             data = bytes(path_or_bytes)
         else:
@@ -41,6 +41,8 @@ class Model:
         self.dtype = np.uint8 if info.element_type == _lib.MF_ELEM_U8 else np.int8
         self._device = device
         self._prepared = False
+        if autotune:
+            self.set_autotune(True)
         if max_batch:
             self.prepare(max_batch)
 
@@ -94,6 +96,11 @@ class Model:
     def set_generic(self, generic=True):
         _lib.check(_lib.lib().mf_model_set_generic(self._h, int(generic)))
         return self
+
+    def set_autotune(self, enabled=True):
+        """before prepare(): time the fused-chain candidates of run-time-geometry models on the device instead of planning them
+        from the cost model (mf_model_set_autotune)"""
+        _lib.check(_lib.lib().mf_model_set_autotune(self._h, int(bool(enabled))))
 
     def set_fusion(self, enabled=True):
         _lib.check(_lib.lib().mf_model_set_fusion(self._h, int(enabled)))

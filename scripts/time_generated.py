@@ -18,7 +18,7 @@ cases = [a for a in sys.argv[1:] if ":" in a] or ["128:1.0", "64:1.0", "96:0.5"]
 for c in cases:
     side, width = int(c.split(":")[0]), float(c.split(":")[1])
     blob = tw.person_detect_like(np.random.default_rng(side), side, width)
-    m = mf.model(blob)
+    m = mf.Model(blob, autotune=(os.environ.get("MF_TIME_GENERATED_AUTOTUNE", "1") != "0"))
     B = int(65536 * 96 * 96 / (side * side))
     m.prepare(B)
     x = synth_i8(9, 0, B * m.input_elems)

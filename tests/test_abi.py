@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol():
 def test_binding_table_matches_header():
     from microflow_rs_amd import _lib
     assert sorted(_lib.SIGNATURES) == declared_functions()
-    assert _lib.lib().mf_abi_version() == 2
+    assert _lib.lib().mf_abi_version() == 3
 
 
 def test_no_torch_types_cross_the_abi():
