@@ -136,20 +136,54 @@ def requant_peak(mode):
     return forms.get(name, {}).get("GBps", REQUANT_PEAK_GBS)
 
 
+def source_sha16():
+    """sha256 (first 16 hex digits) over the kernel sources: what a committed counter profile is tagged with, so that a
+    replayed figure says whether it belongs to the kernels of THIS build"""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "microflow_rs_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".hpp", ".cpp")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def rocprof_name(kernel, mode, u8=False):
+    """the name (prefix) rocprofv3 prints for a launch of the library's kernel `kernel` -- the key into
+    profiles/*kernel_stats.csv; the library's own names spell the fused shapes out, the compiler's the template arguments"""
+    xr = "0u" if (mode == 3 or not u8) else "2155905152u"
+    sp = lambda t: ", ".join(x.strip() for x in t.split(","))  # noqa: E731
+    if kernel.startswith("penta_rr<"):
+        return "mf::k::quad_rr<mf::k::Quad13, true, %d, %s>" % (mode, xr)
+    if kernel.startswith("quad_rr<48,"):
+        return "mf::k::quad_rr<mf::k::Quad13, false, %d, %s>" % (mode, xr)
+    if kernel.startswith("quad_rr<24,"):
+        return "mf::k::quad_rr<mf::k::Quad57, false, %d, %s>" % (mode, xr)
+    if kernel.startswith("stage_6x6x128<"):
+        return "mf::k::stage_6x6x128<4, 512, %d, %s>" % (mode, xr)
+    if "<" in kernel:  # dwpw_mm<H,W,C,S,N,G,T,D>, pair3_tail<H,W,C,S>, pw_mfma<K,N>, ...: the leading template arguments are the same
+        base, args = kernel.split("<", 1)
+        lead = args.rstrip(">").split(",")
+        lead = lead[:7] if base.startswith(("dwpw_", "dw3x3_mm")) else lead
+        return "mf::k::%s<%s" % (base.replace("dw3x3_mm", "dwpw_mm"), sp(",".join(lead)))
+    return "mf::k::" + kernel
+
+
 def sq_counters(kernel):
     """Independent of the microbenchmark: per-kernel figures from the committed rocprofv3 SQ counter passes of this same
-    command (profiles/sq_latest.json = scripts/sq_derived.py --json).  valu_busy = VALU wave-instructions per SIMD clock / 0.5
-    (a wave64 instruction occupies a SIMD-32 for at least two clocks, so 0.5 per clock is the issue ceiling)."""
+    command (profiles/sq_latest.json = scripts/pmc_summary.py --sq).  Reported as measured -- VALU wave-instructions per SIMD
+    clock -- without a normaliser: the issue ceiling depends on the instruction mix (full-rate v_fma / v_add against the
+    0.6-rate conversions), so a single "busy" fraction would under- or over-read."""
     try:
         sq = json.load(open(os.path.join(ROOT, "profiles", "sq_latest.json")))
-        k = sq["kernels"].get(kernel)
-        if not k:  # (rocprofv3 prints template arguments the library's names drop or replace: one kernel of that base name -> that one)
-            same = [v for n, v in sq["kernels"].items() if n.split("<")[0] == kernel.split("<")[0]]
-            k = same[0] if len(same) == 1 else None
+        k = sq["kernels"].get(kernel)  # exact name only: a different template instance or an older kernel is not this one
         if k:
-            return {"valu_busy": k["valu_busy"], "valu_inst_per_clk_per_simd": k["valu_inst_per_clk_per_simd"],
+            stale = sq.get("source_sha16") != source_sha16()
+            return {"valu_inst_per_clk_per_simd": k["valu_inst_per_clk_per_simd"],
                     "lds_bank_conflict_ratio": k["lds_bank_conflict_ratio"], "wait_any_frac": k.get("wait_any_frac"),
-                    "source": "profiles/sq_latest.json"}
+                    "source": "committed profiles/sq_latest.json (a separate rocprofv3 --pmc pass, NOT measured in this run)%s"
+                              % (": STALE -- collected on other kernel sources" if stale else ""), "stale": stale}
     except (OSError, ValueError, KeyError):
         pass
     return None
@@ -163,7 +197,9 @@ def pmc_traffic(kernel, count):
         if count is None or pmc.get("per_gpu_batch") == count:
             for k in pmc["kernels"]:
                 if k["kernel"] == kernel or (kernel == "fc_mfma" and k["kernel"].startswith("fc_mfma<")):
-                    return k["traffic_bytes"], "profiles/pmc_traffic_latest.json"
+                    stale = pmc.get("source_sha16") != source_sha16()
+                    return k["traffic_bytes"], ("committed profiles/pmc_traffic_latest.json (separate rocprofv3 --pmc passes, NOT "
+                                                "measured in this run)" + (": STALE -- collected on other kernel sources" if stale else ""))
     except (OSError, ValueError, KeyError):
         pass
     return None, None
@@ -199,6 +235,9 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend of the N > 1 path (nccl = RCCL; gloo: tests on a 1-GPU box)")
+    ap.add_argument("--dist", action="store_true",
+                    help="with --gpus 1: still initialise the process group (world size 1) and run the barrier, the max-over-ranks "
+                         "all_reduce and the checksum all_gather -- RCCL's library load, device binding and teardown on a 1-GPU box")
     ap.add_argument("--share-device", action="store_true",
                     help="every rank uses GPU 0 (only with --backend gloo: exercises the real multi-rank launch path on one GPU)")
     args = ap.parse_args()
@@ -224,8 +263,11 @@ def main():
         raise SystemExit("bench.py: rank %d has no GPU (only %d device(s) visible)" % (rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     coll_dev = "cuda" if args.backend == "nccl" else "cpu"  # where the three tiny collectives' tensors live
-    if world > 1:
+    use_dist = world > 1 or args.dist  # (--dist: the same collectives over a world of one)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            os.environ.setdefault("MASTER_PORT", str(free_port()))
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
@@ -237,7 +279,7 @@ def main():
     from microflow_rs_amd.shard import gather_checksums, max_over_ranks, shard_range
     from microflow_rs_amd.synth import SEED
 
-    ctx = dict(args=args, mf=mf, _lib=_lib, torch=torch, dist=dist, world=world, rank=rank, local_rank=local_rank,
+    ctx = dict(args=args, mf=mf, _lib=_lib, torch=torch, dist=dist, world=world, rank=rank, local_rank=local_rank, use_dist=use_dist,
                synth_i8=synth_i8, checksum_i8=checksum_i8, SEED=SEED)
     fname, cfg, base_batch = WORKLOADS[args.workload]
     B = args.batch or base_batch
@@ -260,7 +302,7 @@ def main():
         _lib.check(L.mf_model_run_quantized(m._h, x.data_ptr(), count, y.data_ptr(), _lib.MF_MEM_DEVICE))
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -272,7 +314,7 @@ def main():
         step()
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         elapsed = max_over_ranks(dist, elapsed, device=coll_dev)
     ms_per_step = elapsed / args.steps * 1e3
     value = B * world / (elapsed / args.steps)
@@ -280,13 +322,13 @@ def main():
     # the same step, one HIP event pair per iteration on the launch stream: median
     ev = event_times(torch, step, max(20, args.steps))
     ev_med = median(ev)
-    if world > 1:
+    if use_dist:
         ev_med = max_over_ranks(dist, ev_med, device=coll_dev)
 
     # output checksums of every shard (outside the timed region; RCCL all_gather of 8 bytes)
     ck = checksum_i8(y)
     cks = [ck]
-    if world > 1:
+    if use_dist:
         cks = gather_checksums(dist, ck, device=coll_dev)
         # The distributed part of the run ends HERE: everything below (per-kernel tables, parity, CPU baseline, the
         # other workloads) is rank 0's alone and takes tens of seconds, so the process group is torn down first
@@ -369,15 +411,19 @@ def main():
                     "achieved": dom["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["frac"],
                     "hbm_frac": dom["hbm_frac"], "valu_frac": dom["valu_frac"],
                     "requant_GBps": dom["requant_GBps"], "requant_peak_GBps": dom["requant_peak_GBps"], "epilogue_mode": dom["epilogue_mode"],
-                    "valu_busy": (dom["sq"] or {}).get("valu_busy"),
+                    "valu_inst_per_clk_per_simd": (dom["sq"] or {}).get("valu_inst_per_clk_per_simd"),
+                    "sq_src": (dom["sq"] or {}).get("source"),
                     "algorithmic_bytes": dom["bytes"], "requant_bytes": dom["requant_bytes"],
-                    "traffic": traffic, "traffic_source": traffic_src,
+                    "traffic": traffic, "traffic_src": traffic_src, "traffic_source": traffic_src,
+                    "rocprof_name": rocprof_name(dom["kernel"], dom["epilogue_mode"], m.dtype == np.uint8),
+                    "requant_ceiling_src": (REQUANT_CEILING or {}).get("used"),
                     "method": "HIP events on the launch stream, median of %d launches" % iters,
                     "note": "the longest launch of the step.  achieved / peak / frac: algorithmic bytes per launch / its "
                             "duration vs the 8 TB/s HBM peak; valu_frac: every int8 byte the launch requantises (on chip or "
                             "not) / its duration vs the ceiling, measured in this run, of the requantisation form the launch runs "
-                            "(`epilogue_mode`, `requant_ceiling`); valu_busy: VALU wave-instructions per SIMD clock / 0.5 from the "
-                            "committed SQ counter pass -- independent of that microbenchmark; "
+                            "(`epilogue_mode`, `requant_ceiling`, `requant_ceiling_src`); traffic and valu_inst_per_clk_per_simd are "
+                            "REPLAYED from committed counter passes (`traffic_src`, `sq_src` say which, and whether they are stale); "
+                            "rocprof_name = the kernel's name in profiles/*kernel_stats.csv; "
                             "`bound` = the roof with the longer time floor"}
         step_bytes = sum(k["bytes"] for k in kernels)
         step_rq = sum(k["requant_bytes"] for k in kernels)
@@ -487,7 +533,7 @@ def main():
             "config": {"workload": "%s batch=%d per GPU, predict_inner int8->int8, inputs resident in HBM"
                                    % (fname, B), "per_gpu_batch": B, "global_batch": B * world,
                        "parallelism": "batch shard x%d, no data-path collective" % world,
-                       "backend": (args.backend if world > 1 else None),
+                       "backend": (args.backend if (world > 1 or args.dist) else None),
                        "shards": [list(shard_range(B * world, r, world)) for r in range(world)]},
             "roofline": roofline,
             "requant_ceiling": REQUANT_CEILING,
@@ -538,9 +584,11 @@ def _sub_summary(rec):
     """one-line summary of a sub-record (speech, fc4096, fc4096_wzp)"""
     if not isinstance(rec, dict):
         return None
-    out = _pick(rec, ("value", "unit", "ms_per_step"))
+    out = _pick(rec, ("value", "value_batch", "unit", "ms_per_step"))
     rl = rec.get("roofline") or {}
-    out["roofline"] = _pick(rl, ("bound", "kernel", "ms", "achieved", "peak", "unit", "frac", "traffic", "batch"))
+    out["roofline"] = _pick(rl, ("bound", "kernel", "batch", "ms", "achieved", "peak", "unit", "frac", "hbm_frac", "traffic", "traffic_src"))
+    if isinstance(out["roofline"].get("traffic_src"), str):
+        out["roofline"]["traffic_src"] = "stale-committed" if "STALE" in out["roofline"]["traffic_src"] else "committed"
     out["parity"] = bool(rec.get("parity", {}).get("bit_exact_vs_oracle", False))
     return out
 
@@ -556,9 +604,14 @@ def compact_record(full):
     if len(c["config"].get("shards") or []) > 8:
         c["config"]["shards"] = c["config"]["shards"][:8] + ["..."]
     c["roofline"] = _pick(full.get("roofline") or {}, (
-        "bound", "kernel", "ms", "achieved", "peak", "unit", "frac", "hbm_frac", "valu_frac", "valu_busy", "traffic",
-        "algorithmic_bytes", "requant_bytes", "requant_peak_GBps", "epilogue_mode", "method", "peak_guide_floor",
+        "bound", "kernel", "rocprof_name", "ms", "achieved", "peak", "unit", "frac", "hbm_frac", "valu_frac", "traffic", "traffic_src",
+        "algorithmic_bytes", "requant_bytes", "requant_peak_GBps", "requant_ceiling_src", "epilogue_mode", "method", "peak_guide_floor",
         "frac_of_guide_floor", "algorithmic_ops"))
+    for k in ("traffic_src", "requant_ceiling_src"):  # (short forms in the line; the full sentences are in bench_details.json)
+        v = c["roofline"].get(k)
+        if isinstance(v, str):
+            c["roofline"][k] = ("stale-committed" if "STALE" in v else "committed") if v.startswith("committed") else \
+                               ("measured-in-run" if "measured in this run" in v else ("literals(in-run measurement suspect)" if "literal" in v else v[:40]))
     if full.get("whole_step"):
         c["whole_step"] = _pick(full["whole_step"], ("ms", "launches", "algorithmic_bytes", "frac", "hbm_frac", "valu_frac",
                                                      "roof_floor_ms", "frac_of_roof_floor"))
@@ -599,7 +652,7 @@ def compact_record(full):
 
 def finish(ctx, result):
     dist, world, rank = ctx["dist"], ctx["world"], ctx["rank"]
-    if world > 1 and not ctx.get("group_closed"):
+    if (world > 1 or ctx.get("use_dist")) and not ctx.get("group_closed"):
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
@@ -667,7 +720,7 @@ def speech_record(ctx):
     # requantisation of the 4000 depthwise outputs per inference -> the same ceiling as the fused person_detect kernels
     one = next((k for k in kernels if k["kernel"].startswith("dwc1_fc")), None)
     nbytes = (m.input_elems + m.output_elems) * B  # model input + output: all the HBM traffic there is
-    rec = {"metric": "inferences/sec (int8) for speech.tflite", "value": round(B / (ms * 1e-3), 1), "unit": "inferences/s",
+    rec = {"metric": "inferences/sec (int8) for speech.tflite", "value": round(B / (ms * 1e-3), 1), "value_batch": B, "unit": "inferences/s",
            "ms_per_step": round(ms, 5), "config": {"workload": "speech.tflite batch=%d, predict_inner int8->int8" % B},
            "kernels": kernels, "timing": "HIP events on the launch stream, median of %d steps" % nev,
            "parity": {"bit_exact_vs_oracle": ok, "sampled_images": nidx}}
@@ -743,7 +796,7 @@ def fc4096_record(ctx, steps, warmup, wzp=0):
                      "peak": INT8_MFMA_PEAK_NOMINAL, "unit": "TOP/s", "frac": round(tops / INT8_MFMA_PEAK_NOMINAL, 4),
                      "peak_guide_floor": INT8_MFMA_PEAK_GUIDE_FLOOR,
                      "frac_of_guide_floor": round(tops / INT8_MFMA_PEAK_GUIDE_FLOOR, 4),
-                     "traffic": pmc_traffic("fc_mfma", None)[0], "traffic_source": pmc_traffic("fc_mfma", None)[1],
+                     "traffic": pmc_traffic("fc_mfma", None)[0], "traffic_src": pmc_traffic("fc_mfma", None)[1],
                      "algorithmic_bytes": M * K + N * K + M * N,
                      "ms": round(ms, 4), "algorithmic_ops": ops,
                      "method": "HIP events on the launch stream, median of %d steps (whole predict_inner: GEMM"

@@ -79,6 +79,19 @@ pub fn model(args: TokenStream, item: TokenStream) -> TokenStream {
                 let n = out.len() / inputs.len();
                 out.chunks(n).map(|c| microflow_amd::layout::#unflatten(c)).collect()
             }
+            /// `predict_quantized` over B independent inferences (element type i8 or u8, as the model's), sharded the same way:
+            /// the batched counterpart of the reference's second generated method (microflow-macros/src/lib.rs:193-196).
+            pub fn predict_quantized_batch(inputs: &[microflow_amd::buffer::#ibuf<#qty, #(#ishape),*>])
+                -> Vec<microflow_amd::buffer::#obuf<f32, #(#oshape),*>> {
+                if inputs.is_empty() {
+                    return Vec::new();
+                }
+                let mut v = Vec::new();
+                for i in inputs { v.extend(microflow_amd::layout::#flatten(i)); }
+                let out = Self::replicas().#qcall(&v, inputs.len());
+                let n = out.len() / inputs.len();
+                out.chunks(n).map(|c| microflow_amd::layout::#unflatten(c)).collect()
+            }
         }
     }
     .into()

@@ -60,6 +60,8 @@ extern "C" {
     pub fn mf_device_count() -> c_int;
     pub fn mf_models_predict(models: *const *mut mf_model, n_models: c_int, input: *const f32, batch: usize,
                              output: *mut f32) -> c_int;
+    pub fn mf_models_predict_quantized(models: *const *mut mf_model, n_models: c_int, input: *const i8, batch: usize,
+                                       output: *mut f32) -> c_int;
 }
 
 /// One prepared model on one GPU.  Not `Sync`: the C handle is single-threaded; the macro
@@ -155,6 +157,30 @@ impl ModelSet {
         }
         let raws: Vec<*mut mf_model> = self.replicas.iter().map(|m| m.raw).collect();
         check(unsafe { mf_models_predict(raws.as_ptr(), raws.len() as c_int, input.as_ptr(), batch, out.as_mut_ptr()) });
+        out
+    }
+    /// `predict_quantized` (microflow-macros/src/lib.rs:193-196) over a batch, sharded like `predict`: the quantized inputs go
+    /// straight to `predict_inner` on every device, only the outputs are dequantized.
+    pub fn predict_quantized(&mut self, input: &[i8], batch: usize) -> Vec<f32> {
+        let info = self.replicas[0].info;
+        assert_eq!(info.element_type, 0);
+        self.predict_quantized_raw(input.as_ptr(), input.len(), batch)
+    }
+    /// The same for a UINT8 model: the ABI's `int8_t*` parameter carries the raw u8 bytes.
+    pub fn predict_quantized_u8(&mut self, input: &[u8], batch: usize) -> Vec<f32> {
+        let info = self.replicas[0].info;
+        assert_eq!(info.element_type, 1);
+        self.predict_quantized_raw(input.as_ptr() as *const i8, input.len(), batch)
+    }
+    fn predict_quantized_raw(&mut self, input: *const i8, len: usize, batch: usize) -> Vec<f32> {
+        let info = self.replicas[0].info;
+        assert_eq!(len, batch * info.input_elems);
+        let mut out = vec![0f32; batch * info.output_elems];
+        if batch == 0 {
+            return out;
+        }
+        let raws: Vec<*mut mf_model> = self.replicas.iter().map(|m| m.raw).collect();
+        check(unsafe { mf_models_predict_quantized(raws.as_ptr(), raws.len() as c_int, input, batch, out.as_mut_ptr()) });
         out
     }
 }

@@ -17,6 +17,18 @@ import sys
 from collections import defaultdict
 
 
+def source_sha16():
+    """the tag bench.py checks a committed profile against (bench.py source_sha16): sha256 over the kernel sources"""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "microflow_rs_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".hpp", ".cpp")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def load(d, counter):
     # one file per profiled process (bench.py runs its vendor-GEMM cross-check in a child): take them all
     acc = defaultdict(list)
@@ -77,15 +89,16 @@ def sq_main(dirs, stats_csv):
             if "mf::k::" in r["Name"]:
                 dur[short(r["Name"])] = float(r["AverageNs"])
     med = lambda v: sorted(v)[len(v) // 2] if v else 0.0  # noqa: E731
-    out = {"note": "rocprofv3 --pmc SQ passes of bench.py (scripts/gpu_check.sh STEPS=sqpmc), median over launches; valu_busy = "
-                   "SQ_INSTS_VALU / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs) / 0.5", "kernels": {}}
+    out = {"note": "rocprofv3 --pmc SQ passes of bench.py (scripts/gpu_check.sh STEPS=sqpmc), median over launches; "
+                   "valu_inst_per_clk_per_simd = SQ_INSTS_VALU / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs)",
+           "source_sha16": source_sha16(), "kernels": {}}
     for k in sorted(acc):
         c = {n: med(v) for n, v in acc[k].items()}
         cyc = c.get("GRBM_GUI_ACTIVE", 0.0) / 8.0
         if cyc <= 0:
             continue
         v = c.get("SQ_INSTS_VALU", 0.0) / cyc / 1024.0
-        e = {"valu_inst_per_clk_per_simd": round(v, 4), "valu_busy": round(v / 0.5, 4),
+        e = {"valu_inst_per_clk_per_simd": round(v, 4),
              "lds_bank_conflict_ratio": round(c.get("SQ_LDS_BANK_CONFLICT", 0.0) / c["SQ_LDS_IDX_ACTIVE"], 4) if c.get("SQ_LDS_IDX_ACTIVE") else 0.0,
              "wait_any_frac": round(c.get("SQ_WAIT_ANY", 0.0) / c["SQ_WAVE_CYCLES"], 4) if c.get("SQ_WAVE_CYCLES") else None,
              "cycles_per_xcd": round(cyc)}
@@ -114,7 +127,7 @@ def main():
             alg.setdefault(k["kernel"], k["bytes"])
     out = {"per_gpu_batch": bench["config"]["per_gpu_batch"] if bench else None,
            "unit": "bytes per launch", "fetch_correction": "FETCH_SIZE x 2 (gfx950 wide-read calibration)",
-           "kernels": []}
+           "source_sha16": source_sha16(), "kernels": []}
     for name in sorted(set(fetch) | set(write)):
         if "mf::k::" not in name:
             continue

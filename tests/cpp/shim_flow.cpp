@@ -6,6 +6,7 @@
 //                                      (MF_MEM_HOST) -> unflatten
 //     M::predict_quantized(Buffer)  -> the same through mf_model_predict_quantized
 //     M::predict_batch(&[Buffer])   -> flatten each, mf_models_predict over ALL replicas, chunk, unflatten
+//     M::predict_quantized_batch(&[Buffer<i8|u8>]) -> the same through mf_models_predict_quantized
 //
 // The buffers on the Rust side are nalgebra SMatrix (column-major) / [SMatrix<[T; CH], R, C>; B]
 // (memory order [b][col][row][ch], src/buffer.rs:5-16); `Buffer2D` / `Buffer4D` below have exactly those
@@ -163,6 +164,24 @@ static int run_model(const std::string &dir, const char *file, const std::vector
                 }
         // predict_batch(&[]) returns before touching the library; the ABI accepts an empty batch too
         CHECK(mf_models_predict(set.replicas.data(), (int)set.replicas.size(), nullptr, 0, nullptr));
+    }
+
+    // ---- M::predict_quantized_batch(&[a, b, c, d, e]): ModelSet::predict_quantized -> mf_models_predict_quantized ----
+    {
+        const size_t B = 5;
+        const float q = std::round(0.5f / info.input_scale + (float)info.input_zero_point);
+        const int8_t qi = (int8_t)(q < -128.f ? -128.f : (q > 127.f ? 127.f : q));
+        std::vector<int8_t> v(B * info.input_elems, qi); // B flattened Buffer<i8> inputs back to back
+        std::vector<float> ob(B * info.output_elems);
+        CHECK(mf_models_predict_quantized(set.replicas.data(), (int)set.replicas.size(), v.data(), B, ob.data()));
+        const size_t n = ob.size() / B;
+        for (size_t b = 0; b < B; ++b)
+            for (size_t k = 0; k < want.size(); ++k)
+                if (ob[b * n + k] != want[k]) {
+                    std::fprintf(stderr, "%s predict_quantized_batch[%zu]: output %zu = %.9g, want %.9g\n", file, b, k, ob[b * n + k], want[k]);
+                    return 1;
+                }
+        CHECK(mf_models_predict_quantized(set.replicas.data(), (int)set.replicas.size(), nullptr, 0, nullptr));
     }
     return 0;
 }

@@ -49,3 +49,53 @@ def test_bench_two_ranks_share_one_device(O):
         want.append("%016x" % (int(layer_checksum(y)) & 0x7FFFFFFFFFFFFFFF))
     assert rec["parity"]["output_checksums"] == want
     assert want[0] != want[1]
+
+
+_RCCL_CHILD = r"""
+import os, sys
+sys.path.insert(0, {root!r})
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+os.environ.setdefault("MASTER_PORT", "{port}")
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+import torch, torch.distributed as dist
+from microflow_rs_amd.shard import gather_checksums, max_over_ranks, shard_range
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+assert dist.get_backend() == "nccl"
+dist.barrier()
+assert max_over_ranks(dist, 1.25, device="cuda") == 1.25
+assert gather_checksums(dist, 0x7123456789ABCDEF, device="cuda") == [0x7123456789ABCDEF]
+assert shard_range(65536, 0, 1) == (0, 65536)
+dist.barrier()
+dist.destroy_process_group()
+print("rccl-ok", torch.cuda.nccl.version())
+"""
+
+
+def test_rccl_world_of_one():
+    """RCCL itself, on the one GPU this box has: library load, device binding, the three collectives of the multi-GPU path
+    (barrier, all_reduce MAX, all_gather) and the teardown order bench.py uses -- a world size of one is legal for RCCL."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, "-c", _RCCL_CHILD.format(root=ROOT, port=port)], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "rccl-ok" in r.stdout, r.stdout[-1000:] + r.stderr[-3000:]
+
+
+def test_bench_single_rank_over_rccl(O):
+    """`bench.py --gpus 1 --dist`: the driver's multi-GPU line with N = 1 -- init_process_group("nccl", device_id=...), the
+    barrier-bracketed timed region, max over ranks, the checksum all_gather, teardown before the single-rank extras."""
+    per_gpu = 64
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--dist", "--steps", "3", "--warmup", "1",
+           "--batch", str(per_gpu), "--no-extra", "--no-cpu-baseline", "--no-host-fed"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    rec = json.loads(r.stdout.strip().splitlines()[-1])
+    assert rec["n_gpus"] == 1 and rec["config"]["backend"] == "nccl" and rec["parity"]["bit_exact_vs_oracle"] is True
+    om = O.Model(model_path("person_detect"))
+    y = om.run_quantized_batch(synth_i8(3, 0, per_gpu, om.in_elems))
+    assert rec["parity"]["output_checksums"] == ["%016x" % (int(layer_checksum(y)) & 0x7FFFFFFFFFFFFFFF)]

@@ -250,13 +250,12 @@ def test_kernel_routing(models):
     names = [m.op(i)["kernel"] for i in range(m.num_ops)]
     penta = names[0].startswith("penta_rr")   # the stem + ops 1..4 in one launch (k_quad.hip STEM; MF_NO_PENTA=1: not)
     assert penta or names[0].startswith("dw3x3_stem8")
-    # fused depthwise + 1x1 conv pairs: dwpw_rr / dwpw_mm (taps on the matrix pipe) or, with
-    # MF_DWPW_IMPL=valu, r01's dwpw3x3; the five 6x6x128 pairs (ops 13..22) are ONE persistent kernel
-    # (MF_NO_STAGE=1: not)
+    # fused depthwise + 1x1 conv pairs: dwpw_rr / dwpw_mm (taps on the matrix pipe; MF_DWPW_IMPL=mm: dwpw_mm only);
+    # the five 6x6x128 pairs (ops 13..22) are ONE persistent kernel (MF_NO_STAGE=1: not)
     # ops 1..4 and 5..8 are two "quads" (two pairs per launch, k_quad.hip; MF_NO_QUAD=1: four pair launches)
     quads = sum(n.startswith(("quad_rr", "penta_rr")) for n in names)
-    npairs = sum(n.startswith(("dwpw_rr", "dwpw_mm", "dwpw3x3")) for n in names) + 2 * quads
-    pair_tail = not (os.environ.get("MF_NO_PAIRTAIL") or os.environ.get("MF_DWPW_IMPL") == "valu")
+    npairs = sum(n.startswith(("dwpw_rr", "dwpw_mm")) for n in names) + 2 * quads
+    pair_tail = not os.environ.get("MF_NO_PAIRTAIL")
     if not (os.environ.get("MF_NO_QUAD") or os.environ.get("MF_DWPW_IMPL")):
         assert quads == 2 and names[5].startswith("quad_rr<24,24,32"), names
         assert names[0].startswith("penta_rr<96,96,1,2,8|48,48,8") if penta else names[1].startswith("quad_rr<48,48,8"), names
@@ -279,7 +278,7 @@ def test_kernel_routing(models):
     m.set_fusion(False)
     names = [m.op(i)["kernel"] for i in range(m.num_ops)]
     m.set_fusion(True)
-    assert sum(n.startswith(("dw3x3_mm", "dw3x3_nhwc")) for n in names) == 13  # matrix-pipe taps (MF_DW_IMPL=valu: v_dot4)
+    assert sum(n.startswith(("dw3x3_mm", "dw3x3_nhwc")) for n in names) == 13  # matrix-pipe taps on the three large layers, v_dot4 on the rest
     assert sum(n.startswith("pw_mfma") for n in names) == 13
     assert names[28] == "conv1x1_rowwave" and names[27] == "avgpool_c4"
     assert names[29] == "" and names[30] == "softmax_table"
@@ -495,6 +494,29 @@ def test_fully_connected_4096_cubed_through_predict_inner(mf, O, wzp):
     f_trunc = (acc_diag - (acc_diag % 2)).astype(np.float32)       # ulp = 2 in [2^24, 2^25)
     if acc_diag.max() < (1 << 25):
         assert np.any(f_rne != f_trunc)
+
+
+@pytest.mark.parametrize("wzp", [0, 5], ids=["wzp0", "wzp5"])
+def test_fully_connected_mfma_every_row_at_256(mf, O, wzp):
+    """fc_mfma (the 256 x 256 staggered-tile GEMM of BASELINE config 5) at M = 256, K = N = 4096: EVERY output row against the
+    oracle (the 4096-row test above samples 128 rows; this one leaves none out, at a size the oracle finishes in seconds)."""
+    import torch
+    from tools.make_fc_model import fc_model
+    M, K, N = 256, 4096, 4096
+    rng = np.random.default_rng(77 + wzp)
+    w = rng.integers(-128, 128, (N, K), dtype=np.int8)
+    x = rng.integers(-128, 128, (M, K), dtype=np.int8)
+    x[0], x[1] = 127, -128
+    bias = rng.integers(-200000, 200000, N).astype(np.int32)
+    quants = ((1.0 / 128, -128), (1.0 / 128, wzp), (1.0 / 16384, 0), (1.0 / 16, -5))   # c1 = 2^-10: outputs spread over the int8 range
+    blob = fc_model(M, K, N, w, bias, *quants)
+    m = mf.model(blob)
+    m.prepare(1)
+    assert m.op(0)["kernel"] == "fc_mfma"
+    y = m.run_quantized(torch.from_numpy(x).cuda().reshape((1, M, K))).reshape(M, N).cpu().numpy()
+    want = O.Model(blob).run_quantized(x).reshape(M, N)
+    assert np.array_equal(y, want), np.argwhere(y != want)[:5]
+    assert len(np.unique(want)) > 100                         # (not a saturated tensor)
 
 
 def test_models_run_quantized_over_all_devices(mf, O):

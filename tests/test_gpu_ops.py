@@ -286,14 +286,33 @@ def test_softmax_vs_oracle(mf, O):
 
 
 def test_softmax_every_int8_pair(mf, O):
-    """All 65536 (a, b) int8 pairs for person_detect's 2-class softmax: exhaustive parity."""
+    """All 65536 (a, b) int8 pairs for person_detect's 2-class softmax against the oracle: exhaustive parity, every pair."""
     a, b = np.meshgrid(np.arange(-128, 128), np.arange(-128, 128), indexing="ij")
     x = np.stack([a.reshape(-1), b.reshape(-1)], -1).astype(np.int8).reshape(-1, 1, 2)
     op = mf.ops.prepare_softmax(1, 2, 0.0125187514, 1 / 256, -128)
     got = op(x)
-    idx = np.random.default_rng(0).choice(x.shape[0], 4096, replace=False)
-    want = np.stack([O.softmax(x[i], 0.0125187514, 1 / 256, -128) for i in idx])
-    assert np.array_equal(got[idx], want)
+    want = np.stack([O.softmax(x[i], 0.0125187514, 1 / 256, -128) for i in range(x.shape[0])])
+    assert np.array_equal(got, want), np.argwhere(got != want)[:5]
+
+
+def test_softmax_speech_four_classes_every_value_per_position(mf, O):
+    """speech's 4-class softmax (src/ops/softmax.rs:20-27; input scale of speech.tflite's FullyConnected output): every one of
+    the 256 int8 values in each of the four positions against a stride of backgrounds for the other three (4 x 256 x 125 rows),
+    plus all 4^4 combinations of the extreme and middle values."""
+    iscale, oscale, ozp = 0.0917319208, 1 / 256, -128
+    bg = np.array([[b0, b1, b2] for b0 in (-128, -77, -3, 40, 127) for b1 in (-128, -50, 0, 64, 127) for b2 in (-128, -20, 5, 90, 127)], np.int16)
+    rows = []
+    for pos in range(4):
+        for v in range(-128, 128):
+            r = np.insert(bg, pos, v, axis=1)
+            rows.append(r)
+    ext = np.array([-128, -1, 0, 127])
+    g = np.stack(np.meshgrid(ext, ext, ext, ext, indexing="ij"), -1).reshape(-1, 4)
+    x = np.concatenate(rows + [g]).astype(np.int8).reshape(-1, 1, 4)
+    op = mf.ops.prepare_softmax(1, 4, iscale, oscale, ozp)
+    got = op(x)
+    want = np.stack([O.softmax(x[i], iscale, oscale, ozp) for i in range(x.shape[0])])
+    assert x.shape[0] == 4 * 256 * 125 + 256 and np.array_equal(got, want), np.argwhere(got != want)[:5]
 
 
 def test_device_tensors_stay_on_device(mf):
