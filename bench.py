@@ -22,6 +22,7 @@ barrier + synchronize fences, wall clock, max over ranks.  Beside it the line ca
                  weight zero point 0 and != 0
 """
 import argparse
+import ctypes
 import json
 import os
 import socket
@@ -262,6 +263,11 @@ def main():
     if local_rank >= torch.cuda.device_count():
         raise SystemExit("bench.py: rank %d has no GPU (only %d device(s) visible)" % (rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
+    if rank != 0:
+        # Only rank 0 speaks on stdout, and its JSON line must be the LAST thing there.  Libraries write to the C-level stdout behind
+        # Python's back (RCCL prints "Librccl path : ..." through a buffered printf that surfaces when the process exits -- seen
+        # the first time RCCL ran here, round 5): every other rank's stdout goes to stderr from the start.
+        os.dup2(2, 1)
     coll_dev = "cuda" if args.backend == "nccl" else "cpu"  # where the three tiny collectives' tensors live
     use_dist = world > 1 or args.dist  # (--dist: the same collectives over a world of one)
     if use_dist:
@@ -667,7 +673,12 @@ def finish(ctx, result):
                     print("bench.py: cannot write %s: %s" % (os.path.join(d, DETAILS_FILE), e), file=sys.stderr)
         _, line = compact_record(result)
         sys.stderr.flush()
+        try:  # whatever native libraries have buffered for stdout comes out BEFORE the line ...
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
         print(line, flush=True)
+        os.dup2(2, 1)  # ... and whatever they still print at exit (RCCL does) goes to stderr: the JSON line stays the last on stdout
         ok = result.get("parity", {}).get("bit_exact_vs_oracle", False)
         for sub in ("speech", "fc4096", "fc4096_wzp"):
             if sub in result and not result[sub]["parity"]["bit_exact_vs_oracle"]:

@@ -94,7 +94,7 @@ def test_bench_single_rank_over_rccl(O):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
-    rec = json.loads(r.stdout.strip().splitlines()[-1])
+    rec = json.loads(r.stdout.strip().splitlines()[-1])   # the JSON line is the LAST line although RCCL prints to stdout at exit
     assert rec["n_gpus"] == 1 and rec["config"]["backend"] == "nccl" and rec["parity"]["bit_exact_vs_oracle"] is True
     om = O.Model(model_path("person_detect"))
     y = om.run_quantized_batch(synth_i8(3, 0, per_gpu, om.in_elems))
