@@ -112,12 +112,13 @@ SIGNATURES = {
     "mf_selftest_rounding": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint64)]),
     "mf_selftest_requant": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int,
                                       C.POINTER(C.c_uint64)]),
-    "mf_fma_epilogue_search": (C.c_int, [C.c_float, C.c_float, C.c_int, C.c_longlong, C.c_longlong, C.POINTER(C.c_float),
-                                         C.POINTER(C.c_float), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "mf_fma_epilogue_search": (C.c_int, [C.c_float, C.c_float, C.c_int, C.c_longlong, C.c_longlong, C.c_int, C.POINTER(C.c_float),
+                                         C.POINTER(C.c_float), C.POINTER(C.c_int), C.POINTER(C.c_longlong), C.POINTER(C.c_int),
+                                         C.POINTER(C.c_int)]),
     "mf_fma_epilogue_check_host": (C.c_int, [C.c_float, C.c_float, C.c_int, C.c_longlong, C.c_longlong, C.c_float, C.c_float,
-                                             C.c_int, C.POINTER(C.c_uint64)]),
+                                             C.c_int, C.c_longlong, C.c_int, C.POINTER(C.c_uint64)]),
     "mf_selftest_fma_epilogue": (C.c_int, [C.c_int, C.c_float, C.c_float, C.c_int, C.c_longlong, C.c_longlong, C.c_float,
-                                           C.c_float, C.c_int, C.POINTER(C.c_uint64)]),
+                                           C.c_float, C.c_int, C.c_longlong, C.c_int, C.POINTER(C.c_uint64)]),
     "mf_selftest_cvt_pk": (C.c_int, [C.c_int, C.POINTER(C.c_uint64)]),
     "mf_model_time_device": (C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_int, C.c_int,
                                        C.POINTER(C.c_float), _vp]),

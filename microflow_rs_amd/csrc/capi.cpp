@@ -573,31 +573,35 @@ int mf_selftest_requant(int device, int mode, int is_u8, float A, float S, int l
         *mismatches = mf::dev_selftest_epilogue(device, mode, is_u8 != 0, true, A, S, lo, hi);
     })
 }
-int mf_fma_epilogue_search(float A, float S, int is_u8, long long acc_min, long long acc_max, float *S_out, float *C_out,
-                           int *pivot_out, int *found) {
+int mf_fma_epilogue_search(float A, float S, int is_u8, long long acc_min, long long acc_max, int allow_patch, float *S_out,
+                           float *C_out, int *pivot_out, long long *patch_acc_out, int *patch_delta_out, int *found) {
     MF_TRY({
-        MF_NEED(S_out && C_out && pivot_out && found);
+        MF_NEED(S_out && C_out && pivot_out && patch_acc_out && patch_delta_out && found);
         mf::FmaForm f;
-        *found = mf::fma_form_search(A, S, is_u8 ? 0 : 128, is_u8 ? 0 : -128, is_u8 ? 255 : 127, acc_min, acc_max, f) ? 1 : 0;
-        *S_out = f.S, *C_out = f.C, *pivot_out = f.d;
+        *found = mf::fma_form_search(A, S, is_u8 ? 0 : 128, is_u8 ? 0 : -128, is_u8 ? 255 : 127, acc_min, acc_max, f, nullptr, allow_patch != 0) ? 1 : 0;
+        *S_out = f.S, *C_out = f.C, *pivot_out = f.d, *patch_acc_out = f.patch_acc, *patch_delta_out = f.patch_delta;
     })
 }
+static bool fma_args_ok(long long acc_min, long long acc_max, int pivot, long long patch_acc, int patch_delta) {
+    if (!(acc_min <= acc_max && acc_min > -(1ll << 22) && acc_max < (1ll << 22))) return false;
+    if (!(acc_min + pivot >= -(1ll << 22) && acc_max + pivot < (1ll << 22))) return false;
+    if (patch_delta != 0 && patch_delta != 1 && patch_delta != -1) return false;
+    return patch_delta == 0 || (patch_acc + patch_delta + pivot >= -(1ll << 22) && patch_acc + patch_delta + pivot < (1ll << 22));
+}
 int mf_fma_epilogue_check_host(float A, float S, int is_u8, long long acc_min, long long acc_max, float S_fma, float C_fma,
-                               int pivot, uint64_t *mismatches) {
+                               int pivot, long long patch_acc, int patch_delta, uint64_t *mismatches) {
     MF_TRY({
-        MF_NEED(mismatches && acc_min <= acc_max && acc_min > -(1ll << 22) && acc_max < (1ll << 22));
-        MF_NEED(acc_min + pivot >= -(1ll << 22) && acc_max + pivot < (1ll << 22));
+        MF_NEED(mismatches && fma_args_ok(acc_min, acc_max, pivot, patch_acc, patch_delta));
         mf::FmaForm f;
-        f.S = S_fma, f.C = C_fma, f.d = pivot;
+        f.S = S_fma, f.C = C_fma, f.d = pivot, f.patch_acc = patch_acc, f.patch_delta = patch_delta;
         *mismatches = mf::fma_form_mismatches(A, S, is_u8 ? 0 : 128, is_u8 ? 0 : -128, is_u8 ? 255 : 127, acc_min, acc_max, f);
     })
 }
 int mf_selftest_fma_epilogue(int device, float A, float S, int is_u8, long long acc_min, long long acc_max, float S_fma,
-                             float C_fma, int pivot, uint64_t *mismatches) {
+                             float C_fma, int pivot, long long patch_acc, int patch_delta, uint64_t *mismatches) {
     MF_TRY({
-        MF_NEED(mismatches && acc_min <= acc_max && acc_min > -(1ll << 22) && acc_max < (1ll << 22));
-        MF_NEED(acc_min + pivot >= -(1ll << 22) && acc_max + pivot < (1ll << 22));
-        *mismatches = mf::dev_selftest_fma_epilogue(device, A, S, is_u8 != 0, acc_min, acc_max, S_fma, C_fma, pivot);
+        MF_NEED(mismatches && fma_args_ok(acc_min, acc_max, pivot, patch_acc, patch_delta));
+        *mismatches = mf::dev_selftest_fma_epilogue(device, A, S, is_u8 != 0, acc_min, acc_max, S_fma, C_fma, pivot, patch_acc, patch_delta);
     })
 }
 int mf_selftest_cvt_pk(int device, uint64_t *mismatches) {

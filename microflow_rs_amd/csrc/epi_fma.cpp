@@ -62,6 +62,7 @@ int ref_form_eval(float A, float S, int off, int lo, int hi, int64_t acc) {
 // bits) and so is the sum: both terms are multiples of ulp(S) * 1 or ulp(C) -- at least 2^-60 for any S that gives a staircase --
 // and the sum is below 2^9 wherever its value matters (a sum outside [0, 256) saturates whatever its low bits are).
 int fma_form_eval(const FmaForm &f, int64_t acc) {
+    if (f.patch_delta != 0 && acc == f.patch_acc) acc += f.patch_delta; // the one replaced accumulator (see fma_form_search)
     const double F = (double)(M0 + acc + (int64_t)f.d); // an integer in [2^23, 2^24): what the bit pattern 0x4B400000 + acc + d reads as
     const double v = std::fma((double)f.S, F, (double)f.C);
     if (!(v >= 1.0)) return 0;
@@ -69,8 +70,9 @@ int fma_form_eval(const FmaForm &f, int64_t acc) {
     return (int)std::floor(v);
 }
 
-bool fma_form_search(float A, float S, int off, int lo, int hi, int64_t amin, int64_t amax, FmaForm &out, FmaSearchStats *st) {
+bool fma_form_search(float A, float S, int off, int lo, int hi, int64_t amin, int64_t amax, FmaForm &out, FmaSearchStats *st, bool allow_patch) {
     if (st) *st = FmaSearchStats{};
+    out = FmaForm{};
     if (!std::isfinite(A) || !std::isfinite(S) || !(S > 0.0f) || std::fpclassify(S) != FP_NORMAL) return false;
     if (amin > amax || amin <= -(1 << 22) || amax >= (1 << 22) - 1 || lo > hi) return false;
     auto Y = [&](int64_t a) { return ref_form_eval(A, S, off, lo, hi, a); };
@@ -115,9 +117,8 @@ bool fma_form_search(float A, float S, int off, int lo, int hi, int64_t amin, in
             if (ehi > elo) cands.push_back({s, elo, ehi});
         }
     if (st) st->s_candidates = (int)cands.size();
-    if (cands.empty()) return false;
     std::sort(cands.begin(), cands.end(), [](const Cand &a, const Cand &b) { return (a.ehi - a.elo) > (b.ehi - b.elo); });
-    if (st) st->best_width = cands[0].ehi - cands[0].elo;
+    if (st && !cands.empty()) st->best_width = cands[0].ehi - cands[0].elo;
     // --- 3 + 4. pivot and offset, exact check ---
     const int64_t dlo = -(1 << 22) - amin, dhi = (1 << 22) - 1 - amax; // 2^23 <= M0 + acc + d < 2^24 for every acc in [amin, amax]
     auto exact_ok = [&](const FmaForm &f) {
@@ -126,6 +127,69 @@ bool fma_form_search(float A, float S, int off, int lo, int hi, int64_t amin, in
         for (const Con &c : upper)
             if (fma_form_eval(f, c.a) >= c.k) return false;
         return true;
+    };
+    // One patched accumulator.  A channel has no line when two steps of the reference need offsets e that exclude each other (its
+    // own roundings pushed two near-ties apart).  Dropping ONE of the 2 x 255 conditions -- the tightest lower or the tightest upper
+    // one -- usually leaves a non-empty window; the line then differs from the reference at exactly one accumulator a* (the dropped
+    // condition's), by one output step, and replacing a* by its neighbour a* +- 1 BEFORE the fma (a compare and a select in the few
+    // lanes and tiles concerned, k_common.hpp epi_patch) restores equality: the neighbour lies on the right side of the line's step.
+    auto patch_search = [&]() {
+        for (int j = -16; j <= 16; ++j) {
+            const float s = next_up(S, j);
+            if (!(s > 0.0f) || std::fpclassify(s) != FP_NORMAL) continue;
+            // the two largest lower bounds and the two smallest upper bounds, with the conditions they come from
+            int l1 = -1, l2 = -1, h1 = -1, h2 = -1;
+            auto lv = [&](int i) { return th[lower[(size_t)i].k] - (double)s * (double)lower[(size_t)i].a; };
+            auto hv = [&](int i) { return th[upper[(size_t)i].k] - (double)s * (double)upper[(size_t)i].a; };
+            for (int i = 0; i < (int)lower.size(); ++i) {
+                if (l1 < 0 || lv(i) > lv(l1)) l2 = l1, l1 = i;
+                else if (l2 < 0 || lv(i) > lv(l2)) l2 = i;
+            }
+            for (int i = 0; i < (int)upper.size(); ++i) {
+                if (h1 < 0 || hv(i) < hv(h1)) h2 = h1, h1 = i;
+                else if (h2 < 0 || hv(i) < hv(h2)) h2 = i;
+            }
+            if (l1 < 0 || h1 < 0) continue;
+            for (int drop_lower = 1; drop_lower >= 0; --drop_lower) {
+                double elo, ehi;
+                Con dropped;
+                if (drop_lower) {
+                    if (l2 < 0) continue;
+                    elo = lv(l2), ehi = hv(h1), dropped = lower[(size_t)l1];
+                } else {
+                    if (h2 < 0) continue;
+                    elo = lv(l1), ehi = hv(h2), dropped = upper[(size_t)h1];
+                }
+                if (!(ehi > elo)) continue;
+                const double w = ehi - elo, emid = 0.5 * (elo + ehi);
+                const int64_t budget = std::min<int64_t>(2 * std::max(dhi, -dlo) + 1, 2000000);
+                int tries = 0;
+                for (int64_t i = 0; i < budget && tries < 16; ++i) {
+                    const int64_t d = (i & 1) ? (i + 1) / 2 : -(i / 2);
+                    if (d > dhi || d < dlo) continue;
+                    const double t = emid - (double)s * (double)(M0 + d);
+                    const float C = (float)t;
+                    if (!(std::fabs((double)C - t) < 0.499 * w)) continue;
+                    ++tries;
+                    FmaForm f{s, C, (int32_t)d};
+                    // the neighbour that carries the reference's value at the dropped accumulator
+                    const int want = Y(dropped.a);
+                    for (int delta = 1; delta >= -1; delta -= 2) {
+                        const int64_t nb = dropped.a + delta;
+                        if (nb < amin - 1 || nb > amax + 1 || nb + d < -(1 << 22) || nb + d >= (1 << 22)) continue;
+                        f.patch_acc = dropped.a, f.patch_delta = 0;
+                        if (fma_form_eval(f, nb) != want) continue;
+                        f.patch_delta = delta;
+                        if (exact_ok(f)) {
+                            out = f;
+                            if (st) st->s_rank = -2;
+                            return true;
+                        }
+                    }
+                }
+            }
+        }
+        return false;
     };
     for (size_t ci = 0; ci < cands.size(); ++ci) {
         const Cand &c = cands[ci];
@@ -151,7 +215,8 @@ bool fma_form_search(float A, float S, int off, int lo, int hi, int64_t amin, in
         }
         if (st) st->exact_checks += exact_tries;
     }
-    return false;
+    if (!allow_patch) return false;
+    return patch_search();
 }
 
 // every accumulator of [amin, amax]: the host-side twin of the device verifier (tests)

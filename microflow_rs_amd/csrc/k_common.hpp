@@ -58,7 +58,6 @@ __device__ __forceinline__ int requant(int acc, float A, float S, float lo_f, fl
 // one v_add_f32 (full rate) instead of v_cvt_f32_i32 (half rate).  Both are exact, so the
 // epilogue's value is unchanged.  The host enables it per operator only when the worst-case
 // |acc| over ALL inputs -- max|v - izp| * sum|w - wzp| per channel -- is below 2^22 (ops.hip).
-constexpr int MF_MAGIC_I = 0x4B400000;
 // MG (template parameter of every fast kernel) = the epilogue mode the host chose for the operator(s) of a launch:
 //   0  accumulator converted with v_cvt_f32_i32                         (|acc| may reach 2^22)
 //   1  bit-pattern int -> f32 (above)
@@ -90,6 +89,28 @@ __device__ __forceinline__ int requant_t(int acc, float A, float S, float lo_f, 
 // spacing: fewer channels have a solution.)  Such a kernel must contain no other f32 arithmetic that needs round-to-nearest.
 template <int MG> __device__ __forceinline__ void epi_enter() {
     if constexpr (MG == 3) __builtin_amdgcn_s_setreg(0x801 /* hwreg(HW_REG_MODE, 0, 2): FP_ROUND, single precision */, 3u /* toward zero */);
+}
+// Patched accumulators of mode 3 (kernels.hpp EpiPatch).  epi_patch_hits: which entries fall on the four channels c_lane .. c_lane + 3
+// some lane of this wave holds in a tile -- a wave-uniform mask, computed once per tile (or per phase) and zero almost always;
+// epi_patch_apply: the replacement itself, behind a scalar branch on that mask.
+__device__ __forceinline__ uint32_t epi_patch_hits(const EpiPatch &pl, int c_lane) {
+    uint32_t m = 0;
+#pragma unroll
+    for (int e = 0; e < EPI_PATCH_MAX; ++e)
+        if (e < pl.n && __builtin_amdgcn_ballot_w64((unsigned)(pl.ch[e] - c_lane) < 4u) != 0ull) m |= 1u << e;
+    return m;
+}
+__device__ __forceinline__ void epi_patch_apply(v4i &a, const EpiPatch &pl, uint32_t hits, int c_lane) {
+    if (hits == 0u) return;
+#pragma unroll
+    for (int e = 0; e < EPI_PATCH_MAX; ++e)
+        if (hits & (1u << e)) {
+            const int dc = pl.ch[e] - c_lane, P = pl.P[e], R = pl.R[e];
+            a[0] = (dc == 0 && a[0] == P) ? R : a[0];
+            a[1] = (dc == 1 && a[1] == P) ? R : a[1];
+            a[2] = (dc == 2 && a[2] == P) ? R : a[2];
+            a[3] = (dc == 3 && a[3] == P) ? R : a[3];
+        }
 }
 template <int MG> __device__ __forceinline__ int4 magic4(int4 k) {
     if constexpr (MG != 0) k.x += MF_MAGIC_I, k.y += MF_MAGIC_I, k.z += MF_MAGIC_I, k.w += MF_MAGIC_I;

@@ -477,11 +477,12 @@ __device__ __forceinline__ void fp_round_mode(uint32_t m) {
     else asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0\n\ts_nop 3" ::: "memory");
 }
 __global__ __launch_bounds__(256) void verify_fma_form_kernel(const float *A, const float *S, const float *C3, const float *S3, const int *piv,
-                                                             const int *amin, const int *amax, float lo, float hi, uint32_t xr,
-                                                             unsigned long long *bad) {
+                                                             const int *amin, const int *amax, const int *patchP, const int *patchR,
+                                                             float lo, float hi, uint32_t xr, unsigned long long *bad) {
     const int c = blockIdx.y;
     float a_ = A[c], s_ = S[c], c3 = C3[c], s3 = S3[c];
     const int d = piv[c];
+    const int pP = patchP[c], pR = patchR[c]; // the channel's one replaced bit pattern (0: none), as the kernels apply it (epi_patch_apply)
     const long long a0 = amin[c], a1 = amax[c];
     unsigned cnt = 0;
     for (long long base = a0 + 4ll * ((long long)blockIdx.x * 256 + threadIdx.x); base <= a1; base += 4ll * gridDim.x * 256) {
@@ -498,7 +499,10 @@ __global__ __launch_bounds__(256) void verify_fma_form_kernel(const float *A, co
         // the form's half: toward zero
         fp_round_mode(3);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) bits[k] = MF_MAGIC_I + av[k] + d;
+        for (int k = 0; k < 4; ++k) {
+            bits[k] = MF_MAGIC_I + av[k] + d;
+            bits[k] = bits[k] == pP ? pR : bits[k];
+        }
         asm volatile("" : "+v"(bits[0]), "+v"(bits[1]), "+v"(bits[2]), "+v"(bits[3]), "+v"(c3), "+v"(s3));
         uint32_t got = requant_pack4<3, 0u>(bits[0], bits[1], bits[2], bits[3], make_float4(c3, c3, c3, c3), make_float4(s3, s3, s3, s3), lo, hi);
         asm volatile("" : "+v"(got));
@@ -509,9 +513,10 @@ __global__ __launch_bounds__(256) void verify_fma_form_kernel(const float *A, co
     if (cnt) atomicAdd(bad + c, (unsigned long long)cnt);
 }
 // all pointers are DEVICE arrays of n entries (bad: zeroed by the caller); returns false when the launch failed
-bool verify_fma_form(const float *A, const float *S, const float *C3, const float *S3, const int *piv, const int *amin, const int *amax, int n,
-                     float lo, float hi, bool u8, unsigned long long *bad, hipStream_t s) {
-    hipLaunchKernelGGL(verify_fma_form_kernel, dim3(64, n), dim3(256), 0, s, A, S, C3, S3, piv, amin, amax, lo, hi, u8 ? 0x80u : 0u, bad);
+bool verify_fma_form(const float *A, const float *S, const float *C3, const float *S3, const int *piv, const int *amin, const int *amax,
+                     const int *patchP, const int *patchR, int n, float lo, float hi, bool u8, unsigned long long *bad, hipStream_t s) {
+    hipLaunchKernelGGL(verify_fma_form_kernel, dim3(64, n), dim3(256), 0, s, A, S, C3, S3, piv, amin, amax, patchP, patchR, lo, hi,
+                       u8 ? 0x80u : 0u, bad);
     return hipGetLastError() == hipSuccess;
 }
 // v_cvt_pk_u8_f32 itself, over all 2^32 bit patterns, against what epi_fma.cpp assumes of it (in integer arithmetic, so that the

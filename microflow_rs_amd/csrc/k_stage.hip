@@ -175,6 +175,15 @@ __global__ __launch_bounds__(NTHR, 4) void stage_6x6x128(const int8_t *__restric
         }
     };
 
+    // a patch list out of the pair table (scalar loads, like the rest of the table)
+    typedef __attribute__((address_space(4))) const EpiPatch c_patch;
+    auto ldpatch = [](c_patch *src) {
+        EpiPatch r;
+        r.n = src->n;
+#pragma unroll
+        for (int e = 0; e < EPI_PATCH_MAX; ++e) r.ch[e] = src->ch[e], r.P[e] = src->P[e], r.R[e] = src->R[e];
+        return r;
+    };
     DynSteps dq;
     dq.init(lds + OFF_Q, p.queue, tid, p.qcfg);
     __syncthreads(); // halo fill complete before any DMA lands
@@ -215,6 +224,9 @@ __global__ __launch_bounds__(NTHR, 4) void stage_6x6x128(const int8_t *__restric
             // ---------------- depthwise: tile -> MID ----------------
             {
                 const float lo = pairs[rep].dw_lo, hi = pairs[rep].dw_hi;
+                // mode 3: the depthwise operator's patched accumulators that fall on this wave's 16 channels (none, almost always)
+                const EpiPatch dpl = ldpatch(&pairs[rep].dwp);
+                const uint32_t dhit = MG == 3 ? epi_patch_hits(dpl, 16 * wave + 4 * g) : 0u;
                 const int mb = mid + mb6;
                 auto toff = [](int u) { return (u / 3) * 2 * ROW6 + (u % 3) * 2 * 128; };
                 auto moff = [](int u) { return ((u / 3) * 12 + (u % 3) * 2) * 16; };
@@ -229,6 +241,7 @@ __global__ __launch_bounds__(NTHR, 4) void stage_6x6x128(const int8_t *__restric
                     Taps t3 = t2;
                     if (u + 2 < 9) t3 = dw_load(tb6 + toff(u + 2));
                     v4i nxt = {wd.k.x, wd.k.y, wd.k.z, wd.k.w};
+                    if constexpr (MG == 3) epi_patch_apply(acc, dpl, dhit, 16 * wave + 4 * g);
                     __builtin_amdgcn_sched_barrier(0);
                     if (more) nxt = __builtin_amdgcn_mfma_i32_16x16x64_i8(wd.A[0], t2.b[0], nxt, 0, 0, 0);
                     const float r0 = epi_value<MG>(acc[0], wd.a.x, wd.s.x, lo, hi);
@@ -264,6 +277,8 @@ __global__ __launch_bounds__(NTHR, 4) void stage_6x6x128(const int8_t *__restric
             // ---------------- pointwise: MID -> tile (last pair: -> plain output in region A) ----------------
             {
                 const float lo = pairs[rep].pw_lo, hi = pairs[rep].pw_hi;
+                const EpiPatch ppl = ldpatch(&pairs[rep].pwp);
+                const uint32_t phit = MG == 3 ? epi_patch_hits(ppl, 16 * wave + 4 * pg) : 0u;
                 const int rb = mid + pg * PLANE6 + pcol * 16;
                 v4i c0 = *(const v4i *)(lds + rb), c1 = *(const v4i *)(lds + rb + 4 * PLANE6);
                 v4i acc = {wp.k.x, wp.k.y, wp.k.z, wp.k.w};
@@ -279,6 +294,7 @@ __global__ __launch_bounds__(NTHR, 4) void stage_6x6x128(const int8_t *__restric
                         e1 = *(const v4i *)(lds + rb + 4 * PLANE6 + (c + 2) * 256);
                     }
                     v4i nxt = {wp.k.x, wp.k.y, wp.k.z, wp.k.w};
+                    if constexpr (MG == 3) epi_patch_apply(acc, ppl, phit, 16 * wave + 4 * pg);
                     __builtin_amdgcn_sched_barrier(0);
                     if (more) nxt = __builtin_amdgcn_mfma_i32_16x16x64_i8(wp.A[0], c0, nxt, 0, 0, 0);
                     const float r0 = epi_value<MG>(acc[0], wp.a.x, wp.s.x, lo, hi);

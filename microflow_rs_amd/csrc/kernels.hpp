@@ -70,6 +70,17 @@ struct SoftmaxArgs {
     float sat_lo, sat_hi;
     int xr;
 };
+// Epilogue mode 3 with patched accumulators (epi_fma.cpp): for up to EPI_PATCH_MAX channels of an operator ONE accumulator bit
+// pattern P is replaced by R = P +- 1 before the fma.  Lives in the kernel arguments (scalar registers): the kernels that support it
+// (dwpw_mm, stage_6x6x128) test per tile, with scalar instructions, whether an entry falls on it -- almost never.
+constexpr int MF_MAGIC_I = 0x4B400000; // the bit-pattern accumulators' offset: the f32 1.5 * 2^23 (k_common.hpp requant_t)
+constexpr int EPI_PATCH_MAX = 4;
+struct EpiPatch {
+    int n;                      // entries in use (0: none -- the only value the other mode-3 kernels accept)
+    int ch[EPI_PATCH_MAX];      // output channel
+    int P[EPI_PATCH_MAX];       // 0x4B400000 + accumulator + pivot: the bit pattern to replace ...
+    int R[EPI_PATCH_MAX];       // ... and its replacement
+};
 constexpr int DYNQ_INTS = 8 * 32 + 32; // = DynSteps::INTS (k_common.hpp): the counters of one dynamic step queue
 // An operator owns DYNQ_RING counter sets and every launch takes the next one (dq_slot, k_common.hpp): two launches of one
 // handle that are in flight together (two streams) then draw from different counters.  A launch leaves its set zeroed, so a
@@ -93,7 +104,13 @@ struct DwFastArgs {
     // search (epi_fma.cpp) or the device check failed for a channel.  use_fma() switches a COPY of the block to it.
     const float *A3, *S3;
     const int *Kc3;
-    bool use_fma() { return A3 ? (A = A3, S = S3, Kc = Kc3, magic = 3, true) : false; }
+    EpiPatch patch3;    // the patched accumulators that belong to A3 / S3 / Kc3 (n = 0 for most operators)
+    EpiPatch patch;     // ... in effect for this launch (set by use_fma)
+    // with_patches: the launch's kernel applies `patch` (dwpw_mm, the stage); without, an operator that needs patches has no form
+    bool use_fma(bool with_patches = false) {
+        if (!A3 || (patch3.n != 0 && !with_patches)) return false;
+        return A = A3, S = S3, Kc = Kc3, magic = 3, patch = patch3, true;
+    }
 };
 // depthwise with ONE input channel and up to 8 output channels, any filter / stride (speech op 1)
 struct DwC1Args {
@@ -142,7 +159,11 @@ struct PwArgs {
     int magic, xr;
     const float *A3, *S3; // the single-fma form (see DwFastArgs)
     const int *Kc3;
-    bool use_fma() { return A3 ? (A = A3, S = S3, Kc = Kc3, magic = 3, true) : false; }
+    EpiPatch patch3, patch;
+    bool use_fma(bool with_patches = false) {
+        if (!A3 || (patch3.n != 0 && !with_patches)) return false;
+        return A = A3, S = S3, Kc = Kc3, magic = 3, patch = patch3, true;
+    }
 };
 
 // run-time-geometry kernels (k_rt.hip): any H, W, C
@@ -400,6 +421,7 @@ struct StagePair {
     const float *pwA, *pwS;
     const int *pwK;          // + 0x4B400000, like dwK
     float pw_lo, pw_hi;
+    EpiPatch dwp, pwp;       // mode 3: the two operators' patched accumulators (n = 0: none)
 };
 struct StageArgs {
     const StagePair *pairs;  // [number of pairs], in device memory
@@ -512,8 +534,8 @@ unsigned long long selftest_rounding(int mode, bool u8, float lo, float hi, hipS
 unsigned long long selftest_requant(int mode, bool u8, float A, float S, float lo, float hi, hipStream_t s);
 unsigned long long selftest_cvt_pk(hipStream_t s); // v_cvt_pk_u8_f32 over all 2^32 inputs against the model epi_fma.cpp uses
 // exhaustive device check of the single-fma epilogue of one operator (k_generic.hip); device arrays of n channels
-bool verify_fma_form(const float *A, const float *S, const float *C3, const float *S3, const int *piv, const int *amin, const int *amax, int n,
-                     float lo, float hi, bool u8, unsigned long long *bad, hipStream_t s);
+bool verify_fma_form(const float *A, const float *S, const float *C3, const float *S3, const int *piv, const int *amin, const int *amax,
+                     const int *patchP, const int *patchR, int n, float lo, float hi, bool u8, unsigned long long *bad, hipStream_t s);
 void launch_quantize(const float *in, int8_t *out, size_t n, float scale, float zp_f, bool u8, hipStream_t s);
 void launch_xor80(const int8_t *in, int8_t *out, size_t n, hipStream_t s);
 void launch_dequantize(const int8_t *in, float *out, size_t n, float scale, float zp_f, bool raw_u8, hipStream_t s);

@@ -47,6 +47,10 @@ void h_preprocess_pool(float iscale, int izp, float oscale, int ozp, float *c0, 
 struct FmaForm {
     float S = 0, C = 0;
     int32_t d = 0;
+    // at most ONE accumulator per channel is replaced by its neighbour before the fma (patch_delta = +-1; 0: none): the reference's
+    // own roundings can put a single step one accumulator off every line (epi_fma.cpp)
+    int64_t patch_acc = 0;
+    int32_t patch_delta = 0;
 };
 struct FmaSearchStats {
     int steps = 0;            // steps of the reference staircase inside the reachable accumulator range
@@ -57,7 +61,8 @@ struct FmaSearchStats {
 };
 // off: 128 (i8: the form works in the u8 domain, results are XOR-ed back) or 0 (u8); [lo, hi]: the clamp in T's domain;
 // [amin, amax]: the accumulators this channel can produce (inside (-2^22, 2^22)).  false: no (S', C', d) reproduces the reference on it.
-bool fma_form_search(float A, float S, int off, int lo, int hi, int64_t amin, int64_t amax, FmaForm &out, FmaSearchStats *stats = nullptr);
+bool fma_form_search(float A, float S, int off, int lo, int hi, int64_t amin, int64_t amax, FmaForm &out, FmaSearchStats *stats = nullptr,
+                     bool allow_patch = false);
 int ref_form_eval(float A, float S, int off, int lo, int hi, int64_t acc); // the reference's tail, u8 domain
 int fma_form_eval(const FmaForm &f, int64_t acc);                          // the device's instructions, emulated exactly
 uint64_t fma_form_mismatches(float A, float S, int off, int lo, int hi, int64_t amin, int64_t amax, const FmaForm &f); // exhaustive, host
@@ -127,7 +132,8 @@ size_t op_in_elems(const OpImpl *op);
 size_t op_out_elems(const OpImpl *op);
 const char *op_kernel_name(const OpImpl *op);
 int op_epilogue_mode(const OpImpl *op); // k_common.hpp epilogue mode (0 .. 3) of the operator's own launch; -1: no requantising epilogue of that kind
-bool op_has_fma_epilogue(const OpImpl *op); // the single-fma form (mode 3) was found for every channel and confirmed on the device
+bool op_has_fma_epilogue(const OpImpl *op);
+int op_fma_patches(const OpImpl *op); // patched accumulators of the operator's single-fma form (0 for most); -1: no such form // the single-fma form (mode 3) was found for every channel and confirmed on the device
 void op_set_generic(OpImpl *op, bool generic);
 // fuse the model-boundary quantize (f32 -> T) into this operator if it has an f32-input kernel
 bool op_set_input_quant(OpImpl *op, float scale, int zp, bool u8);
@@ -172,7 +178,8 @@ uint64_t dev_checksum_i8(int device, const int8_t *d_in, size_t n, void *stream)
 uint64_t dev_verify_quant_div(int device, float scale, float rcp, int zp, bool u8);
 uint64_t dev_selftest_epilogue(int device, int mode, bool u8, bool have_as, float A, float S, int lo, int hi);
 // one channel of the single-fma epilogue on the device, every accumulator of [amin, amax] (k_generic.hip verify_fma_form): mismatches
-uint64_t dev_selftest_fma_epilogue(int device, float A, float S, bool u8, int64_t amin, int64_t amax, float S3, float C3, int pivot);
+uint64_t dev_selftest_fma_epilogue(int device, float A, float S, bool u8, int64_t amin, int64_t amax, float S3, float C3, int pivot,
+                                   int64_t patch_acc = 0, int patch_delta = 0);
 uint64_t dev_selftest_cvt_pk(int device);
 int dev_count();
 void dev_require(int device); // throws MF_ERR_NO_DEVICE

@@ -134,7 +134,9 @@ struct OpImpl {
     // ... and mode 3, the single-fma form: found per channel by the host search (epi_fma.cpp) AND confirmed on the device over every
     // reachable accumulator (k_generic.hip verify_fma_form).  The arrays hold C', S', Kc + pivot; the two-rounding constants stay
     // beside them (a fused launch uses mode 3 only if every operator in it has it).
-    bool fma_ok = false;
+    bool fma_ok = false;     // ... for every channel, with at most EPI_PATCH_MAX patched accumulators in all (fma_patch)
+    k::EpiPatch fma_patch{}; // the channels whose line needs ONE accumulator replaced (epi_fma.cpp); n = 0: none
+    bool fma_strict() const { return fma_ok && fma_patch.n == 0; } // what the kernels without patch support need
     DevBuf d_A3, d_S3, d_Kc3;
     std::vector<float> h_A3, h_S3;
     std::vector<int32_t> h_Kc3;
@@ -437,13 +439,22 @@ OpImpl *op_create(int device, const OpSpec &spec) {
         static const bool no_fma = getenv("MF_NO_FMA_EPI") != nullptr; // tests / A-B: keep the two-rounding forms
         if (magic >= 1 && !no_fma && lo == (s.u8 ? 0 : -128) && hi == (s.u8 ? 255 : 127) && all_finite(A) && all_finite(S)) {
             std::vector<float> A3((size_t)s.N), S3((size_t)s.N);
-            std::vector<int32_t> K3((size_t)s.N), piv((size_t)s.N), amn((size_t)s.N), amx((size_t)s.N);
+            std::vector<int32_t> K3((size_t)s.N), piv((size_t)s.N), amn((size_t)s.N), amx((size_t)s.N), pP((size_t)s.N, 0), pR((size_t)s.N, 0);
+            k::EpiPatch patch{};
             bool ok = true;
             int fail_c = -1;
             for (int c = 0; c < s.N && ok; ++c) {
                 FmaForm f;
                 const auto &r = acc_range_c[(size_t)c];
-                ok = fma_form_search(A[(size_t)c], S[(size_t)c], s.u8 ? 0 : 128, lo, hi, r.first, r.second, f);
+                ok = fma_form_search(A[(size_t)c], S[(size_t)c], s.u8 ? 0 : 128, lo, hi, r.first, r.second, f, nullptr, true);
+                if (ok && f.patch_delta != 0) { // this channel's line needs one accumulator replaced by its neighbour
+                    if (patch.n == k::EPI_PATCH_MAX) ok = false; // (more than the kernels' patch list holds: the operator keeps the two-rounding form)
+                    else {
+                        const int32_t P = wrap_add(wrap_add(k::MF_MAGIC_I, (int32_t)f.patch_acc), f.d);
+                        patch.ch[patch.n] = c, patch.P[patch.n] = P, patch.R[patch.n] = P + f.patch_delta, ++patch.n;
+                        pP[(size_t)c] = P, pR[(size_t)c] = P + f.patch_delta;
+                    }
+                }
                 if (!ok) fail_c = c;
                 A3[(size_t)c] = f.C, S3[(size_t)c] = f.S, piv[(size_t)c] = f.d, K3[(size_t)c] = wrap_add(Kc[(size_t)c], f.d);
                 amn[(size_t)c] = (int32_t)r.first, amx[(size_t)c] = (int32_t)r.second;
@@ -451,13 +462,15 @@ OpImpl *op_create(int device, const OpSpec &spec) {
             unsigned long long nbad = 0;
             if (ok) {
                 op->d_A3.upload(A3.data(), A3.size() * 4), op->d_S3.upload(S3.data(), S3.size() * 4), op->d_Kc3.upload(K3.data(), K3.size() * 4);
-                DevBuf d_piv, d_amn, d_amx, d_bad;
+                DevBuf d_piv, d_amn, d_amx, d_bad, d_pP, d_pR;
                 const std::vector<unsigned long long> zero((size_t)s.N, 0ull);
                 d_piv.upload(piv.data(), piv.size() * 4), d_amn.upload(amn.data(), amn.size() * 4), d_amx.upload(amx.data(), amx.size() * 4);
+                d_pP.upload(pP.data(), pP.size() * 4), d_pR.upload(pR.data(), pR.size() * 4);
                 d_bad.upload(zero.data(), zero.size() * 8);
                 std::vector<unsigned long long> bad((size_t)s.N, ~0ull);
                 if (k::verify_fma_form(op->d_A.as<float>(), op->d_S.as<float>(), op->d_A3.as<float>(), op->d_S3.as<float>(), d_piv.as<int>(),
-                                       d_amn.as<int>(), d_amx.as<int>(), s.N, (float)lo, (float)hi, s.u8, (unsigned long long *)d_bad.p, nullptr))
+                                       d_amn.as<int>(), d_amx.as<int>(), d_pP.as<int>(), d_pR.as<int>(), s.N, (float)lo, (float)hi, s.u8,
+                                       (unsigned long long *)d_bad.p, nullptr))
                     MF_HIP(hipMemcpy(bad.data(), d_bad.p, bad.size() * 8, hipMemcpyDeviceToHost));
                 for (int c = 0; c < s.N; ++c)
                     if (bad[(size_t)c]) nbad += bad[(size_t)c], fail_c = c;
@@ -465,8 +478,11 @@ OpImpl *op_create(int device, const OpSpec &spec) {
                 if (!ok) // the host's exact arithmetic and the device disagree: that is a bug in one of them, say so -- and do not use the form
                     fprintf(stderr, "[microflow_amd] single-fma epilogue REJECTED by the device check (%llu accumulators differ, channel %d)\n", nbad, fail_c);
             }
+            if (ok) op->fma_patch = patch;
             if (ok) op->fma_ok = true, op->h_A3 = A3, op->h_S3 = S3, op->h_Kc3 = K3;
-            if (epi_dbg) fprintf(stderr, "[epi] single-fma form: %s%s\n", ok ? "all channels" : "no: channel ", ok ? "" : std::to_string(fail_c).c_str());
+            if (epi_dbg)
+                fprintf(stderr, "[epi] single-fma form: %s%s\n", ok ? ("all channels, " + std::to_string(patch.n) + " patched").c_str() : "no: channel ",
+                        ok ? "" : std::to_string(fail_c).c_str());
         }
         k::ConvArgs &a = op->conv;
         a.H = s.H, a.W = s.W, a.C = s.C, a.N = s.N, a.KH = s.KH, a.KW = s.KW, a.sh = s.sh, a.sw = s.sw;
@@ -705,7 +721,8 @@ OpImpl *op_create(int device, const OpSpec &spec) {
         if (op->fma_ok) { // the single-fma constants beside the two-rounding ones, in the blocks of the kernels that have the form
             op->dwf.A3 = op->pw.A3 = op->d_A3.as<float>(), op->dwf.S3 = op->pw.S3 = op->d_S3.as<float>();
             op->dwf.Kc3 = op->pw.Kc3 = op->d_Kc3.as<int>();
-            if (op->fast == OpImpl::DW_STEM) {
+            op->dwf.patch3 = op->pw.patch3 = op->fma_patch;
+            if (op->fast == OpImpl::DW_STEM && op->fma_strict()) {
                 for (int c = 0; c < 8; ++c) op->stem.A3[c] = op->h_A3[(size_t)c], op->stem.S3[c] = op->h_S3[(size_t)c], op->stem.Kc3[c] = op->h_Kc3[(size_t)c];
                 op->stem.fma_ok = 1;
             }
@@ -826,7 +843,7 @@ const char *op_kernel_name(const OpImpl *op) {
 void op_set_generic(OpImpl *op, bool g) { op->force_generic = g; }
 // the layer-wise kernels that have the single-fma epilogue (k_common.hpp mode 3): the matrix-pipe depthwise, the MFMA pointwise, the stem
 static bool op_runs_fma(const OpImpl *op) {
-    if (!op->fma_ok) return false;
+    if (!op->fma_strict()) return false; // (the layer-wise kernels have no patch support)
     const OpSpec &sp = op->s;
     static const bool stem_valu = [] { const char *e = getenv("MF_STEM_IMPL"); return e && e[0] == 'v'; }();
     return (op->fast == OpImpl::DW_NHWC && dw_taps_on_matrix_pipe() && op->dwf.wmm && k::dw_mm_name(sp.H, sp.W, sp.C, sp.sh)) ||
@@ -837,6 +854,7 @@ int op_epilogue_mode(const OpImpl *op) { // of the operator's own (layer-wise) l
     return op_runs_fma(op) ? 3 : op->magic_mode;
 }
 bool op_has_fma_epilogue(const OpImpl *op) { return op->fma_ok; }
+int op_fma_patches(const OpImpl *op) { return op->fma_ok ? op->fma_patch.n : -1; }
 
 void op_run(OpImpl *op, const int8_t *d_in, size_t batch, int8_t *d_out, void *stream) {
     if (!batch) return;
@@ -1054,10 +1072,12 @@ struct FusedImpl {
 };
 // the pair's argument blocks as the operators hold them (two-rounding constants), and switched to the single-fma form when
 // both operators have it
-static k::DwPwArgs pair_args(const OpImpl *dw, const OpImpl *pw, bool fma) {
+// fma: 0 = the two-rounding constants; 1 = the single-fma form if both operators have it WITHOUT patched accumulators (quads,
+// register-resident pairs); 2 = ... with or without (dwpw_mm, the stage: kernels that apply the patch list)
+static k::DwPwArgs pair_args(const OpImpl *dw, const OpImpl *pw, int fma) {
     k::DwPwArgs a;
     a.dw = dw->dwf, a.pw = pw->pw;
-    if (fma && dw->fma_ok && pw->fma_ok) a.dw.use_fma(), a.pw.use_fma();
+    if ((fma == 1 && dw->fma_strict() && pw->fma_strict()) || (fma == 2 && dw->fma_ok && pw->fma_ok)) a.dw.use_fma(true), a.pw.use_fma(true);
     return a;
 }
 static int pair_mode(const k::DwPwArgs &a) { return std::min(a.dw.magic, a.pw.magic); }
@@ -1455,8 +1475,9 @@ FusedImpl *fused_create(OpImpl *dw, OpImpl *pw) {
     const char *nm = k::dwpw_name(d.H, d.W, d.C, d.sh, q.N);
     if (!nm) return nullptr;
     FusedImpl *f = new FusedImpl{FusedImpl::DWPW, dw, pw, nullptr, {}, {}, nm};
-    f->dwpw = pair_args(dw, pw, true);
+    f->dwpw = pair_args(dw, pw, 2);
     f->epi_mode = pair_mode(f->dwpw);
+    if (f->dwpw.dw.patch.n || f->dwpw.pw.patch.n) f->name = k::dwpw_mm_name(d.H, d.W, d.C, d.sh, q.N); // (the patch list is dwpw_mm's: launch_dwpw routes there)
     return f;
 }
 
@@ -1542,7 +1563,7 @@ FusedImpl *fused_stage_create(FusedImpl *const *pairs, int npairs) {
     for (int i = 0; i < npairs; ++i) {
         const FusedImpl *fp = pairs[i];
         FusedImpl tmp{FusedImpl::DWPW, fp->a, fp->b, nullptr, {}, {}, ""};
-        tmp.dwpw = pair_args(fp->a, fp->b, all_fma);
+        tmp.dwpw = pair_args(fp->a, fp->b, all_fma ? 2 : 0);
         const FusedImpl *f = &tmp;
         k::StagePair &sp = table[(size_t)i];
         // Kc + the bit-pattern offset of requant_t<true> (k_common.hpp), as separate arrays for this kernel
@@ -1565,6 +1586,7 @@ FusedImpl *fused_stage_create(FusedImpl *const *pairs, int npairs) {
         sp.pw_w = s->stage_w.back()->p;
         sp.pwA = f->dwpw.pw.A, sp.pwS = f->dwpw.pw.S, sp.pwK = with_magic(f->dwpw.pw.Kc, q.N);
         sp.pw_lo = f->dwpw.pw.lo_f, sp.pw_hi = f->dwpw.pw.hi_f;
+        sp.dwp = f->dwpw.dw.patch, sp.pwp = f->dwpw.pw.patch;
     }
     s->stage_w.emplace_back(new DevBuf);
     s->stage_w.back()->upload(table.data(), table.size() * sizeof(k::StagePair));
@@ -1702,8 +1724,8 @@ FusedImpl *fused_quad_create(FusedImpl *p1, FusedImpl *p2) {
     const char *nm = k::quad_name(d1.H, d1.W, d1.C, d1.sh, q1.N, d2.H, d2.W, d2.C, d2.sh, q2.N);
     if (!nm) return nullptr;
     // (the single-fma form needs it of all four operators)
-    const bool fma = p1->a->fma_ok && p1->b->fma_ok && p2->a->fma_ok && p2->b->fma_ok;
-    const k::DwPwArgs a = pair_args(p1->a, p1->b, fma), b = pair_args(p2->a, p2->b, fma);
+    const bool fma = p1->a->fma_strict() && p1->b->fma_strict() && p2->a->fma_strict() && p2->b->fma_strict();
+    const k::DwPwArgs a = pair_args(p1->a, p1->b, fma ? 1 : 0), b = pair_args(p2->a, p2->b, fma ? 1 : 0);
     if (!a.dw.wmm || !a.pw.wrr || !b.dw.wmm || !b.pw.wrr) return nullptr;
     if (!a.dw.magic || !a.pw.magic || !b.dw.magic || !b.pw.magic) return nullptr; // bit-pattern epilogues
     FusedImpl *f = new FusedImpl{FusedImpl::QUAD, p1->a, p2->b, nullptr, {}, {}, nm};
@@ -1731,8 +1753,8 @@ FusedImpl *fused_quad_stem_create(OpImpl *stem, FusedImpl *quad) {
     for (int i = 0; i < 10; ++i) f->quad_shape[i] = q[i];
     // five operators, one epilogue mode: the single-fma form if all five have it, else everyone's two-rounding constants
     OpImpl *const *qo = quad->quad_ops;
-    const bool fma = stem->fma_ok && qo[0]->fma_ok && qo[1]->fma_ok && qo[2]->fma_ok && qo[3]->fma_ok;
-    f->quad.a = pair_args(qo[0], qo[1], fma), f->quad.b = pair_args(qo[2], qo[3], fma);
+    const bool fma = stem->fma_strict() && qo[0]->fma_strict() && qo[1]->fma_strict() && qo[2]->fma_strict() && qo[3]->fma_strict();
+    f->quad.a = pair_args(qo[0], qo[1], fma ? 1 : 0), f->quad.b = pair_args(qo[2], qo[3], fma ? 1 : 0);
     k::DwStemArgs sa = stem->stem;
     if (fma) sa.use_fma();
     std::vector<uint32_t> tab(152);
@@ -1861,16 +1883,18 @@ uint64_t dev_selftest_epilogue(int device, int mode, bool u8, bool have_as, floa
     if (r == ~0ull) fail(MF_ERR_HIP, "selftest kernel could not run");
     return r;
 }
-uint64_t dev_selftest_fma_epilogue(int device, float A, float S, bool u8, int64_t amin, int64_t amax, float S3, float C3, int pivot) {
+uint64_t dev_selftest_fma_epilogue(int device, float A, float S, bool u8, int64_t amin, int64_t amax, float S3, float C3, int pivot,
+                                   int64_t patch_acc, int patch_delta) {
     dev_require(device);
     MF_HIP(hipSetDevice(device));
-    DevBuf dA, dS, dC3, dS3, dpiv, dmn, dmx, dbad;
-    const int32_t mn = (int32_t)amin, mx = (int32_t)amax;
+    DevBuf dA, dS, dC3, dS3, dpiv, dmn, dmx, dbad, dpP, dpR;
+    const int32_t mn = (int32_t)amin, mx = (int32_t)amax, pP = patch_delta ? k::MF_MAGIC_I + (int32_t)patch_acc + pivot : 0, pR = pP + patch_delta;
     const unsigned long long zero = 0;
+    dpP.upload(&pP, 4), dpR.upload(&pR, 4);
     dA.upload(&A, 4), dS.upload(&S, 4), dC3.upload(&C3, 4), dS3.upload(&S3, 4), dpiv.upload(&pivot, 4), dmn.upload(&mn, 4), dmx.upload(&mx, 4);
     dbad.upload(&zero, 8);
     unsigned long long bad = ~0ull;
-    if (!k::verify_fma_form(dA.as<float>(), dS.as<float>(), dC3.as<float>(), dS3.as<float>(), dpiv.as<int>(), dmn.as<int>(), dmx.as<int>(), 1,
+    if (!k::verify_fma_form(dA.as<float>(), dS.as<float>(), dC3.as<float>(), dS3.as<float>(), dpiv.as<int>(), dmn.as<int>(), dmx.as<int>(), dpP.as<int>(), dpR.as<int>(), 1,
                             u8 ? 0.0f : -128.0f, u8 ? 255.0f : 127.0f, u8, (unsigned long long *)dbad.p, nullptr))
         fail(MF_ERR_HIP, "selftest kernel could not run");
     MF_HIP(hipMemcpy(&bad, dbad.p, 8, hipMemcpyDeviceToHost));
