@@ -90,27 +90,37 @@ __device__ __forceinline__ int requant_t(int acc, float A, float S, float lo_f, 
 template <int MG> __device__ __forceinline__ void epi_enter() {
     if constexpr (MG == 3) __builtin_amdgcn_s_setreg(0x801 /* hwreg(HW_REG_MODE, 0, 2): FP_ROUND, single precision */, 3u /* toward zero */);
 }
-// Patched accumulators of mode 3 (kernels.hpp EpiPatch).  epi_patch_hits: which entries fall on the four channels c_lane .. c_lane + 3
-// some lane of this wave holds in a tile -- a wave-uniform mask, computed once per tile (or per phase) and zero almost always;
-// epi_patch_apply: the replacement itself, behind a scalar branch on that mask.
-__device__ __forceinline__ uint32_t epi_patch_hits(const EpiPatch &pl, int c_lane) {
-    uint32_t m = 0;
-#pragma unroll
-    for (int e = 0; e < EPI_PATCH_MAX; ++e)
-        if (e < pl.n && __builtin_amdgcn_ballot_w64((unsigned)(pl.ch[e] - c_lane) < 4u) != 0ull) m |= 1u << e;
-    return m;
+// Patched accumulators of mode 3 (kernels.hpp EpiPatchRec): `rec` is the record of the tile the four accumulators belong to (wave-
+// uniform: scalar registers), g the lane's 16-lane group.  P == 0 -- no patched channel in this tile -- is the common case and
+// costs one scalar compare and branch.
+#ifndef MF_EPI_PATCH_KO
+#define MF_EPI_PATCH_KO 0 // 1: knock-out timing experiment (WRONG results where an operator has patched accumulators): no patch code
+#endif
+__device__ __forceinline__ EpiPatchRec epi_patch_load(const EpiPatchRec *tab, int idx) { // a scalar load (idx is wave-uniform)
+    typedef __attribute__((address_space(4))) const EpiPatchRec c_rec;
+    if (MF_EPI_PATCH_KO || !tab) return EpiPatchRec{0, 0};
+    c_rec *t = (c_rec *)(uintptr_t)tab;
+    if (MF_EPI_PATCH_KO == 2) return EpiPatchRec{t[idx].P & 0, t[idx].meta}; // (knock-out 2: the loads and branches, never the replacement)
+    return EpiPatchRec{t[idx].P, t[idx].meta};
 }
-__device__ __forceinline__ void epi_patch_apply(v4i &a, const EpiPatch &pl, uint32_t hits, int c_lane) {
-    if (hits == 0u) return;
-#pragma unroll
-    for (int e = 0; e < EPI_PATCH_MAX; ++e)
-        if (hits & (1u << e)) {
-            const int dc = pl.ch[e] - c_lane, P = pl.P[e], R = pl.R[e];
-            a[0] = (dc == 0 && a[0] == P) ? R : a[0];
-            a[1] = (dc == 1 && a[1] == P) ? R : a[1];
-            a[2] = (dc == 2 && a[2] == P) ? R : a[2];
-            a[3] = (dc == 3 && a[3] == P) ? R : a[3];
+__device__ __forceinline__ void epi_patch_apply(v4i &a, const EpiPatchRec &rec, int g) {
+    if (MF_EPI_PATCH_KO) return;
+    if (__builtin_expect(rec.P != 0, 0)) { // this tile has a patched channel (scalar branch; zero for almost every tile)
+        // ... whose accumulator is P about once in 10^5 values: four compares and one more scalar branch decide that NO lane holds
+        // P in any of its four accumulators; only then does the replacement itself run
+        const bool any = (a[0] == rec.P) | (a[1] == rec.P) | (a[2] == rec.P) | (a[3] == rec.P);
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(any) != 0ull, 0)) {
+            asm volatile("" ::: "memory"); // (keeps the block from being speculated or turned into selects on the common path)
+            const bool grp = g == ((rec.meta >> 2) & 3);
+            const int delta = (rec.meta & 16) ? -1 : 1, reg = rec.meta & 3;
+            // (four selects with a uniform "is this the register" folded in, NOT a switch over the register: hipcc 7.2 was seen to
+            // miscompile the uniform switch here -- every accumulator of the tile came out wrong; scripts/layer_parity.py found it)
+            a[0] += (grp && a[0] == rec.P) ? (reg == 0 ? delta : 0) : 0;
+            a[1] += (grp && a[1] == rec.P) ? (reg == 1 ? delta : 0) : 0;
+            a[2] += (grp && a[2] == rec.P) ? (reg == 2 ? delta : 0) : 0;
+            a[3] += (grp && a[3] == rec.P) ? (reg == 3 ? delta : 0) : 0;
         }
+    }
 }
 template <int MG> __device__ __forceinline__ int4 magic4(int4 k) {
     if constexpr (MG != 0) k.x += MF_MAGIC_I, k.y += MF_MAGIC_I, k.z += MF_MAGIC_I, k.w += MF_MAGIC_I;

@@ -156,10 +156,10 @@ __global__ __launch_bounds__(NTHR, WPE) void dwpw_mm(const int8_t *__restrict__ 
         dS[k] = ((const float4 *)p.dw.S)[ch4];
         dK[k] = magic4<MG>(((const int4 *)p.dw.Kc)[ch4]);
     }
-    // mode 3: which of the operators' patched accumulators (kernels.hpp EpiPatch; none, for most operators) fall on this wave's tiles
-    uint32_t dhit[QW], chit[TB > 0 ? TB : 1];
+    // mode 3: the patched channel (kernels.hpp EpiPatchRec; none, for most operators) of each of this wave's tiles
+    EpiPatchRec dpr[QW], cpr[TB > 0 ? TB : 1];
 #pragma unroll
-    for (int k = 0; k < QW; ++k) dhit[k] = MG == 3 ? epi_patch_hits(p.dw.patch, 4 * (PAIR ? (g & 1) : 4 * (q0 + k * NWAVE) + g)) : 0u;
+    for (int k = 0; k < QW; ++k) dpr[k] = MG == 3 && !PAIR ? epi_patch_load(p.dw.patch, q0 + k * NWAVE) : EpiPatchRec{0, 0};
 
     // ---- pointwise per-lane constants ----
     const int pcol = lane & 15, pg = lane >> 4;
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(NTHR, WPE) void dwpw_mm(const int8_t *__restrict__ 
             cA[tt] = *(const float4 *)(p.pw.A + ch);
             cS[tt] = *(const float4 *)(p.pw.S + ch);
             cK[tt] = magic4<MG>(*(const int4 *)(p.pw.Kc + ch));
-            chit[tt] = MG == 3 ? epi_patch_hits(p.pw.patch, ch) : 0u;
+            cpr[tt] = MG == 3 ? epi_patch_load(p.pw.patch, blk * TB + tt) : EpiPatchRec{0, 0};
         }
     }
     __syncthreads(); // halo fill complete before any DMA lands
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(NTHR, WPE) void dwpw_mm(const int8_t *__restrict__ 
 #pragma unroll
                 for (int u = 0; u < UB; ++u) {
                     const int k = (t0 + u) / NU;
-                    if constexpr (MG == 3) epi_patch_apply(acc[u], p.dw.patch, dhit[k], 4 * (PAIR ? (g & 1) : 4 * (q0 + k * NWAVE) + g));
+                    if constexpr (MG == 3 && !PAIR) epi_patch_apply(acc[u], dpr[k], g);
                     const uint32_t d = requant_pack4<MG, XR4>(acc[u][0], acc[u][1], acc[u][2], acc[u][3], dA[k], dS[k], p.dw.lo_f, p.dw.hi_f);
                     const int moff = moff_of(t0 + u);
                     if constexpr (UX * CX != OWC) { // the column grid overhangs the row: those lanes have no pixel
@@ -335,7 +335,7 @@ __global__ __launch_bounds__(NTHR, WPE) void dwpw_mm(const int8_t *__restrict__ 
 #pragma unroll
                     for (int ks = 0; ks < KS; ++ks)
                         acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(Aw[q][tt][ks], B[ks], acc, 0, 0, 0);
-                    if constexpr (MG == 3) epi_patch_apply(acc, p.pw.patch, chit[tt], blk * NB + pg * (NB / 4) + 4 * tt);
+                    if constexpr (MG == 3) epi_patch_apply(acc, cpr[tt], pg);
                     packed[tt] = requant_pack4<MG, XR4>(acc[0], acc[1], acc[2], acc[3], cA[tt], cS[tt], p.pw.lo_f, p.pw.hi_f);
                 }
                 if constexpr (XPOSE) {
@@ -726,7 +726,7 @@ const char *dwpw_rr_name(int H, int W, int C, int S, int N) {
 bool launch_dwpw_rr(int H, int W, int C, int S, int N, const int8_t *in, int8_t *out, const DwPwArgs &a, int batch,
                     hipStream_t s) {
     if (!a.dw.wmm || !a.pw.wrr) return false;
-    if (a.dw.patch.n != 0 || a.pw.patch.n != 0) return false; // (patched accumulators: dwpw_mm's job)
+    if (a.dw.patch || a.pw.patch) return false; // (patched accumulators: dwpw_mm's job)
     static const int alt = [] { const char *e = getenv("MF_DWRR_ALT"); return e ? atoi(e) : -1; }();
     if (alt >= 0) { // tuning candidates, see MF_DWRR_ALT_SHAPES
         int idx = 0;

@@ -175,15 +175,6 @@ __global__ __launch_bounds__(NTHR, 4) void stage_6x6x128(const int8_t *__restric
         }
     };
 
-    // a patch list out of the pair table (scalar loads, like the rest of the table)
-    typedef __attribute__((address_space(4))) const EpiPatch c_patch;
-    auto ldpatch = [](c_patch *src) {
-        EpiPatch r;
-        r.n = src->n;
-#pragma unroll
-        for (int e = 0; e < EPI_PATCH_MAX; ++e) r.ch[e] = src->ch[e], r.P[e] = src->P[e], r.R[e] = src->R[e];
-        return r;
-    };
     DynSteps dq;
     dq.init(lds + OFF_Q, p.queue, tid, p.qcfg);
     __syncthreads(); // halo fill complete before any DMA lands
@@ -224,9 +215,10 @@ __global__ __launch_bounds__(NTHR, 4) void stage_6x6x128(const int8_t *__restric
             // ---------------- depthwise: tile -> MID ----------------
             {
                 const float lo = pairs[rep].dw_lo, hi = pairs[rep].dw_hi;
-                // mode 3: the depthwise operator's patched accumulators that fall on this wave's 16 channels (none, almost always)
-                const EpiPatch dpl = ldpatch(&pairs[rep].dwp);
-                const uint32_t dhit = MG == 3 ? epi_patch_hits(dpl, 16 * wave + 4 * g) : 0u;
+                // mode 3: the depthwise operator's patched channel among this wave's 16 (none, almost always): one scalar load
+                // (two records per wave: two patched channels may share a 16-channel group)
+                const EpiPatchRec dpr = MG == 3 ? epi_patch_load(p.patch_tab, ((2 * rep) * 8 + wave) * 2) : EpiPatchRec{0, 0};
+                const EpiPatchRec dpr2 = MG == 3 ? epi_patch_load(p.patch_tab, ((2 * rep) * 8 + wave) * 2 + 1) : EpiPatchRec{0, 0};
                 const int mb = mid + mb6;
                 auto toff = [](int u) { return (u / 3) * 2 * ROW6 + (u % 3) * 2 * 128; };
                 auto moff = [](int u) { return ((u / 3) * 12 + (u % 3) * 2) * 16; };
@@ -241,9 +233,10 @@ __global__ __launch_bounds__(NTHR, 4) void stage_6x6x128(const int8_t *__restric
                     Taps t3 = t2;
                     if (u + 2 < 9) t3 = dw_load(tb6 + toff(u + 2));
                     v4i nxt = {wd.k.x, wd.k.y, wd.k.z, wd.k.w};
-                    if constexpr (MG == 3) epi_patch_apply(acc, dpl, dhit, 16 * wave + 4 * g);
                     __builtin_amdgcn_sched_barrier(0);
                     if (more) nxt = __builtin_amdgcn_mfma_i32_16x16x64_i8(wd.A[0], t2.b[0], nxt, 0, 0, 0);
+                    // (behind the next unit's first MFMA, like the epilogue itself: acc's own MFMAs have had their latency by now)
+                    if constexpr (MG == 3) epi_patch_apply(acc, dpr, g), epi_patch_apply(acc, dpr2, g);
                     const float r0 = epi_value<MG>(acc[0], wd.a.x, wd.s.x, lo, hi);
                     const float r1 = epi_value<MG>(acc[1], wd.a.y, wd.s.y, lo, hi);
                     __builtin_amdgcn_sched_barrier(0);
@@ -277,8 +270,8 @@ __global__ __launch_bounds__(NTHR, 4) void stage_6x6x128(const int8_t *__restric
             // ---------------- pointwise: MID -> tile (last pair: -> plain output in region A) ----------------
             {
                 const float lo = pairs[rep].pw_lo, hi = pairs[rep].pw_hi;
-                const EpiPatch ppl = ldpatch(&pairs[rep].pwp);
-                const uint32_t phit = MG == 3 ? epi_patch_hits(ppl, 16 * wave + 4 * pg) : 0u;
+                const EpiPatchRec ppr = MG == 3 ? epi_patch_load(p.patch_tab, ((2 * rep + 1) * 8 + wave) * 2) : EpiPatchRec{0, 0};
+                const EpiPatchRec ppr2 = MG == 3 ? epi_patch_load(p.patch_tab, ((2 * rep + 1) * 8 + wave) * 2 + 1) : EpiPatchRec{0, 0};
                 const int rb = mid + pg * PLANE6 + pcol * 16;
                 v4i c0 = *(const v4i *)(lds + rb), c1 = *(const v4i *)(lds + rb + 4 * PLANE6);
                 v4i acc = {wp.k.x, wp.k.y, wp.k.z, wp.k.w};
@@ -294,9 +287,9 @@ __global__ __launch_bounds__(NTHR, 4) void stage_6x6x128(const int8_t *__restric
                         e1 = *(const v4i *)(lds + rb + 4 * PLANE6 + (c + 2) * 256);
                     }
                     v4i nxt = {wp.k.x, wp.k.y, wp.k.z, wp.k.w};
-                    if constexpr (MG == 3) epi_patch_apply(acc, ppl, phit, 16 * wave + 4 * pg);
                     __builtin_amdgcn_sched_barrier(0);
                     if (more) nxt = __builtin_amdgcn_mfma_i32_16x16x64_i8(wp.A[0], c0, nxt, 0, 0, 0);
+                    if constexpr (MG == 3) epi_patch_apply(acc, ppr, pg), epi_patch_apply(acc, ppr2, pg);
                     const float r0 = epi_value<MG>(acc[0], wp.a.x, wp.s.x, lo, hi);
                     const float r1 = epi_value<MG>(acc[1], wp.a.y, wp.s.y, lo, hi);
                     __builtin_amdgcn_sched_barrier(0);

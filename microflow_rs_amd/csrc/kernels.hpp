@@ -71,16 +71,26 @@ struct SoftmaxArgs {
     int xr;
 };
 // Epilogue mode 3 with patched accumulators (epi_fma.cpp): for up to EPI_PATCH_MAX channels of an operator ONE accumulator bit
-// pattern P is replaced by R = P +- 1 before the fma.  Lives in the kernel arguments (scalar registers): the kernels that support it
-// (dwpw_mm, stage_6x6x128) test per tile, with scalar instructions, whether an entry falls on it -- almost never.
+// pattern P is replaced by R = P +- 1 before the fma.  EpiPatch is the operator's list (host side); the kernels that support it
+// (dwpw_mm, stage_6x6x128) get it as a table of EpiPatchRec indexed by THEIR tiles -- one record per 16-channel tile of a wave, at
+// most one patched channel per tile (an operator with two in one tile keeps the two-rounding form in that kernel) -- which a wave
+// reads with one scalar load per tile; the replacement is two VALU instructions behind a scalar branch on P != 0.
 constexpr int MF_MAGIC_I = 0x4B400000; // the bit-pattern accumulators' offset: the f32 1.5 * 2^23 (k_common.hpp requant_t)
 constexpr int EPI_PATCH_MAX = 4;
 struct EpiPatch {
     int n;                      // entries in use (0: none -- the only value the other mode-3 kernels accept)
     int ch[EPI_PATCH_MAX];      // output channel
     int P[EPI_PATCH_MAX];       // 0x4B400000 + accumulator + pivot: the bit pattern to replace ...
-    int R[EPI_PATCH_MAX];       // ... and its replacement
+    int R[EPI_PATCH_MAX];       // ... and its replacement (P + 1 or P - 1)
 };
+struct EpiPatchRec {            // one tile's patched channel, as the kernel sees it
+    int P;                      // the bit pattern to replace; 0: nothing in this tile
+    int meta;                   // bits 0..1: which of a lane's four accumulators; bits 2..3: which 16-lane group holds the channel;
+                                // bit 4: the replacement is P - 1 (else P + 1)
+};
+static inline EpiPatchRec epi_patch_rec(int P, int R, int reg, int lane_group) {
+    return EpiPatchRec{P, (reg & 3) | (lane_group & 3) << 2 | (R < P ? 16 : 0)};
+}
 constexpr int DYNQ_INTS = 8 * 32 + 32; // = DynSteps::INTS (k_common.hpp): the counters of one dynamic step queue
 // An operator owns DYNQ_RING counter sets and every launch takes the next one (dq_slot, k_common.hpp): two launches of one
 // handle that are in flight together (two streams) then draw from different counters.  A launch leaves its set zeroed, so a
@@ -104,12 +114,13 @@ struct DwFastArgs {
     // search (epi_fma.cpp) or the device check failed for a channel.  use_fma() switches a COPY of the block to it.
     const float *A3, *S3;
     const int *Kc3;
-    EpiPatch patch3;    // the patched accumulators that belong to A3 / S3 / Kc3 (n = 0 for most operators)
-    EpiPatch patch;     // ... in effect for this launch (set by use_fma)
-    // with_patches: the launch's kernel applies `patch` (dwpw_mm, the stage); without, an operator that needs patches has no form
+    int npatch3;            // patched accumulators that come with A3 / S3 / Kc3 (0 for most operators)
+    const EpiPatchRec *patch; // (device) this launch's patch table, indexed by the kernel's depthwise tiles (16-channel groups), or nullptr
+    // with_patches: the launch's kernel applies a patch table, which the launch builder provides (ops.hip); without, an operator
+    // that needs patches has no single-fma form
     bool use_fma(bool with_patches = false) {
-        if (!A3 || (patch3.n != 0 && !with_patches)) return false;
-        return A = A3, S = S3, Kc = Kc3, magic = 3, patch = patch3, true;
+        if (!A3 || (npatch3 != 0 && !with_patches)) return false;
+        return A = A3, S = S3, Kc = Kc3, magic = 3, true;
     }
 };
 // depthwise with ONE input channel and up to 8 output channels, any filter / stride (speech op 1)
@@ -159,10 +170,11 @@ struct PwArgs {
     int magic, xr;
     const float *A3, *S3; // the single-fma form (see DwFastArgs)
     const int *Kc3;
-    EpiPatch patch3, patch;
+    int npatch3;
+    const EpiPatchRec *patch; // (device) indexed by the kernel's pointwise tiles (dwpw_mm: blk * TB + tt), or nullptr
     bool use_fma(bool with_patches = false) {
-        if (!A3 || (patch3.n != 0 && !with_patches)) return false;
-        return A = A3, S = S3, Kc = Kc3, magic = 3, patch = patch3, true;
+        if (!A3 || (npatch3 != 0 && !with_patches)) return false;
+        return A = A3, S = S3, Kc = Kc3, magic = 3, true;
     }
 };
 
@@ -421,7 +433,6 @@ struct StagePair {
     const float *pwA, *pwS;
     const int *pwK;          // + 0x4B400000, like dwK
     float pw_lo, pw_hi;
-    EpiPatch dwp, pwp;       // mode 3: the two operators' patched accumulators (n = 0: none)
 };
 struct StageArgs {
     const StagePair *pairs;  // [number of pairs], in device memory
@@ -430,7 +441,8 @@ struct StageArgs {
     int *queue;              // dynamic step queue (k_common.hpp DynSteps)
     int qcfg;                // set by the launcher (dq_config)
     int nrep;                // number of pairs in the run (set by the launcher)
-    int mode;                // epilogue mode of the whole run (k_common.hpp): 1, or 2 when every clamp is the type's range
+    int mode;                // epilogue mode of the whole run (k_common.hpp): 1, or 2 when every clamp is the type's range; 3: single fma
+    const EpiPatchRec *patch_tab; // mode 3: [pair][depthwise, pointwise][wave = 16-channel group][2] (device), or nullptr: no patched channel
 };
 
 // shapes with a compiled fast depthwise kernel: H, W, C, stride, images per step, threads per

@@ -721,7 +721,7 @@ OpImpl *op_create(int device, const OpSpec &spec) {
         if (op->fma_ok) { // the single-fma constants beside the two-rounding ones, in the blocks of the kernels that have the form
             op->dwf.A3 = op->pw.A3 = op->d_A3.as<float>(), op->dwf.S3 = op->pw.S3 = op->d_S3.as<float>();
             op->dwf.Kc3 = op->pw.Kc3 = op->d_Kc3.as<int>();
-            op->dwf.patch3 = op->pw.patch3 = op->fma_patch;
+            op->dwf.npatch3 = op->pw.npatch3 = op->fma_patch.n;
             if (op->fast == OpImpl::DW_STEM && op->fma_strict()) {
                 for (int c = 0; c < 8; ++c) op->stem.A3[c] = op->h_A3[(size_t)c], op->stem.S3[c] = op->h_S3[(size_t)c], op->stem.Kc3[c] = op->h_Kc3[(size_t)c];
                 op->stem.fma_ok = 1;
@@ -1081,6 +1081,18 @@ static k::DwPwArgs pair_args(const OpImpl *dw, const OpImpl *pw, int fma) {
     return a;
 }
 static int pair_mode(const k::DwPwArgs &a) { return std::min(a.dw.magic, a.pw.magic); }
+// An operator's patch list as the table a kernel reads: one EpiPatchRec per tile, `tile_of(channel, reg, lane_group)` = the tile
+// index of the channel in that kernel (and which of a lane's four accumulators / which 16-lane group hold it).  false: two patched
+// channels share a tile -- the kernel's record holds one -- so this launch cannot use the single-fma form.
+template <typename F> static bool patch_table(const k::EpiPatch &pl, std::vector<k::EpiPatchRec> &tab, size_t base, F tile_of) {
+    for (int e = 0; e < pl.n; ++e) {
+        int reg = 0, grp = 0;
+        const int t = tile_of(pl.ch[e], reg, grp);
+        if (t < 0 || base + (size_t)t >= tab.size() || tab[base + (size_t)t].P != 0) return false;
+        tab[base + (size_t)t] = k::epi_patch_rec(pl.P[e], pl.R[e], reg, grp);
+    }
+    return true;
+}
 
 // ---- run-time-geometry chains (k_chain.hip) ----
 static bool chain_enabled() {
@@ -1476,8 +1488,28 @@ FusedImpl *fused_create(OpImpl *dw, OpImpl *pw) {
     if (!nm) return nullptr;
     FusedImpl *f = new FusedImpl{FusedImpl::DWPW, dw, pw, nullptr, {}, {}, nm};
     f->dwpw = pair_args(dw, pw, 2);
+    if (pair_mode(f->dwpw) == 3 && (dw->fma_patch.n || pw->fma_patch.n)) {
+        // patched accumulators: dwpw_mm applies them (launch_dwpw routes there), from one record per tile.  Its depthwise tiles are the
+        // aligned 16-channel groups; pointwise tile (blk, tt) holds channels blk NB + pg NB / 4 + 4 tt + i in lane group pg (k_fused_mm.hip)
+        const int NB = q.N < 64 ? q.N : 64, TB = NB / 16, NQ = d.C / 16;
+        std::vector<k::EpiPatchRec> tab((size_t)NQ + (size_t)(q.N / NB) * TB, k::EpiPatchRec{0, 0});
+        bool ok = d.C >= 16 && patch_table(dw->fma_patch, tab, 0, [&](int ch, int &reg, int &grp) { return reg = ch & 3, grp = (ch >> 2) & 3, ch >> 4; });
+        ok = ok && patch_table(pw->fma_patch, tab, (size_t)NQ, [&](int ch, int &reg, int &grp) {
+                 const int rel = ch % NB, within = rel % (NB / 4);
+                 return reg = within & 3, grp = rel / (NB / 4), (ch / NB) * TB + within / 4;
+             });
+        if (ok) {
+            f->stage_w.emplace_back(new DevBuf);
+            f->stage_w.back()->upload(tab.data(), tab.size() * sizeof(k::EpiPatchRec));
+            const k::EpiPatchRec *t = f->stage_w.back()->as<k::EpiPatchRec>();
+            if (dw->fma_patch.n) f->dwpw.dw.patch = t;
+            if (pw->fma_patch.n) f->dwpw.pw.patch = t + NQ;
+            f->name = k::dwpw_mm_name(d.H, d.W, d.C, d.sh, q.N);
+        } else {
+            f->dwpw = pair_args(dw, pw, 1); // (both strict, or the two-rounding forms)
+        }
+    }
     f->epi_mode = pair_mode(f->dwpw);
-    if (f->dwpw.dw.patch.n || f->dwpw.pw.patch.n) f->name = k::dwpw_mm_name(d.H, d.W, d.C, d.sh, q.N); // (the patch list is dwpw_mm's: launch_dwpw routes there)
     return f;
 }
 
@@ -1557,6 +1589,21 @@ FusedImpl *fused_stage_create(FusedImpl *const *pairs, int npairs) {
     }
     bool all_fma = true; // the single-fma form needs it of every operator of the run
     for (int i = 0; i < npairs; ++i) all_fma = all_fma && pairs[i]->a->fma_ok && pairs[i]->b->fma_ok;
+    // ... and their patched accumulators as the kernel's table: [pair][depthwise, pointwise][wave = aligned 16-channel group][2]
+    std::vector<k::EpiPatchRec> ptab((size_t)npairs * 32, k::EpiPatchRec{0, 0});
+    int npatched = 0;
+    for (int i = 0; i < npairs && all_fma; ++i)
+        for (int ph = 0; ph < 2 && all_fma; ++ph) {
+            const k::EpiPatch &pl = (ph ? pairs[i]->b : pairs[i]->a)->fma_patch;
+            for (int e = 0; e < pl.n && all_fma; ++e) {
+                const int ch = pl.ch[e];
+                k::EpiPatchRec *slot = &ptab[(((size_t)i * 2 + ph) * 8 + (size_t)(ch >> 4)) * 2];
+                if (slot[0].P != 0) ++slot;
+                if (ch >= 128 || slot->P != 0) all_fma = false; // (three in one group: the kernel's table holds two)
+                else *slot = k::epi_patch_rec(pl.P[e], pl.R[e], ch & 3, (ch >> 2) & 3);
+            }
+            npatched += pl.n;
+        }
     std::unique_ptr<FusedImpl> s(new FusedImpl{FusedImpl::STAGE, pairs[0]->a, pairs[npairs - 1]->b, nullptr, {}, {}, nm});
     s->stage_pairs = npairs;
     std::vector<k::StagePair> table((size_t)npairs);
@@ -1586,7 +1633,12 @@ FusedImpl *fused_stage_create(FusedImpl *const *pairs, int npairs) {
         sp.pw_w = s->stage_w.back()->p;
         sp.pwA = f->dwpw.pw.A, sp.pwS = f->dwpw.pw.S, sp.pwK = with_magic(f->dwpw.pw.Kc, q.N);
         sp.pw_lo = f->dwpw.pw.lo_f, sp.pw_hi = f->dwpw.pw.hi_f;
-        sp.dwp = f->dwpw.dw.patch, sp.pwp = f->dwpw.pw.patch;
+    }
+    s->stage.patch_tab = nullptr;
+    if (all_fma && npatched > 0) {
+        s->stage_w.emplace_back(new DevBuf);
+        s->stage_w.back()->upload(ptab.data(), ptab.size() * sizeof(k::EpiPatchRec));
+        s->stage.patch_tab = s->stage_w.back()->as<k::EpiPatchRec>();
     }
     s->stage_w.emplace_back(new DevBuf);
     s->stage_w.back()->upload(table.data(), table.size() * sizeof(k::StagePair));

@@ -268,6 +268,35 @@ def test_person_detect_launch_modes_and_parity(O):
     assert np.array_equal(np.asarray(got).reshape(want.shape), want)
 
 
+@pytest.mark.gpu
+def test_patched_accumulators_occur_and_are_replaced_in_the_fused_kernels():
+    """The kernels' patch path (k_common.hpp epi_patch_apply: which tile, lane group and register hold the patched channel) only
+    runs when a patched channel's accumulator takes its one special value -- about once in 10^5 values.  At batch 49 152 every
+    patched channel of ops 10 .. 22 sees 1.7 .. 7 million accumulators, so the value occurs dozens of times per channel; the tensors
+    behind the patched operators are compared in full, on the device, between the fused launches (dwpw_mm, the stage: single-fma
+    form with patches) and the layer-wise kernels (two-rounding form for these operators, pinned to the oracle by the other tests).
+    A patch applied to the wrong lanes, or not at all, shows as single bytes off by one (the test's teeth were checked by building
+    with -DMF_EPI_PATCH_KO=1, which compiles the patch code out: it fails then)."""
+    import torch
+    import microflow_rs_amd as mf
+    from microflow_rs_amd.model import synth_i8 as synth_dev
+    from microflow_rs_amd.synth import SEED
+    B = 49152
+    m = mf.Model(model_path("person_detect"))
+    m.prepare(B)
+    if not ROUTING_SWITCHED:
+        assert m.op_epilogue_mode(9) == 3 and m.op_epilogue_mode(13) == 3
+    x = synth_dev(SEED + 3, 7 * m.input_elems, B * m.input_elems).reshape(B, -1)
+    for last in (10, 14, 16, 17, 18, 19, 20, 22):
+        m.set_fusion(True)
+        a = m.run_until(x, last).clone()
+        m.set_fusion(False)
+        b = m.run_until(x, last)
+        m.set_fusion(True)
+        ndiff = int((a != b).sum().item())
+        assert ndiff == 0, (last, ndiff)
+
+
 _CHILD = r"""
 import sys, numpy as np
 sys.path.insert(0, {root!r})
