@@ -29,6 +29,8 @@
 // separate launches they replace.
 #include "k_common.hpp"
 
+#include <type_traits>
+
 #include <cstdio>
 
 #ifndef MF_STAGE_DIAG
@@ -213,12 +215,15 @@ __global__ __launch_bounds__(NTHR, 4) void stage_6x6x128(const int8_t *__restric
             const PwW wp = load_pw(rep);                // lands during the depthwise phase
 #endif
             // ---------------- depthwise: tile -> MID ----------------
-            {
+            // PR: where this wave's patched channel sits (mode 3, kernels.hpp EpiPatchRec) -- -1: none (almost every wave and
+            // operator); 0 .. 3: that accumulator of a lane, one compare + select + add per unit, straight-line; 4: two patched
+            // channels in this wave's 16 (epi_patch_apply).  A compile-time constant per copy of the loop: the hand-interleaved
+            // MFMA / epilogue schedule below does not survive a branch inside the loop (0.47 -> 0.56 ms with a never-taken one).
+            auto dw_phase = [&](auto pr_tag, const EpiPatchRec &dpr, const EpiPatchRec &dpr2) {
+                constexpr int PR = decltype(pr_tag)::value;
                 const float lo = pairs[rep].dw_lo, hi = pairs[rep].dw_hi;
-                // mode 3: the depthwise operator's patched channel among this wave's 16 (none, almost always): one scalar load
-                // (two records per wave: two patched channels may share a 16-channel group)
-                const EpiPatchRec dpr = MG == 3 ? epi_patch_load(p.patch_tab, ((2 * rep) * 8 + wave) * 2) : EpiPatchRec{0, 0};
-                const EpiPatchRec dpr2 = MG == 3 ? epi_patch_load(p.patch_tab, ((2 * rep) * 8 + wave) * 2 + 1) : EpiPatchRec{0, 0};
+                const bool pgrp = g == ((dpr.meta >> 2) & 3);
+                const int pdelta = (dpr.meta & 16) ? -1 : 1;
                 const int mb = mid + mb6;
                 auto toff = [](int u) { return (u / 3) * 2 * ROW6 + (u % 3) * 2 * 128; };
                 auto moff = [](int u) { return ((u / 3) * 12 + (u % 3) * 2) * 16; };
@@ -236,7 +241,8 @@ __global__ __launch_bounds__(NTHR, 4) void stage_6x6x128(const int8_t *__restric
                     __builtin_amdgcn_sched_barrier(0);
                     if (more) nxt = __builtin_amdgcn_mfma_i32_16x16x64_i8(wd.A[0], t2.b[0], nxt, 0, 0, 0);
                     // (behind the next unit's first MFMA, like the epilogue itself: acc's own MFMAs have had their latency by now)
-                    if constexpr (MG == 3) epi_patch_apply(acc, dpr, g), epi_patch_apply(acc, dpr2, g);
+                    if constexpr (PR >= 0 && PR < 4) acc[PR] += (pgrp && acc[PR] == dpr.P) ? pdelta : 0;
+                    else if constexpr (PR == 4) epi_patch_apply(acc, dpr, g), epi_patch_apply(acc, dpr2, g);
                     const float r0 = epi_value<MG>(acc[0], wd.a.x, wd.s.x, lo, hi);
                     const float r1 = epi_value<MG>(acc[1], wd.a.y, wd.s.y, lo, hi);
                     __builtin_amdgcn_sched_barrier(0);
@@ -253,6 +259,19 @@ __global__ __launch_bounds__(NTHR, 4) void stage_6x6x128(const int8_t *__restric
                     __builtin_amdgcn_sched_barrier(0);
                     acc = nxt, t2 = t3;
                 }
+            };
+            if constexpr (MG == 3) { // one scalar load per record; the copy of the loop is chosen by a chain of scalar branches
+                const EpiPatchRec dpr = epi_patch_load(p.patch_tab, ((2 * rep) * 8 + wave) * 2);
+                const EpiPatchRec dpr2 = epi_patch_load(p.patch_tab, ((2 * rep) * 8 + wave) * 2 + 1);
+                const int sel = dpr2.P != 0 ? 4 : (dpr.P != 0 ? (dpr.meta & 3) : -1);
+                if (sel < 0) dw_phase(std::integral_constant<int, -1>{}, dpr, dpr2);
+                else if (sel == 0) dw_phase(std::integral_constant<int, 0>{}, dpr, dpr2);
+                else if (sel == 1) dw_phase(std::integral_constant<int, 1>{}, dpr, dpr2);
+                else if (sel == 2) dw_phase(std::integral_constant<int, 2>{}, dpr, dpr2);
+                else if (sel == 3) dw_phase(std::integral_constant<int, 3>{}, dpr, dpr2);
+                else dw_phase(std::integral_constant<int, 4>{}, dpr, dpr2);
+            } else {
+                dw_phase(std::integral_constant<int, -1>{}, EpiPatchRec{0, 0}, EpiPatchRec{0, 0});
             }
             MF_TR(1 + 3 * rep);
 #if MF_STAGE_KO & 8
@@ -268,10 +287,11 @@ __global__ __launch_bounds__(NTHR, 4) void stage_6x6x128(const int8_t *__restric
             }
             if (!((MF_STAGE_KO & 16) && ko_steps > 0)) wd = load_dw(last ? 0 : rep + 1); // the next depthwise's operands land during the pointwise phase
             // ---------------- pointwise: MID -> tile (last pair: -> plain output in region A) ----------------
-            {
+            auto pw_phase = [&](auto pr_tag, const EpiPatchRec &ppr, const EpiPatchRec &ppr2) { // (PR as in dw_phase)
+                constexpr int PR = decltype(pr_tag)::value;
                 const float lo = pairs[rep].pw_lo, hi = pairs[rep].pw_hi;
-                const EpiPatchRec ppr = MG == 3 ? epi_patch_load(p.patch_tab, ((2 * rep + 1) * 8 + wave) * 2) : EpiPatchRec{0, 0};
-                const EpiPatchRec ppr2 = MG == 3 ? epi_patch_load(p.patch_tab, ((2 * rep + 1) * 8 + wave) * 2 + 1) : EpiPatchRec{0, 0};
+                const bool pgrp = pg == ((ppr.meta >> 2) & 3);
+                const int pdelta = (ppr.meta & 16) ? -1 : 1;
                 const int rb = mid + pg * PLANE6 + pcol * 16;
                 v4i c0 = *(const v4i *)(lds + rb), c1 = *(const v4i *)(lds + rb + 4 * PLANE6);
                 v4i acc = {wp.k.x, wp.k.y, wp.k.z, wp.k.w};
@@ -289,7 +309,8 @@ __global__ __launch_bounds__(NTHR, 4) void stage_6x6x128(const int8_t *__restric
                     v4i nxt = {wp.k.x, wp.k.y, wp.k.z, wp.k.w};
                     __builtin_amdgcn_sched_barrier(0);
                     if (more) nxt = __builtin_amdgcn_mfma_i32_16x16x64_i8(wp.A[0], c0, nxt, 0, 0, 0);
-                    if constexpr (MG == 3) epi_patch_apply(acc, ppr, pg), epi_patch_apply(acc, ppr2, pg);
+                    if constexpr (PR >= 0 && PR < 4) acc[PR] += (pgrp && acc[PR] == ppr.P) ? pdelta : 0;
+                    else if constexpr (PR == 4) epi_patch_apply(acc, ppr, pg), epi_patch_apply(acc, ppr2, pg);
                     const float r0 = epi_value<MG>(acc[0], wp.a.x, wp.s.x, lo, hi);
                     const float r1 = epi_value<MG>(acc[1], wp.a.y, wp.s.y, lo, hi);
                     __builtin_amdgcn_sched_barrier(0);
@@ -306,6 +327,19 @@ __global__ __launch_bounds__(NTHR, 4) void stage_6x6x128(const int8_t *__restric
                     __builtin_amdgcn_sched_barrier(0);
                     acc = nxt, c0 = e0, c1 = e1;
                 }
+            };
+            if constexpr (MG == 3) {
+                const EpiPatchRec ppr = epi_patch_load(p.patch_tab, ((2 * rep + 1) * 8 + wave) * 2);
+                const EpiPatchRec ppr2 = epi_patch_load(p.patch_tab, ((2 * rep + 1) * 8 + wave) * 2 + 1);
+                const int sel = ppr2.P != 0 ? 4 : (ppr.P != 0 ? (ppr.meta & 3) : -1);
+                if (sel < 0) pw_phase(std::integral_constant<int, -1>{}, ppr, ppr2);
+                else if (sel == 0) pw_phase(std::integral_constant<int, 0>{}, ppr, ppr2);
+                else if (sel == 1) pw_phase(std::integral_constant<int, 1>{}, ppr, ppr2);
+                else if (sel == 2) pw_phase(std::integral_constant<int, 2>{}, ppr, ppr2);
+                else if (sel == 3) pw_phase(std::integral_constant<int, 3>{}, ppr, ppr2);
+                else pw_phase(std::integral_constant<int, 4>{}, ppr, ppr2);
+            } else {
+                pw_phase(std::integral_constant<int, -1>{}, EpiPatchRec{0, 0}, EpiPatchRec{0, 0});
             }
             MF_TR(3 + 3 * rep);
             // NO barrier here (see the header): the next depthwise of this wave reads only what this wave has written
