@@ -430,7 +430,11 @@ struct DynSteps {
     // Call before the kernel's first __syncthreads().
     __device__ __forceinline__ void init(uint8_t *lds_slot, int *counters, int tid, int cfg) {
         slot = (int *)lds_slot, ctr = counters, step = blockIdx.x, nxt = blockIdx.x + gridDim.x, nn = 0, it = 0, fetched = 0;
-        K = cfg & 0xff, nheads = (cfg >> 8) & 0xff, head = nheads > 1 ? blockIdx.x % nheads : 0; // K == 0: static striding
+        K = cfg & 0xff, nheads = (cfg >> 8) & 0xff; // K == 0: static striding
+        // (a power of two -- 1 or 8 from dq_config -- and a MASK, not `%`: hipcc lowers a modulo by a run-time value through f32
+        // arithmetic, which a kernel that has switched its rounding mode (epi_enter) must not contain)
+        nheads = nheads >= 8 ? 8 : (nheads >= 4 ? 4 : (nheads >= 2 ? 2 : 1));
+        head = (int)blockIdx.x & (nheads - 1);
         S0 = cfg >> 16;
         if (S0 < 2) S0 = 2;
         pool_next = 0, pool_left = 0, sel = 0, write_at = -1;

@@ -8,7 +8,7 @@ import pytest
 
 import microflow_rs_amd as mf
 from microflow_rs_amd import _lib
-from tests.conftest import model_path
+from tests.conftest import ROOT, model_path
 
 f32 = np.float32
 
@@ -266,3 +266,41 @@ def test_softmax_exp_table_exhaustive(O):
     # algorithm): on the other >= 85 % the two restatements are also confirmed by an independent evaluation
     assert worst <= 48, worst
     print("softmax exp table: at most %d of 256 entries per scale differ from correct rounding (1 ulp)" % worst)
+
+
+def test_mode3_kernels_have_no_float_lowered_division():
+    """Epilogue mode 3 runs its kernels in round-toward-zero (k_common.hpp epi_enter).  The compiler does not model the rounding
+    mode: it neither orders f32 instructions against the `s_setreg` nor knows that an integer `x % n` with a run-time n, which it
+    lowers through v_rcp_iflag_f32 / v_mul_f32 / v_cvt_u32_f32, would now round differently.  So a kernel that switches the mode
+    must contain NO f32 arithmetic besides the form's own v_fma_f32 (or its accumulating twin v_fmac_f32) and v_cvt_pk_u8_f32: the generated code of every such kernel
+    (41 instances in five translation units) is scanned for it."""
+    import collections
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    csrc = os.path.join(ROOT, "microflow_rs_amd", "csrc")
+    files = ("k_quad", "k_stage", "k_fused_mm", "k_pointwise", "k_depthwise")
+    with tempfile.TemporaryDirectory() as tmp:
+        procs = [subprocess.Popen([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-mllvm", "-amdgpu-mfma-vgpr-form=1",
+                                   "--cuda-device-only", "-S", "-o", os.path.join(tmp, f + ".s"), os.path.join(csrc, f + ".hip")],
+                                  stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL) for f in files]
+        assert all(p.wait() == 0 for p in procs)
+        f32 = re.compile(r"\s+v_(rcp|rsq|sqrt|div|cvt_f32|cvt_u32_f32|cvt_i32_f32|mul_f32|add_f32|sub_f32|mac_f32|mad_f32|rndne|trunc|floor|ceil|"
+                         r"frexp|ldexp|med3_f32|max_f32|min_f32|mul_legacy|exp|log)")
+        switching = 0
+        for f in files:
+            lines = open(os.path.join(tmp, f + ".s")).read().split("\n")
+            for i in [k for k, l in enumerate(lines) if re.match(r"^_Z[A-Za-z0-9_]+:", l)]:
+                end = next((j for j in range(i + 1, len(lines)) if lines[j].startswith("; Occupancy")), None)
+                body = lines[i:end] if end else []
+                if not any("s_setreg" in l for l in body):
+                    continue
+                switching += 1
+                stray = collections.Counter(l.split()[0] for l in body if f32.match(l))
+                assert not stray, (f, lines[i][:80], dict(stray))
+                assert any("v_fma_f32" in l for l in body) and any("v_cvt_pk_u8_f32" in l for l in body)
+    assert switching >= 30, switching
