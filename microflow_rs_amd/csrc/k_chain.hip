@@ -675,7 +675,7 @@ bool chain_plan(const ChainGeom *g, int n, ChainPair *pairs, ChainArgs &a, int l
     // ---- cost model (microseconds per image and CU): every phase costs its requantised bytes over the rate a workgroup gets
     // (times the imbalance of its work list over the waves) but never less than a phase's latency (dependent chain + barrier);
     // the chain's HBM bytes are the other roof.  Calibrated on the generated models (profiles/r04/chain_*).
-    static const double opcost = [] { const char *e = getenv("MF_CHAIN_OPCOST"); return e ? atof(e) : 1.0; }(); // (tuning: weight of the operand-reload term)
+    const double opcost = switches().chain_opcost; // (tuning: weight of the operand-reload term)
     auto estimate = [&](int G, int lds, int &nwave_out) {
         // workgroups per CU the LDS admits (at most two: 8 waves each = four waves per SIMD); with four k steps the registers allow
         // two waves per SIMD, i.e. one workgroup.  (Four-wave workgroups, four per CU, for small tensors were measured in round 4:
@@ -761,7 +761,7 @@ bool chain_plan(const ChainGeom *g, int n, ChainPair *pairs, ChainArgs &a, int l
         c.pad_ = 0;
         c.rtab = nullptr;
     }
-    static const bool no_res = getenv("MF_CHAIN_NO_RES") != nullptr; // A/B
+    const bool no_res = switches().chain_no_res; // A/B
     a.resident = (n == 1 && pairs[0].single_q && !no_res) ? 1 : 0;
     return true;
 }
@@ -811,7 +811,7 @@ static void launch_chain_t(const int8_t *in, int8_t *out, const ChainArgs &a, in
     // A handful of short steps per workgroup: static striding (the queue's first draw and its arrival count are a fixed cost per
     // launch, and there is nothing to balance over 8 - 16 steps; profiles/r04/chain_dq_ab.txt: 3x3x128 0.073 -> 0.066 ms, 6x6x64 s2 0.074 -> 0.072).
     {
-        static const bool forced = getenv("MF_DQ_CFG") != nullptr || getenv("MF_DQ_TUNE") != nullptr || getenv("MF_CHAIN_DQ_AUTO") != nullptr;
+        const bool forced = switches().dq_cfg_set || switches().dq_tune || switches().chain_dq_auto;
         const double t_step_us = a.est_us_per_image * a.G * per_cu;
         if (!forced && t_step_us < 8.0 && nsteps <= 20 * grid) b.qcfg = 0x100;
     }

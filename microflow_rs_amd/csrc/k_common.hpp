@@ -29,6 +29,7 @@
 #include <type_traits>
 
 #include "kernels.hpp"
+#include "mf_switches.hpp"
 
 namespace mf {
 namespace k {
@@ -499,14 +500,14 @@ unsigned long dq_next_slot(const int *ring); // (k_generic.hip) launch counter o
 static inline int dq_config(int nsteps, int grid, double est_us) {
     // tuning: MF_DQ_CFG = K | heads << 8 for every launch (0x100 = static striding).  With MF_DQ_TUNE set it is re-read per
     // launch, and MF_DQ_CFGS = "c0,c1,..." gives the k-th queue launch of the process configuration c[k % n] (0 = automatic)
-    static const bool tune = getenv("MF_DQ_TUNE") != nullptr;
-    static const int forced0 = [] { const char *e = getenv("MF_DQ_CFG"); return e ? (int)strtol(e, nullptr, 0) : 0; }();
-    int forced = forced0;
-    if (tune) {
+    const Switches &sw = switches();
+    int forced = sw.dq_cfg;
+    if (sw.dq_tune) {
         const unsigned long launches = dq_next_launch();
-        const char *e = getenv("MF_DQ_CFG"), *l = getenv("MF_DQ_CFGS");
-        forced = e ? (int)strtol(e, nullptr, 0) : 0;
-        if (l && *l) {
+        const Switches now = switches_parse(); // the tuning scripts change these between launches of one process
+        forced = now.dq_cfg;
+        const char *l = now.dq_cfgs.c_str();
+        if (*l) {
             int n = 1;
             for (const char *q = l; *q; ++q) n += *q == ',';
             int k = (int)(launches % (unsigned long)n);
@@ -523,12 +524,11 @@ static inline int dq_config(int nsteps, int grid, double est_us) {
     // cycles of one wave at the top of a step that the next barrier makes the whole workgroup's.  What the queue is for -- workgroups
     // of one CU drifting apart, the tail -- needs only the last part of a launch to be dealt dynamically: the first
     // MF_DQ_STATIC (default 0.6) of every workgroup's share is a stride walk.
-    static const double sfrac = [] { const char *e = getenv("MF_DQ_STATIC"); return e ? atof(e) : 0.6; }();
+    const double sfrac = sw.dq_static;
     int S0 = (int)(sfrac * (double)nsteps / (grid > 0 ? grid : 1));
     S0 = S0 < 2 ? 2 : (S0 > 32767 ? 32767 : S0);
     const int cfg = K | (draws_per_us > 60.0 ? 8 : 1) << 8 | S0 << 16;
-    static const bool verbose = getenv("MF_DQ_VERBOSE") != nullptr;
-    if (verbose) fprintf(stderr, "[microflow_amd] step queue: %d steps on %d workgroups, est %.0f us -> cfg 0x%x\n", nsteps, grid, est_us, cfg);
+    if (sw.dq_verbose) fprintf(stderr, "[microflow_amd] step queue: %d steps on %d workgroups, est %.0f us -> cfg 0x%x\n", nsteps, grid, est_us, cfg);
     return cfg;
 }
 // the counter set of this launch: the operator's ring (kernels.hpp DYNQ_RING sets of DynSteps::INTS zeroed ints), next slot.

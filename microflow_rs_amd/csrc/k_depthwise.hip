@@ -592,7 +592,7 @@ const char *dw_fast_name(int H, int W, int C, int S) {
 }
 bool launch_dw_fast(int H, int W, int C, int S, const int8_t *in, int8_t *out, const DwFastArgs &a,
                     int batch, hipStream_t s) {
-    static const int alt = [] { const char *e = getenv("MF_DW_ALT"); return e ? atoi(e) : -1; }();
+    const int alt = switches().dw_alt;
     if (alt >= 0) { // tuning candidates, see MF_DW_ALT_SHAPES
         int idx = 0;
         (void)idx;
@@ -650,7 +650,7 @@ bool launch_dw_stem(int H, int W, int DM, int S, const int8_t *in, int8_t *out, 
 #define MF_STEM2(F)                                                                          \
     if (a.xr) { if (a.magic) MF_STEM(true, 0x80808080u, F); else MF_STEM(false, 0x80808080u, F); } \
     else { if (a.magic) MF_STEM(true, 0u, F); else MF_STEM(false, 0u, F); }
-        static const bool valu = [] { const char *e = getenv("MF_STEM_IMPL"); return e && e[0] == 'v'; }();
+        const bool valu = switches().stem_valu;
         if (a.magic == 3 && valu) return false; // (the single-fma epilogue exists in the matrix-pipe form only; the caller does not ask for it then)
         if (!valu) { // taps on the matrix pipe
             static LaunchState stm, stmf;

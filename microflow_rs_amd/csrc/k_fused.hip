@@ -36,11 +36,7 @@ __global__ __launch_bounds__(256) void tail_pool_head_softmax(const int8_t *__re
 // intermediate tensor in registers (C <= 32), dwpw_mm in LDS (every table shape).  MF_DWPW_IMPL=mm takes dwpw_mm for every pair.
 // (Round 1's dwpw3x3 -- taps on the VALU -- was retired in round 5: every table shape has had a matrix-pipe kernel since round 2.)
 int dwpw_impl() {
-    static const int impl = [] {
-        const char *e = getenv("MF_DWPW_IMPL");
-        return e && e[0] == 'm' ? 1 : 2;
-    }();
-    return impl;
+    return switches().dwpw_mm_only ? 1 : 2;
 }
 const char *dwpw_name(int H, int W, int C, int S, int N) {
     if (dwpw_impl() == 2 && dwpw_rr_name(H, W, C, S, N)) return dwpw_rr_name(H, W, C, S, N);

@@ -675,7 +675,7 @@ const char *dwpw_mm_name(int H, int W, int C, int S, int N) {
 bool launch_dwpw_mm(int H, int W, int C, int S, int N, const int8_t *in, int8_t *out, const DwPwArgs &a, int batch,
                     hipStream_t s) {
     if (!a.dw.wmm) return false;
-    static const int alt = [] { const char *e = getenv("MF_DWMM_ALT"); return e ? atoi(e) : -1; }();
+    const int alt = switches().dwmm_alt;
     if (alt >= 0) { // tuning candidates, see MF_DWMM_ALT_SHAPES
         int idx = 0;
         (void)idx;
@@ -727,7 +727,7 @@ bool launch_dwpw_rr(int H, int W, int C, int S, int N, const int8_t *in, int8_t 
                     hipStream_t s) {
     if (!a.dw.wmm || !a.pw.wrr) return false;
     if (a.dw.patch || a.pw.patch) return false; // (patched accumulators: dwpw_mm's job)
-    static const int alt = [] { const char *e = getenv("MF_DWRR_ALT"); return e ? atoi(e) : -1; }();
+    const int alt = switches().dwrr_alt;
     if (alt >= 0) { // tuning candidates, see MF_DWRR_ALT_SHAPES
         int idx = 0;
         (void)idx;

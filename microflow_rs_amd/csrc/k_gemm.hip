@@ -458,11 +458,11 @@ static void launch_fc_mfma_t(const int8_t *in, int8_t *out, const FcGemmArgs &a,
 // (profiles/r04/fc_rowsum_ab.txt: 75.0-75.7 us against 71.8-73.1 us per 4096^3 step; weight zero point 0: 67.8), so it is the switch,
 // not the default.
 bool fc_mfma_rowsum_prepass() {
-    static const bool fold = getenv("MF_FC_ROWSUM_FOLD") != nullptr;
+    const bool fold = switches().fc_rowsum_fold;
     return !fold;
 }
 void launch_fc_mfma(const int8_t *in, int8_t *out, const FcGemmArgs &a, hipStream_t s) {
-    static const int force = [] { const char *e = getenv("MF_FC_TILE"); return e ? atoi(e) : 0; }();
+    const int force = switches().fc_tile;
     // 256 x 256 tiles halve the L2 -> LDS traffic per MAC; they need >= 256 tiles to fill the chip
     const bool big = a.N % 256 == 0 && (size_t)((a.M + 255) / 256) * (a.N / 256) >= 192;
     const bool rs = a.wzp != 0 && !a.rowsum; // the weight zero point term from in-kernel row sums

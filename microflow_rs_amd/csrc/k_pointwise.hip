@@ -185,7 +185,7 @@ static void launch_pw_t(const int8_t *in, int8_t *out, const PwArgs &a, long lon
 // workgroups of the grid-strided pointwise kernel (r01 sweep, MF_PW_GRID overrides): the wide early
 // layers (K < 64, most pixels) like many short-lived workgroups, the deep late ones few
 static long long pw_grid_cap(int K, int N) {
-    static const long long forced = [] { const char *e = getenv("MF_PW_GRID"); return e ? atoll(e) : 0LL; }();
+    const long long forced = switches().pw_grid;
     if (forced > 0) return forced;
     // r02 sweep (256 x {2 .. 64}, same session): K >= 128: x2 beats x4 by 4 - 8 %; K < 64 with N <= 32: x64 beats x32 by
     // 2 - 12 %; the rest stays

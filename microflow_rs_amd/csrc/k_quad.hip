@@ -472,7 +472,7 @@ template <typename Q> static bool quad_matches(int H, int W, int C, int S, int N
            N2 == GB::N;
 }
 static int quad_mask() { // MF_QUADS: bit 0 = ops 1..4, bit 1 = ops 5..8, bit 2 = the stem in front of ops 1..4 (tuning)
-    static const int m = [] { const char *e = getenv("MF_QUADS"); return e ? atoi(e) : 7; }();
+    const int m = switches().quads;
     return m;
 }
 const char *quad_name(int H, int W, int C, int S, int N, int H2, int W2, int C2, int S2, int N2) {

@@ -645,7 +645,7 @@ bool dw_rt_plan(DwRtArgs &a, int H, int W, int C, int S, int OH, int OW) {
     // threads per workgroup: 256 for the large stride-2 layers (measured on person_detect's shapes with the tables off, 512 ->
     // 256 threads: 48x48x16 s2 0.69 -> 0.56 ms, 24x24x32 s2 0.35 -> 0.32; the small tensors lose 15 - 20 %, stride 1 is indifferent)
     {
-        static const int forced = [] { const char *e = getenv("MF_DW_RT_THREADS"); return e ? atoi(e) : 0; }();
+        const int forced = switches().dw_rt_threads;
         a.NTHR = (S == 2 && H * W * C >= 16384 && C / 4 <= 256) ? 256 : 512;
         if (forced == 256 && C / 4 <= 256) a.NTHR = 256;
         if (forced == 512) a.NTHR = 512;
@@ -1002,7 +1002,7 @@ bool conv_mm_plan(ConvMmArgs &a, std::vector<int> &tap, int H, int W, int C, int
         a.G = g < 1 ? 1 : (g > 16 ? 16 : g);
         // Does a second workgroup fit beside this one?  If not, one 16-wave workgroup with a step as large as the LDS allows
         // (whole chunks per wave: 16 waves x 16 pixels).
-        static const bool small_wg = getenv("MF_CONV_MM_256") != nullptr; // A/B: round 3's four-wave workgroups
+        const bool small_wg = switches().conv_mm_256; // A/B: round 3's four-wave workgroups
         if (!small_wg && 2 * (a.G * a.TILE + wbytes + 1024) > 160 * 1024) {
             int gg = budget / a.TILE;
             gg = gg > 32 ? 32 : gg;

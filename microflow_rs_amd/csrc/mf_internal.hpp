@@ -8,6 +8,7 @@
 //   ops.hip       prepared operators: constant folding, kernel routing, launches
 //   k_*.hip       the HIP kernels (gfx950), one file per family; k_common.hpp shared helpers
 #pragma once
+#include "mf_switches.hpp"
 #include <cstddef>
 #include <cstdint>
 #include <memory>

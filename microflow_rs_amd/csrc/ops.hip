@@ -404,21 +404,21 @@ OpImpl *op_create(int device, const OpSpec &spec) {
         std::vector<int32_t> Kc, wzp;
         // the fast kernels may convert the accumulator to f32 by bit pattern when it provably
         // stays below 2^22 in magnitude (requant_t<true> in k_common.hpp)
-        static const bool no_magic = getenv("MF_NO_MAGIC") != nullptr; // tests: force the convert form
+        const bool no_magic = switches().no_magic; // tests: force the convert form
         std::vector<int64_t> acc_bound_c; // per output channel: max |v - izp| * sum_taps |w - wzp|
         std::vector<std::pair<int64_t, int64_t>> acc_range_c; // per output channel: the exact interval of acc over all inputs
         const int64_t acc_bound = fold_conv_constants(*op, s, dw, A, S, Kc, wzp, &acc_bound_c, &acc_range_c);
         int magic = !no_magic && acc_bound < (1 << 22) ? 1 : 0;
         // mode 2 (k_common.hpp): the clamp is the element type's whole range (so a saturating pack can do it) and
         // |x| = |A + S * acc| stays below 2^15 for every input (so x + 128 fits the i16 the pack saturates from)
-        static const bool no_sat = getenv("MF_NO_SAT_PACK") != nullptr; // tests: force the v_med3 form
+        const bool no_sat = switches().no_sat_pack; // tests: force the v_med3 form
         if (magic && !no_sat && lo == (s.u8 ? 0 : -128) && hi == (s.u8 ? 255 : 127) && all_finite(A) && all_finite(S)) {
             double xmax = 0.0;
             for (int c = 0; c < s.N; ++c)
                 xmax = std::max(xmax, std::fabs((double)A[(size_t)c]) + std::fabs((double)S[(size_t)c]) * (double)acc_bound_c[(size_t)c]);
             if (xmax < 30000.0) magic = 2;
         }
-        static const bool epi_dbg = getenv("MF_DEBUG_EPI") != nullptr; // which epilogue mode each operator gets, and why
+        const bool epi_dbg = switches().debug_epi; // which epilogue mode each operator gets, and why
         if (epi_dbg)
             fprintf(stderr, "[epi] %s %dx%dx%d -> %d: |acc| < %lld, clamp [%d, %d] -> mode %d\n", dw ? "depthwise" : "conv", s.H, s.W, s.C, s.N,
                     (long long)acc_bound, lo, hi, magic);
@@ -436,7 +436,7 @@ OpImpl *op_create(int device, const OpSpec &spec) {
         // Epilogue mode 3: y = v_cvt_pk_u8_f32(v_fma_f32(S', bits(acc + pivot), C')).  Conditions: bit-pattern accumulators (mode >= 1),
         // the clamp is the element type's whole range (the conversion's saturation IS the clamp), finite constants; then a solution
         // for EVERY channel (host, exact: epi_fma.cpp) that the device confirms on every reachable accumulator.
-        static const bool no_fma = getenv("MF_NO_FMA_EPI") != nullptr; // tests / A-B: keep the two-rounding forms
+        const bool no_fma = switches().no_fma_epi; // tests / A-B: keep the two-rounding forms
         if (magic >= 1 && !no_fma && lo == (s.u8 ? 0 : -128) && hi == (s.u8 ? 255 : 127) && all_finite(A) && all_finite(S)) {
             std::vector<float> A3((size_t)s.N), S3((size_t)s.N);
             std::vector<int32_t> K3((size_t)s.N), piv((size_t)s.N), amn((size_t)s.N), amx((size_t)s.N), pP((size_t)s.N, 0), pR((size_t)s.N, 0);
@@ -499,7 +499,7 @@ OpImpl *op_create(int device, const OpSpec &spec) {
         const bool zero_wzp = all_zero(wzp) && op->finite_consts;
         const bool same3x3 = s.KH == 3 && s.KW == 3 && s.pad == MF_PAD_SAME && s.sh == s.sw &&
                              s.OH == (s.H + s.sh - 1) / s.sh && s.OW == (s.W + s.sw - 1) / s.sw;
-        static const bool no_table = getenv("MF_NO_TABLE") != nullptr; // A-B: the run-time-geometry kernels on table shapes
+        const bool no_table = switches().no_table; // A-B: the run-time-geometry kernels on table shapes
         if (!no_table && dw && zero_wzp && same3x3 && s.C == s.N && k::dw_fast_name(s.H, s.W, s.C, s.sh)) {
             op->fast = OpImpl::DW_NHWC;
             op->fast_name = k::dw_fast_name(s.H, s.W, s.C, s.sh);
@@ -541,7 +541,7 @@ OpImpl *op_create(int device, const OpSpec &spec) {
             for (int c = 0; c < 8; ++c) f.A[c] = A[c], f.S[c] = S[c], f.Kc[c] = Kc[c];
             f.izp4 = 0x01010101u * (uint32_t)(uint8_t)(int8_t)s.izp;
             f.lo_f = a.lo_f, f.hi_f = a.hi_f, f.magic = magic, f.xr = xr;
-        } else if (!getenv("MF_NO_RT") && !getenv("MF_NO_STEM_RT") && dw && zero_wzp && same3x3 && s.C == 1 && s.sh == 2 &&
+        } else if (!switches().no_rt && !switches().no_stem_rt && dw && zero_wzp && same3x3 && s.C == 1 && s.sh == 2 &&
                    k::dw_stem_rt_plan(op->stemrt, s.H, s.W, s.N, s.OH, s.OW)) {
             // a one-channel 3x3 stride-2 stem at any resolution: the taps as one MFMA per 256 output bytes (k_rt.hip)
             op->fast = OpImpl::DW_STEM_RT;
@@ -601,7 +601,7 @@ OpImpl *op_create(int device, const OpSpec &spec) {
             }
         }
         // shapes outside the tables: the run-time-geometry kernels (k_rt.hip), with or without weight zero points
-        static const bool no_rt = getenv("MF_NO_RT") != nullptr; // tests / A-B: shape-generic kernels instead
+        const bool no_rt = switches().no_rt; // tests / A-B: shape-generic kernels instead
         if (op->fast == OpImpl::NONE && !no_rt && op->finite_consts && dw && same3x3 && s.C == s.N &&
             k::dw_rt_plan(op->dwrt, s.H, s.W, s.C, s.sh, s.OH, s.OW)) {
             op->fast = OpImpl::DW_RT;
@@ -629,7 +629,7 @@ OpImpl *op_create(int device, const OpSpec &spec) {
             bool reg = group >= 1 && !wz && s.N * group <= 256 && s.C * group <= 512;
             // (... but not past 64 output bytes per row: one wave then stores whole rows, 1 KiB contiguous per store
             // instruction, instead of two waves storing half lines -- MF_PW_RT_NCAP: tuning)
-            static const int ncap = [] { const char *e = getenv("MF_PW_RT_NCAP"); return e ? atoi(e) : 64; }();
+            const int ncap = switches().pw_rt_ncap;
             if (reg)
                 while (s.C * group * 2 <= 64 && s.N * group * 2 <= std::max(ncap, s.N)) group *= 2;
             if (group >= 1 && !(wz && group > 1) && (reg || k::pw_rt_supported(s.C * group, s.N * group, wz))) {
@@ -664,7 +664,7 @@ OpImpl *op_create(int device, const OpSpec &spec) {
         // few input channels (a first convolution; a one-channel depthwise with more than 8 outputs): window rows as dwords
         // (a one-channel depthwise keeps dw_c1_lds only where the one-launch speech kernel builds on it, k_dwfc.hip;
         // measured on the 96x96 stem: dw_c1_lds 1.22 ms, conv_rows_lds 0.70 ms; MF_DW_C1=lds forces the old kernel)
-        static const bool c1_lds = [] { const char *e = getenv("MF_DW_C1"); return e && e[0] == 'l'; }();
+        const bool c1_lds = switches().dw_c1_lds;
         const bool rows_for_c1 = !c1_lds && !k::dwfc_supported(s.H, s.W, s.KH, s.KW, s.sh, s.sw, s.OH, s.OW, s.N, 4);
         if ((op->fast == OpImpl::NONE || (op->fast == OpImpl::DW_C1 && rows_for_c1)) && !no_rt && op->finite_consts &&
             (!dw || s.C == 1) && !(s.KH == 1 && s.KW == 1 && !dw && k::conv1x1_rowwave_supported(a)) &&
@@ -727,7 +727,7 @@ OpImpl *op_create(int device, const OpSpec &spec) {
                 op->stem.fma_ok = 1;
             }
         }
-        if (getenv("MF_VERBOSE"))
+        if (switches().verbose)
             fprintf(stderr, "[microflow_amd] %s %dx%dx%d -> %d: kernel %s, worst-case |acc| %lld%s\n",
                     dw ? "depthwise_conv_2d" : "conv_2d", s.H, s.W, s.C, s.N,
                     op->fast != OpImpl::NONE ? op->fast_name.c_str() : op->generic_name.c_str(),
@@ -845,7 +845,7 @@ void op_set_generic(OpImpl *op, bool g) { op->force_generic = g; }
 static bool op_runs_fma(const OpImpl *op) {
     if (!op->fma_strict()) return false; // (the layer-wise kernels have no patch support)
     const OpSpec &sp = op->s;
-    static const bool stem_valu = [] { const char *e = getenv("MF_STEM_IMPL"); return e && e[0] == 'v'; }();
+    const bool stem_valu = switches().stem_valu;
     return (op->fast == OpImpl::DW_NHWC && dw_taps_on_matrix_pipe() && op->dwf.wmm && k::dw_mm_name(sp.H, sp.W, sp.C, sp.sh)) ||
            op->fast == OpImpl::PW_MFMA || (op->fast == OpImpl::DW_STEM && !stem_valu);
 }
@@ -1001,7 +1001,7 @@ void op_run_external(OpImpl *op, const int8_t *d_in, size_t batch, int8_t *d_out
 // kernel has an f32-input variant.  `zp` is a value of T.
 // quant_div (k_common.hpp): true when the fast form gives the same byte as the true division for EVERY float input
 static bool quant_div_verified(int device, float scale, float rcp, float zp_f, float sat_lo, float sat_hi) {
-    static const bool off = getenv("MF_NO_FAST_QUANT_DIV") != nullptr;
+    const bool off = switches().no_fast_quant_div;
     if (off || !std::isfinite(scale) || !std::isfinite(rcp) || scale == 0.0f) return false;
     static std::mutex mu;
     static std::map<std::array<uint32_t, 4>, bool> cache;
@@ -1015,7 +1015,7 @@ static bool quant_div_verified(int device, float scale, float rcp, float zp_f, f
     const unsigned long long bad = k::verify_quant_div(scale, rcp, zp_f, sat_lo, sat_hi, nullptr);
     if (bad == ~0ull) return false; // the check itself could not run: keep the true division now, try again next time
     const bool ok = bad == 0;
-    if (getenv("MF_VERBOSE")) fprintf(stderr, "[microflow_amd] boundary quantisation: 3-instruction division %s for scale %g\n", ok ? "verified" : "REJECTED", (double)scale);
+    if (switches().verbose) fprintf(stderr, "[microflow_amd] boundary quantisation: 3-instruction division %s for scale %g\n", ok ? "verified" : "REJECTED", (double)scale);
     cache[key] = ok;
     return ok;
 }
@@ -1096,12 +1096,12 @@ template <typename F> static bool patch_table(const k::EpiPatch &pl, std::vector
 
 // ---- run-time-geometry chains (k_chain.hip) ----
 static bool chain_enabled() {
-    static const bool off = getenv("MF_NO_CHAIN") != nullptr;
+    const bool off = switches().no_chain;
     return !off;
 }
 // a DepthwiseConv2D 3x3 + Conv2D 1x1 pair the chain kernel can run: any H / W, C % 16 == 0, N % 16 == 0
 static int chain_superpixel(int C) {
-    static const bool no_sp = getenv("MF_CHAIN_NO_SP") != nullptr; // A/B: only C == 8 stride 1 (round 4's first form) below 16 channels
+    const bool no_sp = switches().chain_no_sp; // A/B: only C == 8 stride 1 (round 4's first form) below 16 channels
     if (C % 16 == 0) return 1;
     if (C == 8 || (!no_sp && (C == 4 || C == 2))) return 16 / C;
     return 0;
@@ -1116,7 +1116,7 @@ static bool chain_pair_ok(const OpImpl *dw, const OpImpl *pw) {
     if ((P == 1 && !f.wmm) || (dw->fast == OpImpl::DW_RT && dw->rt_wz)) return false;
     if (d.KH != 3 || d.KW != 3 || d.pad != MF_PAD_SAME || d.sh != d.sw || (d.sh != 1 && d.sh != 2) || d.C != d.N) return false;
     if (P == 0 || d.W % (P * d.sh) != 0) return false; // (C < 16: whole superpixels in and out, see chain_geom)
-    if (P > 1 && d.sh == 2 && getenv("MF_CHAIN_NO_SP")) return false;
+    if (P > 1 && d.sh == 2 && switches().chain_no_sp) return false;
     if (q.KH != 1 || q.KW != 1 || q.sh != 1 || q.sw != 1 || q.OH != q.H || q.OW != q.W || (P * q.N) % 16 != 0) return false;
     if (q.H != d.OH || q.W != d.OW || q.C != d.N) return false;
     if (pw->fast != OpImpl::PW_RT && pw->fast != OpImpl::PW_MFMA) return false;
@@ -1142,7 +1142,7 @@ static FusedImpl *chain_create(const std::pair<OpImpl *, OpImpl *> *mem, int n, 
     std::vector<k::ChainGeom> geo((size_t)n);
     for (int i = 0; i < n; ++i) {
         if (!chain_pair_ok(mem[i].first, mem[i].second)) {
-            if (n == 1 && getenv("MF_CHAIN_VERBOSE"))
+            if (n == 1 && switches().chain_verbose)
                 fprintf(stderr, "[microflow_amd] not a chain pair: %dx%dx%d s%d (kernels %s, %s; epilogue modes %d, %d)\n", mem[i].first->s.H, mem[i].first->s.W,
                         mem[i].first->s.C, mem[i].first->s.sh, mem[i].first->fast_name.c_str(), mem[i].second->fast_name.c_str(), mem[i].first->magic_mode, mem[i].second->magic_mode);
             return nullptr;
@@ -1154,7 +1154,7 @@ static FusedImpl *chain_create(const std::pair<OpImpl *, OpImpl *> *mem, int n, 
     std::vector<k::ChainPair> tab((size_t)n);
     std::unique_ptr<FusedImpl> c(new FusedImpl{FusedImpl::CHAIN, mem[0].first, mem[n - 1].second, nullptr, {}, {}, ""});
     if (!k::chain_plan(geo.data(), n, tab.data(), c->chain, 150 * 1024, force_G, force_dbuf)) {
-        if (n == 1 && force_G == 0 && getenv("MF_CHAIN_VERBOSE"))
+        if (n == 1 && force_G == 0 && switches().chain_verbose)
             fprintf(stderr, "[microflow_amd] no chain plan for %dx%dx%d s%d -> %d\n", geo[0].H, geo[0].W, geo[0].C, geo[0].S, geo[0].N);
         return nullptr;
     }
@@ -1209,7 +1209,7 @@ static FusedImpl *chain_create(const std::pair<OpImpl *, OpImpl *> *mem, int n, 
     }
     name += ";G" + std::to_string(c->chain.G) + ">";
     c->name = name;
-    if (getenv("MF_CHAIN_VERBOSE")) fprintf(stderr, "[microflow_amd] %s est %.4f us/image/CU lds %d nwave %d dbuf %d\n", name.c_str(), c->chain.est_us_per_image, c->chain.lds_bytes, c->chain.nwave, c->chain.dbuf);
+    if (switches().chain_verbose) fprintf(stderr, "[microflow_amd] %s est %.4f us/image/CU lds %d nwave %d dbuf %d\n", name.c_str(), c->chain.est_us_per_image, c->chain.lds_bytes, c->chain.nwave, c->chain.dbuf);
     c->stage_w.emplace_back(new DevBuf);
     c->stage_w.back()->upload(tab.data(), tab.size() * sizeof(k::ChainPair));
     c->chain.pairs = (const k::ChainPair *)c->stage_w.back()->p;
@@ -1289,7 +1289,7 @@ void fused_chain_partition(FusedImpl *const *groups, int n, int *seg_len, bool *
         const std::pair<OpImpl *, OpImpl *> &m = groups[i]->chain_members[0];
         geo[(size_t)i] = chain_geom(m.first, m.second);
     }
-    static const bool force_fuse = getenv("MF_CHAIN_FORCE") != nullptr; // tests: never prefer the unfused operators
+    const bool force_fuse = switches().chain_force; // tests: never prefer the unfused operators
     const double INF = 1e30;
     std::vector<double> best((size_t)n + 1, INF);
     std::vector<int> choice((size_t)n + 1, 1);
@@ -1298,10 +1298,10 @@ void fused_chain_partition(FusedImpl *const *groups, int n, int *seg_len, bool *
     std::vector<k::ChainPair> tab((size_t)k::CHAIN_MAX);
     // measuring is the CALLER's choice (mf_model_set_autotune; off by default: model creation is then deterministic, allocates no
     // scratch and launches nothing); MF_CHAIN_AUTOTUNE=1 / =0 overrides it for scripts
-    static const int env_tune = [] { const char *e = getenv("MF_CHAIN_AUTOTUNE"); return !e ? -1 : (e[0] == '0' ? 0 : 1); }();
+    const int env_tune = switches().chain_autotune;
     bool autotune = env_tune < 0 ? autotune_opt : env_tune != 0;
-    static const bool verbose_t = getenv("MF_CHAIN_VERBOSE") != nullptr;
-    static const bool tune_g = [] { const char *e = getenv("MF_CHAIN_TUNE_G"); return !(e && e[0] == '0'); }();
+    const bool verbose_t = switches().chain_verbose;
+    const bool tune_g = switches().chain_tune_g;
     // measured[i][len]: microseconds per image of the candidate (< 0: not measured); measured_unf[i]: of the pair's two operators
     std::vector<std::vector<double>> measured((size_t)n, std::vector<double>((size_t)k::CHAIN_MAX + 1, -1.0));
     std::vector<double> measured_unf((size_t)n, -1.0);
@@ -1379,7 +1379,7 @@ void fused_chain_partition(FusedImpl *const *groups, int n, int *seg_len, bool *
         bool complete = tm.ok && !tm.failed;
         for (int i = 0; i < n && complete; ++i) complete = measured[(size_t)i][1] > 0;
         if (!complete) {
-            if (verbose_t || getenv("MF_VERBOSE")) fprintf(stderr, "[microflow_amd] chain autotune incomplete: planning %d pairs from the cost model\n", n);
+            if (verbose_t || switches().verbose) fprintf(stderr, "[microflow_amd] chain autotune incomplete: planning %d pairs from the cost model\n", n);
             autotune = false;
         }
     }
@@ -1464,7 +1464,7 @@ void fused_chain_partition(FusedImpl *const *groups, int n, int *seg_len, bool *
             (void)hipGetLastError();
         }
     }
-    static const bool verbose = getenv("MF_CHAIN_VERBOSE") != nullptr || getenv("MF_VERBOSE") != nullptr; // the plan, so that a run can be reproduced
+    const bool verbose = switches().chain_verbose || switches().verbose; // the plan, so that a run can be reproduced
     if (verbose) {
         fprintf(stderr, "[microflow_amd] chain partition of %d pairs:", n);
         for (int i = 0; i < n; ++i)
@@ -1474,7 +1474,7 @@ void fused_chain_partition(FusedImpl *const *groups, int n, int *seg_len, bool *
 }
 
 FusedImpl *fused_create(OpImpl *dw, OpImpl *pw) {
-    static const bool chain_all = getenv("MF_CHAIN_ALL") != nullptr; // tests / A-B: the chain kernel on table shapes too
+    const bool chain_all = switches().chain_all; // tests / A-B: the chain kernel on table shapes too
     if (dw && pw && (chain_all || dw->fast != OpImpl::DW_NHWC || pw->fast != OpImpl::PW_MFMA ||
                      !k::dwpw_name(dw->s.H, dw->s.W, dw->s.C, dw->s.sh, pw->s.N))) {
         const std::pair<OpImpl *, OpImpl *> one(dw, pw);
@@ -1574,7 +1574,7 @@ static std::vector<int8_t> build_pw_plain_weights(const int8_t *w, int K, int N)
 // kernel (k_stage.hip: five pairs on 6x6x128 = person_detect ops 13..22).  `pairs` are the already created pair
 // groups; returns nullptr when no stage kernel exists for them.
 FusedImpl *fused_stage_create(FusedImpl *const *pairs, int npairs) {
-    static const bool off = getenv("MF_NO_STAGE") != nullptr;
+    const bool off = switches().no_stage;
     if (off || npairs < 2 || !pairs[0] || pairs[0]->kind != FusedImpl::DWPW) return nullptr;
     const OpSpec &d0 = pairs[0]->a->s;
     const char *nm = k::stage_name(d0.H, d0.W, d0.C, npairs);
@@ -1657,7 +1657,7 @@ FusedImpl *fused_stage_create(FusedImpl *const *pairs, int npairs) {
 // one kernel (k_dwfc.hip; speech.tflite ops 1..3).  Second level like the stage: the operator and the group inside
 // stay available for mf_model_run_until.  nullptr when the shapes are not the compiled instance.
 FusedImpl *fused_dwfc_create(OpImpl *dw, FusedImpl *fcsm) {
-    static const bool off = getenv("MF_NO_DWFC") != nullptr;
+    const bool off = switches().no_dwfc;
     if (off || !dw || !fcsm || dw->fast != OpImpl::DW_C1 || fcsm->kind != FusedImpl::FCSM) return nullptr;
     OpImpl *fc = fcsm->a, *sm = fcsm->b;
     const OpSpec &d = dw->s, &q = fc->s;
@@ -1721,7 +1721,7 @@ FusedImpl *fused_dwfc_create(OpImpl *dw, FusedImpl *fcsm) {
 // (AveragePool2D over the whole tensor -> head Conv2D -> Softmax) as one kernel (k_tail3.hip).  Second level like the
 // stage; nullptr when the shapes are not the compiled instance.
 FusedImpl *fused_pair_tail_create(FusedImpl *pair, FusedImpl *tail) {
-    static const bool off = getenv("MF_NO_PAIRTAIL") != nullptr;
+    const bool off = switches().no_pairtail;
     if (off || !pair || !tail || tail->kind != FusedImpl::TAIL) return nullptr;
     // the pair: a table group (dwpw_mm) or a single-pair run-time-geometry chain group
     OpImpl *dw = nullptr, *pw = nullptr;
@@ -1768,7 +1768,7 @@ FusedImpl *fused_pair_tail_create(FusedImpl *pair, FusedImpl *tail) {
 // Two consecutive DepthwiseConv2D 3x3 + Conv2D 1x1 pair groups as one kernel (k_quad.hip), when a quad kernel exists for the two
 // shapes.  Second level like the stage: the pairs inside stay available for mf_model_run_until.
 FusedImpl *fused_quad_create(FusedImpl *p1, FusedImpl *p2) {
-    static const bool off = getenv("MF_NO_QUAD") != nullptr;
+    const bool off = switches().no_quad;
     if (off || !p1 || !p2 || p1->kind != FusedImpl::DWPW || p2->kind != FusedImpl::DWPW) return nullptr;
     const OpSpec &d1 = p1->a->s, &q1 = p1->b->s, &d2 = p2->a->s, &q2 = p2->b->s;
     if (p1->a->device != p2->a->device || d1.u8 != d2.u8) return nullptr;
@@ -1792,7 +1792,7 @@ FusedImpl *fused_quad_create(FusedImpl *p1, FusedImpl *p2) {
 // The network's one-input-channel stem in front of a quad: five operators in one launch (k_quad.hip, STEM instance).  The quad
 // itself stays (mf_model_run_until, and the f32 entry point, whose boundary quantisation is fused into the stem kernel).
 FusedImpl *fused_quad_stem_create(OpImpl *stem, FusedImpl *quad) {
-    static const bool off = getenv("MF_NO_PENTA") != nullptr;
+    const bool off = switches().no_penta;
     if (off || !stem || !quad || quad->kind != FusedImpl::QUAD || quad->quad.stem || stem->fast != OpImpl::DW_STEM) return nullptr;
     const OpSpec &t = stem->s, &d1 = quad->a->s;
     if (stem->device != quad->a->device || t.u8 != d1.u8 || stem->force_generic) return nullptr;

@@ -157,7 +157,8 @@ ROWS = [
     ("conv", 10, 8, 3, 12, 1, 1, 1, 1, 0, False, 5),      # 1x1 with 3 input channels
     ("conv", 9, 9, 4, 8, 3, 3, 2, 2, 0, True, 5),         # filter zero points
     ("conv", 14, 16, 3, 10, 4, 2, 2, 1, 1, True, 5),      # even-sized filter, VALID, filter zero points
-    ("dw", 128, 128, 1, 8, 3, 3, 2, 2, 0, False, 3),      # the person_detect stem at 128 x 128
+    ("dw", 128, 128, 1, 8, 3, 3, 2, 2, 0, False, 3),      # the person_detect stem at 128 x 128 (dw3x3_stem_rt takes 4 / 8 outputs)
+    ("dw", 128, 128, 1, 6, 3, 3, 2, 2, 0, False, 3),      # ... with 6 outputs: dw_c1_lds
     ("dw", 40, 40, 1, 16, 3, 3, 2, 2, 0, False, 5),       # depth multiplier 16 (dw_c1_lds stops at 8)
     ("dw", 30, 28, 1, 12, 5, 3, 1, 1, 0, True, 4),        # weight zero points
 ]
@@ -165,7 +166,7 @@ ROWS = [
 
 @pytest.mark.parametrize("case", ROWS, ids=lambda c: "x".join(map(str, c)))
 @pytest.mark.parametrize("u8", [False, True], ids=["i8", "u8"])
-def test_conv_rows_vs_oracle(mf, O, case, u8, monkeypatch):
+def test_conv_rows_vs_oracle(mf, O, case, u8):
     kind, H, W, C, N, KH, KW, sh, sw, pad, wz, batch = case
     rng = np.random.default_rng(hash(case) % (2 ** 32) + int(u8))
     dt = np.uint8 if u8 else np.int8
@@ -188,9 +189,9 @@ def test_conv_rows_vs_oracle(mf, O, case, u8, monkeypatch):
     else:
         w = rng.integers(lo, hi, (KH, KW, N)).astype(dt)
         opts = mf.ops.DepthwiseConv2DOptions(mf.FusedActivation(act), mf.TensorViewPadding(pad), (sh, sw))
-        monkeypatch.setenv("MF_NO_STEM_RT", "1")    # (3x3 stride-2 stems with 4 / 8 outputs have their own kernel: test_stem_rt_vs_oracle)
         op = mf.ops.prepare_depthwise_conv_2d((H, W, C), w, zp, izp, oscale, ozp, opts, (c0, c1), (OH, OW))
-        assert ROUTING_SWITCHED or op.kernel in ("dw_rows_lds" + ("<wzp>" if wz else ""), "dw_c1_lds"), op.kernel
+        # (3x3 stride-2 stems with 4 / 8 outputs have their own kernel, tested in test_stem_rt_vs_oracle)
+        assert ROUTING_SWITCHED or op.kernel in ("dw_rows_lds" + ("<wzp>" if wz else ""), "dw_c1_lds", "dw3x3_stem_rt<%d>" % N), op.kernel
         want = np.stack([O.depthwise_conv_2d(x[i], w, zp, izp, oscale, ozp, act, pad, (sh, sw), (OH, OW), c0, c1) for i in range(batch)])
     got = op(x)
     assert np.array_equal(got, want), (op.kernel, np.argwhere(got != want)[:5])

@@ -304,3 +304,21 @@ def test_mode3_kernels_have_no_float_lowered_division():
                 assert not stray, (f, lines[i][:80], dict(stray))
                 assert any("v_fma_f32" in l for l in body) and any("v_cvt_pk_u8_f32" in l for l in body)
     assert switching >= 30, switching
+
+
+def test_environment_switches_live_in_one_struct():
+    """the library reads the environment in ONE place (csrc/switches.cpp fills mf::Switches once); every switch
+    parsed there is documented on its field in mf_switches.hpp, and scripts/switch_matrix.sh only uses names that exist."""
+    import glob
+    import re
+    csrc = os.path.join(ROOT, "microflow_rs_amd", "csrc")
+    for path in glob.glob(os.path.join(csrc, "*")):
+        if os.path.basename(path) == "switches.cpp" or os.path.isdir(path):
+            continue
+        assert "getenv" not in open(path).read(), "%s reads the environment itself" % os.path.basename(path)
+    parsed = set(re.findall(r'"(MF_[A-Z0-9_]+)"', open(os.path.join(csrc, "switches.cpp")).read()))
+    documented = set(re.findall(r"//\s+(MF_[A-Z0-9_]+)", open(os.path.join(csrc, "mf_switches.hpp")).read()))
+    assert parsed and parsed == documented, (sorted(parsed - documented), sorted(documented - parsed))
+    matrix = open(os.path.join(ROOT, "scripts", "switch_matrix.sh")).read()
+    used = set(re.findall(r"\b(MF_[A-Z0-9_]+)=", matrix)) - {"MF_ALLOW_DIAG_BUILD", "MF_EXTRA_HIPCC_FLAGS"}
+    assert used <= parsed, sorted(used - parsed)
