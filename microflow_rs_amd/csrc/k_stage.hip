@@ -44,6 +44,9 @@
 #define MF_STAGE_LDS_KB 70 // (tuning: 100 forces one workgroup per CU)
 #endif
 
+#ifndef MF_STAGE_PDIAG
+#define MF_STAGE_PDIAG 0
+#endif
 namespace mf {
 namespace k {
 
@@ -166,6 +169,28 @@ __global__ __launch_bounds__(NTHR, 4) void stage_6x6x128(const int8_t *__restric
         return t;
     };
 
+    // mode 3: the first patch record of (phase, this wave) -- kernels.hpp EpiPatchRec -- fetched like the operands, one phase ahead and
+    // with a VECTOR load (every lane the same 8 bytes): a scalar load at the top of a phase has its whole latency exposed there, and
+    // its s_waitcnt lgkmcnt(0) drains the phase's LDS pipeline with it (0.474 -> 0.557 ms for the kernel, measured).
+    typedef int v2i __attribute__((ext_vector_type(2)));
+    auto ld_rec = [&](int phase) {
+        typedef __attribute__((address_space(1))) const v2i g_v2i;
+        if constexpr (MG == 3) return *(g_v2i *)((uintptr_t)p.patch_tab + (size_t)((phase * 8 + wave) * 2) * sizeof(EpiPatchRec));
+        else return v2i{0, 0};
+    };
+    auto rec_of = [](const v2i &r) {
+        EpiPatchRec rec{__builtin_amdgcn_readfirstlane(r[0]), __builtin_amdgcn_readfirstlane(r[1])};
+#if MF_STAGE_PDIAG & 1 // (timing experiments, WRONG results: 1 only the unpatched copy exists; 2 every wave takes it, all copies compiled)
+        asm volatile("" ::"s"(rec.P), "s"(rec.meta));
+        rec.P = 0;
+#elif MF_STAGE_PDIAG & 2
+        int z = 0;
+        asm volatile("" : "+s"(z));
+        rec.P &= z;
+#endif
+        return rec;
+    };
+
     auto stage = [&](int st) { // G images, 6 rows each, one 768-byte DMA per row, group index swizzled like TS6
         const int src_lane = lane ^ tile_swz<TS6>(lane >> 3);
 #pragma unroll
@@ -182,6 +207,7 @@ __global__ __launch_bounds__(NTHR, 4) void stage_6x6x128(const int8_t *__restric
     __syncthreads(); // halo fill complete before any DMA lands
     const int nsteps = (batch + G - 1) / G;
     if (dq.step < nsteps) stage(dq.step);
+    v2i rdw = ld_rec(0);
     DwW wd = load_dw(0);
     int ko_steps = 0; // (steps done: the knock-out switches 4 / 16 act from the second step on)
 #if MF_STAGE_KO & 16
@@ -212,18 +238,23 @@ __global__ __launch_bounds__(NTHR, 4) void stage_6x6x128(const int8_t *__restric
             if (ko_steps == 0 || rep == 0) wpk = load_pw(ko_steps == 0 ? rep : 0);
             const PwW wp = wpk;
 #else
+            const v2i rpw = ld_rec(2 * rep + 1);
             const PwW wp = load_pw(rep);                // lands during the depthwise phase
 #endif
             // ---------------- depthwise: tile -> MID ----------------
             // PR: where this wave's patched channel sits (mode 3, kernels.hpp EpiPatchRec) -- -1: none (almost every wave and
-            // operator); 0 .. 3: that accumulator of a lane, one compare + select + add per unit, straight-line; 4: two patched
-            // channels in this wave's 16 (epi_patch_apply).  A compile-time constant per copy of the loop: the hand-interleaved
-            // MFMA / epilogue schedule below does not survive a branch inside the loop (0.47 -> 0.56 ms with a never-taken one).
-            auto dw_phase = [&](auto pr_tag, const EpiPatchRec &dpr, const EpiPatchRec &dpr2) {
+            // operator); 0 .. 3: that accumulator of a lane; 4: apply the wave's (up to two) records exactly (epi_patch_apply).
+            // A compile-time constant per copy of the loop: the hand-interleaved MFMA / epilogue schedule below does not survive a
+            // branch inside the loop (0.47 -> 0.56 ms with a never-taken one).  A patched accumulator is ONE value out of millions,
+            // and every wave of the phase waits at the barrier behind it for the slowest: so the copies 0 .. 3 only DETECT it -- one
+            // compare into a scalar mask per unit, the unpatched arithmetic otherwise -- and the phase is redone by copy 4 in the rare
+            // step that saw one (it reads a buffer nobody writes during the phase and rewrites this wave's own outputs: idempotent).
+            // Returns the lanes that saw their patched accumulator.
+            auto dw_phase = [&](auto pr_tag, const EpiPatchRec &dpr, const EpiPatchRec &dpr2) -> unsigned long long {
                 constexpr int PR = decltype(pr_tag)::value;
                 const float lo = pairs[rep].dw_lo, hi = pairs[rep].dw_hi;
-                const bool pgrp = g == ((dpr.meta >> 2) & 3);
-                const int pdelta = (dpr.meta & 16) ? -1 : 1;
+                const int Pl = g == ((dpr.meta >> 2) & 3) ? dpr.P : 0x7fffffff; // (no biased accumulator is 0x7fffffff)
+                unsigned long long hit = 0;
                 const int mb = mid + mb6;
                 auto toff = [](int u) { return (u / 3) * 2 * ROW6 + (u % 3) * 2 * 128; };
                 auto moff = [](int u) { return ((u / 3) * 12 + (u % 3) * 2) * 16; };
@@ -241,10 +272,13 @@ __global__ __launch_bounds__(NTHR, 4) void stage_6x6x128(const int8_t *__restric
                     __builtin_amdgcn_sched_barrier(0);
                     if (more) nxt = __builtin_amdgcn_mfma_i32_16x16x64_i8(wd.A[0], t2.b[0], nxt, 0, 0, 0);
                     // (behind the next unit's first MFMA, like the epilogue itself: acc's own MFMAs have had their latency by now)
-                    if constexpr (PR >= 0 && PR < 4) acc[PR] += (pgrp && acc[PR] == dpr.P) ? pdelta : 0;
-                    else if constexpr (PR == 4) epi_patch_apply(acc, dpr, g), epi_patch_apply(acc, dpr2, g);
+                    if constexpr (PR == 4) epi_patch_apply(acc, dpr, g), epi_patch_apply(acc, dpr2, g);
                     const float r0 = epi_value<MG>(acc[0], wd.a.x, wd.s.x, lo, hi);
                     const float r1 = epi_value<MG>(acc[1], wd.a.y, wd.s.y, lo, hi);
+                    if constexpr (PR >= 0 && PR < 4) {
+                        hit |= __builtin_amdgcn_ballot_w64(acc[PR] == Pl);
+                        asm volatile("" : "+s"(hit)); // one running mask (left alone, the compiler keeps nine and spills scalars)
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                     if (more) nxt = __builtin_amdgcn_mfma_i32_16x16x64_i8(wd.A[1], t2.b[1], nxt, 0, 0, 0);
                     const float r2 = epi_value<MG>(acc[2], wd.a.z, wd.s.z, lo, hi);
@@ -259,19 +293,22 @@ __global__ __launch_bounds__(NTHR, 4) void stage_6x6x128(const int8_t *__restric
                     __builtin_amdgcn_sched_barrier(0);
                     acc = nxt, t2 = t3;
                 }
+                return hit;
             };
-            if constexpr (MG == 3) { // one scalar load per record; the copy of the loop is chosen by a chain of scalar branches
-                const EpiPatchRec dpr = epi_patch_load(p.patch_tab, ((2 * rep) * 8 + wave) * 2);
-                const EpiPatchRec dpr2 = epi_patch_load(p.patch_tab, ((2 * rep) * 8 + wave) * 2 + 1);
-                const int sel = dpr2.P != 0 ? 4 : (dpr.P != 0 ? (dpr.meta & 3) : -1);
-                if (sel < 0) dw_phase(std::integral_constant<int, -1>{}, dpr, dpr2);
-                else if (sel == 0) dw_phase(std::integral_constant<int, 0>{}, dpr, dpr2);
-                else if (sel == 1) dw_phase(std::integral_constant<int, 1>{}, dpr, dpr2);
-                else if (sel == 2) dw_phase(std::integral_constant<int, 2>{}, dpr, dpr2);
-                else if (sel == 3) dw_phase(std::integral_constant<int, 3>{}, dpr, dpr2);
-                else dw_phase(std::integral_constant<int, 4>{}, dpr, dpr2);
+            if constexpr (MG == 3) { // the copy of the loop is chosen by a chain of scalar branches
+                const EpiPatchRec dpr = rec_of(rdw);
+                const int sel = dpr.P == 0 ? -1 : ((dpr.meta & 32) ? 4 : (dpr.meta & 3));
+                unsigned long long redo = 0;
+                if (sel < 0) dw_phase(std::integral_constant<int, -1>{}, dpr, dpr);
+                else if (sel == 0) redo = dw_phase(std::integral_constant<int, 0>{}, dpr, dpr);
+                else if (sel == 1) redo = dw_phase(std::integral_constant<int, 1>{}, dpr, dpr);
+                else if (sel == 2) redo = dw_phase(std::integral_constant<int, 2>{}, dpr, dpr);
+                else if (sel == 3) redo = dw_phase(std::integral_constant<int, 3>{}, dpr, dpr);
+                else redo = ~0ull; // two patched channels in this wave's 16: straight to the exact copy
+                if (__builtin_expect(redo != 0, 0))
+                    dw_phase(std::integral_constant<int, 4>{}, dpr, epi_patch_load(p.patch_tab, ((2 * rep) * 8 + wave) * 2 + 1));
             } else {
-                dw_phase(std::integral_constant<int, -1>{}, EpiPatchRec{0, 0}, EpiPatchRec{0, 0});
+                (void)dw_phase(std::integral_constant<int, -1>{}, EpiPatchRec{0, 0}, EpiPatchRec{0, 0});
             }
             MF_TR(1 + 3 * rep);
 #if MF_STAGE_KO & 8
@@ -285,13 +322,14 @@ __global__ __launch_bounds__(NTHR, 4) void stage_6x6x128(const int8_t *__restric
                 const int next = dq.nxt;
                 if (next < nsteps && !((MF_STAGE_KO & 4) && ko_steps > 0)) stage(next); // the tile is dead: the next step's images fly under the last pointwise phase
             }
+            rdw = ld_rec(last ? 0 : 2 * rep + 2);
             if (!((MF_STAGE_KO & 16) && ko_steps > 0)) wd = load_dw(last ? 0 : rep + 1); // the next depthwise's operands land during the pointwise phase
             // ---------------- pointwise: MID -> tile (last pair: -> plain output in region A) ----------------
-            auto pw_phase = [&](auto pr_tag, const EpiPatchRec &ppr, const EpiPatchRec &ppr2) { // (PR as in dw_phase)
+            auto pw_phase = [&](auto pr_tag, const EpiPatchRec &ppr, const EpiPatchRec &ppr2) -> unsigned long long { // (PR as in dw_phase)
                 constexpr int PR = decltype(pr_tag)::value;
                 const float lo = pairs[rep].pw_lo, hi = pairs[rep].pw_hi;
-                const bool pgrp = pg == ((ppr.meta >> 2) & 3);
-                const int pdelta = (ppr.meta & 16) ? -1 : 1;
+                const int Pl = pg == ((ppr.meta >> 2) & 3) ? ppr.P : 0x7fffffff;
+                unsigned long long hit = 0;
                 const int rb = mid + pg * PLANE6 + pcol * 16;
                 v4i c0 = *(const v4i *)(lds + rb), c1 = *(const v4i *)(lds + rb + 4 * PLANE6);
                 v4i acc = {wp.k.x, wp.k.y, wp.k.z, wp.k.w};
@@ -309,10 +347,13 @@ __global__ __launch_bounds__(NTHR, 4) void stage_6x6x128(const int8_t *__restric
                     v4i nxt = {wp.k.x, wp.k.y, wp.k.z, wp.k.w};
                     __builtin_amdgcn_sched_barrier(0);
                     if (more) nxt = __builtin_amdgcn_mfma_i32_16x16x64_i8(wp.A[0], c0, nxt, 0, 0, 0);
-                    if constexpr (PR >= 0 && PR < 4) acc[PR] += (pgrp && acc[PR] == ppr.P) ? pdelta : 0;
-                    else if constexpr (PR == 4) epi_patch_apply(acc, ppr, pg), epi_patch_apply(acc, ppr2, pg);
+                    if constexpr (PR == 4) epi_patch_apply(acc, ppr, pg), epi_patch_apply(acc, ppr2, pg);
                     const float r0 = epi_value<MG>(acc[0], wp.a.x, wp.s.x, lo, hi);
                     const float r1 = epi_value<MG>(acc[1], wp.a.y, wp.s.y, lo, hi);
+                    if constexpr (PR >= 0 && PR < 4) {
+                        hit |= __builtin_amdgcn_ballot_w64(acc[PR] == Pl);
+                        asm volatile("" : "+s"(hit)); // one running mask (left alone, the compiler keeps nine and spills scalars)
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                     if (more) nxt = __builtin_amdgcn_mfma_i32_16x16x64_i8(wp.A[1], c1, nxt, 0, 0, 0);
                     const float r2 = epi_value<MG>(acc[2], wp.a.z, wp.s.z, lo, hi);
@@ -327,19 +368,22 @@ __global__ __launch_bounds__(NTHR, 4) void stage_6x6x128(const int8_t *__restric
                     __builtin_amdgcn_sched_barrier(0);
                     acc = nxt, c0 = e0, c1 = e1;
                 }
+                return hit;
             };
             if constexpr (MG == 3) {
-                const EpiPatchRec ppr = epi_patch_load(p.patch_tab, ((2 * rep + 1) * 8 + wave) * 2);
-                const EpiPatchRec ppr2 = epi_patch_load(p.patch_tab, ((2 * rep + 1) * 8 + wave) * 2 + 1);
-                const int sel = ppr2.P != 0 ? 4 : (ppr.P != 0 ? (ppr.meta & 3) : -1);
-                if (sel < 0) pw_phase(std::integral_constant<int, -1>{}, ppr, ppr2);
-                else if (sel == 0) pw_phase(std::integral_constant<int, 0>{}, ppr, ppr2);
-                else if (sel == 1) pw_phase(std::integral_constant<int, 1>{}, ppr, ppr2);
-                else if (sel == 2) pw_phase(std::integral_constant<int, 2>{}, ppr, ppr2);
-                else if (sel == 3) pw_phase(std::integral_constant<int, 3>{}, ppr, ppr2);
-                else pw_phase(std::integral_constant<int, 4>{}, ppr, ppr2);
+                const EpiPatchRec ppr = rec_of(rpw);
+                const int sel = ppr.P == 0 ? -1 : ((ppr.meta & 32) ? 4 : (ppr.meta & 3));
+                unsigned long long redo = 0;
+                if (sel < 0) pw_phase(std::integral_constant<int, -1>{}, ppr, ppr);
+                else if (sel == 0) redo = pw_phase(std::integral_constant<int, 0>{}, ppr, ppr);
+                else if (sel == 1) redo = pw_phase(std::integral_constant<int, 1>{}, ppr, ppr);
+                else if (sel == 2) redo = pw_phase(std::integral_constant<int, 2>{}, ppr, ppr);
+                else if (sel == 3) redo = pw_phase(std::integral_constant<int, 3>{}, ppr, ppr);
+                else redo = ~0ull;
+                if (__builtin_expect(redo != 0, 0))
+                    pw_phase(std::integral_constant<int, 4>{}, ppr, epi_patch_load(p.patch_tab, ((2 * rep + 1) * 8 + wave) * 2 + 1));
             } else {
-                pw_phase(std::integral_constant<int, -1>{}, EpiPatchRec{0, 0}, EpiPatchRec{0, 0});
+                (void)pw_phase(std::integral_constant<int, -1>{}, EpiPatchRec{0, 0}, EpiPatchRec{0, 0});
             }
             MF_TR(3 + 3 * rep);
             // NO barrier here (see the header): the next depthwise of this wave reads only what this wave has written

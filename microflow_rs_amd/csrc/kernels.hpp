@@ -86,7 +86,8 @@ struct EpiPatch {
 struct EpiPatchRec {            // one tile's patched channel, as the kernel sees it
     int P;                      // the bit pattern to replace; 0: nothing in this tile
     int meta;                   // bits 0..1: which of a lane's four accumulators; bits 2..3: which 16-lane group holds the channel;
-                                // bit 4: the replacement is P - 1 (else P + 1)
+                                // bit 4: the replacement is P - 1 (else P + 1); bit 5 (stage kernel, first record of a wave): a
+                                // second record follows
 };
 static inline EpiPatchRec epi_patch_rec(int P, int R, int reg, int lane_group) {
     return EpiPatchRec{P, (reg & 3) | (lane_group & 3) << 2 | (R < P ? 16 : 0)};

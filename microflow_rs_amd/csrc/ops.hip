@@ -1591,7 +1591,6 @@ FusedImpl *fused_stage_create(FusedImpl *const *pairs, int npairs) {
     for (int i = 0; i < npairs; ++i) all_fma = all_fma && pairs[i]->a->fma_ok && pairs[i]->b->fma_ok;
     // ... and their patched accumulators as the kernel's table: [pair][depthwise, pointwise][wave = aligned 16-channel group][2]
     std::vector<k::EpiPatchRec> ptab((size_t)npairs * 32, k::EpiPatchRec{0, 0});
-    int npatched = 0;
     for (int i = 0; i < npairs && all_fma; ++i)
         for (int ph = 0; ph < 2 && all_fma; ++ph) {
             const k::EpiPatch &pl = (ph ? pairs[i]->b : pairs[i]->a)->fma_patch;
@@ -1601,8 +1600,8 @@ FusedImpl *fused_stage_create(FusedImpl *const *pairs, int npairs) {
                 if (slot[0].P != 0) ++slot;
                 if (ch >= 128 || slot->P != 0) all_fma = false; // (three in one group: the kernel's table holds two)
                 else *slot = k::epi_patch_rec(pl.P[e], pl.R[e], ch & 3, (ch >> 2) & 3);
+                if (all_fma && slot != &ptab[(((size_t)i * 2 + ph) * 8 + (size_t)(ch >> 4)) * 2]) slot[-1].meta |= 32; // "a second record follows"
             }
-            npatched += pl.n;
         }
     std::unique_ptr<FusedImpl> s(new FusedImpl{FusedImpl::STAGE, pairs[0]->a, pairs[npairs - 1]->b, nullptr, {}, {}, nm});
     s->stage_pairs = npairs;
@@ -1635,7 +1634,7 @@ FusedImpl *fused_stage_create(FusedImpl *const *pairs, int npairs) {
         sp.pw_lo = f->dwpw.pw.lo_f, sp.pw_hi = f->dwpw.pw.hi_f;
     }
     s->stage.patch_tab = nullptr;
-    if (all_fma && npatched > 0) {
+    if (all_fma) { // (also when nothing is patched: the kernel fetches its records with the operands, unconditionally)
         s->stage_w.emplace_back(new DevBuf);
         s->stage_w.back()->upload(ptab.data(), ptab.size() * sizeof(k::EpiPatchRec));
         s->stage.patch_tab = s->stage_w.back()->as<k::EpiPatchRec>();
