@@ -245,6 +245,9 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args)
+    # (the host driver only does dmabuf IPC; RCCL's peer mapping fails with hipIpcGetMemHandle otherwise -- also under an external
+    # torchrun that did not export it.  Must be in the environment before HIP is initialised.)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
     import torch
     import torch.distributed as dist
