@@ -256,7 +256,8 @@ struct RrPhase {
                 int ug = 0, uy = 0, ux = 0;
                 coords(t0 + u, ug, uy, ux);
                 const int doff = ug * D_UG + uy * D_UY + ux * D_UX;
-                if (cg + wug + ug * Ge::CG < gvalid) { // a ragged last step stages fewer than G images
+                // (one image per step: nothing to test, and no branch between the units -- the scheduler then works across them)
+                if (G == 1 || cg + wug + ug * Ge::CG < gvalid) { // a ragged last step stages fewer than G images
                     if constexpr (TO_LDS) {
                         if constexpr (Ge::LB == 8) *(uint2 *)(dst + dst_lane + doff) = make_uint2(packed[0], packed[1]);
                         else *(uint4 *)(dst + dst_lane + doff) = make_uint4(packed[0], packed[1], packed[2], packed[3]);
