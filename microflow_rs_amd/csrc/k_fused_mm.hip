@@ -581,7 +581,7 @@ __global__ __launch_bounds__(NTHR, WPE) void dwpw_rr(const int8_t *__restrict__ 
                 int ug = 0, uy = 0, ux = 0;
                 coords(t0 + u, ug, uy, ux);
                 const int ooff = ug * O_UG + uy * O_UY + ux * O_UX;
-                if (cg + (ug + wpg) * CG < gvalid) // a ragged last step stages fewer than G images
+                if (G == 1 || cg + (ug + wpg) * CG < gvalid) // a ragged last step stages fewer than G images (G = 1: no test, no branch between the units)
                 {
                     if constexpr (LB == 8) st_out(ob + ooff, make_uint2(packed[0], packed[1]));
                     else st_out(ob + ooff, make_uint4(packed[0], packed[1], packed[2], packed[3]));
