@@ -47,6 +47,11 @@
 #ifndef MF_STAGE_PDIAG
 #define MF_STAGE_PDIAG 0
 #endif
+#ifndef MF_STAGE_FENCE
+#define MF_STAGE_FENCE 3 // (tuning) bit 0: the fences inside a unit (MFMA / epilogue interleave), bit 1: the fence at the end of a unit
+#endif
+#define MF_SB_IN() do { if (MF_STAGE_FENCE & 1) __builtin_amdgcn_sched_barrier(0); } while (0)
+#define MF_SB_END() do { if (MF_STAGE_FENCE & 2) __builtin_amdgcn_sched_barrier(0); } while (0)
 namespace mf {
 namespace k {
 
@@ -269,7 +274,7 @@ __global__ __launch_bounds__(NTHR, 4) void stage_6x6x128(const int8_t *__restric
                     Taps t3 = t2;
                     if (u + 2 < 9) t3 = dw_load(tb6 + toff(u + 2));
                     v4i nxt = {wd.k.x, wd.k.y, wd.k.z, wd.k.w};
-                    __builtin_amdgcn_sched_barrier(0);
+                    MF_SB_IN();
                     if (more) nxt = __builtin_amdgcn_mfma_i32_16x16x64_i8(wd.A[0], t2.b[0], nxt, 0, 0, 0);
                     // (behind the next unit's first MFMA, like the epilogue itself: acc's own MFMAs have had their latency by now)
                     if constexpr (PR == 4) epi_patch_apply(acc, dpr, g), epi_patch_apply(acc, dpr2, g);
@@ -279,18 +284,18 @@ __global__ __launch_bounds__(NTHR, 4) void stage_6x6x128(const int8_t *__restric
                         hit |= __builtin_amdgcn_ballot_w64(acc[PR] == Pl);
                         asm volatile("" : "+s"(hit)); // one running mask (left alone, the compiler keeps nine and spills scalars)
                     }
-                    __builtin_amdgcn_sched_barrier(0);
+                    MF_SB_IN();
                     if (more) nxt = __builtin_amdgcn_mfma_i32_16x16x64_i8(wd.A[1], t2.b[1], nxt, 0, 0, 0);
                     const float r2 = epi_value<MG>(acc[2], wd.a.z, wd.s.z, lo, hi);
                     const float r3 = epi_value<MG>(acc[3], wd.a.w, wd.s.w, lo, hi);
-                    __builtin_amdgcn_sched_barrier(0);
+                    MF_SB_IN();
                     if (more) nxt = __builtin_amdgcn_mfma_i32_16x16x64_i8(wd.A[2], t2.b[2], nxt, 0, 0, 0);
 #if MF_STAGE_KO & 1
                     *(uint32_t *)(lds + mb + moff(u)) = (uint32_t)(acc[0] ^ acc[1] ^ acc[2] ^ acc[3]);
 #else
                     *(uint32_t *)(lds + mb + moff(u)) = epi_pack4<MG, XR4>(r0, r1, r2, r3);
 #endif
-                    __builtin_amdgcn_sched_barrier(0);
+                    MF_SB_END();
                     acc = nxt, t2 = t3;
                 }
                 return hit;
@@ -345,7 +350,7 @@ __global__ __launch_bounds__(NTHR, 4) void stage_6x6x128(const int8_t *__restric
                         e1 = *(const v4i *)(lds + rb + 4 * PLANE6 + (c + 2) * 256);
                     }
                     v4i nxt = {wp.k.x, wp.k.y, wp.k.z, wp.k.w};
-                    __builtin_amdgcn_sched_barrier(0);
+                    MF_SB_IN();
                     if (more) nxt = __builtin_amdgcn_mfma_i32_16x16x64_i8(wp.A[0], c0, nxt, 0, 0, 0);
                     if constexpr (PR == 4) epi_patch_apply(acc, ppr, pg), epi_patch_apply(acc, ppr2, pg);
                     const float r0 = epi_value<MG>(acc[0], wp.a.x, wp.s.x, lo, hi);
@@ -354,7 +359,7 @@ __global__ __launch_bounds__(NTHR, 4) void stage_6x6x128(const int8_t *__restric
                         hit |= __builtin_amdgcn_ballot_w64(acc[PR] == Pl);
                         asm volatile("" : "+s"(hit)); // one running mask (left alone, the compiler keeps nine and spills scalars)
                     }
-                    __builtin_amdgcn_sched_barrier(0);
+                    MF_SB_IN();
                     if (more) nxt = __builtin_amdgcn_mfma_i32_16x16x64_i8(wp.A[1], c1, nxt, 0, 0, 0);
                     const float r2 = epi_value<MG>(acc[2], wp.a.z, wp.s.z, lo, hi);
                     const float r3 = epi_value<MG>(acc[3], wp.a.w, wp.s.w, lo, hi);
@@ -365,7 +370,7 @@ __global__ __launch_bounds__(NTHR, 4) void stage_6x6x128(const int8_t *__restric
 #endif
                     if (last) *(uint32_t *)(lds + oplain + c * 2048) = d;
                     else *(uint32_t *)(lds + o6[c]) = d;
-                    __builtin_amdgcn_sched_barrier(0);
+                    MF_SB_END();
                     acc = nxt, c0 = e0, c1 = e1;
                 }
                 return hit;
