@@ -168,8 +168,15 @@ struct RrPhase {
         constexpr int D_UG = TO_LDS ? Ge::CG * DstTile<NEXT>::TILE : Ge::CG * Ge::OPIX * Ge::N;
         constexpr int D_UY = TO_LDS ? Ge::CY * DstTile<NEXT>::ROW : Ge::CY * Ge::OW * Ge::N;
         constexpr int D_UX = TO_LDS ? XF * Ge::CX * DstTile<NEXT>::C : XF * Ge::CX * Ge::N;
-        // units in flight: both pairs' operands are resident, so the two-channel-group pairs (C = 32) keep one
-        constexpr int UB = NQ > 1 ? 1 : (NU % 2 == 0 ? 2 : (NU % 3 == 0 ? 3 : 1));
+        // units in flight (explicitly double-buffered tap rows): both pairs' operands are resident, so the two-channel-group pairs
+        // (C = 32) keep one
+#ifdef MF_QUAD_UB // (tuning: force the units in flight where the unit count allows it)
+        constexpr int UB = NU % MF_QUAD_UB == 0 ? MF_QUAD_UB : 1;
+#else
+        // (three in flight -- pair B of ops 1..4 has three units per wave -- measured 3 % slower for the whole launch than one at a
+        // time since a phase is one block: the scheduler overlaps the units as far as the registers go by itself)
+        constexpr int UB = NQ > 1 ? 1 : (NU % 2 == 0 ? 2 : 1);
+#endif
         auto coords = [](int iu, int &ug, int &uy, int &ux) constexpr {
             ug = (iu / (NUY * NUX)) * PSG, uy = ((iu / NUX) % NUY) * PSY, ux = (iu % NUX) * PSX;
         };
