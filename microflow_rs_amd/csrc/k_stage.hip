@@ -48,7 +48,9 @@
 #define MF_STAGE_PDIAG 0
 #endif
 #ifndef MF_STAGE_FENCE
-#define MF_STAGE_FENCE 3 // (tuning) bit 0: the fences inside a unit (MFMA / epilogue interleave), bit 1: the fence at the end of a unit
+#define MF_STAGE_FENCE 0 // (tuning) scheduling fences -- bit 0: inside a unit (the hand interleave of MFMAs and epilogue halves of rounds
+                         // 3-4), bit 1: at the end of a unit.  With the two-instruction epilogue of round 5 the compiler's own schedule of
+                         // the nine units of a phase is 1 % ahead of the fenced one (four same-box alternations), so none by default.
 #endif
 #define MF_SB_IN() do { if (MF_STAGE_FENCE & 1) __builtin_amdgcn_sched_barrier(0); } while (0)
 #define MF_SB_END() do { if (MF_STAGE_FENCE & 2) __builtin_amdgcn_sched_barrier(0); } while (0)
