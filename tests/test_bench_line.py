@@ -18,7 +18,8 @@ def check_compact(rec, line):
     rl = rec["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in rl, k
-    assert rl["bound"] in ("hbm", "valu", "mfma")
+    assert rl["bound"] in ("hbm", "mfma")            # the roof achieved / peak / frac are stated against (the contract's two)
+    assert rl.get("binding_roof", rl["bound"]) in ("hbm", "valu", "mfma")
     assert abs(rl["frac"] - rl["achieved"] / rl["peak"]) < 1e-3
 
 
