@@ -202,6 +202,44 @@ def test_one_patched_accumulator_rescues_the_channels_without_a_line(O):
     assert patched >= 3, patched
 
 
+def test_search_property_random_constants():
+    """Property test over random (A, S) and random reachable ranges: whatever the search returns -- with or without a patched
+    accumulator -- equals the reference at every accumulator next to one of the reference's steps and at both ends of the range.
+    Both maps are monotone staircases, so that is equality on the whole range (a step of the form inside a flat stretch of the
+    reference would show at the stretch's last accumulator, which is checked).  The reference side is numpy f32, the form side exact
+    python integers; neither uses the library's evaluators."""
+    from hypothesis import given, settings, strategies as st
+
+    stats = {"found": 0, "patched": 0, "none": 0}
+
+    @settings(max_examples=120, deadline=None, derandomize=True)
+    @given(a=st.floats(-300.0, 300.0, width=32), ls=st.floats(-13.0, 0.0), lo_frac=st.floats(0.0, 0.4), hi_frac=st.floats(0.6, 1.0),
+           u8=st.booleans())
+    def prop(a, ls, lo_frac, hi_frac, u8):
+        A, S = f32(a), f32(2.0 ** ls)
+        fmin, fmax = full_range(A, S) if not u8 else full_range(f32(A - 128.0), S)
+        amin = int(fmin + lo_frac * (fmax - fmin))
+        amax = int(fmin + hi_frac * (fmax - fmin))
+        r = search(A, S, amin, amax, u8=u8, patch=True)
+        if r is None:
+            stats["none"] += 1
+            return
+        s3, c3, d, pa, pd = r
+        stats["found"] += 1
+        stats["patched"] += pd != 0
+        acc = np.arange(amin, amax + 1, dtype=np.int64)
+        want = ref_numpy(A, S, acc, 0 if u8 else 128)
+        steps = np.flatnonzero(np.diff(want)) + 1                                   # first accumulator of every new output value
+        pts = np.unique(np.clip(np.concatenate([[0, len(acc) - 1], steps - 1, steps, [max(pa - amin, 0)] if pd else []]).astype(np.int64),
+                                0, len(acc) - 1))
+        got = fma_numpy(s3, c3, d, acc[pts], pa, pd)
+        assert np.array_equal(want[pts], got), (float(A), float(S), amin, amax, u8, acc[pts][want[pts] != got][:4])
+        assert np.all(np.diff(want) >= 0)
+
+    prop()
+    assert stats["found"] >= 60, stats      # (most random constants have a form; "none" is legitimate, see above)
+
+
 # ------------------------------------------------------------------------------------------------------- GPU
 @pytest.mark.gpu
 def test_cvt_pk_u8_f32_is_what_the_search_assumes():
