@@ -527,8 +527,8 @@ def main():
             yq = (yf / float(m.output_scale) + float(m.output_zero_point)).round().to(torch.int8).reshape(-1)
             predict_f32 = {"value": round(count / dt, 1), "unit": "inferences/s", "ms_per_step": round(dt * 1e3, 3),
                            "input_bytes": int(xf.numel() * 4), "same_outputs_as_int8_path": bool(torch.equal(yq, y)),
-                           "note": "f32 in HBM -> predict (boundary quantize fused into the stem kernel where the model "
-                                   "starts with it) -> dequantize kernel"}
+                           "note": "f32 in HBM -> predict (boundary quantize inside the first launch where the model starts "
+                                   "with a stem it has an f32 instance for) -> dequantize kernel"}
             del xf, yf
 
         generic_fb = rt_rec = None

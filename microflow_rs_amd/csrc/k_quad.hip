@@ -48,6 +48,7 @@
 
 namespace mf {
 namespace k {
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 template <int H_, int W_, int C_, int S_, int N_, int CG_, int CY_, int ORD_, int ROWPAD_, int TS_>
 struct RrGeom {
@@ -320,14 +321,21 @@ struct Quad57 {
 template <typename Q, bool STEM> constexpr int quad_stem_bytes() {
     return STEM ? 16 + (2 * Q::A::H + 2) * (2 * Q::A::W) : 0;
 }
-template <typename Q, bool STEM, int MG, uint32_t XR4>
+// F32IN (STEM only): the model's f32 entry (M::predict, microflow-macros/src/lib.rs:186-190: Tensor::quantize of the input, then
+// predict_inner).  The f32 image is DMA-staged into its own 36 KB buffer; between phase B and the stem phase every wave quantises
+// the nine image rows its own stem tiles read (its eight + the row above, which the wave above also writes, with the same bytes:
+// no barrier) into the stem tile, with dw3x3_stem8_mm's arithmetic (src/quantize.rs:16-22; the verified 3-instruction division of
+// k_common.hpp quant_div) -- in round-to-nearest: the single-fma epilogue's round-toward-zero is switched off around these lines.
+template <typename Q, bool STEM, int MG, uint32_t XR4, bool F32IN = false>
 __global__ __launch_bounds__(Q::NTHR, Q::WPE) void quad_rr(const int8_t *__restrict__ in, int8_t *__restrict__ out, QuadArgs p, int batch) {
+    static_assert(!F32IN || STEM, "the f32 entry is the stem's");
     using GA = typename Q::A;
     using GB = typename Q::B;
     epi_enter<MG>();
     constexpr int G = Q::G, NTHR = Q::NTHR, NWAVE = NTHR / 64;
     constexpr int BUF_A = G * GA::TILE, OFF_B = BUF_A + 512, BUF_B = G * GB::TILE, OFF_S = OFF_B + BUF_B + 512;
     constexpr int S_GUARD = 16, SW = 2 * GA::W, SH = 2 * GA::H, S_TILE = quad_stem_bytes<Q, STEM>(), OFF_Q = OFF_S + S_TILE;
+    constexpr int OFF_F = OFF_Q + 16; // (F32IN) the staged f32 image, verbatim: SH rows of SW floats
     static_assert(!STEM || (G == 1 && GA::C == 8 && GA::W == 48 && (GA::H / 2) % NWAVE == 0 && (SH * SW) % 1024 == 0 && S_TILE % 16 == 0),
                   "stem phase: 8 channels, 24 pixel pairs per output row, whole row pairs per wave");
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -347,6 +355,16 @@ __global__ __launch_bounds__(Q::NTHR, Q::WPE) void quad_rr(const int8_t *__restr
     __syncthreads(); // halo fills complete before any DMA lands
 
     auto stage = [&](int st) {
+        if constexpr (F32IN) { // the 96 x 96 f32 image, verbatim, in 1 KiB pieces
+            constexpr int NI = SH * SW * 4 / 1024;
+            static_assert(NI % NWAVE == 0, "f32 staging: whole pieces per wave");
+#pragma unroll
+            for (int k = 0; k < NI / NWAVE; ++k) {
+                const int r = k * NWAVE + wave;
+                dma16(in + ((size_t)st * (SH * SW * 4) + r * 1024 + lane * 16), lds + OFF_F + r * 1024);
+            }
+            return;
+        }
         if constexpr (STEM) { // the 96 x 96 x 1 image, verbatim, in 1 KiB pieces behind the guard and the padding row
             constexpr int NI = SH * SW / 1024;
 #pragma unroll
@@ -364,6 +382,34 @@ __global__ __launch_bounds__(Q::NTHR, Q::WPE) void quad_rr(const int8_t *__restr
             const int gi = r / GA::H, y = r % GA::H;
             if (r < NROWS && st * G + gi < batch && lane < GA::ROWCH)
                 dma16(in + ((size_t)(st * G + gi) * GA::IMG + y * GA::ROWB + src_lane * 16), lds + gi * GA::TILE + (y + 1) * GA::ROW + GA::LP);
+        }
+    };
+    // (F32IN) boundary quantisation of the image rows this wave's stem tiles read: rows 4 RPW wave - 1 .. 4 RPW wave + 4 RPW - 1
+    auto quant_rows = [&]() {
+        if constexpr (F32IN) {
+            constexpr int RPW = GA::H / 2 / NWAVE, NR = 4 * RPW + 1, C4 = SW / 4, NIT = (NR * C4 + 63) / 64;
+            asm volatile("" ::: "memory");
+            if constexpr (MG == 3) __builtin_amdgcn_s_setreg(0x801, 0); // MODE.FP_ROUND (f32) = nearest even, for these lines
+            asm volatile("" ::: "memory");
+            const int y0 = 4 * RPW * wave - 1;
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int item = it * 64 + lane, row = item / C4, c4 = item - row * C4, y = y0 + row;
+                if (item < NR * C4 && y >= 0) {
+                    const f32x4 v = *(const f32x4 *)(lds + OFF_F + (y * SW + 4 * c4) * 4);
+                    int qv[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float t = __fadd_rn(quant_div(v[e], p.in_scale, p.in_rcp, p.in_fast != 0), p.in_zp_f);
+                        const float r = __fadd_rn(t, __builtin_copysignf(0x1.fffffep-2f, t));
+                        qv[e] = (r != r) ? 0 : (int)__builtin_amdgcn_fmed3f(r, p.in_sat_lo, p.in_sat_hi);
+                    }
+                    *(uint32_t *)(lds + OFF_S + S_GUARD + (y + 1) * SW + 4 * c4) = pack4(qv[0], qv[1], qv[2], qv[3]) ^ p.in_xr4;
+                }
+            }
+            asm volatile("" ::: "memory");
+            if constexpr (MG == 3) __builtin_amdgcn_s_setreg(0x801, 3); // back to toward zero
+            asm volatile("" ::: "memory");
         }
     };
     // stem phase: three tile types per row pair (pairs 0..15 of row r0 | 16..23 of r0 and 0..7 of r0 + 1 | 8..23 of r0 + 1)
@@ -423,7 +469,7 @@ __global__ __launch_bounds__(Q::NTHR, Q::WPE) void quad_rr(const int8_t *__restr
         //     Y : tile B complete, tile A free, the next image landed          -> phase B, then the next image's stem phase
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (dq.step < nsteps) stem_phase(sc);
+        if (dq.step < nsteps) quant_rows(), stem_phase(sc);
         for (; dq.step < nsteps; dq.advance(tid)) {
             const int step = dq.step;
             if (!(MF_QUAD_KO & 16)) __syncthreads(); // X
@@ -435,7 +481,7 @@ __global__ __launch_bounds__(Q::NTHR, Q::WPE) void quad_rr(const int8_t *__restr
             if (Q::ACT_B == NWAVE || wave < Q::ACT_B)
                 pb.template run<void>(lds + OFF_B, (uint8_t *)out + (size_t)step * GB::OPIX * GB::N, 1);
             asm volatile("" : "+s"(sc)); // (the stem's operands are fetched here, every step, not hoisted into registers)
-            if (dq.nxt < nsteps) stem_phase(sc);
+            if (dq.nxt < nsteps) quant_rows(), stem_phase(sc);
             ++ko_steps;
         }
     } else {
@@ -456,22 +502,23 @@ __global__ __launch_bounds__(Q::NTHR, Q::WPE) void quad_rr(const int8_t *__restr
     dq.finish(tid);
 }
 
-template <typename Q, bool STEM, int MG, uint32_t XR4>
+template <typename Q, bool STEM, int MG, uint32_t XR4, bool F32IN = false>
 static void launch_quad_t(const int8_t *in, int8_t *out, const QuadArgs &a, int batch, hipStream_t s) {
-    constexpr int lds = Q::G * Q::A::TILE + 512 + Q::G * Q::B::TILE + 512 + quad_stem_bytes<Q, STEM>() + 16;
+    constexpr int lds = Q::G * Q::A::TILE + 512 + Q::G * Q::B::TILE + 512 + quad_stem_bytes<Q, STEM>() + 16 +
+                        (F32IN ? 4 * (2 * Q::A::H) * (2 * Q::A::W) : 0);
     static_assert(lds <= 163840, "quad tiles do not fit the LDS");
     static LaunchState st;
-    const int per_cu = prepared(st, quad_rr<Q, STEM, MG, XR4>, Q::NTHR, lds);
+    const int per_cu = prepared(st, quad_rr<Q, STEM, MG, XR4, F32IN>, Q::NTHR, lds);
     const int nsteps = (batch + Q::G - 1) / Q::G;
     const int grid = nsteps < 256 * per_cu ? nsteps : 256 * per_cu;
     QuadArgs b = a;
     using GA = typename Q::A;
     using GB = typename Q::B;
-    const double hbm = (double)batch * ((STEM ? 4 * GA::H * GA::W : GA::H * GA::W * GA::C) + GB::OPIX * GB::N);
+    const double hbm = (double)batch * ((STEM ? (F32IN ? 16 : 4) * GA::H * GA::W : GA::H * GA::W * GA::C) + GB::OPIX * GB::N);
     const double rq = (double)batch * ((STEM ? GA::H * GA::W * GA::C : 0) + GA::OPIX * (GA::C + GA::N) + GB::OPIX * (GB::C + GB::N));
     b.a.dw.qcfg = dq_config(nsteps, grid, dq_est_us(hbm, rq));
     b.a.dw.queue = dq_slot(b.a.dw.queue);
-    hipLaunchKernelGGL((quad_rr<Q, STEM, MG, XR4>), dim3(grid), dim3(Q::NTHR), lds, s, in, out, b, batch);
+    hipLaunchKernelGGL((quad_rr<Q, STEM, MG, XR4, F32IN>), dim3(grid), dim3(Q::NTHR), lds, s, in, out, b, batch);
 }
 template <typename Q> static bool quad_matches(int H, int W, int C, int S, int N, int H2, int W2, int C2, int S2, int N2) {
     using GA = typename Q::A;
@@ -523,6 +570,24 @@ bool launch_quad(int H, int W, int C, int S, int N, int H2, int W2, int C2, int 
 #undef MF_QUAD_GO
 #undef MF_QUAD_GO2
     return false;
+}
+// the f32 entry of the stem instance: `in` holds batch x (2 H) x (2 W) floats (16-byte aligned), a.in_* the boundary quantisation
+bool launch_quad_f32(int H, int W, int C, int S, int N, int H2, int W2, int C2, int S2, int N2, const float *in, int8_t *out, const QuadArgs &a,
+                     int batch, hipStream_t s) {
+    if (!a.stem || !a.f32_ok || !(quad_mask() & 4) || !quad_matches<Quad13>(H, W, C, S, N, H2, W2, C2, S2, N2)) return false;
+    if (!a.a.dw.wmm || !a.a.pw.wrr || !a.b.dw.wmm || !a.b.pw.wrr) return false;
+    const int mg = std::min(std::min(std::min(a.a.dw.magic, a.a.pw.magic), std::min(a.b.dw.magic, a.b.pw.magic)), a.stem_magic);
+    if (mg == 0) return false;
+    const int8_t *src = (const int8_t *)in;
+    if (mg == 3) launch_quad_t<Quad13, true, 3, 0u, true>(src, out, a, batch, s);
+    else if (a.b.pw.xr) {
+        if (mg == 2) launch_quad_t<Quad13, true, 2, 0x80808080u, true>(src, out, a, batch, s);
+        else launch_quad_t<Quad13, true, 1, 0x80808080u, true>(src, out, a, batch, s);
+    } else {
+        if (mg == 2) launch_quad_t<Quad13, true, 2, 0u, true>(src, out, a, batch, s);
+        else launch_quad_t<Quad13, true, 1, 0u, true>(src, out, a, batch, s);
+    }
+    return true;
 }
 
 } // namespace k

@@ -340,11 +340,18 @@ struct QuadArgs {
     uint32_t stem_izp4;
     float stem_lo, stem_hi;
     int stem_magic;
+    // the f32 entry of the stem instance (launch_quad_f32): the model-boundary quantisation q = sat(roundf(x / in_scale + in_zp_f)),
+    // DwStemArgs' fields (the f32-input stem kernel's); f32_ok: they are set
+    float in_scale, in_zp_f, in_sat_lo, in_sat_hi, in_rcp;
+    uint32_t in_xr4;
+    int in_fast, f32_ok;
 };
 const char *quad_name(int H, int W, int C, int S, int N, int H2, int W2, int C2, int S2, int N2);
 const char *quad_stem_name(int SH, int SW, int H, int W, int C, int S, int N, int H2, int W2, int C2, int S2, int N2); // with a.stem set
 bool launch_quad(int H, int W, int C, int S, int N, int H2, int W2, int C2, int S2, int N2, const int8_t *in, int8_t *out, const QuadArgs &a,
                  int batch, hipStream_t s);
+bool launch_quad_f32(int H, int W, int C, int S, int N, int H2, int W2, int C2, int S2, int N2, const float *in, int8_t *out, const QuadArgs &a,
+                     int batch, hipStream_t s);
 
 // fused network tail: AveragePool2D (to 1x1) -> Conv2D 1x1 (N <= 8) -> [Reshape] -> Softmax
 struct TailArgs {

@@ -162,6 +162,8 @@ FusedImpl *fused_quad_create(FusedImpl *pair1, FusedImpl *pair2); // two consecu
 FusedImpl *fused_quad_stem_create(OpImpl *stem, FusedImpl *quad); // the one-input-channel stem + a quad in one launch, or nullptr
 void fused_destroy(FusedImpl *f);
 void fused_run(FusedImpl *f, const int8_t *d_in, size_t batch, int8_t *d_out, void *stream);
+bool fused_accepts_f32(const FusedImpl *f);
+void fused_run_f32(FusedImpl *f, const float *d_in, size_t batch, int8_t *d_out, void *stream);
 const char *fused_kernel_name(const FusedImpl *f);
 int fused_epilogue_mode(const FusedImpl *f); // epilogue mode of the launch (one for all its requantising operators); -1: none
 

@@ -21,6 +21,7 @@ struct Switches {
     bool no_pairtail = false;      // MF_NO_PAIRTAIL      no pair + pool + conv + softmax tail (k_tail3.hip)
     bool no_quad = false;          // MF_NO_QUAD          no two-pair register-resident kernels (k_quad.hip)
     bool no_penta = false;         // MF_NO_PENTA         no stem + two pairs kernel (k_quad.hip)
+    bool no_f32_group = false;     // MF_NO_F32_GROUP     the f32 entry quantises in the stem kernel, not inside the stem + two pairs launch
     int quads = 7;                 // MF_QUADS            bit mask of the quad shapes allowed (1 | 2 | 4)
     bool no_magic = false;         // MF_NO_MAGIC         requantisation by v_cvt (epilogue mode 0) everywhere
     bool no_sat_pack = false;      // MF_NO_SAT_PACK      clamp by v_med3 (mode 1), never v_sat_pk (mode 2)

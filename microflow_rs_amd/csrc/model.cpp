@@ -400,10 +400,20 @@ static const int8_t *run_ops(ModelImpl *m, const int8_t *src, size_t batch, int 
     int last_real = last_op;
     while (last_real >= 0 && !m->ops[last_real]) --last_real;
     if (src_f32) {
-        op_run_f32(m->ops[0], src_f32, batch, (final_dst && last_real == 0) ? final_dst : m->act[0], stream);
-        cur = (final_dst && last_real == 0) ? final_dst : m->act[0];
+        // the second-level group that starts at operator 0 takes the f32 image itself if it can (penta_rr, k_quad.hip), else the
+        // stem kernel quantises while it stages and the groups behind it run as usual
+        const ModelImpl::Stage *st0 = stage_at(m, 0, last_op);
+        if (st0 && fused_accepts_f32(st0->f)) {
+            int8_t *dst = (final_dst && st0->last >= last_real) ? final_dst : m->act[0];
+            fused_run_f32(st0->f, src_f32, batch, dst, stream);
+            cur = dst;
+            first = st0->last + 1;
+        } else {
+            op_run_f32(m->ops[0], src_f32, batch, (final_dst && last_real == 0) ? final_dst : m->act[0], stream);
+            cur = (final_dst && last_real == 0) ? final_dst : m->act[0];
+            first = 1;
+        }
         which = 1;
-        first = 1;
     }
     for (int i = first; i <= last_op; ++i) {
         OpImpl *o = m->ops[i];

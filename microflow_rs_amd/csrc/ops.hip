@@ -1819,6 +1819,9 @@ FusedImpl *fused_quad_stem_create(OpImpl *stem, FusedImpl *quad) {
     f->stage_w.back()->upload(tab.data(), tab.size() * 4);
     f->quad.stem = f->stage_w.back()->as<uint32_t>();
     f->quad.stem_izp4 = sa.izp4, f->quad.stem_lo = sa.lo_f, f->quad.stem_hi = sa.hi_f, f->quad.stem_magic = sa.magic;
+    // the f32 entry (model.cpp sets the stem's input quantisation before the groups are built): same launch, f32 image in
+    f->quad.in_scale = sa.in_scale, f->quad.in_zp_f = sa.in_zp_f, f->quad.in_sat_lo = sa.in_sat_lo, f->quad.in_sat_hi = sa.in_sat_hi;
+    f->quad.in_rcp = sa.in_rcp, f->quad.in_xr4 = sa.in_xr4, f->quad.in_fast = sa.in_fast, f->quad.f32_ok = stem->accepts_f32 ? 1 : 0;
     f->epi_mode = std::min(std::min(pair_mode(f->quad.a), pair_mode(f->quad.b)), sa.magic);
     return f.release();
 }
@@ -1831,6 +1834,20 @@ int fused_epilogue_mode(const FusedImpl *f) {
     for (const OpImpl *o : {f->a, f->b, f->c})
         if (o && (o->s.kind == MF_OP_CONV_2D || o->s.kind == MF_OP_DEPTHWISE_CONV_2D)) mode = mode < 0 ? o->magic_mode : std::min(mode, o->magic_mode);
     return mode;
+}
+// the f32 entry of a group that starts with the network's first operator (M::predict: the boundary quantisation inside the launch)
+bool fused_accepts_f32(const FusedImpl *f) {
+    return f && f->kind == FusedImpl::QUAD && f->quad.stem && f->quad.f32_ok && !switches().no_f32_group;
+}
+void fused_run_f32(FusedImpl *f, const float *d_in, size_t batch, int8_t *d_out, void *stream) {
+    if (!batch) return;
+    if (!fused_accepts_f32(f)) fail(MF_ERR_UNSUPPORTED, "group has no f32-input kernel");
+    if (!d_in || !d_out || ((uintptr_t)d_in & 15)) fail(MF_ERR_INVALID_ARG, "fused_run_f32: null or unaligned device pointer");
+    if (batch > 0x7fffffffull / 4) fail(MF_ERR_INVALID_ARG, "batch too large for one launch");
+    const int *q = f->quad_shape;
+    if (!k::launch_quad_f32(q[0], q[1], q[2], q[3], q[4], q[5], q[6], q[7], q[8], q[9], d_in, d_out, f->quad, (int)batch, (hipStream_t)stream))
+        fail(MF_ERR_UNSUPPORTED, "f32 quad kernel missing");
+    MF_HIP(hipGetLastError());
 }
 void fused_run(FusedImpl *f, const int8_t *d_in, size_t batch, int8_t *d_out, void *stream) {
     if (!batch) return;

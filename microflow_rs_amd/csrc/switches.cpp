@@ -19,6 +19,7 @@ Switches switches_parse() {
     s.no_pairtail = env_set("MF_NO_PAIRTAIL");
     s.no_quad = env_set("MF_NO_QUAD");
     s.no_penta = env_set("MF_NO_PENTA");
+    s.no_f32_group = env_set("MF_NO_F32_GROUP");
     s.quads = (int)env_ll("MF_QUADS", 7);
     s.no_magic = env_set("MF_NO_MAGIC");
     s.no_sat_pack = env_set("MF_NO_SAT_PACK");

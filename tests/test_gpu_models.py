@@ -424,11 +424,13 @@ def test_sharded_replicas_in_one_process(O, name, n, replicas):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n", [1, 2, 3, 257])
+@pytest.mark.parametrize("n", [1, 2, 3, 257, 4099])
 def test_f32_predict_with_quantize_fused_into_the_stem(O, n):
-    """M::predict on person_detect: with fusion on, the boundary quantize runs inside the stem
-    kernel's staging (f32 pixels in, odd batches exercise the ragged last step); with fusion off it
-    is the separate quantize_f32 kernel.  Both must equal the oracle's predict bit for bit,
+    """M::predict on person_detect: with fusion on, the boundary quantize runs inside the first launch -- the five-operator
+    kernel's f32 instance (k_quad.hip F32IN: the quantisation between two of its phases, in round-to-nearest inside a
+    round-toward-zero kernel), or the stem kernel's staging under MF_NO_F32_GROUP / MF_NO_PENTA (scripts/switch_matrix.sh runs
+    both); odd batches exercise the ragged last step, 4099 many steps per workgroup; with fusion off it
+    is the separate quantize_f32 kernel.  All must equal the oracle's predict bit for bit,
     including values that quantize to ties and beyond the int8 range."""
     import torch
     mf = importlib.import_module("microflow_rs_amd")
