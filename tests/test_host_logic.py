@@ -273,7 +273,7 @@ def test_mode3_kernels_have_no_float_lowered_division():
     mode: it neither orders f32 instructions against the `s_setreg` nor knows that an integer `x % n` with a run-time n, which it
     lowers through v_rcp_iflag_f32 / v_mul_f32 / v_cvt_u32_f32, would now round differently.  So a kernel that switches the mode
     must contain NO f32 arithmetic besides the form's own v_fma_f32 (or its accumulating twin v_fmac_f32) and v_cvt_pk_u8_f32: the generated code of every such kernel
-    (41 instances in five translation units) is scanned for it."""
+    (42 instances in five translation units) is scanned for it."""
     import collections
     import re
     import shutil
@@ -291,7 +291,7 @@ def test_mode3_kernels_have_no_float_lowered_division():
         assert all(p.wait() == 0 for p in procs)
         f32 = re.compile(r"\s+v_(rcp|rsq|sqrt|div|cvt_f32|cvt_u32_f32|cvt_i32_f32|mul_f32|add_f32|sub_f32|mac_f32|mad_f32|rndne|trunc|floor|ceil|"
                          r"frexp|ldexp|med3_f32|max_f32|min_f32|mul_legacy|exp|log)")
-        switching = 0
+        switching = with_rne = 0
         for f in files:
             lines = open(os.path.join(tmp, f + ".s")).read().split("\n")
             for i in [k for k, l in enumerate(lines) if re.match(r"^_Z[A-Za-z0-9_]+:", l)]:
@@ -300,10 +300,21 @@ def test_mode3_kernels_have_no_float_lowered_division():
                 if not any("s_setreg" in l for l in body):
                     continue
                 switching += 1
+                # The one exception is explicit: the f32 entry of the five-operator launch (k_quad.hip F32IN) quantises its input
+                # in round-to-nearest between `s_setreg MODE, 0` and the next `s_setreg MODE, 3`.  LLVM models the mode register on
+                # f32 instructions (they are ordered against the two s_setreg), so every f32 instruction of that arithmetic must
+                # sit between the two in the listing; the lines in between are taken out before the scan.
+                rne = [k for k, l in enumerate(body) if "s_setreg" in l and l.rstrip().endswith(", 0")]
+                for k in reversed(rne):
+                    back = next((j for j in range(k + 1, len(body)) if "s_setreg" in body[j] and body[j].rstrip().endswith(", 3")), None)
+                    assert back is not None, (f, lines[i][:80], "round-to-nearest section never closed")
+                    with_rne += any(f32.match(l) for l in body[k:back])
+                    del body[k:back]
                 stray = collections.Counter(l.split()[0] for l in body if f32.match(l))
                 assert not stray, (f, lines[i][:80], dict(stray))
                 assert any("v_fma_f32" in l for l in body) and any("v_cvt_pk_u8_f32" in l for l in body)
     assert switching >= 30, switching
+    assert with_rne >= 1, with_rne   # (the f32 instance exists and its quantisation is where it belongs)
 
 
 def test_environment_switches_live_in_one_struct():
