@@ -517,15 +517,16 @@ def main():
             yf = torch.empty((count, m.output_elems), dtype=torch.float32, device="cuda")
             run_f = lambda: _lib.check(L.mf_model_predict(  # noqa: E731
                 m._h, xf.data_ptr(), count, yf.data_ptr(), _lib.MF_MEM_DEVICE))
-            run_f()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(5):
+            for _ in range(3):
                 run_f()
             torch.cuda.synchronize()
-            dt = (time.perf_counter() - t0) / 5
+            t0 = time.perf_counter()
+            for _ in range(20):
+                run_f()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / 20    # (wall clock over 20 back-to-back calls, like the headline)
             yq = (yf / float(m.output_scale) + float(m.output_zero_point)).round().to(torch.int8).reshape(-1)
-            predict_f32 = {"value": round(count / dt, 1), "unit": "inferences/s", "ms_per_step": round(dt * 1e3, 3),
+            predict_f32 = {"value": round(count / dt, 1), "unit": "inferences/s", "ms_per_step": round(dt * 1e3, 3), "iterations": 20,
                            "input_bytes": int(xf.numel() * 4), "same_outputs_as_int8_path": bool(torch.equal(yq, y)),
                            "note": "f32 in HBM -> predict (boundary quantize inside the first launch where the model starts "
                                    "with a stem it has an f32 instance for) -> dequantize kernel"}

@@ -38,7 +38,21 @@ def med(fn):
     return sorted(ts)[len(ts) // 2]
 
 
+def wall(fn, n=20):
+    import time
+    fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n * 1e3
+
+
 ti = med(lambda: _lib.check(L.mf_model_run_quantized(m._h, x.data_ptr(), B, y.data_ptr(), _lib.MF_MEM_DEVICE)))
 tf = med(lambda: _lib.check(L.mf_model_predict(m._h, xf.data_ptr(), B, yf.data_ptr(), _lib.MF_MEM_DEVICE)))
 yq = (yf / float(m.output_scale) + float(m.output_zero_point)).round().to(torch.int8).reshape(-1)
+wi = wall(lambda: _lib.check(L.mf_model_run_quantized(m._h, x.data_ptr(), B, y.data_ptr(), _lib.MF_MEM_DEVICE)))
+wf = wall(lambda: _lib.check(L.mf_model_predict(m._h, xf.data_ptr(), B, yf.data_ptr(), _lib.MF_MEM_DEVICE)))
+print("wall, 20 calls back to back: int8 %.4f ms | f32 %.4f ms" % (wi, wf))
 print("int8 %.4f ms (%.2f M/s) | f32 %.4f ms (%.2f M/s) | same outputs: %s" % (ti, B / ti / 1e3, tf, B / tf / 1e3, bool(torch.equal(yq, y))))
