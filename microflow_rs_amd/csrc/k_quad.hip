@@ -43,7 +43,8 @@
 
 #ifndef MF_QUAD_KO
 #define MF_QUAD_KO 0 // knock-out timing experiments (WRONG results, never shipped): 1 no depthwise requantisation, 2 no pointwise requantisation,
-                     // 4 no HBM stores, 8 no staging after the first step, 16 no barriers inside a step, 32 one of the three tap-row LDS loads only
+                     // 4 no HBM stores, 8 no staging after the first step, 16 no barriers inside a step, 32 one of the three tap-row LDS loads only,
+                     // (f32 instance) 64 no quantisation pass, 128 the pass without its arithmetic
 #endif
 
 namespace mf {
@@ -386,7 +387,7 @@ __global__ __launch_bounds__(Q::NTHR, Q::WPE) void quad_rr(const int8_t *__restr
     };
     // (F32IN) boundary quantisation of the image rows this wave's stem tiles read: rows 4 RPW wave - 1 .. 4 RPW wave + 4 RPW - 1
     auto quant_rows = [&]() {
-        if constexpr (F32IN) {
+        if constexpr (F32IN && !(MF_QUAD_KO & 64)) { // (knock-out 64: no quantisation pass at all)
             constexpr int RPW = GA::H / 2 / NWAVE, NR = 4 * RPW + 1, C4 = SW / 4, NIT = (NR * C4 + 63) / 64;
             asm volatile("" ::: "memory");
             if constexpr (MG == 3) __builtin_amdgcn_s_setreg(0x801, 0); // MODE.FP_ROUND (f32) = nearest even, for these lines
@@ -397,12 +398,37 @@ __global__ __launch_bounds__(Q::NTHR, Q::WPE) void quad_rr(const int8_t *__restr
                 const int item = it * 64 + lane, row = item / C4, c4 = item - row * C4, y = y0 + row;
                 if (item < NR * C4 && y >= 0) {
                     const f32x4 v = *(const f32x4 *)(lds + OFF_F + (y * SW + 4 * c4) * 4);
+                    // Four pixels at a time.  The verified 3-instruction division (k_common.hpp quant_div) for all four; its quotient is
+                    // finite for every input the verification let through, and then nothing below can produce a NaN -- so ONE test per
+                    // four pixels (not a branch per pixel: those cut this pass into blocks and were a third of its time) decides whether
+                    // the lane redoes its four with the general arithmetic (true division, NaN -> 0): non-finite inputs, or parameters
+                    // the 3-instruction form was not verified for.
                     int qv[4];
+                    float q[4];
+                    bool plain = p.in_fast != 0;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float t = __fadd_rn(quant_div(v[e], p.in_scale, p.in_rcp, p.in_fast != 0), p.in_zp_f);
-                        const float r = __fadd_rn(t, __builtin_copysignf(0x1.fffffep-2f, t));
-                        qv[e] = (r != r) ? 0 : (int)__builtin_amdgcn_fmed3f(r, p.in_sat_lo, p.in_sat_hi);
+                        const float q0 = __fmul_rn(v[e], p.in_rcp);
+                        q[e] = __fmaf_rn(__fmaf_rn(-p.in_scale, q0, v[e]), p.in_rcp, q0);
+                        plain = plain && (__builtin_fabsf(q[e]) <= 3.0e38f);
+                    }
+                    if constexpr ((MF_QUAD_KO & 128) != 0) { // (knock-out: the staging without the arithmetic)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) qv[e] = __float_as_int(v[e]);
+                    } else if (__builtin_expect(plain, 1)) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float t = __fadd_rn(q[e], p.in_zp_f);
+                            const float r = __fadd_rn(t, __builtin_copysignf(0x1.fffffep-2f, t));
+                            qv[e] = (int)__builtin_amdgcn_fmed3f(r, p.in_sat_lo, p.in_sat_hi);
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float t = __fadd_rn(__fdiv_rn(v[e], p.in_scale), p.in_zp_f);
+                            const float r = __fadd_rn(t, __builtin_copysignf(0x1.fffffep-2f, t));
+                            qv[e] = (r != r) ? 0 : (int)__builtin_amdgcn_fmed3f(r, p.in_sat_lo, p.in_sat_hi);
+                        }
                     }
                     *(uint32_t *)(lds + OFF_S + S_GUARD + (y + 1) * SW + 4 * c4) = pack4(qv[0], qv[1], qv[2], qv[3]) ^ p.in_xr4;
                 }
