@@ -303,13 +303,36 @@ def test_mode3_kernels_have_no_float_lowered_division():
                 # The one exception is explicit: the f32 entry of the five-operator launch (k_quad.hip F32IN) quantises its input
                 # in round-to-nearest between `s_setreg MODE, 0` and the next `s_setreg MODE, 3`.  LLVM models the mode register on
                 # f32 instructions (they are ordered against the two s_setreg), so every f32 instruction of that arithmetic must
-                # sit between the two in the listing; the lines in between are taken out before the scan.
-                rne = [k for k, l in enumerate(body) if "s_setreg" in l and l.rstrip().endswith(", 0")]
-                for k in reversed(rne):
+                # sit between the two in the listing -- or in a block the compiler moved out of line (the rarely taken general
+                # arithmetic) that is entered only from that section and leaves only back into it: checked on the control flow.
+                label = re.compile(r"^(\.LBB\d+_\d+):")
+                starts = [0] + [k for k, l in enumerate(body) if label.match(l)]
+                blocks = [(a, b) for a, b in zip(starts, starts[1:] + [len(body)])]
+                name_of = {a: (label.match(body[a]).group(1) if label.match(body[a]) else "entry") for a, _ in blocks}
+                at = {name_of[a]: n for n, (a, _) in enumerate(blocks)}
+                rne_lines = set()
+                for k in [k for k, l in enumerate(body) if "s_setreg" in l and l.rstrip().endswith(", 0")]:
                     back = next((j for j in range(k + 1, len(body)) if "s_setreg" in body[j] and body[j].rstrip().endswith(", 3")), None)
                     assert back is not None, (f, lines[i][:80], "round-to-nearest section never closed")
-                    with_rne += any(f32.match(l) for l in body[k:back])
-                    del body[k:back]
+                    rne_lines.update(range(k, back))
+                succ = []
+                for n, (a, b) in enumerate(blocks):
+                    ins = [l.split() for l in body[a:b] if l.startswith("\t") and not l.strip().startswith((";", "."))]
+                    out = {at[w[1]] for w in ins if w and w[0].startswith(("s_cbranch", "s_branch")) and w[1] in at}
+                    if not (ins and ins[-1][0] in ("s_branch", "s_endpgm")) and n + 1 < len(blocks):
+                        out.add(n + 1)
+                    succ.append(out)
+                in_rne = [any(k in rne_lines for k in range(a, b)) for a, b in blocks]
+                has_f32 = [any(f32.match(body[k]) and k not in rne_lines for k in range(a, b)) for a, b in blocks]
+                cold = {n for n in range(len(blocks)) if has_f32[n] and not in_rne[n]}
+                for n in sorted(cold):
+                    preds = {m for m in range(len(blocks)) if n in succ[m]}
+                    assert preds and all(in_rne[m] or m in cold for m in preds), (f, lines[i][:80], name_of[blocks[n][0]], "entered from outside the section")
+                    assert succ[n] and all(in_rne[m] or m in cold for m in succ[n]), (f, lines[i][:80], name_of[blocks[n][0]], "leaves the section")
+                with_rne += bool(rne_lines)
+                keep = [k for k in range(len(body)) if k not in rne_lines and not any(a <= k < b for n, (a, b) in enumerate(blocks) if n in cold)]
+                # (a block that straddles a section border keeps its lines outside the section in the scan)
+                body = [body[k] for k in keep]
                 stray = collections.Counter(l.split()[0] for l in body if f32.match(l))
                 assert not stray, (f, lines[i][:80], dict(stray))
                 assert any("v_fma_f32" in l for l in body) and any("v_cvt_pk_u8_f32" in l for l in body)
