@@ -31,6 +31,12 @@ for seed in range(nseeds):
     want = om.run_quantized_batch(xq)
     names = [m.op(i)["kernel"] for i in range(m.num_ops)]
     ok = np.array_equal(got, want)
+    # the f32 entry (M::predict: the boundary quantisation inside the first launch) on the same images, bit for bit
+    xf = ((xq.astype(np.float32) - np.float32(om.in_zp)) * om.in_scale).astype(np.float32)
+    pf = np.asarray(m.predict(xf.reshape((n,) + tuple(m.input_shape)))).reshape(n, -1)
+    wf = np.stack([om.predict(v).reshape(-1) for v in xf[: min(n, 6)]])
+    ok = ok and np.array_equal(pf[: wf.shape[0]].view(np.uint32), wf.view(np.uint32))
+    modes = sorted(set(m.op_epilogue_mode(i) for i in range(m.num_ops) if names[i] and not names[i].startswith("(")))
     if not ok:  # localise
         _, layers = om.run_quantized(xq[0], layers=True)
         for i, lay in enumerate(layers):
@@ -39,6 +45,6 @@ for seed in range(nseeds):
                 print("seed", seed, "first differing layer", i, names[i])
                 break
         bad += 1
-    print("seed %d %s batch %d: %s (%s, %s)" % (seed, "u8" if elem == tw.UINT8 else "i8", n, "ok" if ok else "MISMATCH", names[0].split("<")[0], names[5].split("<")[0]))
+    print("seed %d %s batch %d modes %s: %s (%s, %s)" % (seed, "u8" if elem == tw.UINT8 else "i8", n, modes, "ok" if ok else "MISMATCH", names[0].split("<")[0], names[5].split("<")[0]))
 print("fuzz", "ok" if not bad else "FAILED %d" % bad)
 sys.exit(1 if bad else 0)
