@@ -12,7 +12,7 @@ import microflow_rs_amd as mf  # noqa: E402
 from microflow_rs_amd.model import synth_i8  # noqa: E402
 
 iters = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 40
-B = 65536
+B = int(os.environ.get("MF_TIME_BATCH", "65536"))   # (per-launch times at another batch, e.g. to see what the 256 MB memory-side cache does)
 m = mf.model(os.path.join(ROOT, "models", "person_detect.tflite"))
 m.prepare(B, device=0)
 if "layerwise" in sys.argv:
