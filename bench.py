@@ -917,7 +917,7 @@ def runtime_geometry_record(ctx, table_layerwise):
     rec = {"note": "run-time-geometry kernels (k_rt.hip: dw3x3_rt, pw_rt, conv_rows_lds); GB/s = algorithmic bytes / median launch time"}
     try:
         out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "time_kernels.py"), "20", "layerwise", "--json"],
-                             env=dict(os.environ, MF_NO_TABLE="1"), capture_output=True, text=True, timeout=300)
+                             env=dict(os.environ, MF_DEV="1", MF_NO_TABLE="1"), capture_output=True, text=True, timeout=300)
         j = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
         tab = {k["op"]: k for k in table_layerwise}
         rows = []

@@ -167,7 +167,7 @@ def lib():
         raise ImportError("libmicroflow_amd.so ABI version mismatch")
     import re
     info = (L.mf_build_info() or b"").decode()
-    if re.search(r"-DMF_\w*(KO|DIAG)\w*=(?!0(\s|$))", info) and not os.environ.get("MF_ALLOW_DIAG_BUILD"):
+    if re.search(r"-DMF_\w*(KO|DIAG)\w*(=(?!0(\s|$))|\s|$)", info) and not os.environ.get("MF_ALLOW_DIAG_BUILD"):
         raise ImportError("libmicroflow_amd.so was built with knock-out / diagnostic switches (%s): its kernels are wrong on "
                           "purpose.  Rebuild without MF_EXTRA_HIPCC_FLAGS (python microflow_rs_amd/build.py --force), or set "
                           "MF_ALLOW_DIAG_BUILD=1 for a profiling script." % info)

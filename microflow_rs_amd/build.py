@@ -30,7 +30,7 @@ FLAGS += EXTRA
 # Such a build says so loudly here, carries the flags inside the library (mf_build_info) and is refused by _lib.py unless
 # MF_ALLOW_DIAG_BUILD=1 is set, so that it cannot pass for the product.
 import re  # noqa: E402
-NONSHIPPING = [f for f in EXTRA if re.match(r"-DMF_\w*(KO|DIAG)\w*=(?!0$)", f)]
+NONSHIPPING = [f for f in EXTRA if re.match(r"-DMF_\w*(KO|DIAG)\w*(=(?!0$)|$)", f)]  # (a bare -DMF_X_KO defines it as 1)
 
 
 # measurement tool, not product: the requantisation-rate microbenchmark bench.py runs beside its timed region

@@ -41,6 +41,29 @@
 #define MF_Q57_X2B 3
 #endif
 
+// hipcc orders every LDS *store* behind all of the wave's outstanding LDS-DMA loads (SIInsertWaitcnts cannot tell the two LDS ranges
+// apart): in the stem instance the next image's DMA is issued right in front of phase A, whose first store into tile B then waited
+// for the HBM round trip (scripts/asm_dma_waits.py lists such waits).  1: in the STEM instances pair A's tile-B stores are inline asm
+// (the pass does not look into it); the kernel's own waits -- vmcnt(0) in front of the barrier that hands the staged image over,
+// lgkmcnt(0) in front of every barrier -- are what orders them.  2: in every instance (measured on ops 5..8, where no DMA is in
+// flight during phase A: 0.445 -> 0.475 ms, the asm statements hem the scheduler in).  Same box, ops 0..4: 0.814 -> 0.766 ms.
+#ifndef MF_QUAD_ASM_LDS
+#define MF_QUAD_ASM_LDS 1
+#endif
+#ifndef MF_QUAD_ASM_CLOBBER
+#define MF_QUAD_ASM_CLOBBER 1 // (tuning: 0 = the asm stores carry no "memory" clobber)
+#endif
+// 1: the stem's per-lane operands are read from an LDS copy made once per launch instead of from device memory every step: a
+// vector-memory load returns in order behind phase B's output stores, so the stem phase used to start with a wait for those
+// (same box, ops 0..4: 0.814 -> 0.755 ms; with the asm stores 0.713).
+#ifndef MF_QUAD_STEM_LDS
+#define MF_QUAD_STEM_LDS 1
+#endif
+// 1 (instances without the stem): the wait at the top of a step leaves phase B's output stores in flight -- they were issued after
+// the staging DMAs, and vmcnt retires in order -- instead of draining them.
+#ifndef MF_QUAD_CNT_WAIT
+#define MF_QUAD_CNT_WAIT 0
+#endif
 #ifndef MF_QUAD_KO
 #define MF_QUAD_KO 0 // knock-out timing experiments (WRONG results, never shipped): 1 no depthwise requantisation, 2 no pointwise requantisation,
                      // 4 no HBM stores, 8 no staging after the first step, 16 no barriers inside a step, 32 one of the three tap-row LDS loads only,
@@ -50,6 +73,38 @@
 namespace mf {
 namespace k {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// LDS stores the compiler's wait-count pass does not see (MF_QUAD_ASM_LDS).  `p` points into the workgroup's LDS; OFF is a
+// compile-time byte offset (< 65536: the instruction's offset field).
+typedef __attribute__((address_space(3))) uint8_t lds_u8_t;
+// (`off` must fold to a constant -- the unit loops are fully unrolled -- or the build fails at the "i" constraint)
+__device__ __forceinline__ void lds_store_asm(uint8_t *p, int off, uint2 v) {
+    typedef unsigned int u32x2_ __attribute__((ext_vector_type(2)));
+    const uint32_t a = (uint32_t)(uintptr_t)(lds_u8_t *)p;
+    const u32x2_ d = {v.x, v.y};
+#if MF_QUAD_ASM_CLOBBER
+    asm volatile("ds_write_b64 %0, %1 offset:%2" : : "v"(a), "v"(d), "i"(off) : "memory");
+#else
+    asm volatile("ds_write_b64 %0, %1 offset:%2" : : "v"(a), "v"(d), "i"(off));
+#endif
+}
+__device__ __forceinline__ void lds_store_asm(uint8_t *p, int off, uint4 v) {
+    const uint32_t a = (uint32_t)(uintptr_t)(lds_u8_t *)p;
+    const u32x4 d = {v.x, v.y, v.z, v.w};
+#if MF_QUAD_ASM_CLOBBER
+    asm volatile("ds_write_b128 %0, %1 offset:%2" : : "v"(a), "v"(d), "i"(off) : "memory");
+#else
+    asm volatile("ds_write_b128 %0, %1 offset:%2" : : "v"(a), "v"(d), "i"(off));
+#endif
+}
+// the barrier of a kernel that stores with lds_store_asm: the compiler does not count those stores, so the wait is spelled out
+template <bool ASMST> __device__ __forceinline__ void quad_barrier() {
+    if constexpr (ASMST) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+// the bare instruction: __syncthreads() carries a workgroup-scope fence, which hipcc completes with vmcnt(0) while it believes an
+// LDS-DMA may be outstanding -- that would drain the output stores a counted wait (MF_QUAD_CNT_WAIT) has just left in flight
+__device__ __forceinline__ void quad_barrier_raw() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 template <int H_, int W_, int C_, int S_, int N_, int CG_, int CY_, int ORD_, int ROWPAD_, int TS_>
 struct RrGeom {
@@ -162,7 +217,8 @@ struct RrPhase {
     }
 
     // tb: this pair's staged input tile(s); dst: the step's output tensor in HBM, or the next pair's LDS tile
-    template <typename NEXT>
+    // ASMST: stores into the next pair's tile as inline asm (MF_QUAD_ASM_LDS)
+    template <typename NEXT, bool ASMST = false>
     __device__ __forceinline__ void run(const uint8_t *tb, uint8_t *dst, int gvalid) const {
         constexpr bool TO_LDS = !std::is_void<NEXT>::value;
         // strides of one unit step at the destination
@@ -267,7 +323,11 @@ struct RrPhase {
                 const int doff = ug * D_UG + uy * D_UY + ux * D_UX;
                 // (one image per step: nothing to test, and no branch between the units -- the scheduler then works across them)
                 if (G == 1 || cg + wug + ug * Ge::CG < gvalid) { // a ragged last step stages fewer than G images
-                    if constexpr (TO_LDS) {
+                    if constexpr (TO_LDS && ASMST) {
+                        static_assert(G * DstTile<NEXT>::TILE < 65536, "tile offsets fit the ds offset field");
+                        if constexpr (Ge::LB == 8) lds_store_asm(dst + dst_lane, doff, make_uint2(packed[0], packed[1]));
+                        else lds_store_asm(dst + dst_lane, doff, make_uint4(packed[0], packed[1], packed[2], packed[3]));
+                    } else if constexpr (TO_LDS) {
                         if constexpr (Ge::LB == 8) *(uint2 *)(dst + dst_lane + doff) = make_uint2(packed[0], packed[1]);
                         else *(uint4 *)(dst + dst_lane + doff) = make_uint4(packed[0], packed[1], packed[2], packed[3]);
                     } else if (!(MF_QUAD_KO & 4) || packed[0] == 0x12345678u) {
@@ -337,6 +397,11 @@ __global__ __launch_bounds__(Q::NTHR, Q::WPE) void quad_rr(const int8_t *__restr
     constexpr int BUF_A = G * GA::TILE, OFF_B = BUF_A + 512, BUF_B = G * GB::TILE, OFF_S = OFF_B + BUF_B + 512;
     constexpr int S_GUARD = 16, SW = 2 * GA::W, SH = 2 * GA::H, S_TILE = quad_stem_bytes<Q, STEM>(), OFF_Q = OFF_S + S_TILE;
     constexpr int OFF_F = OFF_Q + 16; // (F32IN) the staged f32 image, verbatim: SH rows of SW floats
+    constexpr int OFF_C = OFF_F + (F32IN ? 4 * SH * SW : 0); // (STEM, MF_QUAD_STEM_LDS) the stem's operands: QuadArgs::stem's 152 dwords
+    // (the f32 instance and the two-rounding epilogue forms sit on the 168-register step, where the copy's LDS pointer costs spills: they
+    // keep the device-memory reads unless MF_QUAD_STEM_LDS is 2)
+    constexpr bool ASMST = MF_QUAD_ASM_LDS == 2 || (MF_QUAD_ASM_LDS == 1 && STEM);
+    constexpr bool STEM_LDS = STEM && MF_QUAD_STEM_LDS != 0 && ((!F32IN && MG == 3) || MF_QUAD_STEM_LDS > 1);
     static_assert(!STEM || (G == 1 && GA::C == 8 && GA::W == 48 && (GA::H / 2) % NWAVE == 0 && (SH * SW) % 1024 == 0 && S_TILE % 16 == 0),
                   "stem phase: 8 channels, 24 pixel pairs per output row, whole row pairs per wave");
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -346,6 +411,8 @@ __global__ __launch_bounds__(Q::NTHR, Q::WPE) void quad_rr(const int8_t *__restr
     dq.init(lds + OFF_Q, p.a.dw.queue, tid, p.a.dw.qcfg);
     if constexpr (STEM) // the stem tile's guard and padding rows hold the stem's input zero point
         for (int i = tid; i < S_TILE / 16; i += NTHR) ((uint4 *)(lds + OFF_S))[i] = make_uint4(p.stem_izp4, p.stem_izp4, p.stem_izp4, p.stem_izp4);
+    if constexpr (STEM_LDS) // the stem's operands, the accumulator start values with the epilogue form's offset folded in
+        if (tid < 152) ((uint32_t *)(lds + OFF_C))[tid] = p.stem[tid] + ((MG != 0 && tid >= 144) ? (uint32_t)MF_MAGIC_I : 0u);
     // tile A's halo holds pair A's input zero point, tile B's pair B's (= the zero point of pair A's output tensor)
     for (int i = tid; i < OFF_B / 16; i += NTHR) ((uint4 *)lds)[i] = make_uint4(p.a.dw.izp4, p.a.dw.izp4, p.a.dw.izp4, p.a.dw.izp4);
     for (int i = tid; i < (BUF_B + 512) / 16; i += NTHR) ((uint4 *)(lds + OFF_B))[i] = make_uint4(p.b.dw.izp4, p.b.dw.izp4, p.b.dw.izp4, p.b.dw.izp4);
@@ -444,17 +511,25 @@ __global__ __launch_bounds__(Q::NTHR, Q::WPE) void quad_rr(const int8_t *__restr
         const int col = lane & 15, g = lane >> 4;
         // (the pointer is laundered every step, so the compiler no longer knows it is global: say so, or these become flat loads
         // that count on lgkmcnt as well and make every LDS wait of the phase wait for them)
-        typedef __attribute__((address_space(1))) const uint32_t g_u32;
-        g_u32 *gsc = (g_u32 *)(uintptr_t)sc;
-        typedef long i64x1 __attribute__((ext_vector_type(1)));
-        const long Aw = (*(__attribute__((address_space(1))) const i64x1 *)(gsc + 2 * lane))[0];
         const int cq = (g & 1) * 4;                   // this lane's channels within its pixel
-        const v4i cA_ = *(__attribute__((address_space(1))) const v4i *)(gsc + 128 + cq), cS_ = *(__attribute__((address_space(1))) const v4i *)(gsc + 136 + cq);
-        const v4i ck_ = *(__attribute__((address_space(1))) const v4i *)(gsc + 144 + cq);
+        long Aw;
+        v4i cA_, cS_, cK;
+        if constexpr (STEM_LDS) { // from the LDS copy (made before the first barrier): no vector-memory wait in this phase
+            const uint32_t *lsc = (const uint32_t *)(lds + OFF_C);
+            Aw = *(const long *)(lsc + 2 * lane);
+            cA_ = *(const v4i *)(lsc + 128 + cq), cS_ = *(const v4i *)(lsc + 136 + cq), cK = *(const v4i *)(lsc + 144 + cq);
+        } else {
+            typedef __attribute__((address_space(1))) const uint32_t g_u32;
+            g_u32 *gsc = (g_u32 *)(uintptr_t)sc;
+            typedef long i64x1 __attribute__((ext_vector_type(1)));
+            Aw = (*(__attribute__((address_space(1))) const i64x1 *)(gsc + 2 * lane))[0];
+            cA_ = *(__attribute__((address_space(1))) const v4i *)(gsc + 128 + cq), cS_ = *(__attribute__((address_space(1))) const v4i *)(gsc + 136 + cq);
+            const v4i ck_ = *(__attribute__((address_space(1))) const v4i *)(gsc + 144 + cq);
+            const int4 ck = magic4<MG>(make_int4(ck_[0], ck_[1], ck_[2], ck_[3]));
+            cK = v4i{ck.x, ck.y, ck.z, ck.w};
+        }
         const float4 cA = make_float4(__int_as_float(cA_[0]), __int_as_float(cA_[1]), __int_as_float(cA_[2]), __int_as_float(cA_[3]));
         const float4 cS = make_float4(__int_as_float(cS_[0]), __int_as_float(cS_[1]), __int_as_float(cS_[2]), __int_as_float(cS_[3]));
-        const int4 ck = magic4<MG>(make_int4(ck_[0], ck_[1], ck_[2], ck_[3]));
-        const v4i cK = {ck.x, ck.y, ck.z, ck.w};
         const int oy1 = col >= 8 ? 1 : 0, j1 = col >= 8 ? col - 8 : 16 + col;
         // operand: the aligned dwords at columns 4j - 4 and 4j of tile row 2 oy + ky (ky = g; tile row 0 = input row -1)
         const int off0 = S_GUARD + g * SW + 4 * col - 4, off1 = S_GUARD + (2 * oy1 + g) * SW + 4 * j1 - 4, off2 = S_GUARD + (2 + g) * SW + 4 * (8 + col) - 4;
@@ -498,12 +573,12 @@ __global__ __launch_bounds__(Q::NTHR, Q::WPE) void quad_rr(const int8_t *__restr
         if (dq.step < nsteps) quant_rows(), stem_phase(sc);
         for (; dq.step < nsteps; dq.advance(tid)) {
             const int step = dq.step;
-            if (!(MF_QUAD_KO & 16)) __syncthreads(); // X
+            if (!(MF_QUAD_KO & 16)) quad_barrier<ASMST>(); // X
             dq.top(tid);
             if (dq.nxt < nsteps && !((MF_QUAD_KO & 8) && ko_steps > 0)) stage(dq.nxt);
-            if (Q::ACT_A == NWAVE || wave < Q::ACT_A) pa.template run<GB>(lds, lds + OFF_B, 1);
+            if (Q::ACT_A == NWAVE || wave < Q::ACT_A) pa.template run<GB, ASMST>(lds, lds + OFF_B, 1);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (!(MF_QUAD_KO & 16)) __syncthreads(); // Y
+            if (!(MF_QUAD_KO & 16)) quad_barrier<ASMST>(); // Y
             if (Q::ACT_B == NWAVE || wave < Q::ACT_B)
                 pb.template run<void>(lds + OFF_B, (uint8_t *)out + (size_t)step * GB::OPIX * GB::N, 1);
             asm volatile("" : "+s"(sc)); // (the stem's operands are fetched here, every step, not hoisted into registers)
@@ -511,14 +586,26 @@ __global__ __launch_bounds__(Q::NTHR, Q::WPE) void quad_rr(const int8_t *__restr
             ++ko_steps;
         }
     } else {
+        bool first = true;
         for (; dq.step < nsteps; dq.advance(tid)) {
             const int step = dq.step;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads(); // this step's image is staged; every wave is done reading tile B (the previous step's phase B)
+            // this step's image must have landed.  Outstanding, oldest first: the staging DMAs (issued behind the barrier in the middle
+            // of the previous step), then that step's NU output stores of phase B -- vmcnt retires in order, so the stores can stay in flight
+            if (MF_QUAD_CNT_WAIT && G == 1 && !first && (Q::ACT_B == NWAVE || wave < Q::ACT_B)) {
+                constexpr int NSTORE = decltype(pb)::NU;
+                static_assert(NSTORE >= 0 && NSTORE < 16, "counted wait");
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSTORE) : "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            first = false;
+            // this step's image is staged; every wave is done reading tile B (the previous step's phase B)
+            if constexpr (MF_QUAD_CNT_WAIT != 0 && G == 1) quad_barrier_raw();
+            else quad_barrier<ASMST>();
             dq.top(tid);
             const int gvalid = min(G, batch - step * G);
-            if (Q::ACT_A == NWAVE || wave < Q::ACT_A) pa.template run<GB>(lds, lds + OFF_B, gvalid); // pair A: tile A -> tile B
-            if (!(MF_QUAD_KO & 16)) __syncthreads(); // tile B is complete; tile A is free
+            if (Q::ACT_A == NWAVE || wave < Q::ACT_A) pa.template run<GB, ASMST>(lds, lds + OFF_B, gvalid); // pair A: tile A -> tile B
+            if (!(MF_QUAD_KO & 16)) quad_barrier<ASMST>(); // tile B is complete; tile A is free
             if (dq.nxt < nsteps && !((MF_QUAD_KO & 8) && ko_steps > 0)) stage(dq.nxt); // lands during phase B
             if (Q::ACT_B == NWAVE || wave < Q::ACT_B)
                 pb.template run<void>(lds + OFF_B, (uint8_t *)out + (size_t)step * G * GB::OPIX * GB::N, gvalid); // pair B: tile B -> HBM
@@ -531,7 +618,7 @@ __global__ __launch_bounds__(Q::NTHR, Q::WPE) void quad_rr(const int8_t *__restr
 template <typename Q, bool STEM, int MG, uint32_t XR4, bool F32IN = false>
 static void launch_quad_t(const int8_t *in, int8_t *out, const QuadArgs &a, int batch, hipStream_t s) {
     constexpr int lds = Q::G * Q::A::TILE + 512 + Q::G * Q::B::TILE + 512 + quad_stem_bytes<Q, STEM>() + 16 +
-                        (F32IN ? 4 * (2 * Q::A::H) * (2 * Q::A::W) : 0);
+                        (F32IN ? 4 * (2 * Q::A::H) * (2 * Q::A::W) : 0) + (STEM ? 640 : 0);
     static_assert(lds <= 163840, "quad tiles do not fit the LDS");
     static LaunchState st;
     const int per_cu = prepared(st, quad_rr<Q, STEM, MG, XR4, F32IN>, Q::NTHR, lds);

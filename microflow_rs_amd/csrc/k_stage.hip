@@ -47,6 +47,9 @@
 #ifndef MF_STAGE_PDIAG
 #define MF_STAGE_PDIAG 0
 #endif
+#ifndef MF_STAGE_CNT_WAIT
+#define MF_STAGE_CNT_WAIT 0 // (tuning) 1: the wait at the top of a step leaves the previous step's output stores in flight
+#endif
 #ifndef MF_STAGE_FENCE
 #define MF_STAGE_FENCE 0 // (tuning) scheduling fences -- bit 0: inside a unit (the hand interleave of MFMAs and epilogue halves of rounds
                          // 3-4), bit 1: at the end of a unit.  With the two-instruction epilogue of round 5 the compiler's own schedule of
@@ -232,8 +235,17 @@ __global__ __launch_bounds__(NTHR, 4) void stage_6x6x128(const int8_t *__restric
     for (; dq.step < nsteps; dq.advance(tid)) {
         const int step = dq.step;
         MF_TR(24);
+#if MF_STAGE_CNT_WAIT
+        // This step's images and the first depthwise operands must have landed; the previous step's copy-out stores -- two or three per
+        // wave, issued after them, and vmcnt retires in order -- may stay in flight.  (The bare barrier: __syncthreads() carries a fence
+        // that hipcc completes with vmcnt(0) while it believes an LDS-DMA may be outstanding.)
+        if (ko_steps > 0) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#else
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads(); // this step's images are in the tile; the previous step's output has been copied out of region A
+#endif
         dq.top(tid);
         asm volatile("" : "+s"(pairs));
         const int gvalid = min(G, batch - step * G);

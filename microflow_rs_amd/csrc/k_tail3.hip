@@ -28,6 +28,9 @@
 // HBM traffic: 2304 B in, N bytes out per inference.  Image pitch 2320 B: the 16 lanes of a b128 service group hit
 // 16 distinct 16-byte bank slots (2320 / 4 = 4 mod 64 words).
 #include "k_common.hpp"
+#ifndef MF_TAIL3_RAW_BARRIER
+#define MF_TAIL3_RAW_BARRIER 0 // (tuning)
+#endif
 
 #ifndef MF_TAIL3_DIAG
 #define MF_TAIL3_DIAG 0 // 1: cycle stamps of block 0 / wave 0 at the phase boundaries of its first two steps (never shipped)
@@ -140,7 +143,13 @@ __global__ __launch_bounds__(NTHR) void pair3_tail(const int8_t *__restrict__ in
                 requant_pack4<MG, XR4>(acc[0], acc[1], acc[2], acc[3], dA, dS, p.dw_lo, p.dw_hi);
         }
         MF_TR(1);
+#if MF_TAIL3_RAW_BARRIER
+        // (the bare instruction: __syncthreads() carries a fence that hipcc completes with vmcnt(0) while an LDS-DMA is outstanding --
+        // the next step's images, staged a whole step ahead, would have to land by here)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); // MID complete
+#else
         __syncthreads(); // MID complete
+#endif
         if constexpr (!DBUF) { // one image set: it has been read, refill it under the rest of the step
             if (blk + gridDim.x < nblk) stage(blk + gridDim.x, 0);
         }

@@ -1,6 +1,8 @@
 // Every switch libmicroflow_amd.so reads from the environment, in one place.
 //
-// None of them is part of the product interface (that is include/microflow_amd.h): they are the A/B levers of the test matrix
+// None of them is part of the product interface (that is include/microflow_amd.h), and the library IGNORES every routing / tuning
+// switch unless the process also sets MF_DEV=1 (a stray MF_NO_QUAD in somebody's shell must not change which kernels a product
+// runs); only the diagnostics (MF_VERBOSE, MF_CHAIN_VERBOSE, MF_DQ_VERBOSE, MF_DEBUG_EPI) work without it.  They are the A/B levers of the test matrix
 // (scripts/switch_matrix.sh: the parity suite must be green under every MF_NO_* switch, because each turns one fused kernel off
 // and sends its operators down the next more general path) and of the tuning scripts (scripts/tune_*.sh, scripts/dq_*.py).
 // The environment is read ONCE, at the first call of switches(); the only exception is the step-queue tuning set, re-read per
@@ -11,6 +13,7 @@
 namespace mf {
 
 struct Switches {
+    bool dev = false;              // MF_DEV=1            master switch: without it every field below the diagnostics keeps its default
     // ---- routing: turn one specialised path off (tests: results must not change) ----
     bool no_rt = false;            // MF_NO_RT            no run-time-shape kernels (k_rt.hip): generated shapes take the generic kernels
     bool no_stem_rt = false;       // MF_NO_STEM_RT       ... for the C = 1 stem only

@@ -10,6 +10,14 @@ static long long env_ll(const char *name, long long dflt) { const char *e = gete
 
 Switches switches_parse() {
     Switches s;
+    // diagnostics: always honoured (they print, they do not change what runs)
+    s.verbose = env_set("MF_VERBOSE");
+    s.chain_verbose = env_set("MF_CHAIN_VERBOSE");
+    s.dq_verbose = env_set("MF_DQ_VERBOSE");
+    s.debug_epi = env_set("MF_DEBUG_EPI");
+    // everything below changes routing or tuning: the product ignores it unless the process says MF_DEV=1
+    s.dev = env_is("MF_DEV", '1');
+    if (!s.dev) return s;
     s.no_rt = env_set("MF_NO_RT");
     s.no_stem_rt = env_set("MF_NO_STEM_RT");
     s.no_chain = env_set("MF_NO_CHAIN");
@@ -50,10 +58,6 @@ Switches switches_parse() {
     s.dq_cfg = (int)env_ll("MF_DQ_CFG", 0);
     if (const char *l = getenv("MF_DQ_CFGS")) s.dq_cfgs = l;
     if (const char *e = getenv("MF_DQ_STATIC")) s.dq_static = atof(e);
-    s.verbose = env_set("MF_VERBOSE");
-    s.chain_verbose = env_set("MF_CHAIN_VERBOSE");
-    s.dq_verbose = env_set("MF_DQ_VERBOSE");
-    s.debug_epi = env_set("MF_DEBUG_EPI");
     return s;
 }
 

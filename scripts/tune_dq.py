@@ -5,6 +5,7 @@ power state, so a launch is only ever judged inside the real mix).  All candidat
 import os
 import sys
 
+os.environ["MF_DEV"] = "1"  # (the library ignores tuning switches without it)
 os.environ["MF_DQ_TUNE"] = "1"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

@@ -22,8 +22,9 @@ VDIR = os.path.join(PKG, "variants")
 def build(src, variants):
     B.build()  # objects of the default build
     os.makedirs(VDIR, exist_ok=True)
-    for f in glob.glob(os.path.join(VDIR, "lib_*.so")):
-        os.remove(f)
+    if not os.environ.get("VARIANTS_KEEP"):  # (VARIANTS_KEEP=1: add to the variants of an earlier call, e.g. of another source file)
+        for f in glob.glob(os.path.join(VDIR, "lib_*.so")):
+            os.remove(f)
     objdir = os.path.join(PKG, "build")
     procs = []
     srcs = [f for f in B.SOURCES if f.endswith(".hip")] if src == "ALL" else [src]  # ALL: a flag that lives in a shared header

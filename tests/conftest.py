@@ -47,7 +47,10 @@ def model_path(name):
 # The assertions about WHICH kernel runs describe the default routing only and are skipped then; every parity assertion stays.
 # Only the switches that change which kernel runs count: a stray debug variable (MF_VERBOSE, MF_DEBUG_EPI, MF_DQ_VERBOSE, ...)
 # must not switch the routing assertions off.
-_NOT_ROUTING = ("MF_VERBOSE", "MF_DEBUG", "MF_DQ_VERBOSE", "MF_STAGE_DIAG", "MF_TAIL3_DIAG")
-ROUTING_SWITCHED = sorted(k for k in os.environ if k.startswith("MF_") and not k.startswith(_NOT_ROUTING))
+# The library itself ignores every routing / tuning switch unless MF_DEV=1 is set (csrc/switches.cpp), and so does this list.
+_NOT_ROUTING = ("MF_VERBOSE", "MF_DEBUG", "MF_DQ_VERBOSE", "MF_CHAIN_VERBOSE", "MF_STAGE_DIAG", "MF_TAIL3_DIAG", "MF_DEV", "MF_ALLOW_DIAG_BUILD",
+                "MF_EXTRA_HIPCC_FLAGS", "MF_TIME_BATCH")
+ROUTING_SWITCHED = (sorted(k for k in os.environ if k.startswith("MF_") and not k.startswith(_NOT_ROUTING))
+                    if os.environ.get("MF_DEV", "")[:1] == "1" else [])
 if ROUTING_SWITCHED:
     print("tests/conftest.py: kernel-routing assertions are SKIPPED because of %s" % ", ".join(ROUTING_SWITCHED), file=sys.stderr)

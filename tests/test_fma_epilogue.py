@@ -354,7 +354,7 @@ for name, cfg, n in (("person_detect", 3, 4099), ("speech", 2, 257)):
 def test_switching_the_form_off_changes_no_byte():
     """MF_NO_FMA_EPI=1 (every operator on the two-rounding forms) in a child process: the same outputs, different modes"""
     outs = []
-    for env_extra in ({}, {"MF_NO_FMA_EPI": "1"}):
+    for env_extra in ({}, {"MF_DEV": "1", "MF_NO_FMA_EPI": "1"}):
         env = dict(os.environ)
         env.pop("MF_NO_FMA_EPI", None)
         env.update(env_extra)

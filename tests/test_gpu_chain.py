@@ -91,7 +91,7 @@ print("KERNELS", sorted({m.op(i)["kernel"] for i in range(m.num_ops)}))
 print("RESULT %%016x %%d" %% (checksum_i8(y.reshape(-1)), int(ok)))
 ''' % (ROOT, model_path("person_detect"), model_path("person_detect"))
     outs = []
-    for env_extra in ({}, {"MF_CHAIN_ALL": "1"}):
+    for env_extra in ({}, {"MF_DEV": "1", "MF_CHAIN_ALL": "1"}):
         env = dict(os.environ, **env_extra)
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]

@@ -227,7 +227,7 @@ def test_quads_equal_the_four_pair_launches(models, O, tmp_path):
         assert np.array_equal(got[b], layers[8].reshape(-1)), b
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = str(tmp_path / "noquad.npy")
-    env = dict(os.environ, MF_NO_QUAD="1")
+    env = dict(os.environ, MF_DEV="1", MF_NO_QUAD="1")
     r = subprocess.run([sys.executable, "-c", _NO_QUAD_SCRIPT.format(root=root, n=n, out=out)], env=env, capture_output=True,
                        text=True, timeout=600)
     assert r.returncode == 0 and "no-quad ok" in r.stdout, r.stdout + r.stderr

@@ -385,7 +385,7 @@ def test_fully_connected_mfma_256_tile_schedule():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, MF_FC_TILE="256")
+    env = dict(os.environ, MF_DEV="1", MF_FC_TILE="256")
     r = subprocess.run([sys.executable, "-c", _TILE256_SCRIPT.format(root=root)], env=env, capture_output=True,
                        text=True, timeout=600)
     assert r.returncode == 0 and "tile256 ok" in r.stdout, r.stdout + r.stderr
@@ -441,7 +441,7 @@ def test_models_without_magic_accumulators():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, MF_NO_MAGIC="1")
+    env = dict(os.environ, MF_DEV="1", MF_NO_MAGIC="1")
     r = subprocess.run([sys.executable, "-c", _NO_MAGIC_SCRIPT.format(root=root)], env=env, capture_output=True,
                        text=True, timeout=600)
     assert r.returncode == 0 and "no-magic ok" in r.stdout, r.stdout + r.stderr
@@ -632,7 +632,7 @@ def test_models_without_saturating_pack():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, MF_NO_SAT_PACK="1")
+    env = dict(os.environ, MF_DEV="1", MF_NO_SAT_PACK="1")
     r = subprocess.run([sys.executable, "-c", _NO_SAT_SCRIPT.format(root=root)], env=env, capture_output=True,
                        text=True, timeout=600)
     assert r.returncode == 0 and "no-sat ok" in r.stdout, r.stdout + r.stderr
@@ -697,6 +697,6 @@ for M, K, N in ((4096, 2048, 4096), (1000, 640, 768), (193, 256, 384)):
     assert torch.equal(got, want), (M, K, N, int((got != want).sum()))
 print("FOLD_OK")
 ''' % ROOT
-    env = dict(os.environ, MF_FC_ROWSUM_FOLD="1")
+    env = dict(os.environ, MF_DEV="1", MF_FC_ROWSUM_FOLD="1")
     r = subprocess.run([_sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert r.returncode == 0 and "FOLD_OK" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
