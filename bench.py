@@ -132,8 +132,8 @@ def requant_peak(mode):
     """the measured requantisation ceiling (GB/s) of the epilogue form a launch runs (k_common.hpp modes 0 / 1 / 2)"""
     forms = (REQUANT_CEILING or {}).get("forms", {})
     name = {3: "mode3_single_fma", 2: "mode2_saturating_pack", 1: "mode1_med3", 0: "round2_form"}.get(mode, "mode2_saturating_pack")
-    if mode == 3 and name not in forms:  # (no literal exists for the single-fma form: it is priced against what this run measured)
-        return 2.4 * REQUANT_PEAK_GBS
+    if mode == 3 and name not in forms:  # no measurement of the single-fma form in this run: its fractions are not computed
+        return None
     return forms.get(name, {}).get("GBps", REQUANT_PEAK_GBS)
 
 
@@ -383,7 +383,7 @@ def main():
                 peak = requant_peak(mode)
                 # the binding roof is the one that gives the longer time floor: HBM for the algorithmic bytes, or the
                 # VALU for the bytes that go through the reference's f32 requantisation
-                bound = "valu" if rq / peak > nbytes / HBM_PEAK_GBS else "hbm"
+                bound = "valu" if (peak and rq / peak > nbytes / HBM_PEAK_GBS) else "hbm"
                 if d["kernel"].startswith("quad_rr"):
                     kind = "quad(2 pairs)"   # two depthwise+pointwise pairs in one launch (k_quad.hip)
                 elif d["kernel"].startswith("penta_rr"):
@@ -396,8 +396,8 @@ def main():
                              "hbm_frac": round(gbs / HBM_PEAK_GBS, 4),
                              "requant_bytes": rq, "requant_GBps": round(rq_gbs, 1),
                              "epilogue_mode": mode, "requant_peak_GBps": peak,
-                             "requant_frac": round(rq_gbs / peak, 4),
-                             "valu_frac": round(rq_gbs / peak, 4), "sq": sq_counters(d["kernel"])})
+                             "requant_frac": round(rq_gbs / peak, 4) if peak else None,
+                             "valu_frac": round(rq_gbs / peak, 4) if peak else None, "sq": sq_counters(d["kernel"])})
             return avg_ms, rows
 
         def agg(rows, kind):
@@ -439,14 +439,18 @@ def main():
                             "`bound` = the roof with the longer time floor"}
         step_bytes = sum(k["bytes"] for k in kernels)
         step_rq = sum(k["requant_bytes"] for k in kernels)
-        floor_ms = sum(max(k["bytes"] / HBM_PEAK_GBS, k["requant_bytes"] / k["requant_peak_GBps"]) for k in kernels) / 1e6
+        have_ceiling = all(k["requant_peak_GBps"] for k in kernels)  # (None: a launch's form was not measured in this run)
+        floor_ms = sum(max(k["bytes"] / HBM_PEAK_GBS, k["requant_bytes"] / k["requant_peak_GBps"] if k["requant_peak_GBps"] else 0.0)
+                       for k in kernels) / 1e6
         whole_step = {"ms": round(ev_med, 4), "launches": len(kernels),
                       "algorithmic_bytes": step_bytes, "GBps": round(step_bytes / (ev_med * 1e-3) / 1e9, 1),
                       "frac": round(step_bytes / (ev_med * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                       "hbm_frac": round(step_bytes / (ev_med * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                       "requant_bytes": step_rq, "requant_GBps": round(step_rq / (ev_med * 1e-3) / 1e9, 1),
-                      "valu_frac": round(sum(k["requant_bytes"] / k["requant_peak_GBps"] for k in kernels) / 1e6 / ev_med, 4),
-                      "roof_floor_ms": round(floor_ms, 4), "frac_of_roof_floor": round(floor_ms / ev_med, 4),
+                      "valu_frac": (round(sum(k["requant_bytes"] / k["requant_peak_GBps"] for k in kernels) / 1e6 / ev_med, 4)
+                                    if have_ceiling else None),
+                      "roof_floor_ms": round(floor_ms, 4) if have_ceiling else None,
+                      "frac_of_roof_floor": round(floor_ms / ev_med, 4) if have_ceiling else None,
                       # fusing launches removes algorithmic bytes, so hbm_frac falls as the step gets faster; for comparison
                       # with earlier rounds: the bytes of round 2's ten launches (pairs + stage + tail) over this step's time
                       "hbm_frac_at_round2_bytes": (round(253442 * count / (ev_med * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)

@@ -815,7 +815,7 @@ static void launch_chain_t(const int8_t *in, int8_t *out, const ChainArgs &a, in
         const double t_step_us = a.est_us_per_image * a.G * per_cu;
         if (!forced && t_step_us < 8.0 && nsteps <= 20 * grid) b.qcfg = 0x100;
     }
-    b.queue = dq_slot(b.queue);
+    b.queue = dq_slot(b.queue, b.qlaunch);
     hipLaunchKernelGGL((chain_rt<KSC, NW, SOLO, RES, MG, XR4>), dim3(grid), dim3(NW * 64), a.lds_bytes, s, in, out, b, batch);
 #if MF_CHAIN_DIAG
     {

@@ -496,7 +496,6 @@ struct DynSteps {
 };
 // Queue configuration of a launch: `est_us` = the launch's expected duration (its bytes over the rates the kernels reach).
 unsigned long dq_next_launch(); // (k_generic.hip) one process-wide counter of queue launches, for MF_DQ_CFGS
-unsigned long dq_next_slot(const int *ring); // (k_generic.hip) launch counter of THIS ring, behind dq_slot below
 static inline int dq_config(int nsteps, int grid, double est_us) {
     // tuning: MF_DQ_CFG = K | heads << 8 for every launch (0x100 = static striding).  With MF_DQ_TUNE set it is re-read per
     // launch, and MF_DQ_CFGS = "c0,c1,..." gives the k-th queue launch of the process configuration c[k % n] (0 = automatic)
@@ -532,10 +531,13 @@ static inline int dq_config(int nsteps, int grid, double est_us) {
     return cfg;
 }
 // the counter set of this launch: the operator's ring (kernels.hpp DYNQ_RING sets of DynSteps::INTS zeroed ints), next slot.
-// Every ring counts its OWN launches, so a handle's slots are only ever used up by launches of that handle: DYNQ_RING launches of
-// one handle may be in flight whatever else the process launches in between.
-static inline int *dq_slot(int *ring) {
-    return ring ? ring + (size_t)(dq_next_slot(ring) % (unsigned long)DYNQ_RING) * DynSteps::INTS : nullptr;
+// Every ring counts its OWN launches -- `launches` lives in host memory next to the ring, in the operator that owns it -- so a
+// handle's slots are only ever used up by launches of that handle: DYNQ_RING launches of one handle may be in flight whatever else
+// the process launches in between.  No process-wide lock or table on the launch path.
+static inline int *dq_slot(int *ring, unsigned long *launches) {
+    if (!ring) return nullptr;
+    const unsigned long n = launches ? __atomic_fetch_add(launches, 1ul, __ATOMIC_RELAXED) : dq_next_launch();
+    return ring + (size_t)(n % (unsigned long)DYNQ_RING) * DynSteps::INTS;
 }
 // expected duration of a depthwise / pair launch from its HBM bytes and requantised bytes (4.5 and 4.0 TB/s: what the kernels reach)
 static inline double dq_est_us(double hbm_bytes, double requant_bytes) {

@@ -579,7 +579,7 @@ static void launch_dw(const int8_t *in, int8_t *out, const DwFastArgs &a, int ba
     constexpr int OPIX = ((H + S - 1) / S) * ((W + S - 1) / S);
     DwFastArgs b = a;
     b.qcfg = dq_config(nsteps, grid, dq_est_us((double)batch * (H * W * C + OPIX * C), (double)batch * OPIX * C));
-    b.queue = dq_slot(b.queue);
+    b.queue = dq_slot(b.queue, b.qlaunch);
     hipLaunchKernelGGL((dw3x3_nhwc<H, W, C, S, G, NTHR, MG, XR4>), dim3(grid), dim3(NTHR), lds, s, in, out, b, batch);
 }
 
@@ -640,7 +640,7 @@ bool launch_dw_stem(int H, int W, int DM, int S, const int8_t *in, int8_t *out, 
         constexpr int G = 2, lds = 2 * G * (16 + (96 + 2) * 96) + 16; // + step queue
         DwStemArgs a = a_in;
         a.qcfg = dq_config((batch + G - 1) / G, 512, dq_est_us((double)batch * (96 * 96 * (f32_input ? 4 : 1) + 48 * 48 * 8), (double)batch * 48 * 48 * 8));
-        a.queue = dq_slot(a.queue);
+        a.queue = dq_slot(a.queue, a.qlaunch);
         static LaunchState st, stf;
         const int per_cu = f32_input ? prepared(stf, dw3x3_stem8<96, 96, G, false, 0u, true>, 256, lds)
                                      : prepared(st, dw3x3_stem8<96, 96, G, false, 0u, false>, 256, lds);

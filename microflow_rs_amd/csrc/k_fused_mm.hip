@@ -618,7 +618,7 @@ static void launch_dwpw_mm_t(const int8_t *in, int8_t *out, const DwPwArgs &a, i
     constexpr int OPIX = ((H + S - 1) / S) * ((W + S - 1) / S);
     DwPwArgs b = a;
     b.dw.qcfg = dq_config(nsteps, grid, dq_est_us((double)batch * (H * W * C + OPIX * N), (double)batch * OPIX * (C + N)));
-    b.dw.queue = dq_slot(b.dw.queue);
+    b.dw.queue = dq_slot(b.dw.queue, b.dw.qlaunch);
     hipLaunchKernelGGL((dwpw_mm<H, W, C, S, N, G, NTHR, (DB != 0), CG, CY, ORD, ROWPAD, TS, WPE, MG, XR4, false>), dim3(grid), dim3(NTHR),
                        lds, s, in, out, b, batch);
 }
@@ -634,7 +634,7 @@ static void launch_dw_mm_t(const int8_t *in, int8_t *out, const DwPwArgs &a, int
     constexpr int OPIX = ((H + S - 1) / S) * ((W + S - 1) / S);
     DwPwArgs b = a;
     b.dw.qcfg = dq_config(nsteps, grid, dq_est_us((double)batch * (H * W * C + OPIX * C), (double)batch * OPIX * C));
-    b.dw.queue = dq_slot(b.dw.queue);
+    b.dw.queue = dq_slot(b.dw.queue, b.dw.qlaunch);
     hipLaunchKernelGGL((dwpw_mm<H, W, C, S, N, G, NTHR, (DB != 0), CG, CY, ORD, ROWPAD, TS, WPE, MG, XR4, true>), dim3(grid), dim3(NTHR),
                        lds, s, in, out, b, batch);
 }
@@ -712,7 +712,7 @@ static void launch_dwpw_rr_t(const int8_t *in, int8_t *out, const DwPwArgs &a, i
     constexpr int OPIX = ((H + S - 1) / S) * ((W + S - 1) / S);
     DwPwArgs b = a;
     b.dw.qcfg = dq_config(nsteps, grid, dq_est_us((double)batch * (H * W * C + OPIX * N), (double)batch * OPIX * (C + N)));
-    b.dw.queue = dq_slot(b.dw.queue);
+    b.dw.queue = dq_slot(b.dw.queue, b.dw.qlaunch);
     hipLaunchKernelGGL((dwpw_rr<H, W, C, S, N, G, NTHR, DB, CG, CY, ORD, ROWPAD, TS, WPE, MG, XR4>), dim3(grid), dim3(NTHR),
                        lds, s, in, out, b, batch);
 }

@@ -574,14 +574,6 @@ unsigned long dq_next_launch() {
     static std::atomic<unsigned long> n{0};
     return n.fetch_add(1);
 }
-unsigned long dq_next_slot(const int *ring) {
-    // one counter per ring (= per operator handle), keyed by the ring's device address.  A destroyed operator's entry stays (a
-    // later ring at the same address continues its count, which is harmless: any starting slot is as good as another).
-    static std::mutex m;
-    static std::unordered_map<const int *, unsigned long> next;
-    std::lock_guard<std::mutex> g(m);
-    return next[ring]++;
-}
 unsigned long long selftest_rounding(int mode, bool u8, float lo, float hi, hipStream_t s) {
     return run_selftest(s, [&](unsigned long long *d) {
         const dim3 g(256 * 16), b(256);

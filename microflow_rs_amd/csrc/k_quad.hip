@@ -60,9 +60,9 @@
 #define MF_QUAD_STEM_LDS 1
 #endif
 // 1 (instances without the stem): the wait at the top of a step leaves phase B's output stores in flight -- they were issued after
-// the staging DMAs, and vmcnt retires in order -- instead of draining them.
+// the staging DMAs, and vmcnt retires in order -- instead of draining them (same box, ops 5..8: 0.441 -> 0.4265 ms).
 #ifndef MF_QUAD_CNT_WAIT
-#define MF_QUAD_CNT_WAIT 0
+#define MF_QUAD_CNT_WAIT 1
 #endif
 #ifndef MF_QUAD_KO
 #define MF_QUAD_KO 0 // knock-out timing experiments (WRONG results, never shipped): 1 no depthwise requantisation, 2 no pointwise requantisation,
@@ -630,7 +630,7 @@ static void launch_quad_t(const int8_t *in, int8_t *out, const QuadArgs &a, int 
     const double hbm = (double)batch * ((STEM ? (F32IN ? 16 : 4) * GA::H * GA::W : GA::H * GA::W * GA::C) + GB::OPIX * GB::N);
     const double rq = (double)batch * ((STEM ? GA::H * GA::W * GA::C : 0) + GA::OPIX * (GA::C + GA::N) + GB::OPIX * (GB::C + GB::N));
     b.a.dw.qcfg = dq_config(nsteps, grid, dq_est_us(hbm, rq));
-    b.a.dw.queue = dq_slot(b.a.dw.queue);
+    b.a.dw.queue = dq_slot(b.a.dw.queue, b.a.dw.qlaunch);
     hipLaunchKernelGGL((quad_rr<Q, STEM, MG, XR4, F32IN>), dim3(grid), dim3(Q::NTHR), lds, s, in, out, b, batch);
 }
 template <typename Q> static bool quad_matches(int H, int W, int C, int S, int N, int H2, int W2, int C2, int S2, int N2) {

@@ -680,7 +680,7 @@ static void launch_dw_rt_t(const int8_t *in, int8_t *out, const DwRtArgs &a, int
     DwRtArgs b = a;
     const double opix = (double)a.OH * a.OW;
     b.dw.qcfg = dq_config(nsteps, grid, dq_est_us((double)batch * ((double)a.H * a.W * a.C + opix * a.C), (double)batch * opix * a.C));
-    b.dw.queue = dq_slot(b.dw.queue);
+    b.dw.queue = dq_slot(b.dw.queue, b.dw.qlaunch);
     hipLaunchKernelGGL((dw3x3_rt<S, R, WZ, MG, XR4>), dim3(grid), dim3(a.NTHR), lds, s, in, out, b, batch);
 }
 void launch_dw_rt(const int8_t *in, int8_t *out, const DwRtArgs &a, int S, bool wz, int batch, hipStream_t s) {
@@ -936,7 +936,7 @@ static void launch_dw_stem_rt_t(const int8_t *in, int8_t *out, const DwStemRtArg
     const int grid = nsteps < 256 * per_cu ? nsteps : 256 * per_cu;
     const double out_bytes = (double)batch * a.OH * a.OW * a.DM;
     a.qcfg = dq_config(nsteps, grid, dq_est_us((double)batch * a.H * a.W + out_bytes, out_bytes));
-    a.queue = dq_slot(a.queue);
+    a.queue = dq_slot(a.queue, a.qlaunch);
     hipLaunchKernelGGL((dw3x3_stem_rt<DM, MG, XR4>), dim3(grid), dim3(256), lds, s, in, out, a, batch);
 }
 void launch_dw_stem_rt(const int8_t *in, int8_t *out, const DwStemRtArgs &a, int batch, hipStream_t s) {

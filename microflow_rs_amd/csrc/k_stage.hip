@@ -50,6 +50,18 @@
 #ifndef MF_STAGE_CNT_WAIT
 #define MF_STAGE_CNT_WAIT 0 // (tuning) 1: the wait at the top of a step leaves the previous step's output stores in flight
 #endif
+// 1: the vector-memory issues that follow the depthwise barrier -- the next record, the next depthwise's operands and, in the last pair,
+// the next step's staging DMAs -- are issued BEHIND the first MFMAs of the pointwise phase instead of in front of it.  vmcnt retires in
+// order: the phase's first use of its own operands and record (loaded a phase earlier) is compiled into `s_waitcnt vmcnt(0)`, and with
+// those issues already in flight that wait was a full L2 round trip (in the last pair: the HBM round trip of the DMAs) at the top of
+// every pointwise phase (scripts/asm_dma_waits.py, the listing of round 5's kernel: `global_load rdw; s_waitcnt vmcnt(0);
+// v_readfirstlane rpw`).
+#ifndef MF_STAGE_LATE_LOADS
+#define MF_STAGE_LATE_LOADS 1
+#endif
+#ifndef MF_STAGE_CNT_WAIT
+#define MF_STAGE_CNT_WAIT 0 // (tuning) 1: the wait at the top of a step leaves the previous step's output stores in flight
+#endif
 #ifndef MF_STAGE_FENCE
 #define MF_STAGE_FENCE 0 // (tuning) scheduling fences -- bit 0: inside a unit (the hand interleave of MFMAs and epilogue halves of rounds
                          // 3-4), bit 1: at the end of a unit.  With the two-instruction epilogue of round 5 the compiler's own schedule of
@@ -243,8 +255,17 @@ __global__ __launch_bounds__(NTHR, 4) void stage_6x6x128(const int8_t *__restric
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #else
+#if MF_STAGE_CNT_WAIT
+        // (tuning, measured +-0: this step's images and the first depthwise operands must have landed; the previous step's copy-out
+        // stores -- two or three per wave, issued after them, and vmcnt retires in order -- stay in flight; the bare barrier because
+        // __syncthreads() carries a fence that hipcc completes with vmcnt(0) while it believes an LDS-DMA may be outstanding)
+        if (ko_steps > 0) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#else
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads(); // this step's images are in the tile; the previous step's output has been copied out of region A
+#endif
 #endif
         dq.top(tid);
         asm volatile("" : "+s"(pairs));
@@ -337,15 +358,20 @@ __global__ __launch_bounds__(NTHR, 4) void stage_6x6x128(const int8_t *__restric
 #endif
             MF_TR(2 + 3 * rep);
             const bool last = rep == NREP - 1;
-            if (last) {
-                const int next = dq.nxt;
-                if (next < nsteps && !((MF_STAGE_KO & 4) && ko_steps > 0)) stage(next); // the tile is dead: the next step's images fly under the last pointwise phase
-            }
-            rdw = ld_rec(last ? 0 : 2 * rep + 2);
-            if (!((MF_STAGE_KO & 16) && ko_steps > 0)) wd = load_dw(last ? 0 : rep + 1); // the next depthwise's operands land during the pointwise phase
+            auto next_issues = [&]() {
+                if (last) {
+                    const int next = dq.nxt;
+                    if (next < nsteps && !((MF_STAGE_KO & 4) && ko_steps > 0)) stage(next); // the tile is dead: the next step's images fly under the last pointwise phase
+                }
+                rdw = ld_rec(last ? 0 : 2 * rep + 2);
+                if (!((MF_STAGE_KO & 16) && ko_steps > 0)) wd = load_dw(last ? 0 : rep + 1); // the next depthwise's operands land during the pointwise phase
+            };
+            if constexpr (!MF_STAGE_LATE_LOADS) next_issues();
             // ---------------- pointwise: MID -> tile (last pair: -> plain output in region A) ----------------
-            auto pw_phase = [&](auto pr_tag, const EpiPatchRec &ppr, const EpiPatchRec &ppr2) -> unsigned long long { // (PR as in dw_phase)
+            // ISSUE: this call also issues next_issues() (MF_STAGE_LATE_LOADS), behind its first MFMAs
+            auto pw_phase = [&](auto pr_tag, auto issue_tag, const EpiPatchRec &ppr, const EpiPatchRec &ppr2) -> unsigned long long { // (PR as in dw_phase)
                 constexpr int PR = decltype(pr_tag)::value;
+                constexpr bool ISSUE = decltype(issue_tag)::value && MF_STAGE_LATE_LOADS != 0;
                 const float lo = pairs[rep].pw_lo, hi = pairs[rep].pw_hi;
                 const int Pl = pg == ((ppr.meta >> 2) & 3) ? ppr.P : 0x7fffffff;
                 unsigned long long hit = 0;
@@ -355,6 +381,11 @@ __global__ __launch_bounds__(NTHR, 4) void stage_6x6x128(const int8_t *__restric
                 acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(wp.A[0], c0, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(wp.A[1], c1, acc, 0, 0, 0);
                 c0 = *(const v4i *)(lds + rb + 256), c1 = *(const v4i *)(lds + rb + 4 * PLANE6 + 256);
+                if constexpr (ISSUE) { // (the fences keep the scheduler from hoisting the loads back in front of the MFMAs' wait)
+                    __builtin_amdgcn_sched_barrier(0);
+                    next_issues();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
 #pragma unroll
                 for (int c = 0; c < 9; ++c) {
                     const bool more = c + 1 < 9;
@@ -393,16 +424,20 @@ __global__ __launch_bounds__(NTHR, 4) void stage_6x6x128(const int8_t *__restric
                 const EpiPatchRec ppr = rec_of(rpw);
                 const int sel = ppr.P == 0 ? -1 : ((ppr.meta & 32) ? 4 : (ppr.meta & 3));
                 unsigned long long redo = 0;
-                if (sel < 0) pw_phase(std::integral_constant<int, -1>{}, ppr, ppr);
-                else if (sel == 0) redo = pw_phase(std::integral_constant<int, 0>{}, ppr, ppr);
-                else if (sel == 1) redo = pw_phase(std::integral_constant<int, 1>{}, ppr, ppr);
-                else if (sel == 2) redo = pw_phase(std::integral_constant<int, 2>{}, ppr, ppr);
-                else if (sel == 3) redo = pw_phase(std::integral_constant<int, 3>{}, ppr, ppr);
-                else redo = ~0ull;
+                using yes = std::true_type;
+                if (sel < 0) pw_phase(std::integral_constant<int, -1>{}, yes{}, ppr, ppr);
+                else if (sel == 0) redo = pw_phase(std::integral_constant<int, 0>{}, yes{}, ppr, ppr);
+                else if (sel == 1) redo = pw_phase(std::integral_constant<int, 1>{}, yes{}, ppr, ppr);
+                else if (sel == 2) redo = pw_phase(std::integral_constant<int, 2>{}, yes{}, ppr, ppr);
+                else if (sel == 3) redo = pw_phase(std::integral_constant<int, 3>{}, yes{}, ppr, ppr);
+                else {
+                    redo = ~0ull; // (two patched channels: straight to the exact copy, which never issues -- a redo must not issue twice)
+                    if constexpr (MF_STAGE_LATE_LOADS != 0) next_issues();
+                }
                 if (__builtin_expect(redo != 0, 0))
-                    pw_phase(std::integral_constant<int, 4>{}, ppr, epi_patch_load(p.patch_tab, ((2 * rep + 1) * 8 + wave) * 2 + 1));
+                    pw_phase(std::integral_constant<int, 4>{}, std::false_type{}, ppr, epi_patch_load(p.patch_tab, ((2 * rep + 1) * 8 + wave) * 2 + 1));
             } else {
-                (void)pw_phase(std::integral_constant<int, -1>{}, EpiPatchRec{0, 0}, EpiPatchRec{0, 0});
+                (void)pw_phase(std::integral_constant<int, -1>{}, std::true_type{}, EpiPatchRec{0, 0}, EpiPatchRec{0, 0});
             }
             MF_TR(3 + 3 * rep);
             // NO barrier here (see the header): the next depthwise of this wave reads only what this wave has written
@@ -456,7 +491,7 @@ bool launch_stage(int H, int W, int C, int npairs, const int8_t *in, int8_t *out
     StageArgs a = a_in;
     a.nrep = npairs;
     a.qcfg = dq_config((batch + G - 1) / G, 512, dq_est_us((double)batch * 2 * H * W * C, (double)batch * 2 * npairs * H * W * C));
-    a.queue = dq_slot(a.queue);
+    a.queue = dq_slot(a.queue, a.qlaunch);
     constexpr int lds = MF_STAGE_LDS_KB * 1024;
     const int nsteps = (batch + G - 1) / G;
     int per_cu = 0, grid = 0;

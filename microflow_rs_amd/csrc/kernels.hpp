@@ -110,6 +110,7 @@ struct DwFastArgs {
                         // conversion; 2: also clamp == the element type's range and |x| < 2^15 -> saturating pack
     int xr;             // 0 (i8) or 0x80 (u8): see ConvArgs
     int *queue;         // dynamic step queue of the persistent kernels (k_common.hpp DynSteps): DYNQ_INTS zeroed device ints
+    unsigned long *qlaunch; // HOST memory: launches of this ring so far (next to the ring in its owner; k_common.hpp dq_slot)
     int qcfg;           // its configuration for this launch (set by the launcher: dq_config)
     // the single-fma form of this operator's epilogue (mode 3, k_common.hpp): C', S', Kc + pivot -- or nullptr when the host
     // search (epi_fma.cpp) or the device check failed for a channel.  use_fma() switches a COPY of the block to it.
@@ -158,6 +159,7 @@ struct DwStemArgs {
     float in_rcp;        // 1 / in_scale (rounded) for quant_div
     int in_fast;         // 1: the 3-instruction division was verified for these parameters (k_common.hpp: quant_div)
     int *queue;          // dynamic step queue (k_common.hpp DynSteps)
+    unsigned long *qlaunch; // HOST memory: launches of this ring so far (next to the ring in its owner; k_common.hpp dq_slot)
     int qcfg;            // set by the launcher (dq_config)
 };
 struct DwPwArgs;
@@ -234,6 +236,7 @@ struct DwStemRtArgs {
     float lo_f, hi_f;
     int magic, xr;
     int *queue;
+    unsigned long *qlaunch; // HOST memory: launches of this ring so far (next to the ring in its owner; k_common.hpp dq_slot)
     int qcfg;
 };
 bool dw_stem_rt_plan(DwStemRtArgs &a, int H, int W, int DM, int OH, int OW);
@@ -313,6 +316,7 @@ struct ChainArgs {
     int fill_off[CHAIN_MAX], fill_bytes[CHAIN_MAX];
     uint32_t fill_izp4[CHAIN_MAX];
     int *queue;
+    unsigned long *qlaunch; // HOST memory: launches of this ring so far (next to the ring in its owner; k_common.hpp dq_slot)
     int qcfg;
     int KSC;                       // template selector: 1, 2 or 4 k steps (max over the pairs)
     int max_cg;                    // images per depthwise column grid (G is a multiple of it)
@@ -447,6 +451,7 @@ struct StageArgs {
     uint32_t izp4;           // zero point of every depthwise input of the run (they must agree: one halo fill)
     uint32_t xr4;            // 0 (i8) or 0x80808080 (u8): XOR of every stored dword
     int *queue;              // dynamic step queue (k_common.hpp DynSteps)
+    unsigned long *qlaunch; // HOST memory: launches of this ring so far (next to the ring in its owner; k_common.hpp dq_slot)
     int qcfg;                // set by the launcher (dq_config)
     int nrep;                // number of pairs in the run (set by the launcher)
     int mode;                // epilogue mode of the whole run (k_common.hpp): 1, or 2 when every clamp is the type's range; 3: single fma

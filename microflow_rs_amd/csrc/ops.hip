@@ -99,7 +99,20 @@ struct OpImpl {
     // two paths are serialised instead of racing; growing a buffer waits for the event on the host before the free.
     hipEvent_t scratch_ev = nullptr;
     bool scratch_used = false;
+    // Under stream capture (mf_model_set_graph) the handshake is skipped: a captured wait on an event recorded outside the capture
+    // is not legal, and an event recorded INTO the graph would leave later eager waits looking at a stale record.  The model runtime
+    // captures one stream, on which the launches are ordered anyway, and a graph's buffers never grow (the eager pass before the
+    // capture sized them).
+    static bool capturing(hipStream_t s) {
+        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &st) != hipSuccess) (void)hipGetLastError();
+        return st != hipStreamCaptureStatusNone;
+    }
     void scratch_acquire(hipStream_t s, bool growing) {
+        if (capturing(s)) {
+            if (growing) fail(MF_ERR_HIP, "a scratch buffer would have to grow inside a stream capture");
+            return;
+        }
         if (!scratch_ev) MF_HIP(hipEventCreateWithFlags(&scratch_ev, hipEventDisableTiming));
         if (scratch_used) {
             if (growing) MF_HIP(hipEventSynchronize(scratch_ev));
@@ -107,11 +120,14 @@ struct OpImpl {
         }
     }
     void scratch_release(hipStream_t s) {
+        if (capturing(s)) return;
+        if (!scratch_ev) MF_HIP(hipEventCreateWithFlags(&scratch_ev, hipEventDisableTiming));
         MF_HIP(hipEventRecord(scratch_ev, s));
         scratch_used = true;
     }
 
     DevBuf d_w, d_wzp, d_A, d_S, d_Kc, d_wprep, d_wrr, d_table;
+    unsigned long q_launches = 0; // launches that drew a counter set from d_queue so far (atomic increments: k_common.hpp dq_slot)
     DevBuf d_queue; // zeroed counters: the dynamic step queue of the persistent kernels launched for this operator (k_common.hpp)
     k::DwC1Args dwc1{};
     k::ConvArgs conv{};
@@ -508,7 +524,7 @@ OpImpl *op_create(int device, const OpSpec &spec) {
             f.izp4 = 0x01010101u * (uint32_t)(uint8_t)(int8_t)s.izp;
             f.lo_f = a.lo_f, f.hi_f = a.hi_f, f.magic = magic, f.xr = xr;
             f.wmm = nullptr;
-            f.queue = (int *)op->d_queue.p;
+            f.queue = (int *)op->d_queue.p, f.qlaunch = &op->q_launches;
             if (s.C == 8 || s.C % 16 == 0) { // matrix-pipe form of the taps for the fused pair kernels
                 const std::vector<int8_t> prep = build_dw_mm_weights(s.weights, s.C);
                 op->d_wprep.upload(prep.data(), prep.size());
@@ -519,7 +535,7 @@ OpImpl *op_create(int device, const OpSpec &spec) {
             op->fast = OpImpl::DW_STEM;
             op->fast_name = k::dw_stem_name(s.H, s.W, s.N, s.sh);
             k::DwStemArgs &f = op->stem;
-            f.queue = (int *)op->d_queue.p;
+            f.queue = (int *)op->d_queue.p, f.qlaunch = &op->q_launches;
             for (int ky = 0; ky < 3; ++ky)
                 for (int c = 0; c < 8; ++c) {
                     uint32_t d = 0;
@@ -547,7 +563,7 @@ OpImpl *op_create(int device, const OpSpec &spec) {
             op->fast = OpImpl::DW_STEM_RT;
             op->fast_name = "dw3x3_stem_rt<" + std::to_string(s.N) + ">";
             k::DwStemRtArgs &f = op->stemrt;
-            f.queue = (int *)op->d_queue.p;
+            f.queue = (int *)op->d_queue.p, f.qlaunch = &op->q_launches;
             // operand A: accumulator row r = (p, c) = pixel p of a 16-byte output group, channel c; lane group g = filter row; the
             // lane's K-bytes are input columns XS j - 4 .. of that row, of which pixel p uses bytes 3 + 2 p .. 5 + 2 p
             const int KB = s.N == 8 ? 8 : 16;
@@ -610,7 +626,7 @@ OpImpl *op_create(int device, const OpSpec &spec) {
             k::DwFastArgs &f = op->dwrt.dw;
             f.w = a.w, f.A = a.A, f.S = a.S, f.Kc = a.Kc, f.wmm = nullptr;
             f.izp4 = 0x01010101u * (uint32_t)(uint8_t)(int8_t)s.izp;
-            f.lo_f = a.lo_f, f.hi_f = a.hi_f, f.magic = magic, f.xr = xr, f.queue = (int *)op->d_queue.p;
+            f.lo_f = a.lo_f, f.hi_f = a.hi_f, f.magic = magic, f.xr = xr, f.queue = (int *)op->d_queue.p, f.qlaunch = &op->q_launches;
             op->dwrt.wzp = a.wzp;
             if (!op->rt_wz && (s.C % 16 == 0 || s.C == 8)) { // matrix-pipe form of the taps: what the fused chain kernel (k_chain.hip) multiplies
                 const std::vector<int8_t> prep = build_dw_mm_weights(s.weights, s.C);
@@ -1216,7 +1232,7 @@ static FusedImpl *chain_create(const std::pair<OpImpl *, OpImpl *> *mem, int n, 
     if (magic == 0 && c->chain.KSC != 4) return nullptr;
     c->chain.magic = magic, c->chain.xr = mem[0].first->s.u8 ? 0x80 : 0;
     c->epi_mode = magic;
-    c->chain.queue = (int *)mem[0].first->d_queue.p;
+    c->chain.queue = (int *)mem[0].first->d_queue.p, c->chain.qlaunch = &mem[0].first->q_launches;
     return c.release();
 }
 // second level: `n` consecutive single-pair chain groups as ONE chain (nullptr: no plan fits)
@@ -1596,9 +1612,13 @@ FusedImpl *fused_stage_create(FusedImpl *const *pairs, int npairs) {
             const k::EpiPatch &pl = (ph ? pairs[i]->b : pairs[i]->a)->fma_patch;
             for (int e = 0; e < pl.n && all_fma; ++e) {
                 const int ch = pl.ch[e];
+                if (ch < 0 || ch >= 128) { // (the table has the eight 16-channel groups of this kernel's 128 channels)
+                    all_fma = false;
+                    break;
+                }
                 k::EpiPatchRec *slot = &ptab[(((size_t)i * 2 + ph) * 8 + (size_t)(ch >> 4)) * 2];
                 if (slot[0].P != 0) ++slot;
-                if (ch >= 128 || slot->P != 0) all_fma = false; // (three in one group: the kernel's table holds two)
+                if (slot->P != 0) all_fma = false; // (three in one group: the kernel's table holds two)
                 else *slot = k::epi_patch_rec(pl.P[e], pl.R[e], ch & 3, (ch >> 2) & 3);
                 if (all_fma && slot != &ptab[(((size_t)i * 2 + ph) * 8 + (size_t)(ch >> 4)) * 2]) slot[-1].meta |= 32; // "a second record follows"
             }
@@ -1644,7 +1664,7 @@ FusedImpl *fused_stage_create(FusedImpl *const *pairs, int npairs) {
     s->stage.pairs = (const k::StagePair *)s->stage_w.back()->p;
     s->stage.izp4 = pairs[0]->dwpw.dw.izp4;
     s->stage.xr4 = d0.u8 ? 0x80808080u : 0u;
-    s->stage.queue = pairs[0]->dwpw.dw.queue;
+    s->stage.queue = pairs[0]->dwpw.dw.queue, s->stage.qlaunch = pairs[0]->dwpw.dw.qlaunch;
     s->stage.mode = all_fma ? 3 : 2; // the saturating-pack epilogue needs it of every operator of the run
     for (int i = 0; i < npairs && !all_fma; ++i)
         if (pairs[i]->a->magic_mode != 2 || pairs[i]->b->magic_mode != 2) s->stage.mode = 1;

@@ -358,6 +358,36 @@ def test_graph_replay_equals_eager(name, batch):
 
 
 @pytest.mark.gpu
+def test_graph_replay_of_a_fully_connected_with_a_weight_zero_point():
+    """the row-sum pre-pass of a FullyConnected with wzp != 0 uses the operator's one scratch buffer, whose event
+    handshake (ops.hip scratch_acquire / _release) must stay out of a stream capture: a captured wait on an event recorded outside
+    the capture is not legal, and an event recorded into the graph would leave later eager waits looking at a stale record.
+    Eager, captured + replayed, replayed again, then eager again on another stream -- all the same bytes."""
+    import torch
+    from tools.make_fc_model import synthetic_fc
+    mf = importlib.import_module("microflow_rs_amd")
+    M = 256
+    m = mf.Model(synthetic_fc(M, 512, 256, wzp=-3, seed=9))
+    rng = np.random.default_rng(6)
+    x = torch.as_tensor(rng.integers(-128, 128, (1, m.input_elems)).astype(np.int8)).cuda()
+    want = m.run_quantized(x).clone()
+    assert "fc_mfma" in m.op(0)["kernel"] or "fc_" in m.op(0)["kernel"]
+    m.set_graph(True)
+    out = torch.empty_like(want)
+    for it in range(4):
+        out.zero_()
+        m.run_quantized(x, out=out)
+        assert torch.equal(out, want), it
+    assert m.graph_launches == 3
+    m.set_graph(False)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):  # an eager launch on another stream behind the replays: the handshake's event is a live one
+        out2 = m.run_quantized(x).clone()
+    side.synchronize()
+    assert torch.equal(out2, want)
+
+
+@pytest.mark.gpu
 def test_host_fed_chunked_equals_device():
     """Host (numpy) batches above ~96 MB are cut into chunks whose H2D copies overlap compute;
     the results must equal the device-resident path's, for the int8 and the f32 entry points,
