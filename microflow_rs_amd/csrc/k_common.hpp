@@ -395,8 +395,31 @@ __device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void gbl_void_t;
 
+// MF_DMA_ASM (default 1): the instruction is issued from inline asm, so that hipcc's wait-count pass does NOT know an LDS-DMA is
+// in flight.  With the builtin it orders every later LDS *store* of the wave behind the DMA (it cannot tell the two LDS ranges
+// apart: `s_waitcnt vmcnt(0)` in front of the first ds_write after a DMA issue -- the HBM round trip of a prefetch that was meant to
+// fly under the phase) and completes every __syncthreads() fence with vmcnt(0) while one is outstanding.  Every kernel here waits for
+// its staged tile itself (`s_waitcnt vmcnt(..)` in front of the barrier that hands the tile over: the builtin's bookkeeping was
+// never what made them correct), and hidden vector-memory operations only make the compiler's own counted waits stricter (vmcnt
+// retires in order).  Round 6, same box: the five-operator launch 0.81 -> 0.71 ms, scripts/asm_dma_waits.py lists the waits.
+#ifndef MF_DMA_ASM
+#define MF_DMA_ASM 1
+#endif
+typedef __attribute__((address_space(3))) uint8_t lds_u8_t;
 __device__ __forceinline__ void dma16(const int8_t *src_lane, uint8_t *lds_wave_base) {
+#if MF_DMA_ASM
+    // M0 = the wave-uniform LDS base; one wait state between an SALU write of M0 and the LDS-DMA that reads it
+    const uint32_t base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_u8_t *)lds_wave_base);
+    // (no "memory" clobber: the barriers and explicit waits on either side of a staged tile's life carry one, and a clobber here
+    // would pin every LDS read of the phase the DMA flies under behind its issue)
+#if MF_DMA_ASM == 2
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src_lane), "s"(base) : "memory");
+#else
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src_lane), "s"(base));
+#endif
+#else
     __builtin_amdgcn_global_load_lds((gbl_void_t *)src_lane, (lds_void_t *)lds_wave_base, 16, 0, 0);
+#endif
 }
 
 // ------------------------------------------------------------------------

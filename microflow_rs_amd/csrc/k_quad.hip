@@ -47,8 +47,9 @@
 // (the pass does not look into it); the kernel's own waits -- vmcnt(0) in front of the barrier that hands the staged image over,
 // lgkmcnt(0) in front of every barrier -- are what orders them.  2: in every instance (measured on ops 5..8, where no DMA is in
 // flight during phase A: 0.445 -> 0.475 ms, the asm statements hem the scheduler in).  Same box, ops 0..4: 0.814 -> 0.766 ms.
+// Superseded by MF_DMA_ASM (k_common.hpp: the DMA itself is what the compiler no longer sees); kept as an A/B switch.
 #ifndef MF_QUAD_ASM_LDS
-#define MF_QUAD_ASM_LDS 1
+#define MF_QUAD_ASM_LDS 0
 #endif
 #ifndef MF_QUAD_ASM_CLOBBER
 #define MF_QUAD_ASM_CLOBBER 1 // (tuning: 0 = the asm stores carry no "memory" clobber)
@@ -64,10 +65,13 @@
 #ifndef MF_QUAD_CNT_WAIT
 #define MF_QUAD_CNT_WAIT 1
 #endif
+#ifndef MF_Q57_DB
+#define MF_Q57_DB 0
+#endif
 #ifndef MF_QUAD_KO
 #define MF_QUAD_KO 0 // knock-out timing experiments (WRONG results, never shipped): 1 no depthwise requantisation, 2 no pointwise requantisation,
                      // 4 no HBM stores, 8 no staging after the first step, 16 no barriers inside a step, 32 one of the three tap-row LDS loads only,
-                     // (f32 instance) 64 no quantisation pass, 128 the pass without its arithmetic
+                     // (f32 instance) 64 no quantisation pass, 128 the pass without its arithmetic; 256 two of the three tap-row MFMAs
 #endif
 
 namespace mf {
@@ -76,7 +80,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // LDS stores the compiler's wait-count pass does not see (MF_QUAD_ASM_LDS).  `p` points into the workgroup's LDS; OFF is a
 // compile-time byte offset (< 65536: the instruction's offset field).
-typedef __attribute__((address_space(3))) uint8_t lds_u8_t;
 // (`off` must fold to a constant -- the unit loops are fully unrolled -- or the build fails at the "i" constraint)
 __device__ __forceinline__ void lds_store_asm(uint8_t *p, int off, uint2 v) {
     typedef unsigned int u32x2_ __attribute__((ext_vector_type(2)));
@@ -261,7 +264,7 @@ struct RrPhase {
             __builtin_amdgcn_s_setprio(MF_QUAD_PRIO);
 #endif
 #pragma unroll
-            for (int ty = 0; ty < 3; ++ty)
+            for (int ty = 0; ty < ((MF_QUAD_KO & 256) ? 2 : 3); ++ty) // (knock-out 256: two of the three tap-row MFMAs)
 #pragma unroll
                 for (int u = 0; u < UB; ++u)
 #pragma unroll
@@ -358,6 +361,7 @@ struct Quad13 {
     using A = RrGeom<48, 48, 8, 1, 16, 1, 4, 0, MF_Q13A_ROWPAD, 0x000>;
     using B = RrGeom<48, 48, 16, 2, 32, 1, 2, 0, MF_Q13B_ROWPAD, 0x000>;
     static constexpr int G = 1, NTHR = 768, WPE = 3, ACT_A = 12, ACT_B = 12, X2A = MF_Q13_X2A, X2B = MF_Q13_X2B;
+    static constexpr bool DBA = false; // one staging buffer (the stem instance stages the stem tile instead)
     static constexpr const char *name = "quad_rr<48,48,8,1,16|48,48,16,2,32>";
 };
 // (measured alternatives for ops 1..4: two 6-wave workgroups per CU -- 1.51 ms, the waves land 4/4/2/2 on the SIMDs; two
@@ -368,6 +372,10 @@ struct Quad57 {
     // 4 waves = one per SIMD, two workgroups per CU (248 VGPRs); pair B's 3 x 3 unit grid runs on three of them.
     // (3-wave workgroups load the SIMDs 2/2/1/1 and every barrier waits for the doubled-up ones: 0.85 ms vs 0.71)
     static constexpr int G = 1, NTHR = 256, WPE = 2, ACT_A = 4, ACT_B = 3, X2A = MF_Q57_X2A, X2B = MF_Q57_X2B;
+    // MF_Q57_DB = 1: two staging buffers, the next image's DMA issued at the TOP of a step so that it has the whole step to land
+    // instead of phase B only.  Measured, same box: 0.436 against 0.4285 ms with one buffer (the loop is unrolled twice for the two
+    // buffers; what the knock-out "no staging after the first step" gains -- 0.05 ms -- is the DMA's own cost, not its latency).
+    static constexpr bool DBA = MF_Q57_DB != 0;
     static constexpr const char *name = "quad_rr<24,24,32,1,32|24,24,32,2,64>";
 };
 
@@ -394,7 +402,8 @@ __global__ __launch_bounds__(Q::NTHR, Q::WPE) void quad_rr(const int8_t *__restr
     using GB = typename Q::B;
     epi_enter<MG>();
     constexpr int G = Q::G, NTHR = Q::NTHR, NWAVE = NTHR / 64;
-    constexpr int BUF_A = G * GA::TILE, OFF_B = BUF_A + 512, BUF_B = G * GB::TILE, OFF_S = OFF_B + BUF_B + 512;
+    constexpr bool DBA = Q::DBA && !STEM; // two tile-A buffers, the next image staged a whole step ahead
+    constexpr int BUF_A = G * GA::TILE, OFF_B = (DBA ? 2 : 1) * BUF_A + 512, BUF_B = G * GB::TILE, OFF_S = OFF_B + BUF_B + 512;
     constexpr int S_GUARD = 16, SW = 2 * GA::W, SH = 2 * GA::H, S_TILE = quad_stem_bytes<Q, STEM>(), OFF_Q = OFF_S + S_TILE;
     constexpr int OFF_F = OFF_Q + 16; // (F32IN) the staged f32 image, verbatim: SH rows of SW floats
     constexpr int OFF_C = OFF_F + (F32IN ? 4 * SH * SW : 0); // (STEM, MF_QUAD_STEM_LDS) the stem's operands: QuadArgs::stem's 152 dwords
@@ -422,7 +431,7 @@ __global__ __launch_bounds__(Q::NTHR, Q::WPE) void quad_rr(const int8_t *__restr
     pb.template init<void>(p.b, lane, wave);
     __syncthreads(); // halo fills complete before any DMA lands
 
-    auto stage = [&](int st) {
+    auto stage = [&](int st, int buf = 0) {
         if constexpr (F32IN) { // the 96 x 96 f32 image, verbatim, in 1 KiB pieces
             constexpr int NI = SH * SW * 4 / 1024;
             static_assert(NI % NWAVE == 0, "f32 staging: whole pieces per wave");
@@ -449,7 +458,7 @@ __global__ __launch_bounds__(Q::NTHR, Q::WPE) void quad_rr(const int8_t *__restr
             const int r = k * NWAVE + wave;
             const int gi = r / GA::H, y = r % GA::H;
             if (r < NROWS && st * G + gi < batch && lane < GA::ROWCH)
-                dma16(in + ((size_t)(st * G + gi) * GA::IMG + y * GA::ROWB + src_lane * 16), lds + gi * GA::TILE + (y + 1) * GA::ROW + GA::LP);
+                dma16(in + ((size_t)(st * G + gi) * GA::IMG + y * GA::ROWB + src_lane * 16), lds + buf * BUF_A + gi * GA::TILE + (y + 1) * GA::ROW + GA::LP);
         }
     };
     // (F32IN) boundary quantisation of the image rows this wave's stem tiles read: rows 4 RPW wave - 1 .. 4 RPW wave + 4 RPW - 1
@@ -587,6 +596,7 @@ __global__ __launch_bounds__(Q::NTHR, Q::WPE) void quad_rr(const int8_t *__restr
         }
     } else {
         bool first = true;
+        int cur = 0;
         for (; dq.step < nsteps; dq.advance(tid)) {
             const int step = dq.step;
             // this step's image must have landed.  Outstanding, oldest first: the staging DMAs (issued behind the barrier in the middle
@@ -604,11 +614,17 @@ __global__ __launch_bounds__(Q::NTHR, Q::WPE) void quad_rr(const int8_t *__restr
             else quad_barrier<ASMST>();
             dq.top(tid);
             const int gvalid = min(G, batch - step * G);
-            if (Q::ACT_A == NWAVE || wave < Q::ACT_A) pa.template run<GB, ASMST>(lds, lds + OFF_B, gvalid); // pair A: tile A -> tile B
+            if constexpr (DBA) { // the other buffer was last read in the previous step's phase A: refill it now, a whole step ahead
+                if (dq.nxt < nsteps && !((MF_QUAD_KO & 8) && ko_steps > 0)) stage(dq.nxt, cur ^ 1);
+            }
+            if (Q::ACT_A == NWAVE || wave < Q::ACT_A) pa.template run<GB, ASMST>(lds + (DBA ? cur * BUF_A : 0), lds + OFF_B, gvalid); // pair A: tile A -> tile B
             if (!(MF_QUAD_KO & 16)) quad_barrier<ASMST>(); // tile B is complete; tile A is free
-            if (dq.nxt < nsteps && !((MF_QUAD_KO & 8) && ko_steps > 0)) stage(dq.nxt); // lands during phase B
+            if constexpr (!DBA) {
+                if (dq.nxt < nsteps && !((MF_QUAD_KO & 8) && ko_steps > 0)) stage(dq.nxt); // lands during phase B
+            }
             if (Q::ACT_B == NWAVE || wave < Q::ACT_B)
                 pb.template run<void>(lds + OFF_B, (uint8_t *)out + (size_t)step * G * GB::OPIX * GB::N, gvalid); // pair B: tile B -> HBM
+            cur ^= 1;
             ++ko_steps;
         }
     }
@@ -617,7 +633,7 @@ __global__ __launch_bounds__(Q::NTHR, Q::WPE) void quad_rr(const int8_t *__restr
 
 template <typename Q, bool STEM, int MG, uint32_t XR4, bool F32IN = false>
 static void launch_quad_t(const int8_t *in, int8_t *out, const QuadArgs &a, int batch, hipStream_t s) {
-    constexpr int lds = Q::G * Q::A::TILE + 512 + Q::G * Q::B::TILE + 512 + quad_stem_bytes<Q, STEM>() + 16 +
+    constexpr int lds = ((Q::DBA && !STEM) ? 2 : 1) * Q::G * Q::A::TILE + 512 + Q::G * Q::B::TILE + 512 + quad_stem_bytes<Q, STEM>() + 16 +
                         (F32IN ? 4 * (2 * Q::A::H) * (2 * Q::A::W) : 0) + (STEM ? 640 : 0);
     static_assert(lds <= 163840, "quad tiles do not fit the LDS");
     static LaunchState st;

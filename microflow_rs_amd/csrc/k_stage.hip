@@ -324,7 +324,7 @@ __global__ __launch_bounds__(NTHR, 4) void stage_6x6x128(const int8_t *__restric
                     const float r2 = epi_value<MG>(acc[2], wd.a.z, wd.s.z, lo, hi);
                     const float r3 = epi_value<MG>(acc[3], wd.a.w, wd.s.w, lo, hi);
                     MF_SB_IN();
-                    if (more) nxt = __builtin_amdgcn_mfma_i32_16x16x64_i8(wd.A[2], t2.b[2], nxt, 0, 0, 0);
+                    if (more && !(MF_STAGE_KO & 32)) nxt = __builtin_amdgcn_mfma_i32_16x16x64_i8(wd.A[2], t2.b[2], nxt, 0, 0, 0); // (knock-out 32: two of three)
 #if MF_STAGE_KO & 1
                     *(uint32_t *)(lds + mb + moff(u)) = (uint32_t)(acc[0] ^ acc[1] ^ acc[2] ^ acc[3]);
 #else
