@@ -65,6 +65,21 @@
 #ifndef MF_QUAD_CNT_WAIT
 #define MF_QUAD_CNT_WAIT 1
 #endif
+// 1: the depthwise taps of both pairs run as ONE structured-sparse v_smfmac_i32_16x16x128_i8 (eight of the nine 16-byte tap chunks)
+// + one v_mfma_i32_16x16x32_i8 (the ninth) per 16-channel unit instead of three v_mfma_i32_16x16x64_i8: the sparse instruction takes
+// the time of ONE dense one (scripts/ubench/mfma_rates.hip), and these launches' time is close to the SUM of their matrix-pipe and
+// VALU time (the knock-out with two of the three dense MFMAs: -7.5 % / -8 %, profiles/r06/d2_mfma_knockouts.txt).  Operands: ops.hip
+// build_dw_sp_weights; the instruction's operand map: scripts/ubench/smfmac_probe.hip / smfmac_check.hip.  Bit-exact (the whole -m gpu
+// suite) -- and NOT faster: ops 0..4 0.76 against 0.725 ms dense, ops 5..8 0.434 against 0.432 (profiles/r06/k_smfmac_variants.txt;
+// with an earlier chunk map 0.42 against 0.43).  What eats the saved MFMA: the dense -> sparse pair of one chain needs 8 idle states
+// between its two instructions (a hazard hipcc 7.2 does not pad: see the comment at the MFMAs), a third tap load per unit, and two
+// more address registers per 16-channel group.  Default 0: the three dense instructions.
+#ifndef MF_RR_SPARSE
+#define MF_RR_SPARSE 0
+#endif
+#ifndef MF_RR_SP_PAD
+#define MF_RR_SP_PAD 7
+#endif
 #ifndef MF_Q57_DB
 #define MF_Q57_DB 0
 #endif
@@ -150,8 +165,15 @@ struct RrPhase {
     static constexpr int T_UG = Ge::CG * Ge::TILE, T_UY = Ge::CY * Ge::S * Ge::ROW, T_UX = Ge::PAIR ? Ge::CX * 16 : Ge::CX * Ge::S * Ge::C;
     static constexpr int NQ = Ge::NQ, NT = Ge::NT;
 
+    static constexpr bool SP = MF_RR_SPARSE == 1 || (MF_RR_SPARSE == 2 && !Ge::PAIR) || (MF_RR_SPARSE == 3 && Ge::PAIR); // (2 / 3: debug)
     int tbase[NQ];
     v4i Adw[NQ][3];
+    // SP: the chunk of this lane group in half 0 / half 1 of the sparse instruction's B operand, its 8 bytes of the ninth chunk;
+    // the stored sparse A, its index register, the ninth chunk's dense A
+    int tb0[NQ], tb1[NQ], tb9[NQ];
+    v4i As[NQ];
+    int Ai[NQ];
+    long A9[NQ];
     float4 dA[NQ], dS[NQ];
     int4 dK[NQ];
     long Apw[NT];
@@ -178,13 +200,24 @@ struct RrPhase {
         const int wpy = wave % PSY, wpx = (wave / PSY) % PSX, wpg = wave / (PSY * PSX);
         wug = wpg * Ge::CG;
         const int wave_t = wpg * T_UG + wpy * T_UY + wpx * T_UX;
-        if constexpr (Ge::PAIR) {
-            tbase[0] = cg * Ge::TILE + cy * Ge::ROW + Ge::LP + (2 * cx - 2) * 8 + g * 16 + wave_t;
-        } else {
-            const int xl = cx * Ge::S + g - 1;
+        // first byte of the 16-byte tap chunk (filter row ty, chunk column gch) of unit (0, 0, 0) in this lane's column
+        auto chunk_addr = [&](int q, int ty, int gch) {
+            if constexpr (Ge::PAIR) {
+                return cg * Ge::TILE + (cy + ty) * Ge::ROW + Ge::LP + (2 * cx - 2) * 8 + gch * 16 + wave_t;
+            } else {
+                const int xl = cx * Ge::S + gch - 1;
+                return cg * Ge::TILE + (cy * Ge::S + ty) * Ge::ROW + Ge::LP + xl * Ge::C + 16 * (q ^ tile_swz<Ge::TS>(xl)) + wave_t;
+            }
+        };
 #pragma unroll
-            for (int q = 0; q < NQ; ++q)
-                tbase[q] = cg * Ge::TILE + cy * Ge::S * Ge::ROW + Ge::LP + xl * Ge::C + 16 * (q ^ tile_swz<Ge::TS>(xl)) + wave_t;
+        for (int q = 0; q < NQ; ++q) {
+            tbase[q] = chunk_addr(q, 0, g);
+            // (ops.hip DW_SP_CHUNK: half 0 = chunks (0,0) (0,1) (0,2) (1,0) of lane groups 0..3, half 1 = (1,1) (1,2) (2,0) (2,1): neighbouring
+            // lane groups read neighbouring chunk columns of one filter row wherever nine chunks allow it, like the dense form, whose
+            // tile pitches were chosen for exactly that)
+            tb0[q] = g < 3 ? chunk_addr(q, 0, g) : chunk_addr(q, 1, 0);
+            tb1[q] = g < 2 ? chunk_addr(q, 1, g + 1) : chunk_addr(q, 2, g - 2);
+            tb9[q] = chunk_addr(q, 2, 2) + 8 * (g & 1);
         }
         const int opar = Ge::PAIR ? (g >> 1) : 0;
         const int n0 = Ge::PAIR ? 8 * (g & 1) : (Ge::N / 4) * g;
@@ -202,8 +235,14 @@ struct RrPhase {
         }
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
+            if constexpr (SP) {
+                const v4i w0 = ((const v4i *)p.dw.wsp)[(q * 64 + lane) * 2], w1 = ((const v4i *)p.dw.wsp)[(q * 64 + lane) * 2 + 1];
+                As[q] = w0, Ai[q] = w1[0];
+                A9[q] = (long)(((unsigned long)(uint32_t)w1[2] << 32) | (unsigned long)(uint32_t)w1[1]);
+            } else {
 #pragma unroll
-            for (int ty = 0; ty < 3; ++ty) Adw[q][ty] = ((const v4i *)p.dw.wmm)[(q * 3 + ty) * 64 + lane];
+                for (int ty = 0; ty < 3; ++ty) Adw[q][ty] = ((const v4i *)p.dw.wmm)[(q * 3 + ty) * 64 + lane];
+            }
             const int ch4 = Ge::PAIR ? (g & 1) : 4 * q + g;
             dA[q] = ((const float4 *)p.dw.A)[ch4];
             dS[q] = ((const float4 *)p.dw.S)[ch4];
@@ -246,13 +285,21 @@ struct RrPhase {
             coords(iu, ug, uy, ux);
             return ug * T_UG + uy * T_UY + ux * T_UX;
         };
-        v4i bq[UB][NQ][3], bn[UB][NQ][3];
+        v4i bq[UB][NQ][3], bn[UB][NQ][3]; // (SP: [0] / [1] = the lane's two chunks of the sparse instruction's B operand; [2] unused)
+        long b9[UB][NQ], n9[UB][NQ];       // (SP) the lane's 8 bytes of the ninth chunk
+        auto load_taps = [&](v4i (&b)[3], long &e, int q, int toff) {
+            if constexpr (SP) {
+                b[0] = *(const v4i *)(tb + tb0[q] + toff), b[1] = *(const v4i *)(tb + tb1[q] + toff);
+                e = *(const long *)(tb + tb9[q] + toff);
+            } else {
+#pragma unroll
+                for (int ty = 0; ty < 3; ++ty) b[ty] = ((MF_QUAD_KO & 32) && ty > 0) ? b[0] : *(const v4i *)(tb + tbase[q] + toff + ty * Ge::ROW);
+            }
+        };
 #pragma unroll
         for (int u = 0; u < UB; ++u)
 #pragma unroll
-            for (int q = 0; q < NQ; ++q)
-#pragma unroll
-                for (int ty = 0; ty < 3; ++ty) bq[u][q][ty] = ((MF_QUAD_KO & 32) && ty > 0) ? bq[u][q][0] : *(const v4i *)(tb + tbase[q] + toff_of(u) + ty * Ge::ROW);
+            for (int q = 0; q < NQ; ++q) load_taps(bq[u][q], b9[u][q], q, toff_of(u));
 #pragma unroll
         for (int t0 = 0; t0 < NU; t0 += UB) {
             v4i acc[UB][NQ];
@@ -263,24 +310,61 @@ struct RrPhase {
 #if MF_QUAD_PRIO
             __builtin_amdgcn_s_setprio(MF_QUAD_PRIO);
 #endif
-#pragma unroll
-            for (int ty = 0; ty < ((MF_QUAD_KO & 256) ? 2 : 3); ++ty) // (knock-out 256: two of the three tap-row MFMAs)
+            if constexpr (SP) {
+                typedef int v8i_ __attribute__((ext_vector_type(8)));
+                // the ninth chunk first: a dense MFMA takes the start values as its srcC, the sparse one accumulates in place
 #pragma unroll
                 for (int u = 0; u < UB; ++u)
 #pragma unroll
-                    for (int q = 0; q < NQ; ++q)
-                        acc[u][q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Adw[q][ty], bq[u][q][ty], acc[u][q], 0, 0, 0);
+                    for (int q = 0; q < NQ; ++q) acc[u][q] = __builtin_amdgcn_mfma_i32_16x16x32_i8(A9[q], b9[u][q], acc[u][q], 0, 0, 0);
+                // HAZARD (gfx950, hipcc 7.2): a v_smfmac whose accumulator is the result of the v_mfma issued right in front of it reads
+                // it too early -- the hardware forwards an accumulator between dense MFMAs, not from a dense to a sparse one, and hipcc
+                // pads nothing here.  Found as wrong, run-to-run varying results with one unit per batch; 4 idle states between the two
+                // are not enough, 8 are (profiles/r06/smfmac_hazard.txt).  The next units' tap loads go here -- they were due anyway --
+                // and idle states make it >= 12 where no other chain's MFMA separates the pair.
+                if (t0 + UB < NU) {
+#pragma unroll
+                    for (int u = 0; u < UB; ++u)
+#pragma unroll
+                        for (int q = 0; q < NQ; ++q) load_taps(bn[u][q], n9[u][q], q, toff_of(t0 + UB + u));
+                }
+                // (the idle states hang on the accumulator itself -- a data dependence between the two instructions of a chain -- so the
+                // scheduler stays free to interleave everything else; a sched_barrier here cost the five-operator launch 6 %)
+#pragma unroll
+                for (int u = 0; u < UB; ++u)
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) {
+#if MF_RR_SP_PAD == 11
+                        asm volatile("s_nop 11" : "+v"(acc[u][q]));
+#else
+                        asm volatile("s_nop 7" : "+v"(acc[u][q]));
+#endif
+                    }
+#pragma unroll
+                for (int u = 0; u < UB; ++u)
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) {
+                        const v4i &lo = bq[u][q][0], &hi = bq[u][q][1];
+                        const v8i_ B = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                        acc[u][q] = __builtin_amdgcn_smfmac_i32_16x16x128_i8(As[q], B, acc[u][q], Ai[q], 0, 0);
+                    }
+            } else {
+#pragma unroll
+                for (int ty = 0; ty < ((MF_QUAD_KO & 256) ? 2 : 3); ++ty) // (knock-out 256: two of the three tap-row MFMAs)
+#pragma unroll
+                    for (int u = 0; u < UB; ++u)
+#pragma unroll
+                        for (int q = 0; q < NQ; ++q)
+                            acc[u][q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Adw[q][ty], bq[u][q][ty], acc[u][q], 0, 0, 0);
+            }
 #if MF_QUAD_PRIO
             __builtin_amdgcn_s_setprio(0);
 #endif
-            if (t0 + UB < NU) {
+            if (!SP && t0 + UB < NU) {
 #pragma unroll
                 for (int u = 0; u < UB; ++u)
 #pragma unroll
-                    for (int q = 0; q < NQ; ++q)
-#pragma unroll
-                        for (int ty = 0; ty < 3; ++ty)
-                            bn[u][q][ty] = ((MF_QUAD_KO & 32) && ty > 0) ? bn[u][q][0] : *(const v4i *)(tb + tbase[q] + toff_of(t0 + UB + u) + ty * Ge::ROW);
+                    for (int q = 0; q < NQ; ++q) load_taps(bn[u][q], n9[u][q], q, toff_of(t0 + UB + u));
             }
 #pragma unroll
             for (int u = 0; u < UB; ++u) {
@@ -342,9 +426,11 @@ struct RrPhase {
 #pragma unroll
             for (int u = 0; u < UB; ++u)
 #pragma unroll
-                for (int q = 0; q < NQ; ++q)
+                for (int q = 0; q < NQ; ++q) {
 #pragma unroll
                     for (int ty = 0; ty < 3; ++ty) bq[u][q][ty] = bn[u][q][ty];
+                    b9[u][q] = n9[u][q];
+                }
         }
     }
 };
@@ -672,6 +758,7 @@ const char *quad_stem_name(int SH, int SW, int H, int W, int C, int S, int N, in
 bool launch_quad(int H, int W, int C, int S, int N, int H2, int W2, int C2, int S2, int N2, const int8_t *in, int8_t *out, const QuadArgs &a,
                  int batch, hipStream_t s) {
     if (!a.a.dw.wmm || !a.a.pw.wrr || !a.b.dw.wmm || !a.b.pw.wrr) return false;
+    if (MF_RR_SPARSE && (!a.a.dw.wsp || !a.b.dw.wsp)) return false; // (no 2:4-sparse form of these taps: the pairs run one by one)
     int mg = std::min(std::min(a.a.dw.magic, a.a.pw.magic), std::min(a.b.dw.magic, a.b.pw.magic));
     if (a.stem) mg = std::min(mg, a.stem_magic);
     if (mg == 0) return false; // (the quads exist for the bit-pattern epilogues only)
@@ -705,6 +792,7 @@ bool launch_quad_f32(int H, int W, int C, int S, int N, int H2, int W2, int C2, 
                      int batch, hipStream_t s) {
     if (!a.stem || !a.f32_ok || !(quad_mask() & 4) || !quad_matches<Quad13>(H, W, C, S, N, H2, W2, C2, S2, N2)) return false;
     if (!a.a.dw.wmm || !a.a.pw.wrr || !a.b.dw.wmm || !a.b.pw.wrr) return false;
+    if (MF_RR_SPARSE && (!a.a.dw.wsp || !a.b.dw.wsp)) return false;
     const int mg = std::min(std::min(std::min(a.a.dw.magic, a.a.pw.magic), std::min(a.b.dw.magic, a.b.pw.magic)), a.stem_magic);
     if (mg == 0) return false;
     const int8_t *src = (const int8_t *)in;

@@ -101,6 +101,8 @@ constexpr int DYNQ_RING = 32;
 struct DwFastArgs {
     const int8_t *w;    // [3][3][C]
     const void *wmm;    // matrix-pipe form of w (k_fused_mm.hip): [C/16 or 1][3 filter rows][64 lanes] x 16 bytes
+    const void *wsp;    // the same taps for v_smfmac_i32_16x16x128_i8 + one v_mfma_i32_16x16x32_i8 (k_quad.hip; ops.hip build_dw_sp_weights):
+                        // [C/16 or 1][64 lanes] x 32 bytes = {sparse A (16 B), index dword, ninth tap's dense A (8 B), pad}
     const float *A;
     const float *S;
     const int *Kc;

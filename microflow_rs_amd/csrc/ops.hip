@@ -126,7 +126,7 @@ struct OpImpl {
         scratch_used = true;
     }
 
-    DevBuf d_w, d_wzp, d_A, d_S, d_Kc, d_wprep, d_wrr, d_table;
+    DevBuf d_w, d_wzp, d_A, d_S, d_Kc, d_wprep, d_wsp, d_wrr, d_table;
     unsigned long q_launches = 0; // launches that drew a counter set from d_queue so far (atomic increments: k_common.hpp dq_slot)
     DevBuf d_queue; // zeroed counters: the dynamic step queue of the persistent kernels launched for this operator (k_common.hpp)
     k::DwC1Args dwc1{};
@@ -270,6 +270,51 @@ std::vector<int8_t> build_dw_mm_weights(const int8_t *w /*[3][3][C]*/, int C) {
                     dst[r] = w[(ty * 3 + g) * C + 16 * q + r];
                 }
             }
+    return out;
+}
+
+// The same taps for the structured-sparse matrix instruction (k_quad.hip).  A 3x3 depthwise operand A is block diagonal: a row has at
+// most two non-zero bytes in any 16-byte chunk, never two in one group of four -- 2:4 sparse with room to spare -- and
+// v_smfmac_i32_16x16x128_i8 multiplies a 2:4-sparse 16 x 128 A in the time v_mfma_i32_16x16x64_i8 takes for a dense 16 x 64
+// (scripts/ubench/mfma_rates.hip: 16.7 against 17 cycles).  Eight of the nine (filter row, chunk column) blocks of
+// build_dw_mm_weights go into ONE sparse instruction, the ninth into a v_mfma_i32_16x16x32_i8: two matrix instructions per unit
+// instead of three.  Operand layout as measured by scripts/ubench/smfmac_probe.hip (profiles/r06/h_smfmac_probe.txt):
+//   B lane (column, group lb) holds 32 bytes = two 16-byte chunks (half 0 / 1); A lane (row, group ga) holds 16 stored bytes:
+//   stored byte s = 8 ha + 2 grp + j is element j of group grp (four dense bytes) of the chunk that B lane group lb = 2 (ga & 1) + ha
+//   holds in half ga >> 1, and bits 2 s + 1 : 2 s of the index register say which of the four dense bytes it is.
+// Chunk of (lb, half) as (filter row, chunk column): half 0 of lane groups 0..3 = (0,0) (0,1) (0,2) (1,0), half 1 = (1,1) (1,2) (2,0) (2,1);
+// the ninth is (2,2).
+// Returns [q][lane][32 bytes] = {stored A (16), index (4), ninth block as operand A of v_mfma_i32_16x16x32_i8 (8: lane group g' holds
+// bytes 8 g' .. 8 g' + 7 of the chunk, groups 2 and 3 zero), 4 bytes padding}; empty if a group of four holds more than two non-zeros.
+const int DW_SP_CHUNK[4][2][2] = {{{0, 0}, {1, 1}}, {{0, 1}, {1, 2}}, {{0, 2}, {2, 0}}, {{1, 0}, {2, 1}}};
+std::vector<int8_t> build_dw_sp_weights(const std::vector<int8_t> &dense /* build_dw_mm_weights */, int NQ) {
+    std::vector<int8_t> out((size_t)NQ * 64 * 32, 0);
+    auto block = [&](int q, int ty, int gch, int r) { return &dense[((((size_t)q * 3 + ty) * 64) + (size_t)(gch * 16 + r)) * 16]; };
+    for (int q = 0; q < NQ; ++q)
+        for (int lane = 0; lane < 64; ++lane) {
+            const int r = lane & 15, ga = lane >> 4;
+            int8_t *dst = &out[((size_t)q * 64 + lane) * 32];
+            uint32_t idx = 0;
+            for (int ha = 0; ha < 2; ++ha) {
+                const int lb = 2 * (ga & 1) + ha, half = ga >> 1;
+                const int8_t *blk = block(q, DW_SP_CHUNK[lb][half][0], DW_SP_CHUNK[lb][half][1], r);
+                for (int grp = 0; grp < 4; ++grp) {
+                    int pos[4], n = 0;
+                    for (int b = 0; b < 4; ++b)
+                        if (blk[4 * grp + b] != 0) pos[n++] = b;
+                    if (n > 2) return {};
+                    if (n == 0) pos[0] = 0, pos[1] = 1;
+                    if (n == 1) pos[1] = (pos[0] + 1) & 3;
+                    for (int j = 0; j < 2; ++j) {
+                        const int sb = 8 * ha + 2 * grp + j;
+                        dst[sb] = j < n ? blk[4 * grp + pos[j]] : (int8_t)0;
+                        idx |= (uint32_t)pos[j] << (2 * sb);
+                    }
+                }
+            }
+            memcpy(dst + 16, &idx, 4);
+            if (ga < 2) memcpy(dst + 20, block(q, 2, 2, r) + 8 * ga, 8);
+        }
     return out;
 }
 
@@ -523,12 +568,17 @@ OpImpl *op_create(int device, const OpSpec &spec) {
             f.w = a.w, f.A = a.A, f.S = a.S, f.Kc = a.Kc;
             f.izp4 = 0x01010101u * (uint32_t)(uint8_t)(int8_t)s.izp;
             f.lo_f = a.lo_f, f.hi_f = a.hi_f, f.magic = magic, f.xr = xr;
-            f.wmm = nullptr;
+            f.wmm = nullptr, f.wsp = nullptr;
             f.queue = (int *)op->d_queue.p, f.qlaunch = &op->q_launches;
             if (s.C == 8 || s.C % 16 == 0) { // matrix-pipe form of the taps for the fused pair kernels
                 const std::vector<int8_t> prep = build_dw_mm_weights(s.weights, s.C);
                 op->d_wprep.upload(prep.data(), prep.size());
                 f.wmm = op->d_wprep.p;
+                const std::vector<int8_t> sp = build_dw_sp_weights(prep, s.C == 8 ? 1 : s.C / 16); // the sparse form of the same taps (k_quad.hip)
+                if (!sp.empty()) {
+                    op->d_wsp.upload(sp.data(), sp.size());
+                    f.wsp = op->d_wsp.p;
+                }
                 if (dw_taps_on_matrix_pipe() && k::dw_mm_name(s.H, s.W, s.C, s.sh)) op->fast_name = k::dw_mm_name(s.H, s.W, s.C, s.sh);
             }
         } else if (!no_table && dw && zero_wzp && same3x3 && s.C == 1 && k::dw_stem_name(s.H, s.W, s.N, s.sh)) {
