@@ -541,6 +541,7 @@ def main():
             generic_fb = generic_fallback_record(ctx, m, x, count, ev_med)
             rt_rec = runtime_geometry_record(ctx, lw_kernels)
             rt_rec["general_conv"] = general_conv_record(ctx)
+            rt_rec["general_depthwise"] = general_depthwise_record(ctx)
 
         result = {
             "metric": "inferences/sec (int8) for %s" % fname, "value": round(value, 1),
@@ -1004,6 +1005,41 @@ def general_conv_record(ctx):
         nbytes, macs = B * (H * W * C + OH * OW * N), float(B) * OH * OW * N * K * K * C
         out[name] = {"kernel": kernel, "batch": B, "ms": round(ms, 4), "GBps": round(nbytes / (ms * 1e-3) / 1e9, 1),
                      "hbm_frac": round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "TMACps": round(macs / (ms * 1e-3) / 1e12, 2),
+                     "generic_ms_scaled": round(gms, 2), "speedup_vs_generic": round(gms / ms, 1), "bit_exact_vs_oracle": ok}
+        del x, y
+        torch.cuda.empty_cache()
+    return out
+
+
+def general_depthwise_record(ctx):
+    """DepthwiseConv2D beyond 3x3 SAME (src/ops/depthwise_conv_2d.rs:28-49 is generic in filter, stride and padding): a 5x5 stride-1 layer
+    on 24x24x32 and a 3x3 VALID one, both conv_mm_rt's depthwise mode (taps of a 16-channel group on the matrix pipe), each against the
+    shape-generic kernel on a slice of its batch."""
+    mf, torch = ctx["mf"], ctx["torch"]
+    from oracle import oracle as O
+    rng = np.random.default_rng(4)
+    out = {}
+    for name, (H, W, C, KH, KW, S, pad, B) in {"dw5x5_24x24x32_s1": (24, 24, 32, 5, 5, 1, 0, 65536), "dw3x3_valid_24x24x64": (24, 24, 64, 3, 3, 1, 1, 32768)}.items():
+        OH, OW = (-(-H // S), -(-W // S)) if pad == 0 else ((H - KH) // S + 1, (W - KW) // S + 1)
+        w = rng.integers(-128, 128, (KH, KW, C)).astype(np.int8)
+        c0 = rng.uniform(-30, 30, C).astype(np.float32)
+        c1 = (rng.uniform(0.5, 1.5, C) * 40.0 / (5476.0 * np.sqrt(KH * KW))).astype(np.float32)
+        opts = mf.ops.DepthwiseConv2DOptions(mf.FusedActivation(3), mf.TensorViewPadding(pad), (S, S))
+        op = mf.ops.prepare_depthwise_conv_2d((H, W, C), w, np.zeros(C, np.int8), -128, 0.0235294122, -128, opts, (c0, c1), (OH, OW))
+        x = torch.randint(-128, 128, (B, H, W, C), dtype=torch.int8, device="cuda")
+        y = op(x)
+        ms = median(event_times(torch, lambda: op(x), 12))
+        idx = [0, B // 2, B - 1]
+        want = np.stack([O.depthwise_conv_2d(x[i].cpu().numpy(), w, np.zeros(C, np.int8), -128, 0.0235294122, -128, 3, pad, (S, S), (OH, OW), c0, c1)
+                         for i in idx])
+        ok = bool(np.array_equal(y[idx].cpu().numpy(), want))
+        kernel = op.kernel
+        nb = min(B, 512)
+        op.set_generic(True)
+        gms = median(event_times(torch, lambda: op(x[:nb]), 3)) * (B / nb)
+        nbytes = B * (H * W * C + OH * OW * C)
+        out[name] = {"kernel": kernel, "batch": B, "ms": round(ms, 4), "GBps": round(nbytes / (ms * 1e-3) / 1e9, 1),
+                     "hbm_frac": round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                      "generic_ms_scaled": round(gms, 2), "speedup_vs_generic": round(gms / ms, 1), "bit_exact_vs_oracle": ok}
         del x, y
         torch.cuda.empty_cache()

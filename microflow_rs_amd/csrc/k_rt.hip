@@ -607,6 +607,178 @@ __global__ __launch_bounds__(NTHR) void conv_mm_rt(const int8_t *__restrict__ in
     }
 }
 
+// ------------------------------------------------------------------------
+// dw_mm_rt -- DepthwiseConv2D with ANY filter KH x KW (<= 7 x 7), strides and SAME / VALID padding, C % 16 == 0, one output per input
+// channel, zero filter zero points (src/ops/depthwise_conv_2d.rs:28-105; the 3x3 SAME stride-1 / 2 family has its own kernels).
+//
+// conv_mm_rt's staging and pixel walk with the depthwise contraction of k_fused_mm.hip: for a 16-channel group the taps are a
+// block-diagonal K = 16 KH KW product -- lane group g of k step ks supplies the group's 16 bytes of tap 4 ks + g (one ds_read_b128
+// at (window start) + (table offset of the tap) + 16 (group)), operand A holds the tap's weight of channel r in byte r of row r
+// (ops.hip build_dw_mm_rt_weights).  A wave works through a contiguous range of (group, 16-pixel chunk) items with the group's operand
+// A, tap offsets and epilogue constants in registers; a lane ends an item with 4 consecutive channels of its pixel = one packed dword,
+// which goes through a 256-byte per-wave LDS patch so that 16 lanes store a pixel's 16 bytes each.  (First versions, 24x24x32 5x5 at
+// batch 65 536: constants and stores per lane from / to device memory 1.08 TB/s; operand A per k step from LDS 1.58 TB/s.)
+// ------------------------------------------------------------------------
+int dw_mm_lds_bytes(const ConvMmArgs &a) {
+    return a.G * a.TILE + 256 + a.KS * 16 + 64 + 3 * a.C * 4 + 4 * 256;
+}
+// KSMAX == p.KS: the k steps (4 taps each) the instance holds in registers -- 1, 2, 3, 4, 7 or 13; the planner pads a filter's k steps up to
+// the next of these with zero weights, so the loops over them have no guards
+template <int MG, uint32_t XR4, int KSMAX>
+__global__ __launch_bounds__(256) void dw_mm_rt(const int8_t *__restrict__ in, int8_t *__restrict__ out, ConvMmArgs p, int batch) {
+    constexpr int NTHR = 256, NWAVE = 4;
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int C = p.C, KS = p.KS, NBLK = p.NBLK, ROW = p.ROW, TILE = p.TILE, G = p.G, RB = p.RB;
+    const int H = p.H, OH = p.OH, OW = p.OW, ROWB = p.W * C, BH = p.BH, NBANDS = p.NBANDS;
+    // One staging buffer and nothing else of size in LDS: occupancy is what hides a step's DMA wait and its two barriers (measured:
+    // a second buffer with the next step's images in flight, 1.58 against 1.30 ms on 24x24x32 5x5 -- three workgroups per CU became
+    // two).  Operand A is read from device memory (L2) at a wave's few group switches, not kept in LDS.
+    const int TBUF = G * TILE + 256;
+    const int O_OFF = TBUF;                              // [KS][4] tap offsets
+    const int C_OFF = O_OFF + KS * 16 + 64;              // A | S | Kc (+ the bit-pattern offset), C entries each
+    const int P_OFF = C_OFF + 3 * C * 4;                 // per-wave output patches: 16 pixels x 16 bytes
+    for (int i = tid; i < TBUF / 16; i += NTHR) ((uint4 *)lds)[i] = make_uint4(p.izp4, p.izp4, p.izp4, p.izp4);
+    for (int i = tid; i < KS * 4; i += NTHR) ((int *)(lds + O_OFF))[i] = p.tap_off[i];
+    for (int i = tid; i < C; i += NTHR) {
+        ((float *)(lds + C_OFF))[i] = p.A[i], ((float *)(lds + C_OFF))[C + i] = p.S[i];
+        ((int *)(lds + C_OFF))[2 * C + i] = p.Kc[i] + (MG != 0 ? MF_MAGIC_I : 0);
+    }
+    const int col = lane & 15, g = lane >> 4;
+    const float inv_ow = 1.0f / (float)OW, inv_bp = 1.0f / (float)(BH * OW);
+    const int nsteps = ((batch + G - 1) / G) * NBANDS;
+    uint8_t *patch = lds + P_OFF + wave * 256;
+    __syncthreads();
+    int toff[KSMAX]; // this lane group's tap offset in every k step
+#pragma unroll
+    for (int ks = 0; ks < KSMAX; ++ks) toff[ks] = ((const int *)(lds + O_OFF))[ks * 4 + g];
+    auto stage = [&](int st, int buf) {
+        const int band = st % NBANDS, ist = st / NBANDS;
+        const int yfirst = band * BH * p.sh - p.padt;   // input row held by tile row 0
+        for (int gi = 0; gi < G; ++gi) {
+            const long img = (long)ist * G + gi;
+            if (img >= batch) break;
+            for (int r = wave; r < RB; r += NWAVE) {
+                const int y = yfirst + r;
+                uint8_t *dst = lds + buf * TBUF + gi * TILE + r * ROW + p.LP;
+                if (y >= 0 && y < H) {
+                    const int8_t *src = in + (img * H + y) * (long)ROWB;
+                    for (int o = 0; o < ROWB; o += 1024)
+                        if (o + lane * 16 < ROWB) dma16(src + o + lane * 16, dst + o);
+                } else if (NBANDS > 1) {                 // band mode: this tile row is padding in this step only
+                    for (int o = lane * 16; o < ROWB; o += 1024) *(uint4 *)(dst + o) = make_uint4(p.izp4, p.izp4, p.izp4, p.izp4);
+                }
+            }
+        }
+    };
+    for (int step = blockIdx.x; step < nsteps; step += gridDim.x) {
+        const int band = step % NBANDS, ist = step / NBANDS;
+        __syncthreads();                                 // the previous step's reads of the tile are done
+        stage(step, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const uint8_t *tile = lds;
+        const int gvalid = min(G, batch - ist * G);
+        const int rows_here = min(BH, OH - band * BH);
+        const int npix = gvalid * BH * OW;               // the step's pixels; a chunk = 16 consecutive ones = 16 C consecutive output bytes
+        const int nlive = NBANDS > 1 ? rows_here * OW : npix; // (band mode, G == 1: the rows past the image are the band's last pixels)
+        int8_t *obase = out + ((size_t)ist * G * OH + (size_t)band * BH) * OW * C;
+        // Work items = (16-channel group, chunk of 16 pixels), group-major; every wave takes one contiguous quarter of them, so that a
+        // group's operand A (KS x 16 bytes per lane) and the tap offsets live in REGISTERS across the wave's chunks of that group
+        // (from LDS per k step they were half of this kernel's LDS traffic: 14.5 KiB per 256 output bytes).
+        const int nchunks = (npix + 15) >> 4, nitems = NBLK * nchunks;
+        const int i0 = (int)(((long)nitems * wave) / NWAVE), i1 = (int)(((long)nitems * (wave + 1)) / NWAVE);
+        int blk_have = -1;
+        v4i wA[KSMAX];
+        int4 kc = make_int4(0, 0, 0, 0);
+        float4 cA = make_float4(0.f, 0.f, 0.f, 0.f), cS = cA;
+        for (int it = i0; it < i1; ++it) {
+            const int blk = it / nchunks, chunk = it - blk * nchunks;
+            if (blk != blk_have) { // (wave-uniform; at most NBLK / NWAVE + 1 times per step)
+                blk_have = blk;
+                const int ch = 16 * blk + 4 * g;
+#pragma unroll
+                for (int ks = 0; ks < KSMAX; ++ks)
+                    wA[ks] = ((const v4i *)p.wprep)[((size_t)blk * KSMAX + ks) * 64 + lane];
+                kc = *(const int4 *)(lds + C_OFF + (2 * C + ch) * 4);
+                cA = *(const float4 *)(lds + C_OFF + ch * 4), cS = *(const float4 *)(lds + C_OFF + (C + ch) * 4);
+            }
+            const int pp = chunk * 16 + col;
+            const int pc = pp < npix ? pp : npix - 1;
+            const int gi = (int)(((float)pc + 0.5f) * inv_bp);
+            const int rr = pc - gi * BH * OW;
+            const int oyl = (int)(((float)rr + 0.5f) * inv_ow), ox = rr - oyl * OW;
+            const uint8_t *winb = tile + gi * TILE + (oyl * p.sh) * ROW + p.LP + (ox * p.sw - p.padl) * C + 16 * blk;
+            v4i acc = {kc.x, kc.y, kc.z, kc.w};
+            // a ring of RING operand-B registers: tap chunk ks + RING is fetched behind the MFMA of chunk ks (all of them at once cost
+            // 28 registers at 5x5 -- one wave per SIMD of occupancy)
+            constexpr int RING = KSMAX < 4 ? KSMAX : 4;
+            v4i b[RING];
+#pragma unroll
+            for (int ks = 0; ks < RING; ++ks) b[ks] = *(const v4i *)(winb + toff[ks]);
+#pragma unroll
+            for (int ks = 0; ks < KSMAX; ++ks) {
+                acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(wA[ks], b[ks % RING], acc, 0, 0, 0);
+                if (ks + RING < KSMAX) b[ks % RING] = *(const v4i *)(winb + toff[ks + RING]);
+            }
+            const uint32_t d = requant_pack4<MG, XR4>(acc[0], acc[1], acc[2], acc[3], cA, cS, p.lo_f, p.hi_f);
+            // 16 pixels x this group's 16 bytes through the wave's patch: lane l < 16 stores pixel l's 16 bytes
+            *(uint32_t *)(patch + col * 16 + 4 * g) = d;
+            if (lane < 16 && chunk * 16 + lane < nlive) st_out_t<false>(obase + ((size_t)chunk * 16 + lane) * C + 16 * blk, *(const uint4 *)(patch + lane * 16));
+        }
+    }
+}
+template <int MG, uint32_t XR4, int KSMAX>
+static void launch_dw_mm_k(const int8_t *in, int8_t *out, const ConvMmArgs &a, int batch, hipStream_t s) {
+    const int lds = dw_mm_lds_bytes(a);
+    int per_cu = 1;
+    {
+        static std::mutex mu;
+        static std::map<std::pair<int, int>, int> cache;
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        std::lock_guard<std::mutex> lock(mu);
+        auto it = cache.find({dev, lds});
+        if (it == cache.end()) {
+            (void)hipFuncSetAttribute((const void *)dw_mm_rt<MG, XR4, KSMAX>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            int n = 1;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, dw_mm_rt<MG, XR4, KSMAX>, 256, (size_t)lds) != hipSuccess || n < 1) {
+                (void)hipGetLastError();
+                n = 1;
+            }
+            it = cache.emplace(std::make_pair(dev, lds), n).first;
+        }
+        per_cu = it->second;
+    }
+    const int nsteps = ((batch + a.G - 1) / a.G) * a.NBANDS;
+    const int grid = nsteps < 256 * per_cu ? nsteps : 256 * per_cu;
+    hipLaunchKernelGGL((dw_mm_rt<MG, XR4, KSMAX>), dim3(grid), dim3(256), lds, s, in, out, a, batch);
+}
+template <int MG, uint32_t XR4>
+static void launch_dw_mm_t(const int8_t *in, int8_t *out, const ConvMmArgs &a, int batch, hipStream_t s) {
+    switch (a.KS) { // (conv_mm_plan pads the k steps of its depthwise mode to one of these)
+    case 1: launch_dw_mm_k<MG, XR4, 1>(in, out, a, batch, s); break;
+    case 2: launch_dw_mm_k<MG, XR4, 2>(in, out, a, batch, s); break;
+    case 3: launch_dw_mm_k<MG, XR4, 3>(in, out, a, batch, s); break;
+    case 4: launch_dw_mm_k<MG, XR4, 4>(in, out, a, batch, s); break;
+    case 7: launch_dw_mm_k<MG, XR4, 7>(in, out, a, batch, s); break;
+    default: launch_dw_mm_k<MG, XR4, 13>(in, out, a, batch, s); break;
+    }
+}
+void launch_dw_mm(const int8_t *in, int8_t *out, const ConvMmArgs &a, int batch, hipStream_t s) {
+    const int mg = a.magic;
+    if (a.xr) {
+        if (mg == 2) launch_dw_mm_t<2, 0x80808080u>(in, out, a, batch, s);
+        else if (mg) launch_dw_mm_t<1, 0x80808080u>(in, out, a, batch, s);
+        else launch_dw_mm_t<0, 0x80808080u>(in, out, a, batch, s);
+    } else {
+        if (mg == 2) launch_dw_mm_t<2, 0u>(in, out, a, batch, s);
+        else if (mg) launch_dw_mm_t<1, 0u>(in, out, a, batch, s);
+        else launch_dw_mm_t<0, 0u>(in, out, a, batch, s);
+    }
+}
+
 // ---- launchers ----
 bool dw_rt_plan(DwRtArgs &a, int H, int W, int C, int S, int OH, int OW) {
     if (C % 4 != 0 || C / 4 > 512 || (S != 1 && S != 2) || (W * C) % 16 != 0) return false;
@@ -979,10 +1151,15 @@ int conv_mm_lds_bytes(const ConvMmArgs &a, bool wz) {
 }
 // fills the geometry and the tap-offset table (host copy in `tap`); false: not for this kernel
 bool conv_mm_plan(ConvMmArgs &a, std::vector<int> &tap, int H, int W, int C, int N, int KH, int KW, int sh, int sw, int OH, int OW,
-                  bool pad_same, bool wz) {
+                  bool pad_same, bool wz, bool dwise) {
     if (C % 16 != 0 || N % 4 != 0 || KH > 7 || KW > 7 || (W * C) % 16 != 0) return false;
-    const int Ktot = KH * KW * C, KS = (Ktot + 63) / 64, NT = (N + 15) / 16;
-    const int TB = NT < 4 ? NT : 4, NBLK = (NT + TB - 1) / TB;
+    if (dwise && (N != C || wz)) return false;           // one output per input channel; filter zero points take the generic kernel
+    const int Ktot = dwise ? KH * KW * 16 : KH * KW * C; // depthwise: 16 k-bytes per tap and block
+    int KS = (Ktot + 63) / 64;
+    if (dwise) KS = KS <= 4 ? KS : (KS <= 7 ? 7 : 13);  // (dw_mm_rt's instances; the steps beyond the filter meet zero weights)
+    const int NT = (N + 15) / 16;
+    const int TB = dwise ? 1 : (NT < 4 ? NT : 4), NBLK = (NT + TB - 1) / TB;
+    a.dwise = dwise ? 1 : 0;
     const int wbytes = NBLK * TB * KS * 1024 + (wz ? KS * 1024 : 0);
     if (wbytes > 96 * 1024) return false;
     const int padl = pad_same ? (KW - 1) / 2 : 0, padt = pad_same ? (KH - 1) / 2 : 0;
@@ -1024,9 +1201,15 @@ bool conv_mm_plan(ConvMmArgs &a, std::vector<int> &tap, int H, int W, int C, int
         for (int g = 0; g < 4; ++g) {
             const int kk0 = ks * 64 + g * 16;
             if (kk0 >= Ktot) continue;                   // beyond K: zero weights, offset 0
-            const int t = kk0 / C, c0 = kk0 % C, ky = t / KW, kx = t % KW;
+            const int CK = dwise ? 16 : C;               // k-bytes per tap
+            const int t = kk0 / CK, c0 = kk0 % CK, ky = t / KW, kx = t % KW;
             tap[(size_t)ks * 4 + g] = ky * ROW + kx * C + c0;
         }
+    if (dwise) {
+        a.NTHR = 256; // (dw_mm_rt: four-wave workgroups; a step of at most what leaves room for a second workgroup)
+        while (a.G > 1 && 2 * dw_mm_lds_bytes(a) > 160 * 1024) --a.G;
+        return dw_mm_lds_bytes(a) <= 160 * 1024;
+    }
     return conv_mm_lds_bytes(a, wz) <= 160 * 1024;
 }
 template <bool WZ, int MG, uint32_t XR4, int NTHR>

@@ -251,6 +251,9 @@ struct ConvMmArgs {
     int padl, padt;      // SAME: (KW - 1) / 2, (KH - 1) / 2 (src/tensor.rs:193); VALID: 0
     int LP, ROW, RB, TILE, G, BH, NBANDS; // tile geometry as DwRtArgs
     int KS, TB, NBLK;    // 64-deep k steps over K = KH KW C; tiles per block (<= 4); blocks
+    int dwise;           // 1: DepthwiseConv2D with C % 16 == 0 (src/ops/depthwise_conv_2d.rs:28-105), kernel dw_mm_rt: block b is the 16-channel
+                         // group b (TB = 1, NBLK = C / 16), its k steps run over the TAPS only -- lane group g of step ks supplies the
+                         // group's 16 bytes of tap 4 ks + g -- against block-diagonal weights (ops.hip build_dw_mm_rt_weights)
     int NTHR;            // threads per workgroup: 256, or 1024 when the weights leave room for one workgroup per CU only
     uint32_t izp4;
     float lo_f, hi_f;
@@ -263,8 +266,9 @@ struct ConvMmArgs {
     int magic, xr;
 };
 bool conv_mm_plan(ConvMmArgs &a, std::vector<int> &tap, int H, int W, int C, int N, int KH, int KW, int sh, int sw, int OH, int OW,
-                  bool pad_same, bool wz);
+                  bool pad_same, bool wz, bool dwise = false);
 void launch_conv_mm(const int8_t *in, int8_t *out, const ConvMmArgs &a, bool wz, int batch, hipStream_t s);
+void launch_dw_mm(const int8_t *in, int8_t *out, const ConvMmArgs &a, int batch, hipStream_t s); // a.dwise: dw_mm_rt (k_rt.hip)
 bool dw_rt_plan(DwRtArgs &a, int H, int W, int C, int S, int OH, int OW); // fills the geometry; false: not supported
 void launch_dw_rt(const int8_t *in, int8_t *out, const DwRtArgs &a, int S, bool wz, int batch, hipStream_t s);
 bool pw_rt_supported(int K, int N, bool wz);

@@ -318,6 +318,20 @@ std::vector<int8_t> build_dw_sp_weights(const std::vector<int8_t> &dense /* buil
     return out;
 }
 
+// Depthwise weights [KH][KW][C] (C % 16 == 0) as operand A of conv_mm_rt's depthwise mode (k_rt.hip): [16-channel group][k step][lane]
+// x 16 bytes; lane (row r, group g) of step ks holds tap t = 4 ks + g: its only non-zero byte is byte r = w[t][16 q + r].
+std::vector<int8_t> build_dw_mm_rt_weights(const int8_t *w, int KH, int KW, int C, int KS /* >= (KH KW + 3) / 4: padded with zero steps */) {
+    const int NQ = C / 16, T = KH * KW;
+    std::vector<int8_t> out((size_t)NQ * KS * 1024, 0);
+    for (int q = 0; q < NQ; ++q)
+        for (int ks = 0; ks < KS; ++ks)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int r = lane & 15, t = 4 * ks + (lane >> 4);
+                if (t < T) out[(((size_t)q * KS + ks) * 64 + lane) * 16 + r] = w[(size_t)t * C + 16 * q + r];
+            }
+    return out;
+}
+
 // The same operand for FEWER than 16 channels (chain_rt, k_chain.hip): P = 16 / C horizontally adjacent pixels are one 16-channel
 // "superpixel", stride S in superpixels.  Row r = (output pixel p = r / C of superpixel X, channel r % C); block g = input superpixel
 // S X - 1 + g, whose byte (pp, c') is input pixel P (S X - 1 + g) + pp: non-zero for c' == channel and the tap column
@@ -755,6 +769,24 @@ OpImpl *op_create(int device, const OpSpec &spec) {
             op->rt_wz = !all_zero(wzp);
             op->fast_name = std::string(dw ? "dw_rows_lds" : "conv_rows_lds") + (op->rt_wz ? "<wzp>" : "");
         }
+        // any other DepthwiseConv2D with C % 16 == 0 and one output per channel -- a filter other than 3x3, VALID padding, unequal
+        // strides -- : the same kernel in its depthwise mode, taps of a 16-channel group on the matrix pipe against block-diagonal weights
+        if (op->fast == OpImpl::NONE && !no_rt && op->finite_consts && dw && s.C == s.N && s.C % 16 == 0 && all_zero(wzp)) {
+            std::vector<int> tap;
+            if (k::conv_mm_plan(op->cmm, tap, s.H, s.W, s.C, s.N, s.KH, s.KW, s.sh, s.sw, s.OH, s.OW, s.pad == MF_PAD_SAME, false, true)) {
+                k::ConvMmArgs &f = op->cmm;
+                const std::vector<int8_t> prep = build_dw_mm_rt_weights(s.weights, s.KH, s.KW, s.C, f.KS);
+                op->d_wprep.upload(prep.data(), prep.size());
+                op->d_tap.upload(tap.data(), tap.size() * sizeof(int));
+                f.wprep = op->d_wprep.p, f.tap_off = op->d_tap.as<int>();
+                f.A = a.A, f.S = a.S, f.Kc = a.Kc, f.wzp = a.wzp;
+                f.izp4 = 0x01010101u * (uint32_t)(uint8_t)(int8_t)s.izp;
+                f.lo_f = a.lo_f, f.hi_f = a.hi_f, f.magic = magic, f.xr = xr;
+                op->fast = OpImpl::CONV_MM;
+                op->rt_wz = false;
+                op->fast_name = "dw_mm_rt<" + std::to_string(s.KH) + "x" + std::to_string(s.KW) + ">";
+            }
+        }
         // any other Conv2D with C % 16 == 0: MFMA product over K = KH KW C with the image staged in LDS
         if (op->fast == OpImpl::NONE && !no_rt && op->finite_consts && !dw && !(s.KH == 1 && s.KW == 1 && k::conv1x1_rowwave_supported(a))) {
             const bool wz = !all_zero(wzp);
@@ -971,7 +1003,8 @@ void op_run(OpImpl *op, const int8_t *d_in, size_t batch, int8_t *d_out, void *s
             break;
         }
         case OpImpl::CONV_MM:
-            k::launch_conv_mm(d_in, d_out, op->cmm, op->rt_wz, (int)batch, s);
+            if (op->cmm.dwise) k::launch_dw_mm(d_in, d_out, op->cmm, (int)batch, s);
+            else k::launch_conv_mm(d_in, d_out, op->cmm, op->rt_wz, (int)batch, s);
             done = true;
             break;
         case OpImpl::CONV_ROWS:

@@ -149,7 +149,17 @@ DW_CASES = [
     (7, 9, 3, 3, 3, 3, 1, 1, 0, 7, 9, True, 0),          # generic, non-zero weight zp
     (8, 8, 4, 4, 2, 3, 1, 2, 1, 7, 3, True, 3),          # VALID, rectangular
     (5, 6, 2, 6, 3, 3, 1, 1, 0, 5, 6, True, 0),          # channels beyond Cin read channel 0
+    # C % 16 == 0 outside the 3x3 SAME stride-1/2 family: conv_mm_rt's depthwise mode (dw_mm_rt<KHxKW>)
+    (24, 24, 32, 32, 5, 5, 1, 1, 0, 24, 24, False, 3),   # 5x5
+    (20, 20, 16, 16, 3, 3, 1, 1, 1, 18, 18, False, 1),   # 3x3 VALID
+    (17, 13, 48, 48, 5, 3, 2, 1, 0, 9, 13, False, 0),    # rectangular filter, unequal strides
+    (12, 12, 64, 64, 7, 7, 2, 2, 0, 6, 6, False, 3),     # 7x7 stride 2
+    (9, 11, 16, 16, 3, 3, 2, 1, 1, 4, 9, False, 3),      # 3x3 VALID, unequal strides
+    (8, 8, 128, 128, 2, 2, 2, 2, 1, 4, 4, False, 0),     # 2x2 VALID stride 2
+    (96, 96, 16, 16, 5, 5, 1, 1, 0, 96, 96, False, 3),   # an image too large for one tile: row bands
 ]
+DW_MM_RT = {c for c in DW_CASES if c[2] == c[3] and c[2] % 16 == 0 and not c[11]
+            and not (c[4] == 3 and c[5] == 3 and c[6] == c[7] and c[6] in (1, 2) and c[8] == 0)}
 
 
 @pytest.mark.parametrize("case", DW_CASES, ids=lambda c: "x".join(map(str, c[:8])))
@@ -169,6 +179,8 @@ def test_depthwise_vs_oracle(mf, O, case):
                                          c0, c1) for i in range(batch)])
     got = op(x)
     assert np.array_equal(got, want), (op.kernel, np.argwhere(got != want)[:5])
+    if case in DW_MM_RT:
+        assert ROUTING_SWITCHED or op.kernel == "dw_mm_rt<%dx%d>" % (KH, KW), op.kernel
     if op.kernel != "dwconv_generic":  # the shape-generic kernel must agree as well
         fast_kernel = op.kernel
         op.set_generic(True)
