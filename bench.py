@@ -35,58 +35,14 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 achievable)
-# The reference's f32 requantisation (two individually rounded operations, roundf, clamp, `as T`) costs 5.75 - 6 VALU
-# instructions per output byte in its shortest exact form (k_common.hpp).  Its ceiling on this chip with nothing else in
-# the loop is MEASURED in every run, outside the timed region, by scripts/ubench/epi_rate.hip (libepi_rate.so, built by
-# __graft_entry__.build(); it executes the library's own requant_pack4): ns per 256-byte wave group per SIMD ->
-# GB/s of requantised bytes over the 1024 SIMDs.  A kernel that keeps its intermediate tensors on chip (the late-stage
-# kernel) is bounded by this, not by HBM.  The literal below is only the fallback when the ubench cannot run
-# (profiles/r03: 39.8 ns -> 6 590 GB/s for the saturating-pack form person_detect's operators use).
-REQUANT_PEAK_GBS = 6590.0
-REQUANT_CEILING = None  # filled by measure_requant_ceiling()
+# the measurement legs live in benchlib/ (this file: the launch path, the timed region, the parity legs and the CPU baseline)
+from benchlib import roofline as rl  # noqa: E402
+from benchlib.compact import COMPACT_CAP, DETAILS_FILE, compact_record  # noqa: E402,F401  (tests import compact_record from here)
+from benchlib.records import (fc4096_record, general_conv_record, general_depthwise_record, generic_fallback_record,  # noqa: E402,F401
+                              runtime_geometry_record, speech_record)
+from benchlib.roofline import (HBM_PEAK_GBS, event_times, measure_requant_ceiling, median, pmc_traffic, requant_peak,  # noqa: E402,F401
+                               rocprof_name, sq_counters)
 
-
-def measure_requant_ceiling():
-    """Run the requantisation microbenchmark on the current device (a few hundred ms) and make its result the ceiling
-    every `valu_frac` / `requant_frac` of this run is priced against."""
-    global REQUANT_PEAK_GBS, REQUANT_CEILING
-    import ctypes
-    rec = {"source": "scripts/ubench/epi_rate.hip (libepi_rate.so), measured in this run outside the timed region",
-           "unit": "GB/s of requantised int8 over 1024 SIMDs", "loop_overhead": "one v_add per value is part of the loop",
-           "forms": {}}
-    try:
-        lib = ctypes.CDLL(os.path.join(ROOT, "scripts", "ubench", "libepi_rate.so"))
-        lib.mf_ubench_requant_ns.restype = ctypes.c_double
-        lib.mf_ubench_requant_ns.argtypes = [ctypes.c_int]
-        # a ceiling is the BEST rate the chip sustains: three repetitions per form, the fastest counts (a repetition that meets
-        # a power-management transient would otherwise understate it)
-        for name, v in (("mode3_single_fma", 8), ("mode2_saturating_pack", 5), ("mode1_med3", 4), ("round2_form", 1)):
-            reps = [lib.mf_ubench_requant_ns(v) for _ in range(3)]  # each: 1 warm-up + 5 timed launches of ~2.6 ms
-            reps = [r for r in reps if r > 0]
-            if reps:
-                ns = min(reps)
-                rec["forms"][name] = {"ns_per_256B_wave_group_per_simd": round(ns, 2), "GBps": round(1024 * 256 / ns, 1),
-                                      "repetitions_ns": [round(r, 2) for r in reps]}
-        if "mode2_saturating_pack" in rec["forms"]:
-            got = rec["forms"]["mode2_saturating_pack"]["GBps"]
-            # Observed once in round 4 (profiles/r04/f_slow_ubench_box.txt): a box whose pure-VALU microbenchmark ran at
-            # 0.73 of every other box's rate while the kernels ran at 0.97 of theirs -- the "ceiling" then sits BELOW what the
-            # kernels reach.  A measurement under 0.85 of the reference figure is reported but not used: the fractions are then priced
-            # against the reference literals (profiles/r03/epi_rate.txt: 6 590 / 6 310 / 5 970 GB/s), and the record says so.
-            if got >= 0.85 * REQUANT_PEAK_GBS:
-                REQUANT_PEAK_GBS = got
-                rec["used"] = "mode2_saturating_pack (measured in this run)"
-            else:
-                rec["used"] = "reference literals: the in-run measurement (%.0f GB/s) is below 0.85 of the reference %.0f GB/s" % (got, REQUANT_PEAK_GBS)
-                rec["suspect"] = True
-                rec["forms_measured"] = rec["forms"]
-                rec["forms"] = {"mode2_saturating_pack": {"GBps": 6590.0}, "mode1_med3": {"GBps": 6310.0}, "round2_form": {"GBps": 5970.0}}
-    except OSError as e:
-        rec["error"] = "libepi_rate.so not loadable (%s): literal fallback" % e
-    rec["GBps"] = REQUANT_PEAK_GBS
-    REQUANT_CEILING = rec
-    return rec
 WORKLOADS = {
     # name: (model file, BASELINE config index used as stream id, per-GPU batch)
     "person_detect": ("person_detect.tflite", 3, 65536),
@@ -94,13 +50,6 @@ WORKLOADS = {
     # BASELINE config 5: generated single-op FullyConnected model, one [4096,4096] input per step
     "fc4096": (None, 5, 1),
 }
-# int8 MFMA peaks (TOP/s, dense).  The guide gives no spec figure for int8: "I8 >= 3944 TOPS (16x16x64,
-# ~2x the bf16 rate)" is its measured floor; 5033 = 2 x the ~2.5 PF dense bf16 peak is the nominal figure.
-INT8_MFMA_PEAK_NOMINAL = 5033.0
-INT8_MFMA_PEAK_GUIDE_FLOOR = 3944.0
-# v_dot4_i32_i8 issue rate measured on this chip (scripts/ubench/inst_rates.hip): 0.55 T wave-inst/s
-# x 64 lanes x 4 MAC = 140.8 TMAC/s -- the ceiling of a dot4-bound kernel (speech's depthwise)
-DOT4_PEAK_TMACS = 140.8
 PARITY_NOTE = ("bit-exact vs the restated CPU oracle (oracle/mf_oracle.c, pinned to every reference KAT; "
                "softmax's expf is pinned at the reference's 9 points only)")
 
@@ -126,101 +75,6 @@ def self_launch(args):
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "4")
     raise SystemExit(subprocess.call(cmd, env=env))
-
-
-def requant_peak(mode):
-    """the measured requantisation ceiling (GB/s) of the epilogue form a launch runs (k_common.hpp modes 0 / 1 / 2)"""
-    forms = (REQUANT_CEILING or {}).get("forms", {})
-    name = {3: "mode3_single_fma", 2: "mode2_saturating_pack", 1: "mode1_med3", 0: "round2_form"}.get(mode, "mode2_saturating_pack")
-    if mode == 3 and name not in forms:  # no measurement of the single-fma form in this run: its fractions are not computed
-        return None
-    return forms.get(name, {}).get("GBps", REQUANT_PEAK_GBS)
-
-
-def source_sha16():
-    """sha256 (first 16 hex digits) over the kernel sources: what a committed counter profile is tagged with, so that a
-    replayed figure says whether it belongs to the kernels of THIS build"""
-    import hashlib
-    h = hashlib.sha256()
-    d = os.path.join(ROOT, "microflow_rs_amd", "csrc")
-    for f in sorted(os.listdir(d)):
-        if f.endswith((".hip", ".hpp", ".cpp")):
-            h.update(f.encode())
-            h.update(open(os.path.join(d, f), "rb").read())
-    return h.hexdigest()[:16]
-
-
-def rocprof_name(kernel, mode, u8=False):
-    """the name (prefix) rocprofv3 prints for a launch of the library's kernel `kernel` -- the key into
-    profiles/*kernel_stats.csv; the library's own names spell the fused shapes out, the compiler's the template arguments"""
-    xr = "0u" if (mode == 3 or not u8) else "2155905152u"
-    sp = lambda t: ", ".join(x.strip() for x in t.split(","))  # noqa: E731
-    if kernel.startswith("penta_rr<"):
-        return "mf::k::quad_rr<mf::k::Quad13, true, %d, %s>" % (mode, xr)
-    if kernel.startswith("quad_rr<48,"):
-        return "mf::k::quad_rr<mf::k::Quad13, false, %d, %s>" % (mode, xr)
-    if kernel.startswith("quad_rr<24,"):
-        return "mf::k::quad_rr<mf::k::Quad57, false, %d, %s>" % (mode, xr)
-    if kernel.startswith("stage_6x6x128<"):
-        return "mf::k::stage_6x6x128<4, 512, %d, %s>" % (mode, xr)
-    if "<" in kernel:  # dwpw_mm<H,W,C,S,N,G,T,D>, pair3_tail<H,W,C,S>, pw_mfma<K,N>, ...: the leading template arguments are the same
-        base, args = kernel.split("<", 1)
-        lead = args.rstrip(">").split(",")
-        lead = lead[:7] if base.startswith(("dwpw_", "dw3x3_mm")) else lead
-        return "mf::k::%s<%s" % (base.replace("dw3x3_mm", "dwpw_mm"), sp(",".join(lead)))
-    return "mf::k::" + kernel
-
-
-def sq_counters(kernel):
-    """Independent of the microbenchmark: per-kernel figures from the committed rocprofv3 SQ counter passes of this same
-    command (profiles/sq_latest.json = scripts/pmc_summary.py --sq).  Reported as measured -- VALU wave-instructions per SIMD
-    clock -- without a normaliser: the issue ceiling depends on the instruction mix (full-rate v_fma / v_add against the
-    0.6-rate conversions), so a single "busy" fraction would under- or over-read."""
-    try:
-        sq = json.load(open(os.path.join(ROOT, "profiles", "sq_latest.json")))
-        k = sq["kernels"].get(kernel)  # exact name only: a different template instance or an older kernel is not this one
-        if k:
-            stale = sq.get("source_sha16") != source_sha16()
-            return {"valu_inst_per_clk_per_simd": k["valu_inst_per_clk_per_simd"],
-                    "lds_bank_conflict_ratio": k["lds_bank_conflict_ratio"], "wait_any_frac": k.get("wait_any_frac"),
-                    "source": "committed profiles/sq_latest.json (a separate rocprofv3 --pmc pass, NOT measured in this run)%s"
-                              % (": STALE -- collected on other kernel sources" if stale else ""), "stale": stale}
-    except (OSError, ValueError, KeyError):
-        pass
-    return None
-
-
-def pmc_traffic(kernel, count):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/pmc_traffic_latest.json =
-    scripts/pmc_summary.py over separate --pmc FETCH_SIZE / WRITE_SIZE passes of this same command)."""
-    try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")))
-        if count is None or pmc.get("per_gpu_batch") == count:
-            for k in pmc["kernels"]:
-                if k["kernel"] == kernel or (kernel == "fc_mfma" and k["kernel"].startswith("fc_mfma<")):
-                    stale = pmc.get("source_sha16") != source_sha16()
-                    return k["traffic_bytes"], ("committed profiles/pmc_traffic_latest.json (separate rocprofv3 --pmc passes, NOT "
-                                                "measured in this run)" + (": STALE -- collected on other kernel sources" if stale else ""))
-    except (OSError, ValueError, KeyError):
-        pass
-    return None, None
-
-
-def median(xs):
-    xs = sorted(xs)
-    n = len(xs)
-    return xs[n // 2] if n % 2 else 0.5 * (xs[n // 2 - 1] + xs[n // 2])
-
-
-def event_times(torch, step, iters):
-    """per-iteration durations (ms) of `step` from HIP event pairs on the current (= launch) stream"""
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
-    for a, b in evs:
-        a.record()
-        step()
-        b.record()
-    torch.cuda.synchronize()
-    return [a.elapsed_time(b) for a, b in evs]
 
 
 def main():
@@ -288,8 +142,11 @@ def main():
     from microflow_rs_amd.shard import gather_checksums, max_over_ranks, shard_range
     from microflow_rs_amd.synth import SEED
 
+    # (the CPU restatement: imported HERE and nowhere else outside tests/ and smoke(); the benchlib legs that spot-check their outputs
+    # get it as ctx["checker"], the CPU baseline and the step's parity legs below use it directly)
+    from oracle import oracle as O
     ctx = dict(args=args, mf=mf, _lib=_lib, torch=torch, dist=dist, world=world, rank=rank, local_rank=local_rank, use_dist=use_dist,
-               synth_i8=synth_i8, checksum_i8=checksum_i8, SEED=SEED)
+               synth_i8=synth_i8, checksum_i8=checksum_i8, SEED=SEED, checker=O)
     fname, cfg, base_batch = WORKLOADS[args.workload]
     B = args.batch or base_batch
     if args.workload == "fc4096":
@@ -428,7 +285,7 @@ def main():
                     "algorithmic_bytes": dom["bytes"], "requant_bytes": dom["requant_bytes"],
                     "traffic": traffic, "traffic_src": traffic_src, "traffic_source": traffic_src,
                     "rocprof_name": rocprof_name(dom["kernel"], dom["epilogue_mode"], m.dtype == np.uint8),
-                    "requant_ceiling_src": (REQUANT_CEILING or {}).get("used"),
+                    "requant_ceiling_src": (rl.REQUANT_CEILING or {}).get("used"),
                     "method": "HIP events on the launch stream, median of %d launches" % iters,
                     "note": "the longest launch of the step.  achieved / peak / frac: algorithmic bytes per launch / its "
                             "duration vs the 8 TB/s HBM peak; valu_frac: every int8 byte the launch requantises (on chip or "
@@ -468,7 +325,6 @@ def main():
                      "conv_2d": agg(lw_kernels, "conv_2d"), "kernels": lw_kernels}
 
         # ---- parity: sampled bit-exact comparison with the CPU oracle ----
-        from oracle import oracle as O
         om = O.Model(os.path.join(ROOT, "models", fname))
         idx = sorted(set([0, 1, count // 3, count // 2, count - 2, count - 1] + list(range(7, count, max(1, count // 42)))))[:48]
         xs = x.reshape(count, -1)[idx].cpu().numpy()
@@ -554,7 +410,7 @@ def main():
                        "backend": (args.backend if (world > 1 or args.dist) else None),
                        "shards": [list(shard_range(B * world, r, world)) for r in range(world)]},
             "roofline": roofline,
-            "requant_ceiling": REQUANT_CEILING,
+            "requant_ceiling": rl.REQUANT_CEILING,
             "event_median": {"ms_per_step": round(ev_med, 4), "value": round(B * world / (ev_med * 1e-3), 1),
                              "iterations": len(ev), "min_ms": round(min(ev), 4), "max_ms": round(max(ev), 4),
                              "note": "HIP event pair per step on the launch stream, median; max over ranks"},
@@ -588,89 +444,6 @@ def main():
             result["value"] = 0.0
             result["error"] = "GPU outputs differ from the CPU oracle: number withheld"
     finish(ctx, result)
-
-
-DETAILS_FILE = "bench_details.json"
-COMPACT_CAP = 8192  # the driver keeps the last 8 KB of stdout: the final line must fit with room to spare (target <= 4 KB)
-
-
-def _pick(d, keys):
-    return {k: d[k] for k in keys if isinstance(d, dict) and k in d}
-
-
-def _sub_summary(rec):
-    """one-line summary of a sub-record (speech, fc4096, fc4096_wzp)"""
-    if not isinstance(rec, dict):
-        return None
-    out = _pick(rec, ("value", "value_batch", "unit", "ms_per_step"))
-    rl = rec.get("roofline") or {}
-    out["roofline"] = _pick(rl, ("bound", "kernel", "batch", "ms", "achieved", "peak", "unit", "frac", "hbm_frac", "traffic", "traffic_src"))
-    if isinstance(out["roofline"].get("traffic_src"), str):
-        out["roofline"]["traffic_src"] = "stale-committed" if "STALE" in out["roofline"]["traffic_src"] else "committed"
-    out["parity"] = bool(rec.get("parity", {}).get("bit_exact_vs_oracle", False))
-    return out
-
-
-def compact_record(full):
-    """The ONE line the driver parses: the contract's keys + roofline + cpu_baseline + whole_step + parity and one-line
-    summaries of the other single-GPU BASELINE configs.  Everything else (per-kernel tables, layer-wise step, run-time
-    geometry, generated models, general conv, requantisation forms, vendor cross-checks) stays in bench_details.json."""
-    c = _pick(full, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-                     "vs_baseline", "dtype", "data", "error"))
-    cfg = full.get("config") or {}
-    c["config"] = _pick(cfg, ("workload", "per_gpu_batch", "global_batch", "parallelism", "backend", "shards"))
-    if len(c["config"].get("shards") or []) > 8:
-        c["config"]["shards"] = c["config"]["shards"][:8] + ["..."]
-    c["roofline"] = _pick(full.get("roofline") or {}, (
-        "bound", "binding_roof", "kernel", "rocprof_name", "ms", "achieved", "peak", "unit", "frac", "hbm_frac", "valu_frac", "traffic", "traffic_src",
-        "algorithmic_bytes", "requant_bytes", "requant_peak_GBps", "requant_ceiling_src", "epilogue_mode", "method", "peak_guide_floor",
-        "frac_of_guide_floor", "algorithmic_ops"))
-    # `bound` follows the contract's vocabulary ("hbm" | "mfma": the roof achieved / peak / frac are stated against); a record that
-    # named the builder-defined requantisation roof there (rounds 3-4) keeps that in `binding_roof`
-    if c["roofline"].get("bound") not in (None, "hbm", "mfma"):
-        c["roofline"].setdefault("binding_roof", c["roofline"]["bound"])
-        c["roofline"]["bound"] = "mfma" if "OP" in str(c["roofline"].get("unit", "")) else "hbm"
-    for k in ("traffic_src", "requant_ceiling_src"):  # (short forms in the line; the full sentences are in bench_details.json)
-        v = c["roofline"].get(k)
-        if isinstance(v, str):
-            c["roofline"][k] = ("stale-committed" if "STALE" in v else "committed") if v.startswith("committed") else \
-                               ("measured-in-run" if "measured in this run" in v else ("literals(in-run measurement suspect)" if "literal" in v else v[:40]))
-    if full.get("whole_step"):
-        c["whole_step"] = _pick(full["whole_step"], ("ms", "launches", "algorithmic_bytes", "frac", "hbm_frac", "valu_frac",
-                                                     "roof_floor_ms", "frac_of_roof_floor"))
-    if full.get("event_median"):
-        c["event_median"] = _pick(full["event_median"], ("ms_per_step", "value", "iterations"))
-    for k in ("depthwise", "conv_2d"):  # the layer-wise aggregates BASELINE.json's targets are quoted on
-        if full.get(k):
-            c["layerwise_" + k] = _pick(full[k], ("kernels", "ms", "GBps", "frac"))
-    cb = full.get("cpu_baseline")
-    if cb:
-        c["cpu_baseline"] = _pick(cb, ("value", "unit", "cores", "kind", "sample"))
-        c["cpu_baseline"]["host"] = (cb.get("host") or {}).get("cpu", "")
-        mt = full.get("cpu_baseline_all_cores")
-        if mt:
-            c["cpu_baseline"]["all_cores"] = _pick(mt, ("value", "cores"))
-    else:
-        c["cpu_baseline"] = None
-    if full.get("parity"):
-        c["parity"] = _pick(full["parity"], ("bit_exact_vs_oracle", "sampled_images", "structured_images", "sampled_rows",
-                                             "output_checksums"))
-        if len(c["parity"].get("output_checksums") or []) > 8:
-            c["parity"]["output_checksums"] = c["parity"]["output_checksums"][:8] + ["..."]
-    for k in ("host_fed", "predict_f32"):
-        if full.get(k):
-            c[k] = _pick(full[k], ("value", "ms_per_step"))
-    for sub in ("speech", "fc4096", "fc4096_wzp"):
-        if sub in full:
-            c[sub] = _sub_summary(full[sub])
-    c["details"] = DETAILS_FILE
-    line = json.dumps(c, separators=(",", ":"))
-    if len(line) >= COMPACT_CAP:  # never let the line outgrow the driver's window: drop the optional blocks
-        for k in ("host_fed", "predict_f32", "layerwise_depthwise", "layerwise_conv_2d", "event_median", "speech", "fc4096_wzp"):
-            c.pop(k, None)
-        line = json.dumps(c, separators=(",", ":"))
-    assert len(line) < COMPACT_CAP, len(line)
-    return c, line
 
 
 def finish(ctx, result):
@@ -711,356 +484,6 @@ def headline_from_sub(args, rec, world):
            "vs_baseline": None, "dtype": "i8", "data": "synthetic", "config": rec["config"]}
     out.update({k: v for k, v in rec.items() if k not in out})
     return out
-
-
-def speech_record(ctx):
-    """BASELINE config 2: speech.tflite (TinyConv), batch 4096, device-resident int8 -> int8; plus the same model at
-    batch 65536 (the throughput regime: 4096 inferences are ONE 16-image step per CU, i.e. launch + latency)."""
-    mf, _lib, torch, synth_i8, SEED = ctx["mf"], ctx["_lib"], ctx["torch"], ctx["synth_i8"], ctx["SEED"]
-    from oracle import oracle as O
-    path = os.path.join(ROOT, "models", "speech.tflite")
-    L = _lib.lib()
-    om = O.Model(path)
-
-    def run(B, iters):
-        m = mf.model(path)
-        m.prepare(B, device=ctx["local_rank"])
-        _lib.check(L.mf_model_set_stream(m._h, torch.cuda.current_stream().cuda_stream))
-        x = synth_i8(SEED + 2, 0, B * m.input_elems)
-        y = torch.empty(B * m.output_elems, dtype=torch.int8, device="cuda")
-        step = lambda: _lib.check(L.mf_model_run_quantized(m._h, x.data_ptr(), B, y.data_ptr(), _lib.MF_MEM_DEVICE))  # noqa: E731
-        for _ in range(5):
-            step()
-        torch.cuda.synchronize()
-        ev = event_times(torch, step, iters)
-        ms = median(ev)
-        _, per_op = m.time_device(x, y, B, warmup=2, iters=20)
-        descs = [m.op(i) for i in range(m.num_ops)]
-        kernels = [{"op": i, "kernel": d["kernel"], "ms": round(per_op[i], 5)} for i, d in enumerate(descs)
-                   if d["kernel"] and not d["kernel"].startswith("(fused")]
-        idx = list(range(0, B, max(1, B // 16) + 1))
-        ok = bool(np.array_equal(y.reshape(B, -1)[idx].cpu().numpy(), om.run_quantized_batch(x.reshape(B, -1)[idx].cpu().numpy())))
-        return m, ms, len(ev), kernels, ok, len(idx)
-
-    B = 4096
-    m, ms, nev, kernels, ok, nidx = run(B, 50)
-    # one launch (k_dwfc.hip): the depthwise taps run on the matrix pipe, what is left on the VALU is the
-    # requantisation of the 4000 depthwise outputs per inference -> the same ceiling as the fused person_detect kernels
-    one = next((k for k in kernels if k["kernel"].startswith("dwc1_fc")), None)
-    nbytes = (m.input_elems + m.output_elems) * B  # model input + output: all the HBM traffic there is
-    rec = {"metric": "inferences/sec (int8) for speech.tflite", "value": round(B / (ms * 1e-3), 1), "value_batch": B, "unit": "inferences/s",
-           "ms_per_step": round(ms, 5), "config": {"workload": "speech.tflite batch=%d, predict_inner int8->int8" % B},
-           "kernels": kernels, "timing": "HIP events on the launch stream, median of %d steps" % nev,
-           "parity": {"bit_exact_vs_oracle": ok, "sampled_images": nidx}}
-    if one:
-        B2 = 65536
-        _m2, ms2, nev2, k2, ok2, nidx2 = run(B2, 20)
-        rq = 4000.0 * B2 / (ms2 * 1e-3) / 1e9
-        rec["roofline"] = {"bound": "valu", "kernel": one["kernel"], "batch": B2, "ms": round(ms2, 5),
-                           "achieved": round(rq, 1), "peak": REQUANT_PEAK_GBS, "unit": "GB/s of requantised int8",
-                           "frac": round(rq / REQUANT_PEAK_GBS, 4),
-                           "note": "measured at batch %d (16 steps per workgroup); at batch %d every CU runs ONE 16-image "
-                                   "step, so that time is launch + one load/compute latency chain, not a rate" % (B2, B),
-                           "hbm_GBps": round((m.input_elems + m.output_elems) * B2 / (ms2 * 1e-3) / 1e9, 1),
-                           "hbm_frac": round((m.input_elems + m.output_elems) * B2 / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
-        rec["batch_%d" % B2] = {"value": round(B2 / (ms2 * 1e-3), 1), "unit": "inferences/s", "ms_per_step": round(ms2, 5),
-                                "kernels": k2, "parity": {"bit_exact_vs_oracle": ok2, "sampled_images": nidx2}}
-    else:  # operator-by-operator kernels (MF_NO_DWFC): the depthwise conv is 320 000 MAC / inference on v_dot4
-        dw = next((k for k in kernels if k["kernel"].startswith("dw_c1")), kernels[0])
-        tmacs = 320000.0 * B / (dw["ms"] * 1e-3) / 1e12 if dw["ms"] > 0 else 0.0
-        rec["roofline"] = {"bound": "valu", "kernel": dw["kernel"], "achieved": round(tmacs, 2), "peak": DOT4_PEAK_TMACS,
-                           "unit": "TMAC/s", "frac": round(tmacs / DOT4_PEAK_TMACS, 4), "ms": dw["ms"],
-                           "note": "54 MAC per input byte: bounded by the v_dot4_i32_i8 issue rate (measured, scripts/ubench)"}
-    rec["roofline"]["hbm_GBps_batch_%d" % B] = round(nbytes / (ms * 1e-3) / 1e9, 1)
-    return rec
-
-
-def fc4096_record(ctx, steps, warmup, wzp=0):
-    """BASELINE config 5: FullyConnected 4096x4096x4096 through the model API: one step = one predict_inner
-    over a [4096, 4096] int8 input (one dense int8 GEMM + fused requantize epilogue; with a non-zero weight
-    zero point also the row-sum pre-pass of src/ops/fully_connected.rs:60-72)."""
-    mf, _lib, torch = ctx["mf"], ctx["_lib"], ctx["torch"]
-    from tools.make_fc_model import synthetic_fc
-    from oracle import oracle as O
-    M = K = N = 4096
-    blob = synthetic_fc(M, K, N, wzp=wzp, seed=5)
-    m = mf.model(blob)
-    m.prepare(1, device=ctx["local_rank"])
-    L = _lib.lib()
-    _lib.check(L.mf_model_set_stream(m._h, torch.cuda.current_stream().cuda_stream))
-    g = torch.Generator(device="cuda").manual_seed(1234 + ctx["rank"])
-    x = torch.randint(-128, 128, (M, K), dtype=torch.int8, device="cuda", generator=g)  # random operands
-    y = torch.empty(M * N, dtype=torch.int8, device="cuda")
-    step = lambda: _lib.check(L.mf_model_run_quantized(m._h, x.data_ptr(), 1, y.data_ptr(), _lib.MF_MEM_DEVICE))  # noqa: E731
-    for _ in range(warmup):
-        step()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    ev = event_times(torch, step, max(20, steps))
-    ms = median(ev)
-    ops = 2.0 * M * K * N
-    tops = ops / (ms * 1e-3) / 1e12
-    rows = sorted(set([0, 777, 4095] + list(range(5, M, 131))))[:40]
-    om = O.Model(synthetic_fc(len(rows), K, N, wzp=wzp, seed=5))
-    want = om.run_quantized(x[rows].cpu().numpy()).reshape(len(rows), N)
-    ok = bool(np.array_equal(y.reshape(M, N)[rows].cpu().numpy(), want))
-    crosscheck = None
-    if wzp == 0:
-        w_nk = torch.from_numpy(np.random.default_rng(5).integers(-128, 128, (N, K), dtype=np.int8)).cuda()  # = synthetic_fc's W
-        crosscheck = int8_gemm_crosscheck(torch, x, w_nk)
-        del w_nk
-    return {
-        "crosscheck": crosscheck,
-        "metric": "int8 GEMM TOP/s, FullyConnected 4096x4096x4096 via predict_inner",
-        "value": round(ops / (elapsed / steps) / 1e12, 1), "unit": "TOP/s",
-        "steps": steps, "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 4),
-        "config": {"workload": "FullyConnected int8 M=K=N=4096 (generated single-op .tflite), weight zero point %d, "
-                               "uniform random int8 operands" % wzp},
-        "roofline": {"bound": "mfma", "kernel": m.op(0)["kernel"], "achieved": round(tops, 1),
-                     "peak": INT8_MFMA_PEAK_NOMINAL, "unit": "TOP/s", "frac": round(tops / INT8_MFMA_PEAK_NOMINAL, 4),
-                     "peak_guide_floor": INT8_MFMA_PEAK_GUIDE_FLOOR,
-                     "frac_of_guide_floor": round(tops / INT8_MFMA_PEAK_GUIDE_FLOOR, 4),
-                     "traffic": pmc_traffic("fc_mfma", None)[0], "traffic_src": pmc_traffic("fc_mfma", None)[1],
-                     "algorithmic_bytes": M * K + N * K + M * N,
-                     "ms": round(ms, 4), "algorithmic_ops": ops,
-                     "method": "HIP events on the launch stream, median of %d steps (whole predict_inner: GEMM"
-                               "%s)" % (len(ev), " + row-sum pre-pass" if wzp else ""),
-                     "peak_note": "5033 = 2 x the ~2.5 PF dense bf16 MFMA peak (nominal); 3944 = the guide's measured "
-                                  "int8 floor (MI355X_MICROARCH.md)"},
-        "parity": {"bit_exact_vs_oracle": ok, "sampled_rows": len(rows)},
-    }
-
-
-def int8_gemm_crosscheck(torch, x, w_nk, iters=20):
-    """What does a vendor int8 GEMM sustain on this chip on the SAME random operands?  (SURVEY.md 7 allows the BLAS
-    libraries as a cross-check; nothing here is linked into libmicroflow_amd.so.)  Tries torch._int_mm (hipBLASLt) and
-    rocBLAS gemm_ex through ctypes; int8 x int8 -> int32, NT layout like the FullyConnected kernel (both K-contiguous)."""
-    M, K = x.shape
-    N = w_nk.shape[0]
-    ops = 2.0 * M * K * N
-    out = {"operands": "the step's own x [%d,%d] and W [%d,%d] (uniform random int8)" % (M, K, N, K), "results": {}}
-    rows = [0, 1, M // 2, M - 1]
-    want = x[rows].cpu().numpy().astype(np.int32) @ w_nk.cpu().numpy().astype(np.int32).T
-
-    def timed(fn):
-        for _ in range(3):
-            fn()
-        torch.cuda.synchronize()
-        return median(event_times(torch, fn, iters))
-
-    try:
-        wt = w_nk.t()  # [K, N] view, column-major = W's own memory
-        c = torch._int_mm(x, wt)
-        ok = bool(np.array_equal(c[rows].cpu().numpy(), want))
-        ms = timed(lambda: torch._int_mm(x, wt))
-        out["results"]["torch._int_mm"] = {"ms": round(ms, 4), "TOPs": round(ops / (ms * 1e-3) / 1e12, 1), "correct": ok,
-                                           "epilogue": "none (int32 out, 4x the output bytes of the fused kernel)"}
-    except Exception as e:  # noqa: BLE001
-        out["results"]["torch._int_mm"] = {"error": str(e)[:200]}
-    try:
-        import ctypes
-        rb = ctypes.CDLL("librocblas.so")
-        h = ctypes.c_void_p()
-        assert rb.rocblas_create_handle(ctypes.byref(h)) == 0
-        rb.rocblas_set_stream(h, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
-        c32 = torch.empty((M, N), dtype=torch.int32, device="cuda")
-        alpha, beta = ctypes.c_int32(1), ctypes.c_int32(0)
-        I8, I32, OP_N, OP_T = 160, 162, 111, 112  # rocblas_datatype_i8_r / i32_r, rocblas_operation_none / transpose
-        # column-major C^T [N, M] = W [N, K] (as A^T of a K x N column-major matrix) * X^T: A = W memory (K x N, lda K,
-        # transposed), B = X memory (K x M, ldb K, not transposed), C memory = row-major [M, N]
-        def gemm():
-            return rb.rocblas_gemm_ex(h, OP_T, OP_N, N, M, K, ctypes.byref(alpha),
-                                      ctypes.c_void_p(w_nk.data_ptr()), I8, K, ctypes.c_void_p(x.data_ptr()), I8, K,
-                                      ctypes.byref(beta), ctypes.c_void_p(c32.data_ptr()), I32, N,
-                                      ctypes.c_void_p(c32.data_ptr()), I32, N, I32, 0, 0, 0)
-        st = gemm()
-        torch.cuda.synchronize()
-        if st != 0:
-            raise RuntimeError("rocblas_gemm_ex status %d" % st)
-        ok = bool(np.array_equal(c32[rows].cpu().numpy(), want))
-        ms = timed(gemm)
-        out["results"]["rocblas_gemm_ex"] = {"ms": round(ms, 4), "TOPs": round(ops / (ms * 1e-3) / 1e12, 1), "correct": ok,
-                                             "epilogue": "none (int32 out)"}
-        rb.rocblas_destroy_handle(h)
-    except Exception as e:  # noqa: BLE001
-        out["results"]["rocblas_gemm_ex"] = {"error": str(e)[:200]}
-    best = [v["TOPs"] for v in out["results"].values() if v.get("correct")]
-    out["best_TOPs"] = max(best) if best else None
-    return out
-
-
-def op_bytes_table(m, per_op, count):
-    """per launch: algorithmic bytes (unique in + out), GB/s -- for the layer-wise (one kernel per operator) sub-records"""
-    rows = []
-    for i in range(m.num_ops):
-        d = m.op(i)
-        if not d["kernel"] or d["kernel"].startswith("(fused") or per_op[i] <= 0:
-            continue
-        nbytes = (int(np.prod(d["in_shape"])) + d["out_elems"]) * count
-        rows.append({"op": i, "kind": d["name"], "kernel": d["kernel"], "ms": round(per_op[i], 4), "bytes": nbytes,
-                     "GBps": round(nbytes / (per_op[i] * 1e-3) / 1e9, 1)})
-    return rows
-
-
-def kind_agg(rows, kind):
-    ks = [k for k in rows if k["kind"] == kind]
-    ms, by = sum(k["ms"] for k in ks), sum(k["bytes"] for k in ks)
-    return {"kernels": len(ks), "ms": round(ms, 4), "GBps": round(by / (ms * 1e-3) / 1e9, 1) if ms > 0 else 0.0,
-            "frac": round(by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ms > 0 else 0.0}
-
-
-def runtime_geometry_record(ctx, table_layerwise):
-    """Shapes outside person_detect's tables (the reference compiles for any shape: src/ops/depthwise_conv_2d.rs:28-49):
-    (1) person_detect itself with the table kernels switched off (MF_NO_TABLE=1, a subprocess because routing is decided
-    when an operator is created) against the table kernels' layer-wise numbers of this run -- same shapes, like for like;
-    (2) generated person_detect-shaped models at other input sizes / widths (tools/tflite_writer.person_detect_like)."""
-    mf, _lib, torch, synth_i8, SEED = ctx["mf"], ctx["_lib"], ctx["torch"], ctx["synth_i8"], ctx["SEED"]
-    rec = {"note": "run-time-geometry kernels (k_rt.hip: dw3x3_rt, pw_rt, conv_rows_lds); GB/s = algorithmic bytes / median launch time"}
-    try:
-        out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "time_kernels.py"), "20", "layerwise", "--json"],
-                             env=dict(os.environ, MF_DEV="1", MF_NO_TABLE="1"), capture_output=True, text=True, timeout=300)
-        j = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
-        tab = {k["op"]: k for k in table_layerwise}
-        rows = []
-        for k in j["kernels"]:
-            t = tab.get(k["op"])
-            if t and k["kernel"] != t["kernel"]:
-                rows.append({"op": k["op"], "kind": t["kind"], "kernel": k["kernel"], "ms": round(k["ms"], 4), "bytes": t["bytes"],
-                             "GBps": round(t["bytes"] / (k["ms"] * 1e-3) / 1e9, 1), "table_kernel": t["kernel"], "table_ms": t["ms"],
-                             "slowdown": round(k["ms"] / t["ms"], 3) if t["ms"] > 0 else None})
-        cmp_ = {"layerwise_ms": round(j["ms_per_step"], 4), "kernels": rows}
-        for kind in ("depthwise_conv_2d", "conv_2d"):
-            ks = [r for r in rows if r["kind"] == kind]
-            if ks:
-                ms, tms, by = sum(r["ms"] for r in ks), sum(r["table_ms"] for r in ks), sum(r["bytes"] for r in ks)
-                cmp_[kind] = {"kernels": len(ks), "ms": round(ms, 4), "GBps": round(by / (ms * 1e-3) / 1e9, 1), "table_ms": round(tms, 4),
-                              "table_GBps": round(by / (tms * 1e-3) / 1e9, 1), "slowdown": round(ms / tms, 3)}
-        rec["person_detect_without_tables"] = cmp_
-    except Exception as e:  # noqa: BLE001
-        rec["person_detect_without_tables"] = {"error": str(e)[:300]}
-    sys.path.insert(0, os.path.join(ROOT, "tools"))
-    import tflite_writer as tw
-    from oracle import oracle as O
-    L = _lib.lib()
-    models = {}
-    for side, width in ((128, 1.0), (64, 1.0), (96, 0.5)):
-        blob = tw.person_detect_like(np.random.default_rng(side), side, width)
-        m, om = mf.Model(blob, autotune=True), O.Model(blob)  # (opt-in: the chain candidates are timed at creation, mf_model_set_autotune)
-        B = int(65536 * 96 * 96 / (side * side))
-        m.prepare(B, device=ctx["local_rank"])
-        _lib.check(L.mf_model_set_stream(m._h, torch.cuda.current_stream().cuda_stream))
-        x = synth_i8(SEED + 6, 0, B * m.input_elems)
-        y = torch.empty(B * m.output_elems, dtype=torch.int8, device="cuda")
-        fused_ms, _ = m.time_device(x, y, B, warmup=2, iters=10, per_op=False)
-        fused_kernels = sorted({m.op(i)["kernel"].split("<")[0] for i in range(m.num_ops) if m.op(i)["kernel"] and not m.op(i)["kernel"].startswith("(fused")})
-        chains = [m.op(i)["kernel"] for i in range(m.num_ops) if m.op(i)["kernel"].startswith("chain_rt<")]
-        idx = [0, 1, B // 2, B - 1]
-        ok = bool(np.array_equal(y.reshape(B, -1)[idx].cpu().numpy(), om.run_quantized_batch(x.reshape(B, -1)[idx].cpu().numpy())))
-        m.set_fusion(False)
-        lw_ms, per = m.time_device(x, y, B, warmup=1, iters=10)
-        rows = op_bytes_table(m, per, B)
-        generic = [r["kernel"] for r in rows if r["kernel"].endswith("_generic")]
-        models["%dx%d_width%s" % (side, side, width)] = {
-            "batch": B, "value": round(B / (fused_ms * 1e-3), 1), "unit": "inferences/s", "ms_per_step": round(fused_ms, 4),
-            "layerwise_ms": round(lw_ms, 4), "depthwise": kind_agg(rows, "depthwise_conv_2d"), "conv_2d": kind_agg(rows, "conv_2d"),
-            "kernels_used": fused_kernels, "chains": chains, "layerwise_kernels": sorted({r["kernel"].split("<")[0] for r in rows}),
-            "speedup_vs_layerwise": round(lw_ms / fused_ms, 3), "generic_kernels": generic,
-            "parity": {"bit_exact_vs_oracle": ok, "sampled_images": len(idx)}}
-        del m, x, y
-        torch.cuda.empty_cache()
-    rec["generated_models"] = models
-    return rec
-
-
-def general_conv_record(ctx):
-    """Conv2D beyond 1x1 (src/ops/conv_2d.rs:28-108 is generic in filter size): a colour MobileNet stem (3x3x3 -> 16, stride 2,
-    batch 65536: conv_rows_lds), a ResNet-8-style 3x3 block (16 -> 16 on 32x32: conv_mm_rt, the MFMA product over
-    K = KH KW C) and a 64 -> 64 one on 8x8, each against the shape-generic kernel on a slice of its batch."""
-    mf, torch = ctx["mf"], ctx["torch"]
-    from oracle import oracle as O
-    rng = np.random.default_rng(3)
-    out = {}
-    for name, (H, W, C, N, K, S, B) in {"stem_96x96x3_to_16_s2": (96, 96, 3, 16, 3, 2, 65536), "block_32x32x16_to_16": (32, 32, 16, 16, 3, 1, 16384),
-                                        "block_8x8x64_to_64": (8, 8, 64, 64, 3, 1, 65536)}.items():
-        OH, OW = -(-H // S), -(-W // S)
-        f = rng.integers(-128, 128, (N, K, K, C)).astype(np.int8)
-        c0 = rng.uniform(-30, 30, N).astype(np.float32)
-        c1 = (rng.uniform(0.5, 1.5, N) * 40.0 / (5476.0 * np.sqrt(K * K * C))).astype(np.float32)
-        opts = mf.ops.Conv2DOptions(mf.FusedActivation(3), mf.TensorViewPadding.SAME, (S, S))
-        op = mf.ops.prepare_conv_2d((H, W, C), f, np.zeros(N, np.int8), -128, 0.0235294122, -128, opts, (c0, c1), (OH, OW))
-        x = torch.randint(-128, 128, (B, H, W, C), dtype=torch.int8, device="cuda")
-        y = op(x)
-        ms = median(event_times(torch, lambda: op(x), 12))
-        idx = [0, B // 2, B - 1]
-        want = np.stack([O.conv_2d(x[i].cpu().numpy(), f, np.zeros(N, np.int8), -128, 0.0235294122, -128, 3, 0, (S, S), (OH, OW), c0, c1) for i in idx])
-        ok = bool(np.array_equal(y[idx].cpu().numpy(), want))
-        kernel = op.kernel
-        nb = min(B, 512)
-        op.set_generic(True)
-        gms = median(event_times(torch, lambda: op(x[:nb]), 3)) * (B / nb)
-        nbytes, macs = B * (H * W * C + OH * OW * N), float(B) * OH * OW * N * K * K * C
-        out[name] = {"kernel": kernel, "batch": B, "ms": round(ms, 4), "GBps": round(nbytes / (ms * 1e-3) / 1e9, 1),
-                     "hbm_frac": round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "TMACps": round(macs / (ms * 1e-3) / 1e12, 2),
-                     "generic_ms_scaled": round(gms, 2), "speedup_vs_generic": round(gms / ms, 1), "bit_exact_vs_oracle": ok}
-        del x, y
-        torch.cuda.empty_cache()
-    return out
-
-
-def general_depthwise_record(ctx):
-    """DepthwiseConv2D beyond 3x3 SAME (src/ops/depthwise_conv_2d.rs:28-49 is generic in filter, stride and padding): a 5x5 stride-1 layer
-    on 24x24x32 and a 3x3 VALID one, both conv_mm_rt's depthwise mode (taps of a 16-channel group on the matrix pipe), each against the
-    shape-generic kernel on a slice of its batch."""
-    mf, torch = ctx["mf"], ctx["torch"]
-    from oracle import oracle as O
-    rng = np.random.default_rng(4)
-    out = {}
-    for name, (H, W, C, KH, KW, S, pad, B) in {"dw5x5_24x24x32_s1": (24, 24, 32, 5, 5, 1, 0, 65536), "dw3x3_valid_24x24x64": (24, 24, 64, 3, 3, 1, 1, 32768)}.items():
-        OH, OW = (-(-H // S), -(-W // S)) if pad == 0 else ((H - KH) // S + 1, (W - KW) // S + 1)
-        w = rng.integers(-128, 128, (KH, KW, C)).astype(np.int8)
-        c0 = rng.uniform(-30, 30, C).astype(np.float32)
-        c1 = (rng.uniform(0.5, 1.5, C) * 40.0 / (5476.0 * np.sqrt(KH * KW))).astype(np.float32)
-        opts = mf.ops.DepthwiseConv2DOptions(mf.FusedActivation(3), mf.TensorViewPadding(pad), (S, S))
-        op = mf.ops.prepare_depthwise_conv_2d((H, W, C), w, np.zeros(C, np.int8), -128, 0.0235294122, -128, opts, (c0, c1), (OH, OW))
-        x = torch.randint(-128, 128, (B, H, W, C), dtype=torch.int8, device="cuda")
-        y = op(x)
-        ms = median(event_times(torch, lambda: op(x), 12))
-        idx = [0, B // 2, B - 1]
-        want = np.stack([O.depthwise_conv_2d(x[i].cpu().numpy(), w, np.zeros(C, np.int8), -128, 0.0235294122, -128, 3, pad, (S, S), (OH, OW), c0, c1)
-                         for i in idx])
-        ok = bool(np.array_equal(y[idx].cpu().numpy(), want))
-        kernel = op.kernel
-        nb = min(B, 512)
-        op.set_generic(True)
-        gms = median(event_times(torch, lambda: op(x[:nb]), 3)) * (B / nb)
-        nbytes = B * (H * W * C + OH * OW * C)
-        out[name] = {"kernel": kernel, "batch": B, "ms": round(ms, 4), "GBps": round(nbytes / (ms * 1e-3) / 1e9, 1),
-                     "hbm_frac": round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                     "generic_ms_scaled": round(gms, 2), "speedup_vs_generic": round(gms / ms, 1), "bit_exact_vs_oracle": ok}
-        del x, y
-        torch.cuda.empty_cache()
-    return out
-
-
-def generic_fallback_record(ctx, m, x, count, fast_ms):
-    """The cliff: person_detect on the byte-wise shape-generic kernels (mf_model_set_generic), on a slice of the batch."""
-    torch = ctx["torch"]
-    n = min(count, 2048)
-    y = torch.empty(n * m.output_elems, dtype=torch.int8, device="cuda")
-    m.set_generic(True)
-    try:
-        ms, _ = m.time_device(x[: n * m.input_elems], y, n, warmup=1, iters=3, per_op=False)
-    finally:
-        m.set_generic(False)
-    fast, _ = m.time_device(x[: n * m.input_elems], y, n, warmup=2, iters=10, per_op=False)
-    return {"batch": n, "ms_per_step": round(ms, 3), "value": round(n / (ms * 1e-3), 1), "unit": "inferences/s",
-            "fast_path_ms_same_batch": round(fast, 4), "slowdown": round(ms / fast, 1),
-            "note": "every operator on its `*_generic` kernel (one thread per output element, byte loads): what a shape with "
-                    "no fast kernel costs; the fused step of the full batch takes %.3f ms" % fast_ms}
 
 
 def cpu_baseline(om, x_dev_rows, seconds):

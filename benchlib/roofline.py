@@ -1,0 +1,172 @@
+"""Peaks, the requantisation ceiling of this run, replayed counter figures, HIP-event timing (bench.py's helpers)."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 achievable)
+# int8 MFMA peaks (TOP/s, dense).  The guide gives no spec figure for int8: "I8 >= 3944 TOPS (16x16x64,
+# ~2x the bf16 rate)" is its measured floor; 5033 = 2 x the ~2.5 PF dense bf16 peak is the nominal figure.
+INT8_MFMA_PEAK_NOMINAL = 5033.0
+INT8_MFMA_PEAK_GUIDE_FLOOR = 3944.0
+# v_dot4_i32_i8 issue rate measured on this chip (scripts/ubench/inst_rates.hip): 0.55 T wave-inst/s
+# x 64 lanes x 4 MAC = 140.8 TMAC/s -- the ceiling of a dot4-bound kernel (speech's depthwise)
+DOT4_PEAK_TMACS = 140.8
+# The reference's f32 requantisation (two individually rounded operations, roundf, clamp, `as T`) costs 5.75 - 6 VALU
+# instructions per output byte in its shortest exact form (k_common.hpp).  Its ceiling on this chip with nothing else in
+# the loop is MEASURED in every run, outside the timed region, by scripts/ubench/epi_rate.hip (libepi_rate.so, built by
+# __graft_entry__.build(); it executes the library's own requant_pack4): ns per 256-byte wave group per SIMD ->
+# GB/s of requantised bytes over the 1024 SIMDs.  A kernel that keeps its intermediate tensors on chip (the late-stage
+# kernel) is bounded by this, not by HBM.  The literal below is only the fallback when the ubench cannot run
+# (profiles/r03: 39.8 ns -> 6 590 GB/s for the saturating-pack form person_detect's operators use).
+
+
+# The reference's f32 requantisation (two individually rounded operations, roundf, clamp, `as T`) costs 5.75 - 6 VALU
+# instructions per output byte in its shortest exact form (k_common.hpp).  Its ceiling on this chip with nothing else in
+# the loop is MEASURED in every run, outside the timed region, by scripts/ubench/epi_rate.hip (libepi_rate.so, built by
+# __graft_entry__.build(); it executes the library's own requant_pack4): ns per 256-byte wave group per SIMD ->
+# GB/s of requantised bytes over the 1024 SIMDs.  A kernel that keeps its intermediate tensors on chip (the late-stage
+# kernel) is bounded by this, not by HBM.  The literal below is only the fallback when the ubench cannot run
+# (profiles/r03: 39.8 ns -> 6 590 GB/s for the saturating-pack form person_detect's operators use).
+REQUANT_PEAK_GBS = 6590.0
+
+
+REQUANT_CEILING = None  # filled by measure_requant_ceiling()
+
+
+def measure_requant_ceiling():
+    """Run the requantisation microbenchmark on the current device (a few hundred ms) and make its result the ceiling
+    every `valu_frac` / `requant_frac` of this run is priced against."""
+    global REQUANT_PEAK_GBS, REQUANT_CEILING
+    import ctypes
+    rec = {"source": "scripts/ubench/epi_rate.hip (libepi_rate.so), measured in this run outside the timed region",
+           "unit": "GB/s of requantised int8 over 1024 SIMDs", "loop_overhead": "one v_add per value is part of the loop",
+           "forms": {}}
+    try:
+        lib = ctypes.CDLL(os.path.join(ROOT, "scripts", "ubench", "libepi_rate.so"))
+        lib.mf_ubench_requant_ns.restype = ctypes.c_double
+        lib.mf_ubench_requant_ns.argtypes = [ctypes.c_int]
+        # a ceiling is the BEST rate the chip sustains: three repetitions per form, the fastest counts (a repetition that meets
+        # a power-management transient would otherwise understate it)
+        for name, v in (("mode3_single_fma", 8), ("mode2_saturating_pack", 5), ("mode1_med3", 4), ("round2_form", 1)):
+            reps = [lib.mf_ubench_requant_ns(v) for _ in range(3)]  # each: 1 warm-up + 5 timed launches of ~2.6 ms
+            reps = [r for r in reps if r > 0]
+            if reps:
+                ns = min(reps)
+                rec["forms"][name] = {"ns_per_256B_wave_group_per_simd": round(ns, 2), "GBps": round(1024 * 256 / ns, 1),
+                                      "repetitions_ns": [round(r, 2) for r in reps]}
+        if "mode2_saturating_pack" in rec["forms"]:
+            got = rec["forms"]["mode2_saturating_pack"]["GBps"]
+            # Observed once in round 4 (profiles/r04/f_slow_ubench_box.txt): a box whose pure-VALU microbenchmark ran at
+            # 0.73 of every other box's rate while the kernels ran at 0.97 of theirs -- the "ceiling" then sits BELOW what the
+            # kernels reach.  A measurement under 0.85 of the reference figure is reported but not used: the fractions are then priced
+            # against the reference literals (profiles/r03/epi_rate.txt: 6 590 / 6 310 / 5 970 GB/s), and the record says so.
+            if got >= 0.85 * REQUANT_PEAK_GBS:
+                REQUANT_PEAK_GBS = got
+                rec["used"] = "mode2_saturating_pack (measured in this run)"
+            else:
+                rec["used"] = "reference literals: the in-run measurement (%.0f GB/s) is below 0.85 of the reference %.0f GB/s" % (got, REQUANT_PEAK_GBS)
+                rec["suspect"] = True
+                rec["forms_measured"] = rec["forms"]
+                rec["forms"] = {"mode2_saturating_pack": {"GBps": 6590.0}, "mode1_med3": {"GBps": 6310.0}, "round2_form": {"GBps": 5970.0}}
+    except OSError as e:
+        rec["error"] = "libepi_rate.so not loadable (%s): literal fallback" % e
+    rec["GBps"] = REQUANT_PEAK_GBS
+    REQUANT_CEILING = rec
+    return rec
+
+
+def requant_peak(mode):
+    """the measured requantisation ceiling (GB/s) of the epilogue form a launch runs (k_common.hpp modes 0 / 1 / 2)"""
+    forms = (REQUANT_CEILING or {}).get("forms", {})
+    name = {3: "mode3_single_fma", 2: "mode2_saturating_pack", 1: "mode1_med3", 0: "round2_form"}.get(mode, "mode2_saturating_pack")
+    if mode == 3 and name not in forms:  # no measurement of the single-fma form in this run: its fractions are not computed
+        return None
+    return forms.get(name, {}).get("GBps", REQUANT_PEAK_GBS)
+
+
+def source_sha16():
+    """sha256 (first 16 hex digits) over the kernel sources: what a committed counter profile is tagged with, so that a
+    replayed figure says whether it belongs to the kernels of THIS build"""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "microflow_rs_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".hpp", ".cpp")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def rocprof_name(kernel, mode, u8=False):
+    """the name (prefix) rocprofv3 prints for a launch of the library's kernel `kernel` -- the key into
+    profiles/*kernel_stats.csv; the library's own names spell the fused shapes out, the compiler's the template arguments"""
+    xr = "0u" if (mode == 3 or not u8) else "2155905152u"
+    sp = lambda t: ", ".join(x.strip() for x in t.split(","))  # noqa: E731
+    if kernel.startswith("penta_rr<"):
+        return "mf::k::quad_rr<mf::k::Quad13, true, %d, %s>" % (mode, xr)
+    if kernel.startswith("quad_rr<48,"):
+        return "mf::k::quad_rr<mf::k::Quad13, false, %d, %s>" % (mode, xr)
+    if kernel.startswith("quad_rr<24,"):
+        return "mf::k::quad_rr<mf::k::Quad57, false, %d, %s>" % (mode, xr)
+    if kernel.startswith("stage_6x6x128<"):
+        return "mf::k::stage_6x6x128<4, 512, %d, %s>" % (mode, xr)
+    if "<" in kernel:  # dwpw_mm<H,W,C,S,N,G,T,D>, pair3_tail<H,W,C,S>, pw_mfma<K,N>, ...: the leading template arguments are the same
+        base, args = kernel.split("<", 1)
+        lead = args.rstrip(">").split(",")
+        lead = lead[:7] if base.startswith(("dwpw_", "dw3x3_mm")) else lead
+        return "mf::k::%s<%s" % (base.replace("dw3x3_mm", "dwpw_mm"), sp(",".join(lead)))
+    return "mf::k::" + kernel
+
+
+def sq_counters(kernel):
+    """Independent of the microbenchmark: per-kernel figures from the committed rocprofv3 SQ counter passes of this same
+    command (profiles/sq_latest.json = scripts/pmc_summary.py --sq).  Reported as measured -- VALU wave-instructions per SIMD
+    clock -- without a normaliser: the issue ceiling depends on the instruction mix (full-rate v_fma / v_add against the
+    0.6-rate conversions), so a single "busy" fraction would under- or over-read."""
+    try:
+        sq = json.load(open(os.path.join(ROOT, "profiles", "sq_latest.json")))
+        k = sq["kernels"].get(kernel)  # exact name only: a different template instance or an older kernel is not this one
+        if k:
+            stale = sq.get("source_sha16") != source_sha16()
+            return {"valu_inst_per_clk_per_simd": k["valu_inst_per_clk_per_simd"],
+                    "lds_bank_conflict_ratio": k["lds_bank_conflict_ratio"], "wait_any_frac": k.get("wait_any_frac"),
+                    "source": "committed profiles/sq_latest.json (a separate rocprofv3 --pmc pass, NOT measured in this run)%s"
+                              % (": STALE -- collected on other kernel sources" if stale else ""), "stale": stale}
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
+
+
+def pmc_traffic(kernel, count):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/pmc_traffic_latest.json =
+    scripts/pmc_summary.py over separate --pmc FETCH_SIZE / WRITE_SIZE passes of this same command)."""
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")))
+        if count is None or pmc.get("per_gpu_batch") == count:
+            for k in pmc["kernels"]:
+                if k["kernel"] == kernel or (kernel == "fc_mfma" and k["kernel"].startswith("fc_mfma<")):
+                    stale = pmc.get("source_sha16") != source_sha16()
+                    return k["traffic_bytes"], ("committed profiles/pmc_traffic_latest.json (separate rocprofv3 --pmc passes, NOT "
+                                                "measured in this run)" + (": STALE -- collected on other kernel sources" if stale else ""))
+    except (OSError, ValueError, KeyError):
+        pass
+    return None, None
+
+
+def median(xs):
+    xs = sorted(xs)
+    n = len(xs)
+    return xs[n // 2] if n % 2 else 0.5 * (xs[n // 2 - 1] + xs[n // 2])
+
+
+def event_times(torch, step, iters):
+    """per-iteration durations (ms) of `step` from HIP event pairs on the current (= launch) stream"""
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    for a, b in evs:
+        a.record()
+        step()
+        b.record()
+    torch.cuda.synchronize()
+    return [a.elapsed_time(b) for a, b in evs]

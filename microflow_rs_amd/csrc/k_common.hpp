@@ -1,7 +1,7 @@
 // k_common.hpp -- what every kernel family of libmicroflow_amd shares (gfx950 / CDNA4 only).
 //
 // The kernels live in one file per family -- k_generic.hip, k_depthwise.hip, k_pointwise.hip,
-// k_fused.hip, k_gemm.hip -- each citing the upstream file:line it implements.  All of them
+// k_fused_mm.hip, k_gemm.hip, ... -- each citing the upstream file:line it implements.  All of them
 // share one arithmetic contract:
 //
 //   acc (i32)  = sum over ALL window taps of (v' - izp) * (w - wzp)

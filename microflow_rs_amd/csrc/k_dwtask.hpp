@@ -1,5 +1,5 @@
 // k_dwtask.hpp -- the per-lane depthwise 3x3 tasks (stride 1 and stride 2) shared by the layer-wise
-// depthwise kernel (k_depthwise.hip) and the fused depthwise + pointwise kernel (k_fused.hip).
+// depthwise kernel (k_depthwise.hip) and the run-time-geometry depthwise kernel (k_rt.hip).
 // (src/ops/depthwise_conv_2d.rs:50-104)
 #pragma once
 #include "k_common.hpp"

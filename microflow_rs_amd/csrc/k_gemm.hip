@@ -150,9 +150,20 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 // a wave feeds the matrix pipe are the rows whose sums are needed, so wave (wm, wn) adds up ITS share of them (row block
 // mt == wn: the WN waves of a wave row hold the same X fragments) with v_dot4 against ones, issued between the MFMAs
 // (the VALU is idle there); the sums meet in LDS after the last k step.  No row-sum pre-pass, no extra launch.
-template <int BM, int BN, int WM, int WN, bool STAGGER, bool RS>
+// RSP: the same term from row sums formed in this launch's PROLOGUE instead of a pre-pass launch (the pre-pass costs 6 - 8 % of a
+// 4096^3 step for a 16 MB read: a kernel boundary and a launch that cannot fill the chip).  The tiles_n workgroups of a tile row each
+// sum 256 / tiles_n of its rows while their first k tile's DMAs fly, publish them with system-scope stores and count themselves in
+// rs_sync[2 tm]; ~60 us later the epilogue polls that counter -- bounded: a workgroup that does not see it complete (the grid was not
+// co-resident: nothing else guarantees that the producers have even started) sums its tile's rows itself -- and the last reader of
+// a tile row zeroes the pair of counters for the next launch.  The operand X is read-only for the launch, so the fallback needs no
+// synchronisation at all.
+#ifndef MF_FC_RSP_POLLS
+#define MF_FC_RSP_POLLS 256
+#endif
+template <int BM, int BN, int WM, int WN, bool STAGGER, bool RS, bool RSP = false>
 __global__ __launch_bounds__(64 * WM * WN) void fc_mfma(const int8_t *__restrict__ X,
                                                         int8_t *__restrict__ Y, FcGemmArgs p) {
+    static_assert(!(RS && RSP), "one way of forming the row sums");
     constexpr int BK = 128;
     constexpr int NW = WM * WN;                              // waves per workgroup
     constexpr int MT = BM / WM / 32, NT = BN / WN / 32;      // 32x32 MFMA tiles per wave
@@ -241,15 +252,93 @@ __global__ __launch_bounds__(64 * WM * WN) void fc_mfma(const int8_t *__restrict
     };
 
     const int nk = K / BK;
+    // RSP: sum_k x[m][k] of `nrows` rows from `row0` on (rows past the matrix: skipped), one wave per row, into dst (device memory
+    // with system-scope stores, or LDS)
+    auto rowsums = [&](int row0, int nrows, int *dst, bool to_lds) {
+        for (int r = wave; r < nrows; r += NW) {
+            const int m = row0 + r;
+            if (m >= p.M) continue;
+            const uint4 *x = (const uint4 *)(X + (size_t)m * K);
+            int acc = 0;
+            for (int k = lane; k < (K >> 4); k += 64) {
+                const uint4 v = x[k];
+                acc = sdot4(v.x, 0x01010101u, acc), acc = sdot4(v.y, 0x01010101u, acc);
+                acc = sdot4(v.z, 0x01010101u, acc), acc = sdot4(v.w, 0x01010101u, acc);
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+            if (lane == 0) {
+                if (to_lds) dst[m - row0] = acc;
+                else __hip_atomic_store(dst + m, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    };
+    // The prologue form of it, split so that nothing of it is on the critical path: the loads are issued in FRONT of the first k
+    // tile's DMAs (rs_issue: up to 8 x 16 bytes per lane in registers) and return under the same wait the first tile needs anyway;
+    // the sums are formed and stored behind that wait (rs_store); the count that publishes them is taken one k tile later, behind
+    // that tile's own vmcnt(0) + barrier, when every wave's stores have been acknowledged (rs_count).  Shapes with more than 8
+    // loads per lane, or a single k tile, do all three at once up front (rs_sync_all).
+    constexpr int RSV = 8;
+    const int rpt = RSP ? BM / tiles_n : 0;             // rows of this tile row that this workgroup sums (launcher: tiles_n divides BM)
+    const int rs_rows = (rpt + NW - 1) / NW, rs_chunks = (K / 16 + 63) / 64;
+    const bool rs_split = RSP && rs_rows * rs_chunks <= RSV && nk > 1;
+    uint4 rsv[RSV];
+    auto rs_issue = [&]() {
+        if constexpr (RSP) {
+            if (!rs_split) return;
+#pragma unroll
+            for (int i = 0; i < RSV; ++i) {
+                const int r = wave + NW * (i / rs_chunks), c = (i % rs_chunks) * 64 + lane, m = tm * BM + tn * rpt + r;
+                rsv[i] = make_uint4(0u, 0u, 0u, 0u);
+                if (i < rs_rows * rs_chunks && r < rpt && m < p.M && c < (K >> 4)) rsv[i] = ((const uint4 *)(X + (size_t)m * K))[c];
+            }
+        }
+    };
+    auto rs_store = [&]() {
+        if constexpr (RSP) {
+            if (!rs_split) return;
+            for (int j = 0; j < rs_rows; ++j) {
+                int acc = 0;
+#pragma unroll
+                for (int i = 0; i < RSV; ++i)
+                    if (i / rs_chunks == j) {
+                        acc = sdot4(rsv[i].x, 0x01010101u, acc), acc = sdot4(rsv[i].y, 0x01010101u, acc);
+                        acc = sdot4(rsv[i].z, 0x01010101u, acc), acc = sdot4(rsv[i].w, 0x01010101u, acc);
+                    }
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+                const int r = wave + NW * j, m = tm * BM + tn * rpt + r;
+                if (lane == 0 && r < rpt && m < p.M) __hip_atomic_store(p.rs_sums + m, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    };
+    auto rs_count = [&]() {
+        if constexpr (RSP) {
+            if (tid == 0) __hip_atomic_fetch_add(p.rs_sync + 2 * tm, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    };
+    auto rs_sync_all = [&]() { // (after stage(0, ..): the first k tile's DMAs fly under the reads)
+        if constexpr (RSP) {
+            if (rs_split) return;
+            rowsums(tm * BM + tn * rpt, rpt, p.rs_sums, false);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's sums have left
+            __syncthreads();
+            rs_count();
+        }
+    };
     int rs = 0; // RS: this lane's share of sum_k x[row][k], row = row block wn of wave row wm, fragment row rho
     if constexpr (!STAGGER) {
         // lockstep loop: the DMAs of step t+1 fly during the MFMAs of step t; one vmcnt(0) +
         // barrier per step
         int cur = 0;
+        rs_issue();
         stage(0, 0);
+        rs_sync_all();
         for (int kt = 0; kt < nk; ++kt, cur ^= 1) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (RSP && rs_split && kt == 0) rs_store();
             __syncthreads();
+            if (RSP && rs_split && kt == 1) rs_count(); // (every wave has waited for its stores: the vmcnt(0) above)
             if (kt + 1 < nk) stage(kt + 1, cur ^ 1);
             const uint8_t *lb = lds + cur * BUF;
 #pragma unroll
@@ -309,8 +398,11 @@ __global__ __launch_bounds__(64 * WM * WN) void fc_mfma(const int8_t *__restrict
                 dma16(Wt + (size_t)row * K + (size_t)kt * BK + ((s8 ^ key(row)) << 4), lds + buf * BUF + XT + i * 1024);
             }
         };
+        rs_issue();
         stage(0, 0);
+        rs_sync_all();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        rs_store();
         __syncthreads();
         if (wm == 1) __builtin_amdgcn_s_barrier(); // the stagger
         int cur = 0;
@@ -327,6 +419,10 @@ __global__ __launch_bounds__(64 * WM * WN) void fc_mfma(const int8_t *__restrict
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                // (RSP: behind tile 0's second barrier every wave -- either wave row: they run one barrier apart, and this is row 1's
+                // turn one barrier later -- has waited for its row-sum stores with the vmcnt(0) above: wave row 1's lane 0 counts)
+                if (RSP && rs_split && kt == 0 && ph == 1 && wave == NW - 1 && lane == 0)
+                    __hip_atomic_fetch_add(p.rs_sync + 2 * tm, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 __builtin_amdgcn_sched_barrier(0);
                 v4i bs[2] = {b[0][0], b[1][0]};
                 if constexpr (RS) {
@@ -370,6 +466,35 @@ __global__ __launch_bounds__(64 * WM * WN) void fc_mfma(const int8_t *__restrict
         if (half == 0) ((int *)lds)[wm * (BM / WM) + wn * 32 + rho] = rs;
         __syncthreads();
     }
+    if constexpr (RSP) {
+        // the tile row's sums: finished when all tiles_n workgroups of the row have counted themselves (they did so ~ a GEMM ago)
+        __syncthreads(); // every wave has passed its last fragment read: the staging buffers are free for the 256 sums
+        int *ls = (int *)lds, *flag = (int *)lds + BM;
+        if (tid == 0) {
+            int ok = 0;
+            for (int poll = 0; poll < MF_FC_RSP_POLLS && !ok; ++poll) {
+                ok = __hip_atomic_load(p.rs_sync + 2 * tm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >= tiles_n;
+                if (!ok) __builtin_amdgcn_s_sleep(32);
+            }
+            *flag = ok;
+        }
+        __syncthreads();
+        if (*flag) {
+            for (int r = tid; r < BM; r += 64 * NW) {
+                const int m = tm * BM + r;
+                ls[r] = m < p.M ? __hip_atomic_load(p.rs_sums + m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0;
+            }
+        } else {
+            rowsums(tm * BM, BM, ls, true); // (the producers never showed up: not co-resident -- sum the tile's rows here)
+        }
+        __syncthreads();
+        // the last reader of this tile row leaves the counters zero for the next launch (every workgroup of the row has produced by
+        // the time it reads: its own prologue precedes its epilogue)
+        if (tid == 0 && __hip_atomic_fetch_add(p.rs_sync + 2 * tm + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == tiles_n - 1) {
+            __hip_atomic_store(p.rs_sync + 2 * tm, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(p.rs_sync + 2 * tm + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
     // epilogue: lane (m column = lane & 31, half) holds n = tile + 16*half + r, r = 0..15
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
@@ -388,7 +513,7 @@ __global__ __launch_bounds__(64 * WM * WN) void fc_mfma(const int8_t *__restrict
             const int m = tm * BM + wm * (BM / WM) + mt * 32 + rho;
             if (m >= p.M) continue; // ragged last row tile
             int corr = 0; // x1 = wzp * row-sum of the input
-            if constexpr (RS) corr = p.wzp * ((const int *)lds)[wm * (BM / WM) + mt * 32 + rho];
+            if constexpr (RS || RSP) corr = p.wzp * ((const int *)lds)[wm * (BM / WM) + mt * 32 + rho];
             else if (p.rowsum) corr = p.wzp * p.rowsum[m];
             uint32_t d[4];
 #pragma unroll
@@ -445,13 +570,19 @@ bool fc_mfma_supported(size_t rows, int N, int K) {
 void launch_fc_rowsum(const int8_t *in, int *rowsum, size_t rows, int K, hipStream_t s) {
     hipLaunchKernelGGL(fc_rowsum, dim3(grid_for(rows, 4)), dim3(256), 0, s, in, rowsum, rows, K);
 }
-template <int BM, int BN, int WM, int WN, bool STAGGER, bool RS>
+template <int BM, int BN, int WM, int WN, bool STAGGER, bool RS, bool RSP = false>
 static void launch_fc_mfma_t(const int8_t *in, int8_t *out, const FcGemmArgs &a, hipStream_t s) {
     constexpr int lds = 2 * (BM + BN) * 128;
     static LaunchState st;
-    (void)prepared(st, fc_mfma<BM, BN, WM, WN, STAGGER, RS>, 64 * WM * WN, lds);
+    (void)prepared(st, fc_mfma<BM, BN, WM, WN, STAGGER, RS, RSP>, 64 * WM * WN, lds);
     const int grid = ((a.M + BM - 1) / BM) * (a.N / BN);
-    hipLaunchKernelGGL((fc_mfma<BM, BN, WM, WN, STAGGER, RS>), dim3(grid), dim3(64 * WM * WN), lds, s, in, out, a);
+    hipLaunchKernelGGL((fc_mfma<BM, BN, WM, WN, STAGGER, RS, RSP>), dim3(grid), dim3(64 * WM * WN), lds, s, in, out, a);
+}
+// the in-launch row sums: 256 x 256 tiles (the instance that fills the chip), a tile row's rows dealt evenly over its tiles
+bool fc_mfma_rowsum_prologue(size_t rows, int N) {
+    if (switches().fc_rowsum_fold || switches().fc_tile == 128 || switches().fc_rowsum_prepass) return false;
+    const int tiles_n = N / 256;
+    return N % 256 == 0 && tiles_n >= 1 && 256 % tiles_n == 0 && (size_t)((rows + 255) / 256) * (size_t)tiles_n >= 192;
 }
 // The weight zero point term needs sum_k x[m][k].  Default: the separate fc_rowsum launch in front of the GEMM.  MF_FC_ROWSUM_FOLD=1:
 // the RS instance forms the sums inside the GEMM (no extra launch, no row-sum buffer) -- measured 3-4 % SLOWER than the pre-pass
@@ -466,6 +597,10 @@ void launch_fc_mfma(const int8_t *in, int8_t *out, const FcGemmArgs &a, hipStrea
     // 256 x 256 tiles halve the L2 -> LDS traffic per MAC; they need >= 256 tiles to fill the chip
     const bool big = a.N % 256 == 0 && (size_t)((a.M + 255) / 256) * (a.N / 256) >= 192;
     const bool rs = a.wzp != 0 && !a.rowsum; // the weight zero point term from in-kernel row sums
+    if (a.rs_sums && a.rs_sync && a.wzp != 0) { // (the caller asked fc_mfma_rowsum_prologue first)
+        launch_fc_mfma_t<256, 256, 2, 4, true, false, true>(in, out, a, s);
+        return;
+    }
     if ((big && force != 128) || (force == 256 && a.N % 256 == 0)) {
         if (rs) launch_fc_mfma_t<256, 256, 2, 4, true, true>(in, out, a, s);
         else launch_fc_mfma_t<256, 256, 2, 4, true, false>(in, out, a, s);

@@ -1,4 +1,4 @@
-// k_tail.hpp -- the network tail of one inference, shared by the standalone tail kernel (k_fused.hip) and the
+// k_tail.hpp -- the network tail of one inference, shared by the standalone tail kernel (k_tail3.hip) and the
 // late-stage kernel (k_stage.hip): AveragePool2D whose output is 1x1 (src/ops/average_pool_2d.rs:29-66) ->
 // Conv2D 1x1 with N <= 8 outputs (src/ops/conv_2d.rs:28-108) -> [Reshape] -> Softmax over the N values
 // (src/ops/softmax.rs:15-27).  One wavefront per inference: lane l owns channels 4l..4l+3 (+256 per extra pass),

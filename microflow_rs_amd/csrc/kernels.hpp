@@ -1,4 +1,4 @@
-// kernels.hpp -- argument blocks and launchers of the HIP kernels (k_generic / k_depthwise / k_pointwise / k_fused / k_gemm .hip).
+// kernels.hpp -- argument blocks and launchers of the HIP kernels (k_*.hip).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stddef.h>
@@ -57,6 +57,11 @@ struct FcGemmArgs {
     const float *A;     // [N]
     const int *Kc;      // [N]
     const int *rowsum;  // [rows] sum_k x[row][k] from the fc_rowsum pre-pass, or nullptr: wzp == 0, or the GEMM forms the sums itself
+    // Row sums formed by the GEMM launch itself, in its prologue (k_gemm.hip fc_mfma<..., RSP>): every workgroup sums a slice of its
+    // tile row's rows into rs_sums, counts itself in rs_sync[2 tm] and reads the finished sums in its epilogue; rs_sync[2 tm + 1]
+    // counts the readers, and the last one zeroes the pair (no memset between launches).  nullptr: not this form.
+    int *rs_sums;       // [rows]
+    int *rs_sync;       // [2 x row tiles], zero between launches
     int wzp;
     float S;
     float lo_f, hi_f;
@@ -554,7 +559,9 @@ bool launch_fc_rowwave_softmax(const int8_t *in, int8_t *out, const FcArgs &a, c
 bool fc_mfma_supported(size_t rows, int N, int K);
 void launch_fc_rowsum(const int8_t *in, int *rowsum, size_t rows, int K, hipStream_t s);
 void launch_fc_mfma(const int8_t *in, int8_t *out, const FcGemmArgs &a, hipStream_t s);
-bool fc_mfma_rowsum_prepass(); // true (default): fc_rowsum runs in front of the GEMM; MF_FC_ROWSUM_FOLD=1: the GEMM forms the sums itself
+bool fc_mfma_rowsum_prepass();
+bool fc_mfma_rowsum_prologue(size_t rows, int N); // the in-launch row sums (fc_mfma<..., RSP>) take this shape
+bool fc_mfma_rowsum_prologue(size_t rows, int N); // the RSP instance takes this shape (256 x 256 tiles, tile columns dividing 256) // true (default): fc_rowsum runs in front of the GEMM; MF_FC_ROWSUM_FOLD=1: the GEMM forms the sums itself
 void launch_softmax(const int8_t *in, int8_t *out, const SoftmaxArgs &a, size_t batch, hipStream_t s);
 // number of float bit patterns (of all 2^32) whose quantised byte differs between quant_div's fast form and the true
 // division, for these parameters; synchronises the stream

@@ -43,7 +43,8 @@ struct Switches {
     int dwmm_alt = -1;             // MF_DWMM_ALT         ... of dwpw_mm
     int dwrr_alt = -1;             // MF_DWRR_ALT         ... of dwpw_rr
     int fc_tile = 0;               // MF_FC_TILE          force the FullyConnected tile (1..)
-    bool fc_rowsum_fold = false;   // MF_FC_ROWSUM_FOLD   fold the row sums into the GEMM prologue
+    bool fc_rowsum_fold = false;   // MF_FC_ROWSUM_FOLD   the row sums of a weight zero point from v_dot4 between the GEMM's MFMAs (round 4's form)
+    bool fc_rowsum_prepass = false;// MF_FC_ROWSUM_PREPASS  ... from the fc_rowsum launch in front of the GEMM (round 1's form), not the GEMM's own prologue
     long long pw_grid = 0;         // MF_PW_GRID          force the pointwise grid
     int pw_rt_ncap = 64;           // MF_PW_RT_NCAP       widest N the run-time pointwise kernel takes
     int dw_rt_threads = 0;         // MF_DW_RT_THREADS    force the run-time depthwise workgroup size

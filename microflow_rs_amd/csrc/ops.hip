@@ -91,7 +91,7 @@ struct OpImpl {
     std::string generic_name, fast_name;
     enum Fast { NONE, DW_NHWC, DW_STEM, DW_STEM_RT, DW_C1, PW_MFMA, FC_ROWWAVE, FC_MFMA, POOL_C4, CONV1X1_ROW, DW_RT, PW_RT, CONV_ROWS, CONV_MM } fast = NONE;
     int *d_rowsum = nullptr; // FC_MFMA with wzp != 0: per-row input sums
-    size_t rowsum_cap = 0;
+    size_t rowsum_cap = 0, rowsum_rows = 0; // (ints allocated; the row count the counter pairs currently sit behind)
     int8_t *d_ext = nullptr; // op_run_external on a u8 operator: input moved to the i8 domain
     size_t ext_cap = 0;
     // d_rowsum and d_ext are ONE scratch each per operator, while a handle may be launched on several streams: every use waits (on
@@ -1038,18 +1038,29 @@ void op_run(OpImpl *op, const int8_t *d_in, size_t batch, int8_t *d_out, void *s
             g.w = op->fc.w, g.A = op->fc.A, g.Kc = op->fc.Kc, g.wzp = op->fc.wzp, g.S = op->fc.S;
             g.lo_f = op->fc.lo_f, g.hi_f = op->fc.hi_f, g.M = (int)rows, g.N = sp.N, g.K = sp.K;
             g.xr4 = 0x01010101u * (uint32_t)op->fc.xr;
-            g.rowsum = nullptr;
-            const bool prepass = op->fc.wzp != 0 && k::fc_mfma_rowsum_prepass();
+            g.rowsum = nullptr, g.rs_sums = nullptr, g.rs_sync = nullptr;
+            // the weight-zero-point term needs sum_k x[m][k]: formed by the GEMM launch itself (its prologue) where the shape
+            // allows, else by a pre-pass launch; either way in the operator's one row-sum scratch (+ the row tiles' counter pairs
+            // behind it), whose uses the event handshake serialises across streams
+            const bool inlaunch = op->fc.wzp != 0 && k::fc_mfma_rowsum_prologue(rows, sp.N);
+            const bool prepass = op->fc.wzp != 0 && (inlaunch || k::fc_mfma_rowsum_prepass());
             if (prepass) {
-                op->scratch_acquire(s, op->rowsum_cap < rows);
-                if (op->rowsum_cap < rows) {
+                const size_t ntm = (rows + 255) / 256, need = rows + 2 * ntm;
+                op->scratch_acquire(s, op->rowsum_cap < need);
+                if (op->rowsum_cap < need) {
                     if (op->d_rowsum) (void)hipFree(op->d_rowsum);
                     op->d_rowsum = nullptr, op->rowsum_cap = 0;
-                    MF_HIP(hipMalloc((void **)&op->d_rowsum, rows * sizeof(int)));
-                    op->rowsum_cap = rows;
+                    MF_HIP(hipMalloc((void **)&op->d_rowsum, need * sizeof(int)));
+                    MF_HIP(hipMemset(op->d_rowsum, 0, need * sizeof(int))); // (the counter pairs start at zero and every launch leaves them so)
+                    op->rowsum_cap = need;
+                    op->rowsum_rows = 0;
                 }
-                k::launch_fc_rowsum(d_in, op->d_rowsum, rows, sp.K, s);
-                g.rowsum = op->d_rowsum;
+                if (inlaunch && op->rowsum_rows != rows) { // the counters sit behind the sums of THIS row count
+                    if (op->rowsum_rows) MF_HIP(hipMemsetAsync(op->d_rowsum, 0, op->rowsum_cap * sizeof(int), s));
+                    op->rowsum_rows = rows;
+                }
+                if (inlaunch) g.rs_sums = op->d_rowsum, g.rs_sync = op->d_rowsum + rows;
+                else k::launch_fc_rowsum(d_in, op->d_rowsum, rows, sp.K, s), g.rowsum = op->d_rowsum;
             }
             k::launch_fc_mfma(d_in, d_out, g, s);
             if (prepass) op->scratch_release(s);

@@ -46,6 +46,7 @@ Switches switches_parse() {
     s.dwrr_alt = (int)env_ll("MF_DWRR_ALT", -1);
     s.fc_tile = (int)env_ll("MF_FC_TILE", 0);
     s.fc_rowsum_fold = env_set("MF_FC_ROWSUM_FOLD");
+    s.fc_rowsum_prepass = env_set("MF_FC_ROWSUM_PREPASS");
     s.pw_grid = env_ll("MF_PW_GRID", 0);
     s.pw_rt_ncap = (int)env_ll("MF_PW_RT_NCAP", 64);
     s.dw_rt_threads = (int)env_ll("MF_DW_RT_THREADS", 0);

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Brute-force search of the LDS layouts of the matrix-pipe depthwise phase (dwpw_mm, k_fused.hip):
+"""Brute-force search of the LDS layouts of the matrix-pipe depthwise phase (dwpw_mm, k_fused_mm.hip):
    * tile-side chunk swizzle (applied on the DMA source address) for the tap reads (ds_read_b128),
    * MID-side chunk swizzle for the depthwise result writes (ds_write_b32) and the pointwise
      operand reads (ds_read_b128),

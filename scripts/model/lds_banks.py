@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """LDS bank-conflict model for gfx950 (MI355X_MICROARCH.md, LDS table) used to choose the tile / MID
-swizzles of the matrix-pipe depthwise phase (k_fused.hip).  Pure arithmetic, no GPU.
+swizzles of the matrix-pipe depthwise phase (k_fused_mm.hip).  Pure arithmetic, no GPU.
 
 cost(addresses of one wave instruction) = LDS-array cycles = sum over lane groups of the largest
 number of DISTINCT addresses that fall on one bank (identical addresses broadcast)."""

@@ -11,4 +11,6 @@ import torch  # noqa: E402
 import bench  # noqa: E402
 import microflow_rs_amd as mf  # noqa: E402
 
-print(json.dumps(bench.general_depthwise_record({"mf": mf, "torch": torch}), indent=1))
+from oracle import oracle as O  # noqa: E402
+
+print(json.dumps(bench.general_depthwise_record({"mf": mf, "torch": torch, "checker": O}), indent=1))
