@@ -241,6 +241,25 @@ def test_quads_equal_the_four_pair_launches(models, O, tmp_path):
         assert np.array_equal(np.asarray(m.run_until(x[2:3], last)).reshape(-1), layers[last].reshape(-1)), last
 
 
+def test_routing_switches_need_the_master_switch():
+    """A stray MF_NO_QUAD / MF_NO_TABLE / MF_NO_FMA_EPI in somebody's environment must not change which kernels the product runs:
+    without MF_DEV=1 the library ignores every routing and tuning variable (csrc/switches.cpp); with it, they act."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r); import microflow_rs_amd as mf; m = mf.model(%r); m.prepare(1); "
+            "print('KERNELS', [m.op(i)['kernel'] for i in (0, 5)], m.op_epilogue_mode(0))" % (root, model_path("person_detect")))
+    base = {k: v for k, v in os.environ.items() if not k.startswith("MF_")}
+    outs = {}
+    for tag, extra in (("plain", {}), ("stray", {"MF_NO_QUAD": "1", "MF_NO_TABLE": "1", "MF_NO_FMA_EPI": "1"}),
+                       ("dev", {"MF_DEV": "1", "MF_NO_QUAD": "1", "MF_NO_FMA_EPI": "1"})):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(base, **extra), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+        outs[tag] = [ln for ln in r.stdout.splitlines() if ln.startswith("KERNELS")][-1]
+    assert outs["stray"] == outs["plain"] and "penta_rr" in outs["plain"] and "quad_rr" in outs["plain"] and outs["plain"].endswith(" 3")
+    assert outs["dev"] != outs["plain"] and "quad_rr" not in outs["dev"] and "penta_rr" not in outs["dev"]
+
+
 def test_kernel_routing(models):
     """The fast HIP kernels are the ones that run for person_detect."""
     if ROUTING_SWITCHED:

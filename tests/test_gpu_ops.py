@@ -651,7 +651,11 @@ def test_models_without_saturating_pack():
 
 
 # ---- FullyConnected GEMM: every row, ragged row counts, both tiles --------------------------
-@pytest.mark.parametrize("M,K,N", [(4096, 4096, 4096), (4099, 1024, 512), (193, 256, 384), (64, 128, 128), (1000, 640, 768)])
+# (4096^3, 5000 x 4096 and 8192 x 8192 run the weight-zero-point term from row sums formed in the GEMM launch's own prologue --
+# fc_mfma<..., RSP> --; 8192 x 8192 is 1024 tiles = four residency waves, where an epilogue may find its producers not started
+# and sums its rows itself; the others use the fc_rowsum pre-pass launch)
+@pytest.mark.parametrize("M,K,N", [(4096, 4096, 4096), (4099, 1024, 512), (193, 256, 384), (64, 128, 128), (1000, 640, 768),
+                                   (5000, 384, 4096), (8192, 256, 8192)])
 def test_fc_mfma_equals_generic_kernel_on_every_row(mf, O, M, K, N):
     """The MFMA GEMM against the shape-generic FullyConnected kernel over the WHOLE output matrix (the oracle checks of
     the 4096^3 test sample 128 rows), including row counts that are not a multiple of the 128- / 256-row tile
@@ -681,10 +685,11 @@ def test_fc_mfma_equals_generic_kernel_on_every_row(mf, O, M, K, N):
     del guard
 
 
-def test_fc_mfma_row_sums_inside_the_gemm():
-    """MF_FC_ROWSUM_FOLD=1: the weight-zero-point term from row sums formed inside the GEMM (fc_mfma<..., RS>, both tile sizes,
-    ragged M) instead of the fc_rowsum pre-pass -- the whole output against the shape-generic kernel.  A child process: the switch
-    is read once per process."""
+@pytest.mark.parametrize("switch", ["MF_FC_ROWSUM_FOLD", "MF_FC_ROWSUM_PREPASS"])
+def test_fc_mfma_row_sums_inside_the_gemm(switch):
+    """The two other ways of forming the weight-zero-point term's row sums -- MF_FC_ROWSUM_FOLD=1: v_dot4 between the GEMM's MFMAs
+    (fc_mfma<..., RS>, both tile sizes, ragged M); MF_FC_ROWSUM_PREPASS=1: the fc_rowsum launch in front of the GEMM everywhere --
+    the whole output against the shape-generic kernel.  A child process: the switches are read once per process."""
     import subprocess
     import sys as _sys
     code = r'''
@@ -709,6 +714,6 @@ for M, K, N in ((4096, 2048, 4096), (1000, 640, 768), (193, 256, 384)):
     assert torch.equal(got, want), (M, K, N, int((got != want).sum()))
 print("FOLD_OK")
 ''' % ROOT
-    env = dict(os.environ, MF_DEV="1", MF_FC_ROWSUM_FOLD="1")
+    env = dict(os.environ, MF_DEV="1", **{switch: "1"})
     r = subprocess.run([_sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert r.returncode == 0 and "FOLD_OK" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
