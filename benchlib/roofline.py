@@ -20,15 +20,6 @@ DOT4_PEAK_TMACS = 140.8
 # GB/s of requantised bytes over the 1024 SIMDs.  A kernel that keeps its intermediate tensors on chip (the late-stage
 # kernel) is bounded by this, not by HBM.  The literal below is only the fallback when the ubench cannot run
 # (profiles/r03: 39.8 ns -> 6 590 GB/s for the saturating-pack form person_detect's operators use).
-
-
-# The reference's f32 requantisation (two individually rounded operations, roundf, clamp, `as T`) costs 5.75 - 6 VALU
-# instructions per output byte in its shortest exact form (k_common.hpp).  Its ceiling on this chip with nothing else in
-# the loop is MEASURED in every run, outside the timed region, by scripts/ubench/epi_rate.hip (libepi_rate.so, built by
-# __graft_entry__.build(); it executes the library's own requant_pack4): ns per 256-byte wave group per SIMD ->
-# GB/s of requantised bytes over the 1024 SIMDs.  A kernel that keeps its intermediate tensors on chip (the late-stage
-# kernel) is bounded by this, not by HBM.  The literal below is only the fallback when the ubench cannot run
-# (profiles/r03: 39.8 ns -> 6 590 GB/s for the saturating-pack form person_detect's operators use).
 REQUANT_PEAK_GBS = 6590.0
 
 

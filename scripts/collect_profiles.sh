@@ -20,7 +20,7 @@ cp gpurun_out/pytest_gpu.log $D/${P}_pytest_gpu.log
 python3 - <<PY
 import json, sys
 sys.path.insert(0, ".")
-import bench
+from benchlib import roofline as bench
 c = json.loads(open("$D/${P}_bench_line.json").read())
 print("value %.1f %s, %.4f ms/step (event median %.4f); dominant %s %.4f ms, frac %.4f" % (
     c["value"], c["unit"], c["ms_per_step"], c["whole_step"]["ms"], c["roofline"]["kernel"], c["roofline"]["ms"], c["roofline"]["frac"]))
