@@ -122,7 +122,7 @@ def sq_counters(kernel):
         if k:
             stale = sq.get("source_sha16") != source_sha16()
             return {"valu_inst_per_clk_per_simd": k["valu_inst_per_clk_per_simd"],
-                    "lds_bank_conflict_ratio": k["lds_bank_conflict_ratio"], "wait_any_frac": k.get("wait_any_frac"),
+                    "lds_bank_conflict_ratio": k["lds_bank_conflict_ratio"], "wait_any_frac": k.get("wait_any_frac"), "mfma_busy_frac": k.get("mfma_busy_frac"),
                     "source": "committed profiles/sq_latest.json (a separate rocprofv3 --pmc pass, NOT measured in this run)%s"
                               % (": STALE -- collected on other kernel sources" if stale else ""), "stale": stale}
     except (OSError, ValueError, KeyError):

@@ -619,6 +619,15 @@ __global__ __launch_bounds__(NTHR) void conv_mm_rt(const int8_t *__restrict__ in
 // which goes through a 256-byte per-wave LDS patch so that 16 lanes store a pixel's 16 bytes each.  (First versions, 24x24x32 5x5 at
 // batch 65 536: constants and stores per lane from / to device memory 1.08 TB/s; operand A per k step from LDS 1.58 TB/s.)
 // ------------------------------------------------------------------------
+// Knock-out timing experiments (WRONG results, never shipped): 1 conflict-free linear operand-B reads, 2 no HBM stores, 4 no
+// requantisation, 8 no staging after a workgroup's first step.  24x24x32 5x5 (profiles/r06/n_dwmm_layout_variants.txt): 1.00-1.03 ms ->
+// 0.88-0.91 / 0.86 / 0.95 / 0.88, all four 0.46: no single cost dominates -- a step is stage -> barrier -> compute -> barrier with
+// nothing overlapping inside a workgroup, occupancy (five workgroups per CU) is what hides it.  A channel-group planar tile
+// ([group][row][pixel] x 16 bytes, row pitch from a bank model: 4.9 modelled LDS cycles per tap read instead of 7.5) was built,
+// bit-exact and 10-16 % SLOWER: its staging is a 16-byte gather at stride C with W of 64 lanes active per instruction.
+#ifndef MF_DWMM_KO
+#define MF_DWMM_KO 0
+#endif
 int dw_mm_lds_bytes(const ConvMmArgs &a) {
     return a.G * a.TILE + 256 + a.KS * 16 + 64 + 3 * a.C * 4 + 4 * 256;
 }
@@ -675,7 +684,7 @@ __global__ __launch_bounds__(256) void dw_mm_rt(const int8_t *__restrict__ in, i
     for (int step = blockIdx.x; step < nsteps; step += gridDim.x) {
         const int band = step % NBANDS, ist = step / NBANDS;
         __syncthreads();                                 // the previous step's reads of the tile are done
-        stage(step, 0);
+        if (!(MF_DWMM_KO & 8) || step == (int)blockIdx.x) stage(step, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         const uint8_t *tile = lds;
@@ -709,23 +718,25 @@ __global__ __launch_bounds__(256) void dw_mm_rt(const int8_t *__restrict__ in, i
             const int gi = (int)(((float)pc + 0.5f) * inv_bp);
             const int rr = pc - gi * BH * OW;
             const int oyl = (int)(((float)rr + 0.5f) * inv_ow), ox = rr - oyl * OW;
-            const uint8_t *winb = tile + gi * TILE + (oyl * p.sh) * ROW + p.LP + (ox * p.sw - p.padl) * C + 16 * blk;
+            const uint8_t *winb = (MF_DWMM_KO & 1) ? tile + lane * 16 : tile + gi * TILE + (oyl * p.sh) * ROW + p.LP + (ox * p.sw - p.padl) * C + 16 * blk;
             v4i acc = {kc.x, kc.y, kc.z, kc.w};
             // a ring of RING operand-B registers: tap chunk ks + RING is fetched behind the MFMA of chunk ks (all of them at once cost
             // 28 registers at 5x5 -- one wave per SIMD of occupancy)
             constexpr int RING = KSMAX < 4 ? KSMAX : 4;
             v4i b[RING];
 #pragma unroll
-            for (int ks = 0; ks < RING; ++ks) b[ks] = *(const v4i *)(winb + toff[ks]);
+            for (int ks = 0; ks < RING; ++ks) b[ks] = *(const v4i *)(winb + ((MF_DWMM_KO & 1) ? ks * 1024 : toff[ks]));
 #pragma unroll
             for (int ks = 0; ks < KSMAX; ++ks) {
                 acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(wA[ks], b[ks % RING], acc, 0, 0, 0);
-                if (ks + RING < KSMAX) b[ks % RING] = *(const v4i *)(winb + toff[ks + RING]);
+                if (ks + RING < KSMAX) b[ks % RING] = *(const v4i *)(winb + ((MF_DWMM_KO & 1) ? (ks + RING) * 1024 : toff[ks + RING]));
             }
-            const uint32_t d = requant_pack4<MG, XR4>(acc[0], acc[1], acc[2], acc[3], cA, cS, p.lo_f, p.hi_f);
-            // 16 pixels x this group's 16 bytes through the wave's patch: lane l < 16 stores pixel l's 16 bytes
+            const uint32_t d = (MF_DWMM_KO & 4) ? (uint32_t)(acc[0] ^ acc[1] ^ acc[2] ^ acc[3])
+                                                : requant_pack4<MG, XR4>(acc[0], acc[1], acc[2], acc[3], cA, cS, p.lo_f, p.hi_f);
+            // 16 pixels x this group's 16 bytes through the wave's patch: lane l < 16 stores pixel l's 16 bytes.  (Collecting four chunks
+            // so that all 64 lanes store, and non-temporal stores: no faster / slower, profiles/r06/n2_dwmm_store_variants.txt.)
             *(uint32_t *)(patch + col * 16 + 4 * g) = d;
-            if (lane < 16 && chunk * 16 + lane < nlive) st_out_t<false>(obase + ((size_t)chunk * 16 + lane) * C + 16 * blk, *(const uint4 *)(patch + lane * 16));
+            if (lane < 16 && chunk * 16 + lane < nlive && (!(MF_DWMM_KO & 2) || d == 0x12345678u)) st_out_t<false>(obase + ((size_t)chunk * 16 + lane) * C + 16 * blk, *(const uint4 *)(patch + lane * 16));
         }
     }
 }

@@ -555,9 +555,15 @@ OpImpl *op_create(int device, const OpSpec &spec) {
             }
             if (ok) op->fma_patch = patch;
             if (ok) op->fma_ok = true, op->h_A3 = A3, op->h_S3 = S3, op->h_Kc3 = K3;
-            if (epi_dbg)
+            if (epi_dbg) {
                 fprintf(stderr, "[epi] single-fma form: %s%s\n", ok ? ("all channels, " + std::to_string(patch.n) + " patched").c_str() : "no: channel ",
                         ok ? "" : std::to_string(fail_c).c_str());
+                if (ok && patch.n) {
+                    fprintf(stderr, "[epi]   patched channels:");
+                    for (int e = 0; e < patch.n; ++e) fprintf(stderr, " %d", patch.ch[e]);
+                    fprintf(stderr, "\n");
+                }
+            }
         }
         k::ConvArgs &a = op->conv;
         a.H = s.H, a.W = s.W, a.C = s.C, a.N = s.N, a.KH = s.KH, a.KW = s.KW, a.sh = s.sh, a.sw = s.sw;

@@ -81,6 +81,11 @@ if [[ $STEPS == *sqpmc* ]]; then
   (cd /tmp && timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU_CVT GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$OLDPWD/$OUT/pmc_sq2" -- \
       python "$OLDPWD/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-host-fed > /dev/null 2> "$OLDPWD/$OUT/pmc_sq2.err")
   echo "sq2 pmc exit $?"
+  # third pass: how busy the matrix pipes are (what the launches whose matrix-pipe and VALU time add up are bounded by)
+  rm -rf $OUT/pmc_sq3
+  (cd /tmp && timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$OLDPWD/$OUT/pmc_sq3" -- \
+      python "$OLDPWD/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-host-fed --no-extra > /dev/null 2> "$OLDPWD/$OUT/pmc_sq3.err")
+  echo "sq3 pmc exit $?"
   python - <<'PY'
 import csv, glob, re
 from collections import defaultdict
@@ -99,7 +104,7 @@ with open("gpurun_out/sq_summary.csv", "w") as o:
 print(open("gpurun_out/sq_summary.csv").read())
 PY
   f=$(find $OUT/prof -name "*kernel_stats.csv" | head -1)
-  python scripts/pmc_summary.py --sq $OUT/pmc_sq $OUT/pmc_sq2 $f > $OUT/sq_latest.json
+  python scripts/pmc_summary.py --sq $OUT/pmc_sq $OUT/pmc_sq2 $OUT/pmc_sq3 $f > $OUT/sq_latest.json
   head -c 600 $OUT/sq_latest.json
 fi
 if [[ $STEPS == *fcprof* ]]; then

@@ -82,7 +82,10 @@ def sq_main(dirs, stats_csv):
         for f in sorted(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)):
             for r in csv.DictReader(open(f)):
                 if "mf::k::" in r["Kernel_Name"]:
-                    acc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+                    name = r["Counter_Name"]
+                    if name == "GRBM_GUI_ACTIVE" and d.rstrip("/").endswith("sq3"):
+                        name = "GRBM_GUI_ACTIVE_sq3"
+                    acc[short(r["Kernel_Name"])][name].append(float(r["Counter_Value"]))
     dur = {}
     if stats_csv:
         for r in csv.DictReader(open(stats_csv)):
@@ -90,7 +93,8 @@ def sq_main(dirs, stats_csv):
                 dur[short(r["Name"])] = float(r["AverageNs"])
     med = lambda v: sorted(v)[len(v) // 2] if v else 0.0  # noqa: E731
     out = {"note": "rocprofv3 --pmc SQ passes of bench.py (scripts/gpu_check.sh STEPS=sqpmc), median over launches; "
-                   "valu_inst_per_clk_per_simd = SQ_INSTS_VALU / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs)",
+                   "valu_inst_per_clk_per_simd = SQ_INSTS_VALU / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs); "
+                   "mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024): the share of the kernel's own cycles its matrix pipes were busy",
            "source_sha16": source_sha16(), "kernels": {}}
     for k in sorted(acc):
         c = {n: med(v) for n, v in acc[k].items()}
@@ -102,6 +106,11 @@ def sq_main(dirs, stats_csv):
              "lds_bank_conflict_ratio": round(c.get("SQ_LDS_BANK_CONFLICT", 0.0) / c["SQ_LDS_IDX_ACTIVE"], 4) if c.get("SQ_LDS_IDX_ACTIVE") else 0.0,
              "wait_any_frac": round(c.get("SQ_WAIT_ANY", 0.0) / c["SQ_WAVE_CYCLES"], 4) if c.get("SQ_WAVE_CYCLES") else None,
              "cycles_per_xcd": round(cyc)}
+        if c.get("SQ_VALU_MFMA_BUSY_CYCLES"):  # third pass (its own GRBM_GUI_ACTIVE: the passes are separate runs)
+            cyc3 = med(acc[k].get("GRBM_GUI_ACTIVE_sq3", [])) / 8.0 or cyc
+            e["mfma_busy_frac"] = round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / cyc3 / 1024.0, 4)
+            if c.get("SQ_INSTS_MFMA"):
+                e["mfma_busy_cycles_per_inst"] = round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / c["SQ_INSTS_MFMA"], 2)
         if k in dur and dur[k] > 0:  # (profiled cycles over the UNprofiled duration of the same command: indicative only)
             e["cycles_per_xcd_over_trace_duration_GHz"] = round(cyc / dur[k], 3)
         out["kernels"][k] = e

@@ -13,4 +13,9 @@ import microflow_rs_amd as mf  # noqa: E402
 
 from oracle import oracle as O  # noqa: E402
 
-print(json.dumps(bench.general_depthwise_record({"mf": mf, "torch": torch, "checker": O}), indent=1))
+rec = bench.general_depthwise_record({"mf": mf, "torch": torch, "checker": O})
+if "--line" in sys.argv:  # one line per run: the A/B form (scripts/variants.py run "python scripts/time_general_dw.py --line")
+    print(" | ".join("%s %s %.4f ms %.3f of HBM %s" % (k, v["kernel"], v["ms"], v["hbm_frac"], "exact" if v["bit_exact_vs_oracle"] else "WRONG")
+                     for k, v in rec.items()))
+else:
+    print(json.dumps(rec, indent=1))
