@@ -282,6 +282,7 @@ def main():
                     "requant_GBps": dom["requant_GBps"], "requant_peak_GBps": dom["requant_peak_GBps"], "epilogue_mode": dom["epilogue_mode"],
                     "valu_inst_per_clk_per_simd": (dom["sq"] or {}).get("valu_inst_per_clk_per_simd"),
                     "mfma_busy_frac": (dom["sq"] or {}).get("mfma_busy_frac"),
+                    "issue_busy_frac": (dom["sq"] or {}).get("issue_busy_frac"),
                     "sq_src": (dom["sq"] or {}).get("source"),
                     "algorithmic_bytes": dom["bytes"], "requant_bytes": dom["requant_bytes"],
                     "traffic": traffic, "traffic_src": traffic_src, "traffic_source": traffic_src,
@@ -292,7 +293,9 @@ def main():
                             "duration vs the 8 TB/s HBM peak; valu_frac: every int8 byte the launch requantises (on chip or "
                             "not) / its duration vs the ceiling, measured in this run, of the requantisation form the launch runs "
                             "(`epilogue_mode`, `requant_ceiling`, `requant_ceiling_src`); traffic, valu_inst_per_clk_per_simd and mfma_busy_frac (the "
-                            "share of the launch's cycles its matrix pipes were busy: this launch's matrix-pipe and VALU time add up, DESIGN 4.4f) are "
+                            "share of the launch's cycles its matrix pipes were busy) and issue_busy_frac (= mfma_busy_frac + 2.75 clocks x VALU instructions per "
+                            "clock: a SIMD's matrix pipe and VALU do not overlap for this instruction mix, scripts/ubench/mfma_valu_overlap.hip, "
+                            "so that sum is the share of the launch's cycles its SIMDs were issuing -- the roof this launch is under, DESIGN 4.4f) are "
                             "REPLAYED from committed counter passes (`traffic_src`, `sq_src` say which, and whether they are stale); "
                             "rocprof_name = the kernel's name in profiles/*kernel_stats.csv; "
                             "`bound` = the roof with the longer time floor"}

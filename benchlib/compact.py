@@ -40,7 +40,7 @@ def compact_record(full):
         c["config"]["shards"] = c["config"]["shards"][:8] + ["..."]
     c["roofline"] = _pick(full.get("roofline") or {}, (
         "bound", "binding_roof", "kernel", "rocprof_name", "ms", "achieved", "peak", "unit", "frac", "hbm_frac", "valu_frac", "traffic", "traffic_src",
-        "algorithmic_bytes", "requant_bytes", "requant_peak_GBps", "requant_ceiling_src", "epilogue_mode", "mfma_busy_frac", "method", "peak_guide_floor",
+        "algorithmic_bytes", "requant_bytes", "requant_peak_GBps", "requant_ceiling_src", "epilogue_mode", "mfma_busy_frac", "issue_busy_frac", "method", "peak_guide_floor",
         "frac_of_guide_floor", "algorithmic_ops"))
     # `bound` follows the contract's vocabulary ("hbm" | "mfma": the roof achieved / peak / frac are stated against); a record that
     # named the builder-defined requantisation roof there (rounds 3-4) keeps that in `binding_roof`

@@ -111,6 +111,14 @@ def rocprof_name(kernel, mode, u8=False):
     return "mf::k::" + kernel
 
 
+# Average issue cost of a VALU instruction in the fused kernels' epilogue mix (v_fma_f32 : v_cvt_pk_u8_f32 : v_xor = 4 : 4 : 1), in
+# SIMD clocks: scripts/ubench/mfma_valu_overlap.hip, VALU-only variant at three waves per SIMD -- 33 ns per 27 instructions
+# (profiles/r06/p_mfma_valu_overlap.txt) at the 2.2-2.3 GHz such a loop runs at.  The same microbenchmark shows that a SIMD's matrix
+# pipe and VALU do NOT overlap for this mix (full unit 65-67 ns = 0.92 x (matrix only 38.5 + VALU only 33.3)), so a launch's
+# "issue busy" share is the SUM of its matrix-pipe busy share and its VALU issue share.
+VALU_CLOCKS_PER_INST = 2.75
+
+
 def sq_counters(kernel):
     """Independent of the microbenchmark: per-kernel figures from the committed rocprofv3 SQ counter passes of this same
     command (profiles/sq_latest.json = scripts/pmc_summary.py --sq).  Reported as measured -- VALU wave-instructions per SIMD
@@ -119,9 +127,15 @@ def sq_counters(kernel):
     try:
         sq = json.load(open(os.path.join(ROOT, "profiles", "sq_latest.json")))
         k = sq["kernels"].get(kernel)  # exact name only: a different template instance or an older kernel is not this one
+        if k is None and kernel.startswith("stage_6x6x128<"):  # (the library's name ends in the run length, the profiler's in the epilogue mode)
+            head = ",".join(kernel.split(",")[:2]) + ","
+            k = next((v for n, v in sq["kernels"].items() if n.startswith(head)), None)
         if k:
             stale = sq.get("source_sha16") != source_sha16()
-            return {"valu_inst_per_clk_per_simd": k["valu_inst_per_clk_per_simd"],
+            busy = None
+            if k.get("mfma_busy_frac") is not None:
+                busy = round(k["mfma_busy_frac"] + VALU_CLOCKS_PER_INST * k["valu_inst_per_clk_per_simd"], 4)
+            return {"valu_inst_per_clk_per_simd": k["valu_inst_per_clk_per_simd"], "issue_busy_frac": busy,
                     "lds_bank_conflict_ratio": k["lds_bank_conflict_ratio"], "wait_any_frac": k.get("wait_any_frac"), "mfma_busy_frac": k.get("mfma_busy_frac"),
                     "source": "committed profiles/sq_latest.json (a separate rocprofv3 --pmc pass, NOT measured in this run)%s"
                               % (": STALE -- collected on other kernel sources" if stale else ""), "stale": stale}
