@@ -33,7 +33,7 @@ def compact_record(full):
     summaries of the other single-GPU BASELINE configs.  Everything else (per-kernel tables, layer-wise step, run-time
     geometry, generated models, general conv, requantisation forms, vendor cross-checks) stays in bench_details.json."""
     c = _pick(full, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-                     "vs_baseline", "dtype", "data", "error"))
+                     "vs_baseline", "dtype", "data", "error", "prewarm_steps"))
     cfg = full.get("config") or {}
     c["config"] = _pick(cfg, ("workload", "per_gpu_batch", "global_batch", "parallelism", "backend", "shards"))
     if len(c["config"].get("shards") or []) > 8:

@@ -28,6 +28,7 @@ def speech_record(ctx):
         x = synth_i8(SEED + 2, 0, B * m.input_elems)
         y = torch.empty(B * m.output_elems, dtype=torch.int8, device="cuda")
         step = lambda: _lib.check(L.mf_model_run_quantized(m._h, x.data_ptr(), B, y.data_ptr(), _lib.MF_MEM_DEVICE))  # noqa: E731
+        roofline.prewarm(torch, step)
         for _ in range(5):
             step()
         torch.cuda.synchronize()
@@ -91,6 +92,7 @@ def fc4096_record(ctx, steps, warmup, wzp=0):
     x = torch.randint(-128, 128, (M, K), dtype=torch.int8, device="cuda", generator=g)  # random operands
     y = torch.empty(M * N, dtype=torch.int8, device="cuda")
     step = lambda: _lib.check(L.mf_model_run_quantized(m._h, x.data_ptr(), 1, y.data_ptr(), _lib.MF_MEM_DEVICE))  # noqa: E731
+    roofline.prewarm(torch, step)  # (the device idled while the host built and verified the model: benchlib/roofline.py prewarm)
     for _ in range(warmup):
         step()
     torch.cuda.synchronize()
@@ -99,8 +101,10 @@ def fc4096_record(ctx, steps, warmup, wzp=0):
         step()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    ev = event_times(torch, step, max(20, steps))  # one event pair per step: each pair adds 3 - 7 us of packet processing to a 65 us launch
-    # the launch's average duration over a back-to-back region bracketed by ONE event pair on the launch stream: what the roofline uses
+    ev = event_times(torch, step, max(20, steps))
+    ms = median(ev)
+    # ... and the same launch inside ONE event pair per 20 back-to-back steps (a per-step event pair adds its own packet processing
+    # to a 65 us launch): reported beside the per-step figure
     nreg = max(20, steps)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     regs = []
@@ -111,7 +115,6 @@ def fc4096_record(ctx, steps, warmup, wzp=0):
         e1.record()
         torch.cuda.synchronize()
         regs.append(e0.elapsed_time(e1) / nreg)
-    ms = median(regs)
     ops = 2.0 * M * K * N
     tops = ops / (ms * 1e-3) / 1e12
     rows = sorted(set([0, 777, 4095] + list(range(5, M, 131))))[:40]
@@ -136,11 +139,11 @@ def fc4096_record(ctx, steps, warmup, wzp=0):
                      "frac_of_guide_floor": round(tops / INT8_MFMA_PEAK_GUIDE_FLOOR, 4),
                      "traffic": pmc_traffic("fc_mfma", None)[0], "traffic_src": pmc_traffic("fc_mfma", None)[1],
                      "algorithmic_bytes": M * K + N * K + M * N,
-                     "ms": round(ms, 4), "ms_event_pair_per_step": round(median(ev), 4), "algorithmic_ops": ops,
-                     "method": "HIP events on the launch stream around %d back-to-back steps / %d, median of 3 regions (whole "
-                               "predict_inner: the GEMM launch%s); ms_event_pair_per_step = one event pair around every step, which "
-                               "adds its own packet processing to a 65 us launch"
-                               % (nreg, nreg, ", row sums formed in its prologue" if wzp else ""),
+                     "ms": round(ms, 4), "algorithmic_ops": ops,
+                     "region": {"ms_per_step": round(median(regs), 4), "TOPs": round(ops / (median(regs) * 1e-3) / 1e12, 1),
+                                "note": "3 regions of %d back-to-back steps, one event pair per region" % nreg},
+                     "method": "HIP events on the launch stream, median of %d steps (whole predict_inner: the GEMM launch"
+                               "%s)" % (len(ev), ", row sums formed in its prologue" if wzp else ""),
                      "peak_note": "5033 = 2 x the ~2.5 PF dense bf16 MFMA peak (nominal); 3944 = the guide's measured "
                                   "int8 floor (MI355X_MICROARCH.md)"},
         "parity": {"bit_exact_vs_oracle": ok, "sampled_rows": len(rows)},

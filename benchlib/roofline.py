@@ -160,6 +160,25 @@ def pmc_traffic(kernel, count):
     return None, None
 
 
+PREWARM_S = 0.06
+
+
+def prewarm(torch, step, seconds=PREWARM_S):
+    """Untimed launches of `step` for `seconds` of wall time, in front of a workload's own warm-up steps.  While the host prepares a
+    model (parsing, the epilogue search, its device verification) the device idles and its clock falls; the first 25 - 35 ms of launches
+    after that run 2 - 3 % slower (person_detect, same box: --warmup 5 -> 2.311 ms per step, --warmup 20 or 40 -> 2.258 = the
+    per-iteration event median taken afterwards; the 4096^3 GEMM: 75 us per step in the first 50 - 150 steps, 63 - 65 afterwards).
+    Returns the number of steps run."""
+    import time
+    t0, n = time.perf_counter(), 0
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(4):
+            step()
+        torch.cuda.synchronize()
+        n += 4
+    return n
+
+
 def median(xs):
     xs = sorted(xs)
     n = len(xs)

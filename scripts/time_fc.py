@@ -38,3 +38,15 @@ for n in (50, 200):
     t2 = time.perf_counter()
     print("n=%d host enqueue %.1f us/step, total %.1f us/step -> %.1f TOP/s  (%s)" % (
         n, (t1 - t0) / n * 1e6, (t2 - t0) / n * 1e6, 2.0 * M * K * N / ((t2 - t0) / n) / 1e12, m.op(0)["kernel"]))
+# the same steps inside ONE HIP event pair (round 6: does an event-bracketed region of n steps agree with the wall clock?)
+for n in (20, 20, 20, 200, 1000):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(n):
+        step()
+    e1.record()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    print("region n=%d: events %.1f us/step, wall %.1f us/step" % (n, e0.elapsed_time(e1) * 1e3 / n, (t2 - t0) / n * 1e6))
