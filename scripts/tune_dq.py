@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""GPU box: coordinate descent over the dynamic-step-queue configuration (k_common.hpp DynSteps) of each of the nine
-queue launches of the person_detect step, scored by the WHOLE step's time (per-launch times move with the chip's
+"""GPU box: coordinate descent over the dynamic-step-queue configuration (k_common.hpp DynSteps) of each of the
+queue launches of the person_detect step (round 6: six -- ops 0-4, 5-8, 9-10, 11-12, 13-22, 23-24; pair3_tail walks statically), scored by the WHOLE step's time (per-launch times move with the chip's
 power state, so a launch is only ever judged inside the real mix).  All candidates of a round are timed interleaved."""
 import os
 import sys
@@ -21,7 +21,7 @@ m = mf.model(os.path.join(ROOT, "models", "person_detect.tflite"))
 m.prepare(B, device=0)
 x = synth_i8(0x4D4643 + 3, 0, B * m.input_elems)
 y = torch.empty(B * m.output_elems, dtype=torch.int8, device="cuda")
-NQ = 9  # queue launches per pass: ops 0 1 3 5 7 9 11 13 23
+NQ = int(os.environ.get("TUNE_DQ_LAUNCHES", "6"))  # queue launches per pass (dq_config calls): ops 0 5 9 11 13 23
 
 
 def score(cfgs, reps=3):
