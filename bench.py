@@ -245,8 +245,8 @@ def main():
                 # the binding roof is the one that gives the longer time floor: HBM for the algorithmic bytes, or the
                 # VALU for the bytes that go through the reference's f32 requantisation
                 bound = "valu" if (peak and rq / peak > nbytes / HBM_PEAK_GBS) else "hbm"
-                if d["kernel"].startswith("quad_rr"):
-                    kind = "quad(2 pairs)"   # two depthwise+pointwise pairs in one launch (k_quad.hip)
+                if d["kernel"].startswith(("quad_rr", "quad_mm")):
+                    kind = "quad(2 pairs)"   # two depthwise+pointwise pairs in one launch (k_quad.hip, k_quad_mm.hip)
                 elif d["kernel"].startswith("penta_rr"):
                     kind = "penta(stem + 2 pairs)"   # ... with the network's first operator in front of them
                 elif nops_in_group > 3:

@@ -99,6 +99,8 @@ def rocprof_name(kernel, mode, u8=False):
         return "mf::k::quad_rr<mf::k::Quad13, true, %d, %s>" % (mode, xr)
     if kernel.startswith("quad_rr<48,"):
         return "mf::k::quad_rr<mf::k::Quad13, false, %d, %s>" % (mode, xr)
+    if kernel.startswith("quad_mm<"):
+        return "mf::k::quad_mm_12x12x64<%d, %s>" % (mode, xr)
     if kernel.startswith("quad_rr<24,"):
         return "mf::k::quad_rr<mf::k::Quad57, false, %d, %s>" % (mode, xr)
     if kernel.startswith("stage_6x6x128<"):

@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmicroflow_amd.so")
 SOURCES = ["capi.cpp", "hostmath.cpp", "epi_fma.cpp", "switches.cpp", "tflite.cpp", "model.cpp", "ops.hip", "k_generic.hip", "k_depthwise.hip",
-           "k_pointwise.hip", "k_fused_mm.hip", "k_stage.hip", "k_dwfc.hip", "k_tail3.hip", "k_gemm.hip", "k_rt.hip", "k_quad.hip", "k_chain.hip"]
+           "k_pointwise.hip", "k_fused_mm.hip", "k_stage.hip", "k_dwfc.hip", "k_tail3.hip", "k_gemm.hip", "k_rt.hip", "k_quad.hip", "k_quad_mm.hip", "k_chain.hip"]
 HEADERS = ["mf_internal.hpp", "mf_switches.hpp", "kernels.hpp", "k_common.hpp", "k_dwtask.hpp", "k_tail.hpp", os.path.join("..", "..", "include", "microflow_amd.h")]
 # -amdgpu-mfma-vgpr-form: MFMA results land in VGPRs (gfx950's register file is unified), which
 # removes one v_accvgpr_read per accumulator element from every fused epilogue.

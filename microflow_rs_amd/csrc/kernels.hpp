@@ -365,6 +365,10 @@ const char *quad_name(int H, int W, int C, int S, int N, int H2, int W2, int C2,
 const char *quad_stem_name(int SH, int SW, int H, int W, int C, int S, int N, int H2, int W2, int C2, int S2, int N2); // with a.stem set
 bool launch_quad(int H, int W, int C, int S, int N, int H2, int W2, int C2, int S2, int N2, const int8_t *in, int8_t *out, const QuadArgs &a,
                  int batch, hipStream_t s);
+// person_detect ops 9..12 -- the two C = 64 pairs, intermediate tensors through LDS (k_quad_mm.hip): QuadArgs' a / b blocks as dwpw_mm
+// takes them (dw.wmm, pw.wprep, the pairs' own patch tables)
+bool quad_mm_shape(int H, int W, int C, int S, int N, int H2, int W2, int C2, int S2, int N2);
+void launch_quad_mm(const int8_t *in, int8_t *out, const QuadArgs &a, int batch, hipStream_t s);
 bool launch_quad_f32(int H, int W, int C, int S, int N, int H2, int W2, int C2, int S2, int N2, const float *in, int8_t *out, const QuadArgs &a,
                      int batch, hipStream_t s);
 

@@ -1179,6 +1179,7 @@ struct FusedImpl {
     k::PairTailArgs pairtail{};
     // QUAD: two consecutive pairs in one kernel (k_quad.hip); a = the first pair's depthwise, b = the second pair's conv
     k::QuadArgs quad{};
+    bool quad_mm = false; // the C = 64 quad (k_quad_mm.hip): intermediate tensors through LDS, the pairs' dwpw_mm argument blocks
     int quad_shape[10] = {0};
     OpImpl *quad_ops[4] = {nullptr, nullptr, nullptr, nullptr}; // the two pairs' operators (the stem variant rebuilds the blocks from them)
     // CHAIN: 1 .. CHAIN_MAX consecutive pairs of any geometry in one launch (k_chain.hip); table and weights in stage_w
@@ -1892,6 +1893,22 @@ FusedImpl *fused_quad_create(FusedImpl *p1, FusedImpl *p2) {
     const OpSpec &d1 = p1->a->s, &q1 = p1->b->s, &d2 = p2->a->s, &q2 = p2->b->s;
     if (p1->a->device != p2->a->device || d1.u8 != d2.u8) return nullptr;
     if (d2.H != q1.H || d2.W != q1.W || d2.C != q1.N) return nullptr; // the second pair consumes the first pair's output
+    if (k::quad_mm_shape(d1.H, d1.W, d1.C, d1.sh, q1.N, d2.H, d2.W, d2.C, d2.sh, q2.N)) {
+        if (switches().no_quad_mm) return nullptr;
+        // the pairs' own blocks (dwpw_mm's: matrix-pipe depthwise weights, pw_mfma-layout pointwise weights, patch tables); one
+        // epilogue mode for the launch: the single-fma form if both pairs run it, else the two-rounding forms for both
+        k::DwPwArgs a = p1->dwpw, b = p2->dwpw;
+        if (pair_mode(a) != 3 || pair_mode(b) != 3) a = pair_args(p1->a, p1->b, 0), b = pair_args(p2->a, p2->b, 0);
+        if (!a.dw.wmm || !a.pw.wprep || !b.dw.wmm || !b.pw.wprep) return nullptr;
+        if (!a.dw.magic || !a.pw.magic || !b.dw.magic || !b.pw.magic) return nullptr; // bit-pattern epilogues
+        FusedImpl *f = new FusedImpl{FusedImpl::QUAD, p1->a, p2->b, nullptr, {}, {}, "quad_mm<12,12,64,1,64|12,12,64,2,128>"};
+        f->quad.a = a, f->quad.b = b, f->quad_mm = true;
+        f->epi_mode = std::min(pair_mode(a), pair_mode(b));
+        f->quad_ops[0] = p1->a, f->quad_ops[1] = p1->b, f->quad_ops[2] = p2->a, f->quad_ops[3] = p2->b;
+        const int shp[10] = {d1.H, d1.W, d1.C, d1.sh, q1.N, d2.H, d2.W, d2.C, d2.sh, q2.N};
+        for (int i = 0; i < 10; ++i) f->quad_shape[i] = shp[i];
+        return f;
+    }
     const char *nm = k::quad_name(d1.H, d1.W, d1.C, d1.sh, q1.N, d2.H, d2.W, d2.C, d2.sh, q2.N);
     if (!nm) return nullptr;
     // (the single-fma form needs it of all four operators)
@@ -1988,6 +2005,11 @@ void fused_run(FusedImpl *f, const int8_t *d_in, size_t batch, int8_t *d_out, vo
     if (f->kind == FusedImpl::QUAD) {
         if (batch > 0x7fffffffull / 4) fail(MF_ERR_INVALID_ARG, "batch too large for one launch");
         const int *q = f->quad_shape;
+        if (f->quad_mm) {
+            k::launch_quad_mm(d_in, d_out, f->quad, (int)batch, (hipStream_t)stream);
+            MF_HIP(hipGetLastError());
+            return;
+        }
         if (!k::launch_quad(q[0], q[1], q[2], q[3], q[4], q[5], q[6], q[7], q[8], q[9], d_in, d_out, f->quad, (int)batch, (hipStream_t)stream))
             fail(MF_ERR_UNSUPPORTED, "quad kernel missing");
         MF_HIP(hipGetLastError());

@@ -56,6 +56,8 @@ def short(name):
         args = "<" + ",".join(args.strip("<>").split(",")[: keep[base]]) + ">"
     if base == "dw_c1_lds":
         args = ""
+    if base == "quad_mm_12x12x64":  # (k_quad_mm.hip: template arguments = epilogue mode, element type)
+        return "quad_mm<12,12,64,1,64|12,12,64,2,128>"
     if base == "quad_rr":  # quad_rr<mf::k::Quad13, MG, XR4>: the library's name carries the two pair shapes
         which = "Quad13" if "Quad13" in name else "Quad57"
         if which == "Quad13" and re.search(r"Quad13,\s*(true|1)\b", name):  # the STEM instance: ops 0..4 in one launch

@@ -200,9 +200,10 @@ m = mf.model({root!r} + "/models/person_detect.tflite")
 x = synth_i8(3, 0, {n}, m.input_elems)
 m.prepare({n})
 names = [m.op(i)["kernel"] for i in range(m.num_ops)]
-assert not any(k.startswith(("quad_rr", "penta_rr")) for k in names), names
+assert not any(k.startswith(("quad_rr", "penta_rr", "quad_mm")) for k in names), names
 assert sum(k.startswith("dwpw_rr") for k in names) == 4, names
 np.save({out!r}, np.asarray(m.run_until(x, 8)))
+np.save({out!r} + ".12.npy", np.asarray(m.run_until(x, 12)))
 print("no-quad ok")
 """
 
@@ -232,6 +233,18 @@ def test_quads_equal_the_four_pair_launches(models, O, tmp_path):
                        text=True, timeout=600)
     assert r.returncode == 0 and "no-quad ok" in r.stdout, r.stdout + r.stderr
     assert np.array_equal(got, np.load(out).reshape(n, -1))
+    # ops 9..12 as one launch (k_quad_mm.hip: both C = 64 pairs, three tensors through LDS) against the two pair launches of the child
+    # process and the oracle; pieces that end inside it fall back to the pairs
+    if any(k.startswith("quad_mm") for k in names):
+        got12 = np.asarray(m.run_until(x, 12)).reshape(n, -1)
+        assert np.array_equal(got12, np.load(out + ".12.npy").reshape(n, -1))
+        for b in (0, 1, n - 1):
+            _, layers = om.run_quantized(x[b], layers=True)
+            assert np.array_equal(got12[b], layers[12].reshape(-1)), b
+            for last in (9, 10, 11):
+                assert np.array_equal(np.asarray(m.run_until(x[b:b + 1], last)).reshape(-1), layers[last].reshape(-1)), (b, last)
+        for k in (1, 3):
+            assert np.array_equal(np.asarray(m.run_until(x[:k], 12)).reshape(k, -1), got12[:k])
     # a single image and a batch smaller than the grid
     for k in (1, 5):
         assert np.array_equal(np.asarray(m.run_until(x[:k], 8)).reshape(k, -1), got[:k])
@@ -273,12 +286,15 @@ def test_kernel_routing(models):
     # the five 6x6x128 pairs (ops 13..22) are ONE persistent kernel (MF_NO_STAGE=1: not)
     # ops 1..4 and 5..8 are two "quads" (two pairs per launch, k_quad.hip; MF_NO_QUAD=1: four pair launches)
     quads = sum(n.startswith(("quad_rr", "penta_rr")) for n in names)
-    npairs = sum(n.startswith(("dwpw_rr", "dwpw_mm")) for n in names) + 2 * quads
+    quads_mm = sum(n.startswith("quad_mm") for n in names)   # ops 9..12 in one launch (k_quad_mm.hip; MF_NO_QUAD_MM=1 / MF_NO_QUAD=1: not)
+    npairs = sum(n.startswith(("dwpw_rr", "dwpw_mm")) for n in names) + 2 * (quads + quads_mm)
     pair_tail = not os.environ.get("MF_NO_PAIRTAIL")
     if not (os.environ.get("MF_NO_QUAD") or os.environ.get("MF_DWPW_IMPL")):
         assert quads == 2 and names[5].startswith("quad_rr<24,24,32"), names
         assert names[0].startswith("penta_rr<96,96,1,2,8|48,48,8") if penta else names[1].startswith("quad_rr<48,48,8"), names
         assert all(n.startswith("(fused") for n in names[2:5] + names[6:9]) and (not penta or names[1].startswith("(fused")), names
+        if not os.environ.get("MF_NO_QUAD_MM"):
+            assert quads_mm == 1 and names[9].startswith("quad_mm<12,12,64,1,64|12,12,64,2,128>") and all(n.startswith("(fused") for n in names[10:13]), names
         if not os.environ.get("MF_NO_PENTA"):
             assert penta, names
     if os.environ.get("MF_NO_STAGE"):

@@ -321,7 +321,7 @@ def test_u8_person_detect_uses_the_fast_kernels(mf, O):
         assert names[0].startswith(("dw3x3_stem8", "penta_rr")), names   # (penta_rr: the stem + ops 1..4 in one launch)
         npairs = sum(k.startswith(("dwpw_rr", "dwpw_mm", "dwpw3x3")) for k in names)
         npairs += 5 * sum(k.startswith("stage_6x6x128") for k in names) + sum(k.startswith("pair3_tail") for k in names)
-        npairs += 2 * sum(k.startswith(("quad_rr", "penta_rr")) for k in names)   # two pairs per quad launch (k_quad.hip)
+        npairs += 2 * sum(k.startswith(("quad_rr", "penta_rr", "quad_mm")) for k in names)   # two pairs per quad launch (k_quad.hip, k_quad_mm.hip)
         assert npairs == 13, names
         assert names[25].startswith("pair3_tail"), names
         assert names[13].startswith("stage_6x6x128"), names
