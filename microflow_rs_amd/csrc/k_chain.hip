@@ -153,7 +153,7 @@ __global__ __launch_bounds__(NW * 64, KSC == 4 ? 2 : (NW == 8 ? MF_CHAIN_WPE : 4
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
 #else
-        __syncthreads();
+        wg_sync();
 #endif
     };
     // A pair's record as the phases use it: plain registers.  SOLO: fetched ONCE before the step loop and laundered, so that the
@@ -455,7 +455,7 @@ __global__ __launch_bounds__(NW * 64, KSC == 4 ? 2 : (NW == 8 ? MF_CHAIN_WPE : 4
         }
     };
 
-    __syncthreads(); // halo fills and tables complete before any DMA lands
+    wg_sync(); // halo fills and tables complete before any DMA lands
     const int nsteps = (batch + G - 1) / G;
     PR cp = fetch_pair(0);
     // (with one k step the kernel sits on the 128-register limit of four waves per SIMD: four more registers are spills there --
@@ -497,7 +497,7 @@ __global__ __launch_bounds__(NW * 64, KSC == 4 ? 2 : (NW == 8 ? MF_CHAIN_WPE : 4
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
         MF_CTR(1);
-        __syncthreads(); // this step's images are in pair 0's tile; every wave has left the previous step's last phase
+        wg_sync(); // this step's images are in pair 0's tile; every wave has left the previous step's last phase
         MF_CTR(2);
         dq.top(tid);
         if constexpr (!SOLO) asm volatile("" : "+s"(pairs));

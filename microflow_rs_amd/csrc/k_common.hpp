@@ -43,6 +43,20 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // ------------------------------------------------------------------------
 // shared device helpers
 // ------------------------------------------------------------------------
+// The workgroup barrier of every kernel here -- NOT a bare __syncthreads().  __syncthreads() is fence(release) + s_barrier +
+// fence(acquire), and the `s_waitcnt lgkmcnt(0)` in front of s_barrier comes from the release fence as a SOFT wait: hipcc's
+// wait-count pass deletes it wherever its scoreboard shows no LDS operation pending.  At a loop header the pass first sees the
+// pre-header's state only, deletes the wait, and does not re-create it when the back edge then brings the previous iteration's
+// pending ds_writes (gfx950 backs off barriers, so the pass never forces a wait in front of one either).  Round 6: quad_mm's
+// barrier at the top of a step was reached with the B.pw stores of the step before still in flight, and the output copy behind
+// it read stale bytes in about one launch of twenty; every step-queue kernel had its `slot` store pending at the same place.
+// The explicit wait cannot be deleted.  scripts/asm_barrier_waits.py scans the listings for barriers reached with LDS operations
+// pending (tests/test_host_logic.py keeps it at zero outside the GEMM's counted-wait schedule).
+__device__ __forceinline__ void wg_sync() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+
 __device__ __forceinline__ int requant(int acc, float A, float S, float lo_f, float hi_f) {
     // (f32(ozp) + c0) + c1 * f32(acc): two roundings, like the reference (conv_2d.rs:93-98)
     const float x = __fadd_rn(A, __fmul_rn(S, (float)acc));

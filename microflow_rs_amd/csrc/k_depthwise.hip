@@ -83,7 +83,7 @@ __global__ __launch_bounds__(NTHR) void dw3x3_nhwc(const int8_t *__restrict__ in
     const int4 Kc = magic4<MG>(((const int4 *)p.Kc)[cg]);
     DynSteps dq;
     dq.init(lds + 2 * BUF + 256, p.queue, tid, p.qcfg); // (the launcher allocates 16 bytes behind the read slack)
-    __syncthreads(); // halo fill complete before any DMA lands
+    wg_sync(); // halo fill complete before any DMA lands
 
     auto stage = [&](int st, int buf) {
 #pragma unroll
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(NTHR) void dw3x3_nhwc(const int8_t *__restrict__ in
     for (; dq.step < nsteps; dq.advance(tid), cur ^= 1) {
         const int step = dq.step;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's DMAs (and old stores) done
-        __syncthreads();                                  // ... and everyone else's
+        wg_sync();                                  // ... and everyone else's
         dq.top(tid);
         const int next = dq.nxt;
         if (next < nsteps) stage(next, cur ^ 1);          // flies during the compute below
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256) void dw3x3_stem8(const int8_t *__restrict__ in
         ((uint4 *)lds)[i] = make_uint4(p.izp4, p.izp4, p.izp4, p.izp4);
     DynSteps dq;
     dq.init(lds + 2 * BUF, p.queue, tid, p.qcfg); // (16 bytes behind the two staging buffers)
-    __syncthreads();
+    wg_sync();
 
     auto stage = [&](int st, int buf) {
 #pragma unroll
@@ -243,7 +243,7 @@ __global__ __launch_bounds__(256) void dw3x3_stem8(const int8_t *__restrict__ in
     for (; dq.step < nsteps; dq.advance(tid), cur ^= 1) {
         const int step = dq.step;
         if constexpr (!F32IN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        wg_sync();
         dq.top(tid);
         const int next = dq.nxt;
         if constexpr (F32IN) {
@@ -361,7 +361,7 @@ __global__ __launch_bounds__(256) void dw3x3_stem8_mm(const int8_t *__restrict__
     const int img_g = wave / WPI, rp0 = (wave % WPI) * RPW;
     DynSteps dq;
     dq.init(lds + 2 * BUF, p.queue, tid, p.qcfg); // (16 bytes behind the two staging buffers)
-    __syncthreads();
+    wg_sync();
 
     auto stage = [&](int st, int buf) {
 #pragma unroll
@@ -417,7 +417,7 @@ __global__ __launch_bounds__(256) void dw3x3_stem8_mm(const int8_t *__restrict__
     for (; dq.step < nsteps; dq.advance(tid), cur ^= 1) {
         const int step = dq.step;
         if constexpr (!F32IN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        wg_sync();
         dq.top(tid);
         const int next = dq.nxt;
         if constexpr (F32IN) {
@@ -520,7 +520,7 @@ __global__ __launch_bounds__(512) void dw_c1_lds(const int8_t *__restrict__ in, 
         int8_t v[MAXE];
 #pragma unroll
         for (int e = 0; e < MAXE; ++e) v[e] = x[gofs[e] < 0 ? 0 : gofs[e]]; // clamped, unconditional
-        __syncthreads(); // previous image fully consumed
+        wg_sync(); // previous image fully consumed
 #pragma unroll
         for (int e = 0; e < MAXE; ++e)
             if (tid + 512 * e < TH * TWP) ((int8_t *)lds)[tid + 512 * e] = gofs[e] < 0 ? (int8_t)p.izp : v[e];
@@ -530,7 +530,7 @@ __global__ __launch_bounds__(512) void dw_c1_lds(const int8_t *__restrict__ in, 
             // columns TW .. TWP-1 only ever meet zero weights; any finite value will do
             ((int8_t *)lds)[i] = (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) ? x[iy * p.W + ix] : (int8_t)p.izp;
         }
-        __syncthreads();
+        wg_sync();
         for (int o = tid; o < p.OH * p.OW; o += 512) {
             const int oy = o / p.OW, ox = o - oy * p.OW;
             int acc[8];

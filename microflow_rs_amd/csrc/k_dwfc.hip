@@ -142,11 +142,11 @@ __global__ __launch_bounds__(NTHR, MF_DWFC_WPE) void dwc1_fc_softmax(const int8_
     };
     if (blockIdx.x >= nblk) return;
     load_images(blockIdx.x);
-    __syncthreads(); // halo and tables written
+    wg_sync(); // halo and tables written
     MF_TR(0);
     write_images(lds);
     if (blockIdx.x + gridDim.x < nblk) load_images(blockIdx.x + gridDim.x);
-    __syncthreads();
+    wg_sync();
     MF_TR(1);
     int cur = 0;
     for (size_t blk = blockIdx.x; blk < nblk; blk += gridDim.x, cur ^= 1) {
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(NTHR, MF_DWFC_WPE) void dwc1_fc_softmax(const int8_
             if (blk + 2 * (size_t)gridDim.x < nblk) load_images(blk + 2 * (size_t)gridDim.x);
         }
         MF_TR(3);
-        __syncthreads(); // partial sums and the next tile set are visible
+        wg_sync(); // partial sums and the next tile set are visible
         MF_TR(4);
         if (tid < 64) { // (image, output) = (lane >> 2, lane & 3)
             const int img = lane >> 2, n = lane & 3;

@@ -184,7 +184,7 @@ __global__ __launch_bounds__(NTHR, WPE) void dwpw_mm(const int8_t *__restrict__ 
             cpr[tt] = MG == 3 ? epi_patch_load(p.pw.patch, blk * TB + tt) : EpiPatchRec{0, 0};
         }
     }
-    __syncthreads(); // halo fill complete before any DMA lands
+    wg_sync(); // halo fill complete before any DMA lands
 
     auto stage = [&](int st, int buf) {
         // chunk i of a row = pixel i / NQ, 16-byte group i % NQ; it receives the source chunk whose group is
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(NTHR, WPE) void dwpw_mm(const int8_t *__restrict__ 
     for (; dq.step < nsteps; dq.advance(tid)) {
         const int step = dq.step;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads(); // B1: staged tile complete; previous pointwise phase done with MID
+        wg_sync(); // B1: staged tile complete; previous pointwise phase done with MID
         dq.top(tid);
         const int next = dq.nxt;
         if constexpr (DBUF) {
@@ -279,7 +279,7 @@ __global__ __launch_bounds__(NTHR, WPE) void dwpw_mm(const int8_t *__restrict__ 
                     for (int ty = 0; ty < 3; ++ty) bq[u][ty] = bn[u][ty];
             }
         }
-        __syncthreads(); // B2: MID complete; everyone is done reading the staged tile
+        wg_sync(); // B2: MID complete; everyone is done reading the staged tile
         if constexpr (!DBUF) {
             if (next < nsteps) stage(next, 0); // flies during the pointwise phase
         }
@@ -487,7 +487,7 @@ __global__ __launch_bounds__(NTHR, WPE) void dwpw_rr(const int8_t *__restrict__ 
         cS[m] = *(const float4 *)(p.pw.S + n0 + 4 * m);
         cK[m] = magic4<MG>(*(const int4 *)(p.pw.Kc + n0 + 4 * m));
     }
-    __syncthreads(); // halo fill complete before any DMA lands
+    wg_sync(); // halo fill complete before any DMA lands
 
     auto stage = [&](int st, int buf) {
         const int src_lane = NQ > 1 ? (lane ^ tile_swz<TS>(lane / (NQ > 1 ? NQ : 1))) : lane;
@@ -508,7 +508,7 @@ __global__ __launch_bounds__(NTHR, WPE) void dwpw_rr(const int8_t *__restrict__ 
     for (; dq.step < nsteps; dq.advance(tid)) {
         const int step = dq.step;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads(); // the staged tile is complete; every wave is done with the buffer the next DMA overwrites
+        wg_sync(); // the staged tile is complete; every wave is done with the buffer the next DMA overwrites
         dq.top(tid);
         const int next = dq.nxt;
         if constexpr (DBUF) {
@@ -598,7 +598,7 @@ __global__ __launch_bounds__(NTHR, WPE) void dwpw_rr(const int8_t *__restrict__ 
             cur ^= 1;
         } else {
             // single staging buffer: everyone must be done reading it before the next DMA lands
-            __syncthreads();
+            wg_sync();
             if (next < nsteps) stage(next, 0);
         }
     }

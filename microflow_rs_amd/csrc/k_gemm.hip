@@ -322,7 +322,7 @@ __global__ __launch_bounds__(64 * WM * WN) void fc_mfma(const int8_t *__restrict
             if (rs_split) return;
             rowsums(tm * BM + tn * rpt, rpt, p.rs_sums, false);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's sums have left
-            __syncthreads();
+            wg_sync();
             rs_count();
         }
     };
@@ -337,7 +337,7 @@ __global__ __launch_bounds__(64 * WM * WN) void fc_mfma(const int8_t *__restrict
         for (int kt = 0; kt < nk; ++kt, cur ^= 1) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (RSP && rs_split && kt == 0) rs_store();
-            __syncthreads();
+            wg_sync();
             if (RSP && rs_split && kt == 1) rs_count(); // (every wave has waited for its stores: the vmcnt(0) above)
             if (kt + 1 < nk) stage(kt + 1, cur ^ 1);
             const uint8_t *lb = lds + cur * BUF;
@@ -362,7 +362,7 @@ __global__ __launch_bounds__(64 * WM * WN) void fc_mfma(const int8_t *__restrict
                     }
             }
         }
-        if constexpr (RS) __syncthreads(); // every wave is done with the staging buffers: the row sums go there
+        if constexpr (RS) wg_sync(); // every wave is done with the staging buffers: the row sums go there
     } else {
         // Staggered wave rows.  Per tile kt every wave runs, in program order,
         //     L0: ds_read the fragments of k-substeps 0,1 of buffer cur
@@ -403,7 +403,7 @@ __global__ __launch_bounds__(64 * WM * WN) void fc_mfma(const int8_t *__restrict
         rs_sync_all();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         rs_store();
-        __syncthreads();
+        wg_sync();
         if (wm == 1) __builtin_amdgcn_s_barrier(); // the stagger
         int cur = 0;
         for (int kt = 0; kt < nk; ++kt, cur ^= 1) {
@@ -464,11 +464,11 @@ __global__ __launch_bounds__(64 * WM * WN) void fc_mfma(const int8_t *__restrict
     if constexpr (RS) {
         rs += __shfl_xor(rs, 32, 64);
         if (half == 0) ((int *)lds)[wm * (BM / WM) + wn * 32 + rho] = rs;
-        __syncthreads();
+        wg_sync();
     }
     if constexpr (RSP) {
         // the tile row's sums: finished when all tiles_n workgroups of the row have counted themselves (they did so ~ a GEMM ago)
-        __syncthreads(); // every wave has passed its last fragment read: the staging buffers are free for the 256 sums
+        wg_sync(); // every wave has passed its last fragment read: the staging buffers are free for the 256 sums
         int *ls = (int *)lds, *flag = (int *)lds + BM;
         if (tid == 0) {
             int ok = 0;
@@ -478,7 +478,7 @@ __global__ __launch_bounds__(64 * WM * WN) void fc_mfma(const int8_t *__restrict
             }
             *flag = ok;
         }
-        __syncthreads();
+        wg_sync();
         if (*flag) {
             for (int r = tid; r < BM; r += 64 * NW) {
                 const int m = tm * BM + r;
@@ -487,7 +487,7 @@ __global__ __launch_bounds__(64 * WM * WN) void fc_mfma(const int8_t *__restrict
         } else {
             rowsums(tm * BM, BM, ls, true); // (the producers never showed up: not co-resident -- sum the tile's rows here)
         }
-        __syncthreads();
+        wg_sync();
         // the last reader of this tile row leaves the counters zero for the next launch (every workgroup of the row has produced by
         // the time it reads: its own prologue precedes its epilogue)
         if (tid == 0 && __hip_atomic_fetch_add(p.rs_sync + 2 * tm + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == tiles_n - 1) {

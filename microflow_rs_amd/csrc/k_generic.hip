@@ -346,10 +346,10 @@ __global__ __launch_bounds__(256) void checksum_i8(const int8_t *__restrict__ in
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
         s += ((unsigned long long)(uint8_t)in[i] + 1ull) * splitmix64(i);
     part[threadIdx.x] = s;
-    __syncthreads();
+    wg_sync();
     for (int off = 128; off > 0; off >>= 1) {
         if ((int)threadIdx.x < off) part[threadIdx.x] += part[threadIdx.x + off];
-        __syncthreads();
+        wg_sync();
     }
     if (threadIdx.x == 0) atomicAdd(result, part[0]);
 }

@@ -118,7 +118,7 @@ __device__ __forceinline__ void lds_store_asm(uint8_t *p, int off, uint4 v) {
 // the barrier of a kernel that stores with lds_store_asm: the compiler does not count those stores, so the wait is spelled out
 template <bool ASMST> __device__ __forceinline__ void quad_barrier() {
     if constexpr (ASMST) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __syncthreads();
+    wg_sync();
 }
 // the bare instruction: __syncthreads() carries a workgroup-scope fence, which hipcc completes with vmcnt(0) while it believes an
 // LDS-DMA may be outstanding -- that would drain the output stores a counted wait (MF_QUAD_CNT_WAIT) has just left in flight
@@ -515,7 +515,7 @@ __global__ __launch_bounds__(Q::NTHR, Q::WPE) void quad_rr(const int8_t *__restr
     RrPhase<GB, G, Q::ACT_B, MG, XR4, Q::X2B> pb;
     pa.template init<GB>(p.a, lane, wave);
     pb.template init<void>(p.b, lane, wave);
-    __syncthreads(); // halo fills complete before any DMA lands
+    wg_sync(); // halo fills complete before any DMA lands
 
     auto stage = [&](int st, int buf = 0) {
         if constexpr (F32IN) { // the 96 x 96 f32 image, verbatim, in 1 KiB pieces
@@ -664,7 +664,7 @@ __global__ __launch_bounds__(Q::NTHR, Q::WPE) void quad_rr(const int8_t *__restr
         //     X : tile A complete (stem phase), tile B and the stem tile free  -> DMA of the next image, phase A
         //     Y : tile B complete, tile A free, the next image landed          -> phase B, then the next image's stem phase
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        wg_sync();
         if (dq.step < nsteps) quant_rows(), stem_phase(sc);
         for (; dq.step < nsteps; dq.advance(tid)) {
             const int step = dq.step;

@@ -16,7 +16,10 @@
 //     B.pw  MID B -> OUT                  wave w: output tile w (of 8) for all 72 pixels; OUT = the plain [pixel][128] tensor, kept in
 //                                         the interior of tile B's first image (dead by then) and copied to HBM with 16-byte stores at
 //                                         the top of the next step
-// Four workgroup barriers per step.  The next step's images are DMA-staged into tile A as soon as A.dw has read it.
+// Four workgroup barriers per step.  The next step's images are DMA-staged into tile A as soon as A.dw has read it.  (Knock-outs, same
+// box: 0.323 ms; staged from cache-resident addresses 0.295; no staging after the first step 0.280; no pair B 0.258; no requantisation
+// 0.288; without the two barriers inside pair B 0.326.  An L2 prefetch of the images two steps ahead -- one dword per 64 bytes -- bought
+// 1.5 % and was not kept.)
 // LDS: 25.5 + 18.5 + 25 + 5.2 + 3.8 (epilogue constants) KB = 78 KB -> two workgroups per CU.
 #include "k_common.hpp"
 
@@ -127,7 +130,7 @@ __global__ __launch_bounds__(512, 4) void quad_mm_12x12x64(const int8_t *__restr
     // mode 3: this wave's patched channel per phase, if any (kernels.hpp EpiPatchRec; dwpw_mm's tables)
     const EpiPatchRec prDA = epi_patch_load(MG == 3 ? p.a.dw.patch : nullptr, qa), prPA = epi_patch_load(MG == 3 ? p.a.pw.patch : nullptr, qa);
     const EpiPatchRec prDB = epi_patch_load(MG == 3 ? p.b.dw.patch : nullptr, qa), prPB = epi_patch_load(MG == 3 ? p.b.pw.patch : nullptr, wave);
-    __syncthreads(); // halo fill complete before any DMA lands
+    wg_sync(); // halo fill complete before any DMA lands
 
     auto stage = [&](int st) { // 24 image rows of 768 bytes over 8 waves, one DMA instruction per row (48 of 64 lanes)
 #pragma unroll
@@ -154,7 +157,7 @@ __global__ __launch_bounds__(512, 4) void quad_mm_12x12x64(const int8_t *__restr
     for (; dq.step < nsteps; dq.advance(tid)) {
         const int step = dq.step;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads(); // B1: tile A has landed; the previous step's OUT is complete
+        wg_sync(); // B1: tile A has landed; the previous step's OUT is complete
         dq.top(tid);
         const int next = dq.nxt;
         const int gvalid = min(Z::G, batch - step * Z::G);
@@ -204,8 +207,8 @@ __global__ __launch_bounds__(512, 4) void quad_mm_12x12x64(const int8_t *__restr
                     for (int ty = 0; ty < 3; ++ty) bq[u][ty] = bn[u][ty];
             }
         }
-        __syncthreads(); // B2: MID A complete; tile A and OUT are dead
-        if (next < nsteps && !((MF_QMM_KO & 8) && prev >= 0)) stage(next); // lands during the three phases that follow
+        wg_sync(); // B2: MID A complete; tile A and OUT are dead
+        if (next < nsteps && !((MF_QMM_KO & 8) && prev >= 0)) stage((MF_QMM_KO & 32) ? (int)(blockIdx.x & 63) : next); // lands during the three phases that follow (knock-out 32: always cache-resident images)
 
         // ---------------- A.pw: MID A -> tile B (pair B's halo tile) ----------------
         {
@@ -236,7 +239,7 @@ __global__ __launch_bounds__(512, 4) void quad_mm_12x12x64(const int8_t *__restr
                 for (int u = 0; u < UB; ++u) bq[u] = bn[u];
             }
         }
-        if (!(MF_QMM_KO & 1)) __syncthreads(); // B3: tile B complete
+        if (!(MF_QMM_KO & 1)) wg_sync(); // B3: tile B complete
 
         // ---------------- B.dw (stride 2): tile B -> MID B ----------------
         if (!(MF_QMM_KO & 4)) {
@@ -262,7 +265,7 @@ __global__ __launch_bounds__(512, 4) void quad_mm_12x12x64(const int8_t *__restr
                 if (liveB) *(uint32_t *)(lds + mbB + t * 2 * 6 * 16) = d;
             }
         }
-        if (!(MF_QMM_KO & 1)) __syncthreads(); // B4: MID B complete; tile B is dead
+        if (!(MF_QMM_KO & 1)) wg_sync(); // B4: MID B complete; tile B is dead
 
         // ---------------- B.pw: MID B -> OUT ----------------
         if (!(MF_QMM_KO & 4)) {
@@ -287,7 +290,7 @@ __global__ __launch_bounds__(512, 4) void quad_mm_12x12x64(const int8_t *__restr
         }
         prev = step, prev_gv = gvalid;
     }
-    __syncthreads();
+    wg_sync();
     if (prev >= 0) copy_out(prev, prev_gv);
     dq.finish(tid);
 }

@@ -78,7 +78,7 @@ __global__ __launch_bounds__(512) void dw3x3_rt(const int8_t *__restrict__ in, i
     const int o_x = 2 * C4, o_row = R * OW * C4, o_img = OH * OW * C4;
     const int o_step = dg * o_img + dr * o_row + dx * o_x, o_cx = o_row - OWP * o_x, o_cr = o_img - OHR * o_row;
     const int tbase0 = LP - C + cg * 4;              // window start of pixel pair 0: one pixel left of the image
-    __syncthreads(); // zero-point fill complete before any DMA lands
+    wg_sync(); // zero-point fill complete before any DMA lands
 
     auto stage = [&](int st, int buf) {
         const int band = st % NBANDS, ist = st / NBANDS;
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(512) void dw3x3_rt(const int8_t *__restrict__ in, i
     for (; dq.step < nsteps; dq.advance(tid), cur ^= 1) {
         const int step = dq.step;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        wg_sync();
         dq.top(tid);
         if (dq.nxt < nsteps) stage(dq.nxt, cur ^ 1);
 
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256) void pw_rt_lds(const int8_t *__restrict__ in, 
         ((int *)(lds + CONST_OFF + NP * 8))[i] = (in_range ? p.Kc[i] : 0) + (MG != 0 ? MF_MAGIC_I : 0);
         ((int *)(lds + CONST_OFF + NP * 12))[i] = (WZ && in_range) ? p.wzp[i] : 0;
     }
-    __syncthreads();
+    wg_sync();
     const int col = lane & 15, g = lane >> 4;
     uint8_t *patch = lds + PATCH_OFF + wave * 16 * PITCH;
     const long long nchunks = (npix + 15) / 16;
@@ -427,11 +427,11 @@ __global__ __launch_bounds__(512) void conv_rows_lds(const int8_t *__restrict__ 
     int step = blockIdx.x;
     if (step < nsteps) fetch(step);
     for (; step < nsteps; step += gridDim.x) {
-        __syncthreads();                                 // the previous step's compute is done with the tiles
+        wg_sync();                                 // the previous step's compute is done with the tiles
 #pragma unroll
         for (int e = 0; e < MAXE; ++e)
             if (gofs[e] >= 0) *(uint32_t *)(lds + lofs[e]) = v[e];
-        __syncthreads();
+        wg_sync();
         if (step + gridDim.x < nsteps) fetch(step + gridDim.x); // in flight during the compute below
         const int gvalid = min(G, batch - step * G);
         for (int po = tid; po < G * OPIX; po += NTHR) {
@@ -521,11 +521,11 @@ __global__ __launch_bounds__(NTHR) void conv_mm_rt(const int8_t *__restrict__ in
     const int col = lane & 15, g = lane >> 4;
     const float inv_ow = 1.0f / (float)OW, inv_bp = 1.0f / (float)(BH * OW);
     const int nsteps = ((batch + G - 1) / G) * NBANDS;
-    __syncthreads();
+    wg_sync();
     for (int step = blockIdx.x; step < nsteps; step += gridDim.x) {
         const int band = step % NBANDS, ist = step / NBANDS;
         const int yfirst = band * BH * p.sh - p.padt;   // input row held by tile row 0
-        __syncthreads();                                 // the previous step's reads of the tile are done
+        wg_sync();                                 // the previous step's reads of the tile are done
         for (int gi = 0; gi < G; ++gi) {
             const long img = (long)ist * G + gi;
             if (img >= batch) break;
@@ -542,7 +542,7 @@ __global__ __launch_bounds__(NTHR) void conv_mm_rt(const int8_t *__restrict__ in
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        wg_sync();
         const int gvalid = min(G, batch - ist * G);
         const int rows_here = min(BH, OH - band * BH);
         const int npix = gvalid * BH * OW;               // (rows past the image are masked below)
@@ -658,7 +658,7 @@ __global__ __launch_bounds__(256) void dw_mm_rt(const int8_t *__restrict__ in, i
     const float inv_ow = 1.0f / (float)OW, inv_bp = 1.0f / (float)(BH * OW);
     const int nsteps = ((batch + G - 1) / G) * NBANDS;
     uint8_t *patch = lds + P_OFF + wave * 256;
-    __syncthreads();
+    wg_sync();
     int toff[KSMAX]; // this lane group's tap offset in every k step
 #pragma unroll
     for (int ks = 0; ks < KSMAX; ++ks) toff[ks] = ((const int *)(lds + O_OFF))[ks * 4 + g];
@@ -683,10 +683,10 @@ __global__ __launch_bounds__(256) void dw_mm_rt(const int8_t *__restrict__ in, i
     };
     for (int step = blockIdx.x; step < nsteps; step += gridDim.x) {
         const int band = step % NBANDS, ist = step / NBANDS;
-        __syncthreads();                                 // the previous step's reads of the tile are done
+        wg_sync();                                 // the previous step's reads of the tile are done
         if (!(MF_DWMM_KO & 8) || step == (int)blockIdx.x) stage(step, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        wg_sync();
         const uint8_t *tile = lds;
         const int gvalid = min(G, batch - ist * G);
         const int rows_here = min(BH, OH - band * BH);
@@ -987,7 +987,7 @@ __global__ __launch_bounds__(256) void dw3x3_stem_rt(const int8_t *__restrict__ 
                     p.Kc[cq + 3] + (MG ? MF_MAGIC_I : 0)};
     DynSteps dq;
     dq.init(lds + 2 * BUF + 64, p.queue, tid, p.qcfg);
-    __syncthreads();
+    wg_sync();
 
     const int NI = (IMG + 1023) >> 10; // 1 KiB DMA instructions per image (the last one partly masked)
     auto stage = [&](int st, int buf) {
@@ -1006,7 +1006,7 @@ __global__ __launch_bounds__(256) void dw3x3_stem_rt(const int8_t *__restrict__ 
     for (; dq.step < nsteps; dq.advance(tid), cur ^= 1) {
         const int step = dq.step;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        wg_sync();
         dq.top(tid);
         if (dq.nxt < nsteps) stage(dq.nxt, cur ^ 1);
         const int gv = min(G, batch - step * G);

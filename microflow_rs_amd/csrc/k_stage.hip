@@ -226,7 +226,7 @@ __global__ __launch_bounds__(NTHR, 4) void stage_6x6x128(const int8_t *__restric
 
     DynSteps dq;
     dq.init(lds + OFF_Q, p.queue, tid, p.qcfg);
-    __syncthreads(); // halo fill complete before any DMA lands
+    wg_sync(); // halo fill complete before any DMA lands
     const int nsteps = (batch + G - 1) / G;
     if (dq.step < nsteps) stage(dq.step);
     v2i rdw = ld_rec(0);
@@ -264,7 +264,7 @@ __global__ __launch_bounds__(NTHR, 4) void stage_6x6x128(const int8_t *__restric
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #else
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads(); // this step's images are in the tile; the previous step's output has been copied out of region A
+        wg_sync(); // this step's images are in the tile; the previous step's output has been copied out of region A
 #endif
 #endif
         dq.top(tid);
@@ -354,7 +354,7 @@ __global__ __launch_bounds__(NTHR, 4) void stage_6x6x128(const int8_t *__restric
 #if MF_STAGE_KO & 8
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #else
-            __syncthreads(); // MID complete (every channel group); every wave is done reading the tile
+            wg_sync(); // MID complete (every channel group); every wave is done reading the tile
 #endif
             MF_TR(2 + 3 * rep);
             const bool last = rep == NREP - 1;
@@ -448,7 +448,7 @@ __global__ __launch_bounds__(NTHR, 4) void stage_6x6x128(const int8_t *__restric
 #if MF_STAGE_KO & 8
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #else
-        __syncthreads(); // every channel group of the output is in region A
+        wg_sync(); // every channel group of the output is in region A
 #endif
         MF_TR(16);
         {

@@ -118,7 +118,7 @@ __global__ __launch_bounds__(NTHR) void pair3_tail(const int8_t *__restrict__ in
     if (blockIdx.x >= nblk) return;
     stage(blockIdx.x, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads(); // zero-point slot, tables, zeroed sums and the first images are in place
+    wg_sync(); // zero-point slot, tables, zeroed sums and the first images are in place
     int cur = 0;
     for (size_t blk = blockIdx.x; blk < nblk; blk += gridDim.x, cur ^= 1) {
         // the other image set was last read before the previous step's barriers: refill it, a whole step ahead
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(NTHR) void pair3_tail(const int8_t *__restrict__ in
         // the next step's images, staged a whole step ahead, would have to land by here)
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); // MID complete
 #else
-        __syncthreads(); // MID complete
+        wg_sync(); // MID complete
 #endif
         if constexpr (!DBUF) { // one image set: it has been read, refill it under the rest of the step
             if (blk + gridDim.x < nblk) stage(blk + gridDim.x, 0);
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(NTHR) void pair3_tail(const int8_t *__restrict__ in
         }
         MF_TR(5);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's pieces of the next step have landed
-        __syncthreads(); // sums complete; MID consumed; the next images are in place for everyone
+        wg_sync(); // sums complete; MID consumed; the next images are in place for everyone
         MF_TR(6);
         if (tid < 16 * N) { // head epilogue + softmax: thread (image, n) = (tid / N, tid % N)  (conv_2d.rs:93-98, softmax.rs:20-27)
             const int img = tid / N, n = tid - img * N;

@@ -268,14 +268,12 @@ def test_softmax_exp_table_exhaustive(O):
     print("softmax exp table: at most %d of 256 entries per scale differ from correct rounding (1 ulp)" % worst)
 
 
-def test_mode3_kernels_have_no_float_lowered_division():
-    """Epilogue mode 3 runs its kernels in round-toward-zero (k_common.hpp epi_enter).  The compiler does not model the rounding
-    mode: it neither orders f32 instructions against the `s_setreg` nor knows that an integer `x % n` with a run-time n, which it
-    lowers through v_rcp_iflag_f32 / v_mul_f32 / v_cvt_u32_f32, would now round differently.  So a kernel that switches the mode
-    must contain NO f32 arithmetic besides the form's own v_fma_f32 (or its accumulating twin v_fmac_f32) and v_cvt_pk_u8_f32: the generated code of every such kernel
-    (42 instances in five translation units) is scanned for it."""
-    import collections
-    import re
+KERNEL_FILES = ("k_generic", "k_depthwise", "k_pointwise", "k_fused_mm", "k_stage", "k_dwfc", "k_tail3", "k_gemm", "k_rt", "k_quad", "k_quad_mm", "k_chain")
+
+
+@pytest.fixture(scope="module")
+def listings():
+    """hipcc -S of every kernel file, once for the ISA scans below (about a minute on 8 cores)"""
     import shutil
     import subprocess
     import tempfile
@@ -283,12 +281,61 @@ def test_mode3_kernels_have_no_float_lowered_division():
     if not os.path.exists(hipcc):
         pytest.skip("hipcc not available")
     csrc = os.path.join(ROOT, "microflow_rs_amd", "csrc")
-    files = ("k_quad", "k_stage", "k_fused_mm", "k_pointwise", "k_depthwise")
     with tempfile.TemporaryDirectory() as tmp:
-        procs = [subprocess.Popen([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-mllvm", "-amdgpu-mfma-vgpr-form=1",
+        procs = [subprocess.Popen([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-mllvm", "-amdgpu-mfma-vgpr-form=1",
                                    "--cuda-device-only", "-S", "-o", os.path.join(tmp, f + ".s"), os.path.join(csrc, f + ".hip")],
-                                  stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL) for f in files]
+                                  stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL) for f in KERNEL_FILES]
         assert all(p.wait() == 0 for p in procs)
+        yield {f: os.path.join(tmp, f + ".s") for f in KERNEL_FILES}
+
+
+def test_no_barrier_is_reached_with_lds_operations_pending(listings):
+    """`__syncthreads()` alone does not guarantee `s_waitcnt lgkmcnt(0)` in front of its s_barrier: hipcc deletes the release
+    fence's soft wait at a loop header (k_common.hpp wg_sync; round 6: quad_mm's output copy read the previous step's OUT stores
+    in flight, wrong once in ~20 launches; every step-queue kernel reached the same barrier with its `slot` store pending).  Every
+    kernel's barriers go through wg_sync() / an explicit wait, and the data-flow scan of scripts/asm_barrier_waits.py over the
+    generated code must find no barrier a wave can reach with LDS loads or stores of its own outstanding -- except in the GEMM's
+    main loop, whose counted-wait schedule (bare s_barrier between sched_barrier(0) pins; k_gemm.hip, the comment block above
+    the loop, argues every hazard) is the one deliberate exception."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("asm_barrier_waits", os.path.join(ROOT, "scripts", "asm_barrier_waits.py"))
+    abw = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(abw)
+    nk = nb = 0
+    for f, path in listings.items():
+        lines = open(path).read().split("\n")
+        for name, body in abw.kernels(lines):
+            hits = abw.scan(body)
+            nk += 1
+            nb += sum(1 for l in body if l.strip().startswith("s_barrier"))
+            if f == "k_gemm" and name.startswith("fc_mfma<256, 256"):
+                # the deliberate ones sit between two sched_barrier pins
+                for off, _ in hits:
+                    prev = next(b.strip() for b in reversed(body[:off]) if b.strip())
+                    assert prev.startswith("; sched_barrier"), (name, off, prev)
+                continue
+            assert not hits, (f, name, [(off, body[off - 3:off + 1]) for off, _ in hits])
+    assert nk >= 600 and nb >= 1400, (nk, nb)   # (the scan saw the library, not an empty listing)
+    # ... and the scan does find the pattern: a loop whose body ends in a ds_write and whose header barrier has no wait
+    demo = ["\ts_waitcnt lgkmcnt(0)", ".LBB0_1:", "\ts_barrier", "\tds_read_b32 v1, v0", "\ts_waitcnt lgkmcnt(0)", "\tds_write_b32 v0, v1",
+            "\ts_cbranch_scc1 .LBB0_1", "\ts_endpgm"]
+    assert [off for off, _ in abw.scan(demo)] == [2]
+    demo[5:5] = []
+    assert not abw.scan(demo[:5] + ["\tds_write_b32 v0, v1", "\ts_waitcnt lgkmcnt(0)"] + demo[6:])
+
+
+def test_mode3_kernels_have_no_float_lowered_division(listings):
+    """Epilogue mode 3 runs its kernels in round-toward-zero (k_common.hpp epi_enter).  The compiler does not model the rounding
+    mode: it neither orders f32 instructions against the `s_setreg` nor knows that an integer `x % n` with a run-time n, which it
+    lowers through v_rcp_iflag_f32 / v_mul_f32 / v_cvt_u32_f32, would now round differently.  So a kernel that switches the mode
+    must contain NO f32 arithmetic besides the form's own v_fma_f32 (or its accumulating twin v_fmac_f32) and v_cvt_pk_u8_f32: the generated code of every such kernel
+    (six translation units; k_generic.hip's verifier kernel switches modes to COMPARE the forms and is not one of them) is scanned
+    for it."""
+    import collections
+    import re
+    files = ("k_quad", "k_quad_mm", "k_stage", "k_fused_mm", "k_pointwise", "k_depthwise")
+    if True:
+        tmp = os.path.dirname(listings[files[0]])
         f32 = re.compile(r"\s+v_(rcp|rsq|sqrt|div|cvt_f32|cvt_u32_f32|cvt_i32_f32|mul_f32|add_f32|sub_f32|mac_f32|mad_f32|rndne|trunc|floor|ceil|"
                          r"frexp|ldexp|med3_f32|max_f32|min_f32|mul_legacy|exp|log)")
         switching = with_rne = 0
