@@ -52,9 +52,30 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // it read stale bytes in about one launch of twenty; every step-queue kernel had its `slot` store pending at the same place.
 // The explicit wait cannot be deleted.  scripts/asm_barrier_waits.py scans the listings for barriers reached with LDS operations
 // pending (tests/test_host_logic.py keeps it at zero outside the GEMM's counted-wait schedule).
+// MF_JITTER_DIAG=n (a diagnostic build, never shipped): every wave sleeps a pseudo-random 0 .. 64 n cycles in front of every barrier,
+// behind it and in front of every LDS-DMA issue.  A correct kernel's results cannot depend on it; a kernel that relies on waves
+// arriving "soon enough" (a missing barrier or wait) fails the race screens far more often (scripts/r06_jitter.sh).
+#ifndef MF_JITTER_DIAG
+#define MF_JITTER_DIAG 0
+#endif
+__device__ __forceinline__ void mf_jitter() {
+#if MF_JITTER_DIAG
+    uint32_t t = (uint32_t)__builtin_readcyclecounter();
+    t = (t ^ (t >> 7) ^ (threadIdx.x >> 6) * 0x9E3779B1u) * 0x85EBCA6Bu;
+    const uint32_t n = __builtin_amdgcn_readfirstlane(t >> 28); // 0 .. 15
+    for (uint32_t i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(MF_JITTER_DIAG);
+#endif
+}
+#ifndef MF_SYNC_KO
+#define MF_SYNC_KO 0 // 1: the bare __syncthreads() again (WRONG: the positive control of the race screens, never shipped)
+#endif
 __device__ __forceinline__ void wg_sync() {
+    mf_jitter();
+#if !MF_SYNC_KO
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
     __syncthreads();
+    mf_jitter();
 }
 
 __device__ __forceinline__ int requant(int acc, float A, float S, float lo_f, float hi_f) {
@@ -421,6 +442,7 @@ typedef __attribute__((address_space(1))) const void gbl_void_t;
 #endif
 typedef __attribute__((address_space(3))) uint8_t lds_u8_t;
 __device__ __forceinline__ void dma16(const int8_t *src_lane, uint8_t *lds_wave_base) {
+    mf_jitter();
 #if MF_DMA_ASM
     // M0 = the wave-uniform LDS base; one wait state between an SALU write of M0 and the LDS-DMA that reads it
     const uint32_t base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_u8_t *)lds_wave_base);

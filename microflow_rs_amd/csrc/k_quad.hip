@@ -122,7 +122,11 @@ template <bool ASMST> __device__ __forceinline__ void quad_barrier() {
 }
 // the bare instruction: __syncthreads() carries a workgroup-scope fence, which hipcc completes with vmcnt(0) while it believes an
 // LDS-DMA may be outstanding -- that would drain the output stores a counted wait (MF_QUAD_CNT_WAIT) has just left in flight
-__device__ __forceinline__ void quad_barrier_raw() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ void quad_barrier_raw() {
+    mf_jitter();
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    mf_jitter();
+}
 
 template <int H_, int W_, int C_, int S_, int N_, int CG_, int CY_, int ORD_, int ROWPAD_, int TS_>
 struct RrGeom {

@@ -324,6 +324,27 @@ def test_no_barrier_is_reached_with_lds_operations_pending(listings):
     assert not abw.scan(demo[:5] + ["\tds_write_b32 v0, v1", "\ts_waitcnt lgkmcnt(0)"] + demo[6:])
 
 
+def test_m0_is_only_written_by_the_dma_helper(listings):
+    """dma16 (k_common.hpp) sets M0 inside its asm statement without declaring it (M0 is a reserved register: a clobber is
+    refused with a warning).  That is sound as long as the compiler never keeps a value of its own in M0 across statements --
+    on gfx950 it would only do so for instructions these kernels do not contain (s_movrel, LDS-direct, GWS, sendmsg).  Pinned:
+    every line of the listings that names m0 sits inside an ;;#ASMSTART .. ;;#ASMEND block."""
+    import re
+    seen = 0
+    for f, path in listings.items():
+        in_asm = False
+        for n, l in enumerate(open(path)):
+            s = l.strip()
+            if s.startswith(";;#ASMSTART"):
+                in_asm = True
+            elif s.startswith(";;#ASMEND"):
+                in_asm = False
+            elif l.startswith("\t") and re.search(r"\bm0\b", s.split(";")[0]):
+                assert in_asm, (f, n, s)
+                seen += 1
+    assert seen >= 100, seen
+
+
 def test_mode3_kernels_have_no_float_lowered_division(listings):
     """Epilogue mode 3 runs its kernels in round-toward-zero (k_common.hpp epi_enter).  The compiler does not model the rounding
     mode: it neither orders f32 instructions against the `s_setreg` nor knows that an integer `x % n` with a run-time n, which it
