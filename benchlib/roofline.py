@@ -105,6 +105,8 @@ def rocprof_name(kernel, mode, u8=False):
         return "mf::k::quad_rr<mf::k::Quad57, false, %d, %s>" % (mode, xr)
     if kernel.startswith("stage_6x6x128<"):
         return "mf::k::stage_6x6x128<4, 512, %d, %s>" % (mode, xr)
+    if kernel.startswith("pair_front_tail<"):  # (k_tail3.hip: pair3_tail's FRONT instance)
+        return "mf::k::pair3_tail<3, 3, 256, 2, 1024, false, %d, %s, true>" % (mode, xr)
     if "<" in kernel:  # dwpw_mm<H,W,C,S,N,G,T,D>, pair3_tail<H,W,C,S>, pw_mfma<K,N>, ...: the leading template arguments are the same
         base, args = kernel.split("<", 1)
         lead = args.rstrip(">").split(",")

@@ -457,6 +457,16 @@ __device__ __forceinline__ void dma16(const int8_t *src_lane, uint8_t *lds_wave_
     __builtin_amdgcn_global_load_lds((gbl_void_t *)src_lane, (lds_void_t *)lds_wave_base, 16, 0, 0);
 #endif
 }
+// The same with the source as (wave-uniform base in scalar registers) + (32-bit lane offset): no 64-bit address pair per lane and
+// per piece to keep or re-compute (pair3_tail's FRONT instance spilled its five hoisted piece addresses).
+__device__ __forceinline__ void dma16_sb(const int8_t *src_wave, uint32_t lane_off, uint8_t *lds_wave_base) {
+    mf_jitter();
+    const uint32_t base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_u8_t *)lds_wave_base);
+    // (both halves through v_readfirstlane: hipcc does not legalise a 64-bit "s" operand that its allocator left in vector registers)
+    const uint64_t a = (uint64_t)(uintptr_t)src_wave;
+    const uint64_t sa = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)a) | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(a >> 32)) << 32; // (the builtin returns a signed int)
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(lane_off), "s"(sa), "s"(base));
+}
 
 // ------------------------------------------------------------------------
 // Dynamic step queue of the persistent kernels.

@@ -47,22 +47,37 @@ __device__ long long g_tail3_trace[32];
 #define MF_TR(k) do { } while (0)
 #endif
 
-template <int H, int W, int C, int N, int NTHR, bool DBUF, int MG, uint32_t XR4>
-__global__ __launch_bounds__(NTHR) void pair3_tail(const int8_t *__restrict__ in, int8_t *__restrict__ out, PairTailArgs p,
+// FRONT (round 6, person_detect ops 23..30 in one launch): the pair in front of this pair runs in the same step -- DepthwiseConv2D 3x3
+// stride 2 on 2H x 2W x C/2 + Conv2D 1x1 C/2 -> C -- with the same 16-images-per-MFMA-column scheme: the staged tensor is the FRONT
+// pair's input X6 [16][2H 2W C/2] (one set, refilled behind the front depthwise's barrier), its depthwise output goes to the (still
+// idle) MID buffer, its 1x1 output -- this pair's input -- to X3, which is then never staged from HBM.  Wave w owns channel group
+// w % (C/32) of the front depthwise for every second pixel and output tile w of the front 1x1 (operands resident: 3 + C/128
+// registers x 4; the epilogue constants of the two front operators are read from an LDS copy per phase).  Two more barriers per step.
+template <int H, int W, int C, int N, int NTHR, bool DBUF, int MG, uint32_t XR4, bool FRONT = false>
+__global__ __launch_bounds__(NTHR) void pair3_tail(const int8_t *__restrict__ in, int8_t *__restrict__ out, PairTailArgs p, PairFrontArgs fr,
                                                    size_t batch) {
     constexpr int IMGS = 16, PIX = H * W, IMG = PIX * C, KS = C / 64;
     constexpr int NPIECE = (IMG + 1023) / 1024;            // 1 KiB DMA pieces per image (the last one may be short)
     constexpr int XP = IMG + 16;                           // image pitch in LDS (X3 and MID)
     constexpr int NW = NTHR / 64;
     static_assert((C == 128 || C == 256) && C / 16 == NW, "one channel group and one output tile per wave");
+    static_assert(!FRONT || !DBUF, "the front pair writes X3 itself: one set");
+    // the front pair's tensor: H1 x W1 x C1, 16 images in X6
+    constexpr int H1 = 2 * H, W1 = 2 * W, C1 = C / 2, IMG1 = H1 * W1 * C1, XP1 = IMG1 + 16, NPIECE1 = (IMG1 + 1023) / 1024;
+    constexpr int KS1 = C1 / 64, NQ1 = C1 / 16, WPG = NW / NQ1; // k steps of the front 1x1; channel groups and waves per group of the front depthwise
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     constexpr int SET = 16 * XP;                           // one set of 16 staged images
-    uint8_t *x3 = lds;                                     // [1 or 2 sets][16][XP] + one all-zero-point image slot
-    uint8_t *zslot = lds + (DBUF ? 2 : 1) * SET;
-    uint8_t *mid = zslot + XP;                             // [16][XP]
+    uint8_t *x6 = lds;                                     // FRONT: [16][XP1]
+    uint8_t *x3 = lds + (FRONT ? 16 * XP1 : 0);            // [1 or 2 sets][16][XP] + one all-zero-point image slot
+    uint8_t *zslot = x3 + (DBUF ? 2 : 1) * SET;
+    constexpr int ZS = FRONT ? 256 : XP;                   // (only its first 16 NW bytes are ever read)
+    uint8_t *mid = zslot + ZS;                             // [16][XP]
     int *part = (int *)(mid + 16 * XP);                    // [2][16 images][4]: head sums + value sum, added up by LDS atomics
     float *expt = (float *)(part + 2 * 16 * 4);            // softmax's 256-entry table
     int *hci = (int *)(expt + 256);                        // head constants [N][4]: wzp, Kc, A, S (kept out of registers)
+    uint8_t *zslot1 = (uint8_t *)(hci + 4 * N);            // FRONT: 256 bytes of the front depthwise's input zero point
+    uint8_t *cst = zslot1 + 256;                           // FRONT: A | S | Kc of the front depthwise (C1 each), the front 1x1, this pair's depthwise and 1x1 (C each)
+    constexpr int CS_FPW = 3 * C1, CS_DW = 3 * C1 + 3 * C, CS_PW = 3 * C1 + 6 * C; // (in 4-byte words)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int col = lane & 15, g = lane >> 4;
@@ -71,12 +86,23 @@ __global__ __launch_bounds__(NTHR) void pair3_tail(const int8_t *__restrict__ in
     if (blockIdx.x == 0 && tid == 0) g_tail3_trace[31] = (long long)__builtin_readcyclecounter();
 #endif
 
-    for (int i = tid; i < XP / 16; i += NTHR) ((uint4 *)zslot)[i] = make_uint4(p.izp4, p.izp4, p.izp4, p.izp4);
+    for (int i = tid; i < ZS / 16; i += NTHR) ((uint4 *)zslot)[i] = make_uint4(p.izp4, p.izp4, p.izp4, p.izp4);
     if (tid < 2 * 16 * 4) part[tid] = 0;
     for (int i = tid; i < 256; i += NTHR) expt[i] = p.tail.exp_table[i];
     if (tid < N) {
         hci[4 * tid] = p.tail.wzp[tid], hci[4 * tid + 1] = p.tail.Kc[tid];
         hci[4 * tid + 2] = __float_as_int(p.tail.A[tid]), hci[4 * tid + 3] = __float_as_int(p.tail.S[tid]);
+    }
+    if constexpr (FRONT) {
+        if (tid < 16) ((uint4 *)zslot1)[tid] = make_uint4(fr.izp4, fr.izp4, fr.izp4, fr.izp4);
+        for (int i = tid; i < C1; i += NTHR) {
+            ((float *)cst)[i] = fr.dwA[i], ((float *)cst)[C1 + i] = fr.dwS[i], ((int *)cst)[2 * C1 + i] = fr.dwK[i];
+        }
+        for (int i = tid; i < C; i += NTHR) {
+            ((float *)cst)[CS_FPW + i] = fr.pwA[i], ((float *)cst)[CS_FPW + C + i] = fr.pwS[i], ((int *)cst)[CS_FPW + 2 * C + i] = fr.pwK[i];
+            ((float *)cst)[CS_DW + i] = p.dwA[i], ((float *)cst)[CS_DW + C + i] = p.dwS[i], ((int *)cst)[CS_DW + 2 * C + i] = p.dwK[i];
+            ((float *)cst)[CS_PW + i] = p.pwA[i], ((float *)cst)[CS_PW + C + i] = p.pwS[i], ((int *)cst)[CS_PW + 2 * C + i] = p.pwK[i];
+        }
     }
     // operands and constants of this wave's channel group / output tile (channels 16 wave + 4 g .. + 3 for this lane)
     v4i Adw[3], Apw[KS];
@@ -84,13 +110,48 @@ __global__ __launch_bounds__(NTHR) void pair3_tail(const int8_t *__restrict__ in
     for (int ky = 0; ky < 3; ++ky) Adw[ky] = ((const v4i *)p.dw_wmm)[(wave * 3 + ky) * 64 + lane];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) Apw[ks] = ((const v4i *)p.pw_w)[(wave * KS + ks) * 64 + lane];
+    // FRONT: channel group q1 of the front depthwise for the pixels px % WPG == h1, output tile `wave` of the front 1x1
+    const int q1 = wave % NQ1, h1 = wave / NQ1;
+    // The front pair's operands are NOT resident (the instance spilled with them: 128 registers at 16 waves per CU): they are
+    // fetched per step from L2 -- the depthwise's at the end of the step before (they return with the explicit vmcnt(0) there), the
+    // 1x1's at the top of the front depthwise phase, consumed behind its barrier and IN FRONT of the staging DMAs' issue (vmcnt
+    // retires in order: a compiler-placed wait for them behind the DMAs would wait for the HBM round trip).  The pointers are
+    // laundered so that the loads are not hoisted out of the step loop again.
+    v4i Adw1[3], Apw1[KS1];
+    // (the OFFSET is laundered, not the pointer: a pointer that went through an asm statement is a generic one, and flat loads count
+    // on lgkmcnt too -- every LDS wait of the phase would then wait for them)
+    auto fetch_dw1 = [&]() {
+        uint32_t off = (uint32_t)((q1 * 3) * 64 + lane) * 16u;
+        asm volatile("" : "+v"(off));
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) Adw1[ky] = *(const v4i *)((const uint8_t *)fr.dw_wmm + off + ky * 1024);
+    };
+    auto fetch_pw1 = [&]() {
+        uint32_t off = (uint32_t)((wave * KS1) * 64 + lane) * 16u;
+        asm volatile("" : "+v"(off));
+#pragma unroll
+        for (int ks = 0; ks < KS1; ++ks) Apw1[ks] = *(const v4i *)((const uint8_t *)fr.pw_w + off + ks * 1024);
+    };
+    if constexpr (FRONT) fetch_dw1();
     const int ch = 16 * wave + 4 * g;
-    const float4 dA = *(const float4 *)(p.dwA + ch), dS = *(const float4 *)(p.dwS + ch);
-    const int4 dK4 = *(const int4 *)(p.dwK + ch);
-    const v4i dK = {dK4.x, dK4.y, dK4.z, dK4.w};
-    const float4 pA = *(const float4 *)(p.pwA + ch), pS = *(const float4 *)(p.pwS + ch);
-    const int4 pK4 = *(const int4 *)(p.pwK + ch);
-    const v4i pK = {pK4.x, pK4.y, pK4.z, pK4.w};
+    // epilogue constants of this pair: resident -- or, with the front pair's operands in the register file too, read from the LDS
+    // copy at the top of each phase (the FRONT instance spilled otherwise, and a spill reload is a vector-memory load that waits
+    // for the staging DMAs in flight: vmcnt retires in order)
+    float4 dA, dS, pA, pS;
+    v4i dK, pK;
+    auto consts_at = [&](int base, int n, int c0, float4 &A, float4 &S, v4i &K) { // block at word `base`, n channels, channels c0 .. c0 + 3
+        A = *(const float4 *)(cst + (base + c0) * 4), S = *(const float4 *)(cst + (base + n + c0) * 4);
+        const int4 k4 = *(const int4 *)(cst + (base + 2 * n + c0) * 4);
+        K = v4i{k4.x, k4.y, k4.z, k4.w};
+    };
+    if constexpr (!FRONT) {
+        dA = *(const float4 *)(p.dwA + ch), dS = *(const float4 *)(p.dwS + ch);
+        const int4 dK4 = *(const int4 *)(p.dwK + ch);
+        dK = v4i{dK4.x, dK4.y, dK4.z, dK4.w};
+        pA = *(const float4 *)(p.pwA + ch), pS = *(const float4 *)(p.pwS + ch);
+        const int4 pK4 = *(const int4 *)(p.pwK + ch);
+        pK = v4i{pK4.x, pK4.y, pK4.z, pK4.w};
+    }
     uint32_t hw[N];
 #pragma unroll
     for (int n = 0; n < N; ++n) hw[n] = *(const uint32_t *)(p.tail.w + (size_t)n * C + ch);
@@ -102,6 +163,13 @@ __global__ __launch_bounds__(NTHR) void pair3_tail(const int8_t *__restrict__ in
         laneoff[x] = (cx >= 0 && cx <= W - 1) ? col * XP + cx * C : -1; // (-1: the zero-point slot, see below)
     }
 
+    // FRONT: input column 2 x + g - 1 of output column x (stride 2; the halo column is on the left only), or the zero-point slot
+    int flo[W];
+#pragma unroll
+    for (int x = 0; x < W; ++x) {
+        const int cx = 2 * x + g - 1;
+        flo[x] = (cx >= 0 && cx <= W1 - 1) ? col * XP1 + cx * C1 : -1;
+    }
     const size_t nblk = (batch + IMGS - 1) / IMGS;
     // staging by LDS-DMA, no registers: an image is 2304 B = two 1 KiB pieces + one of 256 B (16 lanes); 48 pieces per
     // step, 3 per wave.  A ragged last step re-reads the last image.
@@ -115,8 +183,19 @@ __global__ __launch_bounds__(NTHR) void pair3_tail(const int8_t *__restrict__ in
                 dma16(in + image * IMG + piece * 1024 + lane * 16, x3 + set * SET + img * XP + piece * 1024);
         }
     };
+    auto stage6 = [&](size_t blk) { // FRONT: 16 images of IMG1 bytes into X6
+#pragma unroll
+        for (int k = 0; k < (IMGS * NPIECE1 + NW - 1) / NW; ++k) {
+            const int j = wave + NW * k, img = j / NPIECE1, piece = j - img * NPIECE1;
+            size_t image = blk * IMGS + img;
+            image = image < batch ? image : batch - 1;
+            if (j < IMGS * NPIECE1 && piece * 1024 + lane * 16 < IMG1) // (scalar source base: image and piece are wave-uniform)
+                dma16_sb(in + image * IMG1 + piece * 1024, (uint32_t)lane * 16u, x6 + img * XP1 + piece * 1024);
+        }
+    };
     if (blockIdx.x >= nblk) return;
-    stage(blockIdx.x, 0);
+    if constexpr (FRONT) stage6(blockIdx.x);
+    else stage(blockIdx.x, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     wg_sync(); // zero-point slot, tables, zeroed sums and the first images are in place
     int cur = 0;
@@ -125,9 +204,55 @@ __global__ __launch_bounds__(NTHR) void pair3_tail(const int8_t *__restrict__ in
         if constexpr (DBUF) {
             if (blk + gridDim.x < nblk) stage(blk + gridDim.x, cur ^ 1);
         }
+        if constexpr (FRONT) {
+            fetch_pw1(); // (in flight under the front depthwise)
+            // ---- front depthwise 3x3 stride 2: X6 -> MID (as [image][pixel][C1]) ----
+            {
+                const int ch1 = 16 * q1 + 4 * g;
+                float4 fA, fS;
+                v4i fK;
+                consts_at(0, C1, ch1, fA, fS, fK);
+#pragma unroll
+                for (int px = 0; px < PIX; ++px) {
+                    if (px % WPG != h1) continue; // (wave-uniform)
+                    const int y = px / W, x = px % W;
+                    v4i acc = fK;
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky) {
+                        const int iy = 2 * y + ky - 1; // (never below the tensor: 2 (H - 1) + 1 = H1 - 1)
+                        const uint8_t *src = (flo[x] >= 0 && iy >= 0) ? x6 + flo[x] + iy * (W1 * C1) : zslot1;
+                        const v4i B = *(const v4i *)(src + 16 * q1);
+                        acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(Adw1[ky], B, acc, 0, 0, 0);
+                    }
+                    *(uint32_t *)(mid + col * XP + px * C1 + ch1) = requant_pack4<MG, XR4>(acc[0], acc[1], acc[2], acc[3], fA, fS, fr.dw_lo, fr.dw_hi);
+                }
+            }
+            wg_sync(); // the front depthwise's tensor is complete; X6 has been read
+#pragma unroll
+            for (int ks = 0; ks < KS1; ++ks) asm volatile("" : "+v"(Apw1[ks])); // the compiler's wait for the 1x1's operands goes HERE
+            if (blk + gridDim.x < nblk) stage6(blk + gridDim.x); // lands under the four phases that follow
+            // ---- front 1x1 C1 -> C: MID -> X3 (this pair's input, [image][pixel][C]) ----
+            {
+                float4 qA, qS;
+                v4i qK;
+                consts_at(CS_FPW, C, ch, qA, qS, qK);
+#pragma unroll
+                for (int px = 0; px < PIX; ++px) {
+                    v4i acc = qK;
+#pragma unroll
+                    for (int ks = 0; ks < KS1; ++ks) {
+                        const v4i B = *(const v4i *)(mid + col * XP + px * C1 + 64 * ks + 16 * g);
+                        acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(Apw1[ks], B, acc, 0, 0, 0);
+                    }
+                    *(uint32_t *)(x3 + col * XP + px * C + ch) = requant_pack4<MG, XR4>(acc[0], acc[1], acc[2], acc[3], qA, qS, fr.pw_lo, fr.pw_hi);
+                }
+            }
+            wg_sync(); // X3 complete; MID is free for this pair's depthwise
+        }
         const uint8_t *xs = x3 + (DBUF ? cur : 0) * SET;
         MF_TR(0);
         // ---- depthwise 3x3: channel group `wave`, all 9 pixels ----
+        if constexpr (FRONT) consts_at(CS_DW, C, ch, dA, dS, dK);
 #pragma unroll
         for (int px = 0; px < PIX; ++px) {
             const int y = px / W, x = px % W;
@@ -151,12 +276,13 @@ __global__ __launch_bounds__(NTHR) void pair3_tail(const int8_t *__restrict__ in
 #else
         wg_sync(); // MID complete
 #endif
-        if constexpr (!DBUF) { // one image set: it has been read, refill it under the rest of the step
+        if constexpr (!DBUF && !FRONT) { // one image set: it has been read, refill it under the rest of the step
             if (blk + gridDim.x < nblk) stage(blk + gridDim.x, 0);
         }
         MF_TR(2);
         MF_TR(3);
         // ---- pointwise 256 -> 256: output tile `wave`; AveragePool2D = the sum over the 9 pixels ----
+        if constexpr (FRONT) consts_at(CS_PW, C, ch, pA, pS, pK);
         int pool[4] = {0, 0, 0, 0};
 #pragma unroll
         for (int px = 0; px < PIX; ++px) {
@@ -198,7 +324,12 @@ __global__ __launch_bounds__(NTHR) void pair3_tail(const int8_t *__restrict__ in
             atomicAdd(dst + N, vs);
         }
         MF_TR(5);
+        if constexpr (FRONT) fetch_dw1(); // the next step's front depthwise operands
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's pieces of the next step have landed
+        if constexpr (FRONT) {
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) asm volatile("" : "+v"(Adw1[ky]));
+        }
         wg_sync(); // sums complete; MID consumed; the next images are in place for everyone
         MF_TR(6);
         if (tid < 16 * N) { // head epilogue + softmax: thread (image, n) = (tid / N, tid % N)  (conv_2d.rs:93-98, softmax.rs:20-27)
@@ -244,8 +375,32 @@ static int launch_pair_tail_t(const int8_t *in, int8_t *out, const PairTailArgs 
     static LaunchState st;
     const int per_cu = prepared(st, pair3_tail<H, H, C, 2, NTHR, DBUF, MG, XR4>, NTHR, lds);
     const size_t cap = (size_t)256 * per_cu;
-    hipLaunchKernelGGL((pair3_tail<H, H, C, 2, NTHR, DBUF, MG, XR4>), dim3((unsigned)(nblk < cap ? nblk : cap)), dim3(NTHR), lds, s, in, out, a, batch);
+    hipLaunchKernelGGL((pair3_tail<H, H, C, 2, NTHR, DBUF, MG, XR4>), dim3((unsigned)(nblk < cap ? nblk : cap)), dim3(NTHR), lds, s, in, out, a, PairFrontArgs{}, batch);
     return per_cu;
+}
+// ops 23..30 of person_detect: the front pair (6x6x128 stride 2 -> 3x3x256) + pair3_tail<3,3,256,2> in one launch
+bool pair_front_supported(int H, int W, int C, int S, int N, int tailH, int tailC) {
+    return H == 6 && W == 6 && C == 128 && S == 2 && N == 256 && tailH == 3 && tailC == 256;
+}
+template <int MG, uint32_t XR4>
+static void launch_pair_front_tail_t(const int8_t *in, int8_t *out, const PairTailArgs &a, const PairFrontArgs &fr, size_t batch, hipStream_t s) {
+    constexpr int H = 3, C = 256, NTHR = C * 4, XP = H * H * C + 16, XP1 = 4 * H * H * (C / 2) + 16;
+    constexpr int lds = 16 * XP1 + (16 + 16) * XP + 256 + 2 * 16 * 4 * 4 + 256 * 4 + 2 * 4 * 4 + 256 + 3 * (C / 2 + 3 * C) * 4;
+    static_assert(lds <= 160 * 1024, "one workgroup per CU");
+    const size_t nblk = (batch + 15) / 16;
+    static LaunchState st;
+    const int per_cu = prepared(st, pair3_tail<H, H, C, 2, NTHR, false, MG, XR4, true>, NTHR, lds);
+    const size_t cap = (size_t)256 * per_cu;
+    hipLaunchKernelGGL((pair3_tail<H, H, C, 2, NTHR, false, MG, XR4, true>), dim3((unsigned)(nblk < cap ? nblk : cap)), dim3(NTHR), lds, s, in, out, a, fr, batch);
+}
+void launch_pair_front_tail(const int8_t *in, int8_t *out, const PairTailArgs &a, const PairFrontArgs &fr, size_t batch, hipStream_t s) {
+    if (a.tail.xr) {
+        if (a.magic) launch_pair_front_tail_t<1, 0x80808080u>(in, out, a, fr, batch, s);
+        else launch_pair_front_tail_t<0, 0x80808080u>(in, out, a, fr, batch, s);
+    } else {
+        if (a.magic) launch_pair_front_tail_t<1, 0u>(in, out, a, fr, batch, s);
+        else launch_pair_front_tail_t<0, 0u>(in, out, a, fr, batch, s);
+    }
 }
 void launch_pair_tail(const int8_t *in, int8_t *out, const PairTailArgs &a, size_t batch, hipStream_t s) {
     int per_cu = 1;

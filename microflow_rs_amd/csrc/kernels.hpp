@@ -445,6 +445,21 @@ struct PairTailArgs {
     float pw_lo, pw_hi;
     TailArgs tail;
 };
+// ... with the pair IN FRONT of that pair in the same launch (person_detect ops 23..30): DepthwiseConv2D 3x3 stride 2 on 2H x 2H x C/2
+// + Conv2D 1x1 C/2 -> C, whose H x H x C output is pair3_tail's input tensor and never leaves LDS
+struct PairFrontArgs {
+    const void *dw_wmm;      // depthwise taps, matrix-pipe form
+    const float *dwA, *dwS;
+    const int *dwK;          // (+ 0x4B400000 when PairTailArgs::magic)
+    float dw_lo, dw_hi;
+    uint32_t izp4;           // zero point of the front depthwise's input, in every byte
+    const void *pw_w;        // pointwise weights [C/16][C/2/64][64 lanes] x 16 bytes
+    const float *pwA, *pwS;
+    const int *pwK;
+    float pw_lo, pw_hi;
+};
+bool pair_front_supported(int H, int W, int C, int S, int N, int tailH, int tailC);
+void launch_pair_front_tail(const int8_t *in, int8_t *out, const PairTailArgs &a, const PairFrontArgs &fr, size_t batch, hipStream_t s);
 bool pair_tail_supported(int H, int W, int C, int N_pw, int N_head, int ntaps);
 const char *pair_tail_name(int H, int C);
 void launch_pair_tail(const int8_t *in, int8_t *out, const PairTailArgs &a, size_t batch, hipStream_t s);

@@ -155,6 +155,8 @@ FusedImpl *fused_stage_create(FusedImpl *const *pairs, int npairs);
 FusedImpl *fused_dwfc_create(OpImpl *dw, FusedImpl *fc_softmax);
 // the last depthwise + pointwise pair group (3x3x256) + the pool/head/softmax tail group as one kernel (second level)
 FusedImpl *fused_pair_tail_create(FusedImpl *pair, FusedImpl *tail);
+// ... and the pair group in front of that pair in the same launch (6x6x128 stride 2 -> 3x3x256 + the above), or nullptr
+FusedImpl *fused_front_pair_tail_create(FusedImpl *front_pair, FusedImpl *pair_tail);
 FusedImpl *fused_chain_create(FusedImpl *const *single_pair_chains, int n, int force_G = 0); // consecutive run-time-geometry pairs as one launch (k_chain.hip); force_G: images per step (0: the planner's)
 bool fused_is_chain_single(const FusedImpl *f);
 void fused_chain_partition(FusedImpl *const *single_pair_chains, int n, int *seg_len, bool *unfused, int *seg_G, bool autotune); // seg_G[i]: measured images per step of the chain starting at i (0: the planner's); autotune: time the candidates on the device instead of using the cost model

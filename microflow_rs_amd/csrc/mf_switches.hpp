@@ -22,6 +22,7 @@ struct Switches {
     bool no_stage = false;         // MF_NO_STAGE         no 6x6x128 four-pair stage kernel (k_stage.hip)
     bool no_dwfc = false;          // MF_NO_DWFC          no depthwise + FC + softmax kernel (k_dwfc.hip, speech)
     bool no_pairtail = false;      // MF_NO_PAIRTAIL      no pair + pool + conv + softmax tail (k_tail3.hip)
+    bool no_pair_front = false;    // MF_NO_PAIR_FRONT    ops 23..24 as their own dwpw_mm launch, not inside the pair + tail launch (k_tail3.hip FRONT)
     bool no_quad_mm = false;       // MF_NO_QUAD_MM       ops 9..12 as two dwpw_mm launches, not one quad_mm launch (k_quad_mm.hip)
     bool no_quad = false;          // MF_NO_QUAD          no two-pair register-resident kernels (k_quad.hip)
     bool no_penta = false;         // MF_NO_PENTA         no stem + two pairs kernel (k_quad.hip)

@@ -302,7 +302,13 @@ void model_prepare(ModelImpl *m, int device, size_t max_batch) {
             if (!fused[i] || fused_last[i] != (int)i + 1 || covered(i)) continue;
             const size_t j = i + 2;
             if (fused[j] && !covered(j))
-                if (FusedImpl *f = fused_pair_tail_create(fused[i], fused[j])) sg.v.push_back({f, (int)i, fused_last[j]});
+                if (FusedImpl *f = fused_pair_tail_create(fused[i], fused[j])) {
+                    sg.v.push_back({f, (int)i, fused_last[j]});
+                    // ... and with the pair group in front of it: ops i - 2 .. the tail's end in one launch.  Both stay (a run that
+                    // ends before the tail uses the pair groups, mf_model_run_until pieces that start at i the pair + tail stage)
+                    if (i >= 2 && fused[i - 2] && fused_last[i - 2] == (int)i - 1 && !covered(i - 2))
+                        if (FusedImpl *g = fused_front_pair_tail_create(fused[i - 2], f)) sg.v.push_back({g, (int)i - 2, fused_last[j]});
+                }
         }
         // (4c) runs of consecutive run-time-geometry pairs (single-pair chain groups, k_chain.hip): the planner's cost model
         // decides how the run is cut into chain launches (ops.hip: fused_chain_partition); a pair that is cheapest as two

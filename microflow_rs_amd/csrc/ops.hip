@@ -1177,6 +1177,8 @@ struct FusedImpl {
     k::DwFcArgs dwfc{};
     // PAIRTAIL: the last pair + the tail in one kernel (operand arrays in stage_w)
     k::PairTailArgs pairtail{};
+    k::PairFrontArgs pairfront{}; // ... with the pair in front of it in the same launch (has_front; k_tail3.hip FRONT)
+    bool has_front = false;
     // QUAD: two consecutive pairs in one kernel (k_quad.hip); a = the first pair's depthwise, b = the second pair's conv
     k::QuadArgs quad{};
     bool quad_mm = false; // the C = 64 quad (k_quad_mm.hip): intermediate tensors through LDS, the pairs' dwpw_mm argument blocks
@@ -1885,6 +1887,49 @@ FusedImpl *fused_pair_tail_create(FusedImpl *pair, FusedImpl *tail) {
     return f.release();
 }
 
+// The pair group in front of a pair + tail launch joins it (person_detect ops 23..30 in one launch; k_tail3.hip FRONT): second
+// level like the others -- the pair group and the pair + tail stage stay for mf_model_run_until.  Borrows the pair + tail stage's
+// device arrays (destroy it first); the front pair's own arrays are in stage_w.
+FusedImpl *fused_front_pair_tail_create(FusedImpl *front, FusedImpl *pairtail) {
+    if (switches().no_pair_front || !front || !pairtail || pairtail->kind != FusedImpl::PAIRTAIL || pairtail->has_front) return nullptr;
+    if (front->kind != FusedImpl::DWPW) return nullptr;
+    OpImpl *dw = front->a, *pw = front->b;
+    if (!dw || !pw || dw->fast != OpImpl::DW_NHWC || pw->fast != OpImpl::PW_MFMA) return nullptr;
+    const OpSpec &d = dw->s, &q = pw->s;
+    const k::PairTailArgs &t = pairtail->pairtail;
+    if (d.sh != d.sw || !k::pair_front_supported(d.H, d.W, d.C, d.sh, q.N, t.H, t.C)) return nullptr;
+    if (d.KH != 3 || d.KW != 3 || d.pad != MF_PAD_SAME || d.C != d.N || q.KH != 1 || q.KW != 1 || q.C != d.N) return nullptr;
+    if (q.OH != t.H || q.OW != t.H || d.u8 != q.u8 || (d.u8 ? 0x80u : 0u) != (uint32_t)t.tail.xr || dw->device != pairtail->a->device) return nullptr;
+    const k::DwFastArgs &df = dw->dwf;
+    if (!df.wmm || !dw->finite_consts || !pw->finite_consts) return nullptr;
+    // one epilogue form for the launch's four convolutions: the bit-pattern one needs it of all four
+    const int magic = (dw->magic_mode >= 1 && pw->magic_mode >= 1) ? 1 : 0;
+    if (magic != t.magic) return nullptr;
+    std::unique_ptr<FusedImpl> f(new FusedImpl{FusedImpl::PAIRTAIL, dw, pairtail->b, pairtail->c, {}, {}, "pair_front_tail<6,6,128,2,256|3,3,256,2>"});
+    auto with_magic = [&](const int *d_kc, int n) {
+        if (!magic) return d_kc;
+        std::vector<int32_t> h((size_t)n);
+        MF_HIP(hipMemcpy(h.data(), d_kc, h.size() * 4, hipMemcpyDeviceToHost));
+        for (int32_t &v : h) v = wrap_add(v, 0x4B400000);
+        f->stage_w.emplace_back(new DevBuf);
+        f->stage_w.back()->upload(h.data(), h.size() * 4);
+        return (const int *)f->stage_w.back()->p;
+    };
+    f->pairtail = t, f->has_front = true, f->epi_mode = magic;
+    k::PairFrontArgs &a = f->pairfront;
+    a.dw_wmm = df.wmm, a.dwA = df.A, a.dwS = df.S, a.dwK = with_magic(df.Kc, d.N);
+    a.dw_lo = df.lo_f, a.dw_hi = df.hi_f, a.izp4 = df.izp4;
+    std::vector<int8_t> host((size_t)q.N * q.C);
+    MF_HIP(hipMemcpy(host.data(), pw->conv.w, host.size(), hipMemcpyDeviceToHost)); // [N][1][1][C] as uploaded
+    const std::vector<int8_t> prep = build_pw_plain_weights(host.data(), q.C, q.N);
+    f->stage_w.emplace_back(new DevBuf);
+    f->stage_w.back()->upload(prep.data(), prep.size());
+    a.pw_w = f->stage_w.back()->p;
+    a.pwA = pw->conv.A, a.pwS = pw->conv.S, a.pwK = with_magic(pw->conv.Kc, q.N);
+    a.pw_lo = pw->conv.lo_f, a.pw_hi = pw->conv.hi_f;
+    return f.release();
+}
+
 // Two consecutive DepthwiseConv2D 3x3 + Conv2D 1x1 pair groups as one kernel (k_quad.hip), when a quad kernel exists for the two
 // shapes.  Second level like the stage: the pairs inside stay available for mf_model_run_until.
 FusedImpl *fused_quad_create(FusedImpl *p1, FusedImpl *p2) {
@@ -2021,7 +2066,8 @@ void fused_run(FusedImpl *f, const int8_t *d_in, size_t batch, int8_t *d_out, vo
         return;
     }
     if (f->kind == FusedImpl::PAIRTAIL) {
-        if (batch) k::launch_pair_tail(d_in, d_out, f->pairtail, batch, (hipStream_t)stream);
+        if (batch && f->has_front) k::launch_pair_front_tail(d_in, d_out, f->pairtail, f->pairfront, batch, (hipStream_t)stream);
+        else if (batch) k::launch_pair_tail(d_in, d_out, f->pairtail, batch, (hipStream_t)stream);
         MF_HIP(hipGetLastError());
         return;
     }

@@ -26,6 +26,7 @@ Switches switches_parse() {
     s.no_dwfc = env_set("MF_NO_DWFC");
     s.no_pairtail = env_set("MF_NO_PAIRTAIL");
     s.no_quad = env_set("MF_NO_QUAD");
+    s.no_pair_front = env_set("MF_NO_PAIR_FRONT");
     s.no_quad_mm = env_set("MF_NO_QUAD_MM");
     s.no_penta = env_set("MF_NO_PENTA");
     s.no_f32_group = env_set("MF_NO_F32_GROUP");

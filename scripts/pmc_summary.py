@@ -64,6 +64,8 @@ def short(name):
             return "penta_rr<96,96,1,2,8|48,48,8,1,16|48,48,16,2,32>"
         return {"Quad13": "quad_rr<48,48,8,1,16|48,48,16,2,32>", "Quad57": "quad_rr<24,24,32,1,32|24,24,32,2,64>"}[which]
     if base == "pair3_tail":
+        if re.search(r",\s*(true|1)>$", args):  # the FRONT instance: ops 23..30 in one launch
+            return "pair_front_tail<6,6,128,2,256|3,3,256,2>"
         args = "<3,3,256,2>"
     if base == "dwc1_fc_softmax":
         args = "<49,40,10,8,2>"

@@ -289,6 +289,10 @@ def test_kernel_routing(models):
     quads_mm = sum(n.startswith("quad_mm") for n in names)   # ops 9..12 in one launch (k_quad_mm.hip; MF_NO_QUAD_MM=1 / MF_NO_QUAD=1: not)
     npairs = sum(n.startswith(("dwpw_rr", "dwpw_mm")) for n in names) + 2 * (quads + quads_mm)
     pair_tail = not os.environ.get("MF_NO_PAIRTAIL")
+    front = names[23].startswith("pair_front_tail")   # ops 23..30 in one launch (k_tail3.hip FRONT; MF_NO_PAIR_FRONT=1 / MF_NO_PAIRTAIL=1: not)
+    npairs += 2 * front
+    if pair_tail and not any(os.environ.get(k) for k in ("MF_NO_PAIR_FRONT", "MF_NO_MAGIC", "MF_DWPW_IMPL", "MF_NO_TABLE")):
+        assert front, names
     if not (os.environ.get("MF_NO_QUAD") or os.environ.get("MF_DWPW_IMPL")):
         assert quads == 2 and names[5].startswith("quad_rr<24,24,32"), names
         assert names[0].startswith("penta_rr<96,96,1,2,8|48,48,8") if penta else names[1].startswith("quad_rr<48,48,8"), names
@@ -302,11 +306,12 @@ def test_kernel_routing(models):
     else:
         assert npairs in (7, 8) and names[13].startswith("stage_6x6x128"), names
         assert all(n.startswith("(fused") for n in names[14:23]), names
-        assert names[23].startswith("dwpw") and names[25].startswith(("dwpw", "pair3_tail")), names
+        assert front or (names[23].startswith("dwpw") and names[25].startswith(("dwpw", "pair3_tail"))), names
     if not pair_tail:
         assert names[27] == "tail_pool_head_softmax<2>"               # pool + head conv + softmax
     else:  # the last pair (ops 25, 26) + the tail (27..30) in one launch
-        assert names[25].startswith("pair3_tail") and all(n.startswith("(fused") or n == "" for n in names[26:]), names
+        assert names[23 if front else 25].startswith("pair_front_tail<6,6,128,2,256|3,3,256,2>" if front else "pair3_tail"), names
+        assert all(n.startswith("(fused") or n == "" for n in names[(24 if front else 26):]), names
     assert names[28].startswith("(fused") and names[29] == "" and names[30].startswith("(fused")
     if not os.environ.get("MF_DWPW_IMPL"):
         assert sum(n.startswith("dwpw_rr") for n in names) + 2 * quads == 4

@@ -321,9 +321,10 @@ def test_u8_person_detect_uses_the_fast_kernels(mf, O):
         assert names[0].startswith(("dw3x3_stem8", "penta_rr")), names   # (penta_rr: the stem + ops 1..4 in one launch)
         npairs = sum(k.startswith(("dwpw_rr", "dwpw_mm", "dwpw3x3")) for k in names)
         npairs += 5 * sum(k.startswith("stage_6x6x128") for k in names) + sum(k.startswith("pair3_tail") for k in names)
+        npairs += 2 * sum(k.startswith("pair_front_tail") for k in names)   # ops 23..30 in one launch (k_tail3.hip FRONT)
         npairs += 2 * sum(k.startswith(("quad_rr", "penta_rr", "quad_mm")) for k in names)   # two pairs per quad launch (k_quad.hip, k_quad_mm.hip)
         assert npairs == 13, names
-        assert names[25].startswith("pair3_tail"), names
+        assert names[23].startswith("pair_front_tail") and names[25].startswith("(fused"), names
         assert names[13].startswith("stage_6x6x128"), names
     m.set_fusion(False)
     assert np.array_equal(m.run_quantized(xq).reshape(n, -1), want)
