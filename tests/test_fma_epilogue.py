@@ -288,7 +288,9 @@ def test_person_detect_launch_modes_and_parity(O):
         # ops 9..12 in one launch (quad_mm): one channel of op 10 with a patched accumulator; as two dwpw_mm launches: both mode 3
         assert modes[9] == 3 and (m.op(9)["kernel"].startswith("quad_mm") or modes[11] == 3)
         assert m.op(13)["kernel"].startswith("stage_6x6x128") and modes[13] == 3   # ops 13..22: 14 patched channels in seven of the ten operators
-        assert modes[23] == 2 and modes[25] <= 2                               # op 24 / op 26 need more patches than the kernels' list holds
+        # op 24 / op 26 need more patches than the kernels' list holds: ops 23..30 in one launch (pair_front_tail) run the bit-pattern
+        # form with the v_med3 clamp for all four convolutions; as two launches (MF_NO_PAIR_FRONT) ops 23..24 take the saturating pack
+        assert (m.op(23)["kernel"].startswith("pair_front_tail") and modes[23] == 1) or (modes[23] == 2 and modes[25] <= 2)
     om = O.Model(model_path("person_detect"))
     x = synth_i8(3, 0, 64, om.in_elems)
     x[0] = -128
