@@ -316,12 +316,26 @@ def test_no_barrier_is_reached_with_lds_operations_pending(listings):
                 continue
             assert not hits, (f, name, [(off, body[off - 3:off + 1]) for off, _ in hits])
     assert nk >= 600 and nb >= 1400, (nk, nb)   # (the scan saw the library, not an empty listing)
-    # ... and the scan does find the pattern: a loop whose body ends in a ds_write and whose header barrier has no wait
-    demo = ["\ts_waitcnt lgkmcnt(0)", ".LBB0_1:", "\ts_barrier", "\tds_read_b32 v1, v0", "\ts_waitcnt lgkmcnt(0)", "\tds_write_b32 v0, v1",
-            "\ts_cbranch_scc1 .LBB0_1", "\ts_endpgm"]
-    assert [off for off, _ in abw.scan(demo)] == [2]
-    demo[5:5] = []
-    assert not abw.scan(demo[:5] + ["\tds_write_b32 v0, v1", "\ts_waitcnt lgkmcnt(0)"] + demo[6:])
+
+
+def test_barrier_scan_finds_the_loop_header_pattern():
+    """the scan itself, on hand-written listings (no compiler needed): a loop whose body ends in a ds_write and whose header barrier
+    has no wait is reported; the same loop with the wait is not; counted waits are honoured; cross-lane ds_* are not LDS traffic"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("asm_barrier_waits", os.path.join(ROOT, "scripts", "asm_barrier_waits.py"))
+    abw = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(abw)
+    head = ["\ts_waitcnt lgkmcnt(0)", ".LBB0_1:", "\ts_barrier", "\tds_read_b32 v1, v0", "\ts_waitcnt lgkmcnt(0)"]
+    tail = ["\ts_cbranch_scc1 .LBB0_1", "\ts_endpgm"]
+    assert [off for off, _ in abw.scan(head + ["\tds_write_b32 v0, v1"] + tail)] == [2]
+    assert not abw.scan(head + ["\tds_write_b32 v0, v1", "\ts_waitcnt lgkmcnt(0)"] + tail)
+    assert not abw.scan(head + ["\tds_write_b32 v0, v1", "\ts_waitcnt vmcnt(0) lgkmcnt(0)"] + tail)
+    assert abw.scan(head + ["\tds_write_b32 v0, v1", "\ts_waitcnt vmcnt(0)"] + tail)                       # the wrong counter
+    assert abw.scan(head + ["\tds_write_b32 v0, v1", "\tds_write_b32 v0, v2", "\ts_waitcnt lgkmcnt(1)"] + tail)  # one may still be in flight
+    assert not abw.scan(head + ["\tds_bpermute_b32 v0, v0, v1"] + tail)
+    # a pending store reaches the barrier through a side block only
+    side = ["\ts_waitcnt lgkmcnt(0)", "\ts_cbranch_scc0 .LBB0_2", "\tds_write_b32 v0, v1", ".LBB0_2:", "\ts_barrier", "\ts_endpgm"]
+    assert [off for off, _ in abw.scan(side)] == [4]
 
 
 def test_m0_is_only_written_by_the_dma_helper(listings):
