@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """GPU box: coordinate descent over the dynamic-step-queue configuration (k_common.hpp DynSteps) of each of the
-queue launches of the person_detect step (round 6: six -- ops 0-4, 5-8, 9-10, 11-12, 13-22, 23-24; pair3_tail walks statically), scored by the WHOLE step's time (per-launch times move with the chip's
+queue launches of the person_detect step (four with the default routing -- ops 0-4, 5-8, 9-12, 13-22; the ops 23-30 launch walks statically -- six when the sweep of profiles/r06/u_tune_dq_resweep.txt was made: 9-10, 11-12 and 23-24 were launches of their own), scored by the WHOLE step's time (per-launch times move with the chip's
 power state, so a launch is only ever judged inside the real mix).  All candidates of a round are timed interleaved."""
 import os
 import sys
